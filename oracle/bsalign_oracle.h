@@ -1,0 +1,98 @@
+/*
+ * bsalign_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Scalar CPU restatement ("oracle") of the reference's banded striped DP hot
+ * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load or call this; the product path (libbsalign_hip.so) never does.
+ *
+ * Parity status: PINNED -- every function here is checked against the real
+ * reference compiled into oracle/_ref/libbsref.so (tests/test_oracle_vs_ref.py,
+ * runs when /root/reference is present) and against the committed golden
+ * vectors in tests/golden/ (generated from that reference build by
+ * tests/golden/make_golden.py).
+ */
+#ifndef BSALIGN_ORACLE_H
+#define BSALIGN_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MODE_GLOBAL   0
+#define ORC_MODE_OVERLAP  1
+#define ORC_MODE_EXTEND   2
+#define ORC_LANES         16          /* lanes of the reference's SIMD word (bsalign.h:142) */
+#define ORC_EPI8_MIN      (-63)       /* bsalign.h:56 */
+#define ORC_EPI8_MAX      (63)        /* bsalign.h:57 */
+#define ORC_SCORE_MIN     (-(0x7FFFFFFF >> 2)) /* bsalign.h:58 */
+
+/* layout-compatible with seqalign_result_t (bsalign.h:213-218) */
+typedef struct {
+	int32_t score, qb, qe, tb, te, mat, mis, ins, del, aln;
+} orc_result_t;
+
+/* query description used to compute S(x, base) on the fly (replaces the striped profile, bsalign.h:2166-2221) */
+typedef struct {
+	const uint8_t *seq;
+	uint32_t len;
+	const int8_t *mtx;   /* 16 entries, mtx[q*4+t] */
+	int hpc;             /* 0: plain profile; 1: +bonus where q[x] != q[x+1] (bsalign.h:2203-2205) */
+	int bonus;
+} orc_query_t;
+
+void     orc_set_score_matrix(int8_t mtx[16], int mat, int mis);                        /* bsalign.h:323 */
+int      orc_get_piecewise(int gapo1, int gape1, int gapo2, int gape2, int bandwidth); /* bsalign.h:2084 */
+
+/* Row-level functions.  Row buffers use the reference's striped index
+ * idx(p) = (p % W) * 16 + p / W; ubegs has 17 entries. */
+void     orc_row_init(int8_t *us, int8_t *es, int8_t *qs, int32_t *ubegs, int mode, uint32_t bandwidth,
+                      int max_nt, int min_nt, int gapo1, int gape1, int gapo2, int gape2);            /* bsalign.h:2094 */
+void     orc_row_movx(int8_t *us_dst, int8_t *es_dst, int8_t *qs_dst, int32_t *ub_dst,
+                      const int8_t *us_src, const int8_t *es_src, const int8_t *qs_src, const int32_t *ub_src,
+                      uint32_t W, uint32_t movx, int piecewise, int nt_max, int nt_min,
+                      int gapo1, int gape1, int gapo2, int gape2);                                   /* bsalign.h:2244 */
+int      orc_row_cal(uint32_t rbeg, uint8_t base,
+                     const int8_t *us_src, const int8_t *es_src, const int8_t *qs_src, const int32_t *ub_src,
+                     int8_t *us_dst, int8_t *es_dst, int8_t *qs_dst, int32_t *ub_dst,
+                     const orc_query_t *qry, int gapo1, int gape1, int gapo2, int gape2,
+                     uint32_t W, int rh, int piecewise);                                             /* bsalign.h:2727,2885,3084 */
+void     orc_row_merge(const int8_t *us0, const int8_t *es0, const int8_t *qs0, const int32_t *ub0,
+                       const int8_t *us1, const int8_t *es1, const int8_t *qs1, const int32_t *ub1,
+                       int8_t *us2, int8_t *es2, int8_t *qs2, int32_t *ub2, uint32_t W, int piecewise); /* bsalign.h:2474 */
+int      orc_getscore(const int8_t *us, const int32_t *ubegs, uint32_t W, uint64_t pos);            /* bsalign.h:3187 */
+uint32_t orc_row_max(const int8_t *us, const int32_t *ubegs, uint32_t W, int32_t *max_score);       /* bsalign.h:3213 */
+int      orc_band_mov(const int32_t *ubegs, uint32_t W, uint32_t tidx, uint32_t qoff, uint32_t qlen); /* bsalign.h:3331 */
+
+/* Whole-pair functions.  cig may be NULL.  Return value: number of CIGAR words
+ * (len<<4|op, bsalign.h:61-69, 401-417), or -(needed) when cap is too small,
+ * or a large negative code ORC_ERR_* on invalid input. */
+#define ORC_ERR_INPUT (-(1L << 40))
+#define ORC_ERR_TRACE (-(1L << 41))  /* input on which the reference itself does not terminate / leaves its arena */
+long     orc_align_pairwise(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
+                            int mode, uint32_t bandwidth, const int8_t mtx[16],
+                            int gapo1, int gape1, int gapo2, int gape2,
+                            orc_result_t *res, uint32_t *cig, long cap);                             /* bsalign.h:3854 */
+long     orc_edit_pairwise(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
+                           int mode, uint32_t bandwidth,
+                           orc_result_t *res, uint32_t *cig, long cap);                              /* bsalign.h:1046 */
+
+/* optional tracing hook for band-trajectory goldens: begs[i] = band offset of row i (tlen entries) */
+long     orc_align_pairwise_trace(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
+                            int mode, uint32_t bandwidth, const int8_t mtx[16],
+                            int gapo1, int gape1, int gapo2, int gape2,
+                            orc_result_t *res, uint32_t *cig, long cap, int32_t *begs_out);
+
+/* timing helper for bench.py's cpu_baseline (kind = "port") */
+double   orc_align_batch_time(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
+                              const uint64_t *toff, const uint32_t *tlen, long n, int mode, uint32_t bandwidth,
+                              const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2, int64_t *checksum);
+double   orc_edit_batch_time(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
+                             const uint64_t *toff, const uint32_t *tlen, long n, int mode, uint32_t bandwidth,
+                             int64_t *checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
