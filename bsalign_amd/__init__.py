@@ -1,0 +1,255 @@
+"""bsalign_amd -- Python binding of libbsalign_hip.so (the MI355X implementation of bsalign's DP hot path).
+
+This package is plumbing for tests / bench.py: it loads the in-tree C-ABI library
+(include/bsalign_hip.h) with ctypes and mirrors its entry points.  There is NO CPU
+fallback anywhere: if the library is missing or no GPU is usable every compute call
+raises.  The host-side drop-in for C callers is include/bsalign_compat.h.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsalign_hip.so")
+
+MODE_GLOBAL, MODE_OVERLAP, MODE_EXTEND = 0, 1, 2
+ST_BAD_BASE, ST_EMPTY, ST_TRACE = 1, 2, 4
+
+E_NAMES = {0: "OK", -1: "BSA_E_NODEVICE", -2: "BSA_E_ARG", -3: "BSA_E_NOMEM", -4: "BSA_E_HIP",
+           -5: "BSA_E_CIGAR_CAP", -6: "BSA_E_UNSUPPORTED"}
+
+
+class BsaError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("%s (%d) %s" % (E_NAMES.get(code, "?"), code, msg))
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("bandwidth", C.c_uint32), ("matrix", C.c_int8 * 16),
+                ("gapo1", C.c_int8), ("gape1", C.c_int8), ("gapo2", C.c_int8), ("gape2", C.c_int8)]
+
+
+class EditParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("bandwidth", C.c_uint32)]
+
+
+RESULT_DTYPE = np.dtype([(n, np.int32) for n in ("score", "qb", "qe", "tb", "te", "mat", "mis", "ins", "del", "aln")])
+
+_lib = None
+
+
+def build():
+    """compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)"""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "all"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libbsalign_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                               "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, u8p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+        L.bsa_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.bsa_ctx_destroy.argtypes = [vp]
+        L.bsa_ctx_destroy.restype = None
+        L.bsa_ctx_set_stream.argtypes = [vp, vp]
+        L.bsa_ctx_set_workspace_limit.argtypes = [vp, C.c_size_t]
+        L.bsa_ctx_sync.argtypes = [vp]
+        L.bsa_last_error.argtypes = [vp]
+        L.bsa_last_error.restype = C.c_char_p
+        L.bsa_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+        L.bsa_set_score_matrix.argtypes = [C.POINTER(C.c_int8), C.c_int8, C.c_int8]
+        L.bsa_set_score_matrix.restype = None
+        L.bsa_align_batch.argtypes = [vp, u8p, C.c_size_t, u64p, u32p, u64p, u32p, C.c_size_t, C.POINTER(AlignParams),
+                                      vp, u32p, C.c_size_t, u64p, u32p]
+        L.bsa_align_plan_create.argtypes = [vp, u64p, u32p, u64p, u32p, C.c_size_t, C.POINTER(AlignParams), C.POINTER(vp)]
+        L.bsa_align_plan_destroy.argtypes = [vp]
+        L.bsa_align_plan_destroy.restype = None
+        L.bsa_align_plan_cells.argtypes = [vp]
+        L.bsa_align_plan_cells.restype = C.c_double
+        L.bsa_align_run.argtypes = [vp, u8p, vp, u32p, C.c_size_t, u64p, u32p]
+        L.bsa_synth_stride.argtypes = [C.c_uint32]
+        L.bsa_synth_stride.restype = C.c_size_t
+        L.bsa_synth_pairs_host.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32, u8p, u32p]
+        L.bsa_synth_pairs_dev.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32, u8p, u32p]
+        if hasattr(L, "bsa_edit_batch"):
+            L.bsa_edit_batch.argtypes = [vp, u8p, C.c_size_t, u64p, u32p, u64p, u32p, C.c_size_t, C.POINTER(EditParams),
+                                         vp, u32p, C.c_size_t, u64p, u32p]
+            L.bsa_edit_plan_create.argtypes = [vp, u64p, u32p, u64p, u32p, C.c_size_t, C.POINTER(EditParams), C.POINTER(vp)]
+            L.bsa_edit_plan_destroy.argtypes = [vp]
+            L.bsa_edit_plan_destroy.restype = None
+            L.bsa_edit_plan_cells.argtypes = [vp]
+            L.bsa_edit_plan_cells.restype = C.c_double
+            L.bsa_edit_run.argtypes = [vp, u8p, vp, u32p, C.c_size_t, u64p, u32p]
+        L.bsa_align_debug_rows.argtypes = [vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_params(mode=MODE_GLOBAL, bandwidth=128, M=2, X=-6, O=-3, E=-2, Q=0, P=0, matrix=None):
+    p = AlignParams()
+    p.mode, p.bandwidth = mode, bandwidth
+    if matrix is None:
+        lib().bsa_set_score_matrix(p.matrix, M, X)
+    else:
+        for i in range(16):
+            p.matrix[i] = int(matrix[i])
+    p.gapo1, p.gape1, p.gapo2, p.gape2 = O, E, Q, P
+    return p
+
+
+def pack_pairs(pairs):
+    """[(q, t), ...] of uint8 code arrays -> (seqs blob, qoff, qlen, toff, tlen)"""
+    n = len(pairs)
+    qlen = np.array([len(q) for q, _ in pairs], dtype=np.uint32)
+    tlen = np.array([len(t) for _, t in pairs], dtype=np.uint32)
+    qoff = np.zeros(n, dtype=np.uint64)
+    toff = np.zeros(n, dtype=np.uint64)
+    parts, acc = [], 0
+    for k, (q, t) in enumerate(pairs):
+        qoff[k] = acc
+        parts.append(_np(q, np.uint8))
+        acc += len(q)
+        toff[k] = acc
+        parts.append(_np(t, np.uint8))
+        acc += len(t)
+    seqs = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+    if seqs.size == 0:
+        seqs = np.zeros(1, dtype=np.uint8)
+    return seqs, qoff, qlen, toff, tlen
+
+
+class Context:
+    """one context per (thread, device) -- bsa_ctx_create / bsa_ctx_destroy"""
+
+    def __init__(self, device=0, workspace_limit=0):
+        h = C.c_void_p()
+        rc = lib().bsa_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise BsaError(rc, "bsa_ctx_create: no usable GPU; this library has no CPU fallback")
+        self.h = h
+        if workspace_limit:
+            lib().bsa_ctx_set_workspace_limit(self.h, workspace_limit)
+
+    def close(self):
+        if self.h:
+            lib().bsa_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise BsaError(rc, (lib().bsa_last_error(self.h) or b"").decode())
+
+    def set_stream(self, stream_ptr):
+        self._chk(lib().bsa_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        self._chk(lib().bsa_ctx_sync(self.h))
+
+    def last_kernel_ms(self):
+        ms, n, cells = C.c_double(), C.c_long(), C.c_double()
+        self._chk(lib().bsa_ctx_last_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(cells)))
+        return ms.value, n.value, cells.value
+
+    def _batch(self, fn, pairs, par, cigar_cap=None):
+        seqs, qoff, qlen, toff, tlen = pack_pairs(pairs)
+        n = len(pairs)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        status = np.zeros(max(n, 1), dtype=np.uint32)
+        if cigar_cap is None:
+            cigar_cap = int(qlen.sum() + tlen.sum()) + 2 * n + 16
+        cig = np.zeros(cigar_cap, dtype=np.uint32)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        rc = fn(self.h, _p(seqs), seqs.size, _p(qoff), _p(qlen), _p(toff), _p(tlen), n, C.byref(par),
+                _p(out), _p(cig), cigar_cap, _p(off), _p(status))
+        self._chk(rc)
+        cigs = [cig[int(off[k]):int(off[k + 1])].copy() for k in range(n)]
+        return out, cigs, status[:n]
+
+    def align_batch(self, pairs, par, cigar_cap=None):
+        """host-pointer form of bsa_align_batch: returns (results, [cigar arrays], status)"""
+        return self._batch(lib().bsa_align_batch, pairs, par, cigar_cap)
+
+    def edit_batch(self, pairs, mode=MODE_GLOBAL, bandwidth=0, cigar_cap=None):
+        p = EditParams()
+        p.mode, p.bandwidth = mode, bandwidth
+        return self._batch(lib().bsa_edit_batch, pairs, p, cigar_cap)
+
+
+def synth_pairs_host(n, L, eps=0.10, seed=20240611, first_pair=0):
+    """host (C) form of the synthetic generator: returns list of (q, t)"""
+    stride = lib().bsa_synth_stride(L)
+    seqs = np.zeros(2 * n * stride, dtype=np.uint8)
+    qlen = np.zeros(n, dtype=np.uint32)
+    rc = lib().bsa_synth_pairs_host(seed, first_pair, n, L, int(eps * 4294967296.0), _p(seqs), _p(qlen))
+    if rc != 0:
+        raise BsaError(rc)
+    return [(seqs[(n + k) * stride:(n + k) * stride + qlen[k]].copy(), seqs[k * stride:k * stride + L].copy()) for k in range(n)]
+
+
+class AlignPlan:
+    """two-phase form (bsa_align_plan_create / bsa_align_run): host metadata once, device-resident data per run.
+    Device buffers are torch tensors (plumbing only); the run is asynchronous on the context's stream."""
+
+    def __init__(self, ctx, qoff, qlen, toff, tlen, par):
+        self.ctx = ctx
+        self.n = len(qlen)
+        self.qoff, self.qlen = _np(qoff, np.uint64), _np(qlen, np.uint32)
+        self.toff, self.tlen = _np(toff, np.uint64), _np(tlen, np.uint32)
+        self.par = par
+        h = C.c_void_p()
+        ctx._chk(lib().bsa_align_plan_create(ctx.h, _p(self.qoff), _p(self.qlen), _p(self.toff), _p(self.tlen),
+                                             self.n, C.byref(par), C.byref(h)))
+        self.h = h
+
+    def cells(self):
+        return lib().bsa_align_plan_cells(self.h)
+
+    def run(self, d_seqs, d_out, d_cigar=None, d_cigar_off=None, d_status=None):
+        cap = d_cigar.numel() if d_cigar is not None else 0
+        self.ctx._chk(lib().bsa_align_run(self.h, C.c_void_p(d_seqs.data_ptr()), C.c_void_p(d_out.data_ptr()),
+                                          C.c_void_p(d_cigar.data_ptr() if d_cigar is not None else 0), cap,
+                                          C.c_void_p(d_cigar_off.data_ptr() if d_cigar_off is not None else 0),
+                                          C.c_void_p(d_status.data_ptr() if d_status is not None else 0)))
+
+    def debug_rows(self, pair):
+        """row records of `pair` after a single-chunk run: (bytes array [tlen+1, rowb])"""
+        rowb = C.c_uint32()
+        tl = int(self.tlen[pair])
+        # rowb is not known before the call: fetch generously, then trim
+        buf = np.zeros((tl + 1) * 4096, dtype=np.uint8)
+        self.ctx._chk(lib().bsa_align_debug_rows(self.h, pair, _p(buf), 0, C.byref(rowb)))
+        nbytes = (tl + 1) * rowb.value
+        buf = np.zeros(nbytes, dtype=np.uint8)
+        self.ctx._chk(lib().bsa_align_debug_rows(self.h, pair, _p(buf), nbytes, C.byref(rowb)))
+        return buf.reshape(tl + 1, rowb.value)
+
+    def close(self):
+        if self.h:
+            lib().bsa_align_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,687 @@
+// bsa_align8.hip -- 8-bit banded striped pairwise DP on gfx950 (MI355X), lane-exact.
+//
+// Replaces, for a batch of independent pairs, the reference's per-pair row loop
+//   banded_striped_epi8_seqalign_pairwise            /root/reference/bsalign.h:3854-4050
+//     _piecex_row_init :2094   _piecex_row_movx :2244   _piece{0,1,2}_row_cal :2727/:2885/:3084
+//     _row_cal_FPenetration_codes :2639   _row_cal_tail_codes :2618   _band_mov :3331
+//     _piecex_backcal[_cell] :3667-3852   _getscore :3187   _row_max :3213
+//
+// Mapping.  The reference's SSE word has 16 int8 lanes; lane j owns "running block" j = W consecutive
+// band cells (W = bandwidth / 16).  A DPP row on CDNA is exactly 16 lanes, so one pair occupies one DPP
+// row: lane j keeps its W cells of u / e / q in VGPRs (one cell per register, int32 holding an int8
+// value), the SSE byte shifts become row_shr/row_shl DPP moves, and one wave64 advances 4 pairs per row
+// step.  Every saturating int8 operation of the reference is reproduced as add + v_med3_i32 clamp, every
+// int->int8 truncation as v_bfe_i32, in the reference's order, so results are bit-identical including
+// the saturation corner cases.  The row loop is strictly serial per pair (the next band offset depends
+// on the whole row), parallelism is 16 lanes x W cells x batch.
+//
+// HBM traffic per row and pair: one row record (see bsa_common.h) = (pw+1)*bw + 72 bytes written once;
+// the traceback kernel re-derives the path from those records exactly like the reference's backcal.
+#include "bsa_common.h"
+
+// Every DPP move is made opaque to the optimiser.  ROCm 7.2's DPP combiner folds a v_mov_b32_dpp into a
+// following subtraction as `v_subrev_u32_dpp vdst, vsrc(dpp), vdst`, and on gfx950 that instruction returns
+// dpp(vdst) - vsrc instead of vdst - dpp(vsrc) (measured on hardware, scratch/dpp_test.hip); keeping the move
+// explicit costs one VALU op and is always right.
+static __device__ __forceinline__ int dpp_keep(int x){ asm("" : "+v"(x)); return x; }
+#define DPP_SHR(fill, x, n)  dpp_keep(__builtin_amdgcn_update_dpp((fill), (x), 0x110 + (n), 0xf, 0xf, false))  // lane j <- lane j-n (row of 16)
+#define DPP_SHL(fill, x, n)  dpp_keep(__builtin_amdgcn_update_dpp((fill), (x), 0x100 + (n), 0xf, 0xf, false))  // lane j <- lane j+n
+#define DPP_BCAST(x, n)      dpp_keep(__builtin_amdgcn_update_dpp(0, (x), 0x150 + (n), 0xf, 0xf, false))       // row_newbcast:n
+#define DPP_ROR(x, n)        dpp_keep(__builtin_amdgcn_update_dpp(0, (x), 0x120 + (n), 0xf, 0xf, false))       // row rotate right
+
+#define BIGNEG (-(1 << 28))
+
+static __device__ __forceinline__ int sat8(int v){ return min(max(v, -128), 127); }     // _mm_adds_epi8 / _mm_subs_epi8
+static __device__ __forceinline__ int trunc8(int v){ return (int)(int8_t)v; }            // int -> b1i store
+static __device__ __forceinline__ int row_sum16(int x){                                   // sum over the 16 lanes of a DPP row, in every lane
+	x += DPP_ROR(x, 8); x += DPP_ROR(x, 4); x += DPP_ROR(x, 2); x += DPP_ROR(x, 1);
+	return x;
+}
+static __device__ __forceinline__ int row_iscan16(int x){                                 // inclusive prefix sum over the DPP row
+	x += DPP_SHR(0, x, 1); x += DPP_SHR(0, x, 2); x += DPP_SHR(0, x, 4); x += DPP_SHR(0, x, 8);
+	return x;
+}
+
+// active F-loop, literal serial form (bsalign.h:2639-2652): 15 dependent lane-to-lane steps
+static __device__ __forceinline__ int fpen_serial(int f, int ubA, int ubB, int t, int j){
+	int fs = DPP_SHR(BSA_EPI8_MIN, f, 1);       // fs[j] = f[j-1], fs[0] = -63
+	const int dd = ubB - ubA;
+#pragma unroll
+	for(int step = 1; step < 16; step++){
+		int sv  = t + fs - dd;                  // s leaving lane j
+		int sin = DPP_SHR(0, sv, 1);            // s entering lane j
+		int cand = (fs < sin) ? trunc8(sin) : fs;
+		fs = (j == step) ? cand : fs;
+	}
+	return fs;
+}
+
+// same result through a 4-step max-plus scan; falls back to the serial form when an int->int8
+// truncation could have fired (some entering s > 127), which is the only way the two can differ
+static __device__ __forceinline__ int fpen(int f, int ubA, int ubB, int t, int j){
+#ifdef BSA_FPEN_SERIAL
+	return fpen_serial(f, ubA, ubB, t, j);
+#else
+	const int fs = DPP_SHR(BSA_EPI8_MIN, f, 1);
+	const int c  = t - (ubB - ubA);             // fs'[j+1] = max(fs[j+1], fs'[j] + c[j])
+	int A = DPP_SHR(BIGNEG, c, 1);              // map of lane j: x -> max(x + A, B); lane 0 ignores x
+	int B = fs;
+#define FPEN_STEP(n) { int A1 = DPP_SHR(0, A, n); int B1 = DPP_SHR(BIGNEG, B, n); B = max(B1 + A, B); A = max(A1 + A, 2 * BIGNEG); }
+	FPEN_STEP(1) FPEN_STEP(2) FPEN_STEP(4) FPEN_STEP(8)
+#undef FPEN_STEP
+	const int sprev = DPP_SHR(BIGNEG, B + c, 1);
+	if(__any(sprev > 127)) return fpen_serial(f, ubA, ubB, t, j);
+	return B;
+#endif
+}
+
+template<int W> struct QCodes { uint32_t w[(W + 3) / 4]; };
+
+template<int W>
+static __device__ __forceinline__ QCodes<W> load_qcodes(const uint8_t *p){
+	QCodes<W> q;
+	if constexpr (W >= 4){
+		__builtin_memcpy(q.w, p, W);            // unaligned W-byte load (W multiple of 4)
+	} else if constexpr (W == 2){
+		uint16_t v; __builtin_memcpy(&v, p, 2); q.w[0] = v | 0x04040000u;
+	} else {
+		q.w[0] = p[0] | 0x04040400u;
+	}
+	return q;
+}
+
+template<int W, int PW>
+__global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
+	constexpr int BW = W * 16;
+	extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // slow-path movx scratch: per group (PW+1)*BW bytes + 17 ints
+	constexpr int GROUP_LDS = ((PW + 1) * BW + 17 * 4 + 15) & ~15;
+	const int lt = threadIdx.x;
+	const int j = lt & 15;
+	const uint32_t g = (blockIdx.x * 256u + lt) >> 4;
+	const bool live = g < a.count;
+	const uint32_t ppos = a.first + (live ? g : 0u);
+	const uint32_t pair = a.order[ppos];
+	const uint32_t qlen = a.qlen[pair];
+	uint32_t tlen = a.tlen[pair];
+	const uint8_t *qp = a.qst + a.qpoff[pair];
+	const uint8_t *tp = a.tst + a.tpoff[pair];
+	uint8_t *rowp = a.rows + a.slot_off[ppos];
+	if(!live || a.status[pair] != 0u) tlen = 0;
+	const uint32_t rowb = a.rowb;
+	int8_t *gl = smem + (lt >> 4) * GROUP_LDS;
+	int8_t *su = gl, *se = gl + BW, *sq = gl + 2 * BW;
+	int *sub = (int*)(gl + (PW + 1) * BW);
+
+	const int mode = a.mode & 3;
+	const int gapo1 = a.gapo1, gape1 = a.gape1, gapo2 = a.gapo2, gape2 = a.gape2;
+	const int GapE = trunc8(gape1), GapOE = trunc8(gapo1 + gape1);
+	const int GapP = trunc8(gape2), GapQP = trunc8(gapo2 + gape2);
+	const int GapOQ = sat8(GapOE - GapQP);
+	// synthetic values for cells entering the band at its right end (bsalign.h:2357-2369)
+	const int cfirst = (PW == 2) ? (min(a.smin, gapo2 + gape2) - 1 - a.smax + (gapo2 + gape2))
+	                             : (min(a.smin, gapo1 + gape1) - 1 - a.smax + (gapo1 + gape1));
+	const int dsw = (PW == 2) ? (gapo1 - gapo2) / (gape2 - gape1) : (BW + 1);
+	auto newcell_int = [&](int k) -> int { return (k == 0) ? cfirst : ((PW == 2 && k >= dsw) ? gape2 : gape1); };
+	auto newcell_cum = [&](int n) -> int {   // sum of the first n (>= 1) synthetic cells, as the reference's running int `c`
+		int n1 = min(n, dsw);
+		return cfirst + (n1 - 1) * gape1 + ((PW == 2) ? max(0, n - dsw) * gape2 : 0);
+	};
+
+	int u[W], e[W], q2[W];
+	int ubA, ubB;
+	// ---- row -1 (bsalign.h:2094-2140)
+	{
+		int bs = 0;
+		const int first = trunc8(gapo1 + gape1 + a.smin - a.smax);
+		const int xp = (PW == 2) ? (gapo2 - gapo1) / (gape1 - gape2) : 0;
+#pragma unroll
+		for(int i = 0; i < W; i++){
+			int p = j * W + i, v;
+			if(mode == BSA_MODE_OVERLAP) v = 0;
+			else if(p == 0) v = first;
+			else if(PW == 2) v = (p < xp) ? gape1 : gape2;
+			else v = gape1;
+			u[i] = v; bs += v;
+			e[i] = BSA_EPI8_MIN; q2[i] = BSA_EPI8_MIN;
+		}
+		int inc = row_iscan16(bs);
+		int base0 = (mode == BSA_MODE_OVERLAP) ? 0 : (a.smax - a.smin);
+		ubB = base0 + inc;
+		ubA = ubB - bs;
+	}
+	auto store_row = [&](uint8_t *rp, uint32_t rbeg_v){
+		// natural band order: lane j owns bytes [j*W, j*W+W)
+		if constexpr (W >= 4){
+#pragma unroll
+			for(int n = 0; n < W / 4; n++){
+				uint32_t wu = (uint32_t)(u[4*n] & 0xff) | ((uint32_t)(u[4*n+1] & 0xff) << 8) | ((uint32_t)(u[4*n+2] & 0xff) << 16) | ((uint32_t)u[4*n+3] << 24);
+				((uint32_t*)(rp + j * W))[n] = wu;
+				if(PW >= 1){
+					uint32_t we = (uint32_t)(e[4*n] & 0xff) | ((uint32_t)(e[4*n+1] & 0xff) << 8) | ((uint32_t)(e[4*n+2] & 0xff) << 16) | ((uint32_t)e[4*n+3] << 24);
+					((uint32_t*)(rp + BW + j * W))[n] = we;
+				}
+				if(PW == 2){
+					uint32_t wq = (uint32_t)(q2[4*n] & 0xff) | ((uint32_t)(q2[4*n+1] & 0xff) << 8) | ((uint32_t)(q2[4*n+2] & 0xff) << 16) | ((uint32_t)q2[4*n+3] << 24);
+					((uint32_t*)(rp + 2 * BW + j * W))[n] = wq;
+				}
+			}
+		} else {
+#pragma unroll
+			for(int i = 0; i < W; i++){
+				rp[j * W + i] = (uint8_t)u[i];
+				if(PW >= 1) rp[BW + j * W + i] = (uint8_t)e[i];
+				if(PW == 2) rp[2 * BW + j * W + i] = (uint8_t)q2[i];
+			}
+		}
+		int *ubp = (int*)(rp + (PW + 1) * BW);
+		ubp[j] = ubA;
+		if(j == 15){ ubp[16] = ubB; ubp[17] = (int)rbeg_v; }
+	};
+	if(tlen) store_row(rowp, 0u);
+
+	uint32_t rbeg = 0, mov = 0, i = 0;
+	int tb_next = tlen ? (int)tp[0] : 0;
+	const double dqlen = (double)qlen, dtlen = (double)tlen;
+
+	while(__any(i < tlen)){
+		const bool act = i < tlen;
+		// ---- band offset of this row (bsalign.h:3932-3946)
+		const bool moved = (mov != 0u) && (rbeg + BW < qlen);
+		{
+			uint32_t room = qlen - (rbeg + BW);
+			mov = moved ? min(mov, room) : 0u;
+			rbeg += mov;
+		}
+		int rh;
+		if(rbeg) rh = BSA_SCORE_MIN;
+		else if(mode == BSA_MODE_OVERLAP || i == 0) rh = 0;
+		else if(PW < 2) rh = gapo1 + gape1 * (int)i;
+		else rh = max(gapo1 + gape1 * (int)i, gapo2 + gape2 * (int)i);
+		// ---- row_movx (bsalign.h:2244-2392)
+		if(__any(act && mov >= (uint32_t)W)){
+			// generic path through LDS, any movx (rare: band jumps by >= W cells)
+#pragma unroll
+			for(int k = 0; k < W; k++){
+				su[j * W + k] = (int8_t)u[k];
+				if(PW >= 1) se[j * W + k] = (int8_t)e[k];
+				if(PW == 2) sq[j * W + k] = (int8_t)q2[k];
+			}
+			sub[j] = ubA; if(j == 15) sub[16] = ubB;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			if(mov){
+				// H(rbeg-1, y-1) = getscore(previous row, mov-1) (bsalign.h:3935)
+				uint32_t pp = min(mov - 1u, (uint32_t)BW - 1u), yy = pp / W, xx = pp % W;
+				int s = sub[yy];
+				for(uint32_t k = 0; k <= xx; k++) s += su[yy * W + k];
+				rh = s;
+			}
+			if(mov >= (uint32_t)BW){
+#pragma unroll
+				for(int k = 0; k < W; k++){ u[k] = 0; e[k] = 0; q2[k] = 0; }
+				ubA = ubB = BSA_SCORE_MIN;
+			} else if(mov){
+				const uint32_t cyc = mov / W, m = mov % W, p0 = BW - mov;
+#pragma unroll
+				for(int k = 0; k < W; k++){
+					uint32_t src = j * W + k + mov;
+					if(src < (uint32_t)BW){
+						u[k] = su[src];
+						if(PW >= 1) e[k] = se[src];
+						if(PW == 2) q2[k] = sq[src];
+					} else {
+						u[k] = trunc8(newcell_int((int)(src - BW)));
+						e[k] = 0; q2[k] = 0;
+					}
+				}
+				auto new_ub = [&](uint32_t idx) -> int {      // ubegs[idx] of the moved row, idx in 0..16
+					int v;
+					if(idx + cyc < 16u){
+						uint32_t l = idx + cyc;
+						v = sub[l];
+						for(uint32_t k = 0; k < m; k++) v += su[l * W + k];
+					} else v = sub[16];
+					int nbefore = (int)(idx * W) - (int)p0;  // synthetic cells in blocks < idx
+					if(nbefore > 0) v += newcell_cum(nbefore);
+					return v;
+				};
+				ubA = new_ub((uint32_t)j);
+				ubB = new_ub((uint32_t)j + 1u);
+			}
+			__builtin_amdgcn_wave_barrier();
+		} else {
+			// band slides by mov < W cells: `mov` predicated single-cell shifts (registers + one DPP per array)
+			int bacc = 0;
+			for(uint32_t s = 0; __any(act && s < mov); s++){
+				const bool d = s < mov;
+				const int nci = newcell_int((int)s);
+				const int dropped = u[0];
+				const int in_u = DPP_SHL(trunc8(nci), u[0], 1);   // lane 15 receives the synthetic cell
+#pragma unroll
+				for(int k = 0; k + 1 < W; k++) u[k] = d ? u[k + 1] : u[k];
+				u[W - 1] = d ? in_u : u[W - 1];
+				if(PW >= 1){
+					const int in_e = DPP_SHL(0, e[0], 1);
+#pragma unroll
+					for(int k = 0; k + 1 < W; k++) e[k] = d ? e[k + 1] : e[k];
+					e[W - 1] = d ? in_e : e[W - 1];
+				}
+				if(PW == 2){
+					const int in_q = DPP_SHL(0, q2[0], 1);
+#pragma unroll
+					for(int k = 0; k + 1 < W; k++) q2[k] = d ? q2[k + 1] : q2[k];
+					q2[W - 1] = d ? in_q : q2[W - 1];
+				}
+				ubA += d ? dropped : 0;
+				bacc += d ? nci : 0;
+			}
+			const int nb = DPP_SHL(ubB + bacc, ubA, 1);            // ubegs[j+1] of the moved row; lane 15: old end + synthetic sum
+			ubB = mov ? nb : ubB;
+			if(mov) rh = ubA;                                      // lane 0: getscore(prev, mov-1) == new ubegs[0]
+		}
+		// ---- sequences for this row
+		const int tb = tb_next;
+		if(act && i + 1 < tlen) tb_next = tp[i + 1];
+		QCodes<W> qc;
+		if(act) qc = load_qcodes<W>(qp + rbeg + j * W);
+		else { for(int n = 0; n < (W + 3) / 4; n++) qc.w[n] = 0x04040404u; }
+		const uint32_t mr = (tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3];
+		uint32_t s4[(W + 3) / 4];
+#pragma unroll
+		for(int n = 0; n < (W + 3) / 4; n++) s4[n] = __builtin_amdgcn_perm(0xC1C1C1C1u, mr, qc.w[n]);
+#define SCORE(ii) __builtin_amdgcn_sbfe((int)s4[(ii) >> 2], 8 * ((ii) & 3), 8)
+		// ---- row_cal (bsalign.h:2727-2793 / 2885-2960 / 3084-3179)
+		int h0;
+		{
+			int hh = (rh - ubA) + SCORE(0);
+			int t0 = u[0] + ((PW == 0) ? gape1 : (PW == 1) ? e[0] : max(e[0], q2[0]));
+			hh = (hh >= t0) ? min(hh, BSA_EPI8_MAX) : BSA_EPI8_MIN;
+			h0 = trunc8(hh);
+		}
+		int f = BSA_EPI8_MIN, gq = BSA_EPI8_MIN;
+		{
+			int hc = (j == 0) ? h0 : SCORE(0);
+#pragma unroll
+			for(int k = 0; k < W; k++){
+				const int uk = u[k];
+				int h;
+				if(PW == 0){
+					int ee = sat8(uk + GapE);
+					h = max(max(ee, hc), f);
+					f = sat8(sat8(h + GapE) - uk);
+				} else if(PW == 1){
+					int ee = sat8(e[k] + uk);
+					h = max(max(ee, hc), f);
+					f = sat8(f + GapE);
+					h = sat8(h + GapOE);
+					f = sat8(max(f, h) - uk);
+				} else {
+					int ee = sat8(e[k] + uk), qq = sat8(q2[k] + uk);
+					h = max(max(ee, hc), max(qq, max(f, gq)));
+					f = sat8(f + GapE);
+					h = sat8(h + GapOE);
+					f = sat8(max(f, h) - uk);
+					gq = sat8(gq + GapP);
+					h = sat8(h - GapOQ);
+					gq = sat8(max(gq, h) - uk);
+				}
+				if(k + 1 < W) hc = SCORE(k + 1);
+			}
+		}
+#ifdef BSA_DEBUG
+		if(g == 0 && i == 0 && j < 3) printf("lane %d row %u: tb %d mr %08x qc %08x s4 %08x S0 %d S1 %d h0 %d rh %d ubA %d ubB %d f(pass1) %d u0 %d e0 %d\n", j, i, tb, mr, qc.w[0], s4[0], SCORE(0), SCORE(1), h0, rh, ubA, ubB, f, u[0], e[0]);
+#endif
+		f = fpen(f, ubA, ubB, W * gape1, j);
+		if(PW == 2) gq = fpen(gq, ubA, ubB, W * gape2, j);
+#ifdef BSA_DEBUG
+		if(g == 0 && i == 0 && j < 3) printf("lane %d after fpen f %d\n", j, f);
+#endif
+		int htail, ulast;
+		{
+			int v = 0, z = (j == 0) ? h0 : SCORE(0), h = 0;
+			ulast = 0;
+#pragma unroll
+			for(int k = 0; k < W; k++){
+				const int uk = u[k];
+				if(PW == 0){
+					int ee = sat8(uk + GapE);
+					h = max(max(ee, z), f);
+					u[k] = sat8(h - v);
+					v = sat8(h - uk);
+					f = sat8(sat8(h + GapE) - uk);
+				} else if(PW == 1){
+					int ee = sat8(e[k] + uk);
+					h = max(max(ee, z), f);
+					u[k] = sat8(h - v);
+					v = sat8(h - uk);
+					ee = sat8(ee + GapE); ee = sat8(ee - h); e[k] = max(ee, GapOE);
+					f = sat8(f + GapE);
+					h = sat8(h + GapOE);
+					f = sat8(max(f, h) - uk);
+				} else {
+					int ee = sat8(e[k] + uk), qq = sat8(q2[k] + uk);
+					h = max(max(ee, z), max(qq, max(f, gq)));
+					u[k] = sat8(h - v);
+					v = sat8(h - uk);
+					ee = sat8(ee + GapE); ee = sat8(ee - h); e[k] = max(ee, GapOE);
+					qq = sat8(qq + GapP); qq = sat8(qq - h); q2[k] = max(qq, GapQP);
+					f = sat8(f + GapE);
+					h = sat8(h + GapOE);
+					f = sat8(max(f, h) - uk);
+					gq = sat8(gq + GapP);
+					h = sat8(h - GapOQ);
+					gq = sat8(max(gq, h) - uk);
+				}
+				ulast = uk;
+				if(k + 1 < W) z = SCORE(k + 1);
+			}
+			htail = (PW == 0) ? h : (PW == 1) ? sat8(h - GapOE) : sat8(h - GapQP);
+		}
+#undef SCORE
+		// ---- tail (bsalign.h:2618-2636)
+		{
+			const int vlast = sat8(htail - ulast);
+			const int nB = ubB + vlast;                       // ubegs[j+1] += v at the end of block j
+			const int vsh = DPP_SHR(0, vlast, 1);
+#ifdef BSA_DEBUG
+			if(g == 0 && i == 0 && j < 3) printf("lane %d tail: htail %d ulast %d vlast %d vsh %d u0 %d u1 %d f %d\n", j, htail, ulast, vlast, vsh, u[0], u[1], f);
+#endif
+			u[0] = sat8(u[0] - vsh);
+			int nA = DPP_SHR(0, nB, 1);
+			if(j == 0){ nA = ubA + u[0]; u[0] = 0; }         // re-base: ubegs[0] = H(0), u[0] = 0
+			ubA = nA; ubB = nB;
+		}
+		if(act) store_row(rowp + (size_t)(i + 1) * rowb, rbeg);
+		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
+		{
+			int dsum = ubB - ubA; dsum = dsum < 0 ? -dsum : dsum;
+			const int nzsum = row_sum16(dsum);
+			const int ub0 = DPP_BCAST(ubA, 0), ub16 = DPP_BCAST(ubB, 15);
+			uint32_t nz = (uint32_t)(nzsum / 16);
+			nz = nz / (uint32_t)W * 16u / 2u;
+			const int noisy = (int)((16u > nz) ? 16u : nz);
+			int rbx;
+			if(i <= (uint32_t)BW / 4u) rbx = 0;
+			else if(rbeg + BW >= qlen) rbx = 0;
+			else if(ub0 + noisy < ub16) rbx = 2;
+			else if(ub0 > ub16 + noisy) rbx = 0;
+			else rbx = 1;
+			if(mode == BSA_MODE_GLOBAL){
+				const int rbz = 2 * max((int)(tlen / max(qlen, 1u)), 1);
+				const int rby = (int)((1.0 * (double)i / dtlen) * dqlen);
+				const uint32_t left = tlen - i - 1u;
+				if((long long)rbeg + (long long)rbz * (long long)left + (long long)BW <= (long long)(uint32_t)(qlen + (uint32_t)rbz - 1u)){
+					mov = 1u + (uint32_t)(qlen - (rbeg + BW)) / max(left, 1u);
+				} else if((int)rbeg < rby - BW){
+					mov = (uint32_t)(rbx + 1);
+				} else if((int)rbeg > rby){
+					mov = (uint32_t)max(0, rbx - 1);
+				} else mov = (uint32_t)rbx;
+			} else mov = (uint32_t)rbx;
+		}
+		i++;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Traceback: literal restatement of banded_striped_epi8_seqalign_piecex_backcal (bsalign.h:3704-3852)
+// over the stored row records; also the end-score selection of the driver (bsalign.h:4023-4045).
+// One thread per pair.  CIGAR words are produced back-to-front, so they are written downwards from the
+// end of the pair's (already consumed) row slot and come out in forward order.
+// ---------------------------------------------------------------------------------------------
+struct RowView {
+	const uint8_t *base; uint32_t rowb, bw, W; int pw;
+	__device__ __forceinline__ const uint8_t* rec(int row) const { return base + (size_t)(row + 1) * rowb; }
+	__device__ __forceinline__ const int* ub(int row) const { return (const int*)(rec(row) + (size_t)(pw + 1) * bw); }
+	__device__ __forceinline__ int beg(int row) const { return ub(row)[17]; }
+	__device__ __forceinline__ int getscore(int row, long pos) const {       // bsalign.h:3187-3197
+		uint32_t p = (uint32_t)pos;
+		if(p >= bw) p = bw - 1;                                              // keep reads inside the record
+		uint32_t y = p / W, x = p % W;
+		const int8_t *us = (const int8_t*)rec(row);
+		int s = ub(row)[y];
+		for(uint32_t k = 0; k <= x; k++) s += us[y * W + k];
+		return s;
+	}
+	__device__ __forceinline__ int mtx_getscore(int row, int col) const { return getscore(row, (long)col - beg(row)); }
+};
+
+static __device__ uint32_t row_max_dev(const RowView &R, int row, int *max_score){ // bsalign.h:3213-3329
+	const uint32_t W = R.W, STEP = 32;
+	const int8_t *us = (const int8_t*)R.rec(row);
+	const int *ubegs = R.ub(row);
+	int lmax[16]; uint32_t lchunk[16];
+	for(uint32_t l = 0; l < 16; l++){
+		int base = ubegs[l];
+		lmax[l] = BSA_SCORE_MIN; lchunk[l] = 0;
+		for(uint32_t i = 0, c = 0; i < W; i += STEP, c++){
+			uint32_t n = (i + STEP < W) ? STEP : W - i;
+			int run = 0, cmax = -32767;
+			for(uint32_t x = 0; x < n; x++){
+				run += us[l * W + i + x];
+				run = min(max(run, -32768), 32767);
+				cmax = max(cmax, run);
+			}
+			if(base + cmax > lmax[l]){ lmax[l] = base + cmax; lchunk[l] = c; }
+			base += run;
+		}
+	}
+	int best = 0, lane = 0;
+	{
+		int mm[4], ii[4];
+		for(int k = 0; k < 4; k++){
+			int m01, i01, m23, i23;
+			if(lmax[4 + k] > lmax[k]){ m01 = lmax[4 + k]; i01 = 4 + k; } else { m01 = lmax[k]; i01 = k; }
+			if(lmax[12 + k] > lmax[8 + k]){ m23 = lmax[12 + k]; i23 = 12 + k; } else { m23 = lmax[8 + k]; i23 = 8 + k; }
+			if(m23 > m01){ mm[k] = m23; ii[k] = i23; } else { mm[k] = m01; ii[k] = i01; }
+		}
+		best = mm[0]; lane = ii[0];
+		for(int k = 1; k < 4; k++) if(mm[k] > best){ best = mm[k]; lane = ii[k]; }
+	}
+	*max_score = best;
+	uint32_t x = lchunk[lane] * STEP, y = min(x + STEP, W), jj = x;
+	int umax = BSA_SCORE_MIN, uscr = 0;
+	for(; x < y; x++){
+		uscr += us[lane * W + x];
+		if(uscr > umax){ jj = x; umax = uscr; }
+	}
+	return (uint32_t)lane * W + jj;
+}
+
+__global__ void __launch_bounds__(64) k_align8_backcal(const Align8Args a, int pw, bsa_result_t *out, uint32_t *cig_cnt){
+	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	if(g >= a.count) return;
+	const uint32_t ppos = a.first + g;
+	const uint32_t pair = a.order[ppos];
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	if(a.status[pair] != 0u){ out[pair] = rs; cig_cnt[ppos] = 0; return; }
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint8_t *qseq = a.qst + a.qpoff[pair];
+	const uint8_t *tseq = a.tst + a.tpoff[pair];
+	RowView R; R.base = a.rows + a.slot_off[ppos]; R.rowb = a.rowb; R.bw = a.bw; R.W = a.bw / 16; R.pw = pw;
+	const uint32_t bw = a.bw, W = R.W;
+	const int mode = a.mode & 3;
+	const int gapo1 = a.gapo1, gape1 = a.gape1, gapo2 = a.gapo2, gape2 = a.gape2;
+	// cigar scratch: the tail end of this pair's slot (tlen + 3 row records long)
+	uint32_t *cig_end = (uint32_t*)(R.base + (size_t)(tlen + 3) * a.rowb);
+	uint32_t ncig = 0;
+	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
+	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
+		if(op == (cg & 0xf)) return cg + (sz << 4);
+		if(cg) cig_push(cg);
+		return (sz << 4) | op;
+	};
+	bool bad = false;
+	// ---- end cell (bsalign.h:4023-4045)
+	rs.score = BSA_SCORE_MIN;
+	const int lastbeg = R.beg((int)tlen - 1);
+	if(mode == BSA_MODE_GLOBAL){
+		if(qlen - 1u - (uint32_t)lastbeg >= bw) bad = true;
+		rs.score = R.getscore((int)tlen - 1, (long)qlen - 1 - lastbeg);
+		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	} else {
+		for(uint32_t i = 0; i < tlen; i++){
+			int rb = R.beg((int)i);
+			if((uint32_t)rb + bw >= qlen){
+				int sc = R.getscore((int)i, (long)qlen - 1 - rb);
+				if(sc > rs.score){ rs.score = sc; rs.qe = (int)qlen - 1; rs.te = (int)i; }
+			}
+		}
+		int ms; uint32_t rmax = row_max_dev(R, (int)tlen - 1, &ms);
+		if(ms > rs.score){ rs.score = ms; rs.qe = lastbeg + (int)rmax; rs.te = (int)tlen - 1; }
+	}
+	if(!bad){ int b = R.beg(rs.te); if(rs.qe < b || rs.qe >= b + (int)bw) bad = true; }
+	// ---- backcal (bsalign.h:3704-3852)
+	if(!bad){
+		int Hs0 = 0, Hs1, pend = 0, prior_match = 0;
+		uint32_t cg = 0;
+		rs.qb = rs.qe; rs.qe++;
+		rs.tb = rs.te; rs.te++;
+		Hs1 = R.mtx_getscore(rs.tb, rs.qb);
+		for(;;){
+			if((pend & 0xf) == 2 || (pend & 0xf) == 4){
+				const int go = ((pend & 0xf) == 2) ? gapo1 : gapo2, ge = ((pend & 0xf) == 2) ? gape1 : gape2;
+				Hs0 = R.mtx_getscore(rs.tb, rs.qb);
+				long long t = go + (long long)(pend >> 4) * ge;
+				if(Hs0 + t == Hs1){
+					cg = cig_add(cg, 2, (uint32_t)(pend >> 4));
+					rs.del += pend >> 4; rs.aln += pend >> 4;
+					Hs1 = Hs0; pend = 0;
+				} else {
+					pend += 1 << 4; rs.tb--;
+					if(rs.tb < -1){ bad = true; break; }
+					continue;
+				}
+			}
+			if(rs.qb < 0 || rs.tb < 0) break;
+			const int pbeg = R.beg(rs.tb - 1);
+			if(rs.qb == pbeg){
+				if(rs.qb){ Hs0 = R.ub(rs.tb - 1)[0]; prior_match = 0; }
+				else if(mode == BSA_MODE_OVERLAP || rs.tb == 0) Hs0 = 0;
+				else if(pw < 2) Hs0 = gapo1 + gape1 * rs.tb;
+				else Hs0 = max(gapo1 + gape1 * rs.tb, gapo2 + gape2 * rs.tb);
+			} else {
+				Hs0 = R.mtx_getscore(rs.tb - 1, rs.qb - 1);
+			}
+			const int x = rs.qb - pbeg;
+			int uu = 0, ee = 0, qq = 0;
+			if(x >= 0 && x < (int)bw){
+				const int8_t *pr = (const int8_t*)R.rec(rs.tb - 1);
+				uu = pr[x];
+				ee = (pw >= 1) ? pr[bw + x] : gapo1 + gape1;
+				qq = (pw == 2) ? pr[2 * bw + x] : 0;
+			}
+			const int s = a.matrix[qseq[rs.qb] * 4 + tseq[rs.tb]];
+			const int h = Hs1 - Hs0;
+			int bt;   // 0 M, 1 I, 2 D, 4 D2 (bsalign.h:3667-3702)
+			if(x > (int)bw) bt = 1;
+			else if(x == (int)bw) bt = (h == s) ? 0 : 1;
+			else if(prior_match){
+				if(h == s) bt = 0;
+				else if(h == uu + ee) bt = 2;
+				else if(pw == 2 && h == uu + qq) bt = 4;
+				else bt = 1;
+			} else {
+				if(h == uu + ee) bt = 2;
+				else if(pw == 2 && h == uu + qq) bt = 4;
+				else if(h == s) bt = 0;
+				else bt = 1;
+			}
+			prior_match = 1;
+			if(bt == 0){
+				if(qseq[rs.qb] == tseq[rs.tb]) rs.mat++; else rs.mis++;
+				rs.qb--; rs.tb--; rs.aln++;
+				cg = cig_add(cg, 0, 1);
+				Hs1 = Hs0;
+			} else if(bt == 1){
+				if(rs.qb <= 0){
+					cg = cig_add(cg, 1, 1);
+					Hs1 = Hs0;
+					rs.qb--; rs.ins++; rs.aln++;
+				} else {
+					const int cbeg = R.beg(rs.tb);
+					bool found = false;
+					for(int sz = 1; sz + cbeg <= rs.qb; sz++){
+						long long t = (pw == 2) ? (long long)max(gapo1 + sz * gape1, gapo2 + sz * gape2) : (long long)(gapo1 + sz * gape1);
+						Hs0 = R.mtx_getscore(rs.tb, rs.qb - sz);
+						if(Hs0 + t == Hs1){
+							cg = cig_add(cg, 1, (uint32_t)sz);
+							Hs1 = Hs0;
+							rs.qb -= sz; rs.ins += sz; rs.aln += sz;
+							found = true;
+							break;
+						}
+					}
+					if(!found){ bad = true; break; }
+				}
+			} else {
+				pend = (1 << 4) | bt;
+				rs.tb--;
+				continue;
+			}
+		}
+		if(!bad){
+			if(mode == BSA_MODE_OVERLAP){
+				if(cg) cig_push(cg);
+			} else {
+				uint32_t op = 0, sz = 0;
+				if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+				else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+				rs.aln += (int)sz;
+				cg = cig_add(cg, op, sz);
+				if(cg) cig_push(cg);
+			}
+			rs.qb++; rs.tb++;
+		}
+	}
+	if(bad){
+		atomicOr(&a.status[pair], BSA_ST_TRACE);
+		ncig = 0;
+	}
+	out[pair] = rs;
+	cig_cnt[ppos] = ncig;
+}
+
+// ---------------------------------------------------------------------------------------------
+template<int W, int PW>
+static hipError_t launch_fwd(const Align8Args &a, hipStream_t st){
+	constexpr int BW = W * 16;
+	constexpr int GROUP_LDS = ((PW + 1) * BW + 17 * 4 + 15) & ~15;
+	const uint32_t groups_per_block = 16;
+	const uint32_t blocks = (a.count + groups_per_block - 1) / groups_per_block;
+	if(blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL((k_align8_fwd<W, PW>), dim3(blocks), dim3(256), GROUP_LDS * 16, st, a);
+	return hipGetLastError();
+}
+
+template<int W>
+static hipError_t launch_fwd_pw(const Align8Args &a, int pw, hipStream_t st){
+	if(pw == 0) return launch_fwd<W, 0>(a, st);
+	if(pw == 1) return launch_fwd<W, 1>(a, st);
+	return launch_fwd<W, 2>(a, st);
+}
+
+bool bsa_align8_supported_bw(uint32_t bw){
+	switch(bw / 16){ case 1: case 2: case 4: case 8: case 16: case 32: return (bw % 16) == 0; default: return false; }
+}
+
+hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st){
+	switch(a.bw / 16){
+		case 1:  return launch_fwd_pw<1>(a, pw, st);
+		case 2:  return launch_fwd_pw<2>(a, pw, st);
+		case 4:  return launch_fwd_pw<4>(a, pw, st);
+		case 8:  return launch_fwd_pw<8>(a, pw, st);
+		case 16: return launch_fwd_pw<16>(a, pw, st);
+		case 32: return launch_fwd_pw<32>(a, pw, st);
+		default: return hipErrorInvalidValue;
+	}
+}
+
+hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
+	const uint32_t blocks = (a.count + 63) / 64;
+	if(blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_align8_backcal, dim3(blocks), dim3(64), 0, st, a, pw, out, cig_cnt);
+	return hipGetLastError();
+}

@@ -1,0 +1,446 @@
+// bsa_api.hip -- C-ABI of libbsalign_hip.so (include/bsalign_hip.h): context, plans, batch drivers.
+//
+// The drivers play the role of the reference's per-pair loop (main.c:311-326 / main.c:194-205): they
+// stage the sequences, order the pairs by length so the 4 pairs sharing a wavefront finish together,
+// cut the batch into chunks whose traceback rows fit the device workspace, and for every chunk launch
+// forward DP -> traceback -> CIGAR compaction on the context stream.
+#include "bsa_common.h"
+#include <algorithm>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+struct bsa_ctx {
+	int device = 0;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	size_t ws_limit = 0;
+	uint8_t *ws = nullptr; size_t ws_bytes = 0;
+	std::string err;
+	// timing of the dominant kernel in the last run
+	std::vector<hipEvent_t> ev;      // pairs (start, stop)
+	size_t ev_used = 0;
+	double last_cells = 0;
+};
+
+#define HIPCHK(ctx, call) do { hipError_t _e = (call); if(_e != hipSuccess){ (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e); return BSA_E_HIP; } } while(0)
+
+extern "C" void bsa_set_score_matrix(int8_t m[16], int8_t mat, int8_t mis){ // bsalign.h:323
+	for(int i = 0; i < 16; i++) m[i] = ((i >> 2) == (i & 3)) ? mat : mis;
+}
+
+extern "C" int bsa_ctx_create(int device, bsa_ctx_t **out){
+	if(!out) return BSA_E_ARG;
+	*out = nullptr;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BSA_E_NODEVICE;
+	if(hipSetDevice(device) != hipSuccess) return BSA_E_NODEVICE;
+	bsa_ctx *c = new bsa_ctx();
+	c->device = device;
+	if(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess){ delete c; return BSA_E_NODEVICE; }
+	c->stream = c->own_stream;
+	*out = c;
+	return BSA_OK;
+}
+
+extern "C" void bsa_ctx_destroy(bsa_ctx_t *c){
+	if(!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for(hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+	if(c->ws) (void)hipFree(c->ws);
+	if(c->own_stream) (void)hipStreamDestroy(c->own_stream);
+	delete c;
+}
+
+extern "C" int bsa_ctx_set_stream(bsa_ctx_t *c, void *s){ if(!c) return BSA_E_ARG; c->stream = s ? (hipStream_t)s : c->own_stream; return BSA_OK; }
+extern "C" int bsa_ctx_set_workspace_limit(bsa_ctx_t *c, size_t b){ if(!c) return BSA_E_ARG; c->ws_limit = b; return BSA_OK; }
+extern "C" int bsa_ctx_sync(bsa_ctx_t *c){ if(!c) return BSA_E_ARG; (void)hipSetDevice(c->device); HIPCHK(c, hipStreamSynchronize(c->stream)); return BSA_OK; }
+extern "C" const char *bsa_last_error(bsa_ctx_t *c){ return c ? c->err.c_str() : "no context"; }
+
+extern "C" int bsa_ctx_last_kernel_ms(bsa_ctx_t *c, double *ms, long *launches, double *cells){
+	if(!c) return BSA_E_ARG;
+	(void)hipSetDevice(c->device);
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	double tot = 0; long n = 0;
+	for(size_t i = 0; i + 1 < c->ev_used; i += 2){
+		float t = 0;
+		HIPCHK(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+		tot += t; n++;
+	}
+	if(ms) *ms = n ? tot / (double)n : 0.0;
+	if(launches) *launches = n;
+	if(cells) *cells = c->last_cells;
+	return BSA_OK;
+}
+
+static int ctx_event_pair(bsa_ctx *c, hipEvent_t *a, hipEvent_t *b){
+	while(c->ev.size() < c->ev_used + 2){
+		hipEvent_t e;
+		HIPCHK(c, hipEventCreate(&e));
+		c->ev.push_back(e);
+	}
+	*a = c->ev[c->ev_used]; *b = c->ev[c->ev_used + 1];
+	c->ev_used += 2;
+	return BSA_OK;
+}
+
+static size_t ctx_ws_budget(bsa_ctx *c){
+	if(c->ws_limit) return c->ws_limit;
+	size_t fr = 0, tot = 0;
+	if(hipMemGetInfo(&fr, &tot) != hipSuccess) return (size_t)8 << 30;
+	// what is free now plus what the context already holds, keep 20% headroom for the caller
+	return (size_t)((double)(fr + c->ws_bytes) * 0.8);
+}
+
+static int ctx_ws_reserve(bsa_ctx *c, size_t bytes){
+	if(c->ws_bytes >= bytes) return BSA_OK;
+	if(c->ws){ HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+	if(hipMalloc((void**)&c->ws, bytes) != hipSuccess){ c->err = "workspace allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
+	c->ws_bytes = bytes;
+	return BSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------------
+
+// stage one pair per block: copy query codes (padded with BSA_QPAD_CODE) and target bytes, validate codes
+__global__ void __launch_bounds__(256) k_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
+		const uint64_t *toff, const uint32_t *tlen, const uint64_t *qpoff, const uint64_t *tpoff,
+		uint8_t *qst, uint8_t *tst, uint32_t qpad, uint32_t tpad, uint32_t *status, uint32_t n){
+	const uint32_t k = blockIdx.x;
+	if(k >= n) return;
+	const uint32_t ql = qlen[k], tl = tlen[k];
+	const uint8_t *q = seqs + qoff[k], *t = seqs + toff[k];
+	uint8_t *dq = qst + qpoff[k], *dt = tst + tpoff[k];
+	uint32_t bad = 0;
+	for(uint32_t i = threadIdx.x; i < ql + qpad; i += 256){
+		uint8_t c = (i < ql) ? q[i] : (uint8_t)BSA_QPAD_CODE;
+		if(i < ql && c > 3){ bad = 1; c &= 3; }
+		dq[i] = c;
+	}
+	for(uint32_t i = threadIdx.x; i < tl + tpad; i += 256){
+		uint8_t c = (i < tl) ? t[i] : (uint8_t)0;
+		if(c > 3){ bad = 1; c &= 3; }
+		dt[i] = c;
+	}
+	uint32_t st = 0;
+	if(__syncthreads_or((int)bad)) st |= BSA_ST_BAD_BASE;
+	if(ql == 0 || tl == 0) st |= BSA_ST_EMPTY;
+	if(threadIdx.x == 0) status[k] = st;
+}
+
+// single-block exclusive scan of cnt[0..n) into off[0..n], off[n] = total; *carry (optional) is a running base
+__global__ void __launch_bounds__(1024) k_excl_scan(const uint32_t *cnt, uint64_t *off, uint32_t n, uint64_t *carry){
+	__shared__ uint64_t part[1024];
+	__shared__ uint64_t base;
+	const uint32_t t = threadIdx.x;
+	if(t == 0) base = carry ? *carry : 0ull;
+	__syncthreads();
+	for(uint32_t s = 0; s < n; s += 1024u * 8u){
+		uint64_t loc[8]; uint64_t sum = 0;
+		for(int k = 0; k < 8; k++){
+			uint32_t idx = s + t * 8u + k;
+			loc[k] = sum;
+			sum += (idx < n) ? cnt[idx] : 0u;
+		}
+		part[t] = sum;
+		__syncthreads();
+		for(uint32_t d = 1; d < 1024; d <<= 1){   // Hillis-Steele inclusive scan of the per-thread sums
+			uint64_t v = (t >= d) ? part[t - d] : 0ull;
+			__syncthreads();
+			part[t] += v;
+			__syncthreads();
+		}
+		const uint64_t excl = part[t] - sum + base;
+		for(int k = 0; k < 8; k++){
+			uint32_t idx = s + t * 8u + k;
+			if(idx < n) off[idx] = excl + loc[k];
+		}
+		__syncthreads();
+		if(t == 1023) base += part[1023];
+		__syncthreads();
+	}
+	if(t == 0){ off[n] = base; if(carry) *carry = base; }
+}
+
+// one wave per pair: copy the CIGAR words a traceback kernel left at the tail of the pair's row slot
+__global__ void __launch_bounds__(256) k_cigar_collect(const uint8_t *rows, const uint64_t *slot_off, const uint32_t *tlen,
+		const uint32_t *order, uint32_t rowb, uint32_t first, uint32_t count,
+		const uint32_t *cnt, const uint64_t *off, uint32_t *tmp, uint64_t cap){
+	const uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if(g >= count) return;
+	const uint32_t ppos = first + g, pair = order[ppos];
+	const uint32_t c = cnt[ppos];
+	const uint64_t o = off[ppos];
+	if(o + c > cap) return;
+	const uint32_t *src = (const uint32_t*)(rows + slot_off[ppos] + (size_t)(tlen[pair] + 3) * rowb) - c;
+	for(uint32_t i = lane; i < c; i += 64) tmp[o + i] = src[i];
+}
+
+__global__ void k_cnt_by_pair(const uint32_t *order, const uint32_t *cnt_pos, const uint64_t *off_pos,
+		uint32_t *cnt_pair, uint64_t *src_pair, uint32_t n){
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if(p >= n) return;
+	const uint32_t pair = order[p];
+	cnt_pair[pair] = cnt_pos[p];
+	src_pair[pair] = off_pos[p];
+}
+
+__global__ void __launch_bounds__(256) k_cigar_final(const uint32_t *tmp, const uint32_t *cnt_pair, const uint64_t *src_pair,
+		const uint64_t *dst_off, uint32_t *dst, uint64_t cap, uint32_t n){
+	const uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if(g >= n) return;
+	const uint32_t c = cnt_pair[g];
+	const uint64_t s = src_pair[g], d = dst_off[g];
+	if(d + c > cap || s + c > cap) return;
+	for(uint32_t i = lane; i < c; i += 64) dst[d + i] = tmp[s + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8-bit alignment plan
+// ------------------------------------------------------------------------------------------------
+struct Chunk { uint32_t first, count; size_t bytes; };
+
+struct bsa_align_plan {
+	bsa_ctx *ctx = nullptr;
+	size_t n = 0;
+	bsa_align_params_t par;
+	uint32_t bw = 0, rowb = 0; int pw = 0;
+	double cells = 0;
+	std::vector<Chunk> chunks;
+	size_t ws_need = 0;
+	// device metadata
+	uint64_t *d_qoff = nullptr, *d_toff = nullptr, *d_qpoff = nullptr, *d_tpoff = nullptr, *d_slot = nullptr;
+	uint32_t *d_qlen = nullptr, *d_tlen = nullptr, *d_order = nullptr;
+	uint8_t *d_qst = nullptr, *d_tst = nullptr;
+	uint32_t *d_cnt_pos = nullptr, *d_cnt_pair = nullptr, *d_status_own = nullptr;
+	uint64_t *d_off_pos = nullptr, *d_src_pair = nullptr, *d_carry = nullptr;
+	uint32_t *d_tmp = nullptr; size_t tmp_words = 0;
+	size_t qst_bytes = 0, tst_bytes = 0;
+	uint32_t qpad = 0, tpad = 16;
+};
+
+template<typename T> static int dev_upload(bsa_ctx *c, T **dst, const std::vector<T> &src){
+	size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+	if(hipMalloc((void**)dst, bytes) != hipSuccess){ c->err = "metadata allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
+	if(!src.empty()) HIPCHK(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+	return BSA_OK;
+}
+template<typename T> static int dev_alloc(bsa_ctx *c, T **dst, size_t count){
+	if(hipMalloc((void**)dst, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess){ c->err = "device allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
+	return BSA_OK;
+}
+
+extern "C" void bsa_align_plan_destroy(bsa_align_plan_t *p){
+	if(!p) return;
+	(void)hipSetDevice(p->ctx->device);
+	(void)hipStreamSynchronize(p->ctx->stream);
+	void *ptrs[] = { p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_qlen, p->d_tlen, p->d_order, p->d_qst, p->d_tst,
+	                 p->d_cnt_pos, p->d_cnt_pair, p->d_status_own, p->d_off_pos, p->d_src_pair, p->d_carry, p->d_tmp };
+	for(void *q : ptrs) if(q) (void)hipFree(q);
+	delete p;
+}
+
+extern "C" double bsa_align_plan_cells(const bsa_align_plan_t *p){ return p ? p->cells : 0.0; }
+
+extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const uint32_t *qlen,
+		const uint64_t *toff, const uint32_t *tlen, size_t n, const bsa_align_params_t *par, bsa_align_plan_t **out){
+	if(!c || !out || !par || (n && (!qoff || !qlen || !toff || !tlen))) return BSA_E_ARG;
+	*out = nullptr;
+	if(n > 0xFFFFFFF0ull) { c->err = "too many pairs"; return BSA_E_ARG; }
+	const int type = par->mode & 3;
+	if(type != BSA_MODE_GLOBAL && type != BSA_MODE_OVERLAP && type != BSA_MODE_EXTEND){ c->err = "bad mode"; return BSA_E_ARG; }
+	(void)hipSetDevice(c->device);
+	if(par->bandwidth == 0){ c->err = "bandwidth 0 (per-pair full band) is not implemented on the device yet"; return BSA_E_UNSUPPORTED; }
+	uint32_t bw = (par->bandwidth + 15u) / 16u * 16u;   // bsalign.h:3862
+	if(!bsa_align8_supported_bw(bw)){ c->err = "bandwidth/16 must be one of 1,2,4,8,16,32 on the device for now"; return BSA_E_UNSUPPORTED; }
+	bsa_align_plan *p = new bsa_align_plan();
+	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
+	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)bw);
+	p->rowb = bsa_row_bytes(bw, p->pw);
+	p->qpad = bw + 32;
+	std::vector<uint32_t> order(n);
+	for(size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return tlen[x] > tlen[y]; });
+	std::vector<uint64_t> qpoff(n), tpoff(n), slot(n);
+	size_t qacc = 0, tacc = 0;
+	double cells = 0;
+	for(size_t k = 0; k < n; k++){
+		qpoff[k] = qacc; qacc += ((size_t)qlen[k] + p->qpad + 15) & ~(size_t)15;
+		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + p->tpad + 15) & ~(size_t)15;
+		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw;
+	}
+	p->qst_bytes = qacc; p->tst_bytes = tacc; p->cells = cells;
+	// chunks over the processing order, bounded by the workspace budget
+	const size_t budget = ctx_ws_budget(c);
+	size_t acc = 0; uint32_t first = 0;
+	for(size_t pos = 0; pos < n; pos++){
+		const size_t need = ((size_t)tlen[order[pos]] + 3) * p->rowb;
+		if(need > budget){ c->err = "workspace limit too small for one pair"; delete p; return BSA_E_NOMEM; }
+		if(acc + need > budget){
+			p->chunks.push_back({first, (uint32_t)(pos - first), acc});
+			p->ws_need = std::max(p->ws_need, acc);
+			first = (uint32_t)pos; acc = 0;
+		}
+		slot[pos] = acc; acc += need;
+	}
+	if(n > first){ p->chunks.push_back({first, (uint32_t)(n - first), acc}); p->ws_need = std::max(p->ws_need, acc); }
+	int rc;
+	std::vector<uint64_t> vqoff(qoff, qoff + n), vtoff(toff, toff + n);
+	std::vector<uint32_t> vqlen(qlen, qlen + n), vtlen(tlen, tlen + n);
+#define TRY(x) do { rc = (x); if(rc != BSA_OK){ bsa_align_plan_destroy(p); return rc; } } while(0)
+	TRY(dev_upload(c, &p->d_qoff, vqoff)); TRY(dev_upload(c, &p->d_toff, vtoff));
+	TRY(dev_upload(c, &p->d_qlen, vqlen)); TRY(dev_upload(c, &p->d_tlen, vtlen));
+	TRY(dev_upload(c, &p->d_qpoff, qpoff)); TRY(dev_upload(c, &p->d_tpoff, tpoff));
+	TRY(dev_upload(c, &p->d_slot, slot)); TRY(dev_upload(c, &p->d_order, order));
+	TRY(dev_alloc(c, &p->d_qst, p->qst_bytes)); TRY(dev_alloc(c, &p->d_tst, p->tst_bytes));
+	TRY(dev_alloc(c, &p->d_cnt_pos, n)); TRY(dev_alloc(c, &p->d_cnt_pair, n)); TRY(dev_alloc(c, &p->d_status_own, n));
+	TRY(dev_alloc(c, &p->d_off_pos, n + 1)); TRY(dev_alloc(c, &p->d_src_pair, n)); TRY(dev_alloc(c, &p->d_carry, 1));
+	TRY(ctx_ws_reserve(c, p->ws_need));
+#undef TRY
+	*out = p;
+	return BSA_OK;
+}
+
+extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_result_t *d_out, uint32_t *d_cigar,
+		size_t cigar_cap_words, uint64_t *d_cigar_off, uint32_t *d_status){
+	if(!p || !d_out) return BSA_E_ARG;
+	bsa_ctx *c = p->ctx;
+	(void)hipSetDevice(c->device);
+	hipStream_t st = c->stream;
+	const uint32_t n = (uint32_t)p->n;
+	c->ev_used = 0; c->last_cells = 0;
+	if(n == 0){
+		if(d_cigar_off) HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t), st));
+		return BSA_OK;
+	}
+	if(!d_seqs) return BSA_E_ARG;
+	int rc = ctx_ws_reserve(c, p->ws_need);
+	if(rc != BSA_OK) return rc;
+	const bool want_cig = d_cigar != nullptr && d_cigar_off != nullptr;
+	if(want_cig && p->tmp_words < cigar_cap_words){
+		if(p->d_tmp){ HIPCHK(c, hipStreamSynchronize(st)); (void)hipFree(p->d_tmp); p->d_tmp = nullptr; }
+		if(hipMalloc((void**)&p->d_tmp, std::max<size_t>(cigar_cap_words, 1) * 4) != hipSuccess){ c->err = "cigar staging allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
+		p->tmp_words = cigar_cap_words;
+	}
+	uint32_t *status = d_status ? d_status : p->d_status_own;
+	hipLaunchKernelGGL(k_stage, dim3(n), dim3(256), 0, st, d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen,
+		p->d_qpoff, p->d_tpoff, p->d_qst, p->d_tst, p->qpad, p->tpad, status, n);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemsetAsync(p->d_carry, 0, sizeof(uint64_t), st));
+	Align8Args a;
+	memset(&a, 0, sizeof(a));
+	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
+	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
+	a.rows = c->ws; a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode;
+	a.gapo1 = p->par.gapo1; a.gape1 = p->par.gape1; a.gapo2 = p->par.gapo2; a.gape2 = p->par.gape2;
+	int smax = -127, smin = 127;
+	for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)p->par.matrix[i]); smin = std::min(smin, (int)p->par.matrix[i]); a.matrix[i] = p->par.matrix[i]; }
+	a.smax = smax; a.smin = smin;
+	for(int t = 0; t < 4; t++){
+		uint32_t w = 0;
+		for(int q = 0; q < 4; q++) w |= (uint32_t)(uint8_t)p->par.matrix[q * 4 + t] << (8 * q);
+		a.mrow[t] = w;
+	}
+	for(const Chunk &ch : p->chunks){
+		a.first = ch.first; a.count = ch.count;
+		hipEvent_t e0, e1;
+		rc = ctx_event_pair(c, &e0, &e1); if(rc != BSA_OK) return rc;
+		HIPCHK(c, hipEventRecord(e0, st));
+		HIPCHK(c, bsa_launch_align8_fwd(a, p->pw, st));
+		HIPCHK(c, hipEventRecord(e1, st));
+		HIPCHK(c, bsa_launch_align8_backcal(a, p->pw, d_out, p->d_cnt_pos, st));
+		if(want_cig){
+			hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry);
+			HIPCHK(c, hipGetLastError());
+			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, st, c->ws, p->d_slot, p->d_tlen, p->d_order,
+				p->rowb, ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
+			HIPCHK(c, hipGetLastError());
+		}
+	}
+	c->last_cells = p->cells;
+	if(want_cig){
+		hipLaunchKernelGGL(k_cnt_by_pair, dim3((n + 255) / 256), dim3(256), 0, st, p->d_order, p->d_cnt_pos, p->d_off_pos, p->d_cnt_pair, p->d_src_pair, n);
+		HIPCHK(c, hipGetLastError());
+		hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pair, d_cigar_off, n, (uint64_t*)nullptr);
+		HIPCHK(c, hipGetLastError());
+		hipLaunchKernelGGL(k_cigar_final, dim3((n + 3) / 4), dim3(256), 0, st, p->d_tmp, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
+		HIPCHK(c, hipGetLastError());
+	} else if(d_cigar_off){
+		HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t) * ((size_t)n + 1), st));
+	}
+	return BSA_OK;
+}
+
+extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_bytes,
+		const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen, size_t n,
+		const bsa_align_params_t *par, bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words,
+		uint64_t *cigar_off, uint32_t *status){
+	if(!c || !out || !par) return BSA_E_ARG;
+	if(n == 0){ if(cigar_off) cigar_off[0] = 0; return BSA_OK; }
+	if(!seqs) return BSA_E_ARG;
+	(void)hipSetDevice(c->device);
+	bsa_align_plan_t *p = nullptr;
+	int rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
+	if(rc != BSA_OK) return rc;
+	uint8_t *d_seqs = nullptr; bsa_result_t *d_out = nullptr; uint32_t *d_cig = nullptr, *d_status = nullptr; uint64_t *d_off = nullptr;
+	auto cleanup = [&](){
+		if(d_seqs) (void)hipFree(d_seqs); if(d_out) (void)hipFree(d_out); if(d_cig) (void)hipFree(d_cig);
+		if(d_status) (void)hipFree(d_status); if(d_off) (void)hipFree(d_off);
+		bsa_align_plan_destroy(p);
+	};
+	const bool want_cig = cigar && cigar_off;
+#define TRYH(call) do { hipError_t _e = (call); if(_e != hipSuccess){ c->err = std::string(#call) + ": " + hipGetErrorString(_e); cleanup(); return BSA_E_HIP; } } while(0)
+	TRYH(hipMalloc((void**)&d_seqs, std::max<size_t>(seqs_bytes, 1)));
+	TRYH(hipMalloc((void**)&d_out, n * sizeof(bsa_result_t)));
+	TRYH(hipMalloc((void**)&d_status, n * sizeof(uint32_t)));
+	if(want_cig){
+		TRYH(hipMalloc((void**)&d_cig, std::max<size_t>(cigar_cap_words, 1) * 4));
+		TRYH(hipMalloc((void**)&d_off, (n + 1) * sizeof(uint64_t)));
+	}
+	TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+	rc = bsa_align_run(p, d_seqs, d_out, d_cig, cigar_cap_words, d_off, d_status);
+	if(rc != BSA_OK){ cleanup(); return rc; }
+	TRYH(hipMemcpyAsync(out, d_out, n * sizeof(bsa_result_t), hipMemcpyDeviceToHost, c->stream));
+	if(status) TRYH(hipMemcpyAsync(status, d_status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	if(want_cig) TRYH(hipMemcpyAsync(cigar_off, d_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	TRYH(hipStreamSynchronize(c->stream));
+	if(want_cig){
+		if(cigar_off[n] > cigar_cap_words){ cleanup(); c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
+		TRYH(hipMemcpy(cigar, d_cig, cigar_off[n] * 4, hipMemcpyDeviceToHost));
+	}
+#undef TRYH
+	cleanup();
+	return BSA_OK;
+}
+
+// debug / test hook: copy the stored row records of processing position `ppos` (tlen+1 records) to host.
+// Only meaningful right after a single-chunk run.
+extern "C" int bsa_align_debug_rows(bsa_align_plan_t *p, uint32_t pair, uint8_t *host, size_t bytes, uint32_t *rowb_out){
+	if(!p || !host) return BSA_E_ARG;
+	bsa_ctx *c = p->ctx;
+	(void)hipSetDevice(c->device);
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	std::vector<uint32_t> order(p->n);
+	std::vector<uint64_t> slot(p->n);
+	HIPCHK(c, hipMemcpy(order.data(), p->d_order, p->n * 4, hipMemcpyDeviceToHost));
+	HIPCHK(c, hipMemcpy(slot.data(), p->d_slot, p->n * 8, hipMemcpyDeviceToHost));
+	for(size_t pos = 0; pos < p->n; pos++){
+		if(order[pos] == pair){
+			HIPCHK(c, hipMemcpy(host, c->ws + slot[pos], bytes, hipMemcpyDeviceToHost));
+			if(rowb_out) *rowb_out = p->rowb;
+			return BSA_OK;
+		}
+	}
+	return BSA_E_ARG;
+}
+
+extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *c, hipStream_t *st){
+	if(!c || !st) return BSA_E_ARG;
+	(void)hipSetDevice(c->device);
+	*st = c->stream;
+	return BSA_OK;
+}

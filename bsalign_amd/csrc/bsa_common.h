@@ -1,0 +1,56 @@
+// bsa_common.h -- internal definitions shared by the HIP translation units of libbsalign_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/bsalign_hip.h"
+
+#define BSA_LANES      16                      // running blocks per band row == lanes of one DPP row
+#define BSA_EPI8_MIN   (-63)                   // bsalign.h:56
+#define BSA_EPI8_MAX   (63)                    // bsalign.h:57
+#define BSA_SCORE_MIN  (-(0x7FFFFFFF >> 2))    // bsalign.h:58
+#define BSA_QPAD_CODE  4                       // staged query code for columns >= qlen (S = -63, bsalign.h:2157-2160)
+
+// device-side description of one batch chunk of the 8-bit path
+struct Align8Args {
+	// staged sequences: query codes padded with BSA_QPAD_CODE, target bytes
+	const uint8_t  *qst;        // staged queries
+	const uint8_t  *tst;        // staged targets
+	const uint64_t *qpoff;      // [n] offset of pair's staged query
+	const uint64_t *tpoff;      // [n] offset of pair's staged target
+	const uint32_t *qlen;       // [n]
+	const uint32_t *tlen;       // [n]
+	const uint32_t *order;      // [n] processing order (sorted by length); results go to original index
+	const uint64_t *slot_off;   // [n] (indexed by processing position) byte offset of the pair's row slot in `rows`
+	uint8_t        *rows;       // traceback rows workspace
+	uint32_t       *status;     // [n] per original pair
+	uint32_t first, count;      // processing positions [first, first+count) handled by this launch
+	uint32_t bw;                // effective bandwidth (multiple of 16), uniform over the chunk
+	uint32_t rowb;              // bytes per stored row record
+	int32_t  mode;
+	int32_t  gapo1, gape1, gapo2, gape2;
+	int32_t  smax, smin;        // max / min of the score matrix (bsalign.h:3868-3873)
+	uint32_t mrow[4];           // mrow[t] = 4 packed int8 scores {matrix[0*4+t], matrix[1*4+t], matrix[2*4+t], matrix[3*4+t]}
+	int8_t   matrix[16];
+};
+
+// row record layout (natural band order, one record per target row, row -1 first):
+//   [0, bw)            u  (int8)   u[p] = H(p) - H(p-1)
+//   [bw, 2bw)          e  (int8)   only when piecewise >= 1
+//   [2bw, 3bw)         q  (int8)   only when piecewise == 2
+//   [(pw+1)bw, +68)    ubegs (17 x int32)
+//   [(pw+1)bw + 68]    rbeg (int32): band offset of the row
+static inline __host__ __device__ uint32_t bsa_row_bytes(uint32_t bw, int pw){
+	uint32_t b = (uint32_t)(pw + 1) * bw + 17 * 4 + 4;
+	return (b + 15u) & ~15u;
+}
+
+static inline __host__ __device__ int bsa_get_piecewise(int gapo1, int gape1, int gapo2, int gape2, int bandwidth){ // bsalign.h:2084-2092
+	if(gapo2 < gapo1 && gape2 > gape1 && gapo2 + gape2 < gapo1 + gape1 && (gapo1 - gapo2) / (gape1 - gape2) < bandwidth) return 2;
+	return gapo1 ? 1 : 0;
+}
+
+// launchers implemented in the kernel translation units
+hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st);
+hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);
+bool bsa_align8_supported_bw(uint32_t bw);

@@ -1,0 +1,157 @@
+/*
+ * bsalign_hip.h -- C-ABI of libbsalign_hip.so: the MI355X (gfx950) implementation of
+ * bsalign's banded striped DP hot path.
+ *
+ * Plain C types only: no HIP, torch or C++ types cross this boundary.  Every entry
+ * point returns 0 on success or a negative BSA_E_* code (the reference abort()s
+ * instead: bsalign.h:3882-3885, 1076-1079).  Nothing here falls back to a CPU
+ * implementation: without a usable GPU every compute entry point fails with
+ * BSA_E_NODEVICE.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *   bsa_align_*   <- banded_striped_epi8_seqalign_pairwise   bsalign.h:3854 (one call per pair, main.c:323-326)
+ *   bsa_edit_*    <- striped_seqedit_pairwise                bsalign.h:1046 (main.c:196-204)
+ *   bsa_rows_*    <- dpalign_row_update_bspoa / dpalign_row_merge_bspoa  bspoa.h:2232-2272
+ *                    (= banded_striped_epi8_seqalign_piecex_row_movx + _row_cal + _row_merge,
+ *                     bsalign.h:2244, 3181, 2474)
+ *   bsa_result_t  <- seqalign_result_t                       bsalign.h:213-218
+ *   CIGAR words   <- u4v of (len << 4 | op)                  bsalign.h:61-69, 401-417
+ * The reference has no batch interface (one pair per call, one thread); the batch
+ * forms below are the device-sized equivalent of its per-pair loop.  The drop-in
+ * single-pair functions with the reference's exact signatures live in
+ * include/bsalign_compat.h and are thin wrappers over these.
+ */
+#ifndef BSALIGN_HIP_H
+#define BSALIGN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* modes (bsalign.h:30-38) */
+#define BSA_MODE_GLOBAL   0
+#define BSA_MODE_OVERLAP  1
+#define BSA_MODE_EXTEND   2
+
+/* CIGAR op codes (bsalign.h:61-69) */
+#define BSA_CIGAR_M 0
+#define BSA_CIGAR_I 1
+#define BSA_CIGAR_D 2
+
+/* error codes */
+#define BSA_OK            0
+#define BSA_E_NODEVICE   (-1)   /* no HIP device / runtime failure at context creation */
+#define BSA_E_ARG        (-2)   /* invalid argument (NULL pointer, bad mode, W == 0 ...) */
+#define BSA_E_NOMEM      (-3)   /* device allocation failed / workspace limit too small for one pair */
+#define BSA_E_HIP        (-4)   /* a HIP call failed (see bsa_last_error) */
+#define BSA_E_CIGAR_CAP  (-5)   /* cigar arena too small; cigar_off[n] holds the required number of words */
+#define BSA_E_UNSUPPORTED (-6)  /* parameter combination not implemented on the device yet */
+
+/* per-pair status bits written to the optional status array */
+#define BSA_ST_OK          0u
+#define BSA_ST_BAD_BASE    1u   /* a base code > 3 (the reference would index past matrix[16]) */
+#define BSA_ST_EMPTY       2u   /* qlen == 0 or tlen == 0 */
+#define BSA_ST_TRACE       4u   /* traceback left the stored band: the reference does not terminate on this input */
+
+/* == seqalign_result_t (bsalign.h:213-218): 10 x int32, [qb,qe) x [tb,te) half-open */
+typedef struct {
+	int32_t score;
+	int32_t qb, qe;
+	int32_t tb, te;
+	int32_t mat, mis, ins, del, aln;
+} bsa_result_t;
+
+/* arguments of banded_striped_epi8_seqalign_pairwise that are shared by a batch (bsalign.h:399) */
+typedef struct {
+	int32_t  mode;        /* BSA_MODE_* */
+	uint32_t bandwidth;   /* 0 => qlen of each pair; rounded up to a multiple of 16 (bsalign.h:3861-3862) */
+	int8_t   matrix[16];  /* matrix[q*4+t] (bsalign.h:323) */
+	int8_t   gapo1, gape1, gapo2, gape2; /* negative penalties as the reference's CLI stores them (main.c:283-288) */
+} bsa_align_params_t;
+
+typedef struct {
+	int32_t  mode;        /* BSA_MODE_* */
+	uint32_t bandwidth;   /* rounded to a multiple of 64 with the rules of bsalign.h:1055-1067 */
+} bsa_edit_params_t;
+
+typedef struct bsa_ctx bsa_ctx_t;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int         bsa_ctx_create(int device, bsa_ctx_t **out);
+void        bsa_ctx_destroy(bsa_ctx_t *ctx);
+/* run on a caller-owned hipStream_t (passed as void*); NULL = the context's own stream */
+int         bsa_ctx_set_stream(bsa_ctx_t *ctx, void *hip_stream);
+/* cap the device scratch (traceback rows) the context may allocate; 0 = 80% of free memory */
+int         bsa_ctx_set_workspace_limit(bsa_ctx_t *ctx, size_t bytes);
+int         bsa_ctx_sync(bsa_ctx_t *ctx);
+const char *bsa_last_error(bsa_ctx_t *ctx);
+/* average duration (ms) of the dominant kernel's launches in the last *_run call, measured with HIP
+ * events on the launch stream; *launches = number of launches averaged, *cells = band cells they covered */
+int         bsa_ctx_last_kernel_ms(bsa_ctx_t *ctx, double *ms, long *launches, double *cells);
+void        bsa_set_score_matrix(int8_t matrix[16], int8_t mat, int8_t mis);   /* bsalign.h:323 */
+
+/* ---- 8-bit banded striped pairwise alignment (A-rows) ------------------------------------------
+ * Sequences: one base per byte, codes 0..3 (the reference's u1i* qseq/tseq), all pairs in one blob;
+ * pair k uses seqs[qoff[k] .. qoff[k]+qlen[k]) and seqs[toff[k] .. toff[k]+tlen[k]).
+ * Outputs: out[k]; CIGAR words of pair k at cigar[cigar_off[k] .. cigar_off[k+1]) (cigar_off has n+1
+ * entries); status[k] (optional, may be NULL).
+ *
+ * bsa_align_batch      : every pointer is HOST memory (copies in, runs, copies out, synchronises).
+ * bsa_align_plan_*     : two-phase form for resident data -- the plan takes the HOST metadata
+ *                        (offsets, lengths) once; bsa_align_run takes DEVICE pointers for the
+ *                        sequence blob and all outputs and is asynchronous on the context stream. */
+int bsa_align_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t seqs_bytes,
+                    const uint64_t *qoff, const uint32_t *qlen,
+                    const uint64_t *toff, const uint32_t *tlen, size_t n,
+                    const bsa_align_params_t *par,
+                    bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words,
+                    uint64_t *cigar_off, uint32_t *status);
+
+typedef struct bsa_align_plan bsa_align_plan_t;
+int  bsa_align_plan_create(bsa_ctx_t *ctx, const uint64_t *qoff, const uint32_t *qlen,
+                           const uint64_t *toff, const uint32_t *tlen, size_t n,
+                           const bsa_align_params_t *par, bsa_align_plan_t **out);
+void bsa_align_plan_destroy(bsa_align_plan_t *plan);
+/* total band cells of the plan: sum over pairs of tlen * bw_eff (the GCUPS numerator) */
+double bsa_align_plan_cells(const bsa_align_plan_t *plan);
+int  bsa_align_run(bsa_align_plan_t *plan, const uint8_t *d_seqs,
+                   bsa_result_t *d_out, uint32_t *d_cigar, size_t cigar_cap_words,
+                   uint64_t *d_cigar_off, uint32_t *d_status);
+
+/* ---- 2-bit striped edit-distance pairwise alignment (E-rows) --------------------------------- */
+int bsa_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t seqs_bytes,
+                   const uint64_t *qoff, const uint32_t *qlen,
+                   const uint64_t *toff, const uint32_t *tlen, size_t n,
+                   const bsa_edit_params_t *par,
+                   bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words,
+                   uint64_t *cigar_off, uint32_t *status);
+
+typedef struct bsa_edit_plan bsa_edit_plan_t;
+int  bsa_edit_plan_create(bsa_ctx_t *ctx, const uint64_t *qoff, const uint32_t *qlen,
+                          const uint64_t *toff, const uint32_t *tlen, size_t n,
+                          const bsa_edit_params_t *par, bsa_edit_plan_t **out);
+void bsa_edit_plan_destroy(bsa_edit_plan_t *plan);
+double bsa_edit_plan_cells(const bsa_edit_plan_t *plan);
+int  bsa_edit_run(bsa_edit_plan_t *plan, const uint8_t *d_seqs,
+                  bsa_result_t *d_out, uint32_t *d_cigar, size_t cigar_cap_words,
+                  uint64_t *d_cigar_off, uint32_t *d_status);
+
+/* ---- synthetic read pairs (measurement inputs, SURVEY 8(d) / BASELINE.md 3) ---------------------
+ * pair k: target = iid uniform ACGT of length L from splitmix64(seed ^ k*0x9E3779B97F4A7C15);
+ * query = target with errors at rate err_q32 / 2^32 split sub:ins:del = 23:31:46.
+ * Layout: target k at seqs[k*stride .. +L), query k at seqs[n*stride + k*stride .. +qlen[k]),
+ * stride = bsa_synth_stride(L).  *_host fills host memory (no GPU needed); *_dev fills device
+ * memory on the context stream and writes qlen to a device array. */
+size_t bsa_synth_stride(uint32_t L);
+int bsa_synth_pairs_host(uint64_t seed, uint64_t first_pair, size_t n, uint32_t L, uint32_t err_q32,
+                         uint8_t *seqs, uint32_t *qlen);
+int bsa_synth_pairs_dev(bsa_ctx_t *ctx, uint64_t seed, uint64_t first_pair, size_t n, uint32_t L, uint32_t err_q32,
+                        uint8_t *d_seqs, uint32_t *d_qlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

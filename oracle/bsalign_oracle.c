@@ -549,10 +549,10 @@ static int backcal(const uint8_t *qseq, const uint8_t *tseq, const rows_t *R, in
 	return 0;
 }
 
-long orc_align_pairwise_trace(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint32_t tlen,
+static long align_core(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint32_t tlen,
 		int mode, uint32_t bandwidth, const int8_t mtx[16],
 		int gapo1, int gape1, int gapo2, int gape2,
-		orc_result_t *res, uint32_t *cig, long cap, int32_t *begs_out){ /* bsalign.h:3854-4050 */
+		orc_result_t *res, uint32_t *cig, long cap, int32_t *begs_out, uint8_t *rows_out, uint32_t rowb){ /* bsalign.h:3854-4050 */
 	rows_t R;
 	orc_query_t qy;
 	orc_result_t rs;
@@ -643,6 +643,20 @@ long orc_align_pairwise_trace(const uint8_t *q, uint32_t qlen, const uint8_t *tq
 		}
 	}
 	if(begs_out) memcpy(begs_out, R.begs + 1, sizeof(int32_t) * tlen);
+	if(rows_out){ /* dump in the device's row-record layout (natural band order; see bsalign_amd/csrc/bsa_common.h) */
+		uint32_t r, pp;
+		for(r = 0; r <= tlen; r++){
+			uint8_t *rec = rows_out + (size_t)r * rowb;
+			int32_t *ubp = (int32_t*)(rec + (size_t)(pw + 1) * bw);
+			for(pp = 0; pp < bw; pp++){
+				rec[pp] = (uint8_t)R.ups[(size_t)r * bw + sidx(W, pp)];
+				if(pw >= 1) rec[bw + pp] = (uint8_t)R.eps[(size_t)r * bw + sidx(W, pp)];
+				if(pw == 2) rec[2 * bw + pp] = (uint8_t)R.qps[(size_t)r * bw + sidx(W, pp)];
+			}
+			memcpy(ubp, R.ubs + (size_t)r * (NL + 1), sizeof(int32_t) * (NL + 1));
+			ubp[NL + 1] = R.begs[r];
+		}
+	}
 	cv.buf = cig; cv.n = 0; cv.cap = cig ? cap : 0;
 	{
 		int bad = 0;
@@ -661,10 +675,22 @@ long orc_align_pairwise_trace(const uint8_t *q, uint32_t qlen, const uint8_t *tq
 	return cv.n;
 }
 
+long orc_align_pairwise_trace(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
+		int mode, uint32_t bandwidth, const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2,
+		orc_result_t *res, uint32_t *cig, long cap, int32_t *begs_out){
+	return align_core(q, qlen, t, tlen, mode, bandwidth, mtx, gapo1, gape1, gapo2, gape2, res, cig, cap, begs_out, NULL, 0);
+}
+
 long orc_align_pairwise(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
 		int mode, uint32_t bandwidth, const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2,
 		orc_result_t *res, uint32_t *cig, long cap){
-	return orc_align_pairwise_trace(q, qlen, t, tlen, mode, bandwidth, mtx, gapo1, gape1, gapo2, gape2, res, cig, cap, NULL);
+	return align_core(q, qlen, t, tlen, mode, bandwidth, mtx, gapo1, gape1, gapo2, gape2, res, cig, cap, NULL, NULL, 0);
+}
+
+long orc_align_pairwise_rows(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
+		int mode, uint32_t bandwidth, const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2,
+		orc_result_t *res, uint8_t *rows_out, uint32_t rowb){
+	return align_core(q, qlen, t, tlen, mode, bandwidth, mtx, gapo1, gape1, gapo2, gape2, res, NULL, 0, NULL, rows_out, rowb);
 }
 
 double orc_align_batch_time(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,

@@ -84,6 +84,13 @@ long     orc_align_pairwise_trace(const uint8_t *q, uint32_t qlen, const uint8_t
                             int gapo1, int gape1, int gapo2, int gape2,
                             orc_result_t *res, uint32_t *cig, long cap, int32_t *begs_out);
 
+/* row-record dump in the device layout ((tlen+1) records of rowb bytes, row -1 first): lets the GPU tests
+ * locate the first differing DP row */
+long     orc_align_pairwise_rows(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
+                            int mode, uint32_t bandwidth, const int8_t mtx[16],
+                            int gapo1, int gape1, int gapo2, int gape2,
+                            orc_result_t *res, uint8_t *rows_out, uint32_t rowb);
+
 /* timing helper for bench.py's cpu_baseline (kind = "port") */
 double   orc_align_batch_time(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
                               const uint64_t *toff, const uint32_t *tlen, long n, int mode, uint32_t bandwidth,

@@ -17,6 +17,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 MODE_GLOBAL, MODE_OVERLAP, MODE_EXTEND = 0, 1, 2
 ERR_INPUT = -(1 << 40)
+ORC_ERR_TRACE = -(1 << 41)
 
 u8p = C.POINTER(C.c_uint8)
 i8p = C.POINTER(C.c_int8)

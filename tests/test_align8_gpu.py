@@ -1,0 +1,105 @@
+"""GPU parity: HIP 8-bit banded path (through the C-ABI) vs the oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import support as S
+
+pytestmark = pytest.mark.gpu
+
+SCORINGS = {
+    "affine": (2, -6, -3, -2, 0, 0),
+    "paper": (2, -2, -4, -2, 0, 0),
+    "linear": (2, -6, 0, -3, 0, 0),
+    "twopiece": (2, -6, -3, -2, -8, -1),
+}
+
+
+def _mk_pairs(rng, n, lens, eps_list=(0.01, 0.1, 0.2), ratios=(1.0, 1.0, 0.9, 1.1)):
+    pairs = []
+    for _ in range(n):
+        L = int(rng.choice(lens))
+        T = rng.integers(0, 4, size=L).astype(np.uint8)
+        Q = S.mutate(rng, T, float(rng.choice(eps_list)))
+        r = float(rng.choice(ratios))
+        if r != 1.0:
+            Lq = max(1, int(len(Q) * r))
+            Q = Q[:Lq] if Lq <= len(Q) else np.concatenate([Q, rng.integers(0, 4, size=Lq - len(Q)).astype(np.uint8)])
+        if len(Q) == 0:
+            Q = np.array([0], dtype=np.uint8)
+        pairs.append((Q, T))
+    return pairs
+
+
+def _check(ctx, pairs, mode, bw, sc):
+    import bsalign_amd as B
+    par = B.make_params(mode, bw, *sc)
+    out, cigs, status = ctx.align_batch(pairs, par)
+    nbad = 0
+    msgs = []
+    for k, (q, t) in enumerate(pairs):
+        res, cig, n = S.oracle_align(q, t, mode, bw, *sc)
+        if n == S.ORC_ERR_TRACE:
+            ok = bool(status[k] & B.ST_TRACE)
+        else:
+            got = np.array([out[k][f] for f in out.dtype.names], dtype=np.int32)
+            ok = status[k] == 0 and np.array_equal(got, res) and np.array_equal(cigs[k], cig)
+        if not ok:
+            nbad += 1
+            if len(msgs) < 5:
+                msgs.append("pair %d qlen %d tlen %d status %d\n  gpu %s %s\n  orc %s %s" % (
+                    k, len(q), len(t), status[k], out[k], S.cigar_str(cigs[k])[:120], res, S.cigar_str(cig)[:120]))
+    assert nbad == 0, "%d/%d pairs differ (mode %d bw %d sc %s)\n%s" % (nbad, len(pairs), mode, bw, sc, "\n".join(msgs))
+
+
+@pytest.mark.parametrize("scname", list(SCORINGS))
+@pytest.mark.parametrize("mode", [S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND])
+@pytest.mark.parametrize("bw", [128, 64])
+def test_random_pairs(ctx, scname, mode, bw):
+    rng = np.random.default_rng(1000 + bw + 7 * mode + len(scname))
+    pairs = _mk_pairs(rng, 96, [1, 15, 16, 17, 63, 64, 65, 100, 300, 1000, 2000])
+    _check(ctx, pairs, mode, bw, SCORINGS[scname])
+
+
+@pytest.mark.parametrize("bw", [16, 32, 256, 512])
+def test_other_bandwidths(ctx, bw):
+    rng = np.random.default_rng(77 + bw)
+    pairs = _mk_pairs(rng, 64, [10, 100, 700, 1500])
+    for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP):
+        _check(ctx, pairs, mode, bw, SCORINGS["affine"])
+        _check(ctx, pairs, mode, bw, SCORINGS["twopiece"])
+
+
+def test_synthetic_10k_bw128(ctx):
+    """the benchmark shape (C2): 10 kbp synthetic pairs, global, bw 128"""
+    pairs = [S.synth_pair(k, 10000) for k in range(24)]
+    _check(ctx, pairs, S.MODE_GLOBAL, 128, SCORINGS["affine"])
+    _check(ctx, pairs[:8], S.MODE_GLOBAL, 128, SCORINGS["paper"])
+
+
+def test_length_mismatch_and_jumps(ctx):
+    """tlen << qlen forces band jumps >= W cells (generic movx path); qlen << tlen the opposite"""
+    rng = np.random.default_rng(5)
+    pairs = []
+    for _ in range(40):
+        Lt = int(rng.integers(20, 400))
+        Lq = int(Lt * float(rng.choice([2.0, 3.0, 5.0, 0.5, 0.3])))
+        pairs.append((rng.integers(0, 4, size=max(Lq, 1)).astype(np.uint8), rng.integers(0, 4, size=Lt).astype(np.uint8)))
+    for bw in (16, 32, 64):
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+            _check(ctx, pairs, mode, bw, SCORINGS["affine"])
+
+
+def test_bad_and_empty_inputs(ctx):
+    import bsalign_amd as B
+    q = np.array([0, 1, 2, 3] * 10, dtype=np.uint8)
+    bad = q.copy()
+    bad[5] = 4
+    pairs = [(q, q), (bad, q), (np.zeros(0, dtype=np.uint8), q), (q, np.zeros(0, dtype=np.uint8)), (q, q[::-1].copy())]
+    out, cigs, status = ctx.align_batch(pairs, B.make_params(S.MODE_GLOBAL, 64))
+    assert status[0] == 0 and status[4] == 0
+    assert status[1] & B.ST_BAD_BASE
+    assert status[2] & B.ST_EMPTY and status[3] & B.ST_EMPTY
+    assert out[1]["aln"] == 0 and out[2]["aln"] == 0 and len(cigs[1]) == 0
+    res, cig, _ = S.oracle_align(q, q, S.MODE_GLOBAL, 64, 2, -6, -3, -2, 0, 0)
+    assert np.array_equal(np.array([out[0][f] for f in out.dtype.names], dtype=np.int32), res)
+    assert np.array_equal(cigs[0], cig)
