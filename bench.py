@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the banded striped DP hot path on MI355X.
+
+One "step" = one pass of the hot path (stage -> forward DP -> traceback -> CIGAR compaction) over one batch
+of synthetic read pairs that is already resident in HBM.  Default workload = BASELINE.json configs[1]:
+100 k synthetic 10 kbp pairs, 8-bit, global, bandwidth 128, one GPU.  With --gpus N (launched by
+torch.distributed.run, one rank per GPU) every rank aligns its own 100 k pairs (weak scaling, no data-path
+collective: pairs are independent); RCCL is used only for the barrier / max-over-ranks of the timing.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric GCUPS, roofline of the dominant
+kernel (forward DP) measured with HIP events inside the library, and a CPU baseline of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEED = 20240611
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="align8", choices=["align8", "edit"])
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: 100000 for align8, 16384 for edit)")
+    ap.add_argument("--length", type=int, default=0, help="target length (default 10000 / 100000)")
+    ap.add_argument("--bw", type=int, default=0, help="bandwidth (default 128 / 256)")
+    ap.add_argument("--eps", type=float, default=0.10)
+    ap.add_argument("--scoring", default="2,-6,-3,-2,0,0", help="M,X,O,E,Q,P (reference CLI defaults, main.c:264)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs of the CPU baseline sample (0 = auto, -1 = skip)")
+    ap.add_argument("--workspace-gb", type=float, default=0.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, L, bw, sc, mode):
+    """reference (oracle/_ref, kind 'reference') or own restatement (kind 'port') on ONE host core, bounded sample"""
+    import support as S
+    import bsalign_amd as B
+    kind = "reference" if S.have_ref() else "port"
+    if args.workload == "align8":
+        npairs = args.cpu_pairs if args.cpu_pairs > 0 else (4000 if kind == "reference" else 1200)
+    else:
+        npairs = args.cpu_pairs if args.cpu_pairs > 0 else (1500 if kind == "reference" else 60)
+    stride = B.lib().bsa_synth_stride(L)
+    seqs = np.zeros(2 * npairs * stride, dtype=np.uint8)
+    qlen = np.zeros(npairs, dtype=np.uint32)
+    B.lib().bsa_synth_pairs_host(SEED, 0, npairs, L, int(args.eps * 4294967296.0), seqs.ctypes.data_as(C.c_void_p), qlen.ctypes.data_as(C.c_void_p))
+    tlen = np.full(npairs, L, dtype=np.uint32)
+    toff = (np.arange(npairs, dtype=np.uint64) * np.uint64(stride))
+    qoff = ((np.arange(npairs, dtype=np.uint64) + np.uint64(npairs)) * np.uint64(stride))
+    cs = C.c_int64(0)
+    if args.workload == "align8":
+        cells = float(L) * bw * npairs
+        if kind == "reference":
+            lib = S.ref()
+            secs = lib.ref_align_batch_time(lib._ctx, S.ptr(seqs, S.u8p), S.ptr(qoff, S.u64p), S.ptr(qlen, S.u32p), S.ptr(toff, S.u64p),
+                                            S.ptr(tlen, S.u32p), npairs, mode, bw, sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], C.byref(cs))
+        else:
+            m = S.score_matrix(sc[0], sc[1])
+            secs = S.oracle().orc_align_batch_time(S.ptr(seqs, S.u8p), S.ptr(qoff, S.u64p), S.ptr(qlen, S.u32p), S.ptr(toff, S.u64p),
+                                                   S.ptr(tlen, S.u32p), npairs, mode, bw, S.ptr(m, S.i8p), sc[2], sc[3], sc[4], sc[5], C.byref(cs))
+    else:
+        bw_eff = (bw + 63) // 64 * 64
+        cells = float(L) * bw_eff * npairs
+        if kind == "reference":
+            lib = S.ref()
+            secs = lib.ref_edit_batch_time(lib._ctx, S.ptr(seqs, S.u8p), S.ptr(qoff, S.u64p), S.ptr(qlen, S.u32p), S.ptr(toff, S.u64p),
+                                           S.ptr(tlen, S.u32p), npairs, mode, bw, C.byref(cs))
+        else:
+            secs = S.oracle().orc_edit_batch_time(S.ptr(seqs, S.u8p), S.ptr(qoff, S.u64p), S.ptr(qlen, S.u32p), S.ptr(toff, S.u64p),
+                                                  S.ptr(tlen, S.u32p), npairs, mode, bw, C.byref(cs))
+    what = ("the reference's SSE4.2 code (oracle/_ref)" if kind == "reference" else "own scalar C restatement (oracle/), not the reference")
+    return {"value": round(cells / secs / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": kind,
+            "sample": "%d of the same synthetic pairs (L=%d, bw=%d), single thread, %s, %.1f s" % (npairs, L, bw, what, secs)}
+
+
+def main():
+    args = parse()
+    import torch
+    import bsalign_amd as B
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    sc = tuple(int(x) for x in args.scoring.split(","))
+    mode = B.MODE_GLOBAL
+    if args.workload == "align8":
+        n = args.pairs or 100000
+        L = args.length or 10000
+        bw = args.bw or 128
+    else:
+        n = args.pairs or 16384
+        L = args.length or 100000
+        bw = args.bw or 256
+
+    ctx = B.Context(local, int(args.workspace_gb * (1 << 30)))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lib = B.lib()
+    stride = lib.bsa_synth_stride(L)
+    d_seqs = torch.empty(2 * n * stride, dtype=torch.uint8, device=dev)
+    d_qlen = torch.empty(n, dtype=torch.int32, device=dev)
+    rc = lib.bsa_synth_pairs_dev(ctx.h, SEED, rank * n, n, L, int(args.eps * 4294967296.0), C.c_void_p(d_seqs.data_ptr()), C.c_void_p(d_qlen.data_ptr()))
+    assert rc == 0, "synthetic generator failed"
+    torch.cuda.synchronize()
+    qlen = d_qlen.cpu().numpy().astype(np.uint32)
+    tlen = np.full(n, L, dtype=np.uint32)
+    toff = np.arange(n, dtype=np.uint64) * np.uint64(stride)
+    qoff = (np.arange(n, dtype=np.uint64) + np.uint64(n)) * np.uint64(stride)
+
+    if args.workload == "align8":
+        par = B.make_params(mode, bw, *sc)
+        plan = B.AlignPlan(ctx, qoff, qlen, toff, tlen, par)
+    else:
+        plan = B.EditPlan(ctx, qoff, qlen, toff, tlen, mode, bw)
+    cells = plan.cells()
+    cig_cap = int(n) * max(L // 4, 64)
+    d_out = torch.zeros(n * 10, dtype=torch.int32, device=dev)
+    d_cig = torch.empty(cig_cap, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def step():
+        plan.run(d_seqs, d_out, d_cig, d_off, d_st)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        barrier()
+    kms, klaunch, kcells = ctx.last_kernel_ms()
+
+    out = d_out.cpu().numpy().reshape(n, 10)
+    off = d_off.cpu().numpy()
+    status = d_st.cpu().numpy()
+    ncig = int(off[n])
+    nbad = int((status != 0).sum())
+
+    if rank == 0:
+        import support as S
+        # parity spot check (outside the timed region): first pairs of the batch vs the oracle
+        ident = True
+        cig_host = d_cig[: int(off[8])].cpu().numpy().view(np.uint32) if n >= 8 else None
+        for k in range(min(8, n)):
+            q, t = S.synth_pair(k, L, err_q32=int(args.eps * 4294967296.0))
+            if args.workload == "align8":
+                res, cig, _ = S.oracle_align(q, t, mode, bw, *sc)
+            else:
+                res, cig, _ = S.oracle_edit(q, t, mode, bw)
+            ident &= bool(np.array_equal(out[k], res)) and bool(np.array_equal(cig_host[int(off[k]):int(off[k + 1])], cig))
+        # algorithmic bytes: 4-bit (8-bit path) / 2-bit (edit) traceback code per band cell +
+        # sequences at 1 B/base + result struct + CIGAR words
+        per_cell = 0.5 if args.workload == "align8" else 0.25
+        balg = per_cell * cells + float(qlen.sum()) + float(tlen.sum()) + 40.0 * n + 4.0 * ncig
+        achieved = (balg / max(klaunch, 1)) / (kms / 1e3) / 1e9 if kms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "%s_n%d_L%d_bw%d" % (args.workload, n, L, bw)
+                traffic = tj.get(key, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "GCUPS (giga band-cell updates / s), %s" % ("8-bit banded striped global alignment" if args.workload == "align8" else "2-bit striped edit alignment"),
+            "value": round(cells * args.steps * world / elapsed / 1e9, 3),
+            "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i8" if args.workload == "align8" else "u64-bitplanes",
+            "data": "synthetic (splitmix64 pairs, eps=%.2f, sub:ins:del=23:31:46, seed %d)" % (args.eps, SEED),
+            "config": {"workload": "%s: %d pairs/GPU x %d bp, mode global, bandwidth %d, scoring M,X,O,E,Q,P=%s" % (args.workload, n, L, bw, args.scoring),
+                       "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "forward DP (k_align8_fwd)" if args.workload == "align8" else "forward DP (k_edit_fwd)",
+                         "kernel_ms_avg": round(kms, 3), "launches_per_step": klaunch,
+                         "algorithmic_bytes_per_launch": round(balg / max(klaunch, 1), 1),
+                         "kernel_gcups": round(kcells / max(klaunch, 1) / (kms / 1e3) / 1e9, 2) if kms > 0 else None},
+            "checks": {"pairs_flagged": nbad, "cigar_words": ncig, "oracle_identical_first8": ident},
+        }
+        if world == 1 and args.cpu_pairs >= 0:
+            line["cpu_baseline"] = cpu_baseline(args, L, bw, sc, mode)
+        print(json.dumps(line), flush=True)
+    plan.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -253,3 +253,40 @@ class AlignPlan:
             self.close()
         except Exception:
             pass
+
+
+class EditPlan:
+    """bsa_edit_plan_create / bsa_edit_run (striped_seqedit_pairwise on the device)"""
+
+    def __init__(self, ctx, qoff, qlen, toff, tlen, mode=MODE_GLOBAL, bandwidth=0):
+        self.ctx = ctx
+        self.n = len(qlen)
+        self.qoff, self.qlen = _np(qoff, np.uint64), _np(qlen, np.uint32)
+        self.toff, self.tlen = _np(toff, np.uint64), _np(tlen, np.uint32)
+        self.par = EditParams()
+        self.par.mode, self.par.bandwidth = mode, bandwidth
+        h = C.c_void_p()
+        ctx._chk(lib().bsa_edit_plan_create(ctx.h, _p(self.qoff), _p(self.qlen), _p(self.toff), _p(self.tlen),
+                                            self.n, C.byref(self.par), C.byref(h)))
+        self.h = h
+
+    def cells(self):
+        return lib().bsa_edit_plan_cells(self.h)
+
+    def run(self, d_seqs, d_out, d_cigar=None, d_cigar_off=None, d_status=None):
+        cap = d_cigar.numel() if d_cigar is not None else 0
+        self.ctx._chk(lib().bsa_edit_run(self.h, C.c_void_p(d_seqs.data_ptr()), C.c_void_p(d_out.data_ptr()),
+                                         C.c_void_p(d_cigar.data_ptr() if d_cigar is not None else 0), cap,
+                                         C.c_void_p(d_cigar_off.data_ptr() if d_cigar_off is not None else 0),
+                                         C.c_void_p(d_status.data_ptr() if d_status is not None else 0)))
+
+    def close(self):
+        if self.h:
+            lib().bsa_edit_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

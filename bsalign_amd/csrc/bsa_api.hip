@@ -167,16 +167,15 @@ __global__ void __launch_bounds__(1024) k_excl_scan(const uint32_t *cnt, uint64_
 }
 
 // one wave per pair: copy the CIGAR words a traceback kernel left at the tail of the pair's row slot
-__global__ void __launch_bounds__(256) k_cigar_collect(const uint8_t *rows, const uint64_t *slot_off, const uint32_t *tlen,
-		const uint32_t *order, uint32_t rowb, uint32_t first, uint32_t count,
-		const uint32_t *cnt, const uint64_t *off, uint32_t *tmp, uint64_t cap){
+__global__ void __launch_bounds__(256) k_cigar_collect(const uint8_t *rows, const uint64_t *slot_end,
+		uint32_t first, uint32_t count, const uint32_t *cnt, const uint64_t *off, uint32_t *tmp, uint64_t cap){
 	const uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63;
 	if(g >= count) return;
-	const uint32_t ppos = first + g, pair = order[ppos];
+	const uint32_t ppos = first + g;
 	const uint32_t c = cnt[ppos];
 	const uint64_t o = off[ppos];
 	if(o + c > cap) return;
-	const uint32_t *src = (const uint32_t*)(rows + slot_off[ppos] + (size_t)(tlen[pair] + 3) * rowb) - c;
+	const uint32_t *src = (const uint32_t*)(rows + slot_end[ppos]) - c;
 	for(uint32_t i = lane; i < c; i += 64) tmp[o + i] = src[i];
 }
 
@@ -213,7 +212,7 @@ struct bsa_align_plan {
 	std::vector<Chunk> chunks;
 	size_t ws_need = 0;
 	// device metadata
-	uint64_t *d_qoff = nullptr, *d_toff = nullptr, *d_qpoff = nullptr, *d_tpoff = nullptr, *d_slot = nullptr;
+	uint64_t *d_qoff = nullptr, *d_toff = nullptr, *d_qpoff = nullptr, *d_tpoff = nullptr, *d_slot = nullptr, *d_slot_end = nullptr;
 	uint32_t *d_qlen = nullptr, *d_tlen = nullptr, *d_order = nullptr;
 	uint8_t *d_qst = nullptr, *d_tst = nullptr;
 	uint32_t *d_cnt_pos = nullptr, *d_cnt_pair = nullptr, *d_status_own = nullptr;
@@ -238,7 +237,7 @@ extern "C" void bsa_align_plan_destroy(bsa_align_plan_t *p){
 	if(!p) return;
 	(void)hipSetDevice(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
-	void *ptrs[] = { p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_qlen, p->d_tlen, p->d_order, p->d_qst, p->d_tst,
+	void *ptrs[] = { p->d_slot_end, p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_qlen, p->d_tlen, p->d_order, p->d_qst, p->d_tst,
 	                 p->d_cnt_pos, p->d_cnt_pair, p->d_status_own, p->d_off_pos, p->d_src_pair, p->d_carry, p->d_tmp };
 	for(void *q : ptrs) if(q) (void)hipFree(q);
 	delete p;
@@ -265,7 +264,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	std::vector<uint32_t> order(n);
 	for(size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return tlen[x] > tlen[y]; });
-	std::vector<uint64_t> qpoff(n), tpoff(n), slot(n);
+	std::vector<uint64_t> qpoff(n), tpoff(n), slot(n), slot_end(n);
 	size_t qacc = 0, tacc = 0;
 	double cells = 0;
 	for(size_t k = 0; k < n; k++){
@@ -285,7 +284,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 			p->ws_need = std::max(p->ws_need, acc);
 			first = (uint32_t)pos; acc = 0;
 		}
-		slot[pos] = acc; acc += need;
+		slot[pos] = acc; acc += need; slot_end[pos] = acc;
 	}
 	if(n > first){ p->chunks.push_back({first, (uint32_t)(n - first), acc}); p->ws_need = std::max(p->ws_need, acc); }
 	int rc;
@@ -295,7 +294,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	TRY(dev_upload(c, &p->d_qoff, vqoff)); TRY(dev_upload(c, &p->d_toff, vtoff));
 	TRY(dev_upload(c, &p->d_qlen, vqlen)); TRY(dev_upload(c, &p->d_tlen, vtlen));
 	TRY(dev_upload(c, &p->d_qpoff, qpoff)); TRY(dev_upload(c, &p->d_tpoff, tpoff));
-	TRY(dev_upload(c, &p->d_slot, slot)); TRY(dev_upload(c, &p->d_order, order));
+	TRY(dev_upload(c, &p->d_slot, slot)); TRY(dev_upload(c, &p->d_order, order)); TRY(dev_upload(c, &p->d_slot_end, slot_end));
 	TRY(dev_alloc(c, &p->d_qst, p->qst_bytes)); TRY(dev_alloc(c, &p->d_tst, p->tst_bytes));
 	TRY(dev_alloc(c, &p->d_cnt_pos, n)); TRY(dev_alloc(c, &p->d_cnt_pair, n)); TRY(dev_alloc(c, &p->d_status_own, n));
 	TRY(dev_alloc(c, &p->d_off_pos, n + 1)); TRY(dev_alloc(c, &p->d_src_pair, n)); TRY(dev_alloc(c, &p->d_carry, 1));
@@ -356,8 +355,8 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		if(want_cig){
 			hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry);
 			HIPCHK(c, hipGetLastError());
-			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, st, c->ws, p->d_slot, p->d_tlen, p->d_order,
-				p->rowb, ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
+			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, st, c->ws, p->d_slot_end,
+				ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
 			HIPCHK(c, hipGetLastError());
 		}
 	}
@@ -442,5 +441,221 @@ extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *c, hipStream_t *st){
 	if(!c || !st) return BSA_E_ARG;
 	(void)hipSetDevice(c->device);
 	*st = c->stream;
+	return BSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2-bit edit alignment plan (striped_seqedit_pairwise, bsalign.h:1046)
+// ------------------------------------------------------------------------------------------------
+struct EChunk { uint32_t first, count, bw; size_t bytes; };
+
+struct bsa_edit_plan {
+	bsa_ctx *ctx = nullptr;
+	size_t n = 0;
+	bsa_edit_params_t par;
+	double cells = 0;
+	std::vector<EChunk> chunks;
+	size_t ws_need = 0;
+	uint32_t pad_rows = 4;
+	uint64_t *d_qoff = nullptr, *d_toff = nullptr, *d_qpoff = nullptr, *d_tpoff = nullptr, *d_slot = nullptr, *d_slot_end = nullptr, *d_qboff = nullptr;
+	uint32_t *d_qlen = nullptr, *d_tlen = nullptr, *d_order = nullptr, *d_qwords = nullptr;
+	uint8_t *d_qst = nullptr, *d_tst = nullptr;
+	uint64_t *d_qbits = nullptr;
+	int32_t *d_sbeg = nullptr;
+	uint32_t *d_cnt_pos = nullptr, *d_cnt_pair = nullptr, *d_status_own = nullptr;
+	uint64_t *d_off_pos = nullptr, *d_src_pair = nullptr, *d_carry = nullptr;
+	uint32_t *d_tmp = nullptr; size_t tmp_words = 0;
+};
+
+// effective bandwidth of one pair (bsalign.h:1055-1067)
+static uint32_t edit_bw_eff(uint32_t qlen, uint32_t tlen, int type, uint32_t bandwidth){
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+	if(type == BSA_MODE_OVERLAP || type == BSA_MODE_EXTEND) return qround;
+	uint32_t bw = (bandwidth + 63u) / 64u * 64u;
+	if(bw == 0 || bw > qlen) bw = qround;
+	if(bw < qlen){
+		const uint32_t step = (qlen + tlen - 1) / tlen + 1;
+		if(bw < step) bw = (step + 63u) / 64u * 64u;
+	}
+	return bw;
+}
+
+extern "C" void bsa_edit_plan_destroy(bsa_edit_plan_t *p){
+	if(!p) return;
+	(void)hipSetDevice(p->ctx->device);
+	(void)hipStreamSynchronize(p->ctx->stream);
+	void *ptrs[] = { p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_slot_end, p->d_qboff, p->d_qlen, p->d_tlen, p->d_order,
+	                 p->d_qwords, p->d_qst, p->d_tst, p->d_qbits, p->d_sbeg, p->d_cnt_pos, p->d_cnt_pair, p->d_status_own,
+	                 p->d_off_pos, p->d_src_pair, p->d_carry, p->d_tmp };
+	for(void *q : ptrs) if(q) (void)hipFree(q);
+	delete p;
+}
+
+extern "C" double bsa_edit_plan_cells(const bsa_edit_plan_t *p){ return p ? p->cells : 0.0; }
+
+extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const uint32_t *qlen,
+		const uint64_t *toff, const uint32_t *tlen, size_t n, const bsa_edit_params_t *par, bsa_edit_plan_t **out){
+	if(!c || !out || !par || (n && (!qoff || !qlen || !toff || !tlen))) return BSA_E_ARG;
+	*out = nullptr;
+	if(n > 0xFFFFFFF0ull){ c->err = "too many pairs"; return BSA_E_ARG; }
+	const int type = par->mode & 3;
+	if(type != BSA_MODE_GLOBAL && type != BSA_MODE_OVERLAP && type != BSA_MODE_EXTEND){ c->err = "bad mode"; return BSA_E_ARG; }
+	(void)hipSetDevice(c->device);
+	bsa_edit_plan *p = new bsa_edit_plan();
+	p->ctx = c; p->n = n; p->par = *par;
+	std::vector<uint32_t> bwv(n), order(n), qwords(n);
+	double cells = 0;
+	for(size_t k = 0; k < n; k++){
+		bwv[k] = (qlen[k] && tlen[k]) ? edit_bw_eff(qlen[k], tlen[k], type, par->bandwidth) : 64u;
+		if(!bsa_edit_supported_bw(bwv[k])){
+			c->err = "effective edit bandwidth must be <= 1024 on the device for now (overlap/extend use the full query width)";
+			delete p; return BSA_E_UNSUPPORTED;
+		}
+		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bwv[k];
+		order[k] = (uint32_t)k;
+	}
+	p->cells = cells;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return bwv[x] != bwv[y] ? bwv[x] < bwv[y] : tlen[x] > tlen[y]; });
+	std::vector<uint64_t> qpoff(n), tpoff(n), qboff(n), slot(n), slot_end(n);
+	size_t qacc = 0, tacc = 0, bacc = 0;
+	for(size_t k = 0; k < n; k++){
+		qpoff[k] = qacc; qacc += ((size_t)qlen[k] + 16 + 15) & ~(size_t)15;
+		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + 16 + 15) & ~(size_t)15;
+		qwords[k] = (qlen[k] + bwv[k]) / 64u + 4u;
+		qboff[k] = bacc; bacc += 2 * (size_t)qwords[k];
+	}
+	const size_t budget = ctx_ws_budget(c);
+	size_t acc = 0; uint32_t first = 0;
+	for(size_t pos = 0; pos < n; pos++){
+		const uint32_t k = order[pos];
+		const size_t need = ((size_t)tlen[k] + 1 + p->pad_rows) * (size_t)(bwv[k] / 64u) * 16;
+		if(need > budget){ c->err = "workspace limit too small for one pair"; delete p; return BSA_E_NOMEM; }
+		if(pos > first && (acc + need > budget || bwv[k] != bwv[order[first]])){
+			p->chunks.push_back({first, (uint32_t)(pos - first), bwv[order[first]], acc});
+			p->ws_need = std::max(p->ws_need, acc);
+			first = (uint32_t)pos; acc = 0;
+		}
+		slot[pos] = acc; acc += need; slot_end[pos] = acc;
+	}
+	if(n > first){ p->chunks.push_back({first, (uint32_t)(n - first), bwv[order[first]], acc}); p->ws_need = std::max(p->ws_need, acc); }
+	int rc;
+	std::vector<uint64_t> vqoff(qoff, qoff + n), vtoff(toff, toff + n);
+	std::vector<uint32_t> vqlen(qlen, qlen + n), vtlen(tlen, tlen + n);
+#define TRY(x) do { rc = (x); if(rc != BSA_OK){ bsa_edit_plan_destroy(p); return rc; } } while(0)
+	TRY(dev_upload(c, &p->d_qoff, vqoff)); TRY(dev_upload(c, &p->d_toff, vtoff));
+	TRY(dev_upload(c, &p->d_qlen, vqlen)); TRY(dev_upload(c, &p->d_tlen, vtlen));
+	TRY(dev_upload(c, &p->d_qpoff, qpoff)); TRY(dev_upload(c, &p->d_tpoff, tpoff)); TRY(dev_upload(c, &p->d_qboff, qboff));
+	TRY(dev_upload(c, &p->d_qwords, qwords));
+	TRY(dev_upload(c, &p->d_slot, slot)); TRY(dev_upload(c, &p->d_slot_end, slot_end)); TRY(dev_upload(c, &p->d_order, order));
+	TRY(dev_alloc(c, &p->d_qst, qacc)); TRY(dev_alloc(c, &p->d_tst, tacc)); TRY(dev_alloc(c, &p->d_qbits, bacc));
+	TRY(dev_alloc(c, &p->d_sbeg, n));
+	TRY(dev_alloc(c, &p->d_cnt_pos, n)); TRY(dev_alloc(c, &p->d_cnt_pair, n)); TRY(dev_alloc(c, &p->d_status_own, n));
+	TRY(dev_alloc(c, &p->d_off_pos, n + 1)); TRY(dev_alloc(c, &p->d_src_pair, n)); TRY(dev_alloc(c, &p->d_carry, 1));
+	TRY(ctx_ws_reserve(c, p->ws_need));
+#undef TRY
+	*out = p;
+	return BSA_OK;
+}
+
+extern "C" int bsa_edit_run(bsa_edit_plan_t *p, const uint8_t *d_seqs, bsa_result_t *d_out, uint32_t *d_cigar,
+		size_t cigar_cap_words, uint64_t *d_cigar_off, uint32_t *d_status){
+	if(!p || !d_out) return BSA_E_ARG;
+	bsa_ctx *c = p->ctx;
+	(void)hipSetDevice(c->device);
+	hipStream_t st = c->stream;
+	const uint32_t n = (uint32_t)p->n;
+	c->ev_used = 0; c->last_cells = 0;
+	if(n == 0){
+		if(d_cigar_off) HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t), st));
+		return BSA_OK;
+	}
+	if(!d_seqs) return BSA_E_ARG;
+	int rc = ctx_ws_reserve(c, p->ws_need);
+	if(rc != BSA_OK) return rc;
+	const bool want_cig = d_cigar != nullptr && d_cigar_off != nullptr;
+	if(want_cig && p->tmp_words < cigar_cap_words){
+		if(p->d_tmp){ HIPCHK(c, hipStreamSynchronize(st)); (void)hipFree(p->d_tmp); p->d_tmp = nullptr; }
+		if(hipMalloc((void**)&p->d_tmp, std::max<size_t>(cigar_cap_words, 1) * 4) != hipSuccess){ c->err = "cigar staging allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
+		p->tmp_words = cigar_cap_words;
+	}
+	uint32_t *status = d_status ? d_status : p->d_status_own;
+	HIPCHK(c, bsa_launch_edit_stage(d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen, p->d_qpoff, p->d_tpoff, p->d_qboff, p->d_qwords,
+		p->d_qst, p->d_tst, p->d_qbits, status, n, st));
+	HIPCHK(c, hipMemsetAsync(p->d_carry, 0, sizeof(uint64_t), st));
+	EditArgs a;
+	memset(&a, 0, sizeof(a));
+	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
+	a.qbits = p->d_qbits; a.qboff = p->d_qboff; a.qwords = p->d_qwords;
+	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
+	a.rows = c->ws; a.status = status; a.fwd_sbeg = p->d_sbeg; a.pad_rows = p->pad_rows; a.mode = p->par.mode;
+	for(const EChunk &ch : p->chunks){
+		a.first = ch.first; a.count = ch.count; a.bw = ch.bw;
+		hipEvent_t e0, e1;
+		rc = ctx_event_pair(c, &e0, &e1); if(rc != BSA_OK) return rc;
+		HIPCHK(c, hipEventRecord(e0, st));
+		HIPCHK(c, bsa_launch_edit_fwd(a, st));
+		HIPCHK(c, hipEventRecord(e1, st));
+		HIPCHK(c, bsa_launch_edit_trace(a, d_out, p->d_cnt_pos, st));
+		if(want_cig){
+			hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry);
+			HIPCHK(c, hipGetLastError());
+			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, st, c->ws, p->d_slot_end,
+				ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
+			HIPCHK(c, hipGetLastError());
+		}
+	}
+	c->last_cells = p->cells;
+	if(want_cig){
+		hipLaunchKernelGGL(k_cnt_by_pair, dim3((n + 255) / 256), dim3(256), 0, st, p->d_order, p->d_cnt_pos, p->d_off_pos, p->d_cnt_pair, p->d_src_pair, n);
+		HIPCHK(c, hipGetLastError());
+		hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pair, d_cigar_off, n, (uint64_t*)nullptr);
+		HIPCHK(c, hipGetLastError());
+		hipLaunchKernelGGL(k_cigar_final, dim3((n + 3) / 4), dim3(256), 0, st, p->d_tmp, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
+		HIPCHK(c, hipGetLastError());
+	} else if(d_cigar_off){
+		HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t) * ((size_t)n + 1), st));
+	}
+	return BSA_OK;
+}
+
+extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_bytes,
+		const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen, size_t n,
+		const bsa_edit_params_t *par, bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words,
+		uint64_t *cigar_off, uint32_t *status){
+	if(!c || !out || !par) return BSA_E_ARG;
+	if(n == 0){ if(cigar_off) cigar_off[0] = 0; return BSA_OK; }
+	if(!seqs) return BSA_E_ARG;
+	(void)hipSetDevice(c->device);
+	bsa_edit_plan_t *p = nullptr;
+	int rc = bsa_edit_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
+	if(rc != BSA_OK) return rc;
+	uint8_t *d_seqs = nullptr; bsa_result_t *d_out = nullptr; uint32_t *d_cig = nullptr, *d_status = nullptr; uint64_t *d_off = nullptr;
+	auto cleanup = [&](){
+		if(d_seqs) (void)hipFree(d_seqs); if(d_out) (void)hipFree(d_out); if(d_cig) (void)hipFree(d_cig);
+		if(d_status) (void)hipFree(d_status); if(d_off) (void)hipFree(d_off);
+		bsa_edit_plan_destroy(p);
+	};
+	const bool want_cig = cigar && cigar_off;
+#define TRYH(call) do { hipError_t _e = (call); if(_e != hipSuccess){ c->err = std::string(#call) + ": " + hipGetErrorString(_e); cleanup(); return BSA_E_HIP; } } while(0)
+	TRYH(hipMalloc((void**)&d_seqs, std::max<size_t>(seqs_bytes, 1)));
+	TRYH(hipMalloc((void**)&d_out, n * sizeof(bsa_result_t)));
+	TRYH(hipMalloc((void**)&d_status, n * sizeof(uint32_t)));
+	if(want_cig){
+		TRYH(hipMalloc((void**)&d_cig, std::max<size_t>(cigar_cap_words, 1) * 4));
+		TRYH(hipMalloc((void**)&d_off, (n + 1) * sizeof(uint64_t)));
+	}
+	TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+	rc = bsa_edit_run(p, d_seqs, d_out, d_cig, cigar_cap_words, d_off, d_status);
+	if(rc != BSA_OK){ cleanup(); return rc; }
+	TRYH(hipMemcpyAsync(out, d_out, n * sizeof(bsa_result_t), hipMemcpyDeviceToHost, c->stream));
+	if(status) TRYH(hipMemcpyAsync(status, d_status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	if(want_cig) TRYH(hipMemcpyAsync(cigar_off, d_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	TRYH(hipStreamSynchronize(c->stream));
+	if(want_cig){
+		if(cigar_off[n] > cigar_cap_words){ cleanup(); c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
+		TRYH(hipMemcpy(cigar, d_cig, cigar_off[n] * 4, hipMemcpyDeviceToHost));
+	}
+#undef TRYH
+	cleanup();
 	return BSA_OK;
 }

@@ -50,7 +50,32 @@ static inline __host__ __device__ int bsa_get_piecewise(int gapo1, int gape1, in
 	return gapo1 ? 1 : 0;
 }
 
+// device-side description of one batch chunk of the 2-bit edit path
+struct EditArgs {
+	const uint8_t  *qst, *tst;      // staged query / target bytes (codes 0..3)
+	const uint64_t *qpoff, *tpoff;  // [n]
+	const uint64_t *qbits;          // staged query bit planes: plane0 then plane1, qwords[k] words each
+	const uint64_t *qboff;          // [n] word offset of pair's plane0
+	const uint32_t *qwords;         // [n]
+	const uint32_t *qlen, *tlen;    // [n]
+	const uint32_t *order;          // [n]
+	const uint64_t *slot_off;       // [n] by processing position
+	uint8_t        *rows;
+	uint32_t       *status;         // [n] per original pair
+	int32_t        *fwd_sbeg;       // [n] by processing position: H at the band start of the last row
+	uint32_t first, count;
+	uint32_t bw;                    // effective bandwidth of this launch (multiple of 64)
+	uint32_t pad_rows;              // spare row records at the end of every slot (CIGAR scratch)
+	int32_t  mode;
+};
+
 // launchers implemented in the kernel translation units
 hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st);
 hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);
 bool bsa_align8_supported_bw(uint32_t bw);
+bool bsa_edit_supported_bw(uint32_t bw);
+hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
+		const uint64_t *qpoff, const uint64_t *tpoff, const uint64_t *qboff, const uint32_t *qwords,
+		uint8_t *qst, uint8_t *tst, uint64_t *qbits, uint32_t *status, uint32_t n, hipStream_t st);
+hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st);
+hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);

@@ -1,0 +1,344 @@
+// bsa_edit.hip -- 2-bit bit-parallel edit-distance pairwise DP on gfx950 (MI355X).
+//
+// Replaces striped_seqedit_pairwise and its helpers (/root/reference/bsalign.h):
+//   _set_query_prof :612   _row_init :653   _row_movx :658   _row_cal :766   _rowmin :813
+//   _backtrace :965        _pairwise :1046 (band rules :1055-1067, fixed diagonal band :1112-1114,
+//   score by popcount :1189-1203)
+//
+// The reference keeps per row two 64-bit planes of u(p) = H(p,y) - H(p-1,y) in {-1,0,+1} (plane0 bit <=>
+// u = -1, plane1 bit <=> u = +1) in Farrar-striped order and iterates the row to a fix-point.  That
+// recurrence is exact integer arithmetic (no saturation), so any correct evaluation yields the same
+// planes; here the band lives in NATURAL bit order (band position p = bit p%64 of word p/64) and one row
+// step is the Myers/Hyyro block update with the carry (horizontal delta) chained across the W words:
+//     Xv = Eq | Mv;  Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;  Ph = Mv | ~(Xh | Pv);  Mh = Pv & Xh;  ...
+// with Pv = plane1 (u = +1), Mv = plane0 (u = -1), Ph/Mh = the reference's v.  Boundary rules follow the
+// reference exactly: left of the band v = +1 (0 in overlap mode, bsalign.h:770), cells shifted in on the
+// right get u = +1 (:683-718), sbeg tracks H at the band start (:667-676).
+//
+// Mapping: one pair per lane (64 pairs per wave), all state in VGPRs, no cross-lane traffic; the kernel is
+// HBM-bound: per row and pair it writes the two planes (W*16 bytes = 2 bits per band cell), nothing else.
+#include "bsa_common.h"
+
+typedef uint64_t u64;
+
+static __device__ __forceinline__ u64 fsr(u64 lo, u64 hi, uint32_t m){   // (hi:lo) >> m, low 64 bits, m in [0,64]
+	if(m == 0) return lo;
+	if(m >= 64) return hi;
+	return (lo >> m) | (hi << (64 - m));
+}
+static __device__ __forceinline__ u64 lowmask(uint32_t n){ return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+// row records: row r (r = 0 is the initial row, r = i+1 the row of target base i): [plane0: NW u64][plane1: NW u64]
+template<int NW>
+__global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a){
+	constexpr uint32_t BW = NW * 64;
+	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	if(g >= a.count) return;
+	const uint32_t ppos = a.first + g, pair = a.order[ppos];
+	if(a.status[pair] != 0u) return;
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const u64 *Q0m = a.qbits + a.qboff[pair];
+	const u64 *Q1m = Q0m + a.qwords[pair];
+	const uint8_t *tp = a.tst + a.tpoff[pair];
+	u64 *rows = (u64*)(a.rows + a.slot_off[ppos]);
+	const int type = a.mode & 3;
+	const bool overlap = type == BSA_MODE_OVERLAP;
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+
+	u64 Pv[NW], Mv[NW], Q0[NW], Q1[NW];
+	u64 l0c, l0n, l1c, l1n;      // look-ahead of the query planes: next position to shift in = lword*64 + lbit
+	uint32_t lword, lbit;
+	auto load_window = [&](uint32_t rb){
+		const uint32_t w0 = rb >> 6, sh = rb & 63u;
+#pragma unroll
+		for(int k = 0; k < NW; k++){
+			Q0[k] = fsr(Q0m[w0 + k], Q0m[w0 + k + 1], sh);
+			Q1[k] = fsr(Q1m[w0 + k], Q1m[w0 + k + 1], sh);
+		}
+		const uint32_t lp = rb + BW;
+		lword = lp >> 6; lbit = lp & 63u;
+		l0c = Q0m[lword]; l0n = Q0m[lword + 1]; l1c = Q1m[lword]; l1n = Q1m[lword + 1];
+	};
+#pragma unroll
+	for(int k = 0; k < NW; k++){ Pv[k] = ~0ull; Mv[k] = 0ull; rows[k] = 0ull; rows[NW + k] = ~0ull; }   // row_init (:653-656)
+	load_window(0);
+	int sbeg = 0;
+	uint32_t rb0 = 0;
+	// i*qlen/tlen kept incrementally: quo = floor(i*qlen/tlen), rem = (i*qlen) % tlen
+	u64 quo = 0, rem = 0;
+	const u64 qstep = qlen / tlen, rstep = qlen % tlen;
+	u64 tw = 0;   // 8 target bases at a time
+	for(uint32_t i = 0; i < tlen; i++){
+		if((i & 7u) == 0){ tw = 0; __builtin_memcpy(&tw, tp + i, 8); }   // staged with >= 8 bytes of padding
+		const uint32_t tb = (uint32_t)(tw >> (8u * (i & 7u))) & 3u;
+		uint32_t rb1;
+		if(type != BSA_MODE_GLOBAL) rb1 = 0;
+		else {      // fixed diagonal band (:1112-1114)
+			uint32_t c = (uint32_t)quo;
+			c = (c < BW / 2) ? 0u : c - BW / 2;
+			rb1 = (c + BW > qround) ? qround - BW : c;
+		}
+		uint32_t movx = rb1 - rb0;
+		// ---- row_movx (:658-721)
+		if(overlap) sbeg = 0;
+		else if(movx >= BW){
+			int s = 0;
+#pragma unroll
+			for(int k = 0; k < NW; k++){ s += __popcll(Pv[k]) - __popcll(Mv[k]); Pv[k] = ~0ull; Mv[k] = 0ull; }
+			sbeg += s + 1;
+			load_window(rb1);
+		} else {
+			while(movx){
+				const uint32_t m = movx < 64u ? movx : 64u;
+				const u64 mk = lowmask(m);
+				sbeg += __popcll(Pv[0] & mk) - __popcll(Mv[0] & mk);
+				const u64 n0 = fsr(l0c, l0n, lbit), n1 = fsr(l1c, l1n, lbit);
+#pragma unroll
+				for(int k = 0; k < NW; k++){
+					Pv[k] = fsr(Pv[k], (k + 1 < NW) ? Pv[k + 1] : ~0ull, m);
+					Mv[k] = fsr(Mv[k], (k + 1 < NW) ? Mv[k + 1] : 0ull, m);
+					Q0[k] = fsr(Q0[k], (k + 1 < NW) ? Q0[k + 1] : n0, m);
+					Q1[k] = fsr(Q1[k], (k + 1 < NW) ? Q1[k + 1] : n1, m);
+				}
+				lbit += m;
+				if(lbit >= 64u){
+					lbit -= 64u; lword++;
+					l0c = l0n; l1c = l1n;
+					l0n = Q0m[lword + 1]; l1n = Q1m[lword + 1];
+				}
+				movx -= m;
+			}
+			sbeg++;
+		}
+		// ---- row_cal (:766-810) as a chained Myers block update
+		const u64 x0 = (tb & 1u) ? 0ull : ~0ull, x1 = (tb & 2u) ? 0ull : ~0ull;
+		const uint32_t nvalid = (rb1 < qlen) ? qlen - rb1 : 0u;      // band cells that are real query columns
+		int hin = overlap ? 0 : 1;
+#pragma unroll
+		for(int k = 0; k < NW; k++){
+			u64 Eq = (Q0[k] ^ x0) & (Q1[k] ^ x1);
+			if(nvalid < BW){ const uint32_t lo = (uint32_t)k * 64u; Eq &= (nvalid > lo) ? lowmask(nvalid - lo) : 0ull; }
+			const u64 pv = Pv[k], mv = Mv[k];
+			const u64 hneg = (hin < 0) ? 1ull : 0ull, hpos = (hin > 0) ? 1ull : 0ull;
+			const u64 Xv = Eq | mv;
+			const u64 Eq2 = Eq | hneg;
+			const u64 Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
+			u64 Ph = mv | ~(Xh | pv);
+			u64 Mh = pv & Xh;
+			hin = (int)(Ph >> 63) - (int)(Mh >> 63);
+			Ph = (Ph << 1) | hpos;
+			Mh = (Mh << 1) | hneg;
+			Pv[k] = Mh | ~(Xv | Ph);
+			Mv[k] = Ph & Xv;
+		}
+		u64 *rp = rows + (size_t)(i + 1) * (2 * NW);
+#pragma unroll
+		for(int k = 0; k < NW; k++){ rp[k] = Mv[k]; rp[NW + k] = Pv[k]; }
+		// per-row score at the last query column (overlap / extend, :1124-1139) is evaluated by the traceback kernel
+		rb0 = rb1;
+		quo += qstep; rem += rstep;
+		if(rem >= tlen){ rem -= tlen; quo++; }
+	}
+	// H at the band start of the last row; the traceback kernel derives the scores from it
+	a.fwd_sbeg[ppos] = sbeg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// traceback (bsalign.h:965-1044) + end-cell / score selection of the driver (:1124-1139, 1180-1203)
+// one pair per lane
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt){
+	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	if(g >= a.count) return;
+	const uint32_t ppos = a.first + g, pair = a.order[ppos];
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	if(a.status[pair] != 0u){ out[pair] = rs; cig_cnt[ppos] = 0; return; }
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint32_t NW = a.bw / 64u, BW = a.bw;
+	const uint8_t *qs = a.qst + a.qpoff[pair];
+	const uint8_t *ts = a.tst + a.tpoff[pair];
+	const u64 *rows = (const u64*)(a.rows + a.slot_off[ppos]);
+	const int type = a.mode & 3;
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+	auto plane_bit = [&](uint32_t row, int plane, long pos) -> int {
+		// striped_seqedit_getval (:224) on `x - begs[..]`, which is UNSIGNED 32-bit arithmetic in the reference and whose
+		// shift count x86 masks to 6 bits: striped word pos%W, bit (pos/W)&63  <=>  natural position below
+		const uint32_t pu = (uint32_t)pos;
+		const uint32_t p = ((pu / NW) & 63u) * NW + (pu % NW);
+		return (int)((rows[(size_t)row * (2 * NW) + (size_t)plane * NW + (p >> 6)] >> (p & 63u)) & 1ull);
+	};
+	auto beg_of_row = [&](uint32_t r) -> uint32_t {    // begs[r]: r = 0 -> 0, r = i+1 -> band offset of target row i
+		if(r == 0 || type != BSA_MODE_GLOBAL) return 0u;
+		uint32_t c = (uint32_t)(((u64)(r - 1) * qlen) / tlen);
+		c = (c < BW / 2) ? 0u : c - BW / 2;
+		return (c + BW > qround) ? qround - BW : c;
+	};
+	int rx = (int)qlen - 1, ry = (int)tlen - 1, smin = 0x7FFFFFFF;
+	const int sbeg_last = a.fwd_sbeg[ppos];
+	int score = 0;
+	if(type == BSA_MODE_GLOBAL){
+		const uint32_t rbl = beg_of_row(tlen);
+		const u64 *lr = rows + (size_t)tlen * (2 * NW);
+		score = sbeg_last;
+		for(uint32_t k = 0; k < NW; k++) score += __popcll(lr[NW + k]) - __popcll(lr[k]);
+		for(uint32_t k = rbl + BW; k > qlen; k--){
+			score += plane_bit(tlen, 0, (long)(k - 1 - rbl)) - plane_bit(tlen, 1, (long)(k - 1 - rbl));
+		}
+	} else {
+		// full band, rbeg == 0: H(qlen-1, i) per row, then (extend) the first strict minimum of the last row
+		for(uint32_t i = 0; i < tlen; i++){
+			const u64 *lr = rows + (size_t)(i + 1) * (2 * NW);
+			int srow = (type == BSA_MODE_OVERLAP) ? 0 : (int)(i + 1);
+			for(uint32_t k = 0; k < NW; k++){
+				u64 mk = (qlen >= (k + 1) * 64u) ? ~0ull : ((qlen > k * 64u) ? lowmask(qlen - k * 64u) : 0ull);
+				srow += __popcll(lr[NW + k] & mk) - __popcll(lr[k] & mk);
+			}
+			if(srow < smin){ smin = srow; rx = (int)qlen - 1; ry = (int)i; }
+		}
+		if(type == BSA_MODE_EXTEND){     // striped_seqedit_rowmin (:813-963)
+			const u64 *lr = rows + (size_t)tlen * (2 * NW);
+			int sc = (int)tlen, best = sc; uint32_t pmin = 0;
+			for(uint32_t p = 0; p < BW; p++){
+				sc += (int)((lr[NW + (p >> 6)] >> (p & 63u)) & 1ull) - (int)((lr[p >> 6] >> (p & 63u)) & 1ull);
+				if(sc < best){ best = sc; pmin = p; }
+			}
+			if(best < smin){ smin = best; rx = (int)pmin; ry = (int)tlen - 1; }
+		}
+	}
+	// ---- backtrace
+	uint32_t *cig_end = (uint32_t*)((uint8_t*)rows + (size_t)(tlen + 1 + a.pad_rows) * (2 * NW) * 8);
+	uint32_t ncig = 0, cg = 0, op = 0;
+	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
+	int x = rx, y = ry;
+	bool bad = (rx >= (int)qlen);
+	rs.qe = x + 1; rs.te = y + 1;
+	// begs[y+1], begs[y] kept incrementally (y only ever decreases by one): (bq, br) = divmod((y-1)*qlen, tlen)
+	uint32_t b1 = beg_of_row((uint32_t)y + 1u), b0 = beg_of_row((uint32_t)y);
+	const u64 qstep = qlen / tlen, rstep = qlen % tlen;
+	u64 bq = 0, br = 0;
+	if(y >= 1){ const u64 pr = (u64)(y - 1) * qlen; bq = pr / tlen; br = pr % tlen; }
+	int cached_y = y;
+	while(!bad && x >= 0 && y >= 0){
+		if(y != cached_y){
+			b1 = b0; cached_y = y;
+			if(y >= 1 && type == BSA_MODE_GLOBAL){
+				bq -= qstep;
+				if(br < rstep){ br += tlen; bq--; }
+				br -= rstep;
+				uint32_t c = (uint32_t)bq;
+				c = (c < BW / 2) ? 0u : c - BW / 2;
+				b0 = (c + BW > qround) ? qround - BW : c;
+			} else b0 = 0;
+		}
+		if(qs[x] == ts[y]){ rs.mat++; op = 0; x--; y--; }
+		else {
+			const long p1 = (long)x - (long)b1;
+			const int u3 = plane_bit((uint32_t)y + 1u, 0, p1), u4 = plane_bit((uint32_t)y + 1u, 1, p1);
+			if(u3 == 0 && u4 == 1){ rs.ins++; op = 1; x--; }
+			else {
+				const long p0 = (long)x - (long)b0;
+				const int u1 = plane_bit((uint32_t)y, 0, p0), u2 = plane_bit((uint32_t)y, 1, p0);
+				if(u1 == 1 && u2 == 0){ rs.del++; op = 2; y--; }
+				else { rs.mis++; op = 0; x--; y--; }
+			}
+		}
+		if(op == (cg & 0xf)) cg += 0x10;
+		else { if(cg) cig_push(cg); cg = 0x10 | op; }
+	}
+	if(!bad){
+		rs.qb = x + 1; rs.tb = y + 1;
+		if(rs.qb){
+			op = 1;
+			if(op == (cg & 0xf)) cg += 0x10u * (uint32_t)rs.qb;
+			else { if(cg) cig_push(cg); cg = (0x10u * (uint32_t)rs.qb) | op; }
+			rs.ins += rs.qb; rs.qb = 0;
+		}
+		if((type == BSA_MODE_GLOBAL || type == BSA_MODE_EXTEND) && rs.tb){
+			op = 2;
+			if(op == (cg & 0xf)) cg += 0x10u * (uint32_t)rs.tb;
+			else { if(cg) cig_push(cg); cg = (0x10u * (uint32_t)rs.tb) | op; }
+			rs.del += rs.tb; rs.tb = 0;
+		}
+		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
+		if(cg) cig_push(cg);
+		if(type == BSA_MODE_OVERLAP) rs.score = smin + rs.te - rs.tb;
+		else if(type == BSA_MODE_EXTEND) rs.score = smin;
+		else rs.score = score;
+	} else {
+		atomicOr(&a.status[pair], BSA_ST_TRACE);
+		rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+		ncig = 0;
+	}
+	out[pair] = rs;
+	cig_cnt[ppos] = ncig;
+}
+
+// stage one pair per block: query -> two bit planes (bit p of plane b = bit b of base p; zero beyond qlen),
+// query and target bytes copied (the traceback compares bases), codes validated
+__global__ void __launch_bounds__(256) k_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
+		const uint64_t *toff, const uint32_t *tlen, const uint64_t *qpoff, const uint64_t *tpoff,
+		const uint64_t *qboff, const uint32_t *qwords, uint8_t *qst, uint8_t *tst, u64 *qbits, uint32_t *status, uint32_t n){
+	const uint32_t k = blockIdx.x;
+	if(k >= n) return;
+	const uint32_t ql = qlen[k], tl = tlen[k], nw = qwords[k];
+	const uint8_t *q = seqs + qoff[k], *t = seqs + toff[k];
+	uint8_t *dq = qst + qpoff[k], *dt = tst + tpoff[k];
+	u64 *p0 = qbits + qboff[k], *p1 = p0 + nw;
+	uint32_t bad = 0;
+	for(uint32_t w = threadIdx.x; w < nw; w += 256){
+		u64 b0 = 0, b1 = 0;
+		for(uint32_t b = 0; b < 64; b++){
+			uint32_t i = w * 64u + b;
+			if(i < ql){
+				uint8_t c = q[i];
+				if(c > 3){ bad = 1; c &= 3; }
+				b0 |= (u64)(c & 1u) << b;
+				b1 |= (u64)((c >> 1) & 1u) << b;
+			}
+		}
+		p0[w] = b0; p1[w] = b1;
+	}
+	for(uint32_t i = threadIdx.x; i < ql + 16; i += 256) dq[i] = (i < ql) ? (uint8_t)(q[i] & 3) : (uint8_t)0;
+	for(uint32_t i = threadIdx.x; i < tl + 16; i += 256){
+		uint8_t c = (i < tl) ? t[i] : (uint8_t)0;
+		if(c > 3){ bad = 1; c &= 3; }
+		dt[i] = c;
+	}
+	uint32_t st = 0;
+	if(__syncthreads_or((int)bad)) st |= BSA_ST_BAD_BASE;
+	if(ql == 0 || tl == 0) st |= BSA_ST_EMPTY;
+	if(threadIdx.x == 0) status[k] = st;
+}
+
+bool bsa_edit_supported_bw(uint32_t bw){
+	return bw >= 64 && (bw % 64) == 0 && bw / 64 <= 16;
+}
+
+hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
+		const uint64_t *qpoff, const uint64_t *tpoff, const uint64_t *qboff, const uint32_t *qwords,
+		uint8_t *qst, uint8_t *tst, uint64_t *qbits, uint32_t *status, uint32_t n, hipStream_t st){
+	if(n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_edit_stage, dim3(n), dim3(256), 0, st, seqs, qoff, qlen, toff, tlen, qpoff, tpoff, qboff, qwords, qst, tst, (u64*)qbits, status, n);
+	return hipGetLastError();
+}
+
+hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
+	const uint32_t blocks = (a.count + 63) / 64;
+	if(blocks == 0) return hipSuccess;
+#define EDIT_CASE(N) case N: hipLaunchKernelGGL((k_edit_fwd<N>), dim3(blocks), dim3(64), 0, st, a); break;
+	switch(a.bw / 64){
+		EDIT_CASE(1) EDIT_CASE(2) EDIT_CASE(3) EDIT_CASE(4) EDIT_CASE(5) EDIT_CASE(6) EDIT_CASE(7) EDIT_CASE(8)
+		EDIT_CASE(9) EDIT_CASE(10) EDIT_CASE(11) EDIT_CASE(12) EDIT_CASE(13) EDIT_CASE(14) EDIT_CASE(15) EDIT_CASE(16)
+		default: return hipErrorInvalidValue;
+	}
+#undef EDIT_CASE
+	return hipGetLastError();
+}
+
+hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
+	const uint32_t blocks = (a.count + 63) / 64;
+	if(blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_edit_trace, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+	return hipGetLastError();
+}

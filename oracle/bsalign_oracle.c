@@ -720,8 +720,10 @@ double orc_align_batch_time(const uint8_t *seqs, const uint64_t *qoff, const uin
  * reference line by line.
  */
 
-static inline int plane_bit(const uint64_t *pl, uint32_t W, long pos){ /* striped_seqedit_getval, bsalign.h:224; x86 masks the shift count */
-	return (int)((pl[pos % W] >> ((pos / W) & 63)) & 1);
+static inline int plane_bit(const uint64_t *pl, uint32_t W, long pos){ /* striped_seqedit_getval, bsalign.h:224 */
+	/* the reference evaluates `x - begs[..]` in unsigned 32-bit arithmetic and x86 masks the shift count to 6 bits */
+	uint32_t pu = (uint32_t)pos;
+	return (int)((pl[pu % W] >> ((pu / W) & 63u)) & 1);
 }
 
 static int edit_rowmin(int sbeg, const int8_t *u, uint32_t bw, uint32_t *whence){ /* bsalign.h:813-963: first strict minimum of the running score */

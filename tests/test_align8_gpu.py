@@ -103,3 +103,23 @@ def test_bad_and_empty_inputs(ctx):
     res, cig, _ = S.oracle_align(q, q, S.MODE_GLOBAL, 64, 2, -6, -3, -2, 0, 0)
     assert np.array_equal(np.array([out[0][f] for f in out.dtype.names], dtype=np.int32), res)
     assert np.array_equal(cigs[0], cig)
+
+
+def test_golden_align8_cases(ctx):
+    """the committed golden vectors (generated from the real reference) through the HIP path"""
+    import os
+    import bsalign_amd as B
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "align8.npz"))
+    groups = {}
+    for k in range(int(g["n"][0])):
+        meta = tuple(int(x) for x in g["meta_%d" % k])
+        if meta[1] == 0:
+            continue      # bandwidth 0 (per-pair full band) is not on the device yet
+        groups.setdefault(meta, []).append(k)
+    assert len(groups) > 30
+    for meta, ks in groups.items():
+        pairs = [(g["q_%d" % k], g["t_%d" % k]) for k in ks]
+        out, cigs, status = ctx.align_batch(pairs, B.make_params(meta[0], meta[1], *meta[2:]))
+        for i, k in enumerate(ks):
+            got = np.array([out[i][f] for f in out.dtype.names], dtype=np.int32)
+            assert status[i] == 0 and np.array_equal(got, g["res_%d" % k]) and np.array_equal(cigs[i], g["cig_%d" % k]), (meta, k)

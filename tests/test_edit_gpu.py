@@ -1,0 +1,81 @@
+"""GPU parity: HIP 2-bit edit path (through the C-ABI) vs the oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import support as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(rng, L, eps, ratio):
+    T = rng.integers(0, 4, size=L).astype(np.uint8)
+    Q = S.mutate(rng, T, eps)
+    if ratio != 1.0:
+        Lq = max(1, int(len(Q) * ratio))
+        Q = Q[:Lq] if Lq <= len(Q) else np.concatenate([Q, rng.integers(0, 4, size=Lq - len(Q)).astype(np.uint8)])
+    if len(Q) == 0:
+        Q = np.array([0], dtype=np.uint8)
+    return Q, T
+
+
+def _check(ctx, pairs, mode, bw):
+    import bsalign_amd as B
+    out, cigs, status = ctx.edit_batch(pairs, mode, bw)
+    bad = []
+    for k, (q, t) in enumerate(pairs):
+        res, cig, n = S.oracle_edit(q, t, mode, bw)
+        got = np.array([out[k][f] for f in out.dtype.names], dtype=np.int32)
+        if not (status[k] == 0 and np.array_equal(got, res) and np.array_equal(cigs[k], cig)):
+            bad.append("pair %d qlen %d tlen %d status %d\n  gpu %s %s\n  orc %s %s" % (
+                k, len(q), len(t), status[k], got, S.cigar_str(cigs[k])[:100], res, S.cigar_str(cig)[:100]))
+    assert not bad, "%d/%d pairs differ (mode %d bw %d)\n%s" % (len(bad), len(pairs), mode, bw, "\n".join(bad[:5]))
+
+
+@pytest.mark.parametrize("bw", [64, 128, 256, 512])
+def test_global_banded(ctx, bw):
+    rng = np.random.default_rng(400 + bw)
+    pairs = [_mk(rng, int(rng.choice([300, 700, 1500, 3000])), float(rng.choice([0.01, 0.1, 0.2])), float(rng.choice([1.0, 1.0, 0.9, 1.1])))
+             for _ in range(96)]
+    _check(ctx, pairs, S.MODE_GLOBAL, bw)
+
+
+def test_global_short_queries_use_full_width(ctx):
+    """qlen < bandwidth (or bandwidth 0): the band is the whole rounded query (bsalign.h:1059-1061)"""
+    rng = np.random.default_rng(8)
+    pairs = [_mk(rng, int(rng.choice([1, 2, 30, 63, 64, 65, 100, 129, 200, 500, 800])), 0.15, float(rng.choice([1.0, 0.8, 1.2]))) for _ in range(128)]
+    _check(ctx, pairs, S.MODE_GLOBAL, 0)
+    _check(ctx, pairs, S.MODE_GLOBAL, 1024)
+
+
+@pytest.mark.parametrize("mode", [S.MODE_OVERLAP, S.MODE_EXTEND])
+def test_overlap_extend_full_band(ctx, mode):
+    rng = np.random.default_rng(21 + mode)
+    pairs = [_mk(rng, int(rng.choice([5, 64, 100, 300, 800])), 0.15, float(rng.choice([1.0, 0.7, 1.2]))) for _ in range(96)]
+    _check(ctx, pairs, mode, 0)
+
+
+def test_benchmark_shape_100k_bw256(ctx):
+    pairs = [S.synth_pair(k, 100000) for k in range(4)]
+    _check(ctx, pairs, S.MODE_GLOBAL, 256)
+
+
+def test_golden_edit_cases(ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "edit.npz"))
+    import bsalign_amd as B
+    groups = {}
+    for k in range(int(g["n"][0])):
+        mode, bw = [int(x) for x in g["meta_%d" % k]]
+        q = g["q_%d" % k]
+        if mode != 0 and len(q) > 1024:
+            continue      # full-band widths beyond the register kernel are not on the device yet
+        if mode == 0 and (bw == 0 or bw > len(q)) and len(q) > 1024:
+            continue
+        groups.setdefault((mode, bw), []).append(k)
+    assert groups
+    for (mode, bw), ks in groups.items():
+        pairs = [(g["q_%d" % k], g["t_%d" % k]) for k in ks]
+        out, cigs, status = ctx.edit_batch(pairs, mode, bw)
+        for i, k in enumerate(ks):
+            got = np.array([out[i][f] for f in out.dtype.names], dtype=np.int32)
+            assert status[i] == 0 and np.array_equal(got, g["res_%d" % k]) and np.array_equal(cigs[i], g["cig_%d" % k]), (mode, bw, k)

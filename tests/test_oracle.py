@@ -1,0 +1,142 @@
+"""CPU: the oracle (own C restatement) against the committed golden vectors (generated from the real
+reference) and, when the reference build is present in this container, against the reference itself."""
+import os
+
+import numpy as np
+import pytest
+
+import support as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    return np.load(os.path.join(HERE, "golden", name))
+
+
+def test_align8_golden():
+    g = _load("align8.npz")
+    n = int(g["n"][0])
+    assert n > 400
+    for k in range(n):
+        mode, bw, M, X, O, E, Q, P = [int(x) for x in g["meta_%d" % k]]
+        res, cig, cnt = S.oracle_align(g["q_%d" % k], g["t_%d" % k], mode, bw, M, X, O, E, Q, P)
+        assert cnt >= 0, "case %d: oracle refused" % k
+        assert np.array_equal(res, g["res_%d" % k]), "case %d result %s != %s" % (k, res, g["res_%d" % k])
+        assert np.array_equal(cig, g["cig_%d" % k]), "case %d cigar" % k
+
+
+def test_edit_golden():
+    g = _load("edit.npz")
+    n = int(g["n"][0])
+    assert n > 60
+    for k in range(n):
+        mode, bw = [int(x) for x in g["meta_%d" % k]]
+        res, cig, cnt = S.oracle_edit(g["q_%d" % k], g["t_%d" % k], mode, bw)
+        assert np.array_equal(res, g["res_%d" % k]), "case %d result %s != %s" % (k, res, g["res_%d" % k])
+        assert np.array_equal(cig, g["cig_%d" % k]), "case %d cigar" % k
+
+
+def test_golden_conventions():
+    """result conventions of the reference: half-open spans, aln = mat+mis+ins+del, CIGAR covers the spans"""
+    g = _load("align8.npz")
+    for k in range(0, int(g["n"][0]), 7):
+        res, cig = g["res_%d" % k], g["cig_%d" % k]
+        score, qb, qe, tb, te, mat, mis, ins, dele, aln = [int(x) for x in res]
+        assert aln == mat + mis + ins + dele
+        qn, tn = S.cigar_spans(cig)
+        assert qn == qe - qb and tn == te - tb
+        if int(g["meta_%d" % k][0]) == S.MODE_GLOBAL:
+            assert (qb, tb) == (0, 0) and qe == len(g["q_%d" % k]) and te == len(g["t_%d" % k])
+
+
+def test_edit_score_is_levenshtein_when_band_is_full():
+    """independent secondary oracle: unbanded global edit score == Levenshtein distance"""
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        L = int(rng.integers(5, 200))
+        T = rng.integers(0, 4, size=L).astype(np.uint8)
+        Q = S.mutate(rng, T, 0.15)
+        if len(Q) == 0:
+            continue
+        res, cig, _ = S.oracle_edit(Q, T, S.MODE_GLOBAL, 0)
+        prev = np.arange(len(Q) + 1)
+        for y in range(L):
+            cur = np.empty_like(prev)
+            cur[0] = y + 1
+            for x in range(len(Q)):
+                cur[x + 1] = min(prev[x] + (Q[x] != T[y]), prev[x + 1] + 1, cur[x] + 1)
+            prev = cur
+        assert int(res[0]) == int(prev[-1])
+        assert int(res[6] + res[7] + res[8]) == int(res[0])
+
+
+def test_oracle_flags_nonterminating_input():
+    """an input on which the reference's traceback never terminates (large scores, narrow band): the oracle
+    reports ORC_ERR_TRACE instead of hanging (found by the randomized sweep against the reference)"""
+    rng = np.random.default_rng(1)
+    hits = 0
+    for _ in range(300):
+        T = rng.integers(0, 4, size=1000).astype(np.uint8)
+        Q = S.mutate(rng, T, 0.5)
+        _, _, n = S.oracle_align(Q, T, S.MODE_EXTEND, 32, 10, -30, -20, -10, 0, 0)
+        hits += n == S.ORC_ERR_TRACE
+        if hits:
+            break
+    assert hits >= 1
+
+
+def test_oracle_rejects_bad_input():
+    q = np.array([0, 1, 2, 3], dtype=np.uint8)
+    bad = np.array([0, 4, 2, 3], dtype=np.uint8)
+    assert S.oracle_align(bad, q, 0, 16, 2, -6, -3, -2, 0, 0)[2] == S.ERR_INPUT
+    assert S.oracle_align(q[:0], q, 0, 16, 2, -6, -3, -2, 0, 0)[2] == S.ERR_INPUT
+    res, cig, n = S.oracle_edit(q[:0], q, 0, 0)      # the reference returns a zeroed result (bsalign.h:1051-1054)
+    assert n == 0 and not res.any()
+
+
+@pytest.mark.skipif(not S.have_ref(), reason="reference build (oracle/_ref) not present")
+def test_align8_oracle_vs_reference_random():
+    rng = np.random.default_rng(11)
+    scorings = [(2, -6, -3, -2, 0, 0), (2, -2, -4, -2, 0, 0), (2, -6, 0, -3, 0, 0), (2, -6, -3, -2, -8, -1), (1, -1, -1, -1, 0, 0)]
+    n = 0
+    for it in range(700):
+        L = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 100, 200, 500, 1000]))
+        T = rng.integers(0, 4, size=L).astype(np.uint8)
+        Q = S.mutate(rng, T, float(rng.choice([0.01, 0.1, 0.2, 0.5])))
+        r = float(rng.choice([1.0, 1.0, 0.9, 1.1, 2.0, 0.5]))
+        if r != 1.0:
+            Lq = max(1, int(len(Q) * r))
+            Q = Q[:Lq] if Lq <= len(Q) else np.concatenate([Q, rng.integers(0, 4, size=Lq - len(Q)).astype(np.uint8)])
+        if len(Q) == 0:
+            continue
+        bw = int(rng.choice([0, 16, 32, 64, 128, 256]))
+        mode = int(rng.choice([0, 1, 2]))
+        sc = scorings[int(rng.integers(len(scorings)))]
+        o = S.oracle_align(Q, T, mode, bw, *sc)
+        if o[2] == S.ORC_ERR_TRACE:
+            continue        # the reference does not terminate on these
+        rr = S.ref_align(Q, T, mode, bw, *sc)
+        assert np.array_equal(rr[0], o[0]) and np.array_equal(rr[1], o[1]), (it, L, len(Q), bw, mode, sc)
+        n += 1
+    assert n > 600
+
+
+@pytest.mark.skipif(not S.have_ref(), reason="reference build (oracle/_ref) not present")
+def test_edit_oracle_vs_reference_random():
+    rng = np.random.default_rng(12)
+    for it in range(600):
+        L = int(rng.choice([1, 2, 15, 63, 64, 65, 100, 129, 500, 1000, 3000]))
+        T = rng.integers(0, 4, size=L).astype(np.uint8)
+        Q = S.mutate(rng, T, float(rng.choice([0.01, 0.1, 0.2, 0.5])))
+        r = float(rng.choice([1.0, 1.0, 0.9, 1.1, 1.5, 0.6]))
+        if r != 1.0:
+            Lq = max(1, int(len(Q) * r))
+            Q = Q[:Lq] if Lq <= len(Q) else np.concatenate([Q, rng.integers(0, 4, size=Lq - len(Q)).astype(np.uint8)])
+        if len(Q) == 0:
+            continue
+        bw = int(rng.choice([0, 64, 128, 256]))
+        mode = int(rng.choice([0, 1, 2]))
+        rr = S.ref_edit(Q, T, mode, bw)
+        o = S.oracle_edit(Q, T, mode, bw)
+        assert np.array_equal(rr[0], o[0]) and np.array_equal(rr[1], o[1]), (it, L, len(Q), bw, mode)
