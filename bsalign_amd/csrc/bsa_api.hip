@@ -1,20 +1,26 @@
 // bsa_api.hip -- C-ABI of libbsalign_hip.so (include/bsalign_hip.h): context, plans, batch drivers.
 //
 // The drivers play the role of the reference's per-pair loop (main.c:311-326 / main.c:194-205): they
-// stage the sequences, order the pairs by length so the 4 pairs sharing a wavefront finish together,
-// cut the batch into chunks whose traceback rows fit the device workspace, and for every chunk launch
-// forward DP -> traceback -> CIGAR compaction on the context stream.
+// stage the sequences, order the pairs by length so the pairs sharing a wavefront finish together, cut the
+// batch into chunks whose traceback rows fit half of the device workspace, and pipeline the chunks over
+// two HIP streams: forward DP of chunk k+1 (compute / HBM-write bound) runs on the context stream while
+// traceback + CIGAR compaction of chunk k (latency bound, few waves) runs on an auxiliary stream, the two
+// halves of the workspace alternating.
 #include "bsa_common.h"
 #include <algorithm>
 #include <string>
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 struct bsa_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;
+	hipStream_t aux_stream = nullptr;        // traceback side of the chunk pipeline
+	std::vector<hipEvent_t> sev;             // ordering events of the pipeline (no timing)
+	size_t sev_used = 0;
 	size_t ws_limit = 0;
 	uint8_t *ws = nullptr; size_t ws_bytes = 0;
 	std::string err;
@@ -39,6 +45,7 @@ extern "C" int bsa_ctx_create(int device, bsa_ctx_t **out){
 	bsa_ctx *c = new bsa_ctx();
 	c->device = device;
 	if(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess){ delete c; return BSA_E_NODEVICE; }
+	if(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess){ (void)hipStreamDestroy(c->own_stream); delete c; return BSA_E_NODEVICE; }
 	c->stream = c->own_stream;
 	*out = c;
 	return BSA_OK;
@@ -48,8 +55,11 @@ extern "C" void bsa_ctx_destroy(bsa_ctx_t *c){
 	if(!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
+	(void)hipStreamSynchronize(c->aux_stream);
 	for(hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+	for(hipEvent_t e : c->sev) (void)hipEventDestroy(e);
 	if(c->ws) (void)hipFree(c->ws);
+	if(c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
 	if(c->own_stream) (void)hipStreamDestroy(c->own_stream);
 	delete c;
 }
@@ -86,6 +96,16 @@ static int ctx_event_pair(bsa_ctx *c, hipEvent_t *a, hipEvent_t *b){
 	return BSA_OK;
 }
 
+static int ctx_sync_event(bsa_ctx *c, hipEvent_t *e){
+	if(c->sev.size() <= c->sev_used){
+		hipEvent_t ne;
+		HIPCHK(c, hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+		c->sev.push_back(ne);
+	}
+	*e = c->sev[c->sev_used++];
+	return BSA_OK;
+}
+
 static size_t ctx_ws_budget(bsa_ctx *c){
 	if(c->ws_limit) return c->ws_limit;
 	size_t fr = 0, tot = 0;
@@ -96,7 +116,7 @@ static size_t ctx_ws_budget(bsa_ctx *c){
 
 static int ctx_ws_reserve(bsa_ctx *c, size_t bytes){
 	if(c->ws_bytes >= bytes) return BSA_OK;
-	if(c->ws){ HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+	if(c->ws){ HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->aux_stream)); (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
 	if(hipMalloc((void**)&c->ws, bytes) != hipSuccess){ c->err = "workspace allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
 	c->ws_bytes = bytes;
 	return BSA_OK;
@@ -198,19 +218,19 @@ __global__ void __launch_bounds__(256) k_cigar_final(const uint32_t *tmp, const 
 	for(uint32_t i = lane; i < c; i += 64) dst[d + i] = tmp[s + i];
 }
 
-// ------------------------------------------------------------------------------------------------
-// 8-bit alignment plan
-// ------------------------------------------------------------------------------------------------
-struct Chunk { uint32_t first, count; size_t bytes; };
 
-struct bsa_align_plan {
+// ------------------------------------------------------------------------------------------------
+// plans: metadata + staging buffers shared by both paths, chunk pipeline
+// ------------------------------------------------------------------------------------------------
+struct Chunk { uint32_t first, count, bw; size_t bytes; };
+
+struct PlanBase {
 	bsa_ctx *ctx = nullptr;
 	size_t n = 0;
-	bsa_align_params_t par;
-	uint32_t bw = 0, rowb = 0; int pw = 0;
 	double cells = 0;
 	std::vector<Chunk> chunks;
-	size_t ws_need = 0;
+	size_t half_bytes = 0;          // size of one workspace half (0 or 1 chunk in flight per half)
+	bool two_halves = false;
 	// device metadata
 	uint64_t *d_qoff = nullptr, *d_toff = nullptr, *d_qpoff = nullptr, *d_tpoff = nullptr, *d_slot = nullptr, *d_slot_end = nullptr;
 	uint32_t *d_qlen = nullptr, *d_tlen = nullptr, *d_order = nullptr;
@@ -218,8 +238,8 @@ struct bsa_align_plan {
 	uint32_t *d_cnt_pos = nullptr, *d_cnt_pair = nullptr, *d_status_own = nullptr;
 	uint64_t *d_off_pos = nullptr, *d_src_pair = nullptr, *d_carry = nullptr;
 	uint32_t *d_tmp = nullptr; size_t tmp_words = 0;
-	size_t qst_bytes = 0, tst_bytes = 0;
-	uint32_t qpad = 0, tpad = 16;
+	std::vector<void*> extra;       // path-specific device allocations
+	virtual ~PlanBase(){}
 };
 
 template<typename T> static int dev_upload(bsa_ctx *c, T **dst, const std::vector<T> &src){
@@ -233,16 +253,192 @@ template<typename T> static int dev_alloc(bsa_ctx *c, T **dst, size_t count){
 	return BSA_OK;
 }
 
-extern "C" void bsa_align_plan_destroy(bsa_align_plan_t *p){
+static void plan_free(PlanBase *p){
 	if(!p) return;
 	(void)hipSetDevice(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
-	void *ptrs[] = { p->d_slot_end, p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_qlen, p->d_tlen, p->d_order, p->d_qst, p->d_tst,
+	(void)hipStreamSynchronize(p->ctx->aux_stream);
+	void *ptrs[] = { p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_slot_end, p->d_qlen, p->d_tlen, p->d_order, p->d_qst, p->d_tst,
 	                 p->d_cnt_pos, p->d_cnt_pair, p->d_status_own, p->d_off_pos, p->d_src_pair, p->d_carry, p->d_tmp };
 	for(void *q : ptrs) if(q) (void)hipFree(q);
+	for(void *q : p->extra) if(q) (void)hipFree(q);
 	delete p;
 }
 
+// cut the processing order into chunks: every chunk fits one workspace half, has a single bandwidth, and large
+// batches are cut into >= 4 chunks so that the traceback of one chunk hides behind the forward pass of the next
+static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const std::vector<size_t> &need, const std::vector<uint32_t> &bwv,
+		std::vector<uint64_t> &slot, std::vector<uint64_t> &slot_end){
+	bsa_ctx *c = p->ctx;
+	const size_t n = order.size();
+	const size_t budget = ctx_ws_budget(c);
+	size_t total = 0, biggest = 0;
+	for(size_t pos = 0; pos < n; pos++){ total += need[pos]; biggest = std::max(biggest, need[pos]); }
+	if(biggest > budget){ c->err = "workspace limit too small for one pair"; return BSA_E_NOMEM; }
+	// Both kernels are row-serial per pair, so throughput = pairs in flight / per-pair latency: chunks are made as
+	// large as memory allows and run back to back on the context stream.  Measured on MI355X (round 1): splitting the
+	// workspace in two halves and running the traceback of chunk k beside the forward pass of chunk k+1 on a second
+	// stream was SLOWER (394 vs 367 ms per 100k-pair step: smaller chunks lower the forward kernel's occupancy and the
+	// two kernels compete for issue slots), so that mode is opt-in (BSA_PIPELINE=1) until the traceback is cheaper.
+	size_t cap;            // bytes per chunk
+	const char *pe = getenv("BSA_PIPELINE");
+	const bool want_pipe = pe && pe[0] == '1';
+	if(total <= budget || !want_pipe){ cap = std::max(std::min(total, budget), biggest); p->two_halves = false; }
+	else {
+		cap = std::max(budget / 2, biggest);
+		p->two_halves = (2 * cap <= budget);
+		if(!p->two_halves) cap = std::max(budget, biggest);
+	}
+	slot.assign(n, 0); slot_end.assign(n, 0);
+	size_t acc = 0, maxacc = 0; uint32_t first = 0;
+	for(size_t pos = 0; pos < n; pos++){
+		if(pos > first && (acc + need[pos] > cap || bwv[pos] != bwv[first])){
+			p->chunks.push_back({first, (uint32_t)(pos - first), bwv[first], acc});
+			maxacc = std::max(maxacc, acc);
+			first = (uint32_t)pos; acc = 0;
+		}
+		slot[pos] = acc; acc += need[pos]; slot_end[pos] = acc;
+	}
+	if(n > first){ p->chunks.push_back({first, (uint32_t)(n - first), bwv[first], acc}); maxacc = std::max(maxacc, acc); }
+	p->half_bytes = (maxacc + 255) & ~(size_t)255;
+	if(p->chunks.size() < 2) p->two_halves = false;
+	return BSA_OK;
+}
+
+static int plan_common_alloc(PlanBase *p, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
+		const std::vector<uint64_t> &qpoff, const std::vector<uint64_t> &tpoff, const std::vector<uint64_t> &slot,
+		const std::vector<uint64_t> &slot_end, const std::vector<uint32_t> &order, size_t qst_bytes, size_t tst_bytes){
+	bsa_ctx *c = p->ctx; const size_t n = p->n; int rc;
+	std::vector<uint64_t> vqoff(qoff, qoff + n), vtoff(toff, toff + n);
+	std::vector<uint32_t> vqlen(qlen, qlen + n), vtlen(tlen, tlen + n);
+#define TRY(x) do { rc = (x); if(rc != BSA_OK) return rc; } while(0)
+	TRY(dev_upload(c, &p->d_qoff, vqoff)); TRY(dev_upload(c, &p->d_toff, vtoff));
+	TRY(dev_upload(c, &p->d_qlen, vqlen)); TRY(dev_upload(c, &p->d_tlen, vtlen));
+	TRY(dev_upload(c, &p->d_qpoff, qpoff)); TRY(dev_upload(c, &p->d_tpoff, tpoff));
+	TRY(dev_upload(c, &p->d_slot, slot)); TRY(dev_upload(c, &p->d_slot_end, slot_end)); TRY(dev_upload(c, &p->d_order, order));
+	TRY(dev_alloc(c, &p->d_qst, qst_bytes)); TRY(dev_alloc(c, &p->d_tst, tst_bytes));
+	TRY(dev_alloc(c, &p->d_cnt_pos, n)); TRY(dev_alloc(c, &p->d_cnt_pair, n)); TRY(dev_alloc(c, &p->d_status_own, n));
+	TRY(dev_alloc(c, &p->d_off_pos, n + 1)); TRY(dev_alloc(c, &p->d_src_pair, n)); TRY(dev_alloc(c, &p->d_carry, 1));
+	TRY(ctx_ws_reserve(c, p->half_bytes * (p->two_halves ? 2 : 1)));
+#undef TRY
+	return BSA_OK;
+}
+
+// The chunk pipeline.  fwd(chunk, ws_half, stream) launches the forward DP; trace(chunk, ws_half, stream) launches the
+// traceback that fills d_out / d_cnt_pos.  Ordering: fwd(k) waits for trace(k-2) (same half), trace(k) waits for fwd(k).
+template<class FwdFn, class TraceFn>
+static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t cigar_cap_words, uint64_t *d_cigar_off, FwdFn fwd, TraceFn trace){
+	bsa_ctx *c = p->ctx;
+	hipStream_t sf = c->stream, stt = p->two_halves ? c->aux_stream : c->stream;
+	const uint32_t n = (uint32_t)p->n;
+	int rc;
+	c->sev_used = 0;
+	HIPCHK(c, hipMemsetAsync(p->d_carry, 0, sizeof(uint64_t), sf));
+	std::vector<hipEvent_t> trace_done(p->chunks.size());
+	if(p->two_halves){
+		// the auxiliary stream must not start before the staging work already queued on the main stream
+		hipEvent_t e; rc = ctx_sync_event(c, &e); if(rc != BSA_OK) return rc;
+		HIPCHK(c, hipEventRecord(e, sf)); HIPCHK(c, hipStreamWaitEvent(stt, e, 0));
+	}
+	for(size_t k = 0; k < p->chunks.size(); k++){
+		const Chunk &ch = p->chunks[k];
+		uint8_t *half = c->ws + (p->two_halves ? (k & 1) * p->half_bytes : 0);
+		if(p->two_halves && k >= 2) HIPCHK(c, hipStreamWaitEvent(sf, trace_done[k - 2], 0));
+		hipEvent_t e0, e1;
+		rc = ctx_event_pair(c, &e0, &e1); if(rc != BSA_OK) return rc;
+		HIPCHK(c, hipEventRecord(e0, sf));
+		rc = fwd(ch, half, sf); if(rc != BSA_OK) return rc;
+		HIPCHK(c, hipEventRecord(e1, sf));
+		if(p->two_halves) HIPCHK(c, hipStreamWaitEvent(stt, e1, 0));
+		rc = trace(ch, half, stt); if(rc != BSA_OK) return rc;
+		if(want_cig){
+			hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, stt, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry);
+			HIPCHK(c, hipGetLastError());
+			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, stt, half, p->d_slot_end,
+				ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
+			HIPCHK(c, hipGetLastError());
+		}
+		if(p->two_halves){
+			rc = ctx_sync_event(c, &trace_done[k]); if(rc != BSA_OK) return rc;
+			HIPCHK(c, hipEventRecord(trace_done[k], stt));
+		}
+	}
+	if(p->two_halves && !p->chunks.empty()){
+		HIPCHK(c, hipStreamWaitEvent(sf, trace_done.back(), 0));
+		if(p->chunks.size() >= 2) HIPCHK(c, hipStreamWaitEvent(sf, trace_done[p->chunks.size() - 2], 0));
+	}
+	c->last_cells = p->cells;
+	if(want_cig){
+		hipLaunchKernelGGL(k_cnt_by_pair, dim3((n + 255) / 256), dim3(256), 0, sf, p->d_order, p->d_cnt_pos, p->d_off_pos, p->d_cnt_pair, p->d_src_pair, n);
+		HIPCHK(c, hipGetLastError());
+		hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, sf, p->d_cnt_pair, d_cigar_off, n, (uint64_t*)nullptr);
+		HIPCHK(c, hipGetLastError());
+		hipLaunchKernelGGL(k_cigar_final, dim3((n + 3) / 4), dim3(256), 0, sf, p->d_tmp, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
+		HIPCHK(c, hipGetLastError());
+	} else if(d_cigar_off){
+		HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t) * ((size_t)n + 1), sf));
+	}
+	return BSA_OK;
+}
+
+static int run_prologue(PlanBase *p, bool want_cig, size_t cigar_cap_words){
+	bsa_ctx *c = p->ctx;
+	(void)hipSetDevice(c->device);
+	c->ev_used = 0; c->last_cells = 0;
+	int rc = ctx_ws_reserve(c, p->half_bytes * (p->two_halves ? 2 : 1));
+	if(rc != BSA_OK) return rc;
+	if(want_cig && p->tmp_words < cigar_cap_words){
+		if(p->d_tmp){ HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->aux_stream)); (void)hipFree(p->d_tmp); p->d_tmp = nullptr; }
+		if(hipMalloc((void**)&p->d_tmp, std::max<size_t>(cigar_cap_words, 1) * 4) != hipSuccess){ c->err = "cigar staging allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
+		p->tmp_words = cigar_cap_words;
+	}
+	return BSA_OK;
+}
+
+// host-pointer convenience wrapper shared by both paths: copy in, run, copy out, synchronise
+template<class RunFn>
+static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t n, bsa_result_t *out, uint32_t *cigar,
+		size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status, RunFn run){
+	uint8_t *d_seqs = nullptr; bsa_result_t *d_out = nullptr; uint32_t *d_cig = nullptr, *d_status = nullptr; uint64_t *d_off = nullptr;
+	auto cleanup = [&](){
+		if(d_seqs) (void)hipFree(d_seqs); if(d_out) (void)hipFree(d_out); if(d_cig) (void)hipFree(d_cig);
+		if(d_status) (void)hipFree(d_status); if(d_off) (void)hipFree(d_off);
+	};
+	const bool want_cig = cigar && cigar_off;
+#define TRYH(call) do { hipError_t _e = (call); if(_e != hipSuccess){ c->err = std::string(#call) + ": " + hipGetErrorString(_e); cleanup(); return BSA_E_HIP; } } while(0)
+	TRYH(hipMalloc((void**)&d_seqs, std::max<size_t>(seqs_bytes, 1)));
+	TRYH(hipMalloc((void**)&d_out, n * sizeof(bsa_result_t)));
+	TRYH(hipMalloc((void**)&d_status, n * sizeof(uint32_t)));
+	if(want_cig){
+		TRYH(hipMalloc((void**)&d_cig, std::max<size_t>(cigar_cap_words, 1) * 4));
+		TRYH(hipMalloc((void**)&d_off, (n + 1) * sizeof(uint64_t)));
+	}
+	TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+	int rc = run(d_seqs, d_out, d_cig, d_off, d_status);
+	if(rc != BSA_OK){ cleanup(); return rc; }
+	TRYH(hipMemcpyAsync(out, d_out, n * sizeof(bsa_result_t), hipMemcpyDeviceToHost, c->stream));
+	if(status) TRYH(hipMemcpyAsync(status, d_status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	if(want_cig) TRYH(hipMemcpyAsync(cigar_off, d_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	TRYH(hipStreamSynchronize(c->stream));
+	if(want_cig){
+		if(cigar_off[n] > cigar_cap_words){ cleanup(); c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
+		TRYH(hipMemcpy(cigar, d_cig, cigar_off[n] * 4, hipMemcpyDeviceToHost));
+	}
+#undef TRYH
+	cleanup();
+	return BSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8-bit alignment plan (banded_striped_epi8_seqalign_pairwise, bsalign.h:3854)
+// ------------------------------------------------------------------------------------------------
+struct bsa_align_plan : PlanBase {
+	bsa_align_params_t par;
+	uint32_t bw = 0, rowb = 0; int pw = 0;
+	uint32_t qpad = 0, tpad = 16;
+};
+
+extern "C" void bsa_align_plan_destroy(bsa_align_plan_t *p){ plan_free(p); }
 extern "C" double bsa_align_plan_cells(const bsa_align_plan_t *p){ return p ? p->cells : 0.0; }
 
 extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const uint32_t *qlen,
@@ -264,7 +460,8 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	std::vector<uint32_t> order(n);
 	for(size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return tlen[x] > tlen[y]; });
-	std::vector<uint64_t> qpoff(n), tpoff(n), slot(n), slot_end(n);
+	std::vector<uint64_t> qpoff(n), tpoff(n), slot, slot_end;
+	std::vector<size_t> need(n); std::vector<uint32_t> bwv(n, bw);
 	size_t qacc = 0, tacc = 0;
 	double cells = 0;
 	for(size_t k = 0; k < n; k++){
@@ -272,34 +469,11 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + p->tpad + 15) & ~(size_t)15;
 		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw;
 	}
-	p->qst_bytes = qacc; p->tst_bytes = tacc; p->cells = cells;
-	// chunks over the processing order, bounded by the workspace budget
-	const size_t budget = ctx_ws_budget(c);
-	size_t acc = 0; uint32_t first = 0;
-	for(size_t pos = 0; pos < n; pos++){
-		const size_t need = ((size_t)tlen[order[pos]] + 3) * p->rowb;
-		if(need > budget){ c->err = "workspace limit too small for one pair"; delete p; return BSA_E_NOMEM; }
-		if(acc + need > budget){
-			p->chunks.push_back({first, (uint32_t)(pos - first), acc});
-			p->ws_need = std::max(p->ws_need, acc);
-			first = (uint32_t)pos; acc = 0;
-		}
-		slot[pos] = acc; acc += need; slot_end[pos] = acc;
-	}
-	if(n > first){ p->chunks.push_back({first, (uint32_t)(n - first), acc}); p->ws_need = std::max(p->ws_need, acc); }
-	int rc;
-	std::vector<uint64_t> vqoff(qoff, qoff + n), vtoff(toff, toff + n);
-	std::vector<uint32_t> vqlen(qlen, qlen + n), vtlen(tlen, tlen + n);
-#define TRY(x) do { rc = (x); if(rc != BSA_OK){ bsa_align_plan_destroy(p); return rc; } } while(0)
-	TRY(dev_upload(c, &p->d_qoff, vqoff)); TRY(dev_upload(c, &p->d_toff, vtoff));
-	TRY(dev_upload(c, &p->d_qlen, vqlen)); TRY(dev_upload(c, &p->d_tlen, vtlen));
-	TRY(dev_upload(c, &p->d_qpoff, qpoff)); TRY(dev_upload(c, &p->d_tpoff, tpoff));
-	TRY(dev_upload(c, &p->d_slot, slot)); TRY(dev_upload(c, &p->d_order, order)); TRY(dev_upload(c, &p->d_slot_end, slot_end));
-	TRY(dev_alloc(c, &p->d_qst, p->qst_bytes)); TRY(dev_alloc(c, &p->d_tst, p->tst_bytes));
-	TRY(dev_alloc(c, &p->d_cnt_pos, n)); TRY(dev_alloc(c, &p->d_cnt_pair, n)); TRY(dev_alloc(c, &p->d_status_own, n));
-	TRY(dev_alloc(c, &p->d_off_pos, n + 1)); TRY(dev_alloc(c, &p->d_src_pair, n)); TRY(dev_alloc(c, &p->d_carry, 1));
-	TRY(ctx_ws_reserve(c, p->ws_need));
-#undef TRY
+	for(size_t pos = 0; pos < n; pos++) need[pos] = ((size_t)tlen[order[pos]] + 3) * p->rowb;
+	p->cells = cells;
+	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
+	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
+	if(rc != BSA_OK){ plan_free(p); return rc; }
 	*out = p;
 	return BSA_OK;
 }
@@ -308,33 +482,25 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		size_t cigar_cap_words, uint64_t *d_cigar_off, uint32_t *d_status){
 	if(!p || !d_out) return BSA_E_ARG;
 	bsa_ctx *c = p->ctx;
-	(void)hipSetDevice(c->device);
-	hipStream_t st = c->stream;
 	const uint32_t n = (uint32_t)p->n;
-	c->ev_used = 0; c->last_cells = 0;
+	const bool want_cig = d_cigar != nullptr && d_cigar_off != nullptr;
+	int rc = run_prologue(p, want_cig, cigar_cap_words);
+	if(rc != BSA_OK) return rc;
+	hipStream_t st = c->stream;
 	if(n == 0){
 		if(d_cigar_off) HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t), st));
 		return BSA_OK;
 	}
 	if(!d_seqs) return BSA_E_ARG;
-	int rc = ctx_ws_reserve(c, p->ws_need);
-	if(rc != BSA_OK) return rc;
-	const bool want_cig = d_cigar != nullptr && d_cigar_off != nullptr;
-	if(want_cig && p->tmp_words < cigar_cap_words){
-		if(p->d_tmp){ HIPCHK(c, hipStreamSynchronize(st)); (void)hipFree(p->d_tmp); p->d_tmp = nullptr; }
-		if(hipMalloc((void**)&p->d_tmp, std::max<size_t>(cigar_cap_words, 1) * 4) != hipSuccess){ c->err = "cigar staging allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
-		p->tmp_words = cigar_cap_words;
-	}
 	uint32_t *status = d_status ? d_status : p->d_status_own;
 	hipLaunchKernelGGL(k_stage, dim3(n), dim3(256), 0, st, d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen,
 		p->d_qpoff, p->d_tpoff, p->d_qst, p->d_tst, p->qpad, p->tpad, status, n);
 	HIPCHK(c, hipGetLastError());
-	HIPCHK(c, hipMemsetAsync(p->d_carry, 0, sizeof(uint64_t), st));
 	Align8Args a;
 	memset(&a, 0, sizeof(a));
 	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
 	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
-	a.rows = c->ws; a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode;
+	a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode;
 	a.gapo1 = p->par.gapo1; a.gape1 = p->par.gape1; a.gapo2 = p->par.gapo2; a.gape2 = p->par.gape2;
 	int smax = -127, smin = 127;
 	for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)p->par.matrix[i]); smin = std::min(smin, (int)p->par.matrix[i]); a.matrix[i] = p->par.matrix[i]; }
@@ -344,34 +510,19 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		for(int q = 0; q < 4; q++) w |= (uint32_t)(uint8_t)p->par.matrix[q * 4 + t] << (8 * q);
 		a.mrow[t] = w;
 	}
-	for(const Chunk &ch : p->chunks){
-		a.first = ch.first; a.count = ch.count;
-		hipEvent_t e0, e1;
-		rc = ctx_event_pair(c, &e0, &e1); if(rc != BSA_OK) return rc;
-		HIPCHK(c, hipEventRecord(e0, st));
-		HIPCHK(c, bsa_launch_align8_fwd(a, p->pw, st));
-		HIPCHK(c, hipEventRecord(e1, st));
-		HIPCHK(c, bsa_launch_align8_backcal(a, p->pw, d_out, p->d_cnt_pos, st));
-		if(want_cig){
-			hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry);
-			HIPCHK(c, hipGetLastError());
-			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, st, c->ws, p->d_slot_end,
-				ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
-			HIPCHK(c, hipGetLastError());
-		}
-	}
-	c->last_cells = p->cells;
-	if(want_cig){
-		hipLaunchKernelGGL(k_cnt_by_pair, dim3((n + 255) / 256), dim3(256), 0, st, p->d_order, p->d_cnt_pos, p->d_off_pos, p->d_cnt_pair, p->d_src_pair, n);
-		HIPCHK(c, hipGetLastError());
-		hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pair, d_cigar_off, n, (uint64_t*)nullptr);
-		HIPCHK(c, hipGetLastError());
-		hipLaunchKernelGGL(k_cigar_final, dim3((n + 3) / 4), dim3(256), 0, st, p->d_tmp, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
-		HIPCHK(c, hipGetLastError());
-	} else if(d_cigar_off){
-		HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t) * ((size_t)n + 1), st));
-	}
-	return BSA_OK;
+	const int pw = p->pw;
+	uint32_t *cnt = p->d_cnt_pos;
+	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
+		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
+		HIPCHK(c, bsa_launch_align8_fwd(b, pw, s));
+		return BSA_OK;
+	};
+	auto trace = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
+		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
+		HIPCHK(c, bsa_launch_align8_backcal(b, pw, d_out, cnt, s));
+		return BSA_OK;
+	};
+	return run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);
 }
 
 extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_bytes,
@@ -385,51 +536,26 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	bsa_align_plan_t *p = nullptr;
 	int rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
 	if(rc != BSA_OK) return rc;
-	uint8_t *d_seqs = nullptr; bsa_result_t *d_out = nullptr; uint32_t *d_cig = nullptr, *d_status = nullptr; uint64_t *d_off = nullptr;
-	auto cleanup = [&](){
-		if(d_seqs) (void)hipFree(d_seqs); if(d_out) (void)hipFree(d_out); if(d_cig) (void)hipFree(d_cig);
-		if(d_status) (void)hipFree(d_status); if(d_off) (void)hipFree(d_off);
-		bsa_align_plan_destroy(p);
-	};
-	const bool want_cig = cigar && cigar_off;
-#define TRYH(call) do { hipError_t _e = (call); if(_e != hipSuccess){ c->err = std::string(#call) + ": " + hipGetErrorString(_e); cleanup(); return BSA_E_HIP; } } while(0)
-	TRYH(hipMalloc((void**)&d_seqs, std::max<size_t>(seqs_bytes, 1)));
-	TRYH(hipMalloc((void**)&d_out, n * sizeof(bsa_result_t)));
-	TRYH(hipMalloc((void**)&d_status, n * sizeof(uint32_t)));
-	if(want_cig){
-		TRYH(hipMalloc((void**)&d_cig, std::max<size_t>(cigar_cap_words, 1) * 4));
-		TRYH(hipMalloc((void**)&d_off, (n + 1) * sizeof(uint64_t)));
-	}
-	TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
-	rc = bsa_align_run(p, d_seqs, d_out, d_cig, cigar_cap_words, d_off, d_status);
-	if(rc != BSA_OK){ cleanup(); return rc; }
-	TRYH(hipMemcpyAsync(out, d_out, n * sizeof(bsa_result_t), hipMemcpyDeviceToHost, c->stream));
-	if(status) TRYH(hipMemcpyAsync(status, d_status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-	if(want_cig) TRYH(hipMemcpyAsync(cigar_off, d_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-	TRYH(hipStreamSynchronize(c->stream));
-	if(want_cig){
-		if(cigar_off[n] > cigar_cap_words){ cleanup(); c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
-		TRYH(hipMemcpy(cigar, d_cig, cigar_off[n] * 4, hipMemcpyDeviceToHost));
-	}
-#undef TRYH
-	cleanup();
-	return BSA_OK;
+	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, status,
+		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_align_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });
+	bsa_align_plan_destroy(p);
+	return rc;
 }
 
-// debug / test hook: copy the stored row records of processing position `ppos` (tlen+1 records) to host.
-// Only meaningful right after a single-chunk run.
+// debug / test hook: copy the stored row records of `pair` to host.  Only meaningful right after a single-chunk run.
 extern "C" int bsa_align_debug_rows(bsa_align_plan_t *p, uint32_t pair, uint8_t *host, size_t bytes, uint32_t *rowb_out){
 	if(!p || !host) return BSA_E_ARG;
 	bsa_ctx *c = p->ctx;
 	(void)hipSetDevice(c->device);
 	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->aux_stream));
 	std::vector<uint32_t> order(p->n);
 	std::vector<uint64_t> slot(p->n);
 	HIPCHK(c, hipMemcpy(order.data(), p->d_order, p->n * 4, hipMemcpyDeviceToHost));
 	HIPCHK(c, hipMemcpy(slot.data(), p->d_slot, p->n * 8, hipMemcpyDeviceToHost));
 	for(size_t pos = 0; pos < p->n; pos++){
 		if(order[pos] == pair){
-			HIPCHK(c, hipMemcpy(host, c->ws + slot[pos], bytes, hipMemcpyDeviceToHost));
+			if(bytes) HIPCHK(c, hipMemcpy(host, c->ws + slot[pos], bytes, hipMemcpyDeviceToHost));
 			if(rowb_out) *rowb_out = p->rowb;
 			return BSA_OK;
 		}
@@ -447,24 +573,12 @@ extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *c, hipStream_t *st){
 // ------------------------------------------------------------------------------------------------
 // 2-bit edit alignment plan (striped_seqedit_pairwise, bsalign.h:1046)
 // ------------------------------------------------------------------------------------------------
-struct EChunk { uint32_t first, count, bw; size_t bytes; };
-
-struct bsa_edit_plan {
-	bsa_ctx *ctx = nullptr;
-	size_t n = 0;
+struct bsa_edit_plan : PlanBase {
 	bsa_edit_params_t par;
-	double cells = 0;
-	std::vector<EChunk> chunks;
-	size_t ws_need = 0;
 	uint32_t pad_rows = 4;
-	uint64_t *d_qoff = nullptr, *d_toff = nullptr, *d_qpoff = nullptr, *d_tpoff = nullptr, *d_slot = nullptr, *d_slot_end = nullptr, *d_qboff = nullptr;
-	uint32_t *d_qlen = nullptr, *d_tlen = nullptr, *d_order = nullptr, *d_qwords = nullptr;
-	uint8_t *d_qst = nullptr, *d_tst = nullptr;
-	uint64_t *d_qbits = nullptr;
+	uint64_t *d_qboff = nullptr, *d_qbits = nullptr;
+	uint32_t *d_qwords = nullptr;
 	int32_t *d_sbeg = nullptr;
-	uint32_t *d_cnt_pos = nullptr, *d_cnt_pair = nullptr, *d_status_own = nullptr;
-	uint64_t *d_off_pos = nullptr, *d_src_pair = nullptr, *d_carry = nullptr;
-	uint32_t *d_tmp = nullptr; size_t tmp_words = 0;
 };
 
 // effective bandwidth of one pair (bsalign.h:1055-1067)
@@ -480,17 +594,7 @@ static uint32_t edit_bw_eff(uint32_t qlen, uint32_t tlen, int type, uint32_t ban
 	return bw;
 }
 
-extern "C" void bsa_edit_plan_destroy(bsa_edit_plan_t *p){
-	if(!p) return;
-	(void)hipSetDevice(p->ctx->device);
-	(void)hipStreamSynchronize(p->ctx->stream);
-	void *ptrs[] = { p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_slot_end, p->d_qboff, p->d_qlen, p->d_tlen, p->d_order,
-	                 p->d_qwords, p->d_qst, p->d_tst, p->d_qbits, p->d_sbeg, p->d_cnt_pos, p->d_cnt_pair, p->d_status_own,
-	                 p->d_off_pos, p->d_src_pair, p->d_carry, p->d_tmp };
-	for(void *q : ptrs) if(q) (void)hipFree(q);
-	delete p;
-}
-
+extern "C" void bsa_edit_plan_destroy(bsa_edit_plan_t *p){ plan_free(p); }
 extern "C" double bsa_edit_plan_cells(const bsa_edit_plan_t *p){ return p ? p->cells : 0.0; }
 
 extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const uint32_t *qlen,
@@ -503,56 +607,41 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 	(void)hipSetDevice(c->device);
 	bsa_edit_plan *p = new bsa_edit_plan();
 	p->ctx = c; p->n = n; p->par = *par;
-	std::vector<uint32_t> bwv(n), order(n), qwords(n);
+	std::vector<uint32_t> bwk(n), order(n), qwords(n);
 	double cells = 0;
 	for(size_t k = 0; k < n; k++){
-		bwv[k] = (qlen[k] && tlen[k]) ? edit_bw_eff(qlen[k], tlen[k], type, par->bandwidth) : 64u;
-		if(!bsa_edit_supported_bw(bwv[k])){
+		bwk[k] = (qlen[k] && tlen[k]) ? edit_bw_eff(qlen[k], tlen[k], type, par->bandwidth) : 64u;
+		if(!bsa_edit_supported_bw(bwk[k])){
 			c->err = "effective edit bandwidth must be <= 1024 on the device for now (overlap/extend use the full query width)";
-			delete p; return BSA_E_UNSUPPORTED;
+			plan_free(p); return BSA_E_UNSUPPORTED;
 		}
-		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bwv[k];
+		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bwk[k];
 		order[k] = (uint32_t)k;
 	}
 	p->cells = cells;
-	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return bwv[x] != bwv[y] ? bwv[x] < bwv[y] : tlen[x] > tlen[y]; });
-	std::vector<uint64_t> qpoff(n), tpoff(n), qboff(n), slot(n), slot_end(n);
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return bwk[x] != bwk[y] ? bwk[x] < bwk[y] : tlen[x] > tlen[y]; });
+	std::vector<uint64_t> qpoff(n), tpoff(n), qboff(n), slot, slot_end;
+	std::vector<size_t> need(n); std::vector<uint32_t> bwv(n);
 	size_t qacc = 0, tacc = 0, bacc = 0;
 	for(size_t k = 0; k < n; k++){
 		qpoff[k] = qacc; qacc += ((size_t)qlen[k] + 16 + 15) & ~(size_t)15;
 		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + 16 + 15) & ~(size_t)15;
-		qwords[k] = (qlen[k] + bwv[k]) / 64u + 4u;
+		qwords[k] = (qlen[k] + bwk[k]) / 64u + 4u;
 		qboff[k] = bacc; bacc += 2 * (size_t)qwords[k];
 	}
-	const size_t budget = ctx_ws_budget(c);
-	size_t acc = 0; uint32_t first = 0;
 	for(size_t pos = 0; pos < n; pos++){
 		const uint32_t k = order[pos];
-		const size_t need = ((size_t)tlen[k] + 1 + p->pad_rows) * (size_t)(bwv[k] / 64u) * 16;
-		if(need > budget){ c->err = "workspace limit too small for one pair"; delete p; return BSA_E_NOMEM; }
-		if(pos > first && (acc + need > budget || bwv[k] != bwv[order[first]])){
-			p->chunks.push_back({first, (uint32_t)(pos - first), bwv[order[first]], acc});
-			p->ws_need = std::max(p->ws_need, acc);
-			first = (uint32_t)pos; acc = 0;
-		}
-		slot[pos] = acc; acc += need; slot_end[pos] = acc;
+		bwv[pos] = bwk[k];
+		need[pos] = ((size_t)tlen[k] + 1 + p->pad_rows) * (size_t)(bwk[k] / 64u) * 16;
 	}
-	if(n > first){ p->chunks.push_back({first, (uint32_t)(n - first), bwv[order[first]], acc}); p->ws_need = std::max(p->ws_need, acc); }
-	int rc;
-	std::vector<uint64_t> vqoff(qoff, qoff + n), vtoff(toff, toff + n);
-	std::vector<uint32_t> vqlen(qlen, qlen + n), vtlen(tlen, tlen + n);
-#define TRY(x) do { rc = (x); if(rc != BSA_OK){ bsa_edit_plan_destroy(p); return rc; } } while(0)
-	TRY(dev_upload(c, &p->d_qoff, vqoff)); TRY(dev_upload(c, &p->d_toff, vtoff));
-	TRY(dev_upload(c, &p->d_qlen, vqlen)); TRY(dev_upload(c, &p->d_tlen, vtlen));
-	TRY(dev_upload(c, &p->d_qpoff, qpoff)); TRY(dev_upload(c, &p->d_tpoff, tpoff)); TRY(dev_upload(c, &p->d_qboff, qboff));
-	TRY(dev_upload(c, &p->d_qwords, qwords));
-	TRY(dev_upload(c, &p->d_slot, slot)); TRY(dev_upload(c, &p->d_slot_end, slot_end)); TRY(dev_upload(c, &p->d_order, order));
-	TRY(dev_alloc(c, &p->d_qst, qacc)); TRY(dev_alloc(c, &p->d_tst, tacc)); TRY(dev_alloc(c, &p->d_qbits, bacc));
-	TRY(dev_alloc(c, &p->d_sbeg, n));
-	TRY(dev_alloc(c, &p->d_cnt_pos, n)); TRY(dev_alloc(c, &p->d_cnt_pair, n)); TRY(dev_alloc(c, &p->d_status_own, n));
-	TRY(dev_alloc(c, &p->d_off_pos, n + 1)); TRY(dev_alloc(c, &p->d_src_pair, n)); TRY(dev_alloc(c, &p->d_carry, 1));
-	TRY(ctx_ws_reserve(c, p->ws_need));
-#undef TRY
+	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
+	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
+	if(rc == BSA_OK) rc = dev_upload(c, &p->d_qboff, qboff);
+	if(rc == BSA_OK) rc = dev_upload(c, &p->d_qwords, qwords);
+	if(rc == BSA_OK) rc = dev_alloc(c, &p->d_qbits, bacc);
+	if(rc == BSA_OK) rc = dev_alloc(c, &p->d_sbeg, n);
+	p->extra = { p->d_qboff, p->d_qwords, p->d_qbits, p->d_sbeg };
+	if(rc != BSA_OK){ plan_free(p); return rc; }
 	*out = p;
 	return BSA_OK;
 }
@@ -561,61 +650,37 @@ extern "C" int bsa_edit_run(bsa_edit_plan_t *p, const uint8_t *d_seqs, bsa_resul
 		size_t cigar_cap_words, uint64_t *d_cigar_off, uint32_t *d_status){
 	if(!p || !d_out) return BSA_E_ARG;
 	bsa_ctx *c = p->ctx;
-	(void)hipSetDevice(c->device);
-	hipStream_t st = c->stream;
 	const uint32_t n = (uint32_t)p->n;
-	c->ev_used = 0; c->last_cells = 0;
+	const bool want_cig = d_cigar != nullptr && d_cigar_off != nullptr;
+	int rc = run_prologue(p, want_cig, cigar_cap_words);
+	if(rc != BSA_OK) return rc;
+	hipStream_t st = c->stream;
 	if(n == 0){
 		if(d_cigar_off) HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t), st));
 		return BSA_OK;
 	}
 	if(!d_seqs) return BSA_E_ARG;
-	int rc = ctx_ws_reserve(c, p->ws_need);
-	if(rc != BSA_OK) return rc;
-	const bool want_cig = d_cigar != nullptr && d_cigar_off != nullptr;
-	if(want_cig && p->tmp_words < cigar_cap_words){
-		if(p->d_tmp){ HIPCHK(c, hipStreamSynchronize(st)); (void)hipFree(p->d_tmp); p->d_tmp = nullptr; }
-		if(hipMalloc((void**)&p->d_tmp, std::max<size_t>(cigar_cap_words, 1) * 4) != hipSuccess){ c->err = "cigar staging allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
-		p->tmp_words = cigar_cap_words;
-	}
 	uint32_t *status = d_status ? d_status : p->d_status_own;
 	HIPCHK(c, bsa_launch_edit_stage(d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen, p->d_qpoff, p->d_tpoff, p->d_qboff, p->d_qwords,
 		p->d_qst, p->d_tst, p->d_qbits, status, n, st));
-	HIPCHK(c, hipMemsetAsync(p->d_carry, 0, sizeof(uint64_t), st));
 	EditArgs a;
 	memset(&a, 0, sizeof(a));
 	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
 	a.qbits = p->d_qbits; a.qboff = p->d_qboff; a.qwords = p->d_qwords;
 	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
-	a.rows = c->ws; a.status = status; a.fwd_sbeg = p->d_sbeg; a.pad_rows = p->pad_rows; a.mode = p->par.mode;
-	for(const EChunk &ch : p->chunks){
-		a.first = ch.first; a.count = ch.count; a.bw = ch.bw;
-		hipEvent_t e0, e1;
-		rc = ctx_event_pair(c, &e0, &e1); if(rc != BSA_OK) return rc;
-		HIPCHK(c, hipEventRecord(e0, st));
-		HIPCHK(c, bsa_launch_edit_fwd(a, st));
-		HIPCHK(c, hipEventRecord(e1, st));
-		HIPCHK(c, bsa_launch_edit_trace(a, d_out, p->d_cnt_pos, st));
-		if(want_cig){
-			hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry);
-			HIPCHK(c, hipGetLastError());
-			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, st, c->ws, p->d_slot_end,
-				ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
-			HIPCHK(c, hipGetLastError());
-		}
-	}
-	c->last_cells = p->cells;
-	if(want_cig){
-		hipLaunchKernelGGL(k_cnt_by_pair, dim3((n + 255) / 256), dim3(256), 0, st, p->d_order, p->d_cnt_pos, p->d_off_pos, p->d_cnt_pair, p->d_src_pair, n);
-		HIPCHK(c, hipGetLastError());
-		hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, p->d_cnt_pair, d_cigar_off, n, (uint64_t*)nullptr);
-		HIPCHK(c, hipGetLastError());
-		hipLaunchKernelGGL(k_cigar_final, dim3((n + 3) / 4), dim3(256), 0, st, p->d_tmp, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
-		HIPCHK(c, hipGetLastError());
-	} else if(d_cigar_off){
-		HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t) * ((size_t)n + 1), st));
-	}
-	return BSA_OK;
+	a.status = status; a.fwd_sbeg = p->d_sbeg; a.pad_rows = p->pad_rows; a.mode = p->par.mode;
+	uint32_t *cnt = p->d_cnt_pos;
+	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
+		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.bw = ch.bw; b.rows = half;
+		HIPCHK(c, bsa_launch_edit_fwd(b, s));
+		return BSA_OK;
+	};
+	auto trace = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
+		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.bw = ch.bw; b.rows = half;
+		HIPCHK(c, bsa_launch_edit_trace(b, d_out, cnt, s));
+		return BSA_OK;
+	};
+	return run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);
 }
 
 extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_bytes,
@@ -629,33 +694,8 @@ extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_byt
 	bsa_edit_plan_t *p = nullptr;
 	int rc = bsa_edit_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
 	if(rc != BSA_OK) return rc;
-	uint8_t *d_seqs = nullptr; bsa_result_t *d_out = nullptr; uint32_t *d_cig = nullptr, *d_status = nullptr; uint64_t *d_off = nullptr;
-	auto cleanup = [&](){
-		if(d_seqs) (void)hipFree(d_seqs); if(d_out) (void)hipFree(d_out); if(d_cig) (void)hipFree(d_cig);
-		if(d_status) (void)hipFree(d_status); if(d_off) (void)hipFree(d_off);
-		bsa_edit_plan_destroy(p);
-	};
-	const bool want_cig = cigar && cigar_off;
-#define TRYH(call) do { hipError_t _e = (call); if(_e != hipSuccess){ c->err = std::string(#call) + ": " + hipGetErrorString(_e); cleanup(); return BSA_E_HIP; } } while(0)
-	TRYH(hipMalloc((void**)&d_seqs, std::max<size_t>(seqs_bytes, 1)));
-	TRYH(hipMalloc((void**)&d_out, n * sizeof(bsa_result_t)));
-	TRYH(hipMalloc((void**)&d_status, n * sizeof(uint32_t)));
-	if(want_cig){
-		TRYH(hipMalloc((void**)&d_cig, std::max<size_t>(cigar_cap_words, 1) * 4));
-		TRYH(hipMalloc((void**)&d_off, (n + 1) * sizeof(uint64_t)));
-	}
-	TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
-	rc = bsa_edit_run(p, d_seqs, d_out, d_cig, cigar_cap_words, d_off, d_status);
-	if(rc != BSA_OK){ cleanup(); return rc; }
-	TRYH(hipMemcpyAsync(out, d_out, n * sizeof(bsa_result_t), hipMemcpyDeviceToHost, c->stream));
-	if(status) TRYH(hipMemcpyAsync(status, d_status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-	if(want_cig) TRYH(hipMemcpyAsync(cigar_off, d_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-	TRYH(hipStreamSynchronize(c->stream));
-	if(want_cig){
-		if(cigar_off[n] > cigar_cap_words){ cleanup(); c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
-		TRYH(hipMemcpy(cigar, d_cig, cigar_off[n] * 4, hipMemcpyDeviceToHost));
-	}
-#undef TRYH
-	cleanup();
-	return BSA_OK;
+	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, status,
+		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_edit_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });
+	bsa_edit_plan_destroy(p);
+	return rc;
 }
