@@ -231,17 +231,12 @@ class AlignPlan:
                                           C.c_void_p(d_cigar_off.data_ptr() if d_cigar_off is not None else 0),
                                           C.c_void_p(d_status.data_ptr() if d_status is not None else 0)))
 
-    def debug_rows(self, pair):
-        """row records of `pair` after a single-chunk run: (bytes array [tlen+1, rowb])"""
-        rowb = C.c_uint32()
-        tl = int(self.tlen[pair])
-        # rowb is not known before the call: fetch generously, then trim
-        buf = np.zeros((tl + 1) * 4096, dtype=np.uint8)
-        self.ctx._chk(lib().bsa_align_debug_rows(self.h, pair, _p(buf), 0, C.byref(rowb)))
-        nbytes = (tl + 1) * rowb.value
+    def debug_slot(self, pair, nbytes):
+        """raw traceback slot of `pair` after a single-chunk run (band offsets + row records, layout in csrc/bsa_common.h)"""
         buf = np.zeros(nbytes, dtype=np.uint8)
+        rowb = C.c_uint32()
         self.ctx._chk(lib().bsa_align_debug_rows(self.h, pair, _p(buf), nbytes, C.byref(rowb)))
-        return buf.reshape(tl + 1, rowb.value)
+        return buf
 
     def close(self):
         if self.h:

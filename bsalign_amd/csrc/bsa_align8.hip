@@ -18,62 +18,8 @@
 // HBM traffic per row and pair: one row record (see bsa_common.h) = (pw+1)*bw + 72 bytes written once;
 // the traceback kernel re-derives the path from those records exactly like the reference's backcal.
 #include "bsa_common.h"
-
-// Every DPP move is made opaque to the optimiser.  ROCm 7.2's DPP combiner folds a v_mov_b32_dpp into a
-// following subtraction as `v_subrev_u32_dpp vdst, vsrc(dpp), vdst`, and on gfx950 that instruction returns
-// dpp(vdst) - vsrc instead of vdst - dpp(vsrc) (measured on hardware, scratch/dpp_test.hip); keeping the move
-// explicit costs one VALU op and is always right.
-static __device__ __forceinline__ int dpp_keep(int x){ asm("" : "+v"(x)); return x; }
-#define DPP_SHR(fill, x, n)  dpp_keep(__builtin_amdgcn_update_dpp((fill), (x), 0x110 + (n), 0xf, 0xf, false))  // lane j <- lane j-n (row of 16)
-#define DPP_SHL(fill, x, n)  dpp_keep(__builtin_amdgcn_update_dpp((fill), (x), 0x100 + (n), 0xf, 0xf, false))  // lane j <- lane j+n
-#define DPP_BCAST(x, n)      dpp_keep(__builtin_amdgcn_update_dpp(0, (x), 0x150 + (n), 0xf, 0xf, false))       // row_newbcast:n
-#define DPP_ROR(x, n)        dpp_keep(__builtin_amdgcn_update_dpp(0, (x), 0x120 + (n), 0xf, 0xf, false))       // row rotate right
-
-#define BIGNEG (-(1 << 28))
-
-static __device__ __forceinline__ int sat8(int v){ return min(max(v, -128), 127); }     // _mm_adds_epi8 / _mm_subs_epi8
-static __device__ __forceinline__ int trunc8(int v){ return (int)(int8_t)v; }            // int -> b1i store
-static __device__ __forceinline__ int row_sum16(int x){                                   // sum over the 16 lanes of a DPP row, in every lane
-	x += DPP_ROR(x, 8); x += DPP_ROR(x, 4); x += DPP_ROR(x, 2); x += DPP_ROR(x, 1);
-	return x;
-}
-static __device__ __forceinline__ int row_iscan16(int x){                                 // inclusive prefix sum over the DPP row
-	x += DPP_SHR(0, x, 1); x += DPP_SHR(0, x, 2); x += DPP_SHR(0, x, 4); x += DPP_SHR(0, x, 8);
-	return x;
-}
-
-// active F-loop, literal serial form (bsalign.h:2639-2652): 15 dependent lane-to-lane steps
-static __device__ __forceinline__ int fpen_serial(int f, int ubA, int ubB, int t, int j){
-	int fs = DPP_SHR(BSA_EPI8_MIN, f, 1);       // fs[j] = f[j-1], fs[0] = -63
-	const int dd = ubB - ubA;
-#pragma unroll
-	for(int step = 1; step < 16; step++){
-		int sv  = t + fs - dd;                  // s leaving lane j
-		int sin = DPP_SHR(0, sv, 1);            // s entering lane j
-		int cand = (fs < sin) ? trunc8(sin) : fs;
-		fs = (j == step) ? cand : fs;
-	}
-	return fs;
-}
-
-// same result through a 4-step max-plus scan; falls back to the serial form when an int->int8
-// truncation could have fired (some entering s > 127), which is the only way the two can differ
-static __device__ __forceinline__ int fpen(int f, int ubA, int ubB, int t, int j){
-#ifdef BSA_FPEN_SERIAL
-	return fpen_serial(f, ubA, ubB, t, j);
-#else
-	const int fs = DPP_SHR(BSA_EPI8_MIN, f, 1);
-	const int c  = t - (ubB - ubA);             // fs'[j+1] = max(fs[j+1], fs'[j] + c[j])
-	int A = DPP_SHR(BIGNEG, c, 1);              // map of lane j: x -> max(x + A, B); lane 0 ignores x
-	int B = fs;
-#define FPEN_STEP(n) { int A1 = DPP_SHR(0, A, n); int B1 = DPP_SHR(BIGNEG, B, n); B = max(B1 + A, B); A = max(A1 + A, 2 * BIGNEG); }
-	FPEN_STEP(1) FPEN_STEP(2) FPEN_STEP(4) FPEN_STEP(8)
-#undef FPEN_STEP
-	const int sprev = DPP_SHR(BIGNEG, B + c, 1);
-	if(__any(sprev > 127)) return fpen_serial(f, ubA, ubB, t, j);
-	return B;
-#endif
-}
+#include "bsa_dpp.h"
+#include <cstdlib>
 
 template<int W> struct QCodes { uint32_t w[(W + 3) / 4]; };
 
@@ -105,7 +51,8 @@ __global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
 	uint32_t tlen = a.tlen[pair];
 	const uint8_t *qp = a.qst + a.qpoff[pair];
 	const uint8_t *tp = a.tst + a.tpoff[pair];
-	uint8_t *rowp = a.rows + a.slot_off[ppos];
+	int *begs = (int*)(a.rows + a.slot_off[ppos]);
+	uint8_t *rowp = (uint8_t*)begs + bsa_begs_bytes(tlen);
 	if(!live || a.status[pair] != 0u) tlen = 0;
 	const uint32_t rowb = a.rowb;
 	int8_t *gl = smem + (lt >> 4) * GROUP_LDS;
@@ -149,35 +96,30 @@ __global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
 		ubB = base0 + inc;
 		ubA = ubB - bs;
 	}
-	auto store_row = [&](uint8_t *rp, uint32_t rbeg_v){
-		// natural band order: lane j owns bytes [j*W, j*W+W)
+	constexpr uint32_t CELLS = ((uint32_t)(PW + 1) * W + 3u) & ~3u, BLK = CELLS + 4u;
+	auto store_row = [&](uint32_t row_index, uint32_t rbeg_v){
+		// block-interleaved record (bsa_common.h): lane j writes its u / e / q bytes and ubegs[j] contiguously
+		uint8_t *bp = rowp + (size_t)row_index * rowb + (uint32_t)j * BLK;
 		if constexpr (W >= 4){
 #pragma unroll
 			for(int n = 0; n < W / 4; n++){
-				uint32_t wu = (uint32_t)(u[4*n] & 0xff) | ((uint32_t)(u[4*n+1] & 0xff) << 8) | ((uint32_t)(u[4*n+2] & 0xff) << 16) | ((uint32_t)u[4*n+3] << 24);
-				((uint32_t*)(rp + j * W))[n] = wu;
-				if(PW >= 1){
-					uint32_t we = (uint32_t)(e[4*n] & 0xff) | ((uint32_t)(e[4*n+1] & 0xff) << 8) | ((uint32_t)(e[4*n+2] & 0xff) << 16) | ((uint32_t)e[4*n+3] << 24);
-					((uint32_t*)(rp + BW + j * W))[n] = we;
-				}
-				if(PW == 2){
-					uint32_t wq = (uint32_t)(q2[4*n] & 0xff) | ((uint32_t)(q2[4*n+1] & 0xff) << 8) | ((uint32_t)(q2[4*n+2] & 0xff) << 16) | ((uint32_t)q2[4*n+3] << 24);
-					((uint32_t*)(rp + 2 * BW + j * W))[n] = wq;
-				}
+				((uint32_t*)bp)[n] = (uint32_t)(u[4*n] & 0xff) | ((uint32_t)(u[4*n+1] & 0xff) << 8) | ((uint32_t)(u[4*n+2] & 0xff) << 16) | ((uint32_t)u[4*n+3] << 24);
+				if(PW >= 1) ((uint32_t*)(bp + W))[n] = (uint32_t)(e[4*n] & 0xff) | ((uint32_t)(e[4*n+1] & 0xff) << 8) | ((uint32_t)(e[4*n+2] & 0xff) << 16) | ((uint32_t)e[4*n+3] << 24);
+				if(PW == 2) ((uint32_t*)(bp + 2 * W))[n] = (uint32_t)(q2[4*n] & 0xff) | ((uint32_t)(q2[4*n+1] & 0xff) << 8) | ((uint32_t)(q2[4*n+2] & 0xff) << 16) | ((uint32_t)q2[4*n+3] << 24);
 			}
 		} else {
 #pragma unroll
-			for(int i = 0; i < W; i++){
-				rp[j * W + i] = (uint8_t)u[i];
-				if(PW >= 1) rp[BW + j * W + i] = (uint8_t)e[i];
-				if(PW == 2) rp[2 * BW + j * W + i] = (uint8_t)q2[i];
+			for(int k = 0; k < W; k++){
+				bp[k] = (uint8_t)u[k];
+				if(PW >= 1) bp[W + k] = (uint8_t)e[k];
+				if(PW == 2) bp[2 * W + k] = (uint8_t)q2[k];
 			}
 		}
-		int *ubp = (int*)(rp + (PW + 1) * BW);
-		ubp[j] = ubA;
-		if(j == 15){ ubp[16] = ubB; ubp[17] = (int)rbeg_v; }
+		*(int*)(bp + CELLS) = ubA;
+		if(j == 15) *(int*)(bp + BLK) = ubB;
+		if(j == 0) begs[row_index] = (int)rbeg_v;
 	};
-	if(tlen) store_row(rowp, 0u);
+	if(tlen) store_row(0u, 0u);
 
 	uint32_t rbeg = 0, mov = 0, i = 0;
 	int tb_next = tlen ? (int)tp[0] : 0;
@@ -392,7 +334,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
 			if(j == 0){ nA = ubA + u[0]; u[0] = 0; }         // re-base: ubegs[0] = H(0), u[0] = 0
 			ubA = nA; ubB = nB;
 		}
-		if(act) store_row(rowp + (size_t)(i + 1) * rowb, rbeg);
+		if(act) store_row(i + 1u, rbeg);
 		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
 		{
 			int dsum = ubB - ubA; dsum = dsum < 0 ? -dsum : dsum;
@@ -431,17 +373,18 @@ __global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
 // end of the pair's (already consumed) row slot and come out in forward order.
 // ---------------------------------------------------------------------------------------------
 struct RowView {
-	const uint8_t *base; uint32_t rowb, bw, W; int pw;
-	__device__ __forceinline__ const uint8_t* rec(int row) const { return base + (size_t)(row + 1) * rowb; }
-	__device__ __forceinline__ const int* ub(int row) const { return (const int*)(rec(row) + (size_t)(pw + 1) * bw); }
-	__device__ __forceinline__ int beg(int row) const { return ub(row)[17]; }
+	const uint8_t *rows; const int *begs; uint32_t rowb, bw, W, cells, blk; int pw;
+	__device__ __forceinline__ const uint8_t* rec(int row) const { return rows + (size_t)(row + 1) * rowb; }
+	__device__ __forceinline__ const int8_t* blkp(int row, uint32_t y) const { return (const int8_t*)(rec(row) + y * blk); }
+	__device__ __forceinline__ int ubv(int row, uint32_t y) const { return *(const int*)(rec(row) + y * blk + (y < 16u ? cells : 0u)); }   // ubegs[16] follows block 15
+	__device__ __forceinline__ int beg(int row) const { return begs[row + 1]; }
 	__device__ __forceinline__ int getscore(int row, long pos) const {       // bsalign.h:3187-3197
 		uint32_t p = (uint32_t)pos;
 		if(p >= bw) p = bw - 1;                                              // keep reads inside the record
-		uint32_t y = p / W, x = p % W;
-		const int8_t *us = (const int8_t*)rec(row);
-		int s = ub(row)[y];
-		for(uint32_t k = 0; k <= x; k++) s += us[y * W + k];
+		const uint32_t y = p / W, x = p % W;
+		const int8_t *us = blkp(row, y);
+		int s = *(const int*)((const uint8_t*)us + cells);
+		for(uint32_t k = 0; k <= x; k++) s += us[k];
 		return s;
 	}
 	__device__ __forceinline__ int mtx_getscore(int row, int col) const { return getscore(row, (long)col - beg(row)); }
@@ -449,17 +392,16 @@ struct RowView {
 
 static __device__ uint32_t row_max_dev(const RowView &R, int row, int *max_score){ // bsalign.h:3213-3329
 	const uint32_t W = R.W, STEP = 32;
-	const int8_t *us = (const int8_t*)R.rec(row);
-	const int *ubegs = R.ub(row);
 	int lmax[16]; uint32_t lchunk[16];
 	for(uint32_t l = 0; l < 16; l++){
-		int base = ubegs[l];
+		const int8_t *us = R.blkp(row, l);
+		int base = R.ubv(row, l);
 		lmax[l] = BSA_SCORE_MIN; lchunk[l] = 0;
 		for(uint32_t i = 0, c = 0; i < W; i += STEP, c++){
 			uint32_t n = (i + STEP < W) ? STEP : W - i;
 			int run = 0, cmax = -32767;
 			for(uint32_t x = 0; x < n; x++){
-				run += us[l * W + i + x];
+				run += us[i + x];
 				run = min(max(run, -32768), 32767);
 				cmax = max(cmax, run);
 			}
@@ -482,8 +424,9 @@ static __device__ uint32_t row_max_dev(const RowView &R, int row, int *max_score
 	*max_score = best;
 	uint32_t x = lchunk[lane] * STEP, y = min(x + STEP, W), jj = x;
 	int umax = BSA_SCORE_MIN, uscr = 0;
+	const int8_t *usl = R.blkp(row, (uint32_t)lane);
 	for(; x < y; x++){
-		uscr += us[lane * W + x];
+		uscr += usl[x];
 		if(uscr > umax){ jj = x; umax = uscr; }
 	}
 	return (uint32_t)lane * W + jj;
@@ -500,12 +443,14 @@ __global__ void __launch_bounds__(64) k_align8_backcal(const Align8Args a, int p
 	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
 	const uint8_t *qseq = a.qst + a.qpoff[pair];
 	const uint8_t *tseq = a.tst + a.tpoff[pair];
-	RowView R; R.base = a.rows + a.slot_off[ppos]; R.rowb = a.rowb; R.bw = a.bw; R.W = a.bw / 16; R.pw = pw;
+	RowView R;
+	R.begs = (const int*)(a.rows + a.slot_off[ppos]); R.rows = (const uint8_t*)R.begs + bsa_begs_bytes(tlen);
+	R.rowb = a.rowb; R.bw = a.bw; R.W = a.bw / 16; R.pw = pw; R.cells = bsa_blk_cells(R.W, pw); R.blk = R.cells + 4u;
 	const uint32_t bw = a.bw, W = R.W;
 	const int mode = a.mode & 3;
 	const int gapo1 = a.gapo1, gape1 = a.gape1, gapo2 = a.gapo2, gape2 = a.gape2;
 	// cigar scratch: the tail end of this pair's slot (tlen + 3 row records long)
-	uint32_t *cig_end = (uint32_t*)(R.base + (size_t)(tlen + 3) * a.rowb);
+	uint32_t *cig_end = (uint32_t*)(const_cast<uint8_t*>(R.rows) + (size_t)(tlen + 3) * a.rowb);
 	uint32_t ncig = 0;
 	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
 	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
@@ -558,7 +503,7 @@ __global__ void __launch_bounds__(64) k_align8_backcal(const Align8Args a, int p
 			if(rs.qb < 0 || rs.tb < 0) break;
 			const int pbeg = R.beg(rs.tb - 1);
 			if(rs.qb == pbeg){
-				if(rs.qb){ Hs0 = R.ub(rs.tb - 1)[0]; prior_match = 0; }
+				if(rs.qb){ Hs0 = R.ubv(rs.tb - 1, 0u); prior_match = 0; }
 				else if(mode == BSA_MODE_OVERLAP || rs.tb == 0) Hs0 = 0;
 				else if(pw < 2) Hs0 = gapo1 + gape1 * rs.tb;
 				else Hs0 = max(gapo1 + gape1 * rs.tb, gapo2 + gape2 * rs.tb);
@@ -568,10 +513,11 @@ __global__ void __launch_bounds__(64) k_align8_backcal(const Align8Args a, int p
 			const int x = rs.qb - pbeg;
 			int uu = 0, ee = 0, qq = 0;
 			if(x >= 0 && x < (int)bw){
-				const int8_t *pr = (const int8_t*)R.rec(rs.tb - 1);
-				uu = pr[x];
-				ee = (pw >= 1) ? pr[bw + x] : gapo1 + gape1;
-				qq = (pw == 2) ? pr[2 * bw + x] : 0;
+				const int8_t *pr = R.blkp(rs.tb - 1, (uint32_t)x / W);
+				const uint32_t xk = (uint32_t)x % W;
+				uu = pr[xk];
+				ee = (pw >= 1) ? pr[W + xk] : gapo1 + gape1;
+				qq = (pw == 2) ? pr[2 * W + xk] : 0;
 			}
 			const int s = a.matrix[qseq[rs.qb] * 4 + tseq[rs.tb]];
 			const int h = Hs1 - Hs0;
@@ -668,6 +614,9 @@ bool bsa_align8_supported_bw(uint32_t bw){
 }
 
 hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st){
+	// packed two-pairs-per-row kernel where its preconditions hold (BSA_ALIGN8_I32=1 forces the int32 kernel)
+	static const bool force_i32 = [](){ const char *e = getenv("BSA_ALIGN8_I32"); return e && e[0] == '1'; }();
+	if(!force_i32 && bsa_align8_pk_supported(a, pw)) return bsa_launch_align8_fwd_pk(a, pw, st);
 	switch(a.bw / 16){
 		case 1:  return launch_fwd_pw<1>(a, pw, st);
 		case 2:  return launch_fwd_pw<2>(a, pw, st);

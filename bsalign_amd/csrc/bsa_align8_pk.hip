@@ -1,0 +1,487 @@
+// bsa_align8_pk.hip -- packed variant of the 8-bit banded striped forward DP: TWO pairs per 16-lane DPP row.
+//
+// Same algorithm, same row records and same bit-exact results as k_align8_fwd (bsa_align8.hip; reference
+// functions cited there), but every cell register holds two independent alignments: pair A in bits 15..0 and
+// pair B in bits 31..16, each as value << 8 in an int16.  In that form the int16-saturating packed VALU ops
+// (v_pk_add_i16 / v_pk_sub_i16 with clamp, v_pk_max_i16) ARE the reference's int8-saturating SSE ops:
+//   (a << 8) + (b << 8) saturates at -32768 = (-128) << 8 and at 32767, which one AND with 0xFF00FF00 turns
+//   into 127 << 8.  That normalisation is applied exactly where a positive overflow is possible (h - v, h - u,
+//   f - u); it is provably unnecessary after adding the non-positive gap constants and for e + u (e <= 0 always).
+// A wave64 therefore advances 8 pairs per row step with roughly the instruction count the int32 kernel needs
+// for 4.  Per-pair scalars (band offset, ubegs, steering) stay 32-bit and are computed per half.
+// Requires gape1, gapo1+gape1 (and gape2, gapo2+gape2 for 2-piece gaps) <= 0; the dispatcher falls back to the
+// int32 kernel otherwise.
+#include "bsa_common.h"
+#include "bsa_dpp.h"
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ v2s as_v2s(uint32_t a){ return __builtin_bit_cast(v2s, a); }
+static __device__ __forceinline__ uint32_t as_u32(v2s a){ return __builtin_bit_cast(uint32_t, a); }
+static __device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b){ return as_u32(__builtin_elementwise_add_sat(as_v2s(a), as_v2s(b))); }
+static __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b){ return as_u32(__builtin_elementwise_sub_sat(as_v2s(a), as_v2s(b))); }
+static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b){ return as_u32(__builtin_elementwise_max(as_v2s(a), as_v2s(b))); }
+static __device__ __forceinline__ uint32_t pk_norm(uint32_t a){ return a & 0xFF00FF00u; }
+static __device__ __forceinline__ int pk_get(uint32_t x, int h){ return h ? ((int)x >> 24) : __builtin_amdgcn_sbfe((int)x, 8, 8); }
+static __device__ __forceinline__ uint32_t pk_make(int a, int b){ return (((uint32_t)a & 0xffu) << 8) | ((uint32_t)b << 24); }
+static __device__ __forceinline__ uint32_t pk_splat(int x){ return pk_make(x, x); }
+static __device__ __forceinline__ uint32_t pk_dpp_shr1(uint32_t fill, uint32_t x){ return (uint32_t)DPP_SHR((int)fill, (int)x, 1); }
+static __device__ __forceinline__ uint32_t pk_dpp_shl1(uint32_t fill, uint32_t x){ return (uint32_t)DPP_SHL((int)fill, (int)x, 1); }
+
+template<int W>
+static __device__ __forceinline__ void load_qcodes_pk(const uint8_t *p, uint32_t *w){
+	if constexpr (W >= 4) __builtin_memcpy(w, p, W);
+	else if constexpr (W == 2){ uint16_t v; __builtin_memcpy(&v, p, 2); w[0] = v | 0x04040000u; }
+	else w[0] = p[0] | 0x04040400u;
+}
+
+template<int W, int PW>
+__global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
+	constexpr int BW = W * 16;
+	constexpr int NQ = (W + 3) / 4;
+	extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // generic movx scratch: per pair (PW+1)*BW bytes + 17 ints
+	constexpr int PAIR_LDS = ((PW + 1) * BW + 17 * 4 + 15) & ~15;
+	const int lt = threadIdx.x;
+	const int j = lt & 15;
+	const uint32_t g = (blockIdx.x * 256u + lt) >> 4;
+	uint32_t qlen[2], tlen[2];
+	const uint8_t *qp[2], *tp[2];
+	uint8_t *rowp[2];
+	int *begs[2];
+#pragma unroll
+	for(int h = 0; h < 2; h++){
+		const uint32_t idx = 2u * g + h;
+		const bool live = idx < a.count;
+		const uint32_t ppos = a.first + (live ? idx : 0u);
+		const uint32_t pair = a.order[ppos];
+		qlen[h] = a.qlen[pair]; tlen[h] = a.tlen[pair];
+		qp[h] = a.qst + a.qpoff[pair]; tp[h] = a.tst + a.tpoff[pair];
+		begs[h] = (int*)(a.rows + a.slot_off[ppos]);
+		rowp[h] = (uint8_t*)begs[h] + bsa_begs_bytes(tlen[h]);
+		if(!live || a.status[pair] != 0u) tlen[h] = 0;
+	}
+	const uint32_t rowb = a.rowb;
+	int8_t *gl = smem + (lt >> 4) * (2 * PAIR_LDS);
+
+	const int mode = a.mode & 3;
+	const int gapo1 = a.gapo1, gape1 = a.gape1, gapo2 = a.gapo2, gape2 = a.gape2;
+	const int GapE = trunc8(gape1), GapOE = trunc8(gapo1 + gape1);
+	const int GapP = trunc8(gape2), GapQP = trunc8(gapo2 + gape2);
+	const int GapOQ = sat8(GapOE - GapQP);
+	const uint32_t GE = pk_splat(GapE), GOE = pk_splat(GapOE), GP = pk_splat(GapP), GQP = pk_splat(GapQP), GOQ = pk_splat(GapOQ);
+	const uint32_t MIN63 = pk_splat(BSA_EPI8_MIN);
+	const int cfirst = (PW == 2) ? (min(a.smin, gapo2 + gape2) - 1 - a.smax + (gapo2 + gape2))
+	                             : (min(a.smin, gapo1 + gape1) - 1 - a.smax + (gapo1 + gape1));
+	const int dsw = (PW == 2) ? (gapo1 - gapo2) / (gape2 - gape1) : (BW + 1);
+	auto newcell_int = [&](int k) -> int { return (k == 0) ? cfirst : ((PW == 2 && k >= dsw) ? gape2 : gape1); };
+	auto newcell_cum = [&](int n) -> int {
+		int n1 = min(n, dsw);
+		return cfirst + (n1 - 1) * gape1 + ((PW == 2) ? max(0, n - dsw) * gape2 : 0);
+	};
+
+	uint32_t u[W], e[W], q2[W];
+	int ubA[2], ubB[2];
+	// ---- row -1 (bsalign.h:2094-2140): identical for both halves
+	{
+		int bs = 0;
+		const int first = trunc8(gapo1 + gape1 + a.smin - a.smax);
+		const int xp = (PW == 2) ? (gapo2 - gapo1) / (gape1 - gape2) : 0;
+#pragma unroll
+		for(int k = 0; k < W; k++){
+			int p = j * W + k, v;
+			if(mode == BSA_MODE_OVERLAP) v = 0;
+			else if(p == 0) v = first;
+			else if(PW == 2) v = (p < xp) ? gape1 : gape2;
+			else v = gape1;
+			u[k] = pk_splat(v); bs += v;
+			e[k] = MIN63; q2[k] = MIN63;
+		}
+		int inc = row_iscan16(bs);
+		int base0 = (mode == BSA_MODE_OVERLAP) ? 0 : (a.smax - a.smin);
+		ubB[0] = ubB[1] = base0 + inc;
+		ubA[0] = ubA[1] = base0 + inc - bs;
+	}
+	// row record store (block-interleaved record, bsa_common.h): bytes of pair A sit in byte 1, of pair B in
+	// byte 3 of every cell register; lane j writes its u / e / q bytes and ubegs[j] contiguously
+	constexpr uint32_t CELLS = ((uint32_t)(PW + 1) * W + 3u) & ~3u, BLK = CELLS + 4u;
+	auto store_rows = [&](uint32_t row_index, const bool *act, const uint32_t *rbeg_v){
+		if constexpr (W >= 4){
+			uint32_t wa[3][W / 4], wb[3][W / 4];
+#pragma unroll
+			for(int n = 0; n < W / 4; n++){
+#pragma unroll
+				for(int arr = 0; arr <= PW; arr++){
+					const uint32_t *x = (arr == 0) ? u : (arr == 1) ? e : q2;
+					const uint32_t t01 = __builtin_amdgcn_perm(x[4*n+1], x[4*n],   0x07030501u);   // {A0, A1, B0, B1}
+					const uint32_t t23 = __builtin_amdgcn_perm(x[4*n+3], x[4*n+2], 0x07030501u);   // {A2, A3, B2, B3}
+					wa[arr][n] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+					wb[arr][n] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+				}
+			}
+#pragma unroll
+			for(int h = 0; h < 2; h++){
+				if(act[h]){
+					uint32_t *bp = (uint32_t*)(rowp[h] + (size_t)row_index * rowb + (uint32_t)j * BLK);
+#pragma unroll
+					for(int arr = 0; arr <= PW; arr++){
+#pragma unroll
+						for(int n = 0; n < W / 4; n++) bp[arr * (W / 4) + n] = h ? wb[arr][n] : wa[arr][n];
+					}
+					bp[CELLS / 4] = (uint32_t)ubA[h];
+					if(j == 15) bp[BLK / 4] = (uint32_t)ubB[h];
+					if(j == 0) begs[h][row_index] = (int)rbeg_v[h];
+				}
+			}
+		} else {
+#pragma unroll
+			for(int h = 0; h < 2; h++){
+				if(act[h]){
+					uint8_t *bp = rowp[h] + (size_t)row_index * rowb + (uint32_t)j * BLK;
+#pragma unroll
+					for(int k = 0; k < W; k++){
+						bp[k] = (uint8_t)pk_get(u[k], h);
+						if(PW >= 1) bp[W + k] = (uint8_t)pk_get(e[k], h);
+						if(PW == 2) bp[2 * W + k] = (uint8_t)pk_get(q2[k], h);
+					}
+					*(int*)(bp + CELLS) = ubA[h];
+					if(j == 15) *(int*)(bp + BLK) = ubB[h];
+					if(j == 0) begs[h][row_index] = (int)rbeg_v[h];
+				}
+			}
+		}
+	};
+	uint32_t rbeg[2] = {0, 0}, mov[2] = {0, 0}, i = 0;
+	{
+		bool act0[2] = { tlen[0] != 0, tlen[1] != 0 };
+		store_rows(0, act0, rbeg);
+	}
+	int tb_next[2];
+	double dq[2], dt[2];
+#pragma unroll
+	for(int h = 0; h < 2; h++){ tb_next[h] = tlen[h] ? (int)tp[h][0] : 0; dq[h] = (double)qlen[h]; dt[h] = (double)tlen[h]; }
+
+	while(__any(i < tlen[0] || i < tlen[1])){
+		bool act[2];
+		int rh[2];
+		bool slow = false;
+#pragma unroll
+		for(int h = 0; h < 2; h++){
+			act[h] = i < tlen[h];
+			// ---- band offset of this row (bsalign.h:3932-3946)
+			const bool moved = (mov[h] != 0u) && (rbeg[h] + BW < qlen[h]);
+			const uint32_t room = qlen[h] - (rbeg[h] + BW);
+			mov[h] = moved ? min(mov[h], room) : 0u;
+			rbeg[h] += mov[h];
+			if(rbeg[h]) rh[h] = BSA_SCORE_MIN;
+			else if(mode == BSA_MODE_OVERLAP || i == 0) rh[h] = 0;
+			else if(PW < 2) rh[h] = gapo1 + gape1 * (int)i;
+			else rh[h] = max(gapo1 + gape1 * (int)i, gapo2 + gape2 * (int)i);
+			slow = slow || (act[h] && mov[h] >= (uint32_t)W);
+		}
+		// ---- row_movx (bsalign.h:2244-2392)
+		if(__any(slow)){
+			// generic path through LDS for both halves (rare: band jump of >= W cells)
+#pragma unroll
+			for(int h = 0; h < 2; h++){
+				int8_t *su = gl + h * PAIR_LDS, *se = su + BW, *sq = su + 2 * BW;
+				int *sub = (int*)(su + (PW + 1) * BW);
+#pragma unroll
+				for(int k = 0; k < W; k++){
+					su[j * W + k] = (int8_t)pk_get(u[k], h);
+					if(PW >= 1) se[j * W + k] = (int8_t)pk_get(e[k], h);
+					if(PW == 2) sq[j * W + k] = (int8_t)pk_get(q2[k], h);
+				}
+				sub[j] = ubA[h]; if(j == 15) sub[16] = ubB[h];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			int nu[2][W], ne[2][W], nq[2][W];
+#pragma unroll
+			for(int h = 0; h < 2; h++){
+				const int8_t *su = gl + h * PAIR_LDS, *se = su + BW, *sq = su + 2 * BW;
+				const int *sub = (const int*)(su + (PW + 1) * BW);
+				const uint32_t mv = mov[h];
+#pragma unroll
+				for(int k = 0; k < W; k++){ nu[h][k] = su[j * W + k]; ne[h][k] = (PW >= 1) ? se[j * W + k] : 0; nq[h][k] = (PW == 2) ? sq[j * W + k] : 0; }
+				if(mv){
+					uint32_t pp = min(mv - 1u, (uint32_t)BW - 1u), yy = pp / W, xx = pp % W;
+					int s = sub[yy];
+					for(uint32_t k = 0; k <= xx; k++) s += su[yy * W + k];
+					rh[h] = s;
+				}
+				if(mv >= (uint32_t)BW){
+#pragma unroll
+					for(int k = 0; k < W; k++){ nu[h][k] = 0; ne[h][k] = 0; nq[h][k] = 0; }
+					ubA[h] = ubB[h] = BSA_SCORE_MIN;
+				} else if(mv){
+					const uint32_t cyc = mv / W, m = mv % W, p0 = BW - mv;
+#pragma unroll
+					for(int k = 0; k < W; k++){
+						uint32_t src = j * W + k + mv;
+						if(src < (uint32_t)BW){
+							nu[h][k] = su[src];
+							if(PW >= 1) ne[h][k] = se[src];
+							if(PW == 2) nq[h][k] = sq[src];
+						} else {
+							nu[h][k] = trunc8(newcell_int((int)(src - BW)));
+							ne[h][k] = 0; nq[h][k] = 0;
+						}
+					}
+					auto new_ub = [&](uint32_t idx) -> int {
+						int v;
+						if(idx + cyc < 16u){
+							uint32_t l = idx + cyc;
+							v = sub[l];
+							for(uint32_t k = 0; k < m; k++) v += su[l * W + k];
+						} else v = sub[16];
+						int nbefore = (int)(idx * W) - (int)p0;
+						if(nbefore > 0) v += newcell_cum(nbefore);
+						return v;
+					};
+					ubA[h] = new_ub((uint32_t)j);
+					ubB[h] = new_ub((uint32_t)j + 1u);
+				}
+			}
+#pragma unroll
+			for(int k = 0; k < W; k++){
+				u[k] = pk_make(nu[0][k], nu[1][k]);
+				if(PW >= 1) e[k] = pk_make(ne[0][k], ne[1][k]);
+				if(PW == 2) q2[k] = pk_make(nq[0][k], nq[1][k]);
+			}
+			__builtin_amdgcn_wave_barrier();
+		} else {
+			int bacc[2] = {0, 0};
+			for(uint32_t s = 0; __any((act[0] && s < mov[0]) || (act[1] && s < mov[1])); s++){
+				const bool d0 = s < mov[0], d1 = s < mov[1];
+				const uint32_t msk = (d0 ? 0x0000FFFFu : 0u) | (d1 ? 0xFFFF0000u : 0u);
+				const int nci = newcell_int((int)s);
+				const uint32_t dropped = u[0];
+				const uint32_t in_u = pk_dpp_shl1(pk_splat(trunc8(nci)), u[0]);
+#pragma unroll
+				for(int k = 0; k + 1 < W; k++) u[k] = (u[k + 1] & msk) | (u[k] & ~msk);
+				u[W - 1] = (in_u & msk) | (u[W - 1] & ~msk);
+				if(PW >= 1){
+					const uint32_t in_e = pk_dpp_shl1(0u, e[0]);
+#pragma unroll
+					for(int k = 0; k + 1 < W; k++) e[k] = (e[k + 1] & msk) | (e[k] & ~msk);
+					e[W - 1] = (in_e & msk) | (e[W - 1] & ~msk);
+				}
+				if(PW == 2){
+					const uint32_t in_q = pk_dpp_shl1(0u, q2[0]);
+#pragma unroll
+					for(int k = 0; k + 1 < W; k++) q2[k] = (q2[k + 1] & msk) | (q2[k] & ~msk);
+					q2[W - 1] = (in_q & msk) | (q2[W - 1] & ~msk);
+				}
+				ubA[0] += d0 ? pk_get(dropped, 0) : 0; ubA[1] += d1 ? pk_get(dropped, 1) : 0;
+				bacc[0] += d0 ? nci : 0; bacc[1] += d1 ? nci : 0;
+			}
+#pragma unroll
+			for(int h = 0; h < 2; h++){
+				const int nb = DPP_SHL(ubB[h] + bacc[h], ubA[h], 1);
+				ubB[h] = mov[h] ? nb : ubB[h];
+				if(mov[h]) rh[h] = ubA[h];
+			}
+		}
+		// ---- sequences + S(x, y) for both halves: Sv[k] = (S_A << 8) | (S_B << 24)
+		uint32_t s4[2][NQ];
+#pragma unroll
+		for(int h = 0; h < 2; h++){
+			const int tb = tb_next[h];
+			if(act[h] && i + 1 < tlen[h]) tb_next[h] = tp[h][i + 1];
+			uint32_t qc[NQ];
+			if(act[h]) load_qcodes_pk<W>(qp[h] + rbeg[h] + j * W, qc);
+			else { for(int n = 0; n < NQ; n++) qc[n] = 0x04040404u; }
+			const uint32_t mr = (tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3];
+#pragma unroll
+			for(int n = 0; n < NQ; n++) s4[h][n] = __builtin_amdgcn_perm(0xC1C1C1C1u, mr, qc[n]);
+		}
+		uint32_t Sv[W];
+#pragma unroll
+		for(int k = 0; k < W; k++){
+			const uint32_t sel = 0x000C000Cu | ((uint32_t)(k & 3) << 8) | ((uint32_t)(4 + (k & 3)) << 24);   // {0, A.byte[k], 0, B.byte[k]}
+			Sv[k] = __builtin_amdgcn_perm(s4[1][k >> 2], s4[0][k >> 2], sel);
+		}
+		// ---- row_cal (bsalign.h:2727-2793 / 2885-2960 / 3084-3179)
+		uint32_t H0;
+		{
+			int h0[2];
+#pragma unroll
+			for(int h = 0; h < 2; h++){
+				int hh = (rh[h] - ubA[h]) + pk_get(Sv[0], h);
+				int t0 = pk_get(u[0], h) + ((PW == 0) ? gape1 : (PW == 1) ? pk_get(e[0], h) : max(pk_get(e[0], h), pk_get(q2[0], h)));
+				hh = (hh >= t0) ? min(hh, BSA_EPI8_MAX) : BSA_EPI8_MIN;
+				h0[h] = trunc8(hh);
+			}
+			H0 = pk_make(h0[0], h0[1]);
+		}
+		uint32_t f = MIN63, gq = MIN63;
+		{
+			uint32_t hc = (j == 0) ? H0 : Sv[0];
+#pragma unroll
+			for(int k = 0; k < W; k++){
+				const uint32_t uk = u[k];
+				uint32_t h;
+				if(PW == 0){
+					const uint32_t ee = pk_adds(uk, GE);
+					h = pk_max(pk_max(ee, hc), f);
+					f = pk_norm(pk_subs(pk_adds(h, GE), uk));
+				} else if(PW == 1){
+					const uint32_t ee = pk_adds(e[k], uk);
+					h = pk_max(pk_max(ee, hc), f);
+					f = pk_adds(f, GE);
+					h = pk_adds(h, GOE);
+					f = pk_norm(pk_subs(pk_max(f, h), uk));
+				} else {
+					const uint32_t ee = pk_adds(e[k], uk), qq = pk_adds(q2[k], uk);
+					h = pk_max(pk_max(ee, hc), pk_max(qq, pk_max(f, gq)));
+					f = pk_adds(f, GE);
+					h = pk_adds(h, GOE);
+					f = pk_norm(pk_subs(pk_max(f, h), uk));
+					gq = pk_adds(gq, GP);
+					h = pk_subs(h, GOQ);
+					gq = pk_norm(pk_subs(pk_max(gq, h), uk));
+				}
+				if(k + 1 < W) hc = Sv[k + 1];
+			}
+		}
+		{
+			int fa = fpen(pk_get(f, 0), ubA[0], ubB[0], W * gape1, j);
+			int fb = fpen(pk_get(f, 1), ubA[1], ubB[1], W * gape1, j);
+			f = pk_make(fa, fb);
+			if(PW == 2){
+				int ga = fpen(pk_get(gq, 0), ubA[0], ubB[0], W * gape2, j);
+				int gb = fpen(pk_get(gq, 1), ubA[1], ubB[1], W * gape2, j);
+				gq = pk_make(ga, gb);
+			}
+		}
+		uint32_t htail, ulast = 0;
+		{
+			uint32_t v = 0, z = (j == 0) ? H0 : Sv[0], h = 0;
+#pragma unroll
+			for(int k = 0; k < W; k++){
+				const uint32_t uk = u[k];
+				if(PW == 0){
+					const uint32_t ee = pk_adds(uk, GE);
+					h = pk_max(pk_max(ee, z), f);
+					u[k] = pk_norm(pk_subs(h, v));
+					v = pk_norm(pk_subs(h, uk));
+					f = pk_norm(pk_subs(pk_adds(h, GE), uk));
+				} else if(PW == 1){
+					uint32_t ee = pk_adds(e[k], uk);
+					h = pk_max(pk_max(ee, z), f);
+					u[k] = pk_norm(pk_subs(h, v));
+					v = pk_norm(pk_subs(h, uk));
+					ee = pk_subs(pk_adds(ee, GE), h);
+					e[k] = pk_max(ee, GOE);
+					f = pk_adds(f, GE);
+					h = pk_adds(h, GOE);
+					f = pk_norm(pk_subs(pk_max(f, h), uk));
+				} else {
+					uint32_t ee = pk_adds(e[k], uk), qq = pk_adds(q2[k], uk);
+					h = pk_max(pk_max(ee, z), pk_max(qq, pk_max(f, gq)));
+					u[k] = pk_norm(pk_subs(h, v));
+					v = pk_norm(pk_subs(h, uk));
+					ee = pk_subs(pk_adds(ee, GE), h);
+					e[k] = pk_max(ee, GOE);
+					qq = pk_subs(pk_adds(qq, GP), h);
+					q2[k] = pk_max(qq, GQP);
+					f = pk_adds(f, GE);
+					h = pk_adds(h, GOE);
+					f = pk_norm(pk_subs(pk_max(f, h), uk));
+					gq = pk_adds(gq, GP);
+					h = pk_subs(h, GOQ);
+					gq = pk_norm(pk_subs(pk_max(gq, h), uk));
+				}
+				ulast = uk;
+				if(k + 1 < W) z = Sv[k + 1];
+			}
+			htail = (PW == 0) ? h : (PW == 1) ? pk_subs(h, GOE) : pk_subs(h, GQP);
+		}
+		// ---- tail (bsalign.h:2618-2636)
+		{
+			const uint32_t vlast = pk_norm(pk_subs(htail, ulast));
+			const uint32_t vsh = pk_dpp_shr1(0u, vlast);
+#ifdef BSA_DEBUG
+			if(g == 0 && i == 0 && j < 2) printf("pk lane %d: htail %08x ulast %08x vlast %08x vsh %08x u0 %08x ubA %d %d ubB %d %d f %08x H0 %08x Sv0 %08x GOE %08x\n", j, htail, ulast, vlast, vsh, u[0], ubA[0], ubA[1], ubB[0], ubB[1], f, H0, Sv[0], GOE);
+#endif
+			u[0] = pk_norm(pk_subs(u[0], vsh));
+#pragma unroll
+			for(int h = 0; h < 2; h++){
+				const int nB = ubB[h] + pk_get(vlast, h);
+				int nA = DPP_SHR(0, nB, 1);
+				if(j == 0) nA = ubA[h] + pk_get(u[0], h);
+				ubA[h] = nA; ubB[h] = nB;
+			}
+			if(j == 0) u[0] = 0u;
+		}
+		store_rows(i + 1, act, rbeg);
+		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
+#pragma unroll
+		for(int h = 0; h < 2; h++){
+			int dsum = ubB[h] - ubA[h]; dsum = dsum < 0 ? -dsum : dsum;
+			const int nzsum = row_sum16(dsum);
+			const int ub0 = DPP_BCAST(ubA[h], 0), ub16 = DPP_BCAST(ubB[h], 15);
+			uint32_t nz = (uint32_t)(nzsum / 16);
+			nz = nz / (uint32_t)W * 16u / 2u;
+			const int noisy = (int)((16u > nz) ? 16u : nz);
+			int rbx;
+			if(i <= (uint32_t)BW / 4u) rbx = 0;
+			else if(rbeg[h] + BW >= qlen[h]) rbx = 0;
+			else if(ub0 + noisy < ub16) rbx = 2;
+			else if(ub0 > ub16 + noisy) rbx = 0;
+			else rbx = 1;
+			if(mode == BSA_MODE_GLOBAL){
+				const int rbz = 2 * max((int)(tlen[h] / max(qlen[h], 1u)), 1);
+				const int rby = (int)((1.0 * (double)i / dt[h]) * dq[h]);
+				const uint32_t left = tlen[h] - i - 1u;
+				if((long long)rbeg[h] + (long long)rbz * (long long)left + (long long)BW <= (long long)(uint32_t)(qlen[h] + (uint32_t)rbz - 1u)){
+					mov[h] = 1u + (uint32_t)(qlen[h] - (rbeg[h] + BW)) / max(left, 1u);
+				} else if((int)rbeg[h] < rby - BW){
+					mov[h] = (uint32_t)(rbx + 1);
+				} else if((int)rbeg[h] > rby){
+					mov[h] = (uint32_t)max(0, rbx - 1);
+				} else mov[h] = (uint32_t)rbx;
+			} else mov[h] = (uint32_t)rbx;
+		}
+		i++;
+	}
+}
+
+template<int W, int PW>
+static hipError_t launch_fwd_pk(const Align8Args &a, hipStream_t st){
+	constexpr int BW = W * 16;
+	constexpr int PAIR_LDS = ((PW + 1) * BW + 17 * 4 + 15) & ~15;
+	const uint32_t groups = (a.count + 1) / 2;
+	const uint32_t blocks = (groups + 15) / 16;
+	if(blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL((k_align8_fwd_pk<W, PW>), dim3(blocks), dim3(256), 2 * PAIR_LDS * 16, st, a);
+	return hipGetLastError();
+}
+
+template<int W>
+static hipError_t launch_fwd_pk_pw(const Align8Args &a, int pw, hipStream_t st){
+	if(pw == 0) return launch_fwd_pk<W, 0>(a, st);
+	if(pw == 1) return launch_fwd_pk<W, 1>(a, st);
+	return launch_fwd_pk<W, 2>(a, st);
+}
+
+bool bsa_align8_pk_supported(const Align8Args &a, int pw){
+	const uint32_t W = a.bw / 16;
+	if(!(W == 4 || W == 8 || W == 16)) return false;
+	const int GapE = (int)(int8_t)a.gape1, GapOE = (int)(int8_t)(a.gapo1 + a.gape1);
+	if(GapE > 0 || GapOE > 0) return false;
+	if(pw == 2){
+		const int GapP = (int)(int8_t)a.gape2, GapQP = (int)(int8_t)(a.gapo2 + a.gape2);
+		if(GapP > 0 || GapQP > 0 || GapOE - GapQP < 0) return false;
+	}
+	return true;
+}
+
+hipError_t bsa_launch_align8_fwd_pk(const Align8Args &a, int pw, hipStream_t st){
+	switch(a.bw / 16){
+		case 4:  return launch_fwd_pk_pw<4>(a, pw, st);
+		case 8:  return launch_fwd_pk_pw<8>(a, pw, st);
+		case 16: return launch_fwd_pk_pw<16>(a, pw, st);
+		default: return hipErrorInvalidValue;
+	}
+}

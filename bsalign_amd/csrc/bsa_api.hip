@@ -469,7 +469,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + p->tpad + 15) & ~(size_t)15;
 		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw;
 	}
-	for(size_t pos = 0; pos < n; pos++) need[pos] = ((size_t)tlen[order[pos]] + 3) * p->rowb;
+	for(size_t pos = 0; pos < n; pos++) need[pos] = bsa_slot_bytes(tlen[order[pos]], p->rowb);
 	p->cells = cells;
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
 	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
@@ -555,7 +555,7 @@ extern "C" int bsa_align_debug_rows(bsa_align_plan_t *p, uint32_t pair, uint8_t 
 	HIPCHK(c, hipMemcpy(slot.data(), p->d_slot, p->n * 8, hipMemcpyDeviceToHost));
 	for(size_t pos = 0; pos < p->n; pos++){
 		if(order[pos] == pair){
-			if(bytes) HIPCHK(c, hipMemcpy(host, c->ws + slot[pos], bytes, hipMemcpyDeviceToHost));
+			if(bytes) HIPCHK(c, hipMemcpy(host, c->ws + slot[pos], bytes, hipMemcpyDeviceToHost));   // begs array, then the row records
 			if(rowb_out) *rowb_out = p->rowb;
 			return BSA_OK;
 		}

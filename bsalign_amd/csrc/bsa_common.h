@@ -34,16 +34,22 @@ struct Align8Args {
 	int8_t   matrix[16];
 };
 
-// row record layout (natural band order, one record per target row, row -1 first):
-//   [0, bw)            u  (int8)   u[p] = H(p) - H(p-1)
-//   [bw, 2bw)          e  (int8)   only when piecewise >= 1
-//   [2bw, 3bw)         q  (int8)   only when piecewise == 2
-//   [(pw+1)bw, +68)    ubegs (17 x int32)
-//   [(pw+1)bw + 68]    rbeg (int32): band offset of the row
+// Traceback state of one pair ("slot") in the workspace:
+//   [begs: (tlen + 2) int32, padded to 16 B]   begs[r + 1] = band offset of target row r (row -1 first, = 0)
+//   [row records: tlen + 3 of rowb bytes]       record r + 1 = target row r; the 2 spare records + consumed rows
+//                                               at the end are the CIGAR scratch of the traceback
+// Row record, BLOCK-INTERLEAVED so that one traceback step touches one cache line: for running block y = 0..15
+// (= lane y of the forward kernel):
+//   [u: W int8][e: W int8 if pw >= 1][q: W int8 if pw == 2][pad to 4][ubegs[y]: int32]        = blk bytes
+// followed by ubegs[16] (int32).  u[p] = H(p) - H(p-1) for band position p = y*W + k.
+static inline __host__ __device__ uint32_t bsa_blk_cells(uint32_t W, int pw){ return ((uint32_t)(pw + 1) * W + 3u) & ~3u; }
+static inline __host__ __device__ uint32_t bsa_blk_bytes(uint32_t W, int pw){ return bsa_blk_cells(W, pw) + 4u; }
 static inline __host__ __device__ uint32_t bsa_row_bytes(uint32_t bw, int pw){
-	uint32_t b = (uint32_t)(pw + 1) * bw + 17 * 4 + 4;
+	uint32_t b = 16u * bsa_blk_bytes(bw / 16u, pw) + 4u;
 	return (b + 15u) & ~15u;
 }
+static inline __host__ __device__ size_t bsa_begs_bytes(uint32_t tlen){ return (((size_t)tlen + 2) * 4 + 15) & ~(size_t)15; }
+static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t rowb){ return bsa_begs_bytes(tlen) + ((size_t)tlen + 3) * rowb; }
 
 static inline __host__ __device__ int bsa_get_piecewise(int gapo1, int gape1, int gapo2, int gape2, int bandwidth){ // bsalign.h:2084-2092
 	if(gapo2 < gapo1 && gape2 > gape1 && gapo2 + gape2 < gapo1 + gape1 && (gapo1 - gapo2) / (gape1 - gape2) < bandwidth) return 2;
@@ -73,6 +79,8 @@ struct EditArgs {
 hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st);
 hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);
 bool bsa_align8_supported_bw(uint32_t bw);
+bool bsa_align8_pk_supported(const Align8Args &a, int pw);
+hipError_t bsa_launch_align8_fwd_pk(const Align8Args &a, int pw, hipStream_t st);
 bool bsa_edit_supported_bw(uint32_t bw);
 hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
 		const uint64_t *qpoff, const uint64_t *tpoff, const uint64_t *qboff, const uint32_t *qwords,

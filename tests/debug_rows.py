@@ -36,29 +36,37 @@ def main():
     lib = S.oracle()
     lib.orc_align_pairwise_rows.restype = C.c_long
     for k, (q, t) in enumerate(pairs):
-        rows = plan.debug_rows(k)
-        rowb = rows.shape[1]
-        orows = np.zeros(rows.shape, dtype=np.uint8)
+        tl = len(t)
+        pw = lib.orc_get_piecewise(sc[2], sc[3], sc[4], sc[5], bw)
+        W = bw // 16
+        cells = ((pw + 1) * W + 3) & ~3
+        blk = cells + 4
+        rowb = (16 * blk + 4 + 15) & ~15
+        begs_bytes = ((tl + 2) * 4 + 15) & ~15
+        nbytes = begs_bytes + (tl + 1) * rowb
+        slot = plan.debug_slot(k, nbytes)
+        oslot = np.zeros(nbytes, dtype=np.uint8)
         res = np.zeros(10, dtype=np.int32)
         m = S.score_matrix(sc[0], sc[1])
-        lib.orc_align_pairwise_rows(S.ptr(q, S.u8p), len(q), S.ptr(t, S.u8p), len(t), mode, bw, S.ptr(m, S.i8p),
-                                    sc[2], sc[3], sc[4], sc[5], S.ptr(res, S.i32p), orows.ctypes.data_as(C.c_void_p), rowb)
-        pw = lib.orc_get_piecewise(sc[2], sc[3], sc[4], sc[5], bw)
-        nb = (pw + 1) * bw
-        used = nb + 72
-        print("pair", k, "qlen", len(q), "tlen", len(t), "gpu", out[k], "orc", res)
-        for r in range(rows.shape[0]):
-            if not np.array_equal(rows[r, :used], orows[r, :used]):
-                g, o = rows[r], orows[r]
+        lib.orc_align_pairwise_rows(S.ptr(q, S.u8p), len(q), S.ptr(t, S.u8p), tl, mode, bw, S.ptr(m, S.i8p),
+                                    sc[2], sc[3], sc[4], sc[5], S.ptr(res, S.i32p), oslot.ctypes.data_as(C.c_void_p), rowb)
+        print("pair", k, "qlen", len(q), "tlen", tl, "gpu", out[k], "orc", res)
+        gb, ob = slot[:(tl + 1) * 4].view(np.int32), oslot[:(tl + 1) * 4].view(np.int32)
+        if not np.array_equal(gb, ob):
+            r = int(np.nonzero(gb != ob)[0][0])
+            print("  band offsets first differ at row", r - 1, "gpu", gb[r:r + 4], "orc", ob[r:r + 4])
+        used = 16 * blk + 4
+        for r in range(tl + 1):
+            g = slot[begs_bytes + r * rowb: begs_bytes + r * rowb + used]
+            o = oslot[begs_bytes + r * rowb: begs_bytes + r * rowb + used]
+            if not np.array_equal(g, o):
                 print("  first differing row:", r - 1)
-                for name, lo, hi in (("u", 0, bw), ("e", bw, 2 * bw if pw >= 1 else bw), ("q", 2 * bw, 3 * bw if pw == 2 else 2 * bw)):
-                    if hi > lo and not np.array_equal(g[lo:hi], o[lo:hi]):
-                        idx = np.nonzero(g[lo:hi] != o[lo:hi])[0]
-                        print("   ", name, "differs at band pos", idx[:16], "gpu", g[lo:hi].view(np.int8)[idx[:16]], "orc", o[lo:hi].view(np.int8)[idx[:16]])
-                gu, ou = g[nb:nb + 72].view(np.int32), o[nb:nb + 72].view(np.int32)
-                if not np.array_equal(gu, ou):
-                    print("    ubegs/rbeg gpu", gu)
-                    print("    ubegs/rbeg orc", ou)
+                for y in range(16):
+                    gy, oy = g[y * blk:(y + 1) * blk], o[y * blk:(y + 1) * blk]
+                    if not np.array_equal(gy, oy):
+                        print("    block", y, "gpu u", gy[:W].view(np.int8), "e", gy[W:2 * W].view(np.int8) if pw else "", "ub", gy[cells:cells + 4].view(np.int32))
+                        print("    block", y, "orc u", oy[:W].view(np.int8), "e", oy[W:2 * W].view(np.int8) if pw else "", "ub", oy[cells:cells + 4].view(np.int32))
+                print("    ubegs[16] gpu", g[16 * blk:16 * blk + 4].view(np.int32), "orc", o[16 * blk:16 * blk + 4].view(np.int32))
                 break
         else:
             print("  all rows equal")
