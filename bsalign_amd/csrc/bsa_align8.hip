@@ -54,7 +54,6 @@ __global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
 	int *begs = (int*)(a.rows + a.slot_off[ppos]);
 	uint8_t *rowp = (uint8_t*)begs + bsa_begs_bytes(tlen);
 	if(!live || a.status[pair] != 0u) tlen = 0;
-	const uint32_t rowb = a.rowb;
 	int8_t *gl = smem + (lt >> 4) * GROUP_LDS;
 	int8_t *su = gl, *se = gl + BW, *sq = gl + 2 * BW;
 	int *sub = (int*)(gl + (PW + 1) * BW);
@@ -97,29 +96,24 @@ __global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
 		ubA = ubB - bs;
 	}
 	constexpr uint32_t CELLS = ((uint32_t)(PW + 1) * W + 3u) & ~3u, BLK = CELLS + 4u;
-	auto store_row = [&](uint32_t row_index, uint32_t rbeg_v){
-		// block-interleaved record (bsa_common.h): lane j writes its u / e / q bytes and ubegs[j] contiguously
-		uint8_t *bp = rowp + (size_t)row_index * rowb + (uint32_t)j * BLK;
-		if constexpr (W >= 4){
+	constexpr int RW = (int)(BLK / 4u), TG = (64u / BLK) ? (int)(64u / BLK) : 1;
+	TileWriter<RW, TG> tw;
+	auto store_row = [&](uint32_t row_index, uint32_t rbeg_v, bool active){
+		// block record of this lane (bsa_common.h): u / e / q bytes then ubegs[j]
+		uint32_t rec[RW];
 #pragma unroll
-			for(int n = 0; n < W / 4; n++){
-				((uint32_t*)bp)[n] = (uint32_t)(u[4*n] & 0xff) | ((uint32_t)(u[4*n+1] & 0xff) << 8) | ((uint32_t)(u[4*n+2] & 0xff) << 16) | ((uint32_t)u[4*n+3] << 24);
-				if(PW >= 1) ((uint32_t*)(bp + W))[n] = (uint32_t)(e[4*n] & 0xff) | ((uint32_t)(e[4*n+1] & 0xff) << 8) | ((uint32_t)(e[4*n+2] & 0xff) << 16) | ((uint32_t)e[4*n+3] << 24);
-				if(PW == 2) ((uint32_t*)(bp + 2 * W))[n] = (uint32_t)(q2[4*n] & 0xff) | ((uint32_t)(q2[4*n+1] & 0xff) << 8) | ((uint32_t)(q2[4*n+2] & 0xff) << 16) | ((uint32_t)q2[4*n+3] << 24);
-			}
-		} else {
+		for(int d = 0; d < RW; d++) rec[d] = 0u;
 #pragma unroll
-			for(int k = 0; k < W; k++){
-				bp[k] = (uint8_t)u[k];
-				if(PW >= 1) bp[W + k] = (uint8_t)e[k];
-				if(PW == 2) bp[2 * W + k] = (uint8_t)q2[k];
-			}
+		for(int k = 0; k < W; k++){
+			rec[k >> 2] |= (uint32_t)(u[k] & 0xff) << (8 * (k & 3));
+			if(PW >= 1) rec[(W + k) >> 2] |= (uint32_t)(e[k] & 0xff) << (8 * ((W + k) & 3));
+			if(PW == 2) rec[(2 * W + k) >> 2] |= (uint32_t)(q2[k] & 0xff) << (8 * ((2 * W + k) & 3));
 		}
-		*(int*)(bp + CELLS) = ubA;
-		if(j == 15) *(int*)(bp + BLK) = ubB;
-		if(j == 0) begs[row_index] = (int)rbeg_v;
+		rec[RW - 1] = (uint32_t)ubA;
+		tw.push(rowp, (uint32_t)j, row_index, active, row_index == tlen, rec);
+		if(active && j == 0) begs[row_index] = (int)rbeg_v;
 	};
-	if(tlen) store_row(0u, 0u);
+	store_row(0u, 0u, tlen != 0);
 
 	uint32_t rbeg = 0, mov = 0, i = 0;
 	int tb_next = tlen ? (int)tp[0] : 0;
@@ -334,7 +328,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
 			if(j == 0){ nA = ubA + u[0]; u[0] = 0; }         // re-base: ubegs[0] = H(0), u[0] = 0
 			ubA = nA; ubB = nB;
 		}
-		if(act) store_row(i + 1u, rbeg);
+		store_row(i + 1u, rbeg, act);
 		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
 		{
 			int dsum = ubB - ubA; dsum = dsum < 0 ? -dsum : dsum;
@@ -373,11 +367,20 @@ __global__ void __launch_bounds__(256) k_align8_fwd(const Align8Args a){
 // end of the pair's (already consumed) row slot and come out in forward order.
 // ---------------------------------------------------------------------------------------------
 struct RowView {
-	const uint8_t *rows; const int *begs; uint32_t rowb, bw, W, cells, blk; int pw;
-	__device__ __forceinline__ const uint8_t* rec(int row) const { return rows + (size_t)(row + 1) * rowb; }
-	__device__ __forceinline__ const int8_t* blkp(int row, uint32_t y) const { return (const int8_t*)(rec(row) + y * blk); }
-	__device__ __forceinline__ int ubv(int row, uint32_t y) const { return *(const int*)(rec(row) + y * blk + (y < 16u ? cells : 0u)); }   // ubegs[16] follows block 15
+	const uint8_t *rows; const int *begs; uint32_t bw, W, cells, blk, tg, tileb; int pw;
+	__device__ __forceinline__ void init(const uint8_t *slot, uint32_t tlen, uint32_t bw_, int pw_){
+		begs = (const int*)slot; rows = slot + bsa_begs_bytes(tlen);
+		bw = bw_; W = bw_ / 16; pw = pw_; cells = bsa_blk_cells(W, pw_); blk = cells + 4u;
+		tg = bsa_tile_rows(W, pw_); tileb = bsa_tile_bytes(W, pw_);
+	}
+	__device__ __forceinline__ const int8_t* blkp(int row, uint32_t y) const {
+		const uint32_t rr = (uint32_t)(row + 1);
+		return (const int8_t*)(rows + ((size_t)(rr / tg) * 16u + y) * tileb + (rr % tg) * blk);
+	}
+	__device__ __forceinline__ const uint8_t* tilep(int row, uint32_t y) const { return rows + ((size_t)((uint32_t)(row + 1) / tg) * 16u + y) * tileb; }
+	__device__ __forceinline__ int ubv(int row, uint32_t y) const { return *(const int*)((const uint8_t*)blkp(row, y) + cells); }
 	__device__ __forceinline__ int beg(int row) const { return begs[row + 1]; }
+	__device__ __forceinline__ uint32_t* cigar_end(uint32_t tlen) const { return (uint32_t*)(const_cast<uint8_t*>(rows) + bsa_groups(tlen, tg) * 16 * (size_t)tileb); }
 	__device__ __forceinline__ int getscore(int row, long pos) const {       // bsalign.h:3187-3197
 		uint32_t p = (uint32_t)pos;
 		if(p >= bw) p = bw - 1;                                              // keep reads inside the record
@@ -444,13 +447,12 @@ __global__ void __launch_bounds__(64) k_align8_backcal(const Align8Args a, int p
 	const uint8_t *qseq = a.qst + a.qpoff[pair];
 	const uint8_t *tseq = a.tst + a.tpoff[pair];
 	RowView R;
-	R.begs = (const int*)(a.rows + a.slot_off[ppos]); R.rows = (const uint8_t*)R.begs + bsa_begs_bytes(tlen);
-	R.rowb = a.rowb; R.bw = a.bw; R.W = a.bw / 16; R.pw = pw; R.cells = bsa_blk_cells(R.W, pw); R.blk = R.cells + 4u;
+	R.init(a.rows + a.slot_off[ppos], tlen, a.bw, pw);
 	const uint32_t bw = a.bw, W = R.W;
 	const int mode = a.mode & 3;
 	const int gapo1 = a.gapo1, gape1 = a.gape1, gapo2 = a.gapo2, gape2 = a.gape2;
 	// cigar scratch: the tail end of this pair's slot (tlen + 3 row records long)
-	uint32_t *cig_end = (uint32_t*)(const_cast<uint8_t*>(R.rows) + (size_t)(tlen + 3) * a.rowb);
+	uint32_t *cig_end = R.cigar_end(tlen);
 	uint32_t ncig = 0;
 	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
 	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
@@ -591,6 +593,263 @@ __global__ void __launch_bounds__(64) k_align8_backcal(const Align8Args a, int p
 }
 
 // ---------------------------------------------------------------------------------------------
+// Global-mode traceback with a prefetching helper wave (bandwidth <= 128, i.e. W <= 8).
+//
+// Same decisions as k_align8_backcal.  The walk is a chain of ~2 dependent steps per cell (band offset -> block
+// record), and loads of one wave return in order, so a wave cannot hide its own HBM misses by prefetching for
+// itself.  Each block therefore runs TWO waves: wave 0 walks 64 pairs (one per lane) and publishes, per step, the
+// address of the block record it is reading; wave 1 never walks, it only touches the same block of the next few
+// rows (the band-relative position of the path drifts slowly, and a 128-byte line holds ~6 blocks), so that the
+// worker's loads hit L2.  The M-step reads whole block records (u, e, q bytes + ubegs of one running block = one
+// 20..28 byte record) into registers instead of byte loads.
+// ---------------------------------------------------------------------------------------------
+struct BlkRec { uint32_t d[7]; };
+template<int W>
+static __device__ __forceinline__ int rec_prefix(const BlkRec &r, uint32_t cells, uint32_t x){   // ubegs[y] + u[0..x]
+	const uint32_t ubw = cells / 4u;
+	int s = (int)((ubw == 1) ? r.d[1] : (ubw == 2) ? r.d[2] : (ubw == 3) ? r.d[3] : (ubw == 4) ? r.d[4] : (ubw == 5) ? r.d[5] : r.d[6]);
+	const uint32_t lo4 = r.d[0], hi4 = (W > 4) ? r.d[1] : 0u;
+	const uint32_t nlo = x >= 3 ? 0xFFFFFFFFu : ((1u << (8 * (x + 1))) - 1u);
+	const uint32_t nhi = x < 4 ? 0u : (x >= 7 ? 0xFFFFFFFFu : ((1u << (8 * (x - 3))) - 1u));
+	const uint32_t lo = (lo4 & nlo) ^ 0x80808080u, hi = (hi4 & nhi) ^ 0x80808080u;
+	s += (int)__builtin_amdgcn_sad_u8(lo, 0u, 0u) + (int)__builtin_amdgcn_sad_u8(hi, 0u, 0u) - 1024;
+	return s;
+}
+static __device__ __forceinline__ int rec_byte(const BlkRec &r, uint32_t b){                        // signed byte b of the record
+	const uint32_t w = b >> 2;
+	const uint32_t v = (w == 0) ? r.d[0] : (w == 1) ? r.d[1] : (w == 2) ? r.d[2] : (w == 3) ? r.d[3] : (w == 4) ? r.d[4] : r.d[5];
+	return __builtin_amdgcn_sbfe((int)v, 8u * (b & 3u), 8u);
+}
+
+
+// The walk is written as a flat state machine with exactly ONE block-record fetch per iteration, whatever the state
+// of the lane (cell decision, block-boundary cell, insertion-length scan, deletion run): the 64 pairs of a wave are
+// in different states at any time, and with nested loops every state's chain of dependent loads would be paid
+// one after the other on every step.
+template<int W, int PW>
+__global__ void __launch_bounds__(128) k_align8_backcal_g(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
+	constexpr int pw = PW;
+	constexpr uint32_t CELLS = (((uint32_t)(PW + 1) * W + 3u) & ~3u), BLKW = (CELLS + 4u) / 4u;
+	__shared__ volatile unsigned long long hint[64];
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t g = blockIdx.x * 64u + lane;
+	const bool live = g < a.count;
+	const uint32_t ppos = a.first + (live ? g : 0u);
+	const uint32_t pair = a.order[ppos];
+	const bool skip = !live || a.status[pair] != 0u;
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	RowView R;
+	R.init(a.rows + a.slot_off[ppos], tlen, a.bw, pw);
+	if(wave == 0) hint[lane] = skip ? 1ull : 0ull;
+	__syncthreads();
+	if(wave == 1){
+		// ---- helper: touch the rows ahead of every worker lane until all of them are done
+		unsigned long long last = 0ull;
+		const unsigned long long lo_addr = (unsigned long long)(uintptr_t)R.rows;
+		int acc = 0;
+		for(;;){
+			const unsigned long long h = hint[lane];
+			if(h > 1ull && h != last && !(a.mode & 0x100)){
+				// the worker entered a new tile: pull the same block of the next two row groups below into L2
+				int v[2];
+#pragma unroll
+				for(int d = 0; d < 2; d++){
+					unsigned long long ad = h - (unsigned long long)(1 + d) * 16ull * R.tileb;
+					if(ad < lo_addr || ad > h) ad = lo_addr;
+					v[d] = *(const int*)(uintptr_t)ad;
+				}
+				acc += v[0] + v[1];
+				last = h;
+			}
+			if(__all(h == 1ull)) break;
+			__builtin_amdgcn_s_sleep(2);
+		}
+		asm volatile("" :: "v"(acc));
+		return;
+	}
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	if(skip){ if(live){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
+	const uint8_t *qseq = a.qst + a.qpoff[pair];
+	const uint8_t *tseq = a.tst + a.tpoff[pair];
+	const uint32_t bw = a.bw;
+	const int gapo1 = a.gapo1, gape1 = a.gape1, gapo2 = a.gapo2, gape2 = a.gape2;
+	uint32_t *cig_end = R.cigar_end(tlen);
+	uint32_t ncig = 0;
+	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
+	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
+		if(op == (cg & 0xf)) return cg + (sz << 4);
+		if(cg) cig_push(cg);
+		return (sz << 4) | op;
+	};
+	uint64_t qwin = 0, twin = 0; int qwb = -1000, twb = -1000;     // 8 bases of each sequence in a register window
+	auto qbase_at = [&](int idx) -> int {
+		if(idx < qwb || idx >= qwb + 8){ qwb = max(idx - 7, 0); __builtin_memcpy(&qwin, qseq + qwb, 8); }
+		return (int)((qwin >> (8 * (idx - qwb))) & 0xffu);
+	};
+	auto tbase_at = [&](int idx) -> int {
+		if(idx < twb || idx >= twb + 8){ twb = max(idx - 7, 0); __builtin_memcpy(&twin, tseq + twb, 8); }
+		return (int)((twin >> (8 * (idx - twb))) & 0xffu);
+	};
+	bool bad = false;
+	// ---- end cell (global, bsalign.h:4034-4037)
+	const int lastbeg = R.beg((int)tlen - 1);
+	if(qlen - 1u - (uint32_t)lastbeg >= bw) bad = true;
+	rs.score = R.getscore((int)tlen - 1, (long)qlen - 1 - lastbeg);
+	rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	// ---- backcal (bsalign.h:3704-3852) as a state machine
+	enum { ST_CELL = 0, ST_CELLB = 1, ST_ISCAN = 2, ST_DRUN = 3, ST_DONE = 4 };
+	int state = bad ? ST_DONE : ST_CELL;
+	int Hs0 = 0, Hs1 = rs.score, pend = 0, prior_match = 0, isz = 0;
+	uint32_t cg = 0;
+	rs.qb = rs.qe; rs.qe++;
+	rs.tb = rs.te; rs.te++;
+	// band offsets of rows tb, tb-1, tb-2 live in registers
+	int beg_c = lastbeg, beg_p = R.beg(rs.tb - 1), beg_pp = (rs.tb - 2 >= -1) ? R.beg(rs.tb - 2) : 0;
+	auto row_down = [&](){ rs.tb--; beg_c = beg_p; beg_p = beg_pp; beg_pp = (rs.tb - 2 >= -1) ? R.beg(rs.tb - 2) : 0; };
+	BlkRec r1;      // record of the cell's own block, kept across a ST_CELLB iteration
+#pragma unroll
+	for(int k = 0; k < 7; k++) r1.d[k] = 0u;
+	int cx = 0;     // band position of the current cell in row tb-1
+	while(state != ST_DONE){
+		if(state == ST_CELL && (rs.qb < 0 || rs.tb < 0)) break;
+		// ---- which record does this lane need?
+		int frow; uint32_t fblk; uint32_t fx = 0;
+		if(state == ST_CELL){
+			cx = rs.qb - beg_p;
+			const uint32_t xc = (cx < 0) ? 0u : ((uint32_t)cx >= bw ? bw - 1u : (uint32_t)cx);
+			frow = rs.tb - 1; fblk = xc / W;
+		} else if(state == ST_CELLB){
+			frow = rs.tb - 1; fblk = (uint32_t)cx / W - 1u; fx = W - 1u;
+		} else {
+			uint32_t pp = (uint32_t)((state == ST_ISCAN ? rs.qb - isz : rs.qb) - beg_c);
+			if(pp >= bw) pp = bw - 1u;
+			frow = rs.tb; fblk = pp / W; fx = pp % W;
+		}
+		const uint32_t *rp = (const uint32_t*)R.blkp(frow, fblk);
+		hint[lane] = (unsigned long long)(uintptr_t)R.tilep(frow, fblk);
+		BlkRec rc;
+#pragma unroll
+		for(int k = 0; k < 7; k++) rc.d[k] = ((uint32_t)k < BLKW) ? rp[k] : 0u;
+		// ---- act on it
+		bool decide = false;
+		if(state == ST_CELL){
+			r1 = rc;
+			if(rs.qb == beg_p){
+				if(rs.qb){ Hs0 = (int)rc.d[BLKW - 1u]; prior_match = 0; }          // ubegs[0] of row tb-1 (fblk == 0 here)
+				else if(rs.tb == 0) Hs0 = 0;
+				else if(pw < 2) Hs0 = gapo1 + gape1 * rs.tb;
+				else Hs0 = max(gapo1 + gape1 * rs.tb, gapo2 + gape2 * rs.tb);
+				decide = true;
+			} else {
+				uint32_t pp = (uint32_t)(cx - 1);
+				if(pp >= bw) pp = bw - 1u;
+				const uint32_t y2 = pp / W, x2 = pp % W;
+				if(y2 == fblk){ Hs0 = rec_prefix<W>(rc, CELLS, x2); decide = true; }
+				else if(y2 + 1u == fblk) state = ST_CELLB;                           // H(x-1, y-1) lives in the previous block
+				else { Hs0 = R.mtx_getscore(rs.tb - 1, rs.qb - 1); decide = true; }   // off-band corner, generic path
+			}
+		} else if(state == ST_CELLB){
+			Hs0 = rec_prefix<W>(rc, CELLS, fx);
+			decide = true;
+		} else if(state == ST_ISCAN){
+			const int hv = rec_prefix<W>(rc, CELLS, fx);
+			const long long t = (pw == 2) ? (long long)max(gapo1 + isz * gape1, gapo2 + isz * gape2) : (long long)(gapo1 + isz * gape1);
+			if(hv + t == Hs1){
+				cg = cig_add(cg, 1, (uint32_t)isz);
+				Hs1 = hv;
+				rs.qb -= isz; rs.ins += isz; rs.aln += isz;
+				state = ST_CELL;
+			} else {
+				isz++;
+				if(isz + beg_c > rs.qb){ bad = true; state = ST_DONE; }
+			}
+		} else {   // ST_DRUN
+			const int go = ((pend & 0xf) == 2) ? gapo1 : gapo2, ge = ((pend & 0xf) == 2) ? gape1 : gape2;
+			const int hv = rec_prefix<W>(rc, CELLS, fx);
+			const long long t = go + (long long)(pend >> 4) * ge;
+			if(hv + t == Hs1){
+				cg = cig_add(cg, 2, (uint32_t)(pend >> 4));
+				rs.del += pend >> 4; rs.aln += pend >> 4;
+				Hs1 = hv; pend = 0;
+				state = ST_CELL;
+			} else {
+				pend += 1 << 4;
+				row_down();
+				if(rs.tb < -1){ bad = true; state = ST_DONE; }
+			}
+		}
+		if(decide){
+			int uu = 0, ee = 0, qq = 0;
+			if(cx >= 0 && cx < (int)bw){
+				const uint32_t xk = (uint32_t)cx % W;
+				uu = rec_byte(r1, xk);
+				ee = (pw >= 1) ? rec_byte(r1, W + xk) : gapo1 + gape1;
+				qq = (pw == 2) ? rec_byte(r1, 2 * W + xk) : 0;
+			}
+			const int qbase = qbase_at(rs.qb), tbase = tbase_at(rs.tb);
+			const uint32_t mr = (tbase == 0) ? a.mrow[0] : (tbase == 1) ? a.mrow[1] : (tbase == 2) ? a.mrow[2] : a.mrow[3];
+			const int s = __builtin_amdgcn_sbfe((int)mr, 8u * (uint32_t)qbase, 8u);
+			const int h = Hs1 - Hs0;
+			int bt;   // 0 M, 1 I, 2 D, 4 D2 (bsalign.h:3667-3702)
+			if(cx > (int)bw) bt = 1;
+			else if(cx == (int)bw) bt = (h == s) ? 0 : 1;
+			else if(prior_match){
+				if(h == s) bt = 0;
+				else if(h == uu + ee) bt = 2;
+				else if(pw == 2 && h == uu + qq) bt = 4;
+				else bt = 1;
+			} else {
+				if(h == uu + ee) bt = 2;
+				else if(pw == 2 && h == uu + qq) bt = 4;
+				else if(h == s) bt = 0;
+				else bt = 1;
+			}
+			prior_match = 1;
+			state = ST_CELL;
+			if(bt == 0){
+				if(qbase == tbase) rs.mat++; else rs.mis++;
+				rs.qb--; rs.aln++;
+				row_down();
+				cg = cig_add(cg, 0, 1);
+				Hs1 = Hs0;
+			} else if(bt == 1){
+				if(rs.qb <= 0){
+					cg = cig_add(cg, 1, 1);
+					Hs1 = Hs0;
+					rs.qb--; rs.ins++; rs.aln++;
+				} else {
+					isz = 1;
+					if(isz + beg_c > rs.qb){ bad = true; state = ST_DONE; }
+					else state = ST_ISCAN;
+				}
+			} else {
+				pend = (1 << 4) | bt;
+				row_down();
+				if(rs.tb < -1){ bad = true; state = ST_DONE; }
+				else state = ST_DRUN;
+			}
+		}
+	}
+	if(!bad){
+		uint32_t op = 0, sz = 0;      // global: leading clip becomes I / D (bsalign.h:3827-3842)
+		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+		rs.aln += (int)sz;
+		cg = cig_add(cg, op, sz);
+		if(cg) cig_push(cg);
+		rs.qb++; rs.tb++;
+	}
+	hint[lane] = 1ull;
+	if(bad){
+		atomicOr(&a.status[pair], BSA_ST_TRACE);
+		ncig = 0;
+	}
+	out[pair] = rs;
+	cig_cnt[ppos] = ncig;
+}
+
+// ---------------------------------------------------------------------------------------------
 template<int W, int PW>
 static hipError_t launch_fwd(const Align8Args &a, hipStream_t st){
 	constexpr int BW = W * 16;
@@ -629,6 +888,23 @@ hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st){
 }
 
 hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
+	// global mode, W <= 8: two-wave traceback (walker + prefetching helper); BSA_ALIGN8_TRACE1=1 forces the one-wave kernel
+	static const bool force_one = [](){ const char *e = getenv("BSA_ALIGN8_TRACE1"); return e && e[0] == '1'; }();
+	static const bool no_help = [](){ const char *e = getenv("BSA_TRACE_NOHELP"); return e && e[0] == '1'; }();
+	if(no_help){ Align8Args b = a; b.mode |= 0x100; if(!force_one && (b.mode & 3) == BSA_MODE_GLOBAL && b.bw / 16 <= 8 && b.count){ const uint32_t nb = (b.count + 63) / 64; if(b.bw/16 == 8 && pw == 1){ hipLaunchKernelGGL((k_align8_backcal_g<8, 1>), dim3(nb), dim3(128), 0, st, b, out, cig_cnt); return hipGetLastError(); } } }
+	if(!force_one && (a.mode & 3) == BSA_MODE_GLOBAL && a.bw / 16 <= 8 && a.count){
+		const uint32_t nb = (a.count + 63) / 64;
+#define TRACE_CASE(WW) case WW: \
+			if(pw == 0) hipLaunchKernelGGL((k_align8_backcal_g<WW, 0>), dim3(nb), dim3(128), 0, st, a, out, cig_cnt); \
+			else if(pw == 1) hipLaunchKernelGGL((k_align8_backcal_g<WW, 1>), dim3(nb), dim3(128), 0, st, a, out, cig_cnt); \
+			else hipLaunchKernelGGL((k_align8_backcal_g<WW, 2>), dim3(nb), dim3(128), 0, st, a, out, cig_cnt); \
+			return hipGetLastError();
+		switch(a.bw / 16){
+			TRACE_CASE(1) TRACE_CASE(2) TRACE_CASE(4) TRACE_CASE(8)
+			default: break;
+		}
+#undef TRACE_CASE
+	}
 	const uint32_t blocks = (a.count + 63) / 64;
 	if(blocks == 0) return hipSuccess;
 	hipLaunchKernelGGL(k_align8_backcal, dim3(blocks), dim3(64), 0, st, a, pw, out, cig_cnt);

@@ -59,7 +59,6 @@ __global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
 		rowp[h] = (uint8_t*)begs[h] + bsa_begs_bytes(tlen[h]);
 		if(!live || a.status[pair] != 0u) tlen[h] = 0;
 	}
-	const uint32_t rowb = a.rowb;
 	int8_t *gl = smem + (lt >> 4) * (2 * PAIR_LDS);
 
 	const int mode = a.mode & 3;
@@ -100,12 +99,16 @@ __global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
 		ubB[0] = ubB[1] = base0 + inc;
 		ubA[0] = ubA[1] = base0 + inc - bs;
 	}
-	// row record store (block-interleaved record, bsa_common.h): bytes of pair A sit in byte 1, of pair B in
-	// byte 3 of every cell register; lane j writes its u / e / q bytes and ubegs[j] contiguously
+	// row record store (tiled block records, bsa_common.h): bytes of pair A sit in byte 1, of pair B in byte 3 of
+	// every cell register; lane j owns block j.  Records go through a TileWriter per half (whole 64-byte tiles).
 	constexpr uint32_t CELLS = ((uint32_t)(PW + 1) * W + 3u) & ~3u, BLK = CELLS + 4u;
+	constexpr int RW = (int)(BLK / 4u), TG = (64u / BLK) ? (int)(64u / BLK) : 1;
+	TileWriter<RW, TG> tw0, tw1;
 	auto store_rows = [&](uint32_t row_index, const bool *act, const uint32_t *rbeg_v){
+		uint32_t ra[RW], rb[RW];
+#pragma unroll
+		for(int d = 0; d < RW; d++){ ra[d] = 0u; rb[d] = 0u; }
 		if constexpr (W >= 4){
-			uint32_t wa[3][W / 4], wb[3][W / 4];
 #pragma unroll
 			for(int n = 0; n < W / 4; n++){
 #pragma unroll
@@ -113,41 +116,30 @@ __global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
 					const uint32_t *x = (arr == 0) ? u : (arr == 1) ? e : q2;
 					const uint32_t t01 = __builtin_amdgcn_perm(x[4*n+1], x[4*n],   0x07030501u);   // {A0, A1, B0, B1}
 					const uint32_t t23 = __builtin_amdgcn_perm(x[4*n+3], x[4*n+2], 0x07030501u);   // {A2, A3, B2, B3}
-					wa[arr][n] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
-					wb[arr][n] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
-				}
-			}
-#pragma unroll
-			for(int h = 0; h < 2; h++){
-				if(act[h]){
-					uint32_t *bp = (uint32_t*)(rowp[h] + (size_t)row_index * rowb + (uint32_t)j * BLK);
-#pragma unroll
-					for(int arr = 0; arr <= PW; arr++){
-#pragma unroll
-						for(int n = 0; n < W / 4; n++) bp[arr * (W / 4) + n] = h ? wb[arr][n] : wa[arr][n];
-					}
-					bp[CELLS / 4] = (uint32_t)ubA[h];
-					if(j == 15) bp[BLK / 4] = (uint32_t)ubB[h];
-					if(j == 0) begs[h][row_index] = (int)rbeg_v[h];
+					ra[arr * (W / 4) + n] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+					rb[arr * (W / 4) + n] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
 				}
 			}
 		} else {
 #pragma unroll
-			for(int h = 0; h < 2; h++){
-				if(act[h]){
-					uint8_t *bp = rowp[h] + (size_t)row_index * rowb + (uint32_t)j * BLK;
-#pragma unroll
-					for(int k = 0; k < W; k++){
-						bp[k] = (uint8_t)pk_get(u[k], h);
-						if(PW >= 1) bp[W + k] = (uint8_t)pk_get(e[k], h);
-						if(PW == 2) bp[2 * W + k] = (uint8_t)pk_get(q2[k], h);
-					}
-					*(int*)(bp + CELLS) = ubA[h];
-					if(j == 15) *(int*)(bp + BLK) = ubB[h];
-					if(j == 0) begs[h][row_index] = (int)rbeg_v[h];
+			for(int k = 0; k < W; k++){
+				ra[k >> 2] |= (uint32_t)(pk_get(u[k], 0) & 0xff) << (8 * (k & 3));
+				rb[k >> 2] |= (uint32_t)(pk_get(u[k], 1) & 0xff) << (8 * (k & 3));
+				if(PW >= 1){
+					ra[(W + k) >> 2] |= (uint32_t)(pk_get(e[k], 0) & 0xff) << (8 * ((W + k) & 3));
+					rb[(W + k) >> 2] |= (uint32_t)(pk_get(e[k], 1) & 0xff) << (8 * ((W + k) & 3));
+				}
+				if(PW == 2){
+					ra[(2 * W + k) >> 2] |= (uint32_t)(pk_get(q2[k], 0) & 0xff) << (8 * ((2 * W + k) & 3));
+					rb[(2 * W + k) >> 2] |= (uint32_t)(pk_get(q2[k], 1) & 0xff) << (8 * ((2 * W + k) & 3));
 				}
 			}
 		}
+		ra[RW - 1] = (uint32_t)ubA[0]; rb[RW - 1] = (uint32_t)ubA[1];
+		tw0.push(rowp[0], (uint32_t)j, row_index, act[0], row_index == tlen[0], ra);
+		tw1.push(rowp[1], (uint32_t)j, row_index, act[1], row_index == tlen[1], rb);
+#pragma unroll
+		for(int h = 0; h < 2; h++) if(act[h] && j == 0) begs[h][row_index] = (int)rbeg_v[h];
 	};
 	uint32_t rbeg[2] = {0, 0}, mov[2] = {0, 0}, i = 0;
 	{

@@ -455,7 +455,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	bsa_align_plan *p = new bsa_align_plan();
 	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
 	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)bw);
-	p->rowb = bsa_row_bytes(bw, p->pw);
+	p->rowb = 16u * bsa_tile_bytes(bw / 16u, p->pw);
 	p->qpad = bw + 32;
 	std::vector<uint32_t> order(n);
 	for(size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
@@ -469,7 +469,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + p->tpad + 15) & ~(size_t)15;
 		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw;
 	}
-	for(size_t pos = 0; pos < n; pos++) need[pos] = bsa_slot_bytes(tlen[order[pos]], p->rowb);
+	for(size_t pos = 0; pos < n; pos++) need[pos] = bsa_slot_bytes(tlen[order[pos]], bw / 16u, p->pw);
 	p->cells = cells;
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
 	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);

@@ -26,7 +26,7 @@ struct Align8Args {
 	uint32_t       *status;     // [n] per original pair
 	uint32_t first, count;      // processing positions [first, first+count) handled by this launch
 	uint32_t bw;                // effective bandwidth (multiple of 16), uniform over the chunk
-	uint32_t rowb;              // bytes per stored row record
+	uint32_t rowb;              // bytes of one row group = 16 tiles (see the layout note below)
 	int32_t  mode;
 	int32_t  gapo1, gape1, gapo2, gape2;
 	int32_t  smax, smin;        // max / min of the score matrix (bsalign.h:3868-3873)
@@ -36,20 +36,26 @@ struct Align8Args {
 
 // Traceback state of one pair ("slot") in the workspace:
 //   [begs: (tlen + 2) int32, padded to 16 B]   begs[r + 1] = band offset of target row r (row -1 first, = 0)
-//   [row records: tlen + 3 of rowb bytes]       record r + 1 = target row r; the 2 spare records + consumed rows
-//                                               at the end are the CIGAR scratch of the traceback
-// Row record, BLOCK-INTERLEAVED so that one traceback step touches one cache line: for running block y = 0..15
-// (= lane y of the forward kernel):
+//   [row-group tiles]                           see below; the tiles of consumed rows + 1 spare group at the end are
+//                                               the CIGAR scratch of the traceback
+// Block record (what one lane of the forward kernel owns of one row): for running block y = 0..15
 //   [u: W int8][e: W int8 if pw >= 1][q: W int8 if pw == 2][pad to 4][ubegs[y]: int32]        = blk bytes
-// followed by ubegs[16] (int32).  u[p] = H(p) - H(p-1) for band position p = y*W + k.
+// with u[p] = H(p) - H(p-1) for band position p = y*W + k (ubegs[16] is not stored: the traceback never reads it).
+// TILING: the traceback walks up the rows while its band-relative position drifts slowly, so the records of the SAME
+// block y of G consecutive rows share one tile (G = 64 / blk rows, tile = 64 bytes when blk <= 64): one 128-byte
+// line (two neighbouring blocks) serves G steps of the walk instead of one.  The forward kernel keeps the last G-1
+// records of its block in registers and writes whole tiles, so HBM only ever sees full 64-byte stores.
+// Record (row r, block y), with rr = r + 1:
+//   tiles + ((rr / G) * 16 + y) * tileb + (rr % G) * blk
 static inline __host__ __device__ uint32_t bsa_blk_cells(uint32_t W, int pw){ return ((uint32_t)(pw + 1) * W + 3u) & ~3u; }
 static inline __host__ __device__ uint32_t bsa_blk_bytes(uint32_t W, int pw){ return bsa_blk_cells(W, pw) + 4u; }
-static inline __host__ __device__ uint32_t bsa_row_bytes(uint32_t bw, int pw){
-	uint32_t b = 16u * bsa_blk_bytes(bw / 16u, pw) + 4u;
-	return (b + 15u) & ~15u;
-}
+static inline __host__ __device__ uint32_t bsa_tile_rows(uint32_t W, int pw){ uint32_t g = 64u / bsa_blk_bytes(W, pw); return g ? g : 1u; }
+static inline __host__ __device__ uint32_t bsa_tile_bytes(uint32_t W, int pw){ return (bsa_tile_rows(W, pw) * bsa_blk_bytes(W, pw) + 15u) & ~15u; }
 static inline __host__ __device__ size_t bsa_begs_bytes(uint32_t tlen){ return (((size_t)tlen + 2) * 4 + 15) & ~(size_t)15; }
-static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t rowb){ return bsa_begs_bytes(tlen) + ((size_t)tlen + 3) * rowb; }
+static inline __host__ __device__ size_t bsa_groups(uint32_t tlen, uint32_t G){ return ((size_t)tlen + 1 + G - 1) / G + 1; }   // + 1 spare group
+static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t W, int pw){
+	return bsa_begs_bytes(tlen) + bsa_groups(tlen, bsa_tile_rows(W, pw)) * 16 * (size_t)bsa_tile_bytes(W, pw);
+}
 
 static inline __host__ __device__ int bsa_get_piecewise(int gapo1, int gape1, int gapo2, int gape2, int bandwidth){ // bsalign.h:2084-2092
 	if(gapo2 < gapo1 && gape2 > gape1 && gapo2 + gape2 < gapo1 + gape1 && (gapo1 - gapo2) / (gape1 - gape2) < bandwidth) return 2;
@@ -74,6 +80,51 @@ struct EditArgs {
 	uint32_t pad_rows;              // spare row records at the end of every slot (CIGAR scratch)
 	int32_t  mode;
 };
+
+#ifdef __HIPCC__
+// Buffered tile writer used by the forward kernels: RW dwords per block record, TG rows per tile.
+template<int RW, int TG>
+struct TileWriter {
+	uint32_t hist[(TG > 1) ? (TG - 1) : 1][RW];
+	static constexpr uint32_t BLK = RW * 4u, TILEB = (TG * BLK + 15u) & ~15u;
+	// push the record of row index rr (= target row + 1); `last` = this is the final row of the pair
+	__device__ __forceinline__ void push(uint8_t *tiles, uint32_t j, uint32_t rr, bool active, bool last, const uint32_t (&rec)[RW]){
+		const uint32_t slot = rr % (uint32_t)TG;
+		if(active && (slot == (uint32_t)TG - 1u || last)){
+			uint32_t *tile = (uint32_t*)(tiles + ((size_t)(rr / (uint32_t)TG) * 16u + j) * TILEB);
+			if(slot == (uint32_t)TG - 1u){
+#pragma unroll
+				for(int m = 0; m < TG - 1; m++){
+#pragma unroll
+					for(int d = 0; d < RW; d++) tile[m * RW + d] = hist[m][d];
+				}
+#pragma unroll
+				for(int d = 0; d < RW; d++) tile[(TG - 1) * RW + d] = rec[d];
+			} else {           // partial last group of the pair
+#pragma unroll
+				for(int m = 0; m < TG - 1; m++){
+					const int ds = m - (TG - 1 - (int)slot);
+					if(ds >= 0){
+#pragma unroll
+						for(int d = 0; d < RW; d++) tile[ds * RW + d] = hist[m][d];
+					}
+				}
+#pragma unroll
+				for(int d = 0; d < RW; d++) tile[slot * RW + d] = rec[d];
+			}
+		}
+		if(TG > 1){
+#pragma unroll
+			for(int m = 0; m + 1 < TG - 1; m++){
+#pragma unroll
+				for(int d = 0; d < RW; d++) hist[m][d] = hist[m + 1][d];
+			}
+#pragma unroll
+			for(int d = 0; d < RW; d++) hist[(TG > 1) ? (TG - 2) : 0][d] = rec[d];
+		}
+	}
+};
+#endif
 
 // launchers implemented in the kernel translation units
 hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st);

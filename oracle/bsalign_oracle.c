@@ -643,16 +643,17 @@ static long align_core(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint3
 		}
 	}
 	if(begs_out) memcpy(begs_out, R.begs + 1, sizeof(int32_t) * tlen);
-	if(rows_out){ /* dump in the device's slot layout (bsalign_amd/csrc/bsa_common.h): begs array, then block-interleaved row records */
+	if(rows_out){ /* dump in the device's slot layout (bsalign_amd/csrc/bsa_common.h): begs array, then row-group tiles of block records */
 		uint32_t r, y, k2;
 		const uint32_t cells = ((uint32_t)(pw + 1) * W + 3u) & ~3u, blk = cells + 4u;
+		const uint32_t tg = (64u / blk) ? (64u / blk) : 1u, tileb = (tg * blk + 15u) & ~15u;
 		const size_t begs_bytes = (((size_t)tlen + 2) * 4 + 15) & ~(size_t)15;
 		int32_t *bg = (int32_t*)rows_out;
+		(void)rowb;
 		for(r = 0; r <= tlen; r++) bg[r] = R.begs[r];
 		for(r = 0; r <= tlen; r++){
-			uint8_t *rec = rows_out + begs_bytes + (size_t)r * rowb;
 			for(y = 0; y < NL; y++){
-				uint8_t *bp = rec + (size_t)y * blk;
+				uint8_t *bp = rows_out + begs_bytes + ((size_t)(r / tg) * NL + y) * tileb + (size_t)(r % tg) * blk;
 				for(k2 = 0; k2 < W; k2++){
 					bp[k2] = (uint8_t)R.ups[(size_t)r * bw + k2 * NL + y];
 					if(pw >= 1) bp[W + k2] = (uint8_t)R.eps[(size_t)r * bw + k2 * NL + y];
@@ -660,7 +661,6 @@ static long align_core(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint3
 				}
 				memcpy(bp + cells, R.ubs + (size_t)r * (NL + 1) + y, 4);
 			}
-			memcpy(rec + (size_t)NL * blk, R.ubs + (size_t)r * (NL + 1) + NL, 4);
 		}
 	}
 	cv.buf = cig; cv.n = 0; cv.cap = cig ? cap : 0;

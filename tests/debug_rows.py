@@ -41,32 +41,34 @@ def main():
         W = bw // 16
         cells = ((pw + 1) * W + 3) & ~3
         blk = cells + 4
-        rowb = (16 * blk + 4 + 15) & ~15
+        tg = max(64 // blk, 1)
+        tileb = (tg * blk + 15) & ~15
         begs_bytes = ((tl + 2) * 4 + 15) & ~15
-        nbytes = begs_bytes + (tl + 1) * rowb
+        ngroups = (tl + 1 + tg - 1) // tg + 1
+        nbytes = begs_bytes + ngroups * 16 * tileb
         slot = plan.debug_slot(k, nbytes)
         oslot = np.zeros(nbytes, dtype=np.uint8)
         res = np.zeros(10, dtype=np.int32)
         m = S.score_matrix(sc[0], sc[1])
         lib.orc_align_pairwise_rows(S.ptr(q, S.u8p), len(q), S.ptr(t, S.u8p), tl, mode, bw, S.ptr(m, S.i8p),
-                                    sc[2], sc[3], sc[4], sc[5], S.ptr(res, S.i32p), oslot.ctypes.data_as(C.c_void_p), rowb)
+                                    sc[2], sc[3], sc[4], sc[5], S.ptr(res, S.i32p), oslot.ctypes.data_as(C.c_void_p), 0)
         print("pair", k, "qlen", len(q), "tlen", tl, "gpu", out[k], "orc", res)
         gb, ob = slot[:(tl + 1) * 4].view(np.int32), oslot[:(tl + 1) * 4].view(np.int32)
         if not np.array_equal(gb, ob):
             r = int(np.nonzero(gb != ob)[0][0])
             print("  band offsets first differ at row", r - 1, "gpu", gb[r:r + 4], "orc", ob[r:r + 4])
-        used = 16 * blk + 4
         for r in range(tl + 1):
-            g = slot[begs_bytes + r * rowb: begs_bytes + r * rowb + used]
-            o = oslot[begs_bytes + r * rowb: begs_bytes + r * rowb + used]
-            if not np.array_equal(g, o):
-                print("  first differing row:", r - 1)
-                for y in range(16):
-                    gy, oy = g[y * blk:(y + 1) * blk], o[y * blk:(y + 1) * blk]
-                    if not np.array_equal(gy, oy):
-                        print("    block", y, "gpu u", gy[:W].view(np.int8), "e", gy[W:2 * W].view(np.int8) if pw else "", "ub", gy[cells:cells + 4].view(np.int32))
-                        print("    block", y, "orc u", oy[:W].view(np.int8), "e", oy[W:2 * W].view(np.int8) if pw else "", "ub", oy[cells:cells + 4].view(np.int32))
-                print("    ubegs[16] gpu", g[16 * blk:16 * blk + 4].view(np.int32), "orc", o[16 * blk:16 * blk + 4].view(np.int32))
+            diff = False
+            for y in range(16):
+                o0 = begs_bytes + ((r // tg) * 16 + y) * tileb + (r % tg) * blk
+                gy, oy = slot[o0:o0 + blk], oslot[o0:o0 + blk]
+                if not np.array_equal(gy, oy):
+                    if not diff:
+                        print("  first differing row:", r - 1)
+                    diff = True
+                    print("    block", y, "gpu u", gy[:W].view(np.int8), "e", gy[W:2 * W].view(np.int8) if pw else "", "ub", gy[cells:cells + 4].view(np.int32))
+                    print("    block", y, "orc u", oy[:W].view(np.int8), "e", oy[W:2 * W].view(np.int8) if pw else "", "ub", oy[cells:cells + 4].view(np.int32))
+            if diff:
                 break
         else:
             print("  all rows equal")
