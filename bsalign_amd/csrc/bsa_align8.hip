@@ -593,16 +593,16 @@ __global__ void __launch_bounds__(64) k_align8_backcal(const Align8Args a, int p
 }
 
 // ---------------------------------------------------------------------------------------------
-// Global-mode traceback with a prefetching helper wave (bandwidth <= 128, i.e. W <= 8).
+// Global-mode traceback, register-record form (bandwidth <= 128, i.e. W <= 8).
 //
-// Same decisions as k_align8_backcal.  The walk is a chain of ~2 dependent steps per cell (band offset -> block
-// record), and loads of one wave return in order, so a wave cannot hide its own HBM misses by prefetching for
-// itself.  Each block therefore runs TWO waves: wave 0 walks 64 pairs (one per lane) and publishes, per step, the
-// address of the block record it is reading; wave 1 never walks, it only touches the same block of the next few
-// rows (the band-relative position of the path drifts slowly, and a 128-byte line holds ~6 blocks), so that the
-// worker's loads hit L2.  The M-step reads whole block records (u, e, q bytes + ubegs of one running block = one
-// 20..28 byte record) into registers instead of byte loads.
+// Same decisions as k_align8_backcal.  The walk is a chain of dependent loads (band offset -> block record) and the
+// loads of one wave return in order, so what hides the HBM latency is the NUMBER OF WAVES, not prefetching inside a
+// wave (a helper wave that touched the rows ahead was measured: it only added traffic once the records were tiled).
+// The kernel therefore runs one pair per lane but uses only TRACE_LANES lanes of every wave: a 50 k-pair launch
+// becomes ~3000 waves instead of ~800 and a step waits for the slowest of 16 lanes instead of 64.  The cell step
+// reads one whole block record (u, e, q bytes + ubegs of one running block) into registers instead of byte loads.
 // ---------------------------------------------------------------------------------------------
+#define TRACE_LANES 16u
 struct BlkRec { uint32_t d[7]; };
 template<int W>
 static __device__ __forceinline__ int rec_prefix(const BlkRec &r, uint32_t cells, uint32_t x){   // ubegs[y] + u[0..x]
@@ -627,46 +627,18 @@ static __device__ __forceinline__ int rec_byte(const BlkRec &r, uint32_t b){    
 // in different states at any time, and with nested loops every state's chain of dependent loads would be paid
 // one after the other on every step.
 template<int W, int PW>
-__global__ void __launch_bounds__(128) k_align8_backcal_g(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
+__global__ void __launch_bounds__(64) k_align8_backcal_g(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
 	constexpr int pw = PW;
 	constexpr uint32_t CELLS = (((uint32_t)(PW + 1) * W + 3u) & ~3u), BLKW = (CELLS + 4u) / 4u;
-	__shared__ volatile unsigned long long hint[64];
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const uint32_t g = blockIdx.x * 64u + lane;
-	const bool live = g < a.count;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t g = blockIdx.x * TRACE_LANES + lane;
+	const bool live = lane < TRACE_LANES && g < a.count;
 	const uint32_t ppos = a.first + (live ? g : 0u);
 	const uint32_t pair = a.order[ppos];
 	const bool skip = !live || a.status[pair] != 0u;
 	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
 	RowView R;
 	R.init(a.rows + a.slot_off[ppos], tlen, a.bw, pw);
-	if(wave == 0) hint[lane] = skip ? 1ull : 0ull;
-	__syncthreads();
-	if(wave == 1){
-		// ---- helper: touch the rows ahead of every worker lane until all of them are done
-		unsigned long long last = 0ull;
-		const unsigned long long lo_addr = (unsigned long long)(uintptr_t)R.rows;
-		int acc = 0;
-		for(;;){
-			const unsigned long long h = hint[lane];
-			if(h > 1ull && h != last && !(a.mode & 0x100)){
-				// the worker entered a new tile: pull the same block of the next two row groups below into L2
-				int v[2];
-#pragma unroll
-				for(int d = 0; d < 2; d++){
-					unsigned long long ad = h - (unsigned long long)(1 + d) * 16ull * R.tileb;
-					if(ad < lo_addr || ad > h) ad = lo_addr;
-					v[d] = *(const int*)(uintptr_t)ad;
-				}
-				acc += v[0] + v[1];
-				last = h;
-			}
-			if(__all(h == 1ull)) break;
-			__builtin_amdgcn_s_sleep(2);
-		}
-		asm volatile("" :: "v"(acc));
-		return;
-	}
 	bsa_result_t rs;
 	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
 	if(skip){ if(live){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
@@ -727,7 +699,6 @@ __global__ void __launch_bounds__(128) k_align8_backcal_g(const Align8Args a, bs
 			frow = rs.tb; fblk = pp / W; fx = pp % W;
 		}
 		const uint32_t *rp = (const uint32_t*)R.blkp(frow, fblk);
-		hint[lane] = (unsigned long long)(uintptr_t)R.tilep(frow, fblk);
 		BlkRec rc;
 #pragma unroll
 		for(int k = 0; k < 7; k++) rc.d[k] = ((uint32_t)k < BLKW) ? rp[k] : 0u;
@@ -840,7 +811,6 @@ __global__ void __launch_bounds__(128) k_align8_backcal_g(const Align8Args a, bs
 		if(cg) cig_push(cg);
 		rs.qb++; rs.tb++;
 	}
-	hint[lane] = 1ull;
 	if(bad){
 		atomicOr(&a.status[pair], BSA_ST_TRACE);
 		ncig = 0;
@@ -890,14 +860,12 @@ hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st){
 hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	// global mode, W <= 8: two-wave traceback (walker + prefetching helper); BSA_ALIGN8_TRACE1=1 forces the one-wave kernel
 	static const bool force_one = [](){ const char *e = getenv("BSA_ALIGN8_TRACE1"); return e && e[0] == '1'; }();
-	static const bool no_help = [](){ const char *e = getenv("BSA_TRACE_NOHELP"); return e && e[0] == '1'; }();
-	if(no_help){ Align8Args b = a; b.mode |= 0x100; if(!force_one && (b.mode & 3) == BSA_MODE_GLOBAL && b.bw / 16 <= 8 && b.count){ const uint32_t nb = (b.count + 63) / 64; if(b.bw/16 == 8 && pw == 1){ hipLaunchKernelGGL((k_align8_backcal_g<8, 1>), dim3(nb), dim3(128), 0, st, b, out, cig_cnt); return hipGetLastError(); } } }
 	if(!force_one && (a.mode & 3) == BSA_MODE_GLOBAL && a.bw / 16 <= 8 && a.count){
-		const uint32_t nb = (a.count + 63) / 64;
+		const uint32_t nb = (a.count + TRACE_LANES - 1) / TRACE_LANES;
 #define TRACE_CASE(WW) case WW: \
-			if(pw == 0) hipLaunchKernelGGL((k_align8_backcal_g<WW, 0>), dim3(nb), dim3(128), 0, st, a, out, cig_cnt); \
-			else if(pw == 1) hipLaunchKernelGGL((k_align8_backcal_g<WW, 1>), dim3(nb), dim3(128), 0, st, a, out, cig_cnt); \
-			else hipLaunchKernelGGL((k_align8_backcal_g<WW, 2>), dim3(nb), dim3(128), 0, st, a, out, cig_cnt); \
+			if(pw == 0) hipLaunchKernelGGL((k_align8_backcal_g<WW, 0>), dim3(nb), dim3(64), 0, st, a, out, cig_cnt); \
+			else if(pw == 1) hipLaunchKernelGGL((k_align8_backcal_g<WW, 1>), dim3(nb), dim3(64), 0, st, a, out, cig_cnt); \
+			else hipLaunchKernelGGL((k_align8_backcal_g<WW, 2>), dim3(nb), dim3(64), 0, st, a, out, cig_cnt); \
 			return hipGetLastError();
 		switch(a.bw / 16){
 			TRACE_CASE(1) TRACE_CASE(2) TRACE_CASE(4) TRACE_CASE(8)

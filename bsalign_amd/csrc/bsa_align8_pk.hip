@@ -35,7 +35,7 @@ static __device__ __forceinline__ void load_qcodes_pk(const uint8_t *p, uint32_t
 }
 
 template<int W, int PW>
-__global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
+__global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd_pk(const Align8Args a){
 	constexpr int BW = W * 16;
 	constexpr int NQ = (W + 3) / 4;
 	extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // generic movx scratch: per pair (PW+1)*BW bytes + 17 ints
@@ -147,9 +147,8 @@ __global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
 		store_rows(0, act0, rbeg);
 	}
 	int tb_next[2];
-	double dq[2], dt[2];
 #pragma unroll
-	for(int h = 0; h < 2; h++){ tb_next[h] = tlen[h] ? (int)tp[h][0] : 0; dq[h] = (double)qlen[h]; dt[h] = (double)tlen[h]; }
+	for(int h = 0; h < 2; h++) tb_next[h] = tlen[h] ? (int)tp[h][0] : 0;
 
 	while(__any(i < tlen[0] || i < tlen[1])){
 		bool act[2];
@@ -187,14 +186,13 @@ __global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			int nu[2][W], ne[2][W], nq[2][W];
+			// one half at a time (keeps the temporaries of only one pair live)
 #pragma unroll
 			for(int h = 0; h < 2; h++){
 				const int8_t *su = gl + h * PAIR_LDS, *se = su + BW, *sq = su + 2 * BW;
 				const int *sub = (const int*)(su + (PW + 1) * BW);
 				const uint32_t mv = mov[h];
-#pragma unroll
-				for(int k = 0; k < W; k++){ nu[h][k] = su[j * W + k]; ne[h][k] = (PW >= 1) ? se[j * W + k] : 0; nq[h][k] = (PW == 2) ? sq[j * W + k] : 0; }
+				const uint32_t hmask = h ? 0xFFFF0000u : 0x0000FFFFu;
 				if(mv){
 					uint32_t pp = min(mv - 1u, (uint32_t)BW - 1u), yy = pp / W, xx = pp % W;
 					int s = sub[yy];
@@ -203,21 +201,22 @@ __global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
 				}
 				if(mv >= (uint32_t)BW){
 #pragma unroll
-					for(int k = 0; k < W; k++){ nu[h][k] = 0; ne[h][k] = 0; nq[h][k] = 0; }
+					for(int k = 0; k < W; k++){ u[k] &= ~hmask; e[k] &= ~hmask; q2[k] &= ~hmask; }
 					ubA[h] = ubB[h] = BSA_SCORE_MIN;
 				} else if(mv){
 					const uint32_t cyc = mv / W, m = mv % W, p0 = BW - mv;
 #pragma unroll
 					for(int k = 0; k < W; k++){
-						uint32_t src = j * W + k + mv;
+						const uint32_t src = j * W + k + mv;
+						int vu, ve = 0, vq = 0;
 						if(src < (uint32_t)BW){
-							nu[h][k] = su[src];
-							if(PW >= 1) ne[h][k] = se[src];
-							if(PW == 2) nq[h][k] = sq[src];
-						} else {
-							nu[h][k] = trunc8(newcell_int((int)(src - BW)));
-							ne[h][k] = 0; nq[h][k] = 0;
-						}
+							vu = su[src];
+							if(PW >= 1) ve = se[src];
+							if(PW == 2) vq = sq[src];
+						} else vu = trunc8(newcell_int((int)(src - BW)));
+						u[k] = (pk_splat(vu) & hmask) | (u[k] & ~hmask);
+						if(PW >= 1) e[k] = (pk_splat(ve) & hmask) | (e[k] & ~hmask);
+						if(PW == 2) q2[k] = (pk_splat(vq) & hmask) | (q2[k] & ~hmask);
 					}
 					auto new_ub = [&](uint32_t idx) -> int {
 						int v;
@@ -233,12 +232,6 @@ __global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
 					ubA[h] = new_ub((uint32_t)j);
 					ubB[h] = new_ub((uint32_t)j + 1u);
 				}
-			}
-#pragma unroll
-			for(int k = 0; k < W; k++){
-				u[k] = pk_make(nu[0][k], nu[1][k]);
-				if(PW >= 1) e[k] = pk_make(ne[0][k], ne[1][k]);
-				if(PW == 2) q2[k] = pk_make(nq[0][k], nq[1][k]);
 			}
 			__builtin_amdgcn_wave_barrier();
 		} else {
@@ -424,7 +417,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_pk(const Align8Args a){
 			else rbx = 1;
 			if(mode == BSA_MODE_GLOBAL){
 				const int rbz = 2 * max((int)(tlen[h] / max(qlen[h], 1u)), 1);
-				const int rby = (int)((1.0 * (double)i / dt[h]) * dq[h]);
+				const int rby = (int)((1.0 * (double)i / (double)tlen[h]) * (double)qlen[h]);
 				const uint32_t left = tlen[h] - i - 1u;
 				if((long long)rbeg[h] + (long long)rbz * (long long)left + (long long)BW <= (long long)(uint32_t)(qlen[h] + (uint32_t)rbz - 1u)){
 					mov[h] = 1u + (uint32_t)(qlen[h] - (rbeg[h] + BW)) / max(left, 1u);
