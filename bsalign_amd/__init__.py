@@ -31,6 +31,20 @@ class AlignParams(C.Structure):
                 ("gapo1", C.c_int8), ("gape1", C.c_int8), ("gapo2", C.c_int8), ("gape2", C.c_int8)]
 
 
+class RowTask(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("src", C.c_uint32), ("dst", C.c_uint32), ("qoff_src", C.c_uint32), ("qoff_dst", C.c_uint32),
+                ("toff", C.c_uint32), ("query", C.c_uint32), ("base", C.c_uint8), ("prof", C.c_uint8), ("reserved", C.c_uint16)]
+
+
+class RowsParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("bandwidth", C.c_uint32), ("M", C.c_int8), ("X", C.c_int8), ("refbonus", C.c_int8),
+                ("gapo1", C.c_int8), ("gape1", C.c_int8), ("gapo2", C.c_int8), ("gape2", C.c_int8)]
+
+
+ROW_TASK_DTYPE = np.dtype([("op", np.uint32), ("src", np.uint32), ("dst", np.uint32), ("qoff_src", np.uint32), ("qoff_dst", np.uint32),
+                           ("toff", np.uint32), ("query", np.uint32), ("base", np.uint8), ("prof", np.uint8), ("reserved", np.uint16)])
+
+
 class EditParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("bandwidth", C.c_uint32)]
 
@@ -86,6 +100,9 @@ def lib():
             L.bsa_edit_plan_cells.argtypes = [vp]
             L.bsa_edit_plan_cells.restype = C.c_double
             L.bsa_edit_run.argtypes = [vp, u8p, vp, u32p, C.c_size_t, u64p, u32p]
+        L.bsa_rows_block_bytes.argtypes = [C.c_uint32, C.c_int8, C.c_int8, C.c_int8, C.c_int8]
+        L.bsa_rows_block_bytes.restype = C.c_size_t
+        L.bsa_rows_run.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(RowsParams)]
         L.bsa_align_debug_rows.argtypes = [vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
         _lib = L
     return _lib

@@ -139,6 +139,36 @@ int  bsa_edit_run(bsa_edit_plan_t *plan, const uint8_t *d_seqs,
                   bsa_result_t *d_out, uint32_t *d_cigar, size_t cigar_cap_words,
                   uint64_t *d_cigar_off, uint32_t *d_status);
 
+/* ---- row-level kernels for the POA seq->graph DP (P4; reference bspoa.h:2232-2272) ----------------------------
+ * The POA sweep calls, per graph edge u -> v, row_movx + row_cal on u's DP row (dpalign_row_update_bspoa) and, per
+ * extra in-edge, row_merge (dpalign_row_merge_bspoa).  bsa_rows_run executes a batch of such INDEPENDENT tasks (one
+ * topological level of many reads / windows) on device-resident row blocks.  A row block has exactly the reference's
+ * layout and size (bspoa.h:1787-1793, 2217): us[bw] | es[bw] if piecewise >= 1 | qs[bw] if piecewise == 2 |
+ * int32 ubegs[17], striped index (p % W) * 16 + p / W, padded to 16 bytes (bsa_rows_block_bytes). */
+#define BSA_ROW_OP_UPDATE 0u   /* rows[dst] = row_cal(row_movx(rows[src], qoff_dst - qoff_src))   bspoa.h:2232 */
+#define BSA_ROW_OP_MERGE  1u   /* rows[dst] = cell-wise max(rows[src], rows[dst])                  bspoa.h:2263 */
+#define BSA_ROW_OP_INIT   2u   /* rows[dst] = row -1 of the read (row_init, bspoa.h:2226)                      */
+typedef struct {
+	uint32_t op;                  /* BSA_ROW_OP_* */
+	uint32_t src, dst;            /* row block indices (u->mmidx, v->mmidx) */
+	uint32_t qoff_src, qoff_dst;  /* band offsets (u->rpos, v->rpos) */
+	uint32_t toff;                /* v->mpos: row number used by the left-boundary score */
+	uint32_t query;               /* index into the query table */
+	uint8_t  base;                /* v->base */
+	uint8_t  prof;                /* (v->base == u->base) * 2 + v->bonus: which of the 4 profiles of bspoa.h:2199-2213 */
+	uint16_t reserved;
+} bsa_row_task_t;
+typedef struct {
+	int32_t  mode;                /* par->alnmode */
+	uint32_t bandwidth;           /* multiple of 16, bandwidth / 16 in {1,2,4,8,16} */
+	int8_t   M, X, refbonus;      /* par->M, par->X, par->refbonus */
+	int8_t   gapo1, gape1, gapo2, gape2;
+} bsa_rows_params_t;
+size_t bsa_rows_block_bytes(uint32_t bandwidth, int8_t gapo1, int8_t gape1, int8_t gapo2, int8_t gape2);
+/* all pointers are DEVICE memory; asynchronous on the context stream; tasks of one call must not depend on each other */
+int bsa_rows_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task_t *d_tasks, size_t ntasks,
+                 const uint8_t *d_queries, const uint64_t *d_qoff, const uint32_t *d_qlen, const bsa_rows_params_t *par);
+
 /* ---- synthetic read pairs (measurement inputs, SURVEY 8(d) / BASELINE.md 3) ---------------------
  * pair k: target = iid uniform ACGT of length L from splitmix64(seed ^ k*0x9E3779B97F4A7C15);
  * query = target with errors at rate err_q32 / 2^32 split sub:ins:del = 23:31:46.
