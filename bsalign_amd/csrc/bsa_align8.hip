@@ -447,8 +447,9 @@ __global__ void __launch_bounds__(64) k_align8_backcal(const Align8Args a, int p
 	const uint8_t *qseq = a.qst + a.qpoff[pair];
 	const uint8_t *tseq = a.tst + a.tpoff[pair];
 	RowView R;
-	R.init(a.rows + a.slot_off[ppos], tlen, a.bw, pw);
-	const uint32_t bw = a.bw, W = R.W;
+	const uint32_t bw = a.bw ? a.bw : ((qlen + 15u) / 16u * 16u);     // bandwidth 0 = the whole (rounded) query (bsalign.h:3861-3862)
+	R.init(a.rows + a.slot_off[ppos], tlen, bw, pw);
+	const uint32_t W = R.W;
 	const int mode = a.mode & 3;
 	const int gapo1 = a.gapo1, gape1 = a.gape1, gapo2 = a.gapo2, gape2 = a.gape2;
 	// cigar scratch: the tail end of this pair's slot (tlen + 3 row records long)

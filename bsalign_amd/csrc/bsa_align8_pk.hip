@@ -147,8 +147,12 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 		store_rows(0, act0, rbeg);
 	}
 	int tb_next[2];
+	int rbz[2];     // 2 * max(tlen / qlen, 1): suggested max band step (bsalign.h:4008)
 #pragma unroll
-	for(int h = 0; h < 2; h++) tb_next[h] = tlen[h] ? (int)tp[h][0] : 0;
+	for(int h = 0; h < 2; h++){
+		tb_next[h] = tlen[h] ? (int)tp[h][0] : 0;
+		rbz[h] = 2 * max((int)(tlen[h] / max(qlen[h], 1u)), 1);
+	}
 
 	while(__any(i < tlen[0] || i < tlen[1])){
 		bool act[2];
@@ -401,6 +405,7 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 		}
 		store_rows(i + 1, act, rbeg);
 		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
+		bool rush[2] = {false, false};
 #pragma unroll
 		for(int h = 0; h < 2; h++){
 			int dsum = ubB[h] - ubA[h]; dsum = dsum < 0 ? -dsum : dsum;
@@ -416,17 +421,22 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			else if(ub0 > ub16 + noisy) rbx = 0;
 			else rbx = 1;
 			if(mode == BSA_MODE_GLOBAL){
-				const int rbz = 2 * max((int)(tlen[h] / max(qlen[h], 1u)), 1);
 				const int rby = (int)((1.0 * (double)i / (double)tlen[h]) * (double)qlen[h]);
+				// "be quick to move to end": rbeg + rbz * (tlen - i - 1) + bw <= qlen + rbz - 1 (64-bit); its division is rare
 				const uint32_t left = tlen[h] - i - 1u;
-				if((long long)rbeg[h] + (long long)rbz * (long long)left + (long long)BW <= (long long)(uint32_t)(qlen[h] + (uint32_t)rbz - 1u)){
-					mov[h] = 1u + (uint32_t)(qlen[h] - (rbeg[h] + BW)) / max(left, 1u);
-				} else if((int)rbeg[h] < rby - BW){
-					mov[h] = (uint32_t)(rbx + 1);
-				} else if((int)rbeg[h] > rby){
-					mov[h] = (uint32_t)max(0, rbx - 1);
-				} else mov[h] = (uint32_t)rbx;
+				const unsigned long long lhs = (unsigned long long)rbeg[h] + (unsigned long long)(uint32_t)rbz[h] * left + (unsigned long long)BW;
+				rush[h] = act[h] && lhs <= (unsigned long long)(uint32_t)(qlen[h] + (uint32_t)rbz[h] - 1u);
+				if((int)rbeg[h] < rby - BW) mov[h] = (uint32_t)(rbx + 1);
+				else if((int)rbeg[h] > rby) mov[h] = (uint32_t)max(0, rbx - 1);
+				else mov[h] = (uint32_t)rbx;
 			} else mov[h] = (uint32_t)rbx;
+		}
+		if(__any(rush[0] || rush[1])){
+#pragma unroll
+			for(int h = 0; h < 2; h++){
+				const uint32_t left = tlen[h] - i - 1u;
+				if(rush[h]) mov[h] = 1u + (uint32_t)(qlen[h] - (rbeg[h] + BW)) / max(left, 1u);
+			}
 		}
 		i++;
 	}

@@ -434,7 +434,9 @@ static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t
 // ------------------------------------------------------------------------------------------------
 struct bsa_align_plan : PlanBase {
 	bsa_align_params_t par;
-	uint32_t bw = 0, rowb = 0; int pw = 0;
+	uint32_t bw = 0, rowb = 0; int pw = 0;       // bw == 0: per-pair bandwidth = roundup(qlen, 16)
+	bool generic = false;                        // run the LDS-resident generic kernels
+	uint32_t max_bw = 0;
 	uint32_t qpad = 0, tpad = 16;
 };
 
@@ -449,14 +451,20 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	const int type = par->mode & 3;
 	if(type != BSA_MODE_GLOBAL && type != BSA_MODE_OVERLAP && type != BSA_MODE_EXTEND){ c->err = "bad mode"; return BSA_E_ARG; }
 	(void)hipSetDevice(c->device);
-	if(par->bandwidth == 0){ c->err = "bandwidth 0 (per-pair full band) is not implemented on the device yet"; return BSA_E_UNSUPPORTED; }
-	uint32_t bw = (par->bandwidth + 15u) / 16u * 16u;   // bsalign.h:3862
-	if(!bsa_align8_supported_bw(bw)){ c->err = "bandwidth/16 must be one of 1,2,4,8,16,32 on the device for now"; return BSA_E_UNSUPPORTED; }
+	const uint32_t bw = (par->bandwidth + 15u) / 16u * 16u;   // bsalign.h:3862; 0 = per pair roundup(qlen, 16) (bsalign.h:3861)
 	bsa_align_plan *p = new bsa_align_plan();
 	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
-	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)bw);
-	p->rowb = 16u * bsa_tile_bytes(bw / 16u, p->pw);
-	p->qpad = bw + 32;
+	p->generic = (bw == 0) || !bsa_align8_supported_bw(bw);
+	uint32_t max_bw = bw;
+	if(bw == 0) for(size_t k = 0; k < n; k++) max_bw = std::max(max_bw, (qlen[k] + 15u) / 16u * 16u);
+	p->max_bw = max_bw;
+	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)std::max(max_bw, 16u));
+	if(p->generic && bsa_align8_gen_lds(max_bw, p->pw) > 160 * 1024){
+		c->err = "bandwidth too large for the device's generic kernel (two band rows must fit 160 KB of LDS)";
+		delete p; return BSA_E_UNSUPPORTED;
+	}
+	p->rowb = bw ? 16u * bsa_tile_bytes(bw / 16u, p->pw) : 0u;
+	p->qpad = max_bw + 32;
 	std::vector<uint32_t> order(n);
 	for(size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return tlen[x] > tlen[y]; });
@@ -464,12 +472,13 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	std::vector<size_t> need(n); std::vector<uint32_t> bwv(n, bw);
 	size_t qacc = 0, tacc = 0;
 	double cells = 0;
+	auto bw_of = [&](size_t k) -> uint32_t { return bw ? bw : std::max(16u, (qlen[k] + 15u) / 16u * 16u); };
 	for(size_t k = 0; k < n; k++){
 		qpoff[k] = qacc; qacc += ((size_t)qlen[k] + p->qpad + 15) & ~(size_t)15;
 		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + p->tpad + 15) & ~(size_t)15;
-		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw;
+		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw_of(k);
 	}
-	for(size_t pos = 0; pos < n; pos++) need[pos] = bsa_slot_bytes(tlen[order[pos]], bw / 16u, p->pw);
+	for(size_t pos = 0; pos < n; pos++) need[pos] = bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
 	p->cells = cells;
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
 	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
@@ -512,9 +521,11 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	}
 	const int pw = p->pw;
 	uint32_t *cnt = p->d_cnt_pos;
+	const bool generic = p->generic; const uint32_t max_bw = p->max_bw;
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
-		HIPCHK(c, bsa_launch_align8_fwd(b, pw, s));
+		if(generic) HIPCHK(c, bsa_launch_align8_fwd_gen(b, pw, max_bw, s));
+		else HIPCHK(c, bsa_launch_align8_fwd(b, pw, s));
 		return BSA_OK;
 	};
 	auto trace = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {

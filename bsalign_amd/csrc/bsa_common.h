@@ -25,7 +25,7 @@ struct Align8Args {
 	uint8_t        *rows;       // traceback rows workspace
 	uint32_t       *status;     // [n] per original pair
 	uint32_t first, count;      // processing positions [first, first+count) handled by this launch
-	uint32_t bw;                // effective bandwidth (multiple of 16), uniform over the chunk
+	uint32_t bw;                // effective bandwidth (multiple of 16), uniform over the chunk; 0 = per pair roundup(qlen, 16)
 	uint32_t rowb;              // bytes of one row group = 16 tiles (see the layout note below)
 	int32_t  mode;
 	int32_t  gapo1, gape1, gapo2, gape2;
@@ -130,6 +130,8 @@ struct TileWriter {
 hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st);
 hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);
 bool bsa_align8_supported_bw(uint32_t bw);
+size_t bsa_align8_gen_lds(uint32_t bw, int pw);
+hipError_t bsa_launch_align8_fwd_gen(const Align8Args &a, int pw, uint32_t max_bw, hipStream_t st);
 bool bsa_align8_pk_supported(const Align8Args &a, int pw);
 hipError_t bsa_launch_align8_fwd_pk(const Align8Args &a, int pw, hipStream_t st);
 bool bsa_edit_supported_bw(uint32_t bw);

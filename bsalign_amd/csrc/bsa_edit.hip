@@ -147,9 +147,12 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a){
 // traceback (bsalign.h:965-1044) + end-cell / score selection of the driver (:1124-1139, 1180-1203)
 // one pair per lane
 // ---------------------------------------------------------------------------------------------
+// The walk is latency-bound (dependent bit lookups), so only EDIT_TRACE_LANES lanes of every wave carry a pair:
+// 4x more waves for the same batch hide 4x more latency and a step waits for the slowest of 16 lanes, not 64.
+#define EDIT_TRACE_LANES 16u
 __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt){
-	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
-	if(g >= a.count) return;
+	const uint32_t g = blockIdx.x * EDIT_TRACE_LANES + threadIdx.x;
+	if(threadIdx.x >= EDIT_TRACE_LANES || g >= a.count) return;
 	const uint32_t ppos = a.first + g, pair = a.order[ppos];
 	bsa_result_t rs;
 	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
@@ -337,7 +340,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 }
 
 hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
-	const uint32_t blocks = (a.count + 63) / 64;
+	const uint32_t blocks = (a.count + EDIT_TRACE_LANES - 1) / EDIT_TRACE_LANES;
 	if(blocks == 0) return hipSuccess;
 	hipLaunchKernelGGL(k_edit_trace, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
 	return hipGetLastError();

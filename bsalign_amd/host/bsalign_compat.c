@@ -97,7 +97,7 @@ seqalign_result_t banded_striped_epi8_seqalign_pairwise(u1i *qseq, u4i qlen, u1i
 	check_mempool(mempool, __FUNCTION__);
 	if(qlen == 0 || tlen == 0){ if(cigars && !(mode & SEQALIGN_MODE_CIGRESV)) clear_u4v(cigars); return rs; }
 	par.mode = seqalign_mode_type(mode);
-	par.bandwidth = bandwidth ? bandwidth : qlen;      /* bsalign.h:3861 */
+	par.bandwidth = bandwidth;      /* 0 = the whole query, as in bsalign.h:3861 */
 	memcpy(par.matrix, matrix, 16);
 	par.gapo1 = gapo1; par.gape1 = gape1; par.gapo2 = gapo2; par.gape2 = gape2;
 	seqs = (uint8_t*)malloc((size_t)qlen + tlen + 1);
