@@ -45,6 +45,15 @@ ROW_TASK_DTYPE = np.dtype([("op", np.uint32), ("src", np.uint32), ("dst", np.uin
                            ("toff", np.uint32), ("query", np.uint32), ("base", np.uint8), ("prof", np.uint8), ("reserved", np.uint16)])
 
 
+class SweepParams(C.Structure):
+    _fields_ = [("rows", RowsParams), ("T", C.c_int32)]
+
+
+SWEEP_PROG_DTYPE = np.dtype([("first_task", np.uint32), ("ntasks", np.uint32), ("first_block", np.uint32), ("reserved", np.uint32)])
+SWEEP_RESULT_DTYPE = np.dtype([("maxscr", np.int32), ("maxidx", np.int32), ("maxoff", np.int32), ("reserved", np.int32)])
+ROW_OP_UPDATE, ROW_OP_MERGE, ROW_OP_INIT, ROW_OP_SCORE_TAIL, ROW_OP_SCORE_END = 0, 1, 2, 3, 4
+
+
 class EditParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("bandwidth", C.c_uint32)]
 
@@ -103,6 +112,8 @@ def lib():
         L.bsa_rows_block_bytes.argtypes = [C.c_uint32, C.c_int8, C.c_int8, C.c_int8, C.c_int8]
         L.bsa_rows_block_bytes.restype = C.c_size_t
         L.bsa_rows_run.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(RowsParams)]
+        L.bsa_sweep_run.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(SweepParams), vp]
+        L.bsa_sweep_host.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.POINTER(SweepParams), vp, C.c_size_t, vp]
         L.bsa_align_debug_rows.argtypes = [vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
@@ -205,6 +216,25 @@ class Context:
     def align_batch(self, pairs, par, cigar_cap=None):
         """host-pointer form of bsa_align_batch: returns (results, [cigar arrays], status)"""
         return self._batch(lib().bsa_align_batch, pairs, par, cigar_cap)
+
+    def sweep_host(self, tasks, progs, queries, qoff, qlen, par, nblocks, want_rows=True):
+        """host-pointer form of the POA sweep (bsa_sweep_host): tasks ROW_TASK_DTYPE, progs SWEEP_PROG_DTYPE,
+        queries one base per byte; returns (row blocks as uint8 [nblocks * block_bytes] or None, results)"""
+        L = lib()
+        tasks = np.ascontiguousarray(tasks, dtype=ROW_TASK_DTYPE)
+        progs = np.ascontiguousarray(progs, dtype=SWEEP_PROG_DTYPE)
+        queries = np.ascontiguousarray(queries, dtype=np.uint8)
+        qoff = np.ascontiguousarray(qoff, dtype=np.uint64)
+        qlen = np.ascontiguousarray(qlen, dtype=np.uint32)
+        r = par.rows
+        blk = L.bsa_rows_block_bytes(r.bandwidth, r.gapo1, r.gape1, r.gapo2, r.gape2)
+        rows = np.zeros(nblocks * blk, dtype=np.uint8) if want_rows else None
+        res = np.zeros(len(progs), dtype=SWEEP_RESULT_DTYPE)
+        rc = L.bsa_sweep_host(self.h, tasks.ctypes.data, len(tasks), progs.ctypes.data, len(progs), queries.ctypes.data,
+                              qoff.ctypes.data, qlen.ctypes.data, len(qlen), C.byref(par),
+                              rows.ctypes.data if want_rows else None, nblocks, res.ctypes.data)
+        self._chk(rc)
+        return rows, res
 
     def edit_batch(self, pairs, mode=MODE_GLOBAL, bandwidth=0, cigar_cap=None):
         p = EditParams()

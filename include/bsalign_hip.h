@@ -169,6 +169,43 @@ size_t bsa_rows_block_bytes(uint32_t bandwidth, int8_t gapo1, int8_t gape1, int8
 int bsa_rows_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task_t *d_tasks, size_t ntasks,
                  const uint8_t *d_queries, const uint64_t *d_qoff, const uint32_t *d_qlen, const bsa_rows_params_t *par);
 
+/* ---- the whole per-read sweep on the device (align_rd_bspoacore, bspoa.h:2515-2618) ----------
+ * The reference walks the selected sub-graph with a stack and per-node in-degree counters; the visiting order depends
+ * on the graph only, so the host flattens it into a program of row tasks (include/bsalign_poa_adapter.h does that from
+ * the reference's own graph structures).  One program = one read against one graph; its tasks run in order on one
+ * 16-lane DPP row, and many programs (POA windows) run concurrently.  Besides INIT / UPDATE / MERGE a program holds
+ * the two places where the reference samples an end-of-alignment score:
+ *   SCORE_TAIL  edge u -> tail (bspoa.h:2547-2577): H at the last band cell of u's row + the unaligned-tail gap + T,
+ *               and in overlap mode the row maximum (row_max, bsalign.h:3213);
+ *   SCORE_END   node v complete and its band reaches the read end, non-global modes (bspoa.h:2597-2606).
+ * For both: src = the node's row block, qoff_src = its band offset (rpos), toff = the node index reported as maxidx.
+ * A candidate replaces the running best only if strictly greater, in program order -- the reference's rule. */
+#define BSA_ROW_OP_SCORE_TAIL 3u
+#define BSA_ROW_OP_SCORE_END  4u
+typedef struct {
+	uint32_t first_task, ntasks;  /* this program's slice of the task array */
+	uint32_t first_block;         /* task block indices are relative to this row block (mmidx 0 of the read's memp) */
+	uint32_t reserved;
+} bsa_sweep_prog_t;
+typedef struct {
+	int32_t maxscr, maxidx, maxoff; /* g->maxscr, g->maxidx, g->maxoff (bspoa.h:2227-2229); -2^30-ish, -1, -1 when no candidate */
+	int32_t reserved;
+} bsa_sweep_result_t;
+typedef struct {
+	bsa_rows_params_t rows;
+	int32_t T;                    /* par->T: bonus for reaching the read end */
+} bsa_sweep_params_t;
+/* all pointers are DEVICE memory; asynchronous on the context stream */
+int bsa_sweep_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task_t *d_tasks, const bsa_sweep_prog_t *d_progs,
+                  size_t nprogs, const uint8_t *d_queries, const uint64_t *d_qoff, const uint32_t *d_qlen,
+                  const bsa_sweep_params_t *par, bsa_sweep_result_t *d_results);
+/* HOST buffers in, HOST buffers out (uploads, runs, downloads, synchronises): what a single-window caller such as
+ * the adapter uses.  rows_out (nblocks * bsa_rows_block_bytes, may be NULL) receives every row block so that host
+ * traceback code (alignment2graph_bspoa, bspoa.h:2274) can read them as if the CPU had computed them. */
+int bsa_sweep_host(bsa_ctx_t *ctx, const bsa_row_task_t *tasks, size_t ntasks, const bsa_sweep_prog_t *progs, size_t nprogs,
+                   const uint8_t *queries, const uint64_t *qoff, const uint32_t *qlen, size_t nqueries,
+                   const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *results);
+
 /* ---- synthetic read pairs (measurement inputs, SURVEY 8(d) / BASELINE.md 3) ---------------------
  * pair k: target = iid uniform ACGT of length L from splitmix64(seed ^ k*0x9E3779B97F4A7C15);
  * query = target with errors at rate err_q32 / 2^32 split sub:ins:del = 23:31:46.

@@ -902,3 +902,86 @@ double orc_edit_batch_time(const uint8_t *seqs, const uint64_t *qoff, const uint
 	if(checksum) *checksum = cs;
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- POA sweep programs (device counterpart: k_sweep in bsalign_amd/csrc/bsa_rows.hip) ----------------------
+ * Executes flattened align_rd_bspoacore programs (bspoa.h:2515-2618) with the row functions above.  Row blocks use
+ * the reference's layout: us[bw] | es[bw] if piecewise >= 1 | qs[bw] if piecewise == 2 | int32 ubegs[17], block
+ * size roundup(bw * (piecewise + 1) + 68, 16) (bspoa.h:1787-1793, 2217). */
+void orc_sweep_run(uint8_t *rows, const orc_row_task_t *tasks, const orc_sweep_prog_t *progs, size_t nprogs,
+		const uint8_t *queries, const uint64_t *qoff, const uint32_t *qlen,
+		int mode, uint32_t bandwidth, int M, int X, int refbonus, int gapo1, int gape1, int gapo2, int gape2, int T,
+		orc_sweep_result_t *results){
+	const uint32_t bw = (bandwidth + NL - 1) / NL * NL, W = bw / NL;
+	const int pw = orc_get_piecewise(gapo1, gape1, gapo2, gape2, (int)bw);
+	const size_t blk = ((size_t)bw * (pw + 1) + 17 * 4 + 15) & ~(size_t)15;
+	const int type = mode & 3;
+	const int nt_max = M + refbonus + 1, nt_min = X;       /* as the POA passes them, bspoa.h:2226, 2241 */
+	int8_t mtx0[16], mtx1[16];
+	int8_t *tmp = (int8_t*)calloc((size_t)bw * 6 + 16, 1);
+	int8_t *mu = tmp, *me = tmp + bw, *mq = tmp + 2 * bw, *dz0 = tmp + 3 * bw, *dz1 = tmp + 4 * bw, *dz2 = tmp + 5 * bw;
+	int32_t mb[NL + 1];
+	size_t p;
+	orc_set_score_matrix(mtx0, M, X);
+	orc_set_score_matrix(mtx1, M + refbonus, X);
+	for(p = 0; p < nprogs; p++){
+		uint8_t *base = rows + (size_t)progs[p].first_block * blk;
+		int maxscr = ORC_SCORE_MIN, maxidx = -1, maxoff = -1;
+		uint32_t t;
+#define BLK_US(i) ((int8_t*)(base + (size_t)(i) * blk))
+#define BLK_ES(i) ((pw >= 1) ? BLK_US(i) + bw : dz0)
+#define BLK_QS(i) ((pw == 2) ? BLK_US(i) + 2 * bw : dz1)
+#define BLK_UB(i) ((int32_t*)(BLK_US(i) + (size_t)bw * (pw + 1)))
+		for(t = 0; t < progs[p].ntasks; t++){
+			const orc_row_task_t *tk = tasks + progs[p].first_task + t;
+			if(tk->op == ORC_ROW_OP_INIT){
+				orc_row_init(BLK_US(tk->dst), (pw >= 1) ? BLK_ES(tk->dst) : dz0, (pw == 2) ? BLK_QS(tk->dst) : dz1, BLK_UB(tk->dst),
+					mode, bw, nt_max, nt_min, gapo1, gape1, gapo2, gape2);
+			} else if(tk->op == ORC_ROW_OP_MERGE){               /* dst = max(src, dst), dpalign_row_merge_bspoa bspoa.h:2263 */
+				orc_row_merge(BLK_US(tk->src), BLK_ES(tk->src), BLK_QS(tk->src), BLK_UB(tk->src),
+					BLK_US(tk->dst), BLK_ES(tk->dst), BLK_QS(tk->dst), BLK_UB(tk->dst),
+					BLK_US(tk->dst), (pw >= 1) ? BLK_ES(tk->dst) : dz2, (pw == 2) ? BLK_QS(tk->dst) : dz2, BLK_UB(tk->dst), W, pw);
+			} else if(tk->op == ORC_ROW_OP_UPDATE){              /* dpalign_row_update_bspoa bspoa.h:2232-2261 */
+				const uint32_t movx = tk->qoff_dst - tk->qoff_src;
+				orc_query_t qy;
+				int rh;
+				orc_row_movx(mu, me, mq, mb, BLK_US(tk->src), BLK_ES(tk->src), BLK_QS(tk->src), BLK_UB(tk->src),
+					W, movx, pw, nt_max, nt_min, gapo1, gape1, gapo2, gape2);
+				if(movx == 0){
+					if(tk->qoff_src) rh = ORC_SCORE_MIN;
+					else if(type == ORC_MODE_OVERLAP || tk->toff == 0) rh = 0;
+					else if(pw < 2) rh = gapo1 + gape1 * (int)tk->toff;
+					else { int a = gapo1 + gape1 * (int)tk->toff, b = gapo2 + gape2 * (int)tk->toff; rh = a > b ? a : b; }
+				} else if(movx <= bw) rh = mb[0];
+				else rh = ORC_SCORE_MIN;
+				qy.seq = queries + qoff[tk->query]; qy.len = qlen[tk->query];
+				qy.mtx = (tk->prof & 1) ? mtx1 : mtx0;
+				qy.hpc = (tk->prof & 2) ? 0 : 1; qy.bonus = 1;
+				orc_row_cal(tk->qoff_dst, tk->base, mu, me, mq, mb,
+					BLK_US(tk->dst), (pw >= 1) ? BLK_ES(tk->dst) : dz2, (pw == 2) ? BLK_QS(tk->dst) : dz2, BLK_UB(tk->dst),
+					&qy, gapo1, gape1, gapo2, gape2, W, rh, pw);
+			} else if(tk->op == ORC_ROW_OP_SCORE_END){           /* bspoa.h:2597-2606 */
+				const int slen = (int)qlen[tk->query], rpos = (int)tk->qoff_src;
+				const int smax = orc_getscore(BLK_US(tk->src), BLK_UB(tk->src), W, (uint64_t)(slen - 1 - rpos)) + T;
+				if(smax > maxscr){ maxscr = smax; maxidx = (int)tk->toff; maxoff = slen - 1; }
+			} else if(tk->op == ORC_ROW_OP_SCORE_TAIL){          /* bspoa.h:2547-2577 */
+				const int slen = (int)qlen[tk->query], rpos = (int)tk->qoff_src;
+				int mo = (slen < rpos + (int)bw ? slen : rpos + (int)bw) - 1;
+				int smax = orc_getscore(BLK_US(tk->src), BLK_UB(tk->src), W, (uint64_t)(mo - rpos));
+				if(slen > mo + 1){
+					const int n = slen - mo - 1;
+					if(pw < 2) smax += gapo1 + gape1 * n;
+					else { int a = gapo1 + gape1 * n, b = gapo2 + gape2 * n; smax += a > b ? a : b; }
+				}
+				smax += T;
+				if(smax > maxscr){ maxscr = smax; maxidx = (int)tk->toff; maxoff = mo; }
+				if(type == ORC_MODE_OVERLAP){
+					int32_t ms;
+					const uint32_t rmax = orc_row_max(BLK_US(tk->src), BLK_UB(tk->src), W, &ms);
+					if(ms > maxscr){ maxscr = ms; maxidx = (int)tk->toff; maxoff = (int)rmax + rpos; }
+				}
+			}
+		}
+		results[p].maxscr = maxscr; results[p].maxidx = maxidx; results[p].maxoff = maxoff; results[p].reserved = 0;
+	}
+	free(tmp);
+}

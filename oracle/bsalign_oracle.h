@@ -15,6 +15,7 @@
 #define BSALIGN_ORACLE_H
 
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -90,6 +91,21 @@ long     orc_align_pairwise_rows(const uint8_t *q, uint32_t qlen, const uint8_t 
                             int mode, uint32_t bandwidth, const int8_t mtx[16],
                             int gapo1, int gape1, int gapo2, int gape2,
                             orc_result_t *res, uint8_t *rows_out, uint32_t rowb);
+
+/* POA sweep programs: flattened align_rd_bspoacore (bspoa.h:2515-2618); structs are layout-identical to
+ * bsa_row_task_t / bsa_sweep_prog_t / bsa_sweep_result_t of include/bsalign_hip.h */
+#define ORC_ROW_OP_UPDATE     0u
+#define ORC_ROW_OP_MERGE      1u
+#define ORC_ROW_OP_INIT       2u
+#define ORC_ROW_OP_SCORE_TAIL 3u
+#define ORC_ROW_OP_SCORE_END  4u
+typedef struct { uint32_t op, src, dst, qoff_src, qoff_dst, toff, query; uint8_t base, prof; uint16_t reserved; } orc_row_task_t;
+typedef struct { uint32_t first_task, ntasks, first_block, reserved; } orc_sweep_prog_t;
+typedef struct { int32_t maxscr, maxidx, maxoff, reserved; } orc_sweep_result_t;
+void     orc_sweep_run(uint8_t *rows, const orc_row_task_t *tasks, const orc_sweep_prog_t *progs, size_t nprogs,
+                       const uint8_t *queries, const uint64_t *qoff, const uint32_t *qlen,
+                       int mode, uint32_t bandwidth, int M, int X, int refbonus, int gapo1, int gape1, int gapo2, int gape2, int T,
+                       orc_sweep_result_t *results);
 
 /* timing helper for bench.py's cpu_baseline (kind = "port") */
 double   orc_align_batch_time(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,

@@ -1,0 +1,291 @@
+/*
+ * ref_poa_harness.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Drives the REAL reference POA (ruanjue/bsalign bspoa.h, compiled from /root/reference via -I, nothing copied) in
+ * three ways so that the device sweep and its reference-side binding can be pinned:
+ *
+ *   mode 0  beg_bspoa / push_bspoa / end_bspoa untouched                                  bspoa.h:1775, 961, 4722
+ *   mode 1  the same steps driven from here (poa_finish / poa_align_read below restate only the ORCHESTRATION of
+ *           end_bspoa bspoa.h:4722-4776 and align_rd_bspoa bspoa.h:2620-2667 -- every step is a call into the
+ *           reference), with the reference's own align_rd_bspoacore: must reproduce mode 0 exactly
+ *   mode 2  as mode 1, but align_rd_bspoacore is replaced by bsa_poa_align_rd_core() from
+ *           include/bsalign_poa_adapter.h with a backend supplied by the test (the oracle's orc_sweep_run here; the
+ *           GPU's bsa_sweep_host in a deployment).  After every read the reference's core is re-run on the same graph
+ *           state and its row blocks / best end cell are compared with what the backend returned.
+ *
+ * Recorded per read: the seqalign_result_t of align_rd_bspoa, the program (tasks), the best end cell and a hash of
+ * the reference's row blocks -- tests/golden/make_golden_poa.py turns these into the committed fixtures.
+ */
+#include "bspoa.h"
+#include "../include/bsalign_poa_adapter.h"
+#include <stdint.h>
+
+/* the adapter's two link-time dependencies on libbsalign_hip.so, satisfied locally: this library must load without HIP */
+__attribute__((visibility("hidden"))) size_t bsa_rows_block_bytes(uint32_t bandwidth, int8_t gapo1, int8_t gape1, int8_t gapo2, int8_t gape2){
+	const uint32_t bw = (bandwidth + 15u) / 16u * 16u;
+	const int pw = banded_striped_epi8_seqalign_get_piecewise(gapo1, gape1, gapo2, gape2, (int)bw);
+	return ((size_t)bw * (pw + 1) + 17 * 4 + 15) & ~(size_t)15;
+}
+__attribute__((visibility("hidden"))) int bsa_sweep_host(bsa_ctx_t *ctx, const bsa_row_task_t *tasks, size_t ntasks, const bsa_sweep_prog_t *progs, size_t nprogs,
+		const uint8_t *queries, const uint64_t *qoff, const uint32_t *qlen, size_t nqueries,
+		const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *results){
+	(void)ctx; (void)tasks; (void)ntasks; (void)progs; (void)nprogs; (void)queries; (void)qoff; (void)qlen; (void)nqueries;
+	(void)par; (void)rows_out; (void)nblocks; (void)results;
+	return BSA_E_UNSUPPORTED;       /* no device in the checker */
+}
+
+typedef void (*orc_sweep_fn)(uint8_t *rows, const void *tasks, const void *progs, size_t nprogs,
+		const uint8_t *queries, const uint64_t *qoff, const uint32_t *qlen,
+		int mode, uint32_t bandwidth, int M, int X, int refbonus, int gapo1, int gape1, int gapo2, int gape2, int T, void *results);
+
+typedef struct {
+	seqalign_result_t rs;
+	int maxscr, maxidx, maxoff;
+	uint32_t bandwidth, slen, qb, nblocks, ntasks, piecewise;
+	uint64_t task_off;          /* into poa->tasks */
+	uint64_t query_off;         /* into poa->queries */
+	uint64_t rows_hash;         /* FNV-1a over the used bytes of every written node block of the reference's memp */
+	int mismatch;               /* mode 2: bit 0 best end cell differs, bit 1 some row block differs */
+} poa_read_rec_t;
+
+typedef struct {
+	BSPOA *g;
+	bsa_poa_adapter_t ad;
+	orc_sweep_fn sweep;
+	poa_read_rec_t *recs; size_t nrec, caprec;
+	bsa_row_task_t *tasks; size_t ntasks, captasks;
+	uint8_t *queries; size_t nq, capq;
+	int mode, record_programs;
+} ref_poa_t;
+
+static uint64_t fnv1a(uint64_t h, const void *p, size_t n){
+	const uint8_t *b = (const uint8_t*)p; size_t i;
+	for(i = 0; i < n; i++){ h ^= b[i]; h *= 0x100000001B3ULL; }
+	return h;
+}
+
+/* the tail node's block is never written by the sweep (uninitialised arena bytes): skipped */
+static uint64_t hash_node_blocks(BSPOA *g, u4i tail){
+	const size_t used = (size_t)g->bandwidth * (g->piecewise + 1) + (WORDSIZE + 1) * sizeof(int);
+	const u8i skip = ref_bspoanodev(g->nodes, tail)->mmidx;
+	uint64_t h = 0xCBF29CE484222325ULL; u8i i;
+	for(i = 2; i < g->mmcnt; i++) if(i != skip) h = fnv1a(h, g->memp->buffer + i * g->mmblk, used);
+	return h;
+}
+
+/* adapter backend -> the oracle's sweep */
+static int backend_oracle(void *user, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
+		const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *res){
+	ref_poa_t *p = (ref_poa_t*)user;
+	bsa_sweep_prog_t pg; uint64_t qoff = 0;
+	(void)nblocks;
+	pg.first_task = 0; pg.ntasks = (uint32_t)ntasks; pg.first_block = 0; pg.reserved = 0;
+	p->sweep(rows_out, tasks, &pg, 1, query, &qoff, &slen, par->rows.mode, par->rows.bandwidth, par->rows.M, par->rows.X,
+		par->rows.refbonus, par->rows.gapo1, par->rows.gape1, par->rows.gapo2, par->rows.gape2, par->T, res);
+	return 0;
+}
+
+void *ref_poa_create(int bandwidth, int bwtrigger, int alnmode, int nrec, int realn, int seqcore, int shuffle,
+		int M, int X, int O, int E, int Q, int P, int T, int refbonus, int ksz){
+	BSPOAPar par = DEFAULT_BSPOA_PAR;
+	ref_poa_t *p = (ref_poa_t*)calloc(1, sizeof(ref_poa_t));
+	par.bandwidth = bandwidth; par.bwtrigger = bwtrigger; par.alnmode = alnmode; par.nrec = nrec; par.realn = realn;
+	par.seqcore = seqcore; par.shuffle = shuffle;
+	par.M = M; par.X = X; par.O = O; par.E = E; par.Q = Q; par.P = P; par.T = T; par.refbonus = refbonus; par.ksz = ksz;
+	p->g = init_bspoa(par);
+	return p;
+}
+
+void ref_poa_destroy(void *vp){
+	ref_poa_t *p = (ref_poa_t*)vp;
+	free_bspoa(p->g);
+	bsa_poa_adapter_free(&p->ad);
+	free(p->recs); free(p->tasks); free(p->queries);
+	free(p);
+}
+
+static void record_read(ref_poa_t *p, seqalign_result_t rs, int mismatch, uint64_t rows_hash){
+	BSPOA *g = p->g;
+	poa_read_rec_t *r;
+	if(p->nrec == p->caprec){ p->caprec = p->caprec ? p->caprec * 2 : 64; p->recs = (poa_read_rec_t*)realloc(p->recs, p->caprec * sizeof(poa_read_rec_t)); }
+	r = p->recs + p->nrec ++;
+	memset(r, 0, sizeof(*r));
+	r->rs = rs; r->maxscr = g->maxscr; r->maxidx = g->maxidx; r->maxoff = g->maxoff;
+	r->bandwidth = g->bandwidth; r->slen = g->slen; r->qb = g->qb; r->nblocks = (uint32_t)g->mmcnt; r->piecewise = (uint32_t)g->piecewise;
+	r->rows_hash = rows_hash; r->mismatch = mismatch;
+	r->task_off = p->ntasks; r->query_off = p->nq;
+	if(p->mode == 2 && p->record_programs){
+		r->ntasks = (uint32_t)p->ad.ntasks;
+		if(p->ntasks + p->ad.ntasks > p->captasks){
+			p->captasks = (p->ntasks + p->ad.ntasks) * 2;
+			p->tasks = (bsa_row_task_t*)realloc(p->tasks, p->captasks * sizeof(bsa_row_task_t));
+		}
+		memcpy(p->tasks + p->ntasks, p->ad.tasks, p->ad.ntasks * sizeof(bsa_row_task_t));
+		p->ntasks += p->ad.ntasks;
+		if(p->nq + g->slen > p->capq){ p->capq = (p->nq + g->slen) * 2; p->queries = (uint8_t*)realloc(p->queries, p->capq); }
+		memcpy(p->queries + p->nq, g->qseq->buffer + g->qb, g->slen);
+		p->nq += g->slen;
+	}
+}
+
+/* orchestration of align_rd_bspoa (bspoa.h:2620-2667), realn == 0 entry only (the one end_bspoa uses) */
+static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
+	BSPOA *g = p->g;
+	BSPOAPar *par = g->par;
+	seqalign_result_t rs;
+	const int rlen = g->seqs->rdlens->buffer[rid];
+	u4i head, tail, k;
+	u2i rfirst;
+	int score, mismatch = 0;
+	uint64_t rows_hash = 0;
+	clear_u8v(g->todels);
+	ZEROS(&rs);
+	if(rlen == 0) return rs;
+	head = get_rdnode_bspoa(g, rid, -1)->header;
+	tail = get_rdnode_bspoa(g, rid, rlen)->header;
+	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
+	sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
+	prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
+	if(p->mode == 2){
+		int a_scr, a_idx, a_off;
+		const size_t used = (size_t)g->bandwidth * (g->piecewise + 1) + (WORDSIZE + 1) * sizeof(int);
+		b1i *mine;
+		u8i b;
+		score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
+		a_scr = g->maxscr; a_idx = g->maxidx; a_off = g->maxoff;
+		/* run the reference's own sweep on the same graph state and compare */
+		mine = (b1i*)malloc(g->mmcnt * g->mmblk);
+		memcpy(mine, g->memp->buffer, g->mmcnt * g->mmblk);
+		for(k=0;k<g->sels->size;k++) ref_bspoanodev(g->nodes, g->sels->buffer[k])->vst = 0;
+		g->maxscr = SEQALIGN_SCORE_MIN; g->maxidx = -1; g->maxoff = -1;
+		score = align_rd_bspoacore(g, par, rid, head, tail);
+		if(a_scr != g->maxscr || a_idx != g->maxidx || a_off != g->maxoff) mismatch |= 1;
+		for(b=2;b<g->mmcnt;b++){
+			if(b == ref_bspoanodev(g->nodes, tail)->mmidx) continue;
+			if(memcmp(mine + b * g->mmblk, g->memp->buffer + b * g->mmblk, used)){ mismatch |= 2; break; }
+		}
+		rows_hash = hash_node_blocks(g, tail);
+		/* continue with the backend's rows: the traceback must work from them */
+		memcpy(g->memp->buffer, mine, g->mmcnt * g->mmblk);
+		g->maxscr = a_scr; g->maxidx = a_idx; g->maxoff = a_off;
+		score = a_scr;
+		free(mine);
+	} else {
+		score = align_rd_bspoacore(g, par, rid, head, tail);
+		rows_hash = hash_node_blocks(g, tail);
+	}
+	rs = alignment2graph_bspoa(g, par, rid, 0, head, tail, g->maxidx, g->maxoff, NULL);
+	rs.qb += g->qb;
+	rs.qe += g->qb;
+	rs.score = score;
+	for(k=0;k<g->todels->size;k++){
+		chg_edge_bspoa(g, ref_bspoanodev(g->nodes, g->todels->buffer[k] >> 32), ref_bspoanodev(g->nodes, g->todels->buffer[k] & MAX_U4), -1, NULL);
+	}
+	clear_u8v(g->todels);
+	record_read(p, rs, mismatch, rows_hash);
+	return rs;
+}
+
+/* orchestration of end_bspoa (bspoa.h:4722-4776) */
+static void poa_finish(ref_poa_t *p){
+	BSPOA *g = p->g;
+	u4i n0;
+	u2i rid;
+	int round;
+	clear_u1v(g->cns); clear_u1v(g->qlt); clear_u1v(g->alt);
+	if(g->par->refmode){
+		n0 = g->seqs->rdlens->buffer[0];
+		resize_u1v(g->cns, n0); resize_u1v(g->qlt, n0); resize_u1v(g->alt, n0);
+		bitseq_basebank(g->seqs->rdseqs, g->seqs->rdoffs->buffer[0], n0, g->cns->buffer);
+		memset(g->qlt->buffer, 0, n0);
+		memset(g->alt->buffer, 0, n0);
+	}
+	if(g->seqs->nseq <= 1) return;
+	if(g->par->shuffle) shuffle_reads_by_kmers_bspoa(g);
+	g->nmsa = g->par->seqcore ? num_min(g->seqs->nseq, g->par->seqcore) : g->seqs->nseq;
+	for(rid=0;rid<g->seqs->nseq;rid++) _add_read_bspoa_core(g, rid);
+	g->nrds = 1;
+	for(rid=1;rid<g->nmsa;rid++){
+		if(!g->par->refmode && g->par->bwtrigger){
+			msa_bspoa(g);
+			simple_cns_bspoa(g);
+		}
+		poa_align_read(p, rid);
+		g->nrds ++;
+	}
+	for(round=0;round<g->par->realn;round++){
+		msa_bspoa(g);
+		cns_bspoa(g);
+		if(g->par->editbw < 0) remsa_edits_bspoa(g, - g->par->editbw);
+		else remsa_pedits_bspoa(g, g->par->editbw / 2, 1, (round + 1 == g->par->realn));
+	}
+	if(g->par->shuffle) restore_rd_orders_bspoa(g);
+	msa_bspoa(g);
+	cns_bspoa(g);
+}
+
+/* reads: one base per byte (0..3), read k at reads[offs[k] .. +lens[k]).  mode as described in the file header.
+ * sweep_fn = address of orc_sweep_run (mode 2).  Returns the number of reads whose backend results differed from the
+ * reference's core (mode 2), else 0. */
+int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint32_t *lens, int nreads, int mode,
+		void *sweep_fn, int record_programs){
+	ref_poa_t *p = (ref_poa_t*)vp;
+	BSPOA *g = p->g;
+	char *buf;
+	uint32_t maxlen = 0;
+	int k, bad = 0;
+	size_t i;
+	p->mode = mode; p->record_programs = record_programs;
+	p->nrec = 0; p->ntasks = 0; p->nq = 0;
+	p->sweep = (orc_sweep_fn)sweep_fn;
+	bsa_poa_adapter_free(&p->ad);
+	bsa_poa_adapter_init(&p->ad, backend_oracle, p);
+	for(k = 0; k < nreads; k++) if(lens[k] > maxlen) maxlen = lens[k];
+	buf = (char*)malloc(maxlen + 1);
+	beg_bspoa(g);
+	for(k = 0; k < nreads; k++){
+		for(i = 0; i < lens[k]; i++) buf[i] = "ACGT"[reads[offs[k] + i] & 3];
+		buf[lens[k]] = 0;
+		push_bspoa(g, buf, lens[k]);
+	}
+	free(buf);
+	if(mode == 0) end_bspoa(g);
+	else poa_finish(p);
+	for(i = 0; i < p->nrec; i++) if(p->recs[i].mismatch) bad ++;
+	return bad;
+}
+
+/* ---- result access ---- */
+uint32_t ref_poa_cns_len(void *vp){ return (uint32_t)((ref_poa_t*)vp)->g->cns->size; }
+void ref_poa_cns(void *vp, uint8_t *cns, uint8_t *qlt, uint8_t *alt){
+	BSPOA *g = ((ref_poa_t*)vp)->g;
+	if(cns) memcpy(cns, g->cns->buffer, g->cns->size);
+	if(qlt) memcpy(qlt, g->qlt->buffer, g->qlt->size);
+	if(alt) memcpy(alt, g->alt->buffer, g->alt->size);
+}
+uint64_t ref_poa_msa_hash(void *vp, uint32_t *ncols, uint32_t *nrows){
+	BSPOA *g = ((ref_poa_t*)vp)->g;
+	const u4i mrow = g->seqs->nseq + 3;
+	uint64_t h = 0xCBF29CE484222325ULL; u4i c;
+	if(ncols) *ncols = (uint32_t)g->msaidxs->size;
+	if(nrows) *nrows = mrow;
+	for(c = 0; c < g->msaidxs->size; c++) h = fnv1a(h, g->msacols->buffer + (size_t)g->msaidxs->buffer[c] * mrow, g->seqs->nseq);
+	return h;
+}
+uint32_t ref_poa_nrec(void *vp){ return (uint32_t)((ref_poa_t*)vp)->nrec; }
+/* out: 10 ints of rs, maxscr, maxidx, maxoff, bandwidth, slen, qb, nblocks, ntasks, piecewise, mismatch = 20 int32; hash separately */
+void ref_poa_rec(void *vp, uint32_t k, int32_t *out, uint64_t *rows_hash, uint64_t *task_off, uint64_t *query_off){
+	const poa_read_rec_t *r = ((ref_poa_t*)vp)->recs + k;
+	memcpy(out, &r->rs, 10 * sizeof(int32_t));
+	out[10] = r->maxscr; out[11] = r->maxidx; out[12] = r->maxoff; out[13] = (int32_t)r->bandwidth; out[14] = (int32_t)r->slen;
+	out[15] = (int32_t)r->qb; out[16] = (int32_t)r->nblocks; out[17] = (int32_t)r->ntasks; out[18] = (int32_t)r->piecewise; out[19] = r->mismatch;
+	*rows_hash = r->rows_hash; *task_off = r->task_off; *query_off = r->query_off;
+}
+uint64_t ref_poa_ntasks(void *vp){ return ((ref_poa_t*)vp)->ntasks; }
+uint64_t ref_poa_nquery_bytes(void *vp){ return ((ref_poa_t*)vp)->nq; }
+void ref_poa_programs(void *vp, void *tasks, uint8_t *queries){
+	ref_poa_t *p = (ref_poa_t*)vp;
+	memcpy(tasks, p->tasks, p->ntasks * sizeof(bsa_row_task_t));
+	memcpy(queries, p->queries, p->nq);
+}
+uint64_t ref_poa_block_bytes(void *vp){ return ((ref_poa_t*)vp)->g->mmblk; }

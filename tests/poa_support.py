@@ -1,0 +1,150 @@
+"""Helpers for the POA sweep tests: ctypes access to the reference POA harness (oracle/_ref, only in the build
+container) and to the oracle's orc_sweep_run, plus the fixture format of tests/golden/poa_sweep.npz."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import support as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden", "poa_sweep.npz")
+
+TASK_DTYPE = np.dtype([("op", np.uint32), ("src", np.uint32), ("dst", np.uint32), ("qoff_src", np.uint32), ("qoff_dst", np.uint32),
+                       ("toff", np.uint32), ("query", np.uint32), ("base", np.uint8), ("prof", np.uint8), ("reserved", np.uint16)])
+PROG_DTYPE = np.dtype([("first_task", np.uint32), ("ntasks", np.uint32), ("first_block", np.uint32), ("reserved", np.uint32)])
+RESULT_DTYPE = np.dtype([("maxscr", np.int32), ("maxidx", np.int32), ("maxoff", np.int32), ("reserved", np.int32)])
+FNV0, FNVP = 0xCBF29CE484222325, 0x100000001B3
+
+# POA parameter sets: (bandwidth, bwtrigger, alnmode, nrec, realn, seqcore, shuffle, M, X, O, E, Q, P, T, refbonus, ksz)
+DEFAULT = dict(bandwidth=128, bwtrigger=1, alnmode=1, nrec=20, realn=3, seqcore=40, shuffle=1,
+               M=2, X=-6, O=-3, E=-2, Q=-8, P=-1, T=20, refbonus=1, ksz=15)
+PAR_ORDER = ("bandwidth", "bwtrigger", "alnmode", "nrec", "realn", "seqcore", "shuffle", "M", "X", "O", "E", "Q", "P", "T", "refbonus", "ksz")
+
+
+def par(**kw):
+    d = dict(DEFAULT)
+    d.update(kw)
+    return d
+
+
+def ref_poa():
+    r = S.ref()
+    if getattr(r, "_poa_ready", False):
+        return r
+    r.ref_poa_create.restype = C.c_void_p
+    r.ref_poa_create.argtypes = [C.c_int] * 16
+    r.ref_poa_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    r.ref_poa_destroy.argtypes = [C.c_void_p]
+    r.ref_poa_destroy.restype = None
+    r.ref_poa_cns_len.argtypes = [C.c_void_p]
+    r.ref_poa_cns_len.restype = C.c_uint32
+    r.ref_poa_cns.argtypes = [C.c_void_p] * 4
+    r.ref_poa_cns.restype = None
+    r.ref_poa_msa_hash.argtypes = [C.c_void_p] * 3
+    r.ref_poa_msa_hash.restype = C.c_uint64
+    r.ref_poa_nrec.argtypes = [C.c_void_p]
+    r.ref_poa_nrec.restype = C.c_uint32
+    r.ref_poa_rec.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    r.ref_poa_rec.restype = None
+    r.ref_poa_ntasks.argtypes = [C.c_void_p]
+    r.ref_poa_ntasks.restype = C.c_uint64
+    r.ref_poa_nquery_bytes.argtypes = [C.c_void_p]
+    r.ref_poa_nquery_bytes.restype = C.c_uint64
+    r.ref_poa_programs.argtypes = [C.c_void_p] * 3
+    r.ref_poa_programs.restype = None
+    r._poa_ready = True
+    return r
+
+
+def run_ref_poa(reads, mode, p, record=True):
+    """mode 0: end_bspoa untouched; 1: orchestrated from the harness with the reference's own sweep; 2: sweep replaced by
+    include/bsalign_poa_adapter.h + the oracle's orc_sweep_run (every read re-checked against the reference's sweep)"""
+    r, o = ref_poa(), S.oracle()
+    h = r.ref_poa_create(*[int(p[k]) for k in PAR_ORDER])
+    lens = np.array([len(x) for x in reads], dtype=np.uint32)
+    offs = np.zeros(len(reads), dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)[:-1]
+    blob = np.concatenate(reads).astype(np.uint8)
+    bad = r.ref_poa_run(h, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads), mode, C.cast(o.orc_sweep_run, C.c_void_p), int(record))
+    n = r.ref_poa_cns_len(h)
+    cns, qlt, alt = (np.zeros(n, np.uint8) for _ in range(3))
+    r.ref_poa_cns(h, cns.ctypes.data, qlt.ctypes.data, alt.ctypes.data)
+    nc, nr = C.c_uint32(), C.c_uint32()
+    mh = r.ref_poa_msa_hash(h, C.byref(nc), C.byref(nr))
+    recs = []
+    for k in range(r.ref_poa_nrec(h)):
+        out = np.zeros(20, np.int32)
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        r.ref_poa_rec(h, k, out.ctypes.data, C.byref(a), C.byref(b), C.byref(c))
+        recs.append(dict(rs=out[:10].copy(), maxscr=int(out[10]), maxidx=int(out[11]), maxoff=int(out[12]), bandwidth=int(out[13]),
+                         slen=int(out[14]), qb=int(out[15]), nblocks=int(out[16]), ntasks=int(out[17]), piecewise=int(out[18]),
+                         mismatch=int(out[19]), rows_hash=a.value, task_off=b.value, query_off=c.value))
+    tasks = np.zeros(int(r.ref_poa_ntasks(h)), dtype=TASK_DTYPE)
+    queries = np.zeros(int(r.ref_poa_nquery_bytes(h)), dtype=np.uint8)
+    if len(tasks):
+        r.ref_poa_programs(h, tasks.ctypes.data, queries.ctypes.data)
+    r.ref_poa_destroy(h)
+    return dict(bad=bad, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, tasks=tasks, queries=queries)
+
+
+def block_bytes(bw, pw):
+    return (bw * (pw + 1) + 68 + 15) & ~15
+
+
+def hash_node_blocks(rows, nblocks, bw, pw, tasks):
+    """FNV-1a over the used bytes of the node blocks (2..) the program writes -- all but the tail node's, which the
+    reference never touches (oracle/ref_poa_harness.c hash_node_blocks)"""
+    blk, used = block_bytes(bw, pw), bw * (pw + 1) + 68
+    h = FNV0
+    written = np.zeros(nblocks, dtype=bool)
+    written[tasks["dst"][tasks["op"] <= 2]] = True
+    written[:2] = False
+    body = rows[: nblocks * blk].reshape(nblocks, blk)[written, :used].reshape(-1)
+    # vectorised FNV is not possible (sequential); blocks are small enough for a plain loop in C-speed chunks
+    for b in body.tobytes():
+        h = ((h ^ b) * FNVP) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def oracle_sweep(tasks, progs, queries, qoff, qlen, p, bandwidth, nblocks, pw):
+    o = S.oracle()
+    o.orc_sweep_run.restype = None
+    o.orc_sweep_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int, C.c_uint32] + [C.c_int] * 8 + [C.c_void_p]
+    tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)
+    progs = np.ascontiguousarray(progs, dtype=PROG_DTYPE)
+    queries = np.ascontiguousarray(queries, dtype=np.uint8)
+    qoff = np.ascontiguousarray(qoff, dtype=np.uint64)
+    qlen = np.ascontiguousarray(qlen, dtype=np.uint32)
+    rows = np.zeros(nblocks * block_bytes(bandwidth, pw), dtype=np.uint8)
+    res = np.zeros(len(progs), dtype=RESULT_DTYPE)
+    o.orc_sweep_run(rows.ctypes.data, tasks.ctypes.data, progs.ctypes.data, len(progs), queries.ctypes.data, qoff.ctypes.data, qlen.ctypes.data,
+                    int(p["alnmode"]), int(bandwidth), int(p["M"]), int(p["X"]), int(p["refbonus"]), int(p["O"]), int(p["E"]), int(p["Q"]), int(p["P"]),
+                    int(p["T"]), res.ctypes.data)
+    return rows, res
+
+
+def synth_reads(seed, L, n, eps=(0.05, 0.1, 0.15)):
+    rng = np.random.default_rng(seed)
+    T = rng.integers(0, 4, size=L).astype(np.uint8)
+    return [S.mutate(rng, T, float(rng.choice(eps))) for _ in range(n)]
+
+
+def load_golden():
+    """-> list of cases: dict(par, programs=[dict(tasks, query, bandwidth, nblocks, piecewise, maxscr, maxidx, maxoff, rows_hash, rs)])"""
+    g = np.load(GOLDEN)
+    cases = []
+    for c in range(int(g["ncases"][0])):
+        pv = g["par_%d" % c]
+        p = {k: int(v) for k, v in zip(PAR_ORDER, pv)}
+        meta = g["meta_%d" % c]
+        tasks, queries = g["tasks_%d" % c].view(TASK_DTYPE), g["queries_%d" % c]
+        hashes = g["hash_%d" % c]
+        progs = []
+        for k in range(meta.shape[0]):
+            m = meta[k]
+            progs.append(dict(rs=m[:10].copy(), maxscr=int(m[10]), maxidx=int(m[11]), maxoff=int(m[12]), bandwidth=int(m[13]), slen=int(m[14]),
+                              nblocks=int(m[16]), ntasks=int(m[17]), piecewise=int(m[18]), rows_hash=int(hashes[k]),
+                              tasks=tasks[int(m[20]):int(m[20]) + int(m[17])], query=queries[int(m[21]):int(m[21]) + int(m[14])]))
+        cases.append(dict(par=p, programs=progs, cns=g["cns_%d" % c]))
+    return cases
