@@ -32,10 +32,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="align8", choices=["align8", "edit"])
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: 100000 for align8, 16384 for edit)")
-    ap.add_argument("--length", type=int, default=0, help="target length (default 10000 / 100000)")
-    ap.add_argument("--bw", type=int, default=0, help="bandwidth (default 128 / 256)")
+    ap.add_argument("--workload", default="align8", choices=["align8", "edit", "poa"])
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: 100000 for align8, 16384 for edit; poa: POA windows, 8192)")
+    ap.add_argument("--length", type=int, default=0, help="target length (default 10000 / 100000; poa: graph positions per window, 10000)")
+    ap.add_argument("--bw", type=int, default=0, help="bandwidth (default 128 / 256 / 128)")
     ap.add_argument("--eps", type=float, default=0.10)
     ap.add_argument("--scoring", default="2,-6,-3,-2,0,0", help="M,X,O,E,Q,P (reference CLI defaults, main.c:264)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs of the CPU baseline sample (0 = auto, -1 = skip)")
@@ -85,8 +85,171 @@ def cpu_baseline(args, L, bw, sc, mode):
             "sample": "%d of the same synthetic pairs (L=%d, bw=%d), single thread, %s, %.1f s" % (npairs, L, bw, what, secs)}
 
 
+def poa_cpu_baseline(args, bw):
+    """the reference's own align_rd_bspoacore (oracle/_ref) timed inside a real end_bspoa on synthetic reads, one core"""
+    import support as S
+    if not S.have_ref():
+        return {"value": None, "unit": "GCUPS", "cores": 1, "kind": "reference", "sample": "oracle/_ref/libbsref.so absent: not measured"}
+    import poa_support as P
+    nreads, L = (args.cpu_pairs if args.cpu_pairs > 0 else 48), 6000
+    reads = P.synth_reads(SEED & 0xFFFF, L, nreads, eps=(args.eps,))
+    r = P.run_ref_poa(reads, 1, P.par(bandwidth=bw), record=False)
+    return {"value": round(r["core_updates"] * bw / r["core_seconds"] / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "reference",
+            "sample": "reference end_bspoa on %d synthetic reads x %d bp (eps %.2f, default POA parameters, bandwidth %d): %d row updates + %d merges in "
+                      "align_rd_bspoacore, %.2f s inside it, single thread (oracle/_ref)" % (nreads, L, args.eps, bw, r["core_updates"], r["core_merges"], r["core_seconds"])}
+
+
+def main_poa(args):
+    """C4-shaped workload: the per-read sweep (align_rd_bspoacore) of many POA windows side by side, one program per window"""
+    import torch
+    import bsalign_amd as B
+    from bsalign_amd import poa_synth as PS
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    nwin = args.pairs or 8192
+    npos = args.length or 10000
+    bw = args.bw or 128
+    K = 8                                                    # distinct programs, windows cycle through them
+    pp = dict(alnmode=1, M=2, X=-6, O=-3, E=-2, Q=-8, P=-1, T=20, refbonus=1)     # DEFAULT_BSPOA_PAR, bspoa.h:79-81
+    lib = B.lib()
+    sp = B.SweepParams()
+    sp.rows = B.RowsParams(pp["alnmode"], bw, pp["M"], pp["X"], pp["refbonus"], pp["O"], pp["E"], pp["Q"], pp["P"])
+    sp.T = pp["T"]
+    blk = lib.bsa_rows_block_bytes(bw, pp["O"], pp["E"], pp["Q"], pp["P"])
+    rng = np.random.default_rng(SEED + rank)
+    tasks, first, ntask, nblk, nupd, nmrg, queries, qoff, qlen = [], [], [], [], [], [], [], [], []
+    tacc = qacc = 0
+    for k in range(K):
+        t, nb, nu, nm, slen = PS.make_program(SEED + 1000 * rank + k, npos, bw)
+        t["query"] = k
+        tasks.append(t)
+        first.append(tacc)
+        ntask.append(len(t))
+        tacc += len(t)
+        nblk.append(nb)
+        nupd.append(nu)
+        nmrg.append(nm)
+        queries.append(rng.integers(0, 4, size=slen).astype(np.uint8))
+        qoff.append(qacc)
+        qlen.append(slen)
+        qacc += (slen + 63) & ~63
+    qblob = np.zeros(qacc + 64, dtype=np.uint8)
+    for k in range(K):
+        qblob[qoff[k]:qoff[k] + qlen[k]] = queries[k]
+    tasks = np.concatenate(tasks)
+    progs = np.zeros(nwin, dtype=B.SWEEP_PROG_DTYPE)
+    kk = np.arange(nwin) % K
+    progs["first_task"] = np.array(first, dtype=np.uint32)[kk]
+    progs["ntasks"] = np.array(ntask, dtype=np.uint32)[kk]
+    blocks = np.array(nblk, dtype=np.int64)[kk]
+    progs["first_block"] = np.concatenate([[0], np.cumsum(blocks)[:-1]]).astype(np.uint32)
+    total_blocks = int(blocks.sum())
+    updates = float(np.array(nupd, dtype=np.int64)[kk].sum())
+    merges = float(np.array(nmrg, dtype=np.int64)[kk].sum())
+    cells = updates * bw
+    ctx = B.Context(local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_rows = torch.empty(total_blocks * blk, dtype=torch.uint8, device=dev)
+    d_tasks = torch.from_numpy(tasks.view(np.uint8)).to(dev)
+    d_progs = torch.from_numpy(progs.view(np.uint8)).to(dev)
+    d_q = torch.from_numpy(qblob).to(dev)
+    d_qoff = torch.from_numpy(np.array(qoff, dtype=np.int64)).to(dev)
+    d_qlen = torch.from_numpy(np.array(qlen, dtype=np.int32)).to(dev)
+    d_res = torch.zeros(nwin * 4, dtype=torch.int32, device=dev)
+
+    def step():
+        rc = lib.bsa_sweep_run(ctx.h, d_rows.data_ptr(), d_tasks.data_ptr(), d_progs.data_ptr(), nwin, d_q.data_ptr(), d_qoff.data_ptr(),
+                               d_qlen.data_ptr(), C.byref(sp), d_res.data_ptr())
+        assert rc == 0, "bsa_sweep_run failed: %d" % rc
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        barrier()
+    kms, klaunch, _ = ctx.last_kernel_ms()
+    res = d_res.cpu().numpy().view(B.SWEEP_RESULT_DTYPE)
+    if rank == 0:
+        import poa_support as P
+        # parity spot check (outside the timed region): the K distinct programs vs the oracle, rows and results
+        ident = True
+        rows_host = d_rows[: int(blocks[:K].sum()) * blk].cpu().numpy()
+        pw = S_oracle_piecewise(pp, bw)
+        used = bw * (pw + 1) + 68
+        for k in range(K):
+            t = tasks[first[k]:first[k] + ntask[k]].copy()
+            t["query"] = 0
+            orows, ores = P.oracle_sweep(t, np.array([(0, ntask[k], 0, 0)], dtype=P.PROG_DTYPE), queries[k], np.zeros(1, np.uint64),
+                                         np.array([qlen[k]], np.uint32), dict(pp), bw, nblk[k], pw)
+            b0 = int(progs[k]["first_block"])
+            mine = rows_host[b0 * blk:(b0 + nblk[k]) * blk].reshape(nblk[k], blk)[1:, :used]
+            ident &= bool(np.array_equal(mine, orows.reshape(nblk[k], blk)[1:, :used]))
+            ident &= (int(res[k]["maxscr"]), int(res[k]["maxidx"]), int(res[k]["maxoff"])) == (int(ores[0]["maxscr"]), int(ores[0]["maxidx"]), int(ores[0]["maxoff"]))
+        # algorithmic bytes (SURVEY.md 8(d)): one row block read + one written per row update; a merge reads two and writes one
+        balg = (2.0 * updates + 3.0 * merges) * blk
+        achieved = balg / (kms / 1e3) / 1e9 if kms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("poa_n%d_L%d_bw%d" % (nwin, npos, bw), {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP sweep (align_rd_bspoacore)",
+            "value": round(cells * args.steps * world / elapsed / 1e9, 3), "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8",
+            "data": "synthetic sweep programs (bsalign_amd/poa_synth.py: op mix of the reference's real programs), seed %d" % SEED,
+            "config": {"workload": "poa: %d POA windows/GPU, one read-vs-graph sweep each over %d graph positions (%.0f row updates + %.0f merges per window), "
+                                   "overlap mode, bandwidth %d, DEFAULT_BSPOA_PAR scoring (2-piece gaps)" % (nwin, npos, updates / nwin, merges / nwin, bw),
+                       "windows_per_gpu": nwin, "positions": npos, "bandwidth": bw,
+                       "parallelism": "windows sharded across %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic, "kernel": "k_sweep", "kernel_ms_avg": round(kms, 3), "launches_per_step": klaunch,
+                         "algorithmic_bytes_per_launch": round(balg, 1)},
+            "checks": {"oracle_identical_first8_programs": ident},
+        }
+        if world == 1 and args.cpu_pairs >= 0:
+            line["cpu_baseline"] = poa_cpu_baseline(args, bw)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def S_oracle_piecewise(pp, bw):
+    import support as S
+    return int(S.oracle().orc_get_piecewise(pp["O"], pp["E"], pp["Q"], pp["P"], bw))
+
+
 def main():
     args = parse()
+    if args.workload == "poa":
+        return main_poa(args)
     import torch
     import bsalign_amd as B
     rank = int(os.environ.get("RANK", "0"))

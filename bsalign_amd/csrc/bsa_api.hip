@@ -574,6 +574,23 @@ extern "C" int bsa_align_debug_rows(bsa_align_plan_t *p, uint32_t pair, uint8_t 
 	return BSA_E_ARG;
 }
 
+// kernel timing for launches made outside this file (bsa_rows.hip): one (start, stop) event pair around the launch
+extern "C" int bsa_ctx_time_begin_internal(bsa_ctx_t *c, double cells, void **stop_event){
+	if(!c || !stop_event) return BSA_E_ARG;
+	c->ev_used = 0; c->last_cells = cells;
+	hipEvent_t e0, e1;
+	int rc = ctx_event_pair(c, &e0, &e1);
+	if(rc != BSA_OK) return rc;
+	HIPCHK(c, hipEventRecord(e0, c->stream));
+	*stop_event = (void*)e1;
+	return BSA_OK;
+}
+extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *c, void *stop_event){
+	if(!c || !stop_event) return BSA_E_ARG;
+	HIPCHK(c, hipEventRecord((hipEvent_t)stop_event, c->stream));
+	return BSA_OK;
+}
+
 extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *c, hipStream_t *st){
 	if(!c || !st) return BSA_E_ARG;
 	(void)hipSetDevice(c->device);

@@ -28,9 +28,113 @@ struct RowsArgs {
 	int32_t gapo1, gape1, gapo2, gape2;
 };
 
-// one row task on the 16-lane DPP row that calls it; rows = base of the row blocks the task's indices refer to
+// a DP row in registers: lane j holds the W cells of running block j and the absolute scores around it
+template<int W>
+struct RowRegs { int u[W], e[W], q2[W], ubA, ubB; };
+
 template<int W, int PW>
-static __device__ __forceinline__ void rows_task(const RowsArgs &a, uint8_t *rows, const bsa_row_task_t &tk, int8_t *gl, const int j){
+static __device__ __forceinline__ void rows_load(RowRegs<W> &R, const int8_t *bp, const int j){
+	constexpr int BW = W * 16;
+	const int *ub = (const int*)(bp + (PW + 1) * BW);
+#pragma unroll
+	for(int k = 0; k < W; k++){
+		R.u[k] = bp[k * 16 + j];
+		R.e[k] = (PW >= 1) ? bp[BW + k * 16 + j] : 0;
+		R.q2[k] = (PW == 2) ? bp[2 * BW + k * 16 + j] : 0;
+	}
+	R.ubA = ub[j]; R.ubB = ub[j + 1];
+}
+
+template<int W, int PW>
+static __device__ __forceinline__ void rows_store(const RowRegs<W> &R, int8_t *bp, const int j){
+	constexpr int BW = W * 16;
+	int *ub = (int*)(bp + (PW + 1) * BW);
+#pragma unroll
+	for(int k = 0; k < W; k++){
+		bp[k * 16 + j] = (int8_t)R.u[k];
+		if(PW >= 1) bp[BW + k * 16 + j] = (int8_t)R.e[k];
+		if(PW == 2) bp[2 * BW + k * 16 + j] = (int8_t)R.q2[k];
+	}
+	ub[j] = R.ubA;
+	if(j == 15) ub[16] = R.ubB;
+}
+
+// row_init (bsalign.h:2094-2140) with max_nt = M + refbonus + 1, min_nt = X as the POA passes them (bspoa.h:2226)
+template<int W, int PW>
+static __device__ __forceinline__ void rows_init(const RowsArgs &a, RowRegs<W> &R, const int j){
+	const int gapo1 = a.gapo1, gape1 = a.gape1, gapo2 = a.gapo2, gape2 = a.gape2;
+	const int nt_max = a.M + a.refbonus + 1, nt_min = a.X;
+	const int type = a.mode & 3;
+	int bs = 0;
+	const int first = trunc8(gapo1 + gape1 + nt_min - nt_max);
+	const int xp = (PW == 2) ? (gapo2 - gapo1) / (gape1 - gape2) : 0;
+#pragma unroll
+	for(int k = 0; k < W; k++){
+		int p = j * W + k, v;
+		if(type == BSA_MODE_OVERLAP) v = 0;
+		else if(p == 0) v = first;
+		else if(PW == 2) v = (p < xp) ? gape1 : gape2;
+		else v = gape1;
+		R.u[k] = v; bs += v;
+		R.e[k] = BSA_EPI8_MIN; R.q2[k] = BSA_EPI8_MIN;
+	}
+	const int inc = row_iscan16(bs);
+	const int base0 = (type == BSA_MODE_OVERLAP) ? 0 : (nt_max - nt_min);
+	R.ubB = base0 + inc; R.ubA = R.ubB - bs;
+}
+
+// row_merge (bsalign.h:2474-2616): R = cell-wise max(R, row at b1).  Lanes are independent; int16 offsets around a
+// common base, re-based every 256 vectors as the reference does.
+template<int W, int PW>
+static __device__ __forceinline__ void rows_merge(RowRegs<W> &R, const int8_t *b1, const int j){
+	constexpr int BW = W * 16;
+	const int *ub1 = (const int*)(b1 + (PW + 1) * BW);
+	int s0 = R.ubA, s1 = ub1[j];
+	const int end0 = DPP_BCAST(R.ubB, 15), end1 = ub1[16];
+	const int ubn = max(s0, s1);
+	auto s16 = [](int v) -> int { return min(max(v, -32768), 32767); };
+	int t0 = 0, t1 = 0, mprev = 0;
+#pragma unroll
+	for(int k = 0; k < W; k++){
+		if((k & 255) == 0){
+			if(k){ s0 += t0; s1 += t1; }
+			int d = s0 - s1;
+			d = min(max(d, -0x7FFF), 0x7FFF);
+			const int x0 = d >> 1, x1 = x0 - d;
+			s0 -= x0; s1 -= x1;
+			t0 = s16(x0); t1 = s16(x1);
+			mprev = max(t0, t1);
+		}
+		t0 = s16(t0 + R.u[k]);
+		t1 = s16(t1 + b1[k * 16 + j]);
+		const int m = max(t0, t1);
+		R.u[k] = sat8(s16(m - mprev));
+		mprev = m;
+		if(PW >= 1){
+			const int a0 = s16(t0 + R.e[k]), a1 = s16(t1 + b1[BW + k * 16 + j]);
+			R.e[k] = sat8(s16(max(a0, a1) - m));
+		}
+		if(PW == 2){
+			const int a0 = s16(t0 + R.q2[k]), a1 = s16(t1 + b1[2 * BW + k * 16 + j]);
+			R.q2[k] = sat8(s16(max(a0, a1) - m));
+		}
+	}
+	R.ubA = ubn;
+	const int nxt = DPP_SHL(0, ubn, 1);
+	R.ubB = (j == 15) ? max(end0, end1) : nxt;       // ubegs[j + 1]: the next lane's start, ubegs[16] for the last
+}
+
+// the W + 1 query codes lane j needs for a task with band offset qoff_dst (4 = beyond the read end)
+template<int W>
+static __device__ __forceinline__ void rows_fetch_codes(const uint8_t *qp, uint32_t qlen, uint32_t qoff_dst, int (&qc)[W + 1], const int j){
+	const uint32_t x0 = qoff_dst + (uint32_t)j * W;
+#pragma unroll
+	for(int k = 0; k <= W; k++) qc[k] = (x0 + k < qlen) ? (int)qp[x0 + k] : 4;
+}
+
+// update: R = row_cal(row_movx(R, qoff_dst - qoff_src)) (bspoa.h:2232-2261); qc = rows_fetch_codes for this task
+template<int W, int PW>
+static __device__ __forceinline__ void rows_update(const RowsArgs &a, const bsa_row_task_t &tk, RowRegs<W> &R, const int (&qc)[W + 1], int8_t *gl, const int j){
 	constexpr int BW = W * 16;
 	int8_t *su = gl, *se = gl + BW, *sq = gl + 2 * BW;
 	int *sub = (int*)(gl + (PW + 1) * BW);
@@ -40,90 +144,9 @@ static __device__ __forceinline__ void rows_task(const RowsArgs &a, uint8_t *row
 	const int GapOQ = sat8(GapOE - GapQP);
 	const int nt_max = a.M + a.refbonus + 1, nt_min = a.X;       // as the POA passes them (bspoa.h:2241, 2226)
 	const int type = a.mode & 3;
-	auto blkp = [&](uint32_t idx) -> int8_t* { return (int8_t*)(rows + (size_t)idx * a.blk); };
-	int u[W], e[W], q2[W], ubA = 0, ubB = 0;
-	auto load_row = [&](const int8_t *bp){
-		const int *ub = (const int*)(bp + (PW + 1) * BW);
-#pragma unroll
-		for(int k = 0; k < W; k++){
-			u[k] = bp[k * 16 + j];
-			e[k] = (PW >= 1) ? bp[BW + k * 16 + j] : 0;
-			q2[k] = (PW == 2) ? bp[2 * BW + k * 16 + j] : 0;
-		}
-		ubA = ub[j]; ubB = ub[j + 1];
-	};
-	auto store_row = [&](int8_t *bp){
-		int *ub = (int*)(bp + (PW + 1) * BW);
-#pragma unroll
-		for(int k = 0; k < W; k++){
-			bp[k * 16 + j] = (int8_t)u[k];
-			if(PW >= 1) bp[BW + k * 16 + j] = (int8_t)e[k];
-			if(PW == 2) bp[2 * BW + k * 16 + j] = (int8_t)q2[k];
-		}
-		ub[j] = ubA;
-		if(j == 15) ub[16] = ubB;
-	};
-	if(tk.op == BSA_ROW_OP_INIT){
-		// ---- row_init (bsalign.h:2094-2140) with max_nt = M + refbonus + 1, min_nt = X
-		int bs = 0;
-		const int first = trunc8(gapo1 + gape1 + nt_min - nt_max);
-		const int xp = (PW == 2) ? (gapo2 - gapo1) / (gape1 - gape2) : 0;
-#pragma unroll
-		for(int k = 0; k < W; k++){
-			int p = j * W + k, v;
-			if(type == BSA_MODE_OVERLAP) v = 0;
-			else if(p == 0) v = first;
-			else if(PW == 2) v = (p < xp) ? gape1 : gape2;
-			else v = gape1;
-			u[k] = v; bs += v;
-			e[k] = BSA_EPI8_MIN; q2[k] = BSA_EPI8_MIN;
-		}
-		const int inc = row_iscan16(bs);
-		const int base0 = (type == BSA_MODE_OVERLAP) ? 0 : (nt_max - nt_min);
-		ubB = base0 + inc; ubA = ubB - bs;
-		store_row(blkp(tk.dst));
-		return;
-	}
-	if(tk.op == BSA_ROW_OP_MERGE){
-		// ---- row_merge (bsalign.h:2474-2616): lanes are independent; int16 offsets around a common base, 256 vectors per chunk
-		const int8_t *b0 = blkp(tk.src), *b1 = blkp(tk.dst);
-		const int *ub0 = (const int*)(b0 + (PW + 1) * BW), *ub1 = (const int*)(b1 + (PW + 1) * BW);
-		int s0 = ub0[j], s1 = ub1[j];
-		const int end0 = ub0[16], end1 = ub1[16];
-		ubA = max(s0, s1);
-		auto s16 = [](int v) -> int { return min(max(v, -32768), 32767); };
-		int t0 = 0, t1 = 0, mprev = 0;
-#pragma unroll
-		for(int k = 0; k < W; k++){
-			if((k & 255) == 0){
-				if(k){ s0 += t0; s1 += t1; }
-				int d = s0 - s1;
-				d = min(max(d, -0x7FFF), 0x7FFF);
-				const int x0 = d >> 1, x1 = x0 - d;
-				s0 -= x0; s1 -= x1;
-				t0 = s16(x0); t1 = s16(x1);
-				mprev = max(t0, t1);
-			}
-			t0 = s16(t0 + b0[k * 16 + j]);
-			t1 = s16(t1 + b1[k * 16 + j]);
-			const int m = max(t0, t1);
-			u[k] = sat8(s16(m - mprev));
-			mprev = m;
-			if(PW >= 1){
-				const int a0 = s16(t0 + b0[BW + k * 16 + j]), a1 = s16(t1 + b1[BW + k * 16 + j]);
-				e[k] = sat8(s16(max(a0, a1) - m));
-			}
-			if(PW == 2){
-				const int a0 = s16(t0 + b0[2 * BW + k * 16 + j]), a1 = s16(t1 + b1[2 * BW + k * 16 + j]);
-				q2[k] = sat8(s16(max(a0, a1) - m));
-			}
-		}
-		ubB = max(end0, end1);                      // only lane 15's value is stored (ubegs[16])
-		store_row(blkp(tk.dst));
-		return;
-	}
+	int (&u)[W] = R.u; int (&e)[W] = R.e; int (&q2)[W] = R.q2;
+	int &ubA = R.ubA; int &ubB = R.ubB;
 	// ---- update: row_movx(qoff_dst - qoff_src) then row_cal (bspoa.h:2232-2261)
-	load_row(blkp(tk.src));
 	const uint32_t movx = tk.qoff_dst - tk.qoff_src;
 	int rh;
 	if(tk.qoff_src == tk.qoff_dst){
@@ -184,18 +207,14 @@ static __device__ __forceinline__ void rows_task(const RowsArgs &a, uint8_t *row
 		if(tk.qoff_src + (uint32_t)BW >= tk.qoff_dst) rh = DPP_BCAST(ubA, 0);     // "movx -> aligned" (bspoa.h:2252)
 	}
 	// ---- S(x, base) for this lane's cells under the task's profile (bspoa.h:2199-2213, 2588)
-	const uint32_t qlen = a.qlen[tk.query];
-	const uint8_t *qp = a.queries + a.qoff[tk.query];
 	const int mat = (tk.prof & 1) ? (a.M + a.refbonus) : a.M;
 	const bool hpc = !(tk.prof & 2);
 	int S[W];
 	{
-		const uint32_t x0 = tk.qoff_dst + (uint32_t)j * W;
-		int cprev = (x0 < qlen) ? (int)qp[x0] : 4;
+		int cprev = qc[0];
 #pragma unroll
 		for(int k = 0; k < W; k++){
-			const uint32_t x = x0 + k;
-			const int cnext = (x + 1 < qlen) ? (int)qp[x + 1] : 4;
+			const int cnext = qc[k + 1];
 			int s;
 			if(cprev == 4) s = BSA_EPI8_MIN;
 			else {
@@ -296,7 +315,24 @@ static __device__ __forceinline__ void rows_task(const RowsArgs &a, uint8_t *row
 		if(j == 0){ nA = ubA + u[0]; u[0] = 0; }
 		ubA = nA; ubB = nB;
 	}
-	store_row(blkp(tk.dst));
+}
+
+// one independent row task: load, operate, store
+template<int W, int PW>
+static __device__ __forceinline__ void rows_task(const RowsArgs &a, uint8_t *rows, const bsa_row_task_t &tk, int8_t *gl, const int j){
+	auto blkp = [&](uint32_t idx) -> int8_t* { return (int8_t*)(rows + (size_t)idx * a.blk); };
+	RowRegs<W> R;
+	if(tk.op == BSA_ROW_OP_INIT) rows_init<W, PW>(a, R, j);
+	else {
+		rows_load<W, PW>(R, blkp(tk.src), j);
+		if(tk.op == BSA_ROW_OP_MERGE) rows_merge<W, PW>(R, blkp(tk.dst), j);
+		else {
+			int qc[W + 1];
+			rows_fetch_codes<W>(a.queries + a.qoff[tk.query], a.qlen[tk.query], tk.qoff_dst, qc, j);
+			rows_update<W, PW>(a, tk, R, qc, gl, j);
+		}
+	}
+	rows_store<W, PW>(R, blkp(tk.dst), j);
 }
 
 // ---- the same row task for ANY bandwidth (run-time W): cells stay in the row blocks in global memory, lane j walks
@@ -590,9 +626,42 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepArgs a){
 		for(uint32_t k = 0; k <= x; k++) s += bp[k * 16 + y];
 		return s;
 	};
+	// The row a task produces is usually the next task's source (chains of the graph): it stays in registers and the
+	// reload is skipped.  Stores are fire-and-forget; a fence is paid only before a task that reads row blocks from
+	// memory after something was stored (other lanes' ubegs words are involved).  The next task record is fetched
+	// while the current one computes.
+	RowRegs<(WT ? WT : 1)> R;
+	uint32_t held = 0xFFFFFFFFu;                 // block index whose row R holds
+	bool dirty = false;
+	auto sync_rows = [&](){
+		if(dirty){
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			dirty = false;
+		}
+	};
+	auto blkp = [&](uint32_t idx) -> int8_t* { return (int8_t*)(rows + (size_t)idx * a.r.blk); };
+	// software pipeline: tk = current task, tk1 = next (already in registers), tk2 = the one after (load in flight);
+	// the query codes of tk1 are requested while tk computes
+	const uint32_t last = pg.ntasks - 1u;
+	bsa_row_task_t tk = a.r.tasks[pg.first_task];
+	bsa_row_task_t tk1 = a.r.tasks[pg.first_task + min(1u, last)];
+	uint32_t cq = 0xFFFFFFFFu, cq_len = 0; const uint8_t *cq_ptr = nullptr;      // the program's current query
+	auto use_query = [&](uint32_t qi){
+		if(qi != cq){ cq = qi; cq_len = a.r.qlen[qi]; cq_ptr = a.r.queries + a.r.qoff[qi]; }
+	};
+	int qc[(WT ? WT : 1) + 1], qc1[(WT ? WT : 1) + 1];
+	if constexpr(WT != 0){
+		use_query(tk.query);
+		rows_fetch_codes<WT>(cq_ptr, cq_len, tk.qoff_dst, qc, j);
+	}
 	for(uint32_t t = 0; t < pg.ntasks; t++){
-		const bsa_row_task_t tk = a.r.tasks[pg.first_task + t];
+		const bsa_row_task_t tk2 = a.r.tasks[pg.first_task + min(t + 2u, last)];
+		if constexpr(WT != 0){
+			if(tk1.op == BSA_ROW_OP_UPDATE){ use_query(tk1.query); rows_fetch_codes<WT>(cq_ptr, cq_len, tk1.qoff_dst, qc1, j); }
+		}
 		if(tk.op == BSA_ROW_OP_SCORE_TAIL || tk.op == BSA_ROW_OP_SCORE_END){
+			sync_rows();
 			const int8_t *bp = (const int8_t*)(rows + (size_t)tk.src * a.r.blk);
 			const int slen = (int)a.r.qlen[tk.query], rpos = (int)tk.qoff_src;
 			if(tk.op == BSA_ROW_OP_SCORE_END){                       // bspoa.h:2597-2606
@@ -651,13 +720,24 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepArgs a){
 					if(best > maxscr){ maxscr = best; maxidx = (int)tk.toff; maxoff = lane * W + jj + rpos; }
 				}
 			}
+		} else if constexpr(WT != 0){
+			if(tk.op == BSA_ROW_OP_INIT) rows_init<WT, PW>(a.r, R, j);
+			else {
+				if(tk.src != held){ sync_rows(); rows_load<WT, PW>(R, blkp(tk.src), j); }
+				if(tk.op == BSA_ROW_OP_MERGE){ sync_rows(); rows_merge<WT, PW>(R, blkp(tk.dst), j); }
+				else rows_update<WT, PW>(a.r, tk, R, qc, gl, j);
+			}
+			rows_store<WT, PW>(R, blkp(tk.dst), j);
+			held = tk.dst; dirty = true;
 		} else {
-			if constexpr(WT != 0) rows_task<WT, PW>(a.r, rows, tk, gl, j);
-			else rows_task_gen<PW>(a.r, rows, tk, j, sub);
+			rows_task_gen<PW>(a.r, rows, tk, j, sub);
 			// the next task may read, from other lanes, what this one stored (ubegs[j + 1]); same wave, so program order + fence
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		}
+		tk = tk1; tk1 = tk2;
+#pragma unroll
+		for(int k = 0; k <= (WT ? WT : 1); k++) qc[k] = qc1[k];
 	}
 	if(j == 0){
 		bsa_sweep_result_t rs;
@@ -677,6 +757,8 @@ static hipError_t launch_rows_pw(const RowsArgs &a, int pw, hipStream_t st){
 }
 
 extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *ctx, hipStream_t *st);
+extern "C" int bsa_ctx_time_begin_internal(bsa_ctx_t *ctx, double cells, void **stop_event);
+extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *ctx, void *stop_event);
 
 extern "C" size_t bsa_rows_block_bytes(uint32_t bandwidth, int8_t gapo1, int8_t gape1, int8_t gapo2, int8_t gape2){   // == mmblk, bspoa.h:2217
 	const uint32_t bw = (bandwidth + 15u) / 16u * 16u;
@@ -741,6 +823,9 @@ extern "C" int bsa_sweep_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task
 	a.r.blk = (uint32_t)bsa_rows_block_bytes(bw, rp->gapo1, rp->gape1, rp->gapo2, rp->gape2);
 	a.progs = d_progs; a.results = d_results; a.nprogs = (uint32_t)nprogs; a.T = par->T;
 	const int pw = bsa_get_piecewise(rp->gapo1, rp->gape1, rp->gapo2, rp->gape2, (int)bw);
+	void *stop = nullptr;
+	rc = bsa_ctx_time_begin_internal(ctx, 0.0, &stop);
+	if(rc != BSA_OK) return rc;
 	hipError_t e;
 	switch(bw / 16){
 		case 1:  e = launch_sweep_pw<1>(a, pw, st); break;
@@ -750,7 +835,8 @@ extern "C" int bsa_sweep_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task
 		case 16: e = launch_sweep_pw<16>(a, pw, st); break;
 		default: e = launch_sweep_pw<0>(a, pw, st); break;
 	}
-	return e == hipSuccess ? BSA_OK : BSA_E_HIP;
+	if(e != hipSuccess) return BSA_E_HIP;
+	return bsa_ctx_time_end_internal(ctx, stop);
 }
 
 namespace {

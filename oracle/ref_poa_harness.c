@@ -19,6 +19,7 @@
 #include "bspoa.h"
 #include "../include/bsalign_poa_adapter.h"
 #include <stdint.h>
+#include <time.h>
 
 /* the adapter's two link-time dependencies on libbsalign_hip.so, satisfied locally: this library must load without HIP */
 __attribute__((visibility("hidden"))) size_t bsa_rows_block_bytes(uint32_t bandwidth, int8_t gapo1, int8_t gape1, int8_t gapo2, int8_t gape2){
@@ -56,6 +57,9 @@ typedef struct {
 	bsa_row_task_t *tasks; size_t ntasks, captasks;
 	uint8_t *queries; size_t nq, capq;
 	int mode, record_programs;
+	double core_seconds;        /* mode 1: wall time inside the reference's align_rd_bspoacore */
+	uint64_t core_updates;      /* mode 1: row updates (edges) those calls processed */
+	uint64_t core_merges;
 } ref_poa_t;
 
 static uint64_t fnv1a(uint64_t h, const void *p, size_t n){
@@ -171,7 +175,19 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 		score = a_scr;
 		free(mine);
 	} else {
+		struct timespec t0, t1;
+		size_t i;
+		/* count the work first (the flattening walk is the same traversal), then time the reference's sweep alone */
+		bsa_poa_flatten(g, par, head, tail, &p->ad);
+		for(i=0;i<p->ad.ntasks;i++){
+			if(p->ad.tasks[i].op == BSA_ROW_OP_UPDATE) p->core_updates ++;
+			else if(p->ad.tasks[i].op == BSA_ROW_OP_MERGE) p->core_merges ++;
+		}
+		for(k=0;k<g->sels->size;k++) ref_bspoanodev(g->nodes, g->sels->buffer[k])->vst = 0;
+		clock_gettime(CLOCK_MONOTONIC, &t0);
 		score = align_rd_bspoacore(g, par, rid, head, tail);
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		p->core_seconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 		rows_hash = hash_node_blocks(g, tail);
 	}
 	rs = alignment2graph_bspoa(g, par, rid, 0, head, tail, g->maxidx, g->maxoff, NULL);
@@ -237,6 +253,7 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 	size_t i;
 	p->mode = mode; p->record_programs = record_programs;
 	p->nrec = 0; p->ntasks = 0; p->nq = 0;
+	p->core_seconds = 0; p->core_updates = 0; p->core_merges = 0;
 	p->sweep = (orc_sweep_fn)sweep_fn;
 	bsa_poa_adapter_free(&p->ad);
 	bsa_poa_adapter_init(&p->ad, backend_oracle, p);
@@ -289,3 +306,7 @@ void ref_poa_programs(void *vp, void *tasks, uint8_t *queries){
 	memcpy(queries, p->queries, p->nq);
 }
 uint64_t ref_poa_block_bytes(void *vp){ return ((ref_poa_t*)vp)->g->mmblk; }
+void ref_poa_core_stats(void *vp, double *seconds, uint64_t *updates, uint64_t *merges){
+	ref_poa_t *p = (ref_poa_t*)vp;
+	*seconds = p->core_seconds; *updates = p->core_updates; *merges = p->core_merges;
+}

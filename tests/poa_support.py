@@ -53,6 +53,8 @@ def ref_poa():
     r.ref_poa_nquery_bytes.restype = C.c_uint64
     r.ref_poa_programs.argtypes = [C.c_void_p] * 3
     r.ref_poa_programs.restype = None
+    r.ref_poa_core_stats.argtypes = [C.c_void_p] * 4
+    r.ref_poa_core_stats.restype = None
     r._poa_ready = True
     return r
 
@@ -84,8 +86,10 @@ def run_ref_poa(reads, mode, p, record=True):
     queries = np.zeros(int(r.ref_poa_nquery_bytes(h)), dtype=np.uint8)
     if len(tasks):
         r.ref_poa_programs(h, tasks.ctypes.data, queries.ctypes.data)
+    secs, nu, nm = C.c_double(), C.c_uint64(), C.c_uint64()
+    r.ref_poa_core_stats(h, C.byref(secs), C.byref(nu), C.byref(nm))
     r.ref_poa_destroy(h)
-    return dict(bad=bad, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, tasks=tasks, queries=queries)
+    return dict(core_seconds=secs.value, core_updates=nu.value, core_merges=nm.value, bad=bad, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, tasks=tasks, queries=queries)
 
 
 def block_bytes(bw, pw):

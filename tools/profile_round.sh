@@ -1,0 +1,36 @@
+#!/bin/bash
+# Reproduce the rocprofv3 evidence kept under profiles/ (run on the GPU box through gpurun):
+#   tools/profile_round.sh <tag>     e.g. r01d
+# writes gpurun_out/prof_<tag>/{align8,edit,poa}_* : kernel-trace stats of the default bench commands, and for the
+# dominant kernels FETCH_SIZE / WRITE_SIZE in separate --pmc passes (never combined with tracing, see the task notes).
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+run_stats(){ # name, bench args...
+	local name=$1; shift
+	timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${name} -- python bench.py "$@" --cpu-pairs -1 > $OUT/${name}_bench.log 2>&1
+}
+run_pmc(){ # name, counter, bench args...
+	local name=$1 ctr=$2; shift 2
+	timeout 900 rocprofv3 --pmc $ctr --output-format csv -d $OUT -o ${name}_pmc_${ctr} -- python bench.py "$@" --cpu-pairs -1 > $OUT/${name}_pmc_${ctr}.log 2>&1
+}
+run_stats align8 --steps 3 --warmup 1
+run_pmc align8 FETCH_SIZE --steps 1 --warmup 0
+run_pmc align8 WRITE_SIZE --steps 1 --warmup 0
+run_stats edit --workload edit --steps 3 --warmup 1
+run_pmc edit FETCH_SIZE --workload edit --steps 1 --warmup 0
+run_pmc edit WRITE_SIZE --workload edit --steps 1 --warmup 0
+run_stats poa --workload poa --steps 2 --warmup 1
+run_pmc poa FETCH_SIZE --workload poa --steps 1 --warmup 0
+run_pmc poa WRITE_SIZE --workload poa --steps 1 --warmup 0
+# the bench lines themselves (with the CPU baseline), outside the profiler
+timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/align8_bench_line.json 2> $OUT/align8_bench_line.err
+timeout 900 python bench.py --workload edit --steps 3 --warmup 1 > $OUT/edit_bench_line.json 2> $OUT/edit_bench_line.err
+timeout 900 python bench.py --workload poa --steps 2 --warmup 1 > $OUT/poa_bench_line.json 2> $OUT/poa_bench_line.err
+# keep only the small summaries (the merge back is capped at 64 MiB)
+find $OUT -name '*.db' -delete
+find $OUT -name '*_kernel_trace.csv' -delete
+find $OUT -name '*agent_info.csv' -delete
+ls -la $OUT
