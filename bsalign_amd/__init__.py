@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbsalign_hip.so")
+LIB_PATH = os.environ.get("BSA_LIB_PATH") or os.path.join(_HERE, "libbsalign_hip.so")      # BSA_LIB_PATH: development builds
 
 MODE_GLOBAL, MODE_OVERLAP, MODE_EXTEND = 0, 1, 2
 ST_BAD_BASE, ST_EMPTY, ST_TRACE = 1, 2, 4

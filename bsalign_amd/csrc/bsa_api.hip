@@ -276,10 +276,13 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 	for(size_t pos = 0; pos < n; pos++){ total += need[pos]; biggest = std::max(biggest, need[pos]); }
 	if(biggest > budget){ c->err = "workspace limit too small for one pair"; return BSA_E_NOMEM; }
 	// Both kernels are row-serial per pair, so throughput = pairs in flight / per-pair latency: chunks are made as
-	// large as memory allows and run back to back on the context stream.  Measured on MI355X (round 1): splitting the
-	// workspace in two halves and running the traceback of chunk k beside the forward pass of chunk k+1 on a second
-	// stream was SLOWER (394 vs 367 ms per 100k-pair step: smaller chunks lower the forward kernel's occupancy and the
-	// two kernels compete for issue slots), so that mode is opt-in (BSA_PIPELINE=1) until the traceback is cheaper.
+	// large as memory allows and run back to back on the context stream.  Splitting the workspace in two halves and
+	// running the traceback of chunk k beside the forward pass of chunk k+1 on a second stream is SLOWER on MI355X
+	// (100k x 10 kbp, bw 128: 284-302 ms per step for chunk sizes 16k..33k pairs against 256 ms back to back; kernel
+	// trace: the forward pass of a third of the batch takes 86-88 ms beside a traceback instead of 57 ms, and that
+	// traceback 61-89 ms instead of 34 ms).  The packed forward kernel fills the register file (4 waves x 128 VGPRs
+	// per SIMD), so every resident traceback wave evicts a forward wave, and raising the traceback's wave priority
+	// changes nothing.  The mode stays opt-in (BSA_PIPELINE=1); BSA_CHUNK_PAIRS caps the pairs per chunk (tuning knob).
 	size_t cap;            // bytes per chunk
 	const char *pe = getenv("BSA_PIPELINE");
 	const bool want_pipe = pe && pe[0] == '1';
@@ -289,10 +292,12 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 		p->two_halves = (2 * cap <= budget);
 		if(!p->two_halves) cap = std::max(budget, biggest);
 	}
+	size_t cap_pairs = n ? n : 1;
+	if(const char *ce = getenv("BSA_CHUNK_PAIRS")){ const long v = atol(ce); if(v > 0) cap_pairs = (size_t)v; }
 	slot.assign(n, 0); slot_end.assign(n, 0);
 	size_t acc = 0, maxacc = 0; uint32_t first = 0;
 	for(size_t pos = 0; pos < n; pos++){
-		if(pos > first && (acc + need[pos] > cap || bwv[pos] != bwv[first])){
+		if(pos > first && (acc + need[pos] > cap || bwv[pos] != bwv[first] || pos - first >= cap_pairs)){
 			p->chunks.push_back({first, (uint32_t)(pos - first), bwv[first], acc});
 			maxacc = std::max(maxacc, acc);
 			first = (uint32_t)pos; acc = 0;
