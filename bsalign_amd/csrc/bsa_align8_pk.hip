@@ -34,7 +34,24 @@ static __device__ __forceinline__ void load_qcodes_pk(const uint8_t *p, uint32_t
 	else w[0] = p[0] | 0x04040400u;
 }
 
-template<int W, int PW>
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+// per 16-bit half: 1 where the halves of a and b are equal, else 0 (v_xor + v_pk_sub_u16 clamp)
+static __device__ __forceinline__ uint32_t pk_eq(uint32_t a, uint32_t b){
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, 0x00010001u), __builtin_bit_cast(v2us, a ^ b)));
+}
+// acc = acc * 2 + flag per half (v_pk_mad_u16)
+static __device__ __forceinline__ uint32_t pk_acc(uint32_t acc, uint32_t flag){
+	return __builtin_bit_cast(uint32_t, (v2us)(__builtin_bit_cast(v2us, acc) * (v2us)(2) + __builtin_bit_cast(v2us, flag)));
+}
+
+// CODES = true: the compact traceback of the global mode.  Instead of the row records the kernel stores, per band
+// cell, the outcome of the four equality tests the reference's backcal would make there (bsa_common.h, "COMPACT
+// slot"; oracle/bsalign_oracle.c orc_align_pairwise_codes is the scalar statement of the same rules), computed from
+// the values the recurrence has in registers anyway:
+//   M  = h == S          D = h == e + u          R = h + gapoe >= f + gape          Od = e' == gapoe
+// with the reference's quirks at band position 0 (frame of ubegs[0], bsalign.h:3760-3771, 2632-2633) and beyond the
+// previous row's band end (bsalign.h:3672-3678) applied when the row is assembled.  64 bytes per row at bw 128.
+template<int W, int PW, bool CODES = false>
 __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd_pk(const Align8Args a){
 	constexpr int BW = W * 16;
 	constexpr int NQ = (W + 3) / 4;
@@ -142,10 +159,14 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 		for(int h = 0; h < 2; h++) if(act[h] && j == 0) begs[h][row_index] = (int)rbeg_v[h];
 	};
 	uint32_t rbeg[2] = {0, 0}, mov[2] = {0, 0}, i = 0;
-	{
+	if constexpr (!CODES){
 		bool act0[2] = { tlen[0] != 0, tlen[1] != 0 };
 		store_rows(0, act0, rbeg);
+	} else {
+#pragma unroll
+		for(int h = 0; h < 2; h++) if(tlen[h] != 0 && j == 0) begs[h][0] = 0;
 	}
+	constexpr uint32_t CW = (W >= 8) ? (uint32_t)W / 8u : 1u;
 	int tb_next[2];
 	int rbz[2];     // 2 * max(tlen / qlen, 1): suggested max band step (bsalign.h:4008)
 #pragma unroll
@@ -344,6 +365,9 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			}
 		}
 		uint32_t htail, ulast = 0;
+		uint32_t accM = 0, accD = 0, accR = 0, accO = 0;        // CODES: flag planes, pair A in the low half, pair B in the high half
+		const uint32_t u0_old = u[0], e0_old = e[0];
+		uint32_t hfirst = 0;
 		{
 			uint32_t v = 0, z = (j == 0) ? H0 : Sv[0], h = 0;
 #pragma unroll
@@ -352,19 +376,34 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 				if(PW == 0){
 					const uint32_t ee = pk_adds(uk, GE);
 					h = pk_max(pk_max(ee, z), f);
+					if constexpr (CODES){
+						accM = pk_acc(accM, pk_eq(h, Sv[k]));
+						accD = pk_acc(accD, pk_eq(h, ee));
+						if(k == 0) hfirst = h;
+					}
 					u[k] = pk_norm(pk_subs(h, v));
 					v = pk_norm(pk_subs(h, uk));
 					f = pk_norm(pk_subs(pk_adds(h, GE), uk));
 				} else if(PW == 1){
 					uint32_t ee = pk_adds(e[k], uk);
 					h = pk_max(pk_max(ee, z), f);
+					if constexpr (CODES){
+						accM = pk_acc(accM, pk_eq(h, Sv[k]));
+						accD = pk_acc(accD, pk_eq(h, ee));
+						if(k == 0) hfirst = h;
+					}
 					u[k] = pk_norm(pk_subs(h, v));
 					v = pk_norm(pk_subs(h, uk));
 					ee = pk_subs(pk_adds(ee, GE), h);
 					e[k] = pk_max(ee, GOE);
 					f = pk_adds(f, GE);
 					h = pk_adds(h, GOE);
-					f = pk_norm(pk_subs(pk_max(f, h), uk));
+					const uint32_t fm = pk_max(f, h);
+					if constexpr (CODES){
+						accO = pk_acc(accO, pk_eq(e[k], GOE));
+						accR = pk_acc(accR, pk_eq(fm, h));             // opening at this cell reaches the next one at least as well as extending
+					}
+					f = pk_norm(pk_subs(fm, uk));
 				} else {
 					uint32_t ee = pk_adds(e[k], uk), qq = pk_adds(q2[k], uk);
 					h = pk_max(pk_max(ee, z), pk_max(qq, pk_max(f, gq)));
@@ -386,6 +425,39 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			}
 			htail = (PW == 0) ? h : (PW == 1) ? pk_subs(h, GOE) : pk_subs(h, GQP);
 		}
+		if constexpr (CODES){
+			// ---- assemble and store the code row of both pairs
+			constexpr uint32_t FULL = (W == 16) ? 0xFFFFu : ((1u << W) - 1u);
+#pragma unroll
+			for(int hf = 0; hf < 2; hf++){
+				uint32_t pm = (accM >> (16 * hf)) & 0xFFFFu, pd = (accD >> (16 * hf)) & 0xFFFFu;
+				uint32_t pr = (PW == 0) ? FULL : ((accR >> (16 * hf)) & 0xFFFFu), po = (PW == 0) ? FULL : ((accO >> (16 * hf)) & 0xFFFFu);
+				// band position 0 of a band that starts at query column 0: backcal compares in the frame of the boundary
+				// column (bsalign.h:3763-3767) -- 32-bit arithmetic on ubegs[0], rh and the raw score
+				if(j == 0 && rbeg[hf] == 0u){
+					const int hh0 = pk_get(hfirst, hf), s0 = pk_get(Sv[0], hf), uu0 = pk_get(u0_old, hf);
+					const int ee0 = (PW == 0) ? (gapo1 + gape1) : pk_get(e0_old, hf);
+					const bool m0 = hh0 == rh[hf] - ubA[hf] + s0;
+					const bool d0 = ubA[hf] + hh0 - rh[hf] == uu0 + ee0;
+					pm = (pm & ~(1u << (W - 1))) | ((uint32_t)m0 << (W - 1));
+					pd = (pd & ~(1u << (W - 1))) | ((uint32_t)d0 << (W - 1));
+				}
+				// cells at / beyond the end of the previous row's band: x == bw decides M or I only, x > bw is always I
+				{
+					const int lim = BW - (int)mov[hf] - j * W;             // cells k < lim have x < bw
+					const int nd = min(max(lim, 0), W), nm = min(max(lim + 1, 0), W);
+					pd &= (FULL << (W - nd)) & FULL;
+					pm &= (FULL << (W - nm)) & FULL;
+				}
+				if(act[hf]){
+					uint32_t *rp = (uint32_t*)(rowp[hf] + (size_t)i * (64u * CW)) + (uint32_t)j * CW;
+					if constexpr (W == 4) rp[0] = pm | (pd << 4) | (pr << 8) | (po << 12);
+					else if constexpr (W == 8) rp[0] = pm | (pd << 8) | (pr << 16) | (po << 24);
+					else { rp[0] = pm | (pd << 16); rp[1] = pr | (po << 16); }
+					if(j == 0) begs[hf][i + 1] = (int)rbeg[hf];
+				}
+			}
+		}
 		// ---- tail (bsalign.h:2618-2636)
 		{
 			const uint32_t vlast = pk_norm(pk_subs(htail, ulast));
@@ -403,7 +475,21 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			}
 			if(j == 0) u[0] = 0u;
 		}
-		store_rows(i + 1, act, rbeg);
+		if constexpr (!CODES) store_rows(i + 1, act, rbeg);
+		else if(__any((act[0] && i + 1u == tlen[0]) || (act[1] && i + 1u == tlen[1]))){
+			// last row of a pair: global score = H at query column qlen - 1 (bsalign.h:4034-4037), kept in begs[tlen + 1]
+#pragma unroll
+			for(int hf = 0; hf < 2; hf++){
+				if(act[hf] && i + 1u == tlen[hf]){
+					const uint32_t pos = qlen[hf] - 1u - rbeg[hf];
+					int sc = ubA[hf];
+#pragma unroll
+					for(int k = 0; k < W; k++) sc += ((uint32_t)k <= pos % W) ? pk_get(u[k], hf) : 0;
+					if(pos >= (uint32_t)BW){ if(j == 0) begs[hf][tlen[hf] + 1u] = (int)0x80000000u; }      // band never reached the query end
+					else if((uint32_t)j == pos / W) begs[hf][tlen[hf] + 1u] = sc;
+				}
+			}
+		}
 		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
 		bool rush[2] = {false, false};
 #pragma unroll
@@ -451,6 +537,39 @@ static hipError_t launch_fwd_pk(const Align8Args &a, hipStream_t st){
 	if(blocks == 0) return hipSuccess;
 	hipLaunchKernelGGL((k_align8_fwd_pk<W, PW>), dim3(blocks), dim3(256), 2 * PAIR_LDS * 16, st, a);
 	return hipGetLastError();
+}
+
+template<int W, int PW>
+static hipError_t launch_fwd_codes(const Align8Args &a, hipStream_t st){
+	constexpr int BW = W * 16;
+	constexpr int PAIR_LDS = ((PW + 1) * BW + 17 * 4 + 15) & ~15;
+	const uint32_t groups = (a.count + 1) / 2;
+	const uint32_t blocks = (groups + 15) / 16;
+	if(blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL((k_align8_fwd_pk<W, PW, true>), dim3(blocks), dim3(256), 2 * PAIR_LDS * 16, st, a);
+	return hipGetLastError();
+}
+
+// The compact path is sound only when no saturating operation can clamp and no int8 store can wrap: then the stored
+// differences are exact and the flags equal backcal's tests on reconstructed scores (checked against the literal
+// restatement on 40 k random pairs, tests/test_oracle_codes.py).  With m = max score, g = |gapo + gape|, every
+// intermediate of the recurrence lies within [-(m + 3g), m + g] and the synthetic band-edge cell is
+// min(smin, gapoe) - 1 - smax + gapoe (bsalign.h:2362); the limits below keep both well inside int8.
+bool bsa_align8_codes_supported(const Align8Args &a, int pw){
+	if(!bsa_align8_pk_supported(a, pw) || pw > 1) return false;
+	if((a.mode & 3) != BSA_MODE_GLOBAL) return false;
+	const int g = -((int)(int8_t)(a.gapo1 + a.gape1)), m = a.smax, n = -a.smin;
+	if(m < 0 || n < 0 || g < 0) return false;
+	return m + 3 * g <= 100 && n + m + g <= 120 && m <= 48;
+}
+
+hipError_t bsa_launch_align8_fwd_codes(const Align8Args &a, int pw, hipStream_t st){
+#define CODES_CASE(WW) case WW: return pw == 0 ? launch_fwd_codes<WW, 0>(a, st) : launch_fwd_codes<WW, 1>(a, st);
+	switch(a.bw / 16){
+		CODES_CASE(4) CODES_CASE(8) CODES_CASE(16)
+		default: return hipErrorInvalidValue;
+	}
+#undef CODES_CASE
 }
 
 template<int W>

@@ -441,6 +441,7 @@ struct bsa_align_plan : PlanBase {
 	bsa_align_params_t par;
 	uint32_t bw = 0, rowb = 0; int pw = 0;       // bw == 0: per-pair bandwidth = roundup(qlen, 16)
 	bool generic = false;                        // run the LDS-resident generic kernels
+	bool codes = false;                          // compact 4-bit-code traceback (global mode, bsa_align8_pk.hip CODES)
 	uint32_t max_bw = 0;
 	uint32_t qpad = 0, tpad = 16;
 };
@@ -470,6 +471,17 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	}
 	p->rowb = bw ? 16u * bsa_tile_bytes(bw / 16u, p->pw) : 0u;
 	p->qpad = max_bw + 32;
+	{
+		// compact traceback where its preconditions hold (BSA_ALIGN8_LITERAL=1 keeps the row-record path)
+		const char *le = getenv("BSA_ALIGN8_LITERAL");
+		Align8Args t;
+		memset(&t, 0, sizeof(t));
+		t.bw = bw; t.mode = par->mode; t.gapo1 = par->gapo1; t.gape1 = par->gape1; t.gapo2 = par->gapo2; t.gape2 = par->gape2;
+		int smax = -127, smin = 127;
+		for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
+		t.smax = smax; t.smin = smin;
+		p->codes = !p->generic && !(le && le[0] == '1') && bsa_align8_codes_supported(t, p->pw);
+	}
 	std::vector<uint32_t> order(n);
 	for(size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return tlen[x] > tlen[y]; });
@@ -483,7 +495,8 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + p->tpad + 15) & ~(size_t)15;
 		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw_of(k);
 	}
-	for(size_t pos = 0; pos < n; pos++) need[pos] = bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
+	for(size_t pos = 0; pos < n; pos++)
+		need[pos] = p->codes ? bsa_code_slot_bytes(tlen[order[pos]], bw / 16u) : bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
 	p->cells = cells;
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
 	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
@@ -526,16 +539,18 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	}
 	const int pw = p->pw;
 	uint32_t *cnt = p->d_cnt_pos;
-	const bool generic = p->generic; const uint32_t max_bw = p->max_bw;
+	const bool generic = p->generic, codes = p->codes; const uint32_t max_bw = p->max_bw;
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
-		if(generic) HIPCHK(c, bsa_launch_align8_fwd_gen(b, pw, max_bw, s));
+		if(codes) HIPCHK(c, bsa_launch_align8_fwd_codes(b, pw, s));
+		else if(generic) HIPCHK(c, bsa_launch_align8_fwd_gen(b, pw, max_bw, s));
 		else HIPCHK(c, bsa_launch_align8_fwd(b, pw, s));
 		return BSA_OK;
 	};
 	auto trace = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
-		HIPCHK(c, bsa_launch_align8_backcal(b, pw, d_out, cnt, s));
+		if(codes) HIPCHK(c, bsa_launch_align8_trace_codes(b, pw, d_out, cnt, s));
+		else HIPCHK(c, bsa_launch_align8_backcal(b, pw, d_out, cnt, s));
 		return BSA_OK;
 	};
 	return run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);

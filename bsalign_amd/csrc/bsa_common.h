@@ -57,6 +57,17 @@ static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t 
 	return bsa_begs_bytes(tlen) + bsa_groups(tlen, bsa_tile_rows(W, pw)) * 16 * (size_t)bsa_tile_bytes(W, pw);
 }
 
+// COMPACT (4-bit code) slot of the global-mode fast path (bsa_align8_pk.hip, CODES = true):
+//   int32 begs[tlen + 2]  (begs[tlen + 1] = final score)  |  code rows 0 .. tlen-1, then one spare row (CIGAR scratch)
+// Code row = 16 lanes x CW dwords (CW = max(1, W / 8)); lane y owns running block y.  The 4W bits of a lane are four
+// planes of W bits, plane n at bit n*W: M, D, R (insert opens here for the next cell), Od (stored e is a fresh
+// opening); inside a plane cell k of the block is bit W-1-k.
+static inline __host__ __device__ uint32_t bsa_code_words(uint32_t W){ return W >= 8u ? W / 8u : 1u; }
+static inline __host__ __device__ uint32_t bsa_code_row_bytes(uint32_t W){ return 64u * bsa_code_words(W); }
+static inline __host__ __device__ size_t bsa_code_slot_bytes(uint32_t tlen, uint32_t W){
+	return bsa_begs_bytes(tlen) + ((size_t)tlen + 1) * bsa_code_row_bytes(W);
+}
+
 static inline __host__ __device__ int bsa_get_piecewise(int gapo1, int gape1, int gapo2, int gape2, int bandwidth){ // bsalign.h:2084-2092
 	if(gapo2 < gapo1 && gape2 > gape1 && gapo2 + gape2 < gapo1 + gape1 && (gapo1 - gapo2) / (gape1 - gape2) < bandwidth) return 2;
 	return gapo1 ? 1 : 0;
@@ -134,6 +145,9 @@ size_t bsa_align8_gen_lds(uint32_t bw, int pw);
 hipError_t bsa_launch_align8_fwd_gen(const Align8Args &a, int pw, uint32_t max_bw, hipStream_t st);
 bool bsa_align8_pk_supported(const Align8Args &a, int pw);
 hipError_t bsa_launch_align8_fwd_pk(const Align8Args &a, int pw, hipStream_t st);
+bool bsa_align8_codes_supported(const Align8Args &a, int pw);          // global mode, piecewise <= 1, small scores
+hipError_t bsa_launch_align8_fwd_codes(const Align8Args &a, int pw, hipStream_t st);
+hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);
 bool bsa_edit_supported_bw(uint32_t bw);
 hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
 		const uint64_t *qpoff, const uint64_t *tpoff, const uint64_t *qboff, const uint32_t *qwords,

@@ -178,6 +178,18 @@ static void f_penetrate(uint32_t W, int f[NL], const int32_t *ub, int gape){
 	for(i = 0; i < NL; i++) f[i] = fs[i];
 }
 
+/* ---- 4-bit traceback codes (prototype of the device's compact traceback; see orc_align_pairwise_codes below) ----
+ * When tl_codes is set, orc_row_cal also emits, per band cell p of the row it computes, the outcome of the equality
+ * tests the reference's backcal would make there, from values the row kernel has at hand:
+ *   bit 0  M   h == s                     (backcal_cell, bsalign.h:3679-3699)
+ *   bit 1  D   h == u + e                 (same; u, e of the previous row at this column)
+ *   bit 2  R   the insertion reaching cell p+1 is opened at p (h + gapoe >= f + gape): the insert-length scan
+ *              bsalign.h:3798-3814 stops at the first such cell to the left
+ *   bit 3  Od  the stored e of this cell equals gapo+gape: the delete-length scan bsalign.h:3730-3744 stops here
+ * Sound only when no saturation fires anywhere (stored differences exact); piecewise <= 1. */
+static __thread uint8_t *tl_codes = NULL;   /* bw bytes for the row being computed, natural band order */
+static __thread uint32_t tl_mov = 0;
+
 int orc_row_cal(uint32_t rbeg, uint8_t base,
 		const int8_t *us0, const int8_t *es0, const int8_t *qs0, const int32_t *ub0,
 		int8_t *us1, int8_t *es1, int8_t *qs1, int32_t *ub1,
@@ -238,12 +250,32 @@ int orc_row_cal(uint32_t rbeg, uint8_t base,
 			if(piecewise == 0){
 				e = sat8(u + GapE);
 				hh = imax(e, z[j]); hh = imax(f[j], hh);
+				if(tl_codes){
+					const uint32_t pp = (uint32_t)j * W + i, xx = pp + tl_mov;
+					const int sraw = score_at(qy, (uint64_t)rbeg + pp, base);
+					int code = 4 | 8, lhs = hh, zc = sraw;                 /* linear gaps: every gap is "opened" at length 1 */
+					if(pp == 0 && rbeg == 0){ zc = rh - ub0[0] + sraw; lhs = ub0[0] + hh - rh; }
+					if(xx <= W * NL && hh == zc) code |= 1;
+					if(xx < W * NL && lhs == (int)u + gapo1 + gape1) code |= 2;
+					tl_codes[pp] = (uint8_t)code;
+				}
 				v[j] = sat8(hh - v[j]); us1[i * NL + j] = (int8_t)v[j];
 				v[j] = sat8(hh - u);
 				f[j] = sat8(sat8(hh + GapE) - u);
 			} else if(piecewise == 1){
 				e = sat8(es0[i * NL + j] + u);
 				hh = imax(e, z[j]); hh = imax(f[j], hh);
+				if(tl_codes){
+					const uint32_t pp = (uint32_t)j * W + i, xx = pp + tl_mov;
+					const int sraw = score_at(qy, (uint64_t)rbeg + pp, base);
+					int code = 0, lhs = hh, zc = sraw;
+					if(pp == 0 && rbeg == 0){ zc = rh - ub0[0] + sraw; lhs = ub0[0] + hh - rh; }
+					if(xx <= W * NL && hh == zc) code |= 1;
+					if(xx < W * NL && lhs == (int)u + (int)es0[i * NL + j]) code |= 2;
+					if(sat8(hh + GapOE) >= sat8(f[j] + GapE)) code |= 4;
+					if(imax(sat8(sat8(e + GapE) - hh), GapOE) == GapOE) code |= 8;
+					tl_codes[pp] = (uint8_t)code;
+				}
 				v[j] = sat8(hh - v[j]); us1[i * NL + j] = (int8_t)v[j];
 				v[j] = sat8(hh - u);
 				e = sat8(e + GapE); e = sat8(e - hh); e = imax(e, GapOE);
@@ -676,6 +708,157 @@ static long align_core(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint3
 		}
 	}
 	free(R.ups); free(R.eps); free(R.qps); free(R.ubs); free(R.begs); free(us0); free(es0); free(qs0);
+	if(res) *res = rs;
+	if(cig && cv.n > cap) return -cv.n;
+	return cv.n;
+}
+
+/* Traceback from the 4-bit codes alone (global mode): same decisions as backcal() above, every equality test replaced
+ * by the bit the forward pass recorded.  codes[(r + 1) * bw + p] = code of band cell p of row r; begs[r + 1] = band
+ * offset of row r (begs[0] = 0 for row -1).  Returns 0, or -1 where the literal traceback is needed (a scan leaves the
+ * band, or the situation in which the reference itself does not terminate). */
+static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t *codes, const int32_t *begs, uint32_t bw,
+		orc_result_t *rs, cigv_t *cv){
+	int prior_match = 0;
+	uint32_t cg = 0;
+	rs->qb = rs->qe; rs->qe++;
+	rs->tb = rs->te; rs->te++;
+	rs->mat = rs->mis = rs->ins = rs->del = rs->aln = 0;
+	for(;;){
+		int p, code, bt;
+		if(rs->qb < 0 || rs->tb < 0) break;
+		if(rs->qb == begs[rs->tb] && rs->qb) prior_match = 0;
+		p = rs->qb - begs[rs->tb + 1];                       /* position in row tb's own band */
+		if(p < 0 || p >= (int)bw) return -1;
+		code = codes[((size_t)rs->tb + 1) * bw + (size_t)p];
+		if(prior_match) bt = (code & 1) ? BT_M : (code & 2) ? BT_D : BT_I;
+		else bt = (code & 2) ? BT_D : (code & 1) ? BT_M : BT_I;
+		prior_match = 1;
+		if(bt == BT_M){
+			if(qseq[rs->qb] == tseq[rs->tb]) rs->mat++; else rs->mis++;
+			rs->qb--; rs->tb--; rs->aln++;
+			cg = cig_add(cv, cg, 0, 1);
+		} else if(bt == BT_I){
+			if(rs->qb <= 0){
+				cg = cig_add(cv, cg, 1, 1);
+				rs->qb--; rs->ins++; rs->aln++;
+			} else {
+				int sz, found = 0;
+				for(sz = 1; sz <= p; sz++){
+					if(codes[((size_t)rs->tb + 1) * bw + (size_t)(p - sz)] & 4){ found = 1; break; }
+				}
+				if(!found) return -1;
+				cg = cig_add(cv, cg, 1, (uint32_t)sz);
+				rs->qb -= sz; rs->ins += sz; rs->aln += sz;
+			}
+		} else {
+			/* deletion: walk up the column until the row whose stored e is a fresh opening */
+			int len = 1;
+			for(;;){
+				int r = rs->tb - len, pr;
+				if(r < -1) return -1;
+				if(r == -1){ if(rs->qb >= (int)bw) return -1; break; }   /* row -1 holds no vertical gap: the run opens there */
+				pr = rs->qb - begs[r + 1];
+				if(pr < 0 || pr >= (int)bw) return -1;
+				if(codes[((size_t)r + 1) * bw + (size_t)pr] & 8) break;
+				len++;
+			}
+			cg = cig_add(cv, cg, BT_D, (uint32_t)len);
+			rs->del += len; rs->aln += len;
+			rs->tb -= len;
+		}
+	}
+	{
+		uint32_t op = 0, sz = 0;
+		if(rs->qb >= 0){ op = 1; sz = (uint32_t)rs->qb + 1; rs->ins += sz; rs->qb = -1; }
+		else if(rs->tb >= 0){ op = 2; sz = (uint32_t)rs->tb + 1; rs->del += sz; rs->tb = -1; }
+		rs->aln += sz;
+		cg = cig_add(cv, cg, op, sz);
+		if(cg) cig_push(cv, cg);
+	}
+	rs->qb++; rs->tb++;
+	if(cv->buf){
+		long a = 0, b = (cv->n < cv->cap ? cv->n : cv->cap) - 1;
+		if(cv->n <= cv->cap){ while(a < b){ uint32_t w = cv->buf[a]; cv->buf[a] = cv->buf[b]; cv->buf[b] = w; a++; b--; } }
+	}
+	return 0;
+}
+
+/* global alignment through the compact path: forward pass recording 4-bit codes, traceback from the codes.
+ * Returns the CIGAR word count, ORC_ERR_TRACE when the compact traceback hands over to the literal one, ORC_ERR_INPUT
+ * for inputs outside its domain (piecewise 2, non-global modes). */
+long orc_align_pairwise_codes(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint32_t tlen,
+		uint32_t bandwidth, const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2,
+		orc_result_t *res, uint32_t *cig, long cap){
+	orc_query_t qy;
+	orc_result_t rs;
+	cigv_t cv;
+	uint32_t bw, W, i, rbeg = 0, mov = 0;
+	int pw, smax = -127, smin = 127, rh;
+	int8_t *rowbuf;           /* two rows (u, e) + moved scratch */
+	int32_t ubA[NL + 1], ubB[NL + 1], ub0[NL + 1], *begs;
+	uint8_t *codes;
+	memset(&rs, 0, sizeof(rs));
+	if(res) *res = rs;
+	if(qlen == 0 || tlen == 0) return ORC_ERR_INPUT;
+	bw = bandwidth ? bandwidth : qlen;
+	bw = (bw + NL - 1) / NL * NL;
+	W = bw / NL;
+	pw = orc_get_piecewise(gapo1, gape1, gapo2, gape2, (int)bw);
+	if(pw == 2) return ORC_ERR_INPUT;
+	for(i = 0; i < 16; i++){ smax = imax(smax, mtx[i]); smin = imin(smin, mtx[i]); }
+	rowbuf = (int8_t*)calloc((size_t)bw * 9, 1);
+	codes = (uint8_t*)calloc((size_t)bw * ((size_t)tlen + 1), 1);
+	begs = (int32_t*)calloc((size_t)tlen + 2, sizeof(int32_t));
+	{
+		int8_t *pu = rowbuf, *pe = rowbuf + bw, *pq = rowbuf + 2 * bw, *cu = rowbuf + 3 * bw, *ce = rowbuf + 4 * bw, *cq = rowbuf + 5 * bw;
+		int8_t *mu = rowbuf + 6 * bw, *me = rowbuf + 7 * bw, *mq = rowbuf + 8 * bw;
+		int32_t *pb = ubA, *cb = ubB;
+		qy.seq = q; qy.len = qlen; qy.mtx = mtx; qy.hpc = 0; qy.bonus = 0;
+		orc_row_init(pu, pe, pq, pb, ORC_MODE_GLOBAL, bw, smax, smin, gapo1, gape1, gapo2, gape2);
+		for(i = 0; i < tlen; i++){
+			int rbx;
+			int8_t *t8; int32_t *t32;
+			if(mov && rbeg + bw < qlen){
+				uint32_t room = qlen - (rbeg + bw);
+				if(mov > room) mov = room;
+				rbeg += mov;
+				rh = orc_getscore(pu, pb, W, mov - 1);
+			} else {
+				mov = 0;
+				if(rbeg) rh = ORC_SCORE_MIN;
+				else if(i == 0) rh = 0;
+				else rh = gapo1 + gape1 * (int)i;
+			}
+			orc_row_movx(mu, me, mq, ub0, pu, pe, pq, pb, W, mov, pw, smax, smin, gapo1, gape1, gapo2, gape2);
+			tl_codes = codes + ((size_t)i + 1) * bw; tl_mov = mov;
+			orc_row_cal(rbeg, tq[i], mu, me, mq, ub0, cu, ce, cq, cb, &qy, gapo1, gape1, gapo2, gape2, W, rh, pw);
+			tl_codes = NULL;
+			rbx = orc_band_mov(cb, W, i, rbeg, qlen);
+			{
+				int rbz = 2 * imax((int)(tlen / qlen), 1);
+				int rby = (int)((1.0 * i / tlen) * qlen);
+				uint32_t left = tlen - i - 1;
+				if((long long)rbeg + (long long)rbz * (long long)left + (long long)bw <= (long long)(uint32_t)(qlen + (uint32_t)rbz - 1)){
+					mov = 1 + ((uint32_t)(qlen - (rbeg + bw)) / (left > 1 ? left : 1));
+				} else if((int)rbeg < rby - (int)bw) mov = (uint32_t)(rbx + 1);
+				else if((int)rbeg > rby) mov = (uint32_t)imax(0, rbx - 1);
+				else mov = (uint32_t)rbx;
+			}
+			begs[i + 1] = (int32_t)rbeg;
+			t8 = pu; pu = cu; cu = t8; t8 = pe; pe = ce; ce = t8; t8 = pq; pq = cq; cq = t8;
+			t32 = pb; pb = cb; cb = t32;
+		}
+		if(qlen - 1 - rbeg >= bw){ free(rowbuf); free(codes); free(begs); return ORC_ERR_TRACE; }
+		rs.score = orc_getscore(pu, pb, W, qlen - 1 - rbeg);
+		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	}
+	cv.buf = cig; cv.n = 0; cv.cap = cig ? cap : 0;
+	{
+		int bad = backcal_codes(q, tq, codes, begs, bw, &rs, &cv);
+		free(rowbuf); free(codes); free(begs);
+		if(bad){ memset(&rs, 0, sizeof(rs)); if(res) *res = rs; return ORC_ERR_TRACE; }
+	}
 	if(res) *res = rs;
 	if(cig && cv.n > cap) return -cv.n;
 	return cv.n;

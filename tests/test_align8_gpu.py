@@ -141,3 +141,32 @@ def test_golden_align8_cases(ctx):
         for i, k in enumerate(ks):
             got = np.array([out[i][f] for f in out.dtype.names], dtype=np.int32)
             assert status[i] == 0 and np.array_equal(got, g["res_%d" % k]) and np.array_equal(cigs[i], g["cig_%d" % k]), (meta, k)
+
+
+def test_literal_row_record_path_still_matches(ctx, monkeypatch):
+    """global alignments normally take the compact 4-bit-code path; BSA_ALIGN8_LITERAL=1 keeps the row-record kernels
+    (the ones every other mode uses) on the same inputs"""
+    monkeypatch.setenv("BSA_ALIGN8_LITERAL", "1")
+    rng = np.random.default_rng(31337)
+    pairs = _mk_pairs(rng, 64, [1, 17, 100, 300, 1000, 2000])
+    for bw in (64, 128):
+        _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS["affine"])
+    _check(ctx, [S.synth_pair(k, 10000) for k in range(8)], S.MODE_GLOBAL, 128, SCORINGS["affine"])
+
+
+def test_compact_path_band_and_ratio_corners(ctx):
+    """length mismatches (rush-to-end steering, band jumps), tiny inputs and high divergence through the compact path"""
+    rng = np.random.default_rng(99)
+    pairs = []
+    for _ in range(120):
+        Lt = int(rng.choice([1, 2, 15, 16, 17, 33, 80, 200, 600]))
+        Lq = max(1, int(Lt * float(rng.choice([1.0, 0.5, 0.3, 2.0, 3.0, 1.1]))))
+        T = rng.integers(0, 4, size=Lt).astype(np.uint8)
+        Q = S.mutate(rng, T, float(rng.choice([0.0, 0.1, 0.4])))
+        Q = Q[:Lq] if Lq <= len(Q) else np.concatenate([Q, rng.integers(0, 4, size=Lq - len(Q)).astype(np.uint8)])
+        if len(Q) == 0:
+            Q = np.array([2], np.uint8)
+        pairs.append((Q, T))
+    for bw in (64, 128, 256):
+        for sc in ("affine", "paper", "linear"):
+            _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS[sc])
