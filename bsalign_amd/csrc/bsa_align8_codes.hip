@@ -6,8 +6,8 @@
 //   cell (qb, tb):  prior_match ? (M ? match : D ? delete : insert) : (D ? delete : M ? match : insert)
 //   insert:         length = distance to the nearest cell on the left whose R bit is set (bsalign.h:3798-3814)
 //   delete:         walk up the column until a row whose Od bit is set (bsalign.h:3730-3744)
-// oracle/bsalign_oracle.c backcal_codes() is the scalar statement of these rules; both are checked against the literal
-// backcal.  Whatever the bits cannot decide (a scan leaves the band; the cases in which the reference itself does not
+// The test-only scalar restatement states the same rules (tests/test_oracle_codes.py); both are checked against the
+// literal backcal.  Whatever the bits cannot decide (a scan leaves the band; the cases in which the reference itself does not
 // terminate) is reported as BSA_ST_TRACE.
 //
 // One pair per lane.  Rows are 64 bytes and are visited strictly upwards, and the band follows the path, so the

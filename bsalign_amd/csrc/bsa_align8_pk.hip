@@ -46,7 +46,7 @@ static __device__ __forceinline__ uint32_t pk_acc(uint32_t acc, uint32_t flag){
 
 // CODES = true: the compact traceback of the global mode.  Instead of the row records the kernel stores, per band
 // cell, the outcome of the four equality tests the reference's backcal would make there (bsa_common.h, "COMPACT
-// slot"; oracle/bsalign_oracle.c orc_align_pairwise_codes is the scalar statement of the same rules), computed from
+// slot"; the test-only scalar restatement states the same rules, tests/test_oracle_codes.py), computed from
 // the values the recurrence has in registers anyway:
 //   M  = h == S          D = h == e + u          R = h + gapoe >= f + gape          Od = e' == gapoe
 // with the reference's quirks at band position 0 (frame of ubegs[0], bsalign.h:3760-3771, 2632-2633) and beyond the
