@@ -2,24 +2,227 @@
 //
 // The forward kernel (k_align8_fwd_pk<W, PW, true>, bsa_align8_pk.hip) leaves, per target row, one code row of 16
 // lanes x CW dwords (bsa_common.h "COMPACT slot"): for every band cell the outcome of the equality tests the
-// reference's backcal would make there (bsalign.h:3667-3852).  This kernel makes the same walk from those bits alone:
+// reference's backcal would make there (bsalign.h:3667-3852).  These kernels make the same walk from those bits alone:
 //   cell (qb, tb):  prior_match ? (M ? match : D ? delete : insert) : (D ? delete : M ? match : insert)
 //   insert:         length = distance to the nearest cell on the left whose R bit is set (bsalign.h:3798-3814)
 //   delete:         walk up the column until a row whose Od bit is set (bsalign.h:3730-3744)
 // The test-only scalar restatement states the same rules (tests/test_oracle_codes.py); both are checked against the
-// literal backcal.  Whatever the bits cannot decide (a scan leaves the band; the cases in which the reference itself does not
-// terminate) is reported as BSA_ST_TRACE.
+// literal backcal.  Whatever the bits cannot decide (a scan leaves the band; the cases in which the reference itself
+// does not terminate) is reported as BSA_ST_TRACE.
 //
-// One pair per lane.  Rows are 64 bytes and are visited strictly upwards, and the band follows the path, so the
-// dword a lane needs from the next rows is almost always the same block's: the lane keeps the dwords of the next
-// RING rows of its current block in registers, requested RING steps ahead (loads of a wave return in order, so the
-// request stream simply runs ahead of the walk); only a block change costs a memory round trip.
+// One pair per lane, 64 pairs per wave: the walk is ~50 instructions per step, so a wave64 of 64 walks is the cheap
+// way to issue them -- provided NO step waits for memory, because a wave waits whenever any of its 64 lanes does.
+// k_align8_trace_codes_pf therefore takes everything from register windows that were requested a whole window
+// earlier: per row three code dwords (the path's block and its neighbours, so drifting across a block boundary costs
+// nothing) and the band offset, 8 rows per window, one window being walked and the next one in flight; the two
+// sequences as 16-byte windows handled the same way.  Deletion runs are steps of the same loop (one row per
+// iteration), not an inner loop with its own loads.  A shift register was tried first and does not work: moving a
+// register one step after its load was issued waits for that load.
 #include "bsa_common.h"
 
-#define CODE_RING 8
+#define CODE_WIN 8
 
 template<int W>
-__global__ void __launch_bounds__(64) k_align8_trace_codes(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
+__global__ void __launch_bounds__(64) k_align8_trace_codes_pf(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
+	static_assert(W == 4 || W == 8, "one code dword per block");
+	constexpr uint32_t RB = 64u;
+	constexpr uint32_t FULL = (1u << W) - 1u;
+	constexpr int bw = W * 16;
+	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	const bool live = g < a.count;
+	const uint32_t ppos = a.first + (live ? g : 0u);
+	const uint32_t pair = a.order[ppos];
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	const bool skip = !live || a.status[pair] != 0u;
+	const uint32_t qlen = a.qlen[pair], tlen = skip ? 1u : a.tlen[pair];
+	const uint8_t *qseq = a.qst + a.qpoff[pair];
+	const uint8_t *tseq = a.tst + a.tpoff[pair];
+	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
+	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(a.tlen[pair]);
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)a.tlen[pair] + 1) * RB);
+	uint32_t ncig = 0;
+	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
+	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
+		if(op == (cg & 0xf)) return cg + (sz << 4);
+		if(cg) cig_push(cg);
+		return (sz << 4) | op;
+	};
+	// ---- row windows: rows wtop - k, k = 0..7 (cur) and wtop - 8 - k (nxt); three dwords from block wbase / nbase
+	uint32_t c0[CODE_WIN], c1[CODE_WIN], c2[CODE_WIN], n0[CODE_WIN], n1[CODE_WIN], n2[CODE_WIN];
+	int cb[CODE_WIN], nb[CODE_WIN];
+	int wtop = 0; uint32_t wbase = 0, nbase = 0;
+	auto load_rows = [&](uint32_t (&x0)[CODE_WIN], uint32_t (&x1)[CODE_WIN], uint32_t (&x2)[CODE_WIN], int (&xb)[CODE_WIN], int top, uint32_t base){
+#pragma unroll
+		for(int k = 0; k < CODE_WIN; k++){
+			const int rr = max(top - k, 0);
+			const uint32_t *rp = (const uint32_t*)(rows + (size_t)rr * RB) + base;
+			x0[k] = rp[0]; x1[k] = rp[1]; x2[k] = rp[2];
+			xb[k] = begs[max(top - k, -1) + 1];
+		}
+	};
+	auto sel = [&](const auto (&arr)[CODE_WIN], int idx){
+		auto v = arr[0];
+#pragma unroll
+		for(int k = 1; k < CODE_WIN; k++) v = (idx == k) ? arr[k] : v;
+		return v;
+	};
+	auto base_for = [&](uint32_t y) -> uint32_t { return (y == 0u) ? 0u : ((y >= 14u) ? 13u : y - 1u); };
+	// ---- sequence windows: 16 bases each, aligned chunks (the staged sequences start 16-byte aligned)
+	uint4 tw = {0, 0, 0, 0}, twn = {0, 0, 0, 0}, qw = {0, 0, 0, 0}, qwn = {0, 0, 0, 0};
+	int tch = -1000, qch = -1000;                 // chunk index held in tw / qw; twn / qwn hold chunk - 1
+	auto chunk = [&](const uint8_t *s, int ch) -> uint4 { return *(const uint4*)(s + (size_t)max(ch, 0) * 16u); };
+	auto base_in = [&](const uint4 &w, int idx) -> int {
+		const uint32_t d = (idx & 12) == 0 ? w.x : (idx & 12) == 4 ? w.y : (idx & 12) == 8 ? w.z : w.w;
+		return (int)((d >> (8 * (idx & 3))) & 0xffu);
+	};
+	auto tbase_at = [&](int i) -> int {
+		const int ch = i >> 4;
+		if(ch != tch){
+			if(ch == tch - 1){ tw = twn; tch = ch; twn = chunk(tseq, ch - 1); }
+			else { tw = chunk(tseq, ch); twn = chunk(tseq, ch - 1); tch = ch; }
+		}
+		return base_in(tw, i & 15);
+	};
+	auto qbase_at = [&](int i) -> int {
+		const int ch = i >> 4;
+		if(ch != qch){
+			if(ch == qch - 1){ qw = qwn; qch = ch; qwn = chunk(qseq, ch - 1); }
+			else { qw = chunk(qseq, ch); qwn = chunk(qseq, ch - 1); qch = ch; }
+		}
+		return base_in(qw, i & 15);
+	};
+	bool bad = false, done = skip;
+	if(!skip){
+		const int score = begs[tlen + 1];
+		if(score == (int)0x80000000u) bad = true;                  // band never reached the query end (bsalign.h:4034)
+		rs.score = score;
+		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+		rs.qb = rs.qe; rs.qe++;
+		rs.tb = rs.te; rs.te++;
+		const int lastbeg = begs[tlen];
+		const int p0 = max(min((int)qlen - 1 - lastbeg, bw - 1), 0);
+		wtop = rs.tb; wbase = base_for((uint32_t)p0 / W); nbase = wbase;
+		load_rows(c0, c1, c2, cb, wtop, wbase);
+		load_rows(n0, n1, n2, nb, wtop - CODE_WIN, nbase);
+	}
+	int prior_match = 0, dlen = 0;                // dlen > 0: inside a deletion run that started dlen rows below
+	uint32_t cg = 0;
+	while(__any(!done)){
+		if(done) continue;
+		if(bad || rs.qb < 0 || rs.tb < 0){
+			if(dlen && !bad){
+				// the run reached row -1: it opens there (no vertical gap can come from above the matrix)
+				if(rs.qb >= bw) bad = true;
+				else { cg = cig_add(cg, 2, (uint32_t)dlen); rs.del += dlen; rs.aln += dlen; dlen = 0; }
+			}
+			done = true;
+			continue;
+		}
+		// ---- bring row tb into the current window
+		if(rs.tb <= wtop - CODE_WIN){
+			if(rs.tb > wtop - 2 * CODE_WIN){
+#pragma unroll
+				for(int k = 0; k < CODE_WIN; k++){ c0[k] = n0[k]; c1[k] = n1[k]; c2[k] = n2[k]; cb[k] = nb[k]; }
+				wtop -= CODE_WIN; wbase = nbase;
+			} else {                                      // long deletion: start over at row tb
+				wtop = rs.tb;
+				load_rows(c0, c1, c2, cb, wtop, wbase);
+			}
+			// request the window above; aim it at the block the path is in now
+			{
+				const int pc = rs.qb - sel(cb, wtop - rs.tb);
+				nbase = base_for((uint32_t)max(min(pc, bw - 1), 0) / W);
+				load_rows(n0, n1, n2, nb, wtop - CODE_WIN, nbase);
+			}
+		}
+		const int idx = wtop - rs.tb;
+		const int beg_c = sel(cb, idx);
+		const int beg_p = (idx + 1 < CODE_WIN) ? sel(cb, idx + 1) : nb[0];
+		const int p = rs.qb - beg_c;
+		if(p < 0 || p >= bw){ bad = true; continue; }
+		const uint32_t y = (uint32_t)p / W, k = (uint32_t)p % W, bit = 1u << (W - 1 - k);
+		if(y < wbase || y > wbase + 2u){                  // the path left the three blocks the window holds (rare)
+			wbase = base_for(y); wtop = rs.tb;
+			load_rows(c0, c1, c2, cb, wtop, wbase);
+			nbase = wbase;
+			load_rows(n0, n1, n2, nb, wtop - CODE_WIN, nbase);
+			continue;
+		}
+		const uint32_t off = y - wbase;
+		const uint32_t w0 = sel(c0, idx), w1 = sel(c1, idx), w2 = sel(c2, idx);
+		const uint32_t wc = off == 0u ? w0 : off == 1u ? w1 : w2;
+		const uint32_t pm = wc & FULL, pd = (wc >> W) & FULL, pr = (wc >> (2 * W)) & FULL, po = (wc >> (3 * W)) & FULL;
+		if(dlen){
+			// deletion run (bsalign.h:3730-3744): this row ends it if its stored e is a fresh opening
+			if(po & bit){
+				cg = cig_add(cg, 2, (uint32_t)dlen);
+				rs.del += dlen; rs.aln += dlen;
+				dlen = 0;
+				// fall through: the cell (qb, tb) is decided in this same iteration, as the reference does
+			} else { dlen++; rs.tb--; continue; }
+		}
+		if(rs.qb == beg_p && rs.qb) prior_match = 0;                // bsalign.h:3761-3764
+		const bool fm = (pm & bit) != 0u, fd = (pd & bit) != 0u;
+		int bt;                                                       // 0 M, 1 I, 2 D
+		if(prior_match) bt = fm ? 0 : fd ? 2 : 1;
+		else bt = fd ? 2 : fm ? 0 : 1;
+		prior_match = 1;
+		if(bt == 0){
+			const int qbase = qbase_at(rs.qb), tbase = tbase_at(rs.tb);
+			if(qbase == tbase) rs.mat++; else rs.mis++;
+			rs.qb--; rs.aln++; rs.tb--;
+			cg = cig_add(cg, 0, 1);
+		} else if(bt == 1){
+			if(rs.qb <= 0){
+				cg = cig_add(cg, 1, 1);
+				rs.qb--; rs.ins++; rs.aln++;
+			} else {
+				// nearest cell to the left with R set: cells left of k are the bits above `bit`
+				int sz = 0;
+				const uint32_t cand = pr & ~((bit << 1) - 1u);
+				if(cand) sz = (int)__builtin_ctz(cand) - (int)(W - 1 - k);
+				else {
+					int left = (int)k;
+					for(int yy = (int)y - 1; yy >= 0 && sz == 0; yy--){
+						uint32_t wl;
+						if(yy >= (int)wbase) wl = ((uint32_t)yy - wbase == 0u) ? w0 : w1;       // still inside the window
+						else wl = ((const uint32_t*)(rows + (size_t)rs.tb * RB))[yy];
+						const uint32_t r2 = (wl >> (2 * W)) & FULL;
+						if(r2) sz = left + 1 + (int)__builtin_ctz(r2);
+						else left += W;
+					}
+					if(sz == 0){ bad = true; continue; }              // the reference's scan finds no length either: it never terminates
+				}
+				cg = cig_add(cg, 1, (uint32_t)sz);
+				rs.qb -= sz; rs.ins += sz; rs.aln += sz;
+			}
+		} else {
+			dlen = 1; rs.tb--;                                           // the rows above decide the length
+		}
+	}
+	if(skip){ if(live){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
+	if(!bad){
+		uint32_t op = 0, sz = 0;      // global: leading clip becomes I / D (bsalign.h:3827-3842)
+		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+		rs.aln += (int)sz;
+		cg = cig_add(cg, op, sz);
+		if(cg) cig_push(cg);
+		rs.qb++; rs.tb++;
+	}
+	if(bad){
+		atomicOr(&a.status[pair], BSA_ST_TRACE);
+		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+		ncig = 0;
+	}
+	out[pair] = rs;
+	cig_cnt[ppos] = ncig;
+}
+
+// plain version: every access is a load (W = 16, and the reference point for the prefetching kernel)
+template<int W>
+__global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
 	constexpr uint32_t CW = (W >= 8) ? (uint32_t)W / 8u : 1u, RB = 64u * CW;
 	constexpr uint32_t FULL = (W == 16) ? 0xFFFFu : ((1u << W) - 1u);
 	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
@@ -65,31 +268,6 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes(const Align8Args a, b
 		const uint32_t *rp = (const uint32_t*)(rows + (size_t)r * RB) + y * CW;
 		return unpack(rp[0], (CW > 1) ? rp[CW - 1] : 0u);
 	};
-	// ring of the next CODE_RING rows (r = ring_top, ring_top - 1, ...) of block ring_y
-	uint32_t ring0[CODE_RING], ring1[CODE_RING];
-	int ring_top = -1000; uint32_t ring_y = 0xFFFFu;
-	auto ring_fill = [&](int r, uint32_t y){
-#pragma unroll
-		for(int k = 0; k < CODE_RING; k++){
-			const int rr = max(r - k, 0);
-			const uint32_t *rp = (const uint32_t*)(rows + (size_t)rr * RB) + y * CW;
-			ring0[k] = rp[0]; ring1[k] = (CW > 1) ? rp[CW - 1] : 0u;
-		}
-		ring_top = r; ring_y = y;
-	};
-	auto ring_get = [&](int r, uint32_t y) -> Code {          // r must be ring_top or ring_top - 1 for the fast path
-		if(y != ring_y || r > ring_top || r < ring_top - 1) ring_fill(r, y);
-		if(r == ring_top - 1){
-			// advance by one row: drop the top entry, request the row that enters at the bottom
-#pragma unroll
-			for(int k = 0; k + 1 < CODE_RING; k++){ ring0[k] = ring0[k + 1]; ring1[k] = ring1[k + 1]; }
-			const int rr = max(r - (CODE_RING - 1), 0);
-			const uint32_t *rp = (const uint32_t*)(rows + (size_t)rr * RB) + y * CW;
-			ring0[CODE_RING - 1] = rp[0]; ring1[CODE_RING - 1] = (CW > 1) ? rp[CW - 1] : 0u;
-			ring_top = r;
-		}
-		return unpack(ring0[0], ring1[0]);
-	};
 	bool bad = false;
 	const int score = begs[tlen + 1];
 	if(score == (int)0x80000000u) bad = true;                      // band never reached the query end (bsalign.h:4034)
@@ -108,7 +286,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes(const Align8Args a, b
 		const int p = rs.qb - beg_c;
 		if(p < 0 || p >= bw){ bad = true; break; }
 		const uint32_t y = (uint32_t)p / W, k = (uint32_t)p % W, bit = 1u << (W - 1 - k);
-		const Code c = ring_get(rs.tb, y);
+		const Code c = load_code(rs.tb, y);
 		const bool fm = (c.m & bit) != 0u, fd = (c.d & bit) != 0u;
 		int bt;                                                       // 0 M, 1 I, 2 D
 		if(prior_match) bt = fm ? 0 : fd ? 2 : 1;
@@ -181,12 +359,19 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes(const Align8Args a, b
 
 hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	(void)pw;
+	if(a.count == 0) return hipSuccess;
+	static const bool simple = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
 	const uint32_t blocks = (a.count + 63u) / 64u;
-	if(blocks == 0) return hipSuccess;
 	switch(a.bw / 16){
-		case 4:  hipLaunchKernelGGL((k_align8_trace_codes<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
-		case 8:  hipLaunchKernelGGL((k_align8_trace_codes<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
-		case 16: hipLaunchKernelGGL((k_align8_trace_codes<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
+		case 4:
+			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			else hipLaunchKernelGGL((k_align8_trace_codes_pf<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			break;
+		case 8:
+			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			else hipLaunchKernelGGL((k_align8_trace_codes_pf<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			break;
+		case 16: hipLaunchKernelGGL((k_align8_trace_codes_simple<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
 		default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError();
