@@ -220,6 +220,248 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_pf(const Align8Args a
 	cig_cnt[ppos] = ncig;
 }
 
+// ---- the stall-free walker --------------------------------------------------------------------------------------
+// A wave waits (s_waitcnt is a counter, not a per-register flag) whenever ANY lane uses an older load while another
+// lane has just issued a new one, so with 64 desynchronised walks per wave "prefetch into registers" still stalls on
+// almost every step (k_align8_trace_codes_pf above runs no faster than the plain kernel).  Here all lanes fetch at the
+// SAME iterations: every CODE_SVC steps each lane requests the 8 rows above what it already holds, and the rows
+// requested at the previous service point -- long since arrived -- are filed into the lane's own LDS ring, from
+// where the walk reads them with dynamic indexing and no memory wait.  Ring entry (16 bytes) of row r:
+//   x, y, z = code dwords of blocks base .. base+2 (the path's block and its neighbours when the row was requested)
+//   w       = band offset of the row | target base << 26 | base << 28
+// The query is held as three 16-byte chunks refreshed on the same schedule.  A lane that outruns its ring (a long
+// insertion or deletion) simply idles until the next service point.
+#define CODE_SVC 8
+#define CODE_RING_ROWS 32
+
+// LPW = pairs (active lanes) per wave: the walk is a chain of dependent ALU ops, so a SIMD needs several waves to keep
+// issuing; fewer lanes per wave = more waves for the same batch
+template<int W, int LPW>
+__global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
+	static_assert(W == 4 || W == 8, "one code dword per block");
+	constexpr uint32_t RB = 64u;
+	constexpr uint32_t FULL = (1u << W) - 1u;
+	constexpr int bw = W * 16;
+	__shared__ uint4 ring[CODE_RING_ROWS * LPW];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t g = blockIdx.x * (uint32_t)LPW + lane;
+	const bool live = lane < (uint32_t)LPW && g < a.count;
+	const uint32_t ppos = a.first + (live ? g : 0u);
+	const uint32_t pair = a.order[ppos];
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	const bool skip = !live || a.status[pair] != 0u;
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint8_t *qseq = a.qst + a.qpoff[pair];
+	const uint8_t *tseq = a.tst + a.tpoff[pair];
+	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
+	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)tlen + 1) * RB);
+	uint32_t ncig = 0;
+	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
+	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
+		if(op == (cg & 0xf)) return cg + (sz << 4);
+		if(cg) cig_push(cg);
+		return (sz << 4) | op;
+	};
+	auto base_for = [&](uint32_t y) -> uint32_t { return (y == 0u) ? 0u : ((y >= 14u) ? 13u : y - 1u); };
+	auto slot = [&](int r) -> uint4& { return ring[((uint32_t)r & (CODE_RING_ROWS - 1u)) * (uint32_t)LPW + (live ? lane : 0u)]; };
+	// rows requested at the last service point, still in registers
+	uint32_t p0[CODE_SVC], p1[CODE_SVC], p2[CODE_SVC], p3[CODE_SVC];
+	int pend_top = 0; bool pend = false;
+	int have_lo = 0x7FFFFFFF;                     // lowest row filed in the ring (rows have_lo .. are readable)
+	uint4 qc0 = {0, 0, 0, 0}, qc1 = {0, 0, 0, 0}, qc2 = {0, 0, 0, 0}, qp0 = {0, 0, 0, 0}, qp1 = {0, 0, 0, 0}, qp2 = {0, 0, 0, 0};
+	int qc_ch = -1000, qp_ch = -1000;             // qc0 = chunk qc_ch, qc1 = qc_ch - 1, qc2 = qc_ch - 2
+	auto request = [&](int top, uint32_t base){
+#pragma unroll
+		for(int k = 0; k < CODE_SVC; k++){
+			const int rr = max(top - k, 0);
+			const uint32_t *rp = (const uint32_t*)(rows + (size_t)rr * RB) + base;
+			p0[k] = rp[0]; p1[k] = rp[1]; p2[k] = rp[2];
+			p3[k] = (uint32_t)begs[rr + 1] | ((uint32_t)tseq[rr] << 26) | (base << 28);
+		}
+		pend_top = top; pend = true;
+	};
+	auto file = [&](){
+		if(pend){
+#pragma unroll
+			for(int k = 0; k < CODE_SVC; k++){
+				if(pend_top - k >= 0){ uint4 e; e.x = p0[k]; e.y = p1[k]; e.z = p2[k]; e.w = p3[k]; slot(pend_top - k) = e; }
+			}
+			have_lo = max(pend_top - (CODE_SVC - 1), 0);
+			pend = false;
+		}
+	};
+	auto chunk = [&](int ch) -> uint4 { return *(const uint4*)(qseq + (size_t)max(ch, 0) * 16u); };
+	auto base_in = [&](const uint4 &w, int idx) -> int {
+		const uint32_t d = (idx & 12) == 0 ? w.x : (idx & 12) == 4 ? w.y : (idx & 12) == 8 ? w.z : w.w;
+		return (int)((d >> (8 * (idx & 3))) & 0xffu);
+	};
+	bool bad = false, done = skip;
+	uint32_t cury = 0;
+	if(!skip){
+		const int score = begs[tlen + 1];
+		if(score == (int)0x80000000u) bad = true;                  // band never reached the query end (bsalign.h:4034)
+		if(qlen >= (1u << 26)) bad = true;                          // band offsets are kept in 26 bits here
+		rs.score = score;
+		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+		rs.qb = rs.qe; rs.qe++;
+		rs.tb = rs.te; rs.te++;
+		const int lastbeg = begs[tlen];
+		cury = (uint32_t)max(min((int)qlen - 1 - lastbeg, bw - 1), 0) / W;
+		// prologue: two windows, filed immediately
+		request(rs.tb, base_for(cury)); file();
+		{ const int lo = have_lo; if(lo > 0){ request(lo - 1, base_for(cury)); file(); } }
+		qc_ch = rs.qb >> 4; qc0 = chunk(qc_ch); qc1 = chunk(qc_ch - 1); qc2 = chunk(qc_ch - 2);
+	}
+	int prior_match = 0, dlen = 0;
+	uint32_t cg = 0;
+	// Two kinds of iteration.  Seven out of eight handle only the common step -- a match / mismatch cell reached after
+	// another cell (prior_match set, M flag set): ~40 instructions.  Everything else (insertions, deletions, band start,
+	// window misses, termination) is handled by the general step, which all lanes run together at the service point; a
+	// lane that needs it waits for that iteration.  The 16 walks of a wave diverge constantly, so running the general
+	// step on every iteration would cost its full instruction count every time (measured: 370 instructions per step).
+	bool slow = true;                                 // this lane needs the general step
+	for(uint32_t it = 0; __any(!done); it++){
+		const bool svc = (it & (CODE_SVC - 1u)) == 0u;
+		if(svc){
+			// ---- service point (all lanes together): file what was requested last time, request what comes next
+			file();
+			if(qp_ch != -1000){ qc0 = qp0; qc1 = qp1; qc2 = qp2; qc_ch = qp_ch; qp_ch = -1000; }
+			if(!done){
+				if(have_lo > 0 && rs.tb - have_lo + 1 < 3 * CODE_SVC) request(have_lo - 1, base_for(cury));   // ring holds 32 rows: at most 23 live + 8 new
+				if(rs.qb >= 0 && (rs.qb >> 4) != qc_ch){ qp_ch = rs.qb >> 4; qp0 = chunk(qp_ch); qp1 = chunk(qp_ch - 1); qp2 = chunk(qp_ch - 2); }
+			}
+		}
+		if(done) continue;
+		if(!svc){
+			// ---- common step: a cell inside the ring and the window, decided from one ring entry
+			if(slow) continue;
+			if(rs.qb <= 0 || rs.tb <= 0 || rs.tb - 1 < have_lo){ slow = true; continue; }
+			const uint4 e = slot(rs.tb);
+			const int beg_c = (int)(e.w & 0x3FFFFFFu), beg_p = (int)(slot(rs.tb - 1).w & 0x3FFFFFFu);
+			const uint32_t wbase = e.w >> 28;
+			const int p = rs.qb - beg_c;
+			const uint32_t y = (uint32_t)p / W, off = y - wbase, kk = (uint32_t)p % W, bit = 1u << (W - 1 - kk);
+			const int dch = qc_ch - (rs.qb >> 4);
+			if((uint32_t)p >= (uint32_t)bw || off > 2u || (uint32_t)dch > 2u){ slow = true; continue; }
+			const uint32_t wc = off == 0u ? e.x : off == 1u ? e.y : e.z;
+			cury = y;
+			if(dlen){
+				if((wc >> (3 * W)) & bit){ cg = cig_add(cg, 2, (uint32_t)dlen); rs.del += dlen; rs.aln += dlen; dlen = 0; }
+				else { dlen++; rs.tb--; continue; }
+			}
+			const bool pmatch = (rs.qb != beg_p) && prior_match;
+			const bool fm = (wc & bit) != 0u, fd = ((wc >> W) & bit) != 0u;
+			if(!fm && !fd && !(((wc >> (2 * W)) & FULL) & ~((bit << 1) - 1u))){ slow = true; continue; }   // insertion crossing a block boundary: general step
+			prior_match = 1;
+			if(fm && (pmatch || !fd)){
+				const int qbase = base_in(dch == 0 ? qc0 : dch == 1 ? qc1 : qc2, rs.qb & 15);
+				if(qbase == (int)((e.w >> 26) & 3u)) rs.mat++; else rs.mis++;
+				rs.qb--; rs.aln++; rs.tb--;
+				cg = cig_add(cg, 0, 1);
+			} else if(fd){
+				dlen = 1; rs.tb--;
+			} else {
+				const uint32_t cand = ((wc >> (2 * W)) & FULL) & ~((bit << 1) - 1u);
+				const int sz = (int)__builtin_ctz(cand) - (int)(W - 1 - kk);
+				cg = cig_add(cg, 1, (uint32_t)sz);
+				rs.qb -= sz; rs.ins += sz; rs.aln += sz;
+			}
+			continue;
+		}
+		// ---- general step (service iterations only)
+		slow = false;
+		if(bad || rs.qb < 0 || rs.tb < 0){
+			if(dlen && !bad){
+				if(rs.qb >= bw) bad = true;                              // the run reached row -1 outside its band
+				else { cg = cig_add(cg, 2, (uint32_t)dlen); rs.del += dlen; rs.aln += dlen; dlen = 0; }
+			}
+			done = true;
+			continue;
+		}
+		if(rs.tb < have_lo || (rs.tb > 0 && rs.tb - 1 < have_lo)){ slow = true; continue; }     // outran the ring: wait for the next service point
+		const uint4 e = slot(rs.tb);
+		const int beg_c = (int)(e.w & 0x3FFFFFFu);
+		const int beg_p = rs.tb > 0 ? (int)(slot(rs.tb - 1).w & 0x3FFFFFFu) : 0;
+		const uint32_t wbase = e.w >> 28;
+		const int p = rs.qb - beg_c;
+		if(p < 0 || p >= bw){ bad = true; slow = true; continue; }
+		const uint32_t y = (uint32_t)p / W, k = (uint32_t)p % W, bit = 1u << (W - 1 - k);
+		cury = y;
+		uint32_t wc;
+		if(y >= wbase && y <= wbase + 2u){ const uint32_t off = y - wbase; wc = off == 0u ? e.x : off == 1u ? e.y : e.z; }
+		else wc = ((const uint32_t*)(rows + (size_t)rs.tb * RB))[y];           // drifted two blocks inside one ring: plain load
+		const uint32_t pm = wc & FULL, pd = (wc >> W) & FULL, pr = (wc >> (2 * W)) & FULL, po = (wc >> (3 * W)) & FULL;
+		if(dlen){
+			// deletion run (bsalign.h:3730-3744): this row ends it if its stored e is a fresh opening
+			if(po & bit){
+				cg = cig_add(cg, 2, (uint32_t)dlen);
+				rs.del += dlen; rs.aln += dlen;
+				dlen = 0;
+			} else { dlen++; rs.tb--; slow = true; continue; }
+		}
+		const bool pmatch = !(rs.qb == beg_p && rs.qb) && prior_match;      // bsalign.h:3761-3764
+		const bool fm = (pm & bit) != 0u, fd = (pd & bit) != 0u;
+		int bt;                                                       // 0 M, 1 I, 2 D
+		if(pmatch) bt = fm ? 0 : fd ? 2 : 1;
+		else bt = fd ? 2 : fm ? 0 : 1;
+		if(bt == 0){
+			const int ch = rs.qb >> 4, dch = qc_ch - ch;
+			if(dch < 0 || dch > 2){ slow = true; continue; }           // query chunk not here yet (prior_match untouched)
+			const int qbase = base_in(dch == 0 ? qc0 : dch == 1 ? qc1 : qc2, rs.qb & 15);
+			const int tbase = (int)((e.w >> 26) & 3u);
+			if(qbase == tbase) rs.mat++; else rs.mis++;
+			rs.qb--; rs.aln++; rs.tb--;
+			cg = cig_add(cg, 0, 1);
+		} else if(bt == 1){
+			if(rs.qb <= 0){
+				cg = cig_add(cg, 1, 1);
+				rs.qb--; rs.ins++; rs.aln++;
+			} else {
+				int sz = 0;
+				const uint32_t cand = pr & ~((bit << 1) - 1u);
+				if(cand) sz = (int)__builtin_ctz(cand) - (int)(W - 1 - k);
+				else {
+					int left = (int)k;
+					for(int yy = (int)y - 1; yy >= 0 && sz == 0; yy--){
+						uint32_t wl;
+						if(yy >= (int)wbase && yy <= (int)wbase + 2) wl = ((uint32_t)yy == wbase) ? e.x : ((uint32_t)yy == wbase + 1u) ? e.y : e.z;
+						else wl = ((const uint32_t*)(rows + (size_t)rs.tb * RB))[yy];
+						const uint32_t r2 = (wl >> (2 * W)) & FULL;
+						if(r2) sz = left + 1 + (int)__builtin_ctz(r2);
+						else left += W;
+					}
+					if(sz == 0){ bad = true; slow = true; continue; }  // the reference's scan finds no length either: it never terminates
+				}
+				cg = cig_add(cg, 1, (uint32_t)sz);
+				rs.qb -= sz; rs.ins += sz; rs.aln += sz;
+			}
+		} else {
+			dlen = 1; rs.tb--; slow = true;                              // the rows above decide the length, at the next general steps
+		}
+		prior_match = 1;
+		if(rs.qb < 0 || rs.tb < 0) slow = true;                          // termination is a general step
+	}
+	if(skip){ if(live){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
+	if(!bad){
+		uint32_t op = 0, sz = 0;      // global: leading clip becomes I / D (bsalign.h:3827-3842)
+		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+		rs.aln += (int)sz;
+		cg = cig_add(cg, op, sz);
+		if(cg) cig_push(cg);
+		rs.qb++; rs.tb++;
+	}
+	if(bad){
+		atomicOr(&a.status[pair], BSA_ST_TRACE);
+		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+		ncig = 0;
+	}
+	out[pair] = rs;
+	cig_cnt[ppos] = ncig;
+}
+
 // plain version: every access is a load (W = 16, and the reference point for the prefetching kernel)
 template<int W>
 __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
@@ -357,19 +599,27 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 	cig_cnt[ppos] = ncig;
 }
 
-hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
+hipError_t bsa_launch_align8_trace_codes(const Align8Args &a_in, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	(void)pw;
-	if(a.count == 0) return hipSuccess;
-	static const bool simple = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
+	if(a_in.count == 0) return hipSuccess;
+	const Align8Args &a = a_in;
+	// BSA_ALIGN8_TRACE_SIMPLE=1: plain kernel, =2: register-window kernel (both kept as reference points)
+	static const int variant = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e ? atoi(e) : 0; }();
+	const bool simple = variant == 1;
 	const uint32_t blocks = (a.count + 63u) / 64u;
 	switch(a.bw / 16){
 		case 4:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			else hipLaunchKernelGGL((k_align8_trace_codes_pf<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			else if(variant == 2) hipLaunchKernelGGL((k_align8_trace_codes_pf<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			else hipLaunchKernelGGL((k_align8_trace_codes_lds<4, 32>), dim3((a.count + 31u) / 32u), dim3(64), 0, st, a, out, cig_cnt);
 			break;
 		case 8:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			else hipLaunchKernelGGL((k_align8_trace_codes_pf<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			else if(variant == 2) hipLaunchKernelGGL((k_align8_trace_codes_pf<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			// 32 pairs per wave measured best on MI355X for 100 k pairs (ms per launch: 64 -> 46, 32 -> 34.9, 16 -> 35.7, 8 -> 57):
+			// the kernel is bound by instruction issue (242 instructions per step and wave, SQ counters) at few lanes per
+			// wave and by the latency of its own dependent chain at many
+			else hipLaunchKernelGGL((k_align8_trace_codes_lds<8, 32>), dim3((a.count + 31u) / 32u), dim3(64), 0, st, a, out, cig_cnt);
 			break;
 		case 16: hipLaunchKernelGGL((k_align8_trace_codes_simple<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
 		default: return hipErrorInvalidValue;
