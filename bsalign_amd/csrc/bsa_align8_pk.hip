@@ -426,36 +426,59 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			htail = (PW == 0) ? h : (PW == 1) ? pk_subs(h, GOE) : pk_subs(h, GQP);
 		}
 		if constexpr (CODES){
-			// ---- assemble and store the code row of both pairs
+			// ---- assemble and store the code row of both pairs (planes stay packed: pair A low half, pair B high half)
 			constexpr uint32_t FULL = (W == 16) ? 0xFFFFu : ((1u << W) - 1u);
+			if constexpr (PW == 0){ accR = FULL * 0x00010001u; accO = FULL * 0x00010001u; }
+			// band position 0 of a band that starts at query column 0: backcal compares in the frame of the boundary
+			// column (bsalign.h:3763-3767) -- 32-bit arithmetic on ubegs[0], rh and the raw score.  Only the first rows.
+			if(__any(rbeg[0] == 0u || rbeg[1] == 0u)){
 #pragma unroll
-			for(int hf = 0; hf < 2; hf++){
-				uint32_t pm = (accM >> (16 * hf)) & 0xFFFFu, pd = (accD >> (16 * hf)) & 0xFFFFu;
-				uint32_t pr = (PW == 0) ? FULL : ((accR >> (16 * hf)) & 0xFFFFu), po = (PW == 0) ? FULL : ((accO >> (16 * hf)) & 0xFFFFu);
-				// band position 0 of a band that starts at query column 0: backcal compares in the frame of the boundary
-				// column (bsalign.h:3763-3767) -- 32-bit arithmetic on ubegs[0], rh and the raw score
-				if(j == 0 && rbeg[hf] == 0u){
-					const int hh0 = pk_get(hfirst, hf), s0 = pk_get(Sv[0], hf), uu0 = pk_get(u0_old, hf);
-					const int ee0 = (PW == 0) ? (gapo1 + gape1) : pk_get(e0_old, hf);
-					const bool m0 = hh0 == rh[hf] - ubA[hf] + s0;
-					const bool d0 = ubA[hf] + hh0 - rh[hf] == uu0 + ee0;
-					pm = (pm & ~(1u << (W - 1))) | ((uint32_t)m0 << (W - 1));
-					pd = (pd & ~(1u << (W - 1))) | ((uint32_t)d0 << (W - 1));
+				for(int hf = 0; hf < 2; hf++){
+					if(j == 0 && rbeg[hf] == 0u){
+						const int hh0 = pk_get(hfirst, hf), s0 = pk_get(Sv[0], hf), uu0 = pk_get(u0_old, hf);
+						const int ee0 = (PW == 0) ? (gapo1 + gape1) : pk_get(e0_old, hf);
+						const bool m0 = hh0 == rh[hf] - ubA[hf] + s0;
+						const bool d0 = ubA[hf] + hh0 - rh[hf] == uu0 + ee0;
+						const uint32_t b0 = 1u << (W - 1 + 16 * hf);
+						accM = (accM & ~b0) | (m0 ? b0 : 0u);
+						accD = (accD & ~b0) | (d0 ? b0 : 0u);
+					}
 				}
-				// cells at / beyond the end of the previous row's band: x == bw decides M or I only, x > bw is always I
-				{
-					const int lim = BW - (int)mov[hf] - j * W;             // cells k < lim have x < bw
+			}
+			// cells at / beyond the end of the previous row's band: x == bw decides M or I only, x > bw is always I
+			{
+				uint32_t kd = 0, km = 0;
+#pragma unroll
+				for(int hf = 0; hf < 2; hf++){
+					const int lim = BW - (int)mov[hf] - j * W;                 // cells k < lim have x < bw
 					const int nd = min(max(lim, 0), W), nm = min(max(lim + 1, 0), W);
-					pd &= (FULL << (W - nd)) & FULL;
-					pm &= (FULL << (W - nm)) & FULL;
+					kd |= ((FULL << (W - nd)) & FULL) << (16 * hf);
+					km |= ((FULL << (W - nm)) & FULL) << (16 * hf);
 				}
-				if(act[hf]){
-					uint32_t *rp = (uint32_t*)(rowp[hf] + (size_t)i * (64u * CW)) + (uint32_t)j * CW;
-					if constexpr (W == 4) rp[0] = pm | (pd << 4) | (pr << 8) | (po << 12);
-					else if constexpr (W == 8) rp[0] = pm | (pd << 8) | (pr << 16) | (po << 24);
-					else { rp[0] = pm | (pd << 16); rp[1] = pr | (po << 16); }
-					if(j == 0) begs[hf][i + 1] = (int)rbeg[hf];
-				}
+				accD &= kd; accM &= km;
+			}
+			uint32_t dA0, dA1 = 0, dB0, dB1 = 0;
+			if constexpr (W == 8){
+				const uint32_t t1 = __builtin_amdgcn_perm(accD, accM, 0x06020400u);   // {M.A, D.A, M.B, D.B}
+				const uint32_t t2 = __builtin_amdgcn_perm(accO, accR, 0x06020400u);   // {R.A, O.A, R.B, O.B}
+				dA0 = __builtin_amdgcn_perm(t2, t1, 0x05040100u);
+				dB0 = __builtin_amdgcn_perm(t2, t1, 0x07060302u);
+			} else if constexpr (W == 4){
+				const uint32_t lo = accM | (accD << 4) | (accR << 8) | (accO << 12);     // fields of 4 bits stay inside each half
+				dA0 = lo & 0xFFFFu; dB0 = lo >> 16;
+			} else {
+				dA0 = (accM & 0xFFFFu) | (accD << 16); dA1 = (accR & 0xFFFFu) | (accO << 16);
+				dB0 = (accM >> 16) | (accD & 0xFFFF0000u); dB1 = (accR >> 16) | (accO & 0xFFFF0000u);
+			}
+			if(act[0]){
+				uint32_t *rp = (uint32_t*)(rowp[0] + (size_t)i * (64u * CW)) + (uint32_t)j * CW;
+				rp[0] = dA0; if constexpr (CW > 1) rp[1] = dA1;
+				if(j == 0) begs[0][i + 1] = (int)rbeg[0];
+			}
+			if(act[1]){
+				uint32_t *rp = (uint32_t*)(rowp[1] + (size_t)i * (64u * CW)) + (uint32_t)j * CW;
+				rp[0] = dB0; if constexpr (CW > 1) rp[1] = dB1;
+				if(j == 0) begs[1][i + 1] = (int)rbeg[1];
 			}
 		}
 		// ---- tail (bsalign.h:2618-2636)
