@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 		for(int h = 0; h < 2; h++) if(tlen[h] != 0 && j == 0) begs[h][0] = 0;
 	}
 	constexpr uint32_t CW = (W >= 8) ? (uint32_t)W / 8u : 1u;
+	int begq[2] = {0, 0};
 	int tb_next[2];
 	int rbz[2];     // 2 * max(tlen / qlen, 1): suggested max band step (bsalign.h:4008)
 #pragma unroll
@@ -470,15 +471,17 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 				dA0 = (accM & 0xFFFFu) | (accD << 16); dA1 = (accR & 0xFFFFu) | (accO << 16);
 				dB0 = (accM >> 16) | (accD & 0xFFFF0000u); dB1 = (accR >> 16) | (accO & 0xFFFF0000u);
 			}
-			if(act[0]){
-				uint32_t *rp = (uint32_t*)(rowp[0] + (size_t)i * (64u * CW)) + (uint32_t)j * CW;
-				rp[0] = dA0; if constexpr (CW > 1) rp[1] = dA1;
-				if(j == 0) begs[0][i + 1] = (int)rbeg[0];
-			}
-			if(act[1]){
-				uint32_t *rp = (uint32_t*)(rowp[1] + (size_t)i * (64u * CW)) + (uint32_t)j * CW;
-				rp[0] = dB0; if constexpr (CW > 1) rp[1] = dB1;
-				if(j == 0) begs[1][i + 1] = (int)rbeg[1];
+			// band offsets: lane (i mod 16) keeps the offset of row i, all 16 lanes store together every 16th row (one
+			// 64-byte store instead of sixteen 4-byte ones) and at the pair's last row
+#pragma unroll
+			for(int hf = 0; hf < 2; hf++){
+				if(act[hf]){
+					uint32_t *rp = (uint32_t*)(rowp[hf] + (size_t)i * (64u * CW)) + (uint32_t)j * CW;
+					rp[0] = hf ? dB0 : dA0; if constexpr (CW > 1) rp[1] = hf ? dB1 : dA1;
+					if((i & 15u) == (uint32_t)j) begq[hf] = (int)rbeg[hf];
+					const bool lastrow = i + 1u == tlen[hf];
+					if(((i & 15u) == 15u || lastrow) && (uint32_t)j <= (i & 15u)) begs[hf][(i & ~15u) + 1u + (uint32_t)j] = begq[hf];
+				}
 			}
 		}
 		// ---- tail (bsalign.h:2618-2636)
