@@ -480,7 +480,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		int smax = -127, smin = 127;
 		for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
 		t.smax = smax; t.smin = smin;
-		p->codes = !p->generic && !(le && le[0] == '1') && bsa_align8_codes_supported(t, p->pw);
+		p->codes = !p->generic && !(le && le[0] == '1') && !(par->mode & BSA_MODE_ROWRECORDS) && bsa_align8_codes_supported(t, p->pw);
 	}
 	std::vector<uint32_t> order(n);
 	for(size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
@@ -567,10 +567,51 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	bsa_align_plan_t *p = nullptr;
 	int rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
 	if(rc != BSA_OK) return rc;
-	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, status,
+	std::vector<uint32_t> st_own;
+	uint32_t *st = status;
+	const bool codes = p->codes;
+	if(codes && !st){ st_own.resize(n); st = st_own.data(); }
+	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, st,
 		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_align_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });
 	bsa_align_plan_destroy(p);
-	return rc;
+	if(rc != BSA_OK || !codes) return rc;
+	// ---- hand-over: pairs the compact traceback could not decide go through the literal kernels, so that a flag that
+	// survives means what it means for the reference (its own traceback does not terminate there)
+	std::vector<size_t> idx;
+	const char *dbg = getenv("BSA_DEBUG_HANDOVER");          // test hook: treat every N-th pair as undecided
+	const long every = dbg ? atol(dbg) : 0;
+	for(size_t k = 0; k < n; k++) if((st[k] & BSA_ST_TRACE) || (every > 0 && k % (size_t)every == 0 && st[k] == 0)) idx.push_back(k);
+	if(idx.empty()) return BSA_OK;
+	const size_t m = idx.size();
+	std::vector<uint64_t> sq(m), stt(m), soff(m + 1);
+	std::vector<uint32_t> sql(m), stl(m), sst(m);
+	std::vector<bsa_result_t> sout(m);
+	size_t scap = 16;
+	for(size_t k = 0; k < m; k++){ sq[k] = qoff[idx[k]]; stt[k] = toff[idx[k]]; sql[k] = qlen[idx[k]]; stl[k] = tlen[idx[k]]; scap += (size_t)sql[k] + stl[k] + 2; }
+	std::vector<uint32_t> scig(cigar ? scap : 0);
+	bsa_align_params_t lp = *par;
+	lp.mode |= BSA_MODE_ROWRECORDS;
+	rc = bsa_align_batch(c, seqs, seqs_bytes, sq.data(), sql.data(), stt.data(), stl.data(), m, &lp, sout.data(),
+		cigar ? scig.data() : nullptr, scap, (cigar && cigar_off) ? soff.data() : nullptr, sst.data());
+	if(rc != BSA_OK) return rc;
+	for(size_t k = 0; k < m; k++){ out[idx[k]] = sout[k]; st[idx[k]] = sst[k]; }
+	if(cigar && cigar_off){
+		// splice the re-run pairs' CIGARs into the arena (the compact pass left them empty or, in the debug hook, filled)
+		std::vector<uint32_t> merged;
+		std::vector<uint64_t> noff(n + 1);
+		merged.reserve((size_t)cigar_off[n] + (size_t)soff[m]);
+		size_t j = 0;
+		for(size_t k = 0; k < n; k++){
+			noff[k] = merged.size();
+			if(j < m && idx[j] == k){ merged.insert(merged.end(), scig.begin() + soff[j], scig.begin() + soff[j + 1]); j++; }
+			else merged.insert(merged.end(), cigar + cigar_off[k], cigar + cigar_off[k + 1]);
+		}
+		noff[n] = merged.size();
+		memcpy(cigar_off, noff.data(), (n + 1) * sizeof(uint64_t));
+		if(merged.size() > cigar_cap_words){ c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
+		if(!merged.empty()) memcpy(cigar, merged.data(), merged.size() * 4);
+	}
+	return BSA_OK;
 }
 
 // debug / test hook: copy the stored row records of `pair` to host.  Only meaningful right after a single-chunk run.

@@ -35,6 +35,8 @@ extern "C" {
 #define BSA_MODE_GLOBAL   0
 #define BSA_MODE_OVERLAP  1
 #define BSA_MODE_EXTEND   2
+#define BSA_MODE_ROWRECORDS 0x100 /* flag: keep the reference-layout row records and the literal traceback even where the
+                                      compact 4-bit-code path applies (global mode, 1-piece gaps, small scores) */
 
 /* CIGAR op codes (bsalign.h:61-69) */
 #define BSA_CIGAR_M 0
@@ -54,7 +56,10 @@ extern "C" {
 #define BSA_ST_OK          0u
 #define BSA_ST_BAD_BASE    1u   /* a base code > 3 (the reference would index past matrix[16]) */
 #define BSA_ST_EMPTY       2u   /* qlen == 0 or tlen == 0 */
-#define BSA_ST_TRACE       4u   /* traceback left the stored band: the reference does not terminate on this input */
+#define BSA_ST_TRACE       4u   /* traceback left the stored band: the reference does not terminate on this input.
+                                    With device pointers (bsa_align_run) the compact path also sets it for a pair its flags
+                                    cannot decide (none seen in testing): resubmit such pairs with BSA_MODE_ROWRECORDS.
+                                    bsa_align_batch does that itself. */
 
 /* == seqalign_result_t (bsalign.h:213-218): 10 x int32, [qb,qe) x [tb,te) half-open */
 typedef struct {

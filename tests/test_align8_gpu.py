@@ -170,3 +170,13 @@ def test_compact_path_band_and_ratio_corners(ctx):
     for bw in (64, 128, 256):
         for sc in ("affine", "paper", "linear"):
             _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS[sc])
+
+
+def test_handover_to_literal_path_merges_results(ctx, monkeypatch):
+    """bsa_align_batch re-runs pairs the compact traceback flags through the row-record kernels and splices their
+    results and CIGARs back; the debug hook declares every 3rd pair undecided so that the merge is exercised"""
+    monkeypatch.setenv("BSA_DEBUG_HANDOVER", "3")
+    rng = np.random.default_rng(4711)
+    pairs = _mk_pairs(rng, 50, [1, 17, 100, 300, 1000])
+    _check(ctx, pairs, S.MODE_GLOBAL, 128, SCORINGS["affine"])
+    _check(ctx, pairs, S.MODE_GLOBAL, 64, SCORINGS["paper"])
