@@ -180,3 +180,33 @@ def test_handover_to_literal_path_merges_results(ctx, monkeypatch):
     pairs = _mk_pairs(rng, 50, [1, 17, 100, 300, 1000])
     _check(ctx, pairs, S.MODE_GLOBAL, 128, SCORINGS["affine"])
     _check(ctx, pairs, S.MODE_GLOBAL, 64, SCORINGS["paper"])
+
+
+@pytest.mark.parametrize("literal", [False, True])
+def test_chunked_batches_and_cigar_properties(monkeypatch, literal):
+    """a workspace limit forces the batch through several chunks (and, with BSA_PIPELINE, two streams); results must not
+    depend on the chunking, and every CIGAR must consume exactly [qb,qe) x [tb,te) with aln = mat+mis+ins+del"""
+    import bsalign_amd as B
+    if literal:
+        monkeypatch.setenv("BSA_ALIGN8_LITERAL", "1")
+    pairs = [S.synth_pair(k, 1500) for k in range(300)]
+    par = B.make_params(S.MODE_GLOBAL, 128, *SCORINGS["affine"])
+    big = B.Context(0)
+    out0, cig0, st0 = big.align_batch(pairs, par)
+    big.close()
+    small = B.Context(0, workspace_limit=(24 << 20) if not literal else (80 << 20))
+    out1, cig1, st1 = small.align_batch(pairs, par)
+    monkeypatch.setenv("BSA_PIPELINE", "1")
+    out2, cig2, st2 = small.align_batch(pairs, par)
+    small.close()
+    assert (st0 == 0).all() and np.array_equal(st0, st1) and np.array_equal(st0, st2)
+    assert np.array_equal(out0, out1) and np.array_equal(out0, out2)
+    for k, (q, t) in enumerate(pairs):
+        assert np.array_equal(cig0[k], cig1[k]) and np.array_equal(cig0[k], cig2[k]), k
+        qs, ts = S.cigar_spans(cig0[k])
+        r = out0[k]
+        assert (r["qb"], r["qe"], r["tb"], r["te"]) == (0, len(q), 0, len(t))
+        assert qs == r["qe"] - r["qb"] and ts == r["te"] - r["tb"]
+        assert r["aln"] == r["mat"] + r["mis"] + r["ins"] + r["del"]
+    res, cig, _ = S.oracle_align(pairs[7][0], pairs[7][1], S.MODE_GLOBAL, 128, *SCORINGS["affine"])
+    assert np.array_equal(np.array([out0[7][f] for f in out0.dtype.names], dtype=np.int32), res) and np.array_equal(cig0[7], cig)
