@@ -24,6 +24,7 @@ static __device__ __forceinline__ uint32_t pk_norm(uint32_t a){ return a & 0xFF0
 static __device__ __forceinline__ int pk_get(uint32_t x, int h){ return h ? ((int)x >> 24) : __builtin_amdgcn_sbfe((int)x, 8, 8); }
 static __device__ __forceinline__ uint32_t pk_make(int a, int b){ return (((uint32_t)a & 0xffu) << 8) | ((uint32_t)b << 24); }
 static __device__ __forceinline__ uint32_t pk_splat(int x){ return pk_make(x, x); }
+static __device__ __forceinline__ uint32_t pk_make16(int a, int b){ return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16); }   // plain int16 halves
 static __device__ __forceinline__ uint32_t pk_dpp_shr1(uint32_t fill, uint32_t x){ return (uint32_t)DPP_SHR((int)fill, (int)x, 1); }
 static __device__ __forceinline__ uint32_t pk_dpp_shl1(uint32_t fill, uint32_t x){ return (uint32_t)DPP_SHL((int)fill, (int)x, 1); }
 
@@ -39,9 +40,40 @@ typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ uint32_t pk_eq(uint32_t a, uint32_t b){
 	return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, 0x00010001u), __builtin_bit_cast(v2us, a ^ b)));
 }
-// acc = acc * 2 + flag per half (v_pk_mad_u16)
+// acc = acc * 2 + flag per half: one v_pk_mad_u16 (the compiler splits the C expression into a shift and an or; the
+// multiplier comes from a register because a VOP3P inline constant only reaches the low half)
 static __device__ __forceinline__ uint32_t pk_acc(uint32_t acc, uint32_t flag){
-	return __builtin_bit_cast(uint32_t, (v2us)(__builtin_bit_cast(v2us, acc) * (v2us)(2) + __builtin_bit_cast(v2us, flag)));
+	uint32_t r;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "s"(0x00020002u), "v"(flag));
+	return r;
+}
+
+// F-penetration (bsalign.h:2639-2652) of both pairs at once: the max-plus scan of bsa_dpp.h fpen() on plain int16
+// halves.  f comes and goes in the value << 8 form.  Entering sums stay inside int16 for W <= 16 (|ubegs[j+1] -
+// ubegs[j]| <= 128 W, 15 lanes); anything below -128 can never win against an int8 f, so negative saturation is
+// harmless, and the only way the scan can differ from the reference's serial chain -- an entering value above 127
+// being truncated to int8 -- sends the row through the literal chain, exactly as in fpen().
+static __device__ __forceinline__ uint32_t fpen_pk(uint32_t f, const int (&ubA)[2], const int (&ubB)[2], int t, int j){
+	const uint32_t NEG = 0x80008000u;
+	uint32_t f16;
+	asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(f16) : "s"(0x00080008u), "v"(f));
+	const uint32_t fs = (uint32_t)DPP_SHR((int)pk_make16(BSA_EPI8_MIN, BSA_EPI8_MIN), (int)f16, 1);
+	const uint32_t c = pk_make16(t - (ubB[0] - ubA[0]), t - (ubB[1] - ubA[1]));
+	uint32_t A = (uint32_t)DPP_SHR((int)NEG, (int)c, 1);
+	uint32_t B = fs;
+#define FPK_STEP(n) { const uint32_t A1 = (uint32_t)DPP_SHR(0, (int)A, n); const uint32_t B1 = (uint32_t)DPP_SHR((int)NEG, (int)B, n); B = pk_max(pk_adds(B1, A), B); A = pk_adds(A1, A); }
+	FPK_STEP(1) FPK_STEP(2) FPK_STEP(4) FPK_STEP(8)
+#undef FPK_STEP
+	const uint32_t sprev = (uint32_t)DPP_SHR((int)NEG, (int)pk_adds(B, c), 1);
+	const uint32_t lim = pk_make16(127, 127);
+	if(__any(pk_max(sprev, lim) != lim)){
+		const int fa = fpen_serial(__builtin_amdgcn_sbfe((int)f16, 0, 16), ubA[0], ubB[0], t, j);
+		const int fb = fpen_serial((int)f16 >> 16, ubA[1], ubB[1], t, j);
+		return pk_make(fa, fb);
+	}
+	uint32_t r;
+	asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(r) : "s"(0x00080008u), "v"(B));
+	return r;
 }
 
 // CODES = true: the compact traceback of the global mode.  Instead of the row records the kernel stores, per band
@@ -356,14 +388,8 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			}
 		}
 		{
-			int fa = fpen(pk_get(f, 0), ubA[0], ubB[0], W * gape1, j);
-			int fb = fpen(pk_get(f, 1), ubA[1], ubB[1], W * gape1, j);
-			f = pk_make(fa, fb);
-			if(PW == 2){
-				int ga = fpen(pk_get(gq, 0), ubA[0], ubB[0], W * gape2, j);
-				int gb = fpen(pk_get(gq, 1), ubA[1], ubB[1], W * gape2, j);
-				gq = pk_make(ga, gb);
-			}
+			f = fpen_pk(f, ubA, ubB, W * gape1, j);
+			if(PW == 2) gq = fpen_pk(gq, ubA, ubB, W * gape2, j);
 		}
 		uint32_t htail, ulast = 0;
 		uint32_t accM = 0, accD = 0, accR = 0, accO = 0;        // CODES: flag planes, pair A in the low half, pair B in the high half
