@@ -208,10 +208,20 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 		rbz[h] = 2 * max((int)(tlen[h] / max(qlen[h], 1u)), 1);
 	}
 
+	// rby = (int)((1.0 * i / tlen) * qlen) (bsalign.h:4009) depends on the row number only: every 16th row each lane
+	// evaluates it for one of the next 16 rows (lane j: row i + j) and the row loop fetches its value with a lane
+	// permute.  Same expression, same rounding, one double division per 16 rows and pair instead of one per row.
+	int rby_tab[2] = {0, 0};
+	const int rby_lane = (lt & 48) << 2;                 // byte address of lane 0 of this DPP row for ds_bpermute
 	while(__any(i < tlen[0] || i < tlen[1])){
 		bool act[2];
 		int rh[2];
 		bool slow = false;
+		if(mode == BSA_MODE_GLOBAL && (i & 15u) == 0u){
+#pragma unroll
+			for(int h = 0; h < 2; h++)
+				rby_tab[h] = (int)((1.0 * (double)(i + (uint32_t)j) / (double)tlen[h]) * (double)qlen[h]);
+		}
 #pragma unroll
 		for(int h = 0; h < 2; h++){
 			act[h] = i < tlen[h];
@@ -559,7 +569,7 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			else if(ub0 > ub16 + noisy) rbx = 0;
 			else rbx = 1;
 			if(mode == BSA_MODE_GLOBAL){
-				const int rby = (int)((1.0 * (double)i / (double)tlen[h]) * (double)qlen[h]);
+				const int rby = __builtin_amdgcn_ds_bpermute(rby_lane + (int)((i & 15u) << 2), rby_tab[h]);
 				// "be quick to move to end": rbeg + rbz * (tlen - i - 1) + bw <= qlen + rbz - 1 (64-bit); its division is rare
 				const uint32_t left = tlen[h] - i - 1u;
 				const unsigned long long lhs = (unsigned long long)rbeg[h] + (unsigned long long)(uint32_t)rbz[h] * left + (unsigned long long)BW;
