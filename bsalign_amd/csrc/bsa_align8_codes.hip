@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 		{ const int lo = have_lo; if(lo > 0){ request(lo - 1, base_for(cury)); file(); } }
 		qc_ch = rs.qb >> 4; qc0 = chunk(qc_ch); qc1 = chunk(qc_ch - 1); qc2 = chunk(qc_ch - 2);
 	}
-	int prior_match = 0, dlen = 0;
+	int prior_match = 0, dlen = 0;                // dlen != 0: inside a deletion run
 	uint32_t cg = 0;
 	// Two kinds of iteration.  Seven out of eight handle only the common step -- a match / mismatch cell reached after
 	// another cell (prior_match set, M flag set): ~40 instructions.  Everything else (insertions, deletions, band start,
@@ -335,48 +335,55 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 		}
 		if(done) continue;
 		if(!svc){
-			// ---- common step: a cell inside the ring and the window, decided from one ring entry
+			// ---- common step: a cell inside the ring and the window, decided from one ring entry.  Written with
+			// predicates instead of branches: the 32 walks of a wave are in different cases on every step, and each
+			// divergent branch costs its scalar bookkeeping whether or not any lane takes it.
 			if(slow) continue;
-			if(rs.qb <= 0 || rs.tb <= 0 || rs.tb - 1 < have_lo){ slow = true; continue; }
-			const uint4 e = slot(rs.tb);
-			const int beg_c = (int)(e.w & 0x3FFFFFFu), beg_p = (int)(slot(rs.tb - 1).w & 0x3FFFFFFu);
+			const int tbm = max(rs.tb, 1);
+			const uint4 e = slot(tbm);
+			const uint32_t ew1 = slot(tbm - 1).w;
+			const int beg_c = (int)(e.w & 0x3FFFFFFu), beg_p = (int)(ew1 & 0x3FFFFFFu);
 			const uint32_t wbase = e.w >> 28;
 			const int p = rs.qb - beg_c;
 			const uint32_t y = (uint32_t)p / W, off = y - wbase, kk = (uint32_t)p % W, bit = 1u << (W - 1 - kk);
 			const int dch = qc_ch - (rs.qb >> 4);
-			if((uint32_t)p >= (uint32_t)bw || off > 2u || (uint32_t)dch > 2u){ slow = true; continue; }
+			const bool ok = rs.qb > 0 && rs.tb > 0 && rs.tb - 1 >= have_lo && (uint32_t)p < (uint32_t)bw && off <= 2u && (uint32_t)dch <= 2u;
 			const uint32_t wc = off == 0u ? e.x : off == 1u ? e.y : e.z;
-			cury = y;
-			if(dlen){
-				if((wc >> (3 * W)) & bit){ cg = cig_add(cg, 2, (uint32_t)dlen); rs.del += dlen; rs.aln += dlen; dlen = 0; }
-				else { dlen++; rs.tb--; continue; }
-			}
+			const bool fm = (wc & bit) != 0u, fd = ((wc >> W) & bit) != 0u, fo = ((wc >> (3 * W)) & bit) != 0u;
+			const uint32_t cand = ((wc >> (2 * W)) & FULL) & ~((bit << 1) - 1u);
+			const bool run_cont = dlen != 0 && !fo;                    // deletion run goes on through this row
 			const bool pmatch = (rs.qb != beg_p) && prior_match;
-			const bool fm = (wc & bit) != 0u, fd = ((wc >> W) & bit) != 0u;
-			if(!fm && !fd && !(((wc >> (2 * W)) & FULL) & ~((bit << 1) - 1u))){ slow = true; continue; }   // insertion crossing a block boundary: general step
-			prior_match = 1;
-			if(fm && (pmatch || !fd)){
-				const int qbase = base_in(dch == 0 ? qc0 : dch == 1 ? qc1 : qc2, rs.qb & 15);
-				if(qbase == (int)((e.w >> 26) & 3u)) rs.mat++; else rs.mis++;
-				rs.qb--; rs.aln++; rs.tb--;
-				cg = cig_add(cg, 0, 1);
-			} else if(fd){
-				dlen = 1; rs.tb--;
-			} else {
-				const uint32_t cand = ((wc >> (2 * W)) & FULL) & ~((bit << 1) - 1u);
-				const int sz = (int)__builtin_ctz(cand) - (int)(W - 1 - kk);
-				cg = cig_add(cg, 1, (uint32_t)sz);
-				rs.qb -= sz; rs.ins += sz; rs.aln += sz;
-			}
+			const bool is_m = !run_cont && fm && (pmatch || !fd);
+			const bool is_d = !run_cont && !is_m && fd;
+			const bool is_i = !run_cont && !is_m && !is_d;
+			if(!ok || (is_i && cand == 0u)){ slow = true; continue; }   // general step: edges, window misses, insertions crossing a block
+			cury = y;
+			const int sz = (int)__builtin_ctz(cand | 0x80000000u) - (int)(W - 1 - kk);
+			const int qbase = base_in(dch == 0 ? qc0 : dch == 1 ? qc1 : qc2, rs.qb & 15);
+			const bool same = qbase == (int)((e.w >> 26) & 3u);
+			// CIGAR: a deletion is counted row by row (its length is only known when the run ends), so every step adds
+			// to exactly one run
+			const uint32_t op = is_m ? 0u : is_i ? 1u : 2u;
+			const uint32_t n = is_i ? (uint32_t)sz : 1u;
+			const bool ext = op == (cg & 0xfu);
+			if(!ext && cg) cig_push(cg);
+			cg = ext ? cg + (n << 4) : ((n << 4) | op);
+			rs.mat += (is_m && same) ? 1 : 0;
+			rs.mis += (is_m && !same) ? 1 : 0;
+			rs.ins += is_i ? sz : 0;
+			rs.del += (is_d || run_cont) ? 1 : 0;
+			rs.aln += (int)n;
+			rs.qb -= is_m ? 1 : is_i ? sz : 0;
+			rs.tb -= is_i ? 0 : 1;
+			dlen = (is_d || run_cont) ? 1 : 0;
+			prior_match = run_cont ? prior_match : 1;
 			continue;
 		}
 		// ---- general step (service iterations only)
 		slow = false;
 		if(bad || rs.qb < 0 || rs.tb < 0){
-			if(dlen && !bad){
-				if(rs.qb >= bw) bad = true;                              // the run reached row -1 outside its band
-				else { cg = cig_add(cg, 2, (uint32_t)dlen); rs.del += dlen; rs.aln += dlen; dlen = 0; }
-			}
+			if(dlen && !bad && rs.qb >= bw) bad = true;                  // a deletion run reached row -1 outside its band
+			dlen = 0;
 			done = true;
 			continue;
 		}
@@ -394,12 +401,9 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 		else wc = ((const uint32_t*)(rows + (size_t)rs.tb * RB))[y];           // drifted two blocks inside one ring: plain load
 		const uint32_t pm = wc & FULL, pd = (wc >> W) & FULL, pr = (wc >> (2 * W)) & FULL, po = (wc >> (3 * W)) & FULL;
 		if(dlen){
-			// deletion run (bsalign.h:3730-3744): this row ends it if its stored e is a fresh opening
-			if(po & bit){
-				cg = cig_add(cg, 2, (uint32_t)dlen);
-				rs.del += dlen; rs.aln += dlen;
-				dlen = 0;
-			} else { dlen++; rs.tb--; slow = true; continue; }
+			// deletion run (bsalign.h:3730-3744), counted row by row: this row ends it if its stored e is a fresh opening
+			if(po & bit) dlen = 0;
+			else { cg = cig_add(cg, 2, 1); rs.del++; rs.aln++; rs.tb--; continue; }
 		}
 		const bool pmatch = !(rs.qb == beg_p && rs.qb) && prior_match;      // bsalign.h:3761-3764
 		const bool fm = (pm & bit) != 0u, fd = (pd & bit) != 0u;
@@ -438,7 +442,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 				rs.qb -= sz; rs.ins += sz; rs.aln += sz;
 			}
 		} else {
-			dlen = 1; rs.tb--; slow = true;                              // the rows above decide the length, at the next general steps
+			cg = cig_add(cg, 2, 1); rs.del++; rs.aln++;
+			dlen = 1; rs.tb--;                                           // the rows above decide how far the run goes
 		}
 		prior_match = 1;
 		if(rs.qb < 0 || rs.tb < 0) slow = true;                          // termination is a general step
@@ -619,6 +624,8 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a_in, int pw, bsa_res
 			// 32 pairs per wave measured best on MI355X for 100 k pairs (ms per launch: 64 -> 46, 32 -> 34.9, 16 -> 35.7, 8 -> 57):
 			// the kernel is bound by instruction issue (242 instructions per step and wave, SQ counters) at few lanes per
 			// wave and by the latency of its own dependent chain at many
+			else if(variant == 3) hipLaunchKernelGGL((k_align8_trace_codes_lds<8, 64>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			else if(variant == 4) hipLaunchKernelGGL((k_align8_trace_codes_lds<8, 16>), dim3((a.count + 15u) / 16u), dim3(64), 0, st, a, out, cig_cnt);
 			else hipLaunchKernelGGL((k_align8_trace_codes_lds<8, 32>), dim3((a.count + 31u) / 32u), dim3(64), 0, st, a, out, cig_cnt);
 			break;
 		case 16: hipLaunchKernelGGL((k_align8_trace_codes_simple<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
