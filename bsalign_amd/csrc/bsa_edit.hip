@@ -222,6 +222,17 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 	u64 bq = 0, br = 0;
 	if(y >= 1){ const u64 pr = (u64)(y - 1) * qlen; bq = pr / tlen; br = pr % tlen; }
 	int cached_y = y;
+	// 8 bases of each sequence in a register window: the common step (equal bases, no plane lookup) then touches
+	// memory once per 8 steps instead of twice per step
+	u64 qwin = 0, twin = 0; int qwb = -1000, twb = -1000;
+	auto qbase_at = [&](int idx) -> int {
+		if(idx < qwb || idx >= qwb + 8){ qwb = max(idx - 7, 0); __builtin_memcpy(&qwin, qs + qwb, 8); }
+		return (int)((qwin >> (8 * (idx - qwb))) & 0xffu);
+	};
+	auto tbase_at = [&](int idx) -> int {
+		if(idx < twb || idx >= twb + 8){ twb = max(idx - 7, 0); __builtin_memcpy(&twin, ts + twb, 8); }
+		return (int)((twin >> (8 * (idx - twb))) & 0xffu);
+	};
 	while(!bad && x >= 0 && y >= 0){
 		if(y != cached_y){
 			b1 = b0; cached_y = y;
@@ -234,7 +245,7 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 				b0 = (c + BW > qround) ? qround - BW : c;
 			} else b0 = 0;
 		}
-		if(qs[x] == ts[y]){ rs.mat++; op = 0; x--; y--; }
+		if(qbase_at(x) == tbase_at(y)){ rs.mat++; op = 0; x--; y--; }
 		else {
 			const long p1 = (long)x - (long)b1;
 			const int u3 = plane_bit((uint32_t)y + 1u, 0, p1), u4 = plane_bit((uint32_t)y + 1u, 1, p1);
