@@ -701,7 +701,7 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 	for(size_t k = 0; k < n; k++){
 		bwk[k] = (qlen[k] && tlen[k]) ? edit_bw_eff(qlen[k], tlen[k], type, par->bandwidth) : 64u;
 		if(!bsa_edit_supported_bw(bwk[k])){
-			c->err = "effective edit bandwidth must be <= 1024 on the device for now (overlap/extend use the full query width)";
+			c->err = "effective edit bandwidth must be a multiple of 64";
 			plan_free(p); return BSA_E_UNSUPPORTED;
 		}
 		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bwk[k];

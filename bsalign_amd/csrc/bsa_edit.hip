@@ -143,6 +143,87 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a){
 	a.fwd_sbeg[ppos] = sbeg;
 }
 
+
+// ---- any band width (multiple of 64): the generic forward kernel ------------------------------------------------
+// Same recurrence and row records as k_edit_fwd, but the band state is not held in registers: the previous row is
+// read back from its row record (it has to be written anyway), shifted by the band step on the fly, and the query
+// planes are taken straight from the staged bit planes at the row's band offset.  One pair per lane, NW a run-time
+// value; used when NW > 16, i.e. for the full-width bands of overlap / extend mode and of `bandwidth 0` on queries
+// longer than 1024 bp (bsalign.h:1055-1067).  Streaming loads and stores, four words in and two out per 64 cells.
+__global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a){
+	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	if(g >= a.count) return;
+	const uint32_t ppos = a.first + g, pair = a.order[ppos];
+	if(a.status[pair] != 0u) return;
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint32_t NW = a.bw / 64u, BW = a.bw;
+	const u64 *Q0m = a.qbits + a.qboff[pair];
+	const u64 *Q1m = Q0m + a.qwords[pair];
+	const uint8_t *tp = a.tst + a.tpoff[pair];
+	u64 *rows = (u64*)(a.rows + a.slot_off[ppos]);
+	const int type = a.mode & 3;
+	const bool overlap = type == BSA_MODE_OVERLAP;
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+	for(uint32_t k = 0; k < NW; k++){ rows[k] = 0ull; rows[NW + k] = ~0ull; }      // row_init (:653-656)
+	int sbeg = 0;
+	uint32_t rb0 = 0;
+	u64 quo = 0, rem = 0;
+	const u64 qstep = qlen / tlen, rstep = qlen % tlen;
+	for(uint32_t i = 0; i < tlen; i++){
+		const uint32_t tb = (uint32_t)tp[i] & 3u;
+		uint32_t rb1;
+		if(type != BSA_MODE_GLOBAL) rb1 = 0;
+		else {
+			uint32_t c = (uint32_t)quo;
+			c = (c < BW / 2) ? 0u : c - BW / 2;
+			rb1 = (c + BW > qround) ? qround - BW : c;
+		}
+		const uint32_t movx = rb1 - rb0;
+		const u64 *pm = rows + (size_t)i * (2 * NW), *pp = pm + NW;      // previous row: Mv words, Pv words
+		u64 *nm = rows + (size_t)(i + 1) * (2 * NW), *np = nm + NW;
+		const uint32_t ws = movx >> 6, bs = movx & 63u;
+		// ---- row_movx (:658-721): H at the new band start
+		if(overlap) sbeg = 0;
+		else {
+			int s = 0;
+			const uint32_t full = ws < NW ? ws : NW;
+			for(uint32_t w = 0; w < full; w++) s += __popcll(pp[w]) - __popcll(pm[w]);
+			if(ws < NW && bs){ const u64 mk = lowmask(bs); s += __popcll(pp[ws] & mk) - __popcll(pm[ws] & mk); }
+			sbeg += s + 1;
+		}
+		auto prevP = [&](uint32_t idx) -> u64 { return idx < NW ? pp[idx] : ~0ull; };   // cells shifted in on the right: u = +1
+		auto prevM = [&](uint32_t idx) -> u64 { return idx < NW ? pm[idx] : 0ull; };
+		// ---- row_cal (:766-810), word by word
+		const u64 x0 = (tb & 1u) ? 0ull : ~0ull, x1 = (tb & 2u) ? 0ull : ~0ull;
+		const uint32_t nvalid = (rb1 < qlen) ? qlen - rb1 : 0u;
+		const uint32_t w0 = rb1 >> 6, sh = rb1 & 63u;
+		int hin = overlap ? 0 : 1;
+		u64 plo = prevP(ws), mlo = prevM(ws), q0lo = Q0m[w0], q1lo = Q1m[w0];
+		for(uint32_t k = 0; k < NW; k++){
+			const u64 phi = prevP(ws + k + 1), mhi = prevM(ws + k + 1), q0hi = Q0m[w0 + k + 1], q1hi = Q1m[w0 + k + 1];
+			const u64 pv = fsr(plo, phi, bs), mv = fsr(mlo, mhi, bs);
+			u64 Eq = (fsr(q0lo, q0hi, sh) ^ x0) & (fsr(q1lo, q1hi, sh) ^ x1);
+			if(nvalid < BW){ const uint32_t lo = k * 64u; Eq &= (nvalid > lo) ? lowmask(nvalid - lo) : 0ull; }
+			const u64 hneg = (hin < 0) ? 1ull : 0ull, hpos = (hin > 0) ? 1ull : 0ull;
+			const u64 Xv = Eq | mv;
+			const u64 Eq2 = Eq | hneg;
+			const u64 Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
+			u64 Ph = mv | ~(Xh | pv);
+			u64 Mh = pv & Xh;
+			hin = (int)(Ph >> 63) - (int)(Mh >> 63);
+			Ph = (Ph << 1) | hpos;
+			Mh = (Mh << 1) | hneg;
+			np[k] = Mh | ~(Xv | Ph);
+			nm[k] = Ph & Xv;
+			plo = phi; mlo = mhi; q0lo = q0hi; q1lo = q1hi;
+		}
+		rb0 = rb1;
+		quo += qstep; rem += rstep;
+		if(rem >= tlen){ rem -= tlen; quo++; }
+	}
+	a.fwd_sbeg[ppos] = sbeg;
+}
+
 // ---------------------------------------------------------------------------------------------
 // traceback (bsalign.h:965-1044) + end-cell / score selection of the driver (:1124-1139, 1180-1203)
 // one pair per lane
@@ -325,8 +406,8 @@ __global__ void __launch_bounds__(256) k_edit_stage(const uint8_t *seqs, const u
 	if(threadIdx.x == 0) status[k] = st;
 }
 
-bool bsa_edit_supported_bw(uint32_t bw){
-	return bw >= 64 && (bw % 64) == 0 && bw / 64 <= 16;
+bool bsa_edit_supported_bw(uint32_t bw){       // register kernels up to 16 words, the generic kernel beyond
+	return bw >= 64 && (bw % 64) == 0;
 }
 
 hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
@@ -344,7 +425,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 	switch(a.bw / 64){
 		EDIT_CASE(1) EDIT_CASE(2) EDIT_CASE(3) EDIT_CASE(4) EDIT_CASE(5) EDIT_CASE(6) EDIT_CASE(7) EDIT_CASE(8)
 		EDIT_CASE(9) EDIT_CASE(10) EDIT_CASE(11) EDIT_CASE(12) EDIT_CASE(13) EDIT_CASE(14) EDIT_CASE(15) EDIT_CASE(16)
-		default: return hipErrorInvalidValue;
+		default: hipLaunchKernelGGL(k_edit_fwd_gen, dim3(blocks), dim3(64), 0, st, a); break;
 	}
 #undef EDIT_CASE
 	return hipGetLastError();

@@ -67,10 +67,6 @@ def test_golden_edit_cases(ctx):
     for k in range(int(g["n"][0])):
         mode, bw = [int(x) for x in g["meta_%d" % k]]
         q = g["q_%d" % k]
-        if mode != 0 and len(q) > 1024:
-            continue      # full-band widths beyond the register kernel are not on the device yet
-        if mode == 0 and (bw == 0 or bw > len(q)) and len(q) > 1024:
-            continue
         groups.setdefault((mode, bw), []).append(k)
     assert groups
     for (mode, bw), ks in groups.items():
@@ -79,3 +75,15 @@ def test_golden_edit_cases(ctx):
         for i, k in enumerate(ks):
             got = np.array([out[i][f] for f in out.dtype.names], dtype=np.int32)
             assert status[i] == 0 and np.array_equal(got, g["res_%d" % k]) and np.array_equal(cigs[i], g["cig_%d" % k]), (mode, bw, k)
+
+
+@pytest.mark.parametrize("mode", [S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND])
+def test_wide_bands_use_the_generic_kernel(ctx, mode):
+    """full-width bands of queries longer than 1024 bp (overlap / extend, bandwidth 0) and banded widths above 1024"""
+    rng = np.random.default_rng(77 + mode)
+    pairs = [_mk(rng, int(rng.choice([1100, 1500, 2500, 4000])), float(rng.choice([0.02, 0.1, 0.2])), float(rng.choice([1.0, 0.8, 1.2])))
+             for _ in range(24)]
+    _check(ctx, pairs, mode, 0)
+    if mode == S.MODE_GLOBAL:
+        _check(ctx, pairs, mode, 2048)
+        _check(ctx, pairs, mode, 1088)
