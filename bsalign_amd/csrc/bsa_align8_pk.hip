@@ -200,11 +200,11 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 	}
 	constexpr uint32_t CW = (W >= 8) ? (uint32_t)W / 8u : 1u;
 	int begq[2] = {0, 0};
-	int tb_next[2];
+	uint64_t twin[2] = {0, 0};       // 8 target bases per pair, reloaded every 8th row (the staged targets carry 16 bytes of padding)
 	int rbz[2];     // 2 * max(tlen / qlen, 1): suggested max band step (bsalign.h:4008)
 #pragma unroll
 	for(int h = 0; h < 2; h++){
-		tb_next[h] = tlen[h] ? (int)tp[h][0] : 0;
+		if(tlen[h]) __builtin_memcpy(&twin[h], tp[h], 8);
 		rbz[h] = 2 * max((int)(tlen[h] / max(qlen[h], 1u)), 1);
 	}
 
@@ -339,8 +339,7 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 		uint32_t s4[2][NQ];
 #pragma unroll
 		for(int h = 0; h < 2; h++){
-			const int tb = tb_next[h];
-			if(act[h] && i + 1 < tlen[h]) tb_next[h] = tp[h][i + 1];
+			const int tb = (int)((twin[h] >> (8u * (i & 7u))) & 3u);
 			uint32_t qc[NQ];
 			if(act[h]) load_qcodes_pk<W>(qp[h] + rbeg[h] + j * W, qc);
 			else { for(int n = 0; n < NQ; n++) qc[n] = 0x04040404u; }
@@ -587,6 +586,10 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			}
 		}
 		i++;
+		if((i & 7u) == 0u){
+#pragma unroll
+			for(int h = 0; h < 2; h++) if(i < tlen[h]) __builtin_memcpy(&twin[h], tp[h] + i, 8);
+		}
 	}
 }
 
