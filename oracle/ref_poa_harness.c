@@ -12,6 +12,8 @@
  *           include/bsalign_poa_adapter.h with a backend supplied by the test (the oracle's orc_sweep_run here; the
  *           GPU's bsa_sweep_host in a deployment).  After every read the reference's core is re-run on the same graph
  *           state and its row blocks / best end cell are compared with what the backend returned.
+ *   mode 3  as mode 2 with the DEVICE as backend: bsa_poa_backend_hip -> bsa_sweep_host of libbsalign_hip.so, whose
+ *           address the GPU test hands in (ref_poa_set_device) -- the real end_bspoa with its sweep on the MI355X.
  *
  * Recorded per read: the seqalign_result_t of align_rd_bspoa, the program (tasks), the best end cell and a hash of
  * the reference's row blocks -- tests/golden/make_golden_poa.py turns these into the committed fixtures.
@@ -21,7 +23,13 @@
 #include <stdint.h>
 #include <time.h>
 
-/* the adapter's two link-time dependencies on libbsalign_hip.so, satisfied locally: this library must load without HIP */
+/* the adapter's two link-time dependencies on libbsalign_hip.so, satisfied locally: this library must load without HIP.
+ * bsa_sweep_host forwards to the real one when a GPU test has attached it (ref_poa_set_device). */
+typedef int (*sweep_host_fn)(bsa_ctx_t*, const bsa_row_task_t*, size_t, const bsa_sweep_prog_t*, size_t, const uint8_t*, const uint64_t*,
+		const uint32_t*, size_t, const bsa_sweep_params_t*, uint8_t*, size_t, bsa_sweep_result_t*);
+static sweep_host_fn g_sweep_host = NULL;
+static void *g_device_ctx = NULL;
+void ref_poa_set_device(void *sweep_host_addr, void *ctx){ g_sweep_host = (sweep_host_fn)sweep_host_addr; g_device_ctx = ctx; }
 __attribute__((visibility("hidden"))) size_t bsa_rows_block_bytes(uint32_t bandwidth, int8_t gapo1, int8_t gape1, int8_t gapo2, int8_t gape2){
 	const uint32_t bw = (bandwidth + 15u) / 16u * 16u;
 	const int pw = banded_striped_epi8_seqalign_get_piecewise(gapo1, gape1, gapo2, gape2, (int)bw);
@@ -30,9 +38,8 @@ __attribute__((visibility("hidden"))) size_t bsa_rows_block_bytes(uint32_t bandw
 __attribute__((visibility("hidden"))) int bsa_sweep_host(bsa_ctx_t *ctx, const bsa_row_task_t *tasks, size_t ntasks, const bsa_sweep_prog_t *progs, size_t nprogs,
 		const uint8_t *queries, const uint64_t *qoff, const uint32_t *qlen, size_t nqueries,
 		const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *results){
-	(void)ctx; (void)tasks; (void)ntasks; (void)progs; (void)nprogs; (void)queries; (void)qoff; (void)qlen; (void)nqueries;
-	(void)par; (void)rows_out; (void)nblocks; (void)results;
-	return BSA_E_UNSUPPORTED;       /* no device in the checker */
+	if(g_sweep_host) return g_sweep_host(ctx, tasks, ntasks, progs, nprogs, queries, qoff, qlen, nqueries, par, rows_out, nblocks, results);
+	return BSA_E_UNSUPPORTED;       /* no device library attached */
 }
 
 typedef void (*orc_sweep_fn)(uint8_t *rows, const void *tasks, const void *progs, size_t nprogs,
@@ -118,7 +125,7 @@ static void record_read(ref_poa_t *p, seqalign_result_t rs, int mismatch, uint64
 	r->bandwidth = g->bandwidth; r->slen = g->slen; r->qb = g->qb; r->nblocks = (uint32_t)g->mmcnt; r->piecewise = (uint32_t)g->piecewise;
 	r->rows_hash = rows_hash; r->mismatch = mismatch;
 	r->task_off = p->ntasks; r->query_off = p->nq;
-	if(p->mode == 2 && p->record_programs){
+	if(p->mode >= 2 && p->record_programs){
 		r->ntasks = (uint32_t)p->ad.ntasks;
 		if(p->ntasks + p->ad.ntasks > p->captasks){
 			p->captasks = (p->ntasks + p->ad.ntasks) * 2;
@@ -150,7 +157,7 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
 	sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
 	prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
-	if(p->mode == 2){
+	if(p->mode >= 2){
 		int a_scr, a_idx, a_off;
 		const size_t used = (size_t)g->bandwidth * (g->piecewise + 1) + (WORDSIZE + 1) * sizeof(int);
 		b1i *mine;
@@ -256,7 +263,8 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 	p->core_seconds = 0; p->core_updates = 0; p->core_merges = 0;
 	p->sweep = (orc_sweep_fn)sweep_fn;
 	bsa_poa_adapter_free(&p->ad);
-	bsa_poa_adapter_init(&p->ad, backend_oracle, p);
+	if(mode == 3) bsa_poa_adapter_init(&p->ad, bsa_poa_backend_hip, g_device_ctx);
+	else bsa_poa_adapter_init(&p->ad, backend_oracle, p);
 	for(k = 0; k < nreads; k++) if(lens[k] > maxlen) maxlen = lens[k];
 	buf = (char*)malloc(maxlen + 1);
 	beg_bspoa(g);
