@@ -10,220 +10,69 @@
 // literal backcal.  Whatever the bits cannot decide (a scan leaves the band; the cases in which the reference itself
 // does not terminate) is reported as BSA_ST_TRACE.
 //
-// One pair per lane, 64 pairs per wave: the walk is ~50 instructions per step, so a wave64 of 64 walks is the cheap
-// way to issue them -- provided NO step waits for memory, because a wave waits whenever any of its 64 lanes does.
-// k_align8_trace_codes_pf therefore takes everything from register windows that were requested a whole window
-// earlier: per row three code dwords (the path's block and its neighbours, so drifting across a block boundary costs
-// nothing) and the band offset, 8 rows per window, one window being walked and the next one in flight; the two
-// sequences as 16-byte windows handled the same way.  Deletion runs are steps of the same loop (one row per
-// iteration), not an inner loop with its own loads.  A shift register was tried first and does not work: moving a
-// register one step after its load was issued waits for that load.
+// Start and end of the walk follow the mode: global starts at (qlen-1, tlen-1) and turns what is left at the top into
+// a leading insertion / deletion; overlap and extend start at the best end cell -- the end-of-query candidates the
+// forward pass recorded or the maximum of the last row (row_max, bsalign.h:3213-3329, taken here from the end record) --
+// and overlap stops without a leading gap (bsalign.h:3822-3842).
 #include "bsa_common.h"
 
-#define CODE_WIN 8
-
+// end cell of the non-global modes from the forward pass's end record (bsa_common.h bsa_code_end_t): the best
+// end-of-query candidate (strictly greater wins, in row order) against the maximum of the last row, whose tie rules are
+// the reference's: per lane the first best 32-vector chunk, lanes reduced in its register order, then the first
+// maximum inside the winning chunk (bsalign.h:3213-3329).
 template<int W>
-__global__ void __launch_bounds__(64) k_align8_trace_codes_pf(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
-	static_assert(W == 4 || W == 8, "one code dword per block");
-	constexpr uint32_t RB = 64u;
-	constexpr uint32_t FULL = (1u << W) - 1u;
-	constexpr int bw = W * 16;
-	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
-	const bool live = g < a.count;
-	const uint32_t ppos = a.first + (live ? g : 0u);
-	const uint32_t pair = a.order[ppos];
-	bsa_result_t rs;
-	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
-	const bool skip = !live || a.status[pair] != 0u;
-	const uint32_t qlen = a.qlen[pair], tlen = skip ? 1u : a.tlen[pair];
-	const uint8_t *qseq = a.qst + a.qpoff[pair];
-	const uint8_t *tseq = a.tst + a.tpoff[pair];
-	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
-	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(a.tlen[pair]);
-	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)a.tlen[pair] + 1) * RB);
-	uint32_t ncig = 0;
-	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
-	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
-		if(op == (cg & 0xf)) return cg + (sz << 4);
-		if(cg) cig_push(cg);
-		return (sz << 4) | op;
-	};
-	// ---- row windows: rows wtop - k, k = 0..7 (cur) and wtop - 8 - k (nxt); three dwords from block wbase / nbase
-	uint32_t c0[CODE_WIN], c1[CODE_WIN], c2[CODE_WIN], n0[CODE_WIN], n1[CODE_WIN], n2[CODE_WIN];
-	int cb[CODE_WIN], nb[CODE_WIN];
-	int wtop = 0; uint32_t wbase = 0, nbase = 0;
-	auto load_rows = [&](uint32_t (&x0)[CODE_WIN], uint32_t (&x1)[CODE_WIN], uint32_t (&x2)[CODE_WIN], int (&xb)[CODE_WIN], int top, uint32_t base){
-#pragma unroll
-		for(int k = 0; k < CODE_WIN; k++){
-			const int rr = max(top - k, 0);
-			const uint32_t *rp = (const uint32_t*)(rows + (size_t)rr * RB) + base;
-			x0[k] = rp[0]; x1[k] = rp[1]; x2[k] = rp[2];
-			xb[k] = begs[max(top - k, -1) + 1];
-		}
-	};
-	auto sel = [&](const auto (&arr)[CODE_WIN], int idx){
-		auto v = arr[0];
-#pragma unroll
-		for(int k = 1; k < CODE_WIN; k++) v = (idx == k) ? arr[k] : v;
-		return v;
-	};
-	auto base_for = [&](uint32_t y) -> uint32_t { return (y == 0u) ? 0u : ((y >= 14u) ? 13u : y - 1u); };
-	// ---- sequence windows: 16 bases each, aligned chunks (the staged sequences start 16-byte aligned)
-	uint4 tw = {0, 0, 0, 0}, twn = {0, 0, 0, 0}, qw = {0, 0, 0, 0}, qwn = {0, 0, 0, 0};
-	int tch = -1000, qch = -1000;                 // chunk index held in tw / qw; twn / qwn hold chunk - 1
-	auto chunk = [&](const uint8_t *s, int ch) -> uint4 { return *(const uint4*)(s + (size_t)max(ch, 0) * 16u); };
-	auto base_in = [&](const uint4 &w, int idx) -> int {
-		const uint32_t d = (idx & 12) == 0 ? w.x : (idx & 12) == 4 ? w.y : (idx & 12) == 8 ? w.z : w.w;
-		return (int)((d >> (8 * (idx & 3))) & 0xffu);
-	};
-	auto tbase_at = [&](int i) -> int {
-		const int ch = i >> 4;
-		if(ch != tch){
-			if(ch == tch - 1){ tw = twn; tch = ch; twn = chunk(tseq, ch - 1); }
-			else { tw = chunk(tseq, ch); twn = chunk(tseq, ch - 1); tch = ch; }
-		}
-		return base_in(tw, i & 15);
-	};
-	auto qbase_at = [&](int i) -> int {
-		const int ch = i >> 4;
-		if(ch != qch){
-			if(ch == qch - 1){ qw = qwn; qch = ch; qwn = chunk(qseq, ch - 1); }
-			else { qw = chunk(qseq, ch); qwn = chunk(qseq, ch - 1); qch = ch; }
-		}
-		return base_in(qw, i & 15);
-	};
-	bool bad = false, done = skip;
-	if(!skip){
-		const int score = begs[tlen + 1];
-		if(score == (int)0x80000000u) bad = true;                  // band never reached the query end (bsalign.h:4034)
-		rs.score = score;
-		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
-		rs.qb = rs.qe; rs.qe++;
-		rs.tb = rs.te; rs.te++;
-		const int lastbeg = begs[tlen];
-		const int p0 = max(min((int)qlen - 1 - lastbeg, bw - 1), 0);
-		wtop = rs.tb; wbase = base_for((uint32_t)p0 / W); nbase = wbase;
-		load_rows(c0, c1, c2, cb, wtop, wbase);
-		load_rows(n0, n1, n2, nb, wtop - CODE_WIN, nbase);
+static __device__ void codes_end_cell(const uint8_t *rows, uint32_t RB, uint32_t qlen, uint32_t tlen, int &score, int &qe, int &te){
+	const bsa_code_end_t *er = (const bsa_code_end_t*)(rows + (size_t)tlen * RB);
+	const int8_t *us = (const int8_t*)(er + 1);           // natural band order: lane l, cell x at l * W + x
+	int best = BSA_SCORE_MIN, bte = 0;
+	for(int l = 0; l < 16; l++){
+		const int sc = er->cand_sc[l], t = er->cand_te[l];
+		if(sc > best || (sc == best && sc != BSA_SCORE_MIN && t < bte)){ best = sc; bte = t; }
 	}
-	int prior_match = 0, dlen = 0;                // dlen > 0: inside a deletion run that started dlen rows below
-	uint32_t cg = 0;
-	while(__any(!done)){
-		if(done) continue;
-		if(bad || rs.qb < 0 || rs.tb < 0){
-			if(dlen && !bad){
-				// the run reached row -1: it opens there (no vertical gap can come from above the matrix)
-				if(rs.qb >= bw) bad = true;
-				else { cg = cig_add(cg, 2, (uint32_t)dlen); rs.del += dlen; rs.aln += dlen; dlen = 0; }
+	int lmax[16]; uint32_t lchunk[16];
+	for(uint32_t l = 0; l < 16; l++){
+		int base = er->ubegs[l];
+		lmax[l] = BSA_SCORE_MIN; lchunk[l] = 0;
+		for(uint32_t i = 0, c = 0; i < (uint32_t)W; i += 32, c++){
+			const uint32_t n = (i + 32 < (uint32_t)W) ? 32 : (uint32_t)W - i;
+			int run = 0, cmax = -32767;
+			for(uint32_t x = 0; x < n; x++){
+				run += us[l * W + i + x];
+				run = min(max(run, -32768), 32767);
+				cmax = max(cmax, run);
 			}
-			done = true;
-			continue;
-		}
-		// ---- bring row tb into the current window
-		if(rs.tb <= wtop - CODE_WIN){
-			if(rs.tb > wtop - 2 * CODE_WIN){
-#pragma unroll
-				for(int k = 0; k < CODE_WIN; k++){ c0[k] = n0[k]; c1[k] = n1[k]; c2[k] = n2[k]; cb[k] = nb[k]; }
-				wtop -= CODE_WIN; wbase = nbase;
-			} else {                                      // long deletion: start over at row tb
-				wtop = rs.tb;
-				load_rows(c0, c1, c2, cb, wtop, wbase);
-			}
-			// request the window above; aim it at the block the path is in now
-			{
-				const int pc = rs.qb - sel(cb, wtop - rs.tb);
-				nbase = base_for((uint32_t)max(min(pc, bw - 1), 0) / W);
-				load_rows(n0, n1, n2, nb, wtop - CODE_WIN, nbase);
-			}
-		}
-		const int idx = wtop - rs.tb;
-		const int beg_c = sel(cb, idx);
-		const int beg_p = (idx + 1 < CODE_WIN) ? sel(cb, idx + 1) : nb[0];
-		const int p = rs.qb - beg_c;
-		if(p < 0 || p >= bw){ bad = true; continue; }
-		const uint32_t y = (uint32_t)p / W, k = (uint32_t)p % W, bit = 1u << (W - 1 - k);
-		if(y < wbase || y > wbase + 2u){                  // the path left the three blocks the window holds (rare)
-			wbase = base_for(y); wtop = rs.tb;
-			load_rows(c0, c1, c2, cb, wtop, wbase);
-			nbase = wbase;
-			load_rows(n0, n1, n2, nb, wtop - CODE_WIN, nbase);
-			continue;
-		}
-		const uint32_t off = y - wbase;
-		const uint32_t w0 = sel(c0, idx), w1 = sel(c1, idx), w2 = sel(c2, idx);
-		const uint32_t wc = off == 0u ? w0 : off == 1u ? w1 : w2;
-		const uint32_t pm = wc & FULL, pd = (wc >> W) & FULL, pr = (wc >> (2 * W)) & FULL, po = (wc >> (3 * W)) & FULL;
-		if(dlen){
-			// deletion run (bsalign.h:3730-3744): this row ends it if its stored e is a fresh opening
-			if(po & bit){
-				cg = cig_add(cg, 2, (uint32_t)dlen);
-				rs.del += dlen; rs.aln += dlen;
-				dlen = 0;
-				// fall through: the cell (qb, tb) is decided in this same iteration, as the reference does
-			} else { dlen++; rs.tb--; continue; }
-		}
-		if(rs.qb == beg_p && rs.qb) prior_match = 0;                // bsalign.h:3761-3764
-		const bool fm = (pm & bit) != 0u, fd = (pd & bit) != 0u;
-		int bt;                                                       // 0 M, 1 I, 2 D
-		if(prior_match) bt = fm ? 0 : fd ? 2 : 1;
-		else bt = fd ? 2 : fm ? 0 : 1;
-		prior_match = 1;
-		if(bt == 0){
-			const int qbase = qbase_at(rs.qb), tbase = tbase_at(rs.tb);
-			if(qbase == tbase) rs.mat++; else rs.mis++;
-			rs.qb--; rs.aln++; rs.tb--;
-			cg = cig_add(cg, 0, 1);
-		} else if(bt == 1){
-			if(rs.qb <= 0){
-				cg = cig_add(cg, 1, 1);
-				rs.qb--; rs.ins++; rs.aln++;
-			} else {
-				// nearest cell to the left with R set: cells left of k are the bits above `bit`
-				int sz = 0;
-				const uint32_t cand = pr & ~((bit << 1) - 1u);
-				if(cand) sz = (int)__builtin_ctz(cand) - (int)(W - 1 - k);
-				else {
-					int left = (int)k;
-					for(int yy = (int)y - 1; yy >= 0 && sz == 0; yy--){
-						uint32_t wl;
-						if(yy >= (int)wbase) wl = ((uint32_t)yy - wbase == 0u) ? w0 : w1;       // still inside the window
-						else wl = ((const uint32_t*)(rows + (size_t)rs.tb * RB))[yy];
-						const uint32_t r2 = (wl >> (2 * W)) & FULL;
-						if(r2) sz = left + 1 + (int)__builtin_ctz(r2);
-						else left += W;
-					}
-					if(sz == 0){ bad = true; continue; }              // the reference's scan finds no length either: it never terminates
-				}
-				cg = cig_add(cg, 1, (uint32_t)sz);
-				rs.qb -= sz; rs.ins += sz; rs.aln += sz;
-			}
-		} else {
-			dlen = 1; rs.tb--;                                           // the rows above decide the length
+			if(base + cmax > lmax[l]){ lmax[l] = base + cmax; lchunk[l] = c; }
+			base += run;
 		}
 	}
-	if(skip){ if(live){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
-	if(!bad){
-		uint32_t op = 0, sz = 0;      // global: leading clip becomes I / D (bsalign.h:3827-3842)
-		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
-		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
-		rs.aln += (int)sz;
-		cg = cig_add(cg, op, sz);
-		if(cg) cig_push(cg);
-		rs.qb++; rs.tb++;
+	int ms, lane;
+	{
+		int mm[4], ii[4];
+		for(int k = 0; k < 4; k++){
+			int m01, i01, m23, i23;
+			if(lmax[4 + k] > lmax[k]){ m01 = lmax[4 + k]; i01 = 4 + k; } else { m01 = lmax[k]; i01 = k; }
+			if(lmax[12 + k] > lmax[8 + k]){ m23 = lmax[12 + k]; i23 = 12 + k; } else { m23 = lmax[8 + k]; i23 = 8 + k; }
+			if(m23 > m01){ mm[k] = m23; ii[k] = i23; } else { mm[k] = m01; ii[k] = i01; }
+		}
+		ms = mm[0]; lane = ii[0];
+		for(int k = 1; k < 4; k++) if(mm[k] > ms){ ms = mm[k]; lane = ii[k]; }
 	}
-	if(bad){
-		atomicOr(&a.status[pair], BSA_ST_TRACE);
-		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
-		ncig = 0;
+	uint32_t x = lchunk[lane] * 32u, jj = x;
+	const uint32_t y = min(x + 32u, (uint32_t)W);
+	int umax = BSA_SCORE_MIN, uscr = 0;
+	for(; x < y; x++){
+		uscr += us[lane * W + x];
+		if(uscr > umax){ jj = x; umax = uscr; }
 	}
-	out[pair] = rs;
-	cig_cnt[ppos] = ncig;
+	if(ms > best){ score = ms; qe = er->rbeg_last + (int)((uint32_t)lane * W + jj); te = (int)tlen - 1; }
+	else { score = best; qe = (int)qlen - 1; te = bte; }
 }
+
 
 // ---- the stall-free walker --------------------------------------------------------------------------------------
 // A wave waits (s_waitcnt is a counter, not a per-register flag) whenever ANY lane uses an older load while another
 // lane has just issued a new one, so with 64 desynchronised walks per wave "prefetch into registers" still stalls on
-// almost every step (k_align8_trace_codes_pf above runs no faster than the plain kernel).  Here all lanes fetch at the
+// almost every step (a register-window variant was measured: no faster than the plain kernel).  Here all lanes fetch at the
 // SAME iterations: every CODE_SVC steps each lane requests the 8 rows above what it already holds, and the rows
 // requested at the previous service point -- long since arrived -- are filed into the lane's own LDS ring, from
 // where the walk reads them with dynamic indexing and no memory wait.  Ring entry (16 bytes) of row r:
@@ -242,6 +91,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 	constexpr uint32_t RB = 64u;
 	constexpr uint32_t FULL = (1u << W) - 1u;
 	constexpr int bw = W * 16;
+	const int type = a.mode & 3;
+	const bool lin = a.gapo1 == 0;                                 // linear gaps (piecewise 0)
 	__shared__ uint4 ring[CODE_RING_ROWS * LPW];
 	const uint32_t lane = threadIdx.x;
 	const uint32_t g = blockIdx.x * (uint32_t)LPW + lane;
@@ -256,7 +107,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 	const uint8_t *tseq = a.tst + a.tpoff[pair];
 	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
 	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
-	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)tlen + 1) * RB);
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)tlen + BSA_CODE_SPARE_ROWS) * RB);
 	uint32_t ncig = 0;
 	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
 	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
@@ -300,15 +151,17 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 	bool bad = false, done = skip;
 	uint32_t cury = 0;
 	if(!skip){
-		const int score = begs[tlen + 1];
-		if(score == (int)0x80000000u) bad = true;                  // band never reached the query end (bsalign.h:4034)
+		if(type == BSA_MODE_GLOBAL){
+			rs.score = begs[tlen + 1];
+			if(rs.score == (int)0x80000000u) bad = true;            // band never reached the query end (bsalign.h:4034)
+			rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+		} else codes_end_cell<W>(rows, RB, qlen, tlen, rs.score, rs.qe, rs.te);
 		if(qlen >= (1u << 26)) bad = true;                          // band offsets are kept in 26 bits here
-		rs.score = score;
-		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+		const int lastbeg = begs[rs.te + 1];
+		if(rs.qe < lastbeg || rs.qe >= lastbeg + bw) bad = true;    // end cell outside the stored band
 		rs.qb = rs.qe; rs.qe++;
 		rs.tb = rs.te; rs.te++;
-		const int lastbeg = begs[tlen];
-		cury = (uint32_t)max(min((int)qlen - 1 - lastbeg, bw - 1), 0) / W;
+		cury = (uint32_t)max(min(rs.qb - lastbeg, bw - 1), 0) / W;
 		// prologue: two windows, filed immediately
 		request(rs.tb, base_for(cury)); file();
 		{ const int lo = have_lo; if(lo > 0){ request(lo - 1, base_for(cury)); file(); } }
@@ -382,7 +235,9 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 		// ---- general step (service iterations only)
 		slow = false;
 		if(bad || rs.qb < 0 || rs.tb < 0){
-			if(dlen && !bad && rs.qb >= bw) bad = true;                  // a deletion run reached row -1 outside its band
+			// a deletion run that reached row -1: an ordinary move with linear gaps; with affine gaps only the e = -63 sentinel of
+			// row -1 leads here and the reference then compares real scores -- literal path (BSA_ST_TRACE, hand-over)
+			if(dlen && !bad && (!lin || rs.qb >= bw)) bad = true;
 			dlen = 0;
 			done = true;
 			continue;
@@ -450,12 +305,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 	}
 	if(skip){ if(live){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
 	if(!bad){
-		uint32_t op = 0, sz = 0;      // global: leading clip becomes I / D (bsalign.h:3827-3842)
-		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
-		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
-		rs.aln += (int)sz;
-		cg = cig_add(cg, op, sz);
-		if(cg) cig_push(cg);
+		if(type == BSA_MODE_OVERLAP){ if(cg) cig_push(cg); }         // overlap: the alignment simply starts here (bsalign.h:3822-3826)
+		else {
+			uint32_t op = 0, sz = 0;      // global / extend: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
+			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+			else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+			rs.aln += (int)sz;
+			cg = cig_add(cg, op, sz);
+			if(cg) cig_push(cg);
+		}
 		rs.qb++; rs.tb++;
 	}
 	if(bad){
@@ -484,7 +342,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 	const uint8_t *tseq = a.tst + a.tpoff[pair];
 	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
 	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
-	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)tlen + 1) * RB);
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)tlen + BSA_CODE_SPARE_ROWS) * RB);
 	const int bw = W * 16;
 	uint32_t ncig = 0;
 	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
@@ -516,10 +374,14 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 		return unpack(rp[0], (CW > 1) ? rp[CW - 1] : 0u);
 	};
 	bool bad = false;
-	const int score = begs[tlen + 1];
-	if(score == (int)0x80000000u) bad = true;                      // band never reached the query end (bsalign.h:4034)
-	rs.score = score;
-	rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	const int type = a.mode & 3;
+	const bool lin = a.gapo1 == 0;                                 // linear gaps (piecewise 0)
+	if(type == BSA_MODE_GLOBAL){
+		rs.score = begs[tlen + 1];
+		if(rs.score == (int)0x80000000u) bad = true;               // band never reached the query end (bsalign.h:4034)
+		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	} else codes_end_cell<W>(rows, RB, qlen, tlen, rs.score, rs.qe, rs.te);
+	if(rs.qe < begs[rs.te + 1] || rs.qe >= begs[rs.te + 1] + bw) bad = true;
 	rs.qb = rs.qe; rs.qe++;
 	rs.tb = rs.te; rs.te++;
 	int prior_match = 0;
@@ -572,7 +434,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 			int len = 1;
 			for(;;){
 				const int r = rs.tb - len;
-				if(r == -1){ if(rs.qb >= bw) bad = true; break; }
+				if(r == -1){ if(!lin || rs.qb >= bw) bad = true; break; }      // see the general step of the LDS kernel
 				const int pr = rs.qb - begs[r + 1];
 				if(pr < 0 || pr >= bw){ bad = true; break; }
 				const Code c2 = load_code(r, (uint32_t)pr / W);
@@ -587,12 +449,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 		}
 	}
 	if(!bad){
-		uint32_t op = 0, sz = 0;      // global: leading clip becomes I / D (bsalign.h:3827-3842)
-		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
-		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
-		rs.aln += (int)sz;
-		cg = cig_add(cg, op, sz);
-		if(cg) cig_push(cg);
+		if(type == BSA_MODE_OVERLAP){ if(cg) cig_push(cg); }         // overlap: the alignment simply starts here (bsalign.h:3822-3826)
+		else {
+			uint32_t op = 0, sz = 0;      // global / extend: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
+			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+			else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+			rs.aln += (int)sz;
+			cg = cig_add(cg, op, sz);
+			if(cg) cig_push(cg);
+		}
 		rs.qb++; rs.tb++;
 	}
 	if(bad){
@@ -608,19 +473,17 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a_in, int pw, bsa_res
 	(void)pw;
 	if(a_in.count == 0) return hipSuccess;
 	const Align8Args &a = a_in;
-	// BSA_ALIGN8_TRACE_SIMPLE=1: plain kernel, =2: register-window kernel (both kept as reference points)
+	// BSA_ALIGN8_TRACE_SIMPLE=1: plain kernel (kept as the reference point); 3 / 4: other lane counts of the LDS kernel
 	static const int variant = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e ? atoi(e) : 0; }();
 	const bool simple = variant == 1;
 	const uint32_t blocks = (a.count + 63u) / 64u;
 	switch(a.bw / 16){
 		case 4:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			else if(variant == 2) hipLaunchKernelGGL((k_align8_trace_codes_pf<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
 			else hipLaunchKernelGGL((k_align8_trace_codes_lds<4, 32>), dim3((a.count + 31u) / 32u), dim3(64), 0, st, a, out, cig_cnt);
 			break;
 		case 8:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			else if(variant == 2) hipLaunchKernelGGL((k_align8_trace_codes_pf<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
 			// 32 pairs per wave measured best on MI355X for 100 k pairs (ms per launch: 64 -> 46, 32 -> 34.9, 16 -> 35.7, 8 -> 57):
 			// the kernel is bound by instruction issue (242 instructions per step and wave, SQ counters) at few lanes per
 			// wave and by the latency of its own dependent chain at many

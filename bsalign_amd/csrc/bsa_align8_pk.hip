@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 	}
 	constexpr uint32_t CW = (W >= 8) ? (uint32_t)W / 8u : 1u;
 	int begq[2] = {0, 0};
+	int cand_sc[2] = {BSA_SCORE_MIN, BSA_SCORE_MIN}, cand_te[2] = {0, 0};
 	uint64_t twin[2] = {0, 0};       // 8 target bases per pair, reloaded every 8th row (the staged targets carry 16 bytes of padding)
 	int rbz[2];     // 2 * max(tlen / qlen, 1): suggested max band step (bsalign.h:4008)
 #pragma unroll
@@ -537,17 +538,44 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			if(j == 0) u[0] = 0u;
 		}
 		if constexpr (!CODES) store_rows(i + 1, act, rbeg);
-		else if(__any((act[0] && i + 1u == tlen[0]) || (act[1] && i + 1u == tlen[1]))){
-			// last row of a pair: global score = H at query column qlen - 1 (bsalign.h:4034-4037), kept in begs[tlen + 1]
+		else {
+			if(mode != BSA_MODE_GLOBAL && __any((act[0] && rbeg[0] + BW >= qlen[0]) || (act[1] && rbeg[1] + BW >= qlen[1]))){
+				// overlap / extend: while the band touches the query end, H at query column qlen - 1 is a candidate end
+				// (bsalign.h:4023-4032); the lane that owns that cell keeps the best one it has seen (strictly greater wins)
 #pragma unroll
-			for(int hf = 0; hf < 2; hf++){
-				if(act[hf] && i + 1u == tlen[hf]){
+				for(int hf = 0; hf < 2; hf++){
 					const uint32_t pos = qlen[hf] - 1u - rbeg[hf];
-					int sc = ubA[hf];
+					if(act[hf] && rbeg[hf] + BW >= qlen[hf] && (uint32_t)j == pos / W){
+						int sc = ubA[hf];
 #pragma unroll
-					for(int k = 0; k < W; k++) sc += ((uint32_t)k <= pos % W) ? pk_get(u[k], hf) : 0;
-					if(pos >= (uint32_t)BW){ if(j == 0) begs[hf][tlen[hf] + 1u] = (int)0x80000000u; }      // band never reached the query end
-					else if((uint32_t)j == pos / W) begs[hf][tlen[hf] + 1u] = sc;
+						for(int k = 0; k < W; k++) sc += ((uint32_t)k <= pos % W) ? pk_get(u[k], hf) : 0;
+						if(sc > cand_sc[hf]){ cand_sc[hf] = sc; cand_te[hf] = (int)i; }
+					}
+				}
+			}
+			if(__any((act[0] && i + 1u == tlen[0]) || (act[1] && i + 1u == tlen[1]))){
+#pragma unroll
+				for(int hf = 0; hf < 2; hf++){
+					if(act[hf] && i + 1u == tlen[hf]){
+						if(mode == BSA_MODE_GLOBAL){
+							// global score = H at query column qlen - 1 of the last row (bsalign.h:4034-4037), kept in begs[tlen + 1]
+							const uint32_t pos = qlen[hf] - 1u - rbeg[hf];
+							int sc = ubA[hf];
+#pragma unroll
+							for(int k = 0; k < W; k++) sc += ((uint32_t)k <= pos % W) ? pk_get(u[k], hf) : 0;
+							if(pos >= (uint32_t)BW){ if(j == 0) begs[hf][tlen[hf] + 1u] = (int)0x80000000u; }      // band never reached the query end
+							else if((uint32_t)j == pos / W) begs[hf][tlen[hf] + 1u] = sc;
+						} else {
+							// end record: the candidates and the last row itself (row_max is taken by the traceback kernel)
+							bsa_code_end_t *er = (bsa_code_end_t*)(rowp[hf] + (size_t)tlen[hf] * (64u * CW));
+							er->cand_sc[j] = cand_sc[hf]; er->cand_te[j] = cand_te[hf];
+							er->ubegs[j] = ubA[hf];
+							if(j == 15){ er->ubegs[16] = ubB[hf]; er->rbeg_last = (int)rbeg[hf]; }
+							int8_t *ub = (int8_t*)(er + 1) + j * W;
+#pragma unroll
+							for(int k = 0; k < W; k++) ub[k] = (int8_t)pk_get(u[k], hf);
+						}
+					}
 				}
 			}
 		}
@@ -617,15 +645,16 @@ static hipError_t launch_fwd_codes(const Align8Args &a, hipStream_t st){
 
 // The compact path is sound only when no saturating operation can clamp and no int8 store can wrap: then the stored
 // differences are exact and the flags equal backcal's tests on reconstructed scores (checked against the literal
-// restatement on 40 k random pairs, tests/test_oracle_codes.py).  With m = max score, g = |gapo + gape|, every
+// restatement on 60 k random pairs in all three modes, tests/test_oracle_codes.py).  With m = max score, g = |gapo + gape|, every
 // intermediate of the recurrence lies within [-(m + 3g), m + g] and the synthetic band-edge cell is
-// min(smin, gapoe) - 1 - smax + gapoe (bsalign.h:2362); the limits below keep both well inside int8.
+// min(smin, gapoe) - 1 - smax + gapoe (bsalign.h:2362); the limits below keep both well inside int8 (with larger
+// scores the reference's own traceback stops terminating on divergent inputs and the two paths can disagree on which
+// pairs get flagged).
 bool bsa_align8_codes_supported(const Align8Args &a, int pw){
 	if(!bsa_align8_pk_supported(a, pw) || pw > 1) return false;
-	if((a.mode & 3) != BSA_MODE_GLOBAL) return false;
 	const int g = -((int)(int8_t)(a.gapo1 + a.gape1)), m = a.smax, n = -a.smin;
 	if(m < 0 || n < 0 || g < 0) return false;
-	return m + 3 * g <= 100 && n + m + g <= 120 && m <= 48;
+	return m + 3 * g <= 64 && n + m + g <= 100;
 }
 
 hipError_t bsa_launch_align8_fwd_codes(const Align8Args &a, int pw, hipStream_t st){

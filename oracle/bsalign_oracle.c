@@ -718,7 +718,7 @@ static long align_core(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint3
  * offset of row r (begs[0] = 0 for row -1).  Returns 0, or -1 where the literal traceback is needed (a scan leaves the
  * band, or the situation in which the reference itself does not terminate). */
 static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t *codes, const int32_t *begs, uint32_t bw,
-		orc_result_t *rs, cigv_t *cv){
+		int type, int pw, orc_result_t *rs, cigv_t *cv){
 	int prior_match = 0;
 	uint32_t cg = 0;
 	rs->qb = rs->qe; rs->qe++;
@@ -757,7 +757,12 @@ static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t
 			for(;;){
 				int r = rs->tb - len, pr;
 				if(r < -1) return -1;
-				if(r == -1){ if(rs->qb >= (int)bw) return -1; break; }   /* row -1 holds no vertical gap: the run opens there */
+				if(r == -1){
+					/* linear gaps: a deletion out of row -1 is an ordinary move.  Affine gaps: row -1 carries the e = -63 sentinel, so only
+					 * a coincidence (h == u - 63 in row 0) sends a run here; the reference then compares real scores -- literal path */
+					if(pw != 0 || rs->qb >= (int)bw) return -1;
+					break;
+				}
 				pr = rs->qb - begs[r + 1];
 				if(pr < 0 || pr >= (int)bw) return -1;
 				if(codes[((size_t)r + 1) * bw + (size_t)pr] & 8) break;
@@ -768,7 +773,8 @@ static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t
 			rs->tb -= len;
 		}
 	}
-	{
+	if(type == ORC_MODE_OVERLAP){ if(cg) cig_push(cv, cg); }
+	else {
 		uint32_t op = 0, sz = 0;
 		if(rs->qb >= 0){ op = 1; sz = (uint32_t)rs->qb + 1; rs->ins += sz; rs->qb = -1; }
 		else if(rs->tb >= 0){ op = 2; sz = (uint32_t)rs->tb + 1; rs->del += sz; rs->tb = -1; }
@@ -790,6 +796,13 @@ static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t
 long orc_align_pairwise_codes(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint32_t tlen,
 		uint32_t bandwidth, const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2,
 		orc_result_t *res, uint32_t *cig, long cap){
+	return orc_align_pairwise_codes_mode(q, qlen, tq, tlen, ORC_MODE_GLOBAL, bandwidth, mtx, gapo1, gape1, gapo2, gape2, res, cig, cap);
+}
+
+long orc_align_pairwise_codes_mode(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint32_t tlen, int mode,
+		uint32_t bandwidth, const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2,
+		orc_result_t *res, uint32_t *cig, long cap){
+	const int type = mode & 3;
 	orc_query_t qy;
 	orc_result_t rs;
 	cigv_t cv;
@@ -815,7 +828,8 @@ long orc_align_pairwise_codes(const uint8_t *q, uint32_t qlen, const uint8_t *tq
 		int8_t *mu = rowbuf + 6 * bw, *me = rowbuf + 7 * bw, *mq = rowbuf + 8 * bw;
 		int32_t *pb = ubA, *cb = ubB;
 		qy.seq = q; qy.len = qlen; qy.mtx = mtx; qy.hpc = 0; qy.bonus = 0;
-		orc_row_init(pu, pe, pq, pb, ORC_MODE_GLOBAL, bw, smax, smin, gapo1, gape1, gapo2, gape2);
+		orc_row_init(pu, pe, pq, pb, mode, bw, smax, smin, gapo1, gape1, gapo2, gape2);
+		rs.score = ORC_SCORE_MIN;
 		for(i = 0; i < tlen; i++){
 			int rbx;
 			int8_t *t8; int32_t *t32;
@@ -827,7 +841,7 @@ long orc_align_pairwise_codes(const uint8_t *q, uint32_t qlen, const uint8_t *tq
 			} else {
 				mov = 0;
 				if(rbeg) rh = ORC_SCORE_MIN;
-				else if(i == 0) rh = 0;
+				else if(type == ORC_MODE_OVERLAP || i == 0) rh = 0;
 				else rh = gapo1 + gape1 * (int)i;
 			}
 			orc_row_movx(mu, me, mq, ub0, pu, pe, pq, pb, W, mov, pw, smax, smin, gapo1, gape1, gapo2, gape2);
@@ -835,7 +849,7 @@ long orc_align_pairwise_codes(const uint8_t *q, uint32_t qlen, const uint8_t *tq
 			orc_row_cal(rbeg, tq[i], mu, me, mq, ub0, cu, ce, cq, cb, &qy, gapo1, gape1, gapo2, gape2, W, rh, pw);
 			tl_codes = NULL;
 			rbx = orc_band_mov(cb, W, i, rbeg, qlen);
-			{
+			if(type == ORC_MODE_GLOBAL){
 				int rbz = 2 * imax((int)(tlen / qlen), 1);
 				int rby = (int)((1.0 * i / tlen) * qlen);
 				uint32_t left = tlen - i - 1;
@@ -844,18 +858,29 @@ long orc_align_pairwise_codes(const uint8_t *q, uint32_t qlen, const uint8_t *tq
 				} else if((int)rbeg < rby - (int)bw) mov = (uint32_t)(rbx + 1);
 				else if((int)rbeg > rby) mov = (uint32_t)imax(0, rbx - 1);
 				else mov = (uint32_t)rbx;
-			}
+			} else mov = (uint32_t)rbx;
 			begs[i + 1] = (int32_t)rbeg;
+			if(type != ORC_MODE_GLOBAL && rbeg + bw >= qlen){ /* end-of-query score of this row (bsalign.h:4023-4032) */
+				int sc = orc_getscore(cu, cb, W, qlen - 1 - rbeg);
+				if(sc > rs.score){ rs.score = sc; rs.qe = (int)qlen - 1; rs.te = (int)i; }
+			}
 			t8 = pu; pu = cu; cu = t8; t8 = pe; pe = ce; ce = t8; t8 = pq; pq = cq; cq = t8;
 			t32 = pb; pb = cb; cb = t32;
 		}
-		if(qlen - 1 - rbeg >= bw){ free(rowbuf); free(codes); free(begs); return ORC_ERR_TRACE; }
-		rs.score = orc_getscore(pu, pb, W, qlen - 1 - rbeg);
-		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+		if(type == ORC_MODE_GLOBAL){
+			if(qlen - 1 - rbeg >= bw){ free(rowbuf); free(codes); free(begs); return ORC_ERR_TRACE; }
+			rs.score = orc_getscore(pu, pb, W, qlen - 1 - rbeg);
+			rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+		} else {
+			int32_t ms; uint32_t rmax = orc_row_max(pu, pb, W, &ms);
+			if(ms > rs.score){ rs.score = ms; rs.qe = (int)(rbeg + rmax); rs.te = (int)tlen - 1; }
+		}
 	}
 	cv.buf = cig; cv.n = 0; cv.cap = cig ? cap : 0;
 	{
-		int bad = backcal_codes(q, tq, codes, begs, bw, &rs, &cv);
+		int bad = 0;
+		if(rs.qe < begs[rs.te + 1] || rs.qe >= begs[rs.te + 1] + (int)bw) bad = 1;
+		if(!bad) bad = backcal_codes(q, tq, codes, begs, bw, type, pw, &rs, &cv);
 		free(rowbuf); free(codes); free(begs);
 		if(bad){ memset(&rs, 0, sizeof(rs)); if(res) *res = rs; return ORC_ERR_TRACE; }
 	}

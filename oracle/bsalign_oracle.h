@@ -84,6 +84,10 @@ long     orc_align_pairwise_codes(const uint8_t *q, uint32_t qlen, const uint8_t
                             uint32_t bandwidth, const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2,
                             orc_result_t *res, uint32_t *cig, long cap);
 
+long     orc_align_pairwise_codes_mode(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen, int mode,
+                            uint32_t bandwidth, const int8_t mtx[16], int gapo1, int gape1, int gapo2, int gape2,
+                            orc_result_t *res, uint32_t *cig, long cap);
+
 /* optional tracing hook for band-trajectory goldens: begs[i] = band offset of row i (tlen entries) */
 long     orc_align_pairwise_trace(const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
                             int mode, uint32_t bandwidth, const int8_t mtx[16],

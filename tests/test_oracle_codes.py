@@ -1,5 +1,5 @@
-"""CPU: the compact traceback (4-bit codes recorded by the forward pass, orc_align_pairwise_codes -- the scalar statement
-of the device's fast path for global alignments) gives exactly what the literal restatement of the reference's backcal
+"""CPU: the compact traceback (4-bit codes recorded by the forward pass, orc_align_pairwise_codes_mode -- the scalar
+statement of the device's fast path, all three modes) gives exactly what the literal restatement of the reference's backcal
 gives: result struct and CIGAR words, on random pairs and on every global golden case."""
 import ctypes as C
 import os
@@ -10,20 +10,21 @@ import pytest
 import support as S
 
 
-def codes_align(q, t, bw, M, X, O, E, Q, P):
+def codes_align(q, t, bw, M, X, O, E, Q, P, mode=0):
     o = S.oracle()
-    o.orc_align_pairwise_codes.restype = C.c_long
-    o.orc_align_pairwise_codes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_long]
+    o.orc_align_pairwise_codes_mode.restype = C.c_long
+    o.orc_align_pairwise_codes_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_long]
     mtx = S.score_matrix(M, X)
     res = np.zeros(10, np.int32)
     cap = 4 * (len(q) + len(t)) + 16
     cig = np.zeros(cap, np.uint32)
     q, t = np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(t, dtype=np.uint8)
-    n = o.orc_align_pairwise_codes(q.ctypes.data, len(q), t.ctypes.data, len(t), bw, mtx.ctypes.data, O, E, Q, P, res.ctypes.data, cig.ctypes.data, cap)
+    n = o.orc_align_pairwise_codes_mode(q.ctypes.data, len(q), t.ctypes.data, len(t), mode, bw, mtx.ctypes.data, O, E, Q, P, res.ctypes.data, cig.ctypes.data, cap)
     return res, cig[:max(n, 0)].copy(), n
 
 
-SCORINGS = [(2, -6, -3, -2, 0, 0), (2, -2, -4, -2, 0, 0), (2, -6, 0, -3, 0, 0), (1, -1, -1, -1, 0, 0), (3, -4, -6, -1, 0, 0), (10, -30, -20, -10, 0, 0)]
+# inside the guard of the device's compact path (m + 3g <= 64, |smin| + m + g <= 100)
+SCORINGS = [(2, -6, -3, -2, 0, 0), (2, -2, -4, -2, 0, 0), (2, -6, 0, -3, 0, 0), (1, -1, -1, -1, 0, 0), (3, -4, -6, -1, 0, 0), (5, -10, -8, -4, 0, 0), (4, -8, 0, -6, 0, 0)]
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -34,7 +35,7 @@ def test_codes_equal_literal_on_random_pairs(seed):
         L = int(rng.choice([1, 5, 15, 16, 17, 40, 100, 300, 800, 1500]))
         T = rng.integers(0, 4, size=L).astype(np.uint8)
         Q = S.mutate(rng, T, float(rng.choice([0.0, 0.02, 0.1, 0.2, 0.4])))
-        r = float(rng.choice([1.0, 1.0, 1.0, 0.8, 1.25, 2.0, 0.5]))
+        r = float(rng.choice([1.0, 1.0, 1.0, 0.8, 1.25, 2.0, 0.5, 0.3]))
         if r != 1.0:
             Lq = max(1, int(len(Q) * r))
             Q = Q[:Lq] if Lq <= len(Q) else np.concatenate([Q, rng.integers(0, 4, size=Lq - len(Q)).astype(np.uint8)])
@@ -42,25 +43,28 @@ def test_codes_equal_literal_on_random_pairs(seed):
             Q = np.array([1], np.uint8)
         bw = int(rng.choice([0, 16, 32, 48, 64, 128, 256]))
         sc = SCORINGS[int(rng.integers(len(SCORINGS)))]
-        res, cig, n = S.oracle_align(Q, T, S.MODE_GLOBAL, bw, *sc)
-        cres, ccig, cn = codes_align(Q, T, bw, *sc)
+        mode = int(rng.integers(3))
+        if mode and rng.random() < 0.3 and len(Q) > 10:
+            Q = Q[int(len(Q) * 0.3):]                      # overlap-like: the query is a suffix
+        res, cig, n = S.oracle_align(Q, T, mode, bw, *sc)
+        cres, ccig, cn = codes_align(Q, T, bw, *sc, mode=mode)
         if n == S.ORC_ERR_TRACE:
-            assert cn == S.ORC_ERR_TRACE, (L, len(Q), bw, sc)      # where the reference does not terminate, the codes say so too
+            assert cn == S.ORC_ERR_TRACE, (mode, L, len(Q), bw, sc)      # where the reference does not terminate, the codes say so too
             both_bad += 1
             continue
-        assert cn == n and np.array_equal(res, cres) and np.array_equal(cig, ccig), (L, len(Q), bw, sc, res, cres)
+        assert cn == n and np.array_equal(res, cres) and np.array_equal(cig, ccig), (mode, L, len(Q), bw, sc, res, cres)
         same += 1
     assert same > 600
 
 
-def test_codes_reproduce_global_goldens():
+def test_codes_reproduce_goldens():
     g = np.load(os.path.join(S.ROOT, "tests", "golden", "align8.npz"))
     done = 0
     for k in range(int(g["n"][0])):
         mode, bw, M, X, O, E, Q, P = (int(x) for x in g["meta_%d" % k])
-        if mode != S.MODE_GLOBAL or S.oracle().orc_get_piecewise(O, E, Q, P, max(bw, 16)) == 2:
+        if S.oracle().orc_get_piecewise(O, E, Q, P, max(bw, 16)) == 2:
             continue
-        res, cig, n = codes_align(g["q_%d" % k], g["t_%d" % k], bw, M, X, O, E, Q, P)
+        res, cig, n = codes_align(g["q_%d" % k], g["t_%d" % k], bw, M, X, O, E, Q, P, mode=mode)
         assert np.array_equal(res, g["res_%d" % k]) and np.array_equal(cig, g["cig_%d" % k]), k
         done += 1
-    assert done > 100
+    assert done > 300
