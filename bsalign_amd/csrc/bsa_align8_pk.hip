@@ -21,6 +21,8 @@ static __device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b){ retu
 static __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b){ return as_u32(__builtin_elementwise_sub_sat(as_v2s(a), as_v2s(b))); }
 static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b){ return as_u32(__builtin_elementwise_max(as_v2s(a), as_v2s(b))); }
 static __device__ __forceinline__ uint32_t pk_norm(uint32_t a){ return a & 0xFF00FF00u; }
+typedef unsigned short v2us_ __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ uint32_t pk_addu(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, (v2us_)(__builtin_bit_cast(v2us_, a) + __builtin_bit_cast(v2us_, b))); }
 static __device__ __forceinline__ int pk_get(uint32_t x, int h){ return h ? ((int)x >> 24) : __builtin_amdgcn_sbfe((int)x, 8, 8); }
 static __device__ __forceinline__ uint32_t pk_make(int a, int b){ return (((uint32_t)a & 0xffu) << 8) | ((uint32_t)b << 24); }
 static __device__ __forceinline__ uint32_t pk_splat(int x){ return pk_make(x, x); }
@@ -203,10 +205,13 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 	int cand_sc[2] = {BSA_SCORE_MIN, BSA_SCORE_MIN}, cand_te[2] = {0, 0};
 	uint64_t twin[2] = {0, 0};       // 8 target bases per pair, reloaded every 8th row (the staged targets carry 16 bytes of padding)
 	int rbz[2];     // 2 * max(tlen / qlen, 1): suggested max band step (bsalign.h:4008)
+	bool rush32[2];
 #pragma unroll
 	for(int h = 0; h < 2; h++){
 		if(tlen[h]) __builtin_memcpy(&twin[h], tp[h], 8);
 		rbz[h] = 2 * max((int)(tlen[h] / max(qlen[h], 1u)), 1);
+		// the rush test fits 32-bit arithmetic when rbz * tlen + qlen + bw cannot wrap
+		rush32[h] = (unsigned long long)(uint32_t)rbz[h] * tlen[h] + qlen[h] + (uint32_t)BW + (uint32_t)rbz[h] < 0xFFFFFFFFull;
 	}
 
 	// rby = (int)((1.0 * i / tlen) * qlen) (bsalign.h:4009) depends on the row number only: every 16th row each lane
@@ -581,10 +586,20 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 		}
 		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
 		bool rush[2] = {false, false};
+		// noisy = sum over the 16 blocks of |ubegs[j+1] - ubegs[j]|: both pairs in one packed u16 rotate-and-add
+		// (|difference| <= 128 W, so 16 of them stay below 65536)
+		uint32_t nzs;
+		{
+			const int d0 = ubB[0] - ubA[0], d1 = ubB[1] - ubA[1];
+			uint32_t x = (uint32_t)max(d0, -d0) | ((uint32_t)max(d1, -d1) << 16);
+			x = pk_addu(x, (uint32_t)DPP_ROR((int)x, 8)); x = pk_addu(x, (uint32_t)DPP_ROR((int)x, 4));
+			x = pk_addu(x, (uint32_t)DPP_ROR((int)x, 2)); x = pk_addu(x, (uint32_t)DPP_ROR((int)x, 1));
+			nzs = x;
+		}
+		const bool wide = __any(!rush32[0] || !rush32[1]);      // a pair too long for the 32-bit form of the rush test
 #pragma unroll
 		for(int h = 0; h < 2; h++){
-			int dsum = ubB[h] - ubA[h]; dsum = dsum < 0 ? -dsum : dsum;
-			const int nzsum = row_sum16(dsum);
+			const int nzsum = (int)(h ? (nzs >> 16) : (nzs & 0xFFFFu));
 			const int ub0 = DPP_BCAST(ubA[h], 0), ub16 = DPP_BCAST(ubB[h], 15);
 			uint32_t nz = (uint32_t)(nzsum / 16);
 			nz = nz / (uint32_t)W * 16u / 2u;
@@ -597,10 +612,13 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 			else rbx = 1;
 			if(mode == BSA_MODE_GLOBAL){
 				const int rby = __builtin_amdgcn_ds_bpermute(rby_lane + (int)((i & 15u) << 2), rby_tab[h]);
-				// "be quick to move to end": rbeg + rbz * (tlen - i - 1) + bw <= qlen + rbz - 1 (64-bit); its division is rare
+				// "be quick to move to end": rbeg + rbz * (tlen - i - 1) + bw <= qlen + rbz - 1; its division is rare
 				const uint32_t left = tlen[h] - i - 1u;
-				const unsigned long long lhs = (unsigned long long)rbeg[h] + (unsigned long long)(uint32_t)rbz[h] * left + (unsigned long long)BW;
-				rush[h] = act[h] && lhs <= (unsigned long long)(uint32_t)(qlen[h] + (uint32_t)rbz[h] - 1u);
+				if(!wide) rush[h] = act[h] && rbeg[h] + (uint32_t)rbz[h] * left + (uint32_t)BW <= qlen[h] + (uint32_t)rbz[h] - 1u;
+				else {
+					const unsigned long long lhs = (unsigned long long)rbeg[h] + (unsigned long long)(uint32_t)rbz[h] * left + (unsigned long long)BW;
+					rush[h] = act[h] && lhs <= (unsigned long long)(uint32_t)(qlen[h] + (uint32_t)rbz[h] - 1u);
+				}
 				if((int)rbeg[h] < rby - BW) mov[h] = (uint32_t)(rbx + 1);
 				else if((int)rbeg[h] > rby) mov[h] = (uint32_t)max(0, rbx - 1);
 				else mov[h] = (uint32_t)rbx;
