@@ -38,3 +38,119 @@ def gather_results(local_results, group=None):
     for part in bucket:
         out.extend(part)
     return out
+
+
+# ---- the one exchange each way of SURVEY.md 8(e): scatter the inputs, gather the results ----------------------
+# Point-to-point messages of unequal size, posted together (torch.distributed.batch_isend_irecv == one
+# ncclGroupStart / ncclGroupEnd around N-1 sends on the source rank: on MI355X that is one message per xGMI link,
+# all links busy at once).  Tensors may live on the device (backend "nccl" = RCCL) or on the host (gloo, CPU tests).
+
+def _dev(device):
+    import torch
+    return torch.device(device) if device is not None else torch.device("cpu")
+
+
+def scatter_batch(batch, bw, src=0, device=None, group=None):
+    """rank `src` passes batch = dict(seqs uint8 blob, qoff, qlen, toff, tlen as numpy); the others pass None.
+    Every rank gets its contiguous shard back as a dict of the same keys (offsets re-based to the shard's own blob,
+    `seqs` a uint8 tensor on `device`) plus `first` (global index of its first pair) and `bounds`."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = _dev(device)
+    meta = [None]
+    if rank == src:
+        qoff, qlen = np.asarray(batch["qoff"], np.uint64), np.asarray(batch["qlen"], np.uint32)
+        toff, tlen = np.asarray(batch["toff"], np.uint64), np.asarray(batch["tlen"], np.uint32)
+        bounds = partition_pairs(tlen, bw, world)
+        meta = [dict(bounds=bounds, qlen=qlen, tlen=tlen)]
+    dist.broadcast_object_list(meta, src=src, group=group)        # lengths only: a few bytes per pair
+    bounds, qlen, tlen = meta[0]["bounds"], meta[0]["qlen"], meta[0]["tlen"]
+    lo, hi = bounds[rank], bounds[rank + 1]
+    # shard layout: target k then query k, each padded to 16 bytes -- the same on every rank, so sizes are known up front
+    pad = lambda n: (int(n) + 15) & ~15
+
+    def layout(a, b):
+        to, qo, acc = [], [], 0
+        for k in range(a, b):
+            to.append(acc)
+            acc += pad(tlen[k])
+            qo.append(acc)
+            acc += pad(qlen[k])
+        return np.array(to, np.uint64), np.array(qo, np.uint64), acc
+    my_toff, my_qoff, my_bytes = layout(lo, hi)
+    mine = torch.zeros(max(my_bytes, 1), dtype=torch.uint8, device=dev)
+    ops, keep = [], []
+    if rank == src:
+        seqs = np.asarray(batch["seqs"], np.uint8)
+        for r in range(world):
+            a, b = bounds[r], bounds[r + 1]
+            to, qo, nbytes = layout(a, b)
+            blob = np.zeros(max(nbytes, 1), np.uint8)
+            for i, k in enumerate(range(a, b)):
+                blob[int(to[i]):int(to[i]) + int(tlen[k])] = seqs[int(toff[k]):int(toff[k]) + int(tlen[k])]
+                blob[int(qo[i]):int(qo[i]) + int(qlen[k])] = seqs[int(qoff[k]):int(qoff[k]) + int(qlen[k])]
+            t = torch.from_numpy(blob).to(dev)
+            if r == src:
+                mine.copy_(t)
+            elif nbytes:
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, r, group))
+    elif my_bytes:
+        ops.append(dist.P2POp(dist.irecv, mine, src, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return dict(seqs=mine, qoff=my_qoff, qlen=qlen[lo:hi].copy(), toff=my_toff, tlen=tlen[lo:hi].copy(), first=lo, bounds=bounds)
+
+
+def gather_batch(results, cigar, cigar_off, dst=0, group=None):
+    """results: [n_r, 10] int32 tensor, cigar: uint32/int32 word tensor, cigar_off: [n_r + 1] int64 offsets into it
+    (all of this rank's pairs, in pair order).  Rank `dst` returns (results [n, 10], cigar words, offsets [n + 1]) of the
+    whole batch in pair order; the other ranks return None.  Sizes first (one all_gather of two integers per rank),
+    then the payloads as grouped point-to-point messages."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = results.device
+    n_r = int(results.shape[0])
+    nw_r = int(cigar_off[n_r]) if n_r else 0
+    sizes = torch.zeros(world, 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([[n_r, nw_r]], dtype=torch.int64, device=dev), group=group)
+    sizes = sizes.cpu().numpy()
+    counts = torch.from_numpy((np.asarray(cigar_off.cpu().numpy()[1:n_r + 1]) - np.asarray(cigar_off.cpu().numpy()[:n_r])).astype(np.int64)).to(dev) \
+        if n_r else torch.zeros(0, dtype=torch.int64, device=dev)
+    res32 = results.to(torch.int32).contiguous()
+    cig32 = cigar[:nw_r].view(torch.int32).contiguous() if nw_r else torch.zeros(0, dtype=torch.int32, device=dev)
+    if rank != dst:
+        ops = []
+        if n_r:
+            ops += [dist.P2POp(dist.isend, res32, dst, group), dist.P2POp(dist.isend, counts, dst, group)]
+        if nw_r:
+            ops.append(dist.P2POp(dist.isend, cig32, dst, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return None
+    parts_r, parts_c, parts_w, ops = [], [], [], []
+    for r in range(world):
+        nr, nw = int(sizes[r, 0]), int(sizes[r, 1])
+        if r == dst:
+            parts_r.append(res32); parts_c.append(counts); parts_w.append(cig32)
+            continue
+        pr = torch.zeros(nr, 10, dtype=torch.int32, device=dev)
+        pc = torch.zeros(nr, dtype=torch.int64, device=dev)
+        pw = torch.zeros(nw, dtype=torch.int32, device=dev)
+        parts_r.append(pr); parts_c.append(pc); parts_w.append(pw)
+        if nr:
+            ops += [dist.P2POp(dist.irecv, pr, r, group), dist.P2POp(dist.irecv, pc, r, group)]
+        if nw:
+            ops.append(dist.P2POp(dist.irecv, pw, r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    allr = torch.cat(parts_r, dim=0)
+    allc = torch.cat(parts_c)
+    off = torch.zeros(allc.numel() + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(allc, dim=0)
+    return allr, torch.cat(parts_w), off

@@ -210,3 +210,18 @@ def test_chunked_batches_and_cigar_properties(monkeypatch, literal):
         assert r["aln"] == r["mat"] + r["mis"] + r["ins"] + r["del"]
     res, cig, _ = S.oracle_align(pairs[7][0], pairs[7][1], S.MODE_GLOBAL, 128, *SCORINGS["affine"])
     assert np.array_equal(np.array([out0[7][f] for f in out0.dtype.names], dtype=np.int32), res) and np.array_equal(cig0[7], cig)
+
+
+def test_sharded_flow_over_rccl_single_rank():
+    """examples/align_sharded.py under torch.distributed.run with the nccl (= RCCL) backend: scatter on device tensors,
+    align through device pointers, gather -- with the one GPU this box has (the N > 1 message pattern is covered by the
+    gloo test tests/test_shard_cpu.py)"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(S.ROOT, "examples", "align_sharded.py"), "--pairs", "300", "--length", "2000"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    assert "identical to the oracle: True" in r.stdout
