@@ -469,27 +469,42 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 	cig_cnt[ppos] = ncig;
 }
 
-hipError_t bsa_launch_align8_trace_codes(const Align8Args &a_in, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
+template<int W>
+static void launch_trace_lds(const Align8Args &a, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
+	// Pairs per wave: 32 where the batch is large enough (100 k pairs on MI355X, ms per launch: 64 -> 46, 32 -> 31.0,
+	// 16 -> 31.2, 8 -> 57: instruction issue binds at few lanes per wave, the walk's own dependent chain at many); smaller
+	// batches take fewer, so that there are still a few waves per SIMD to interleave.
+	int dev = 0, cus = 256;
+	if(hipGetDevice(&dev) == hipSuccess){
+		int v = 0;
+		if(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+	}
+	const uint32_t want_waves = (uint32_t)cus * 4u * 3u;            // about three waves per SIMD
+	uint32_t lanes = 4;
+	while(lanes < 32u && a.count / lanes > want_waves) lanes <<= 1;
+	const dim3 grid((a.count + lanes - 1) / lanes);
+	switch(lanes){
+		case 4:  hipLaunchKernelGGL((k_align8_trace_codes_lds<W, 4>), grid, dim3(64), 0, st, a, out, cig_cnt); break;
+		case 8:  hipLaunchKernelGGL((k_align8_trace_codes_lds<W, 8>), grid, dim3(64), 0, st, a, out, cig_cnt); break;
+		case 16: hipLaunchKernelGGL((k_align8_trace_codes_lds<W, 16>), grid, dim3(64), 0, st, a, out, cig_cnt); break;
+		default: hipLaunchKernelGGL((k_align8_trace_codes_lds<W, 32>), grid, dim3(64), 0, st, a, out, cig_cnt); break;
+	}
+}
+
+hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	(void)pw;
-	if(a_in.count == 0) return hipSuccess;
-	const Align8Args &a = a_in;
-	// BSA_ALIGN8_TRACE_SIMPLE=1: plain kernel (kept as the reference point); 3 / 4: other lane counts of the LDS kernel
-	static const int variant = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e ? atoi(e) : 0; }();
-	const bool simple = variant == 1;
+	if(a.count == 0) return hipSuccess;
+	// BSA_ALIGN8_TRACE_SIMPLE=1: the plain kernel (kept as the reference point)
+	static const bool simple = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
 	const uint32_t blocks = (a.count + 63u) / 64u;
 	switch(a.bw / 16){
 		case 4:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			else hipLaunchKernelGGL((k_align8_trace_codes_lds<4, 32>), dim3((a.count + 31u) / 32u), dim3(64), 0, st, a, out, cig_cnt);
+			else launch_trace_lds<4>(a, out, cig_cnt, st);
 			break;
 		case 8:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			// 32 pairs per wave measured best on MI355X for 100 k pairs (ms per launch: 64 -> 46, 32 -> 34.9, 16 -> 35.7, 8 -> 57):
-			// the kernel is bound by instruction issue (242 instructions per step and wave, SQ counters) at few lanes per
-			// wave and by the latency of its own dependent chain at many
-			else if(variant == 3) hipLaunchKernelGGL((k_align8_trace_codes_lds<8, 64>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			else if(variant == 4) hipLaunchKernelGGL((k_align8_trace_codes_lds<8, 16>), dim3((a.count + 15u) / 16u), dim3(64), 0, st, a, out, cig_cnt);
-			else hipLaunchKernelGGL((k_align8_trace_codes_lds<8, 32>), dim3((a.count + 31u) / 32u), dim3(64), 0, st, a, out, cig_cnt);
+			else launch_trace_lds<8>(a, out, cig_cnt, st);
 			break;
 		case 16: hipLaunchKernelGGL((k_align8_trace_codes_simple<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
 		default: return hipErrorInvalidValue;

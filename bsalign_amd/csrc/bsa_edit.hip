@@ -228,12 +228,13 @@ __global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a){
 // traceback (bsalign.h:965-1044) + end-cell / score selection of the driver (:1124-1139, 1180-1203)
 // one pair per lane
 // ---------------------------------------------------------------------------------------------
-// The walk is latency-bound (dependent bit lookups), so only EDIT_TRACE_LANES lanes of every wave carry a pair:
-// 4x more waves for the same batch hide 4x more latency and a step waits for the slowest of 16 lanes, not 64.
-#define EDIT_TRACE_LANES 16u
-__global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt){
-	const uint32_t g = blockIdx.x * EDIT_TRACE_LANES + threadIdx.x;
-	if(threadIdx.x >= EDIT_TRACE_LANES || g >= a.count) return;
+// The walk is latency-bound (dependent bit lookups) and every step of a wave waits for its slowest lane, so only a few
+// lanes of every wave carry a pair: as few as still let ALL waves of the launch be resident at once (8 per SIMD).
+// Measured on MI355X, 16384 pairs x 100 kbp (ms per launch): 32 lanes 151, 16 lanes 155, 8 lanes 137, 4 lanes 121,
+// 2 lanes 114 (8192 waves = 8 per SIMD); one lane per wave would need two rounds.
+__global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt, uint32_t lanes){
+	const uint32_t g = blockIdx.x * lanes + threadIdx.x;
+	if(threadIdx.x >= lanes || g >= a.count) return;
 	const uint32_t ppos = a.first + g, pair = a.order[ppos];
 	bsa_result_t rs;
 	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
@@ -432,8 +433,17 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 }
 
 hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
-	const uint32_t blocks = (a.count + EDIT_TRACE_LANES - 1) / EDIT_TRACE_LANES;
-	if(blocks == 0) return hipSuccess;
-	hipLaunchKernelGGL(k_edit_trace, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+	if(a.count == 0) return hipSuccess;
+	// fewest pairs per wave that keep every wave resident (8 waves per SIMD, 4 SIMDs per CU), a power of two in [2, 64]
+	int dev = 0, cus = 256;
+	if(hipGetDevice(&dev) == hipSuccess){
+		int v = 0;
+		if(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+	}
+	const uint32_t slots = (uint32_t)cus * 4u * 8u;
+	uint32_t lanes = 2;
+	while(lanes < 64u && (a.count + lanes - 1) / lanes > slots) lanes <<= 1;
+	const uint32_t blocks = (a.count + lanes - 1) / lanes;
+	hipLaunchKernelGGL(k_edit_trace, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt, lanes);
 	return hipGetLastError();
 }
