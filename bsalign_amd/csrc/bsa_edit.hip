@@ -30,10 +30,10 @@ static __device__ __forceinline__ u64 lowmask(uint32_t n){ return n >= 64 ? ~0ul
 
 // row records: row r (r = 0 is the initial row, r = i+1 the row of target base i): [plane0: NW u64][plane1: NW u64]
 template<int NW>
-__global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a){
+__global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lanes){
 	constexpr uint32_t BW = NW * 64;
-	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
-	if(g >= a.count) return;
+	const uint32_t g = blockIdx.x * lanes + threadIdx.x;      // `lanes` pairs per wave (bsa_launch_edit_fwd)
+	if(threadIdx.x >= lanes || g >= a.count) return;
 	const uint32_t ppos = a.first + g, pair = a.order[ppos];
 	if(a.status[pair] != 0u) return;
 	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
@@ -420,9 +420,15 @@ hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, cons
 }
 
 hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
+	if(a.count == 0) return hipSuccess;
 	const uint32_t blocks = (a.count + 63) / 64;
-	if(blocks == 0) return hipSuccess;
-#define EDIT_CASE(N) case N: hipLaunchKernelGGL((k_edit_fwd<N>), dim3(blocks), dim3(64), 0, st, a); break;
+	// pairs per wave of the register kernels (BSA_EDIT_FWD_LANES overrides, for measurements).  64 is best: a wave's time
+	// is its own serial chain (~600 instructions per row of 64-bit funnel shifts and block updates) whatever its lane
+	// count -- 16384 pairs x 100 kbp, ms per launch: 64 lanes 102, 32 -> 104, 16 -> 136, 8 -> 261, 4 -> 374
+	uint32_t lanes = 64;
+	if(const char *e = getenv("BSA_EDIT_FWD_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64) lanes = (uint32_t)v; }
+	const uint32_t fblocks = (a.count + lanes - 1) / lanes;
+#define EDIT_CASE(N) case N: hipLaunchKernelGGL((k_edit_fwd<N>), dim3(fblocks), dim3(64), 0, st, a, lanes); break;
 	switch(a.bw / 64){
 		EDIT_CASE(1) EDIT_CASE(2) EDIT_CASE(3) EDIT_CASE(4) EDIT_CASE(5) EDIT_CASE(6) EDIT_CASE(7) EDIT_CASE(8)
 		EDIT_CASE(9) EDIT_CASE(10) EDIT_CASE(11) EDIT_CASE(12) EDIT_CASE(13) EDIT_CASE(14) EDIT_CASE(15) EDIT_CASE(16)
