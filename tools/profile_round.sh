@@ -25,6 +25,11 @@ run_pmc edit WRITE_SIZE --workload edit --steps 1 --warmup 0
 run_stats poa --workload poa --steps 2 --warmup 1
 run_pmc poa FETCH_SIZE --workload poa --steps 1 --warmup 0
 run_pmc poa WRITE_SIZE --workload poa --steps 1 --warmup 0
+# SQ instruction counters of the align8 kernels (VALU / SALU / LDS / VMEM per launch): three more --pmc passes
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM"; do
+	tag=$(echo $set | cut -d' ' -f1)
+	timeout 900 rocprofv3 --pmc $set --output-format csv -d $OUT -o align8_pmc_sq_$tag -- python bench.py --steps 1 --warmup 0 --cpu-pairs -1 > $OUT/align8_pmc_sq_$tag.log 2>&1
+done
 # the bench lines themselves (with the CPU baseline), outside the profiler
 timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/align8_bench_line.json 2> $OUT/align8_bench_line.err
 timeout 900 python bench.py --workload edit --steps 3 --warmup 1 > $OUT/edit_bench_line.json 2> $OUT/edit_bench_line.err
