@@ -87,6 +87,25 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lane
 			for(int k = 0; k < NW; k++){ s += __popcll(Pv[k]) - __popcll(Mv[k]); Pv[k] = ~0ull; Mv[k] = 0ull; }
 			sbeg += s + 1;
 			load_window(rb1);
+		} else if(movx && movx < 64u){
+			// the usual band step (a few cells): one funnel shift per word with 0 < m < 64, no special cases
+			const uint32_t m = movx, r = 64u - movx;
+			const u64 mk = (1ull << m) - 1ull;
+			sbeg += __popcll(Pv[0] & mk) - __popcll(Mv[0] & mk) + 1;
+			const u64 n0 = fsr(l0c, l0n, lbit), n1 = fsr(l1c, l1n, lbit);
+#pragma unroll
+			for(int k = 0; k < NW; k++){
+				Pv[k] = (Pv[k] >> m) | (((k + 1 < NW) ? Pv[k + 1] : ~0ull) << r);
+				Mv[k] = (Mv[k] >> m) | (((k + 1 < NW) ? Mv[k + 1] : 0ull) << r);
+				Q0[k] = (Q0[k] >> m) | (((k + 1 < NW) ? Q0[k + 1] : n0) << r);
+				Q1[k] = (Q1[k] >> m) | (((k + 1 < NW) ? Q1[k + 1] : n1) << r);
+			}
+			lbit += m;
+			if(lbit >= 64u){
+				lbit -= 64u; lword++;
+				l0c = l0n; l1c = l1n;
+				l0n = Q0m[lword + 1]; l1n = Q1m[lword + 1];
+			}
 		} else {
 			while(movx){
 				const uint32_t m = movx < 64u ? movx : 64u;
