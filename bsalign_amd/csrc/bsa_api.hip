@@ -481,6 +481,8 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
 		t.smax = smax; t.smin = smin;
 		p->codes = !p->generic && !(le && le[0] == '1') && !(par->mode & BSA_MODE_ROWRECORDS) && bsa_align8_codes_supported(t, p->pw);
+		// the compact traceback packs band offsets into 26 bits of its ring entries
+		for(size_t k = 0; k < n && p->codes; k++) if(qlen[k] >= (1u << 26)) p->codes = false;
 	}
 	std::vector<uint32_t> order(n);
 	for(size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
