@@ -155,13 +155,40 @@ static __device__ __forceinline__ void rows_update(const RowsArgs &a, const bsa_
 		else if(PW < 2) rh = gapo1 + gape1 * (int)tk.toff;
 		else rh = max(gapo1 + gape1 * (int)tk.toff, gapo2 + gape2 * (int)tk.toff);
 	} else rh = BSA_SCORE_MIN;                      // replaced below by the moved ubegs[0] when the bands overlap
-	if(movx){
+	const int cfirst = (PW == 2) ? (min(nt_min, gapo2 + gape2) - 1 - nt_max + (gapo2 + gape2))
+	                             : (min(nt_min, gapo1 + gape1) - 1 - nt_max + (gapo1 + gape1));
+	const int dsw = (PW == 2) ? (gapo1 - gapo2) / (gape2 - gape1) : (BW + 1);
+	auto newcell_int = [&](int k) -> int { return (k == 0) ? cfirst : ((PW == 2 && k >= dsw) ? gape2 : gape1); };
+	auto newcell_cum = [&](int n) -> int { int n1 = min(n, dsw); return cfirst + (n1 - 1) * gape1 + ((PW == 2) ? max(0, n - dsw) * gape2 : 0); };
+	if(movx && movx < (uint32_t)W){
+		// the usual step of a few cells: single-cell shifts in registers, one DPP per plane (same as the pairwise kernel)
+		int bacc = 0;
+		for(uint32_t sft = 0; sft < movx; sft++){
+			const int nci = newcell_int((int)sft);
+			const int dropped = u[0];
+			const int in_u = DPP_SHL(trunc8(nci), u[0], 1);       // lane 15 receives the synthetic cell
+#pragma unroll
+			for(int k = 0; k + 1 < W; k++) u[k] = u[k + 1];
+			u[W - 1] = in_u;
+			if(PW >= 1){
+				const int in_e = DPP_SHL(0, e[0], 1);
+#pragma unroll
+				for(int k = 0; k + 1 < W; k++) e[k] = e[k + 1];
+				e[W - 1] = in_e;
+			}
+			if(PW == 2){
+				const int in_q = DPP_SHL(0, q2[0], 1);
+#pragma unroll
+				for(int k = 0; k + 1 < W; k++) q2[k] = q2[k + 1];
+				q2[W - 1] = in_q;
+			}
+			ubA += dropped;
+			bacc += nci;
+		}
+		ubB = DPP_SHL(ubB + bacc, ubA, 1);                        // ubegs[j+1] of the moved row; lane 15: old end + synthetic sum
+		rh = DPP_BCAST(ubA, 0);                                    // "movx -> aligned" (bspoa.h:2252)
+	} else if(movx){
 		// generic movx through LDS (bsalign.h:2244-2392)
-		const int cfirst = (PW == 2) ? (min(nt_min, gapo2 + gape2) - 1 - nt_max + (gapo2 + gape2))
-		                             : (min(nt_min, gapo1 + gape1) - 1 - nt_max + (gapo1 + gape1));
-		const int dsw = (PW == 2) ? (gapo1 - gapo2) / (gape2 - gape1) : (BW + 1);
-		auto newcell_int = [&](int k) -> int { return (k == 0) ? cfirst : ((PW == 2 && k >= dsw) ? gape2 : gape1); };
-		auto newcell_cum = [&](int n) -> int { int n1 = min(n, dsw); return cfirst + (n1 - 1) * gape1 + ((PW == 2) ? max(0, n - dsw) * gape2 : 0); };
 #pragma unroll
 		for(int k = 0; k < W; k++){
 			su[j * W + k] = (int8_t)u[k];
