@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="align8", choices=["align8", "edit", "poa"])
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: 100000 for align8, 16384 for edit; poa: POA windows, 8192)")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: 100000 for align8, 16384 for edit; poa: POA windows, 16384)")
     ap.add_argument("--length", type=int, default=0, help="target length (default 10000 / 100000; poa: graph positions per window, 10000)")
     ap.add_argument("--bw", type=int, default=0, help="bandwidth (default 128 / 256 / 128)")
     ap.add_argument("--eps", type=float, default=0.10)
@@ -115,7 +115,7 @@ def main_poa(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
-    nwin = args.pairs or 8192
+    nwin = args.pairs or 16384                                 # 4 programs per wave: 4096 waves = 4 per SIMD
     npos = args.length or 10000
     bw = args.bw or 128
     K = 8                                                    # distinct programs, windows cycle through them
