@@ -58,6 +58,11 @@ class EditParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("bandwidth", C.c_uint32)]
 
 
+class KmerParams(C.Structure):
+    """bsa_kmer_params_t: k-mer size (the reference's CLI default is 13) and host threads (0 = all)"""
+    _fields_ = [("ksz", C.c_uint32), ("threads", C.c_uint32)]
+
+
 RESULT_DTYPE = np.dtype([(n, np.int32) for n in ("score", "qb", "qe", "tb", "te", "mat", "mis", "ins", "del", "aln")])
 
 _lib = None
@@ -109,6 +114,8 @@ def lib():
             L.bsa_edit_plan_cells.argtypes = [vp]
             L.bsa_edit_plan_cells.restype = C.c_double
             L.bsa_edit_run.argtypes = [vp, u8p, vp, u32p, C.c_size_t, u64p, u32p]
+        L.bsa_kmer_edit_batch.argtypes = [vp, u8p, C.c_size_t, u64p, u32p, u64p, u32p, C.c_size_t, C.POINTER(KmerParams),
+                                          vp, u32p, C.c_size_t, u64p, u32p]
         L.bsa_rows_block_bytes.argtypes = [C.c_uint32, C.c_int8, C.c_int8, C.c_int8, C.c_int8]
         L.bsa_rows_block_bytes.restype = C.c_size_t
         L.bsa_rows_run.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(RowsParams)]
@@ -240,6 +247,12 @@ class Context:
         p = EditParams()
         p.mode, p.bandwidth = mode, bandwidth
         return self._batch(lib().bsa_edit_batch, pairs, p, cigar_cap)
+
+    def kmer_edit_batch(self, pairs, ksz=13, threads=0, cigar_cap=None):
+        """k-mer anchored edit alignment (the reference's kmer_striped_seqedit_pairwise, bsalign.h:1209) of a batch"""
+        p = KmerParams()
+        p.ksz, p.threads = ksz, threads
+        return self._batch(lib().bsa_kmer_edit_batch, pairs, p, cigar_cap)
 
 
 def synth_pairs_host(n, L, eps=0.10, seed=20240611, first_pair=0):

@@ -1,0 +1,369 @@
+/*
+ * bsa_kmer.cpp -- k-mer anchored edit alignment (the reference's kmer_striped_seqedit_pairwise,
+ * /root/reference/bsalign.h:1209-1536; `bsalign edit -m kmer -k <ksz>`, main.c:153,196-206) on top of the device
+ * edit path.
+ *
+ * The reference finds k-mers that occur exactly once in each sequence and on the same strand, chains them (longest
+ * increasing subsequence on the target offsets, then an iterated diagonal-outlier filter) and runs the plain edit DP
+ * only between consecutive anchors: the head in front of the first anchor as a reversed EXTEND alignment, the gaps as
+ * GLOBAL alignments, the tail as an EXTEND alignment.  Every one of those small alignments is independent of the
+ * others, so here the host does the chaining (threads over pairs) and ALL segments of ALL pairs of a batch go to the
+ * GPU as three bsa_edit_batch calls (reversed heads, gaps, tails); the per-pair CIGAR is then stitched on the host.
+ *
+ * Host pieces are exported on their own (bsa_kmer_chain / bsa_kmer_segments / bsa_kmer_assemble) so that the chaining
+ * and stitching can be checked without a GPU.  There is no CPU alignment in this file.
+ */
+#include "../../include/bsalign_hip.h"
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Kmer { uint32_t kmer; uint32_t off; uint8_t flg, dir; };      /* flg: 0 query, 1 target; dir: 1 = reverse strand is the canonical one */
+struct Hit  { uint32_t qoff, toff; uint8_t keep; };
+
+const uint32_t NONE = 0xFFFFFFFFu;
+
+/* all canonical k-mers of one sequence (bsalign.h:1236-1256) */
+void kmers_of(std::vector<Kmer> &dst, const uint8_t *seq, uint32_t len, uint32_t ksz, uint8_t flg){
+	const uint32_t mask = 0xFFFFFFFFu >> ((16 - ksz) << 1), top = (ksz - 1) << 1;
+	uint32_t fwd = 0, rev = 0, i;
+	for(i = 0; i + 1 < ksz && i < len; i++){
+		const uint32_t b = seq[i];
+		fwd = (fwd << 2) | b;
+		rev = (rev >> 2) | (((~b) & 3u) << top);
+	}
+	for(; i < len; i++){
+		const uint32_t b = seq[i];
+		fwd = ((fwd << 2) | b) & mask;
+		rev = (rev >> 2) | (((~b) & 3u) << top);
+		Kmer k;
+		k.dir = rev < fwd;
+		k.kmer = (k.dir ? rev : fwd) & 0x3FFFFFFFu;
+		k.flg = flg;
+		k.off = i + 1 - ksz;
+		dst.push_back(k);
+	}
+}
+
+/* coverage threshold (bsalign.h:1220-1221) */
+uint32_t min_cover(uint32_t qlen, uint32_t tlen, uint32_t ksz){
+	uint32_t c = (uint32_t)(std::min(qlen, tlen) * 0.05 + 1);
+	return std::min(c, 2 * ksz);
+}
+
+/* returns the anchors that survive, in query order (empty = align the whole pair globally) */
+void chain(uint32_t ksz, const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen, std::vector<Hit> &hits){
+	hits.clear();
+	if(ksz > 15) ksz = 15;
+	if(ksz == 0) return;
+	const uint32_t cmin = min_cover(qlen, tlen, ksz);
+	std::vector<Kmer> km;
+	km.reserve((size_t)qlen + tlen + 1);
+	kmers_of(km, q, qlen, ksz, 0);
+	kmers_of(km, t, tlen, ksz, 1);
+	/* only groups of exactly two are used below, so the order inside a group of equal k-mers does not matter */
+	std::sort(km.begin(), km.end(), [](const Kmer &a, const Kmer &b){ return a.kmer < b.kmer; });
+	const uint32_t cnt = (uint32_t)km.size();
+	Kmer zero; memset(&zero, 0, sizeof(zero));
+	km.push_back(zero);                                   /* the reference's zeroed sentinel: a run of k-mer 0 that reaches the end is never closed (bsalign.h:1259-1262) */
+	for(uint32_t b = 0, i = 0; i <= cnt; i++){
+		if(km[i].kmer == km[b].kmer) continue;
+		if(i - b == 2 && km[b].flg != km[b + 1].flg && km[b].dir == km[b + 1].dir){
+			const Kmer &kq = km[b].flg ? km[b + 1] : km[b], &kt = km[b].flg ? km[b] : km[b + 1];
+			Hit h; h.qoff = kq.off; h.toff = kt.off; h.keep = 0;
+			hits.push_back(h);
+		}
+		b = i;
+	}
+	uint32_t n = (uint32_t)hits.size();
+	if(n * ksz < cmin){ hits.clear(); return; }
+	std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b){ return a.qoff < b.qoff; });     /* keys are unique */
+	/* longest increasing subsequence over the target offsets, with the reference's predecessor rule (bsalign.h:1288-1315) */
+	std::vector<uint32_t> tail(n), prev(n);
+	tail[0] = 0; prev[0] = NONE;
+	uint32_t len = 1;
+	for(uint32_t i = 1; i < n; i++){
+		const uint32_t tv = hits[i].toff;
+		if(tv > hits[tail[len - 1]].toff){
+			prev[i] = tail[len - 1];
+			tail[len ++] = i;
+		} else if(tv <= hits[tail[0]].toff){
+			prev[i] = NONE;
+			tail[0] = i;
+		} else {
+			uint32_t b = 0, e = len;
+			while(b < e){
+				const uint32_t m = b + ((e - b) >> 1);
+				if(tv > hits[tail[m]].toff) b = m + 1;
+				else if(tv < hits[tail[m]].toff) e = m;
+				else { b = m; break; }
+			}
+			prev[i] = prev[tail[b - 1]];                   /* as written in the reference: the predecessor of that tail, not the tail */
+			tail[b] = i;
+		}
+	}
+	{
+		uint32_t cov = 0, e = NONE, m = tail[len - 1];
+		while(m != NONE){
+			Hit &h = hits[m];
+			h.keep = 1;
+			cov += (h.toff + ksz <= e) ? ksz : e - h.toff;
+			e = h.toff;
+			m = prev[m];
+		}
+		if(cov < cmin){ hits.clear(); return; }
+	}
+	/* drop anchors whose diagonal is far from the mean; repeat until stable (bsalign.h:1347-1392) */
+	std::vector<int> diag(n);
+	for(;;){
+		int tot = 0; uint32_t e = 0;
+		for(uint32_t i = 0; i < n; i++){
+			if(!hits[i].keep) continue;
+			const int d = (int)hits[i].qoff - (int)hits[i].toff;
+			tot += d;
+			diag[e ++] = d;
+		}
+		if(e * ksz < cmin) break;
+		const int mean = tot / (int)e;
+		std::nth_element(diag.begin(), diag.begin() + e / 2, diag.begin() + e);        /* quick_median_array: the element of rank e/2 */
+		const int median = diag[e / 2];
+		const int var = std::max(std::abs(median - mean) * 3, 50);
+		uint32_t dropped = 0;
+		for(uint32_t i = 0; i < n; i++){
+			if(!hits[i].keep) continue;
+			const int d = (int)hits[i].qoff - (int)hits[i].toff;
+			if(std::abs(d - mean) > var){ hits[i].keep = 0; dropped ++; }
+		}
+		if(dropped == 0) break;
+	}
+	uint32_t w = 0;
+	for(uint32_t i = 0; i < n; i++) if(hits[i].keep) hits[w ++] = hits[i];
+	hits.resize(w);
+	uint32_t cov = 0, e = 0;
+	for(uint32_t i = 0; i < w; i++){
+		cov += (hits[i].toff >= e + ksz) ? ksz : hits[i].toff + ksz - e;
+		e = hits[i].toff + ksz;
+	}
+	if(cov < cmin) hits.clear();
+}
+
+/* the segment list of one pair (bsalign.h:1451-1530): anchor i sits at (qoff + ksz/2, toff + ksz/2); the segment in
+ * front of it is aligned, the anchor column itself is emitted as a match in front of the next non-empty segment */
+uint32_t segments(uint32_t ksz, const uint64_t *maps, uint32_t kmap, uint32_t qlen, uint32_t tlen, bsa_kmer_seg_t *segs){
+	if(ksz > 15) ksz = 15;
+	uint32_t n = 0;
+	if(kmap == 0){
+		bsa_kmer_seg_t s = { 0, qlen, 0, tlen, BSA_MODE_GLOBAL, 0 };
+		segs[n ++] = s;
+		return n;
+	}
+	uint32_t qb = 0, tb = 0, ml = 0, mode = BSA_MODE_EXTEND | BSA_KMER_SEG_REVERSED;
+	for(uint32_t i = 0; i <= kmap; i++){
+		uint32_t qe, te;
+		if(i == kmap){ qe = qlen; te = tlen; mode = BSA_MODE_EXTEND; }
+		else { qe = (uint32_t)(maps[i] >> 32) + ksz / 2; te = (uint32_t)maps[i] + ksz / 2; ml ++; }
+		if(!(qb == qe && tb == te)){
+			bsa_kmer_seg_t s = { qb, qe, tb, te, mode, ml };
+			segs[n ++] = s;
+			ml = 0;
+		}
+		qb = qe + 1; tb = te + 1;
+		mode = BSA_MODE_GLOBAL;
+	}
+	return n;                                               /* matches still pending in ml are dropped, as in the reference */
+}
+
+void push_op(uint32_t *cig, uint64_t &n, uint32_t op, uint32_t sz){      /* _push_cigar_u4v, bsalign.h:401-407 */
+	if(n && (cig[n - 1] & 0xFu) == op) cig[n - 1] += sz << 4;
+	else cig[n ++] = sz << 4 | op;
+}
+
+int assemble(const bsa_kmer_seg_t *segs, uint32_t nseg, const bsa_result_t *rs2, const uint32_t *const *seg_cig, const uint64_t *seg_ncig,
+		bsa_result_t *out, uint32_t *cig, uint64_t cap, uint64_t *ncig){
+	bsa_result_t R;
+	memset(&R, 0, sizeof(R));
+	uint64_t n = 0;
+	for(uint32_t k = 0; k < nseg; k++){
+		const bsa_kmer_seg_t &s = segs[k];
+		const bsa_result_t &r = rs2[k];
+		if(n + 1 + seg_ncig[k] > cap) return BSA_E_CIGAR_CAP;
+		if(s.ml){ push_op(cig, n, 0, s.ml); R.mat += (int32_t)s.ml; R.aln += (int32_t)s.ml; }
+		if(seg_ncig[k]) memcpy(cig + n, seg_cig[k], seg_ncig[k] * sizeof(uint32_t));       /* CIGRESV appends without merging (bsalign.h:974-975,1043) */
+		n += seg_ncig[k];
+		if(s.mode & BSA_KMER_SEG_REVERSED){
+			R.qb = (int32_t)s.qe - r.qe; R.tb = (int32_t)s.te - r.te;
+			R.qe = (int32_t)s.qe; R.te = (int32_t)s.te;
+			std::reverse(cig, cig + n);
+		} else {
+			R.qe = (int32_t)s.qb + r.qe; R.te = (int32_t)s.tb + r.te;
+		}
+		R.mat += r.mat; R.mis += r.mis; R.ins += r.ins; R.del += r.del; R.aln += r.aln; R.score += r.score;
+	}
+	*out = R;
+	*ncig = n;
+	return BSA_OK;
+}
+
+template <typename F> void parallel_for(size_t n, unsigned threads, F body){
+	if(threads == 0){
+		const char *e = getenv("BSA_KMER_THREADS");
+		threads = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+		if(threads == 0) threads = 1;
+	}
+	if(threads > 64) threads = 64;
+	if(threads > n) threads = (unsigned)(n ? n : 1);
+	if(threads <= 1){ for(size_t k = 0; k < n; k++) body(k); return; }
+	std::atomic<size_t> next(0);
+	std::vector<std::thread> pool;
+	for(unsigned w = 0; w < threads; w++) pool.emplace_back([&](){
+		for(;;){
+			const size_t b = next.fetch_add(64);
+			if(b >= n) break;
+			const size_t e = std::min(n, b + 64);
+			for(size_t k = b; k < e; k++) body(k);
+		}
+	});
+	for(auto &th : pool) th.join();
+}
+
+} // namespace
+
+extern "C" uint32_t bsa_kmer_chain(uint32_t ksz, const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen, uint64_t *maps, uint32_t cap){
+	std::vector<Hit> hits;
+	chain(ksz, q, qlen, t, tlen, hits);
+	if(hits.size() > cap) return NONE;
+	for(size_t i = 0; i < hits.size(); i++) maps[i] = ((uint64_t)hits[i].qoff << 32) | hits[i].toff;
+	return (uint32_t)hits.size();
+}
+
+extern "C" uint32_t bsa_kmer_segments(uint32_t ksz, const uint64_t *maps, uint32_t kmap, uint32_t qlen, uint32_t tlen, bsa_kmer_seg_t *segs){
+	return segments(ksz, maps, kmap, qlen, tlen, segs);
+}
+
+extern "C" int bsa_kmer_assemble(const bsa_kmer_seg_t *segs, uint32_t nseg, const bsa_result_t *seg_out, const uint32_t *seg_cigar,
+		const uint64_t *seg_cigar_off, bsa_result_t *out, uint32_t *cigar, uint64_t cigar_cap_words, uint64_t *cigar_words){
+	if(!segs || !seg_out || !out || !cigar || !cigar_words || (nseg && !seg_cigar_off)) return BSA_E_ARG;
+	std::vector<const uint32_t*> ptr(nseg); std::vector<uint64_t> cnt(nseg);
+	for(uint32_t k = 0; k < nseg; k++){ ptr[k] = seg_cigar + seg_cigar_off[k]; cnt[k] = seg_cigar_off[k + 1] - seg_cigar_off[k]; }
+	return assemble(segs, nseg, seg_out, ptr.data(), cnt.data(), out, cigar, cigar_cap_words, cigar_words);
+}
+
+extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t seqs_bytes,
+		const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen, size_t n,
+		const bsa_kmer_params_t *par, bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status){
+	if(!ctx || !par || !out || (n && (!seqs || !qoff || !qlen || !toff || !tlen))) return BSA_E_ARG;
+	if(par->ksz == 0) return BSA_E_ARG;
+	const uint32_t ksz = par->ksz > 15 ? 15 : par->ksz;
+	for(size_t k = 0; k < n; k++)
+		if(qoff[k] + qlen[k] > seqs_bytes || toff[k] + tlen[k] > seqs_bytes) return BSA_E_ARG;
+	/* 1. chains and segment lists, threads over pairs */
+	std::vector<std::vector<bsa_kmer_seg_t>> segs(n);
+	parallel_for(n, par->threads, [&](size_t k){
+		std::vector<Hit> hits;
+		chain(ksz, seqs + qoff[k], qlen[k], seqs + toff[k], tlen[k], hits);
+		std::vector<uint64_t> maps(hits.size());
+		for(size_t i = 0; i < hits.size(); i++) maps[i] = ((uint64_t)hits[i].qoff << 32) | hits[i].toff;
+		segs[k].resize(hits.size() + 1);
+		segs[k].resize(segments(ksz, maps.data(), (uint32_t)maps.size(), qlen[k], tlen[k], segs[k].data()));
+	});
+	/* 2. three device batches: reversed heads (own blob), gaps and tails (views into the caller's blob) */
+	struct Job { std::vector<uint64_t> qo, to; std::vector<uint32_t> ql, tl, pair, seg; std::vector<bsa_result_t> rs; std::vector<uint32_t> cig; std::vector<uint64_t> coff; std::vector<uint32_t> st; size_t cap = 8; };
+	Job job[3];
+	std::vector<uint8_t> heads;
+	std::vector<size_t> seg_base(n + 1, 0);
+	for(size_t k = 0; k < n; k++) seg_base[k + 1] = seg_base[k] + segs[k].size();
+	std::vector<uint8_t> seg_job(seg_base[n], 0xFF); std::vector<uint32_t> seg_idx(seg_base[n], 0);
+	for(size_t k = 0; k < n; k++){
+		for(size_t j = 0; j < segs[k].size(); j++){
+			const bsa_kmer_seg_t &s = segs[k][j];
+			const uint32_t ql = s.qe - s.qb, tl = s.te - s.tb;
+			if(ql == 0 || tl == 0) continue;                  /* an empty side gives the all-zero result (bsalign.h:1051-1054) */
+			const int w = (s.mode & BSA_KMER_SEG_REVERSED) ? 0 : ((s.mode & 3) == BSA_MODE_GLOBAL ? 1 : 2);
+			Job &J = job[w];
+			if(w == 0){
+				const size_t base = heads.size();
+				heads.resize(base + ql + tl);
+				std::reverse_copy(seqs + qoff[k], seqs + qoff[k] + s.qe, heads.begin() + base);
+				std::reverse_copy(seqs + toff[k], seqs + toff[k] + s.te, heads.begin() + base + ql);
+				J.qo.push_back(base); J.to.push_back(base + ql);
+			} else {
+				J.qo.push_back(qoff[k] + s.qb); J.to.push_back(toff[k] + s.tb);
+			}
+			J.ql.push_back(ql); J.tl.push_back(tl);
+			J.cap += (size_t)ql + tl + 2;
+			seg_job[seg_base[k] + j] = (uint8_t)w;
+			seg_idx[seg_base[k] + j] = (uint32_t)J.ql.size() - 1;
+		}
+	}
+	for(int w = 0; w < 3; w++){
+		Job &J = job[w];
+		const size_t m = J.ql.size();
+		if(m == 0) continue;
+		J.rs.resize(m); J.cig.resize(J.cap); J.coff.resize(m + 1); J.st.assign(m, 0);
+		bsa_edit_params_t ep;
+		ep.mode = (w == 1) ? BSA_MODE_GLOBAL : BSA_MODE_EXTEND;
+		ep.bandwidth = 0;
+		const uint8_t *blob = (w == 0) ? heads.data() : seqs;
+		const size_t bytes = (w == 0) ? heads.size() : seqs_bytes;
+		const int rc = bsa_edit_batch(ctx, blob, bytes, J.qo.data(), J.ql.data(), J.to.data(), J.tl.data(), m, &ep,
+			J.rs.data(), J.cig.data(), J.cap, J.coff.data(), J.st.data());
+		if(rc != BSA_OK) return rc;
+	}
+	/* 3. stitch per pair */
+	std::vector<uint64_t> need(n + 1, 0);
+	for(size_t k = 0; k < n; k++){
+		uint64_t w = 0;
+		for(size_t j = 0; j < segs[k].size(); j++){
+			const size_t g = seg_base[k] + j;
+			w += 1;
+			if(seg_job[g] != 0xFF){ const Job &J = job[seg_job[g]]; w += J.coff[seg_idx[g] + 1] - J.coff[seg_idx[g]]; }
+		}
+		need[k + 1] = need[k] + w;
+	}
+	const bool want_cig = cigar != nullptr && cigar_off != nullptr;
+	std::vector<uint32_t> scratch;
+	uint32_t *work = cigar;
+	if(!want_cig || need[n] > cigar_cap_words){
+		if(want_cig) return BSA_E_CIGAR_CAP;
+		scratch.resize(need[n] + 1); work = scratch.data();
+	}
+	std::vector<uint64_t> used(n, 0);
+	std::atomic<int> bad(BSA_OK);
+	parallel_for(n, par->threads, [&](size_t k){
+		const size_t ns = segs[k].size();
+		std::vector<bsa_result_t> rs(ns); std::vector<const uint32_t*> ptr(ns); std::vector<uint64_t> cnt(ns);
+		uint32_t st = 0;
+		for(size_t j = 0; j < ns; j++){
+			const size_t g = seg_base[k] + j;
+			if(seg_job[g] == 0xFF){ memset(&rs[j], 0, sizeof(bsa_result_t)); ptr[j] = nullptr; cnt[j] = 0; continue; }
+			const Job &J = job[seg_job[g]];
+			const uint32_t x = seg_idx[g];
+			rs[j] = J.rs[x]; ptr[j] = J.cig.data() + J.coff[x]; cnt[j] = J.coff[x + 1] - J.coff[x];
+			st |= J.st[x];
+		}
+		const int rc = assemble(segs[k].data(), (uint32_t)ns, rs.data(), ptr.data(), cnt.data(), &out[k], work + need[k], need[k + 1] - need[k], &used[k]);
+		if(rc != BSA_OK) bad = rc;
+		if(status) status[k] = st;
+	});
+	if(bad != BSA_OK) return bad;
+	if(want_cig){
+		/* close the gaps left by merged match runs so that pair k owns cigar[cigar_off[k] .. cigar_off[k+1]) */
+		uint64_t w = 0;
+		for(size_t k = 0; k < n; k++){
+			cigar_off[k] = w;
+			if(w != need[k]) memmove(cigar + w, cigar + need[k], used[k] * sizeof(uint32_t));
+			w += used[k];
+		}
+		cigar_off[n] = w;
+	} else if(cigar_off){
+		uint64_t w = 0;
+		for(size_t k = 0; k < n; k++){ cigar_off[k] = w; w += used[k]; }
+		cigar_off[n] = w;
+	}
+	return BSA_OK;
+}

@@ -90,7 +90,7 @@ static int usage(void){
 		"bsalign-hip: pairwise alignment of consecutive FASTA/FASTQ records on an AMD MI355X\n"
 		"Usage: bsalign-hip align [-m global|extend|overlap] [-W bandwidth] [-M mat] [-X mis] [-O gapo1] [-E gape1]\n"
 		"                         [-Q gapo2] [-P gape2] [-L 1] [-R repeats] [-v] <in.fa[.gz]> ...\n"
-		"       bsalign-hip edit  [-m global|extend|overlap] [-W bandwidth] [-R repeats] [-v] <in.fa[.gz]> ...\n"
+		"       bsalign-hip edit  [-m global|extend|overlap|kmer] [-k ksz] [-W bandwidth] [-R repeats] [-v] <in.fa[.gz]> ...\n"
 		"Options and output are those of `bsalign align` / `bsalign edit` (penalties are given as positive numbers).\n");
 	return 1;
 }
@@ -102,15 +102,17 @@ int main(int argc, char **argv){
 	argc --; argv ++;
 	/* defaults: main.c:262-266 (align: overlap, M2 X-6 O-3 E-2 Q0 P0) and main.c:131-134 (edit: global) */
 	int mode = is_edit ? SEQALIGN_MODE_GLOBAL : SEQALIGN_MODE_OVERLAP;
-	int W_opt = 0, M = 2, X = -6, O = -3, E = -2, Q = 0, P = 0, line = 0, repm = 1, verbose = 0, c;
-	while((c = getopt(argc, argv, is_edit ? "hm:W:R:v" : "hm:W:M:X:O:E:Q:P:L:R:v")) != -1){
+	int W_opt = 0, M = 2, X = -6, O = -3, E = -2, Q = 0, P = 0, line = 0, repm = 1, verbose = 0, ksz = 13, c;     /* ksz: main.c:141 */
+	while((c = getopt(argc, argv, is_edit ? "hm:k:W:R:v" : "hm:W:M:X:O:E:Q:P:L:R:v")) != -1){
 		switch(c){
 			case 'm':
 				if(strcasecmp(optarg, "GLOBAL") == 0) mode = SEQALIGN_MODE_GLOBAL;
 				else if(strcasecmp(optarg, "EXTEND") == 0) mode = SEQALIGN_MODE_EXTEND;
 				else if(strcasecmp(optarg, "OVERLAP") == 0) mode = SEQALIGN_MODE_OVERLAP;
+				else if(is_edit && strcasecmp(optarg, "KMER") == 0) mode = SEQALIGN_MODE_KMER;      /* main.c:153 */
 				else return usage();
 				break;
+			case 'k': ksz = atoi(optarg); break;
 			case 'W': W_opt = atoi(optarg); break;
 			case 'M': M = atoi(optarg); break;
 			case 'X': X = - atoi(optarg); break;
@@ -156,7 +158,8 @@ int main(int argc, char **argv){
 			int rep;
 			memset(&rs, 0, sizeof(rs));
 			for(rep = 0; rep < (repm > 0 ? repm : 1); rep++){
-				if(is_edit) rs = striped_seqedit_pairwise(q, qlen, t, tlen, mode, (u4i)W_opt, mempool, cigars, verbose);
+				if(is_edit && mode == SEQALIGN_MODE_KMER) rs = kmer_striped_seqedit_pairwise((u1i)ksz, q, qlen, t, tlen, mempool, cigars, verbose);
+				else if(is_edit) rs = striped_seqedit_pairwise(q, qlen, t, tlen, mode, (u4i)W_opt, mempool, cigars, verbose);
 				else {
 					const u4i W = (W_opt <= 0) ? (qlen + 15u) / 16u * 16u : (u4i)W_opt;      /* main.c:314-315 */
 					rs = banded_striped_epi8_seqalign_pairwise(q, qlen, t, tlen, mempool, cigars, mode, W, mtx, (b1i)O, (b1i)E, (b1i)Q, (b1i)P, verbose);

@@ -148,6 +148,38 @@ seqalign_result_t striped_seqedit_pairwise(u1i *qseq, u4i qlen, u1i *tseq, u4i t
 	return rs;
 }
 
+seqalign_result_t kmer_striped_seqedit_pairwise(u1i ksz, u1i *qseq, u4i qlen, u1i *tseq, u4i tlen, b1v *mempool, u4v *cigars, int verbose){
+	seqalign_result_t rs;
+	bsa_kmer_params_t par;
+	bsa_result_t out;
+	uint64_t qoff = 0, toff = qlen, off[2] = {0, 0};
+	uint32_t status = 0, *cig;
+	uint8_t *seqs;
+	size_t cap = (size_t)qlen + tlen + 8;
+	int rc;
+	(void)verbose;
+	memset(&rs, 0, sizeof(rs));
+	check_mempool(mempool, __FUNCTION__);
+	if(cigars) clear_u4v(cigars);                        /* bsalign.h:1435 */
+	if(qlen == 0 || tlen == 0) return rs;                /* falls through to the global alignment's empty case, bsalign.h:1436-1438 */
+	if(ksz == 0) die("k-mer size 0", __FUNCTION__);
+	par.ksz = ksz; par.threads = 1;
+	seqs = (uint8_t*)malloc((size_t)qlen + tlen + 1);
+	cig = (uint32_t*)malloc(cap * sizeof(uint32_t));
+	memcpy(seqs, qseq, qlen); memcpy(seqs + qlen, tseq, tlen);
+	rc = bsa_kmer_edit_batch(ctx(__FUNCTION__), seqs, (size_t)qlen + tlen, &qoff, &qlen, &toff, &tlen, 1, &par, &out, cig, cap, off, &status);
+	if(rc != BSA_OK){
+		fprintf(stderr, " -- device alignment failed (%d: %s)", rc, bsa_last_error(g_ctx));
+		die("", __FUNCTION__);
+	}
+	if(status & BSA_ST_BAD_BASE) die("base code > 3 in input", __FUNCTION__);
+	if(status & BSA_ST_TRACE) die("traceback left the band", __FUNCTION__);
+	memcpy(&rs, &out, sizeof(rs));
+	deliver_cigars(cigars, 0, cig, off[1]);
+	free(seqs); free(cig);
+	return rs;
+}
+
 u4i seqalign_cigar2alnstr(u1i *qseq, u1i *tseq, seqalign_result_t *rs, u4v *cigars, char *alnstr[3], u4i length){ /* bsalign.h:531-582 */
 	static const char codes[] = "ACGTN-";
 	u4i z = 0, x, y, k, j, op, sz;

@@ -15,6 +15,7 @@
  *   banded_striped_epi8_seqalign_set_score_matrix   bsalign.h:323
  *   banded_striped_epi8_seqalign_pairwise           bsalign.h:399 / 3854
  *   striped_seqedit_pairwise                        bsalign.h:232 / 1046
+ *   kmer_striped_seqedit_pairwise                   bsalign.h:1209           (SEQALIGN_MODE_KMER, bsalign.h:33)
  *   seqalign_cigar2alnstr                           bsalign.h:394 / 531
  * Error behaviour follows the reference: a mempool whose `aligned` field is < 16 aborts with a message
  * (bsalign.h:3882-3885); "no alignment" is reported as rs.mat == 0 / zeroed result (main.c:206, 327).  Device or
@@ -40,6 +41,7 @@ typedef int8_t   b1i;
 #define SEQALIGN_MODE_GLOBAL   0
 #define SEQALIGN_MODE_OVERLAP  1
 #define SEQALIGN_MODE_EXTEND   2
+#define SEQALIGN_MODE_KMER     3   /* only as the CLI's mode switch and inside kmer_striped_seqedit_pairwise */
 #define SEQALIGN_MODEMASK_TYPE 0x3
 #define SEQALIGN_MODE_QPROF    4
 #define SEQALIGN_MODE_MEMRESV  8
@@ -82,6 +84,11 @@ seqalign_result_t banded_striped_epi8_seqalign_pairwise(u1i *qseq, u4i qlen, u1i
 
 seqalign_result_t striped_seqedit_pairwise(u1i *qseq, u4i qlen, u1i *tseq, u4i tlen, int mode, u4i bandwidth,
 		b1v *mempool, u4v *cigars, int verbose);
+
+/* k-mer anchored edit alignment: anchors are chained on the host, everything between them is aligned on the GPU in
+ * one go (bsa_kmer_edit_batch, include/bsalign_hip.h).  qseq / tseq are not modified (the reference reverses their
+ * heads in place and back, bsalign.h:1490-1495). */
+seqalign_result_t kmer_striped_seqedit_pairwise(u1i ksz, u1i *qseq, u4i qlen, u1i *tseq, u4i tlen, b1v *mempool, u4v *cigars, int verbose);
 
 u4i seqalign_cigar2alnstr(u1i *qseq, u1i *tseq, seqalign_result_t *rs, u4v *cigars, char *alnstr[3], u4i length);
 

@@ -144,6 +144,41 @@ int  bsa_edit_run(bsa_edit_plan_t *plan, const uint8_t *d_seqs,
                   bsa_result_t *d_out, uint32_t *d_cigar, size_t cigar_cap_words,
                   uint64_t *d_cigar_off, uint32_t *d_status);
 
+/* ---- k-mer anchored edit alignment (reference: kmer_striped_seqedit_pairwise, bsalign.h:1209-1536; CLI `edit -m kmer`) ---
+ * Unique same-strand k-mers (ksz <= 15) shared by the two sequences are chained on the host; only the stretches
+ * between consecutive anchors are aligned, every one of them by the device edit path (three bsa_edit_batch calls for
+ * the whole batch: reversed heads, gaps, tails), and the CIGAR of each pair is stitched together exactly as the
+ * reference does it (including where it puts the anchor matches).  A pair without a usable chain is aligned globally.
+ * All pointers are HOST memory; cigar/cigar_off/status follow bsa_edit_batch. */
+typedef struct {
+	uint32_t ksz;        /* k-mer size, values above 15 mean 15 (bsalign.h:1217); the CLI default is 13 (main.c:141) */
+	uint32_t threads;    /* host threads for chaining and stitching; 0 = all hardware threads (or $BSA_KMER_THREADS) */
+} bsa_kmer_params_t;
+
+int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t seqs_bytes,
+                        const uint64_t *qoff, const uint32_t *qlen,
+                        const uint64_t *toff, const uint32_t *tlen, size_t n,
+                        const bsa_kmer_params_t *par,
+                        bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words,
+                        uint64_t *cigar_off, uint32_t *status);
+
+/* The host-only pieces of the above, usable without a GPU.
+ * bsa_kmer_chain   : anchors of one pair in query order, maps[i] = query offset << 32 | target offset of the k-mer
+ *                    (the reference's `maps`, bsalign.h:1431-1433); returns their number, 0 when the pair has to be
+ *                    aligned as a whole, 0xFFFFFFFF when cap is too small (min(qlen, tlen) always suffices).
+ * bsa_kmer_segments: the alignments the reference would run for these anchors (bsalign.h:1451-1530), at most kmap + 1.
+ * bsa_kmer_assemble: result and CIGAR of the pair from the results of its segments. */
+#define BSA_KMER_SEG_REVERSED 0x100u   /* head segment: both sequences are aligned reversed, SEQALIGN_MODE_KMER (bsalign.h:1489-1499) */
+typedef struct {
+	uint32_t qb, qe, tb, te;   /* the segment aligns query[qb, qe) with target[tb, te); a reversed head has qb = tb = 0 */
+	uint32_t mode;             /* BSA_MODE_GLOBAL | BSA_MODE_EXTEND, optionally | BSA_KMER_SEG_REVERSED */
+	uint32_t ml;               /* anchor matches emitted in front of this segment's CIGAR */
+} bsa_kmer_seg_t;
+uint32_t bsa_kmer_chain(uint32_t ksz, const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen, uint64_t *maps, uint32_t cap);
+uint32_t bsa_kmer_segments(uint32_t ksz, const uint64_t *maps, uint32_t kmap, uint32_t qlen, uint32_t tlen, bsa_kmer_seg_t *segs);
+int      bsa_kmer_assemble(const bsa_kmer_seg_t *segs, uint32_t nseg, const bsa_result_t *seg_out, const uint32_t *seg_cigar,
+                           const uint64_t *seg_cigar_off, bsa_result_t *out, uint32_t *cigar, uint64_t cigar_cap_words, uint64_t *cigar_words);
+
 /* ---- row-level kernels for the POA seq->graph DP (P4; reference bspoa.h:2232-2272) ----------------------------
  * The POA sweep calls, per graph edge u -> v, row_movx + row_cal on u's DP row (dpalign_row_update_bspoa) and, per
  * extra in-edge, row_merge (dpalign_row_merge_bspoa).  bsa_rows_run executes a batch of such INDEPENDENT tasks (one

@@ -11,6 +11,7 @@
  *   banded_striped_epi8_seqalign_pairwise        bsalign.h:3854
  *   banded_striped_epi8_seqalign_set_score_matrix bsalign.h:323
  *   striped_seqedit_pairwise                     bsalign.h:1046
+ *   kmer_striped_seqedit_pairwise                bsalign.h:1209
  *   banded_striped_epi8_seqalign_piecex_row_init bsalign.h:2094
  *   banded_striped_epi8_seqalign_piecex_row_movx bsalign.h:2244
  *   banded_striped_epi8_seqalign_piecex_row_cal  bsalign.h:3181
@@ -78,6 +79,23 @@ long ref_edit_pairwise(void *vc, const uint8_t *q, uint32_t qlen, const uint8_t 
 	seqalign_result_t rs;
 	clear_b1v(c->mempool);
 	rs = striped_seqedit_pairwise((u1i*)q, qlen, (u1i*)t, tlen, mode, bandwidth, c->mempool, c->cigars, 0);
+	memcpy(res, &rs, sizeof(rs));
+	if((long)c->cigars->size > cap) return -(long)c->cigars->size;
+	memcpy(cig, c->cigars->buffer, c->cigars->size * sizeof(u4i));
+	return (long)c->cigars->size;
+}
+
+/* kmer_striped_seqedit_pairwise (bsalign.h:1209); the reference reverses its inputs in place and back, so work on copies */
+long ref_kmer_edit_pairwise(void *vc, int ksz, const uint8_t *q, uint32_t qlen, const uint8_t *t, uint32_t tlen,
+		int32_t *res, uint32_t *cig, long cap){
+	ref_ctx_t *c = (ref_ctx_t*)vc;
+	seqalign_result_t rs;
+	u1i *qq = (u1i*)malloc(qlen + 16), *tt = (u1i*)malloc(tlen + 16);
+	memset(qq, 0, qlen + 16); memset(tt, 0, tlen + 16);
+	memcpy(qq, q, qlen); memcpy(tt, t, tlen);
+	clear_b1v(c->mempool);
+	rs = kmer_striped_seqedit_pairwise(ksz, qq, qlen, tt, tlen, c->mempool, c->cigars, 0);
+	free(qq); free(tt);
 	memcpy(res, &rs, sizeof(rs));
 	if((long)c->cigars->size > cap) return -(long)c->cigars->size;
 	memcpy(cig, c->cigars->buffer, c->cigars->size * sizeof(u4i));

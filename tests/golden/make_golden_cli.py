@@ -63,6 +63,8 @@ def main():
         ("c1_edit_w128", ["edit", "-W", "128", "c1.fa"]),
         ("multi_edit_overlap", ["edit", "-m", "overlap", "multi.fa"]),
         ("multi_edit_extend", ["edit", "-m", "extend", "multi.fa"]),
+        ("c1_edit_kmer", ["edit", "-m", "kmer", "c1.fa"]),
+        ("multi_edit_kmer_k9", ["edit", "-m", "kmer", "-k", "9", "multi.fa"]),
     ]
     manifest = []
     for name, args in cases:
