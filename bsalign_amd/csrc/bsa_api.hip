@@ -672,19 +672,6 @@ struct bsa_edit_plan : PlanBase {
 	int32_t *d_sbeg = nullptr;
 };
 
-// effective bandwidth of one pair (bsalign.h:1055-1067)
-static uint32_t edit_bw_eff(uint32_t qlen, uint32_t tlen, int type, uint32_t bandwidth){
-	const uint32_t qround = (qlen + 63u) / 64u * 64u;
-	if(type == BSA_MODE_OVERLAP || type == BSA_MODE_EXTEND) return qround;
-	uint32_t bw = (bandwidth + 63u) / 64u * 64u;
-	if(bw == 0 || bw > qlen) bw = qround;
-	if(bw < qlen){
-		const uint32_t step = (qlen + tlen - 1) / tlen + 1;
-		if(bw < step) bw = (step + 63u) / 64u * 64u;
-	}
-	return bw;
-}
-
 extern "C" void bsa_edit_plan_destroy(bsa_edit_plan_t *p){ plan_free(p); }
 extern "C" double bsa_edit_plan_cells(const bsa_edit_plan_t *p){ return p ? p->cells : 0.0; }
 
@@ -701,7 +688,7 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 	std::vector<uint32_t> bwk(n), order(n), qwords(n);
 	double cells = 0;
 	for(size_t k = 0; k < n; k++){
-		bwk[k] = (qlen[k] && tlen[k]) ? edit_bw_eff(qlen[k], tlen[k], type, par->bandwidth) : 64u;
+		bwk[k] = (qlen[k] && tlen[k]) ? bsa_edit_bw_eff(qlen[k], tlen[k], type, par->bandwidth) : 64u;
 		if(!bsa_edit_supported_bw(bwk[k])){
 			c->err = "effective edit bandwidth must be a multiple of 64";
 			plan_free(p); return BSA_E_UNSUPPORTED;
@@ -722,7 +709,7 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 	}
 	for(size_t pos = 0; pos < n; pos++){
 		const uint32_t k = order[pos];
-		bwv[pos] = bwk[k];
+		bwv[pos] = bsa_edit_class(bwk[k]);     // bands wider than the register kernels: a few classes, each one launch
 		need[pos] = ((size_t)tlen[k] + 1 + p->pad_rows) * (size_t)(bwk[k] / 64u) * 16;
 	}
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
@@ -759,15 +746,17 @@ extern "C" int bsa_edit_run(bsa_edit_plan_t *p, const uint8_t *d_seqs, bsa_resul
 	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
 	a.qbits = p->d_qbits; a.qboff = p->d_qboff; a.qwords = p->d_qwords;
 	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
-	a.status = status; a.fwd_sbeg = p->d_sbeg; a.pad_rows = p->pad_rows; a.mode = p->par.mode;
+	a.status = status; a.fwd_sbeg = p->d_sbeg; a.pad_rows = p->pad_rows; a.mode = p->par.mode; a.bandwidth = p->par.bandwidth;
 	uint32_t *cnt = p->d_cnt_pos;
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
-		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.bw = ch.bw; b.rows = half;
+		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
+		b.bw = ch.bw <= BSA_EDIT_REG_BW ? ch.bw : 0u; b.wide = ch.bw <= BSA_EDIT_REG_BW ? 0u : (ch.bw & 0xFFu);
 		HIPCHK(c, bsa_launch_edit_fwd(b, s));
 		return BSA_OK;
 	};
 	auto trace = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
-		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.bw = ch.bw; b.rows = half;
+		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
+		b.bw = ch.bw <= BSA_EDIT_REG_BW ? ch.bw : 0u; b.wide = ch.bw <= BSA_EDIT_REG_BW ? 0u : (ch.bw & 0xFFu);
 		HIPCHK(c, bsa_launch_edit_trace(b, d_out, cnt, s));
 		return BSA_OK;
 	};

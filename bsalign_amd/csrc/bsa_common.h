@@ -80,6 +80,30 @@ static inline __host__ __device__ int bsa_get_piecewise(int gapo1, int gape1, in
 }
 
 // device-side description of one batch chunk of the 2-bit edit path
+// effective bandwidth of one pair (bsalign.h:1055-1067)
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint32_t bsa_edit_bw_eff(uint32_t qlen, uint32_t tlen, int type, uint32_t bandwidth){
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+	if(type == BSA_MODE_OVERLAP || type == BSA_MODE_EXTEND) return qround;
+	uint32_t bw = (bandwidth + 63u) / 64u * 64u;
+	if(bw == 0 || bw > qlen) bw = qround;
+	if(bw < qlen){
+		const uint32_t step = (qlen + tlen - 1) / tlen + 1;
+		if(bw < step) bw = (step + 63u) / 64u * 64u;
+	}
+	return bw;
+}
+#define BSA_EDIT_REG_BW 1024u       // widest band of the register kernels (16 words)
+// launch classes of the edit plan: the band itself up to BSA_EDIT_REG_BW; above, by the words per lane the wave-per-pair
+// kernel needs (64 lanes x WPL words x 64 columns), 0 = only the generic kernel is left
+static inline uint32_t bsa_edit_class(uint32_t bw){
+	if(bw <= BSA_EDIT_REG_BW) return bw;
+	const uint32_t nw = bw / 64u;
+	return nw <= 64u ? 0xFFFFFF01u : nw <= 128u ? 0xFFFFFF02u : nw <= 256u ? 0xFFFFFF04u : 0xFFFFFF00u;
+}
+
 struct EditArgs {
 	const uint8_t  *qst, *tst;      // staged query / target bytes (codes 0..3)
 	const uint64_t *qpoff, *tpoff;  // [n]
@@ -93,7 +117,10 @@ struct EditArgs {
 	uint32_t       *status;         // [n] per original pair
 	int32_t        *fwd_sbeg;       // [n] by processing position: H at the band start of the last row
 	uint32_t first, count;
-	uint32_t bw;                    // effective bandwidth of this launch (multiple of 64)
+	uint32_t bw;                    // effective bandwidth of this launch (multiple of 64); 0 = wide class, every pair has its own
+	                                //   (bsa_edit_bw_eff of its lengths), all above 1024 -- one launch of the generic kernel
+	uint32_t bandwidth;             // the caller's bandwidth parameter, for bsa_edit_bw_eff
+	uint32_t wide;                  // bw == 0 only: words per lane of the wave-per-pair kernel for static bands (1, 2, 4), 0 = none
 	uint32_t pad_rows;              // spare row records at the end of every slot (CIGAR scratch)
 	int32_t  mode;
 };

@@ -169,13 +169,14 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lane
 // planes are taken straight from the staged bit planes at the row's band offset.  One pair per lane, NW a run-time
 // value; used when NW > 16, i.e. for the full-width bands of overlap / extend mode and of `bandwidth 0` on queries
 // longer than 1024 bp (bsalign.h:1055-1067).  Streaming loads and stores, four words in and two out per 64 cells.
-__global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a){
-	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
-	if(g >= a.count) return;
+__global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a, uint32_t lanes){
+	const uint32_t g = blockIdx.x * lanes + threadIdx.x;
+	if(threadIdx.x >= lanes || g >= a.count) return;
 	const uint32_t ppos = a.first + g, pair = a.order[ppos];
 	if(a.status[pair] != 0u) return;
 	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
-	const uint32_t NW = a.bw / 64u, BW = a.bw;
+	const uint32_t BW = a.bw ? a.bw : bsa_edit_bw_eff(qlen, tlen, a.mode & 3, a.bandwidth), NW = BW / 64u;
+	if(a.wide != 0u && BW == (qlen + 63u) / 64u * 64u) return;      // static band: done by k_edit_fwd_wide in the same launch
 	const u64 *Q0m = a.qbits + a.qboff[pair];
 	const u64 *Q1m = Q0m + a.qwords[pair];
 	const uint8_t *tp = a.tst + a.tpoff[pair];
@@ -243,6 +244,124 @@ __global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a){
 	a.fwd_sbeg[ppos] = sbeg;
 }
 
+// ---- wide static bands: one pair per WAVE -----------------------------------------------------------------------
+// Overlap / extend mode and `bandwidth 0` make the band the whole (rounded) query, so it never moves: no row_movx, the
+// query planes of a word are the same for every row and the whole band state fits the wave's registers -- lane l owns
+// words l*WPL .. l*WPL+WPL-1 (up to 64*WPL*64 = 16384 query columns for WPL = 4).  What is left of the serial chain
+// across words is one number per word, the horizontal delta hin in {-1, 0, +1} entering it, and the block update only
+// looks at its sign: Xh takes (hin < 0) as bit 0 of Eq, (hin > 0) is just shifted into Ph afterwards.  So every lane
+// evaluates its words for both cases (a negative delta entering or not), the wave resolves the chain in scalar code
+//     neg[k+1] = neg[k] ? B[k] : A[k],   A[k] = hout(k | not negative) < 0,  B[k] = hout(k | negative) < 0
+// as the carry chain of a 64-bit addition (A generates, B propagates; lowering the delta entering a block never raises
+// the one leaving it, so A implies B -- if a word ever violates that the chain is walked bit by bit instead), and each
+// lane then keeps the variant that was right.  Row records are identical to the other forward kernels' (natural word
+// order), written as one coalesced 8*WPL-byte store per lane and plane.
+static __device__ __forceinline__ uint32_t mask_pick(uint32_t if0, uint32_t if1, u64 mask){   // per lane: bit `lane` of mask ? if1 : if0
+	uint32_t r;
+	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+	return r;
+}
+static __device__ __forceinline__ u64 mask_pick64(u64 if0, u64 if1, u64 mask){
+	const uint32_t lo = mask_pick((uint32_t)if0, (uint32_t)if1, mask), hi = mask_pick((uint32_t)(if0 >> 32), (uint32_t)(if1 >> 32), mask);
+	return (u64)hi << 32 | lo;
+}
+static __device__ __forceinline__ u64 uniform64(u64 x){      // tell the compiler the value is wave-uniform (it is): keep it in SGPRs
+	return (u64)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32 | (u64)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x);
+}
+// carries of the chain neg[k+1] = neg[k] ? B[k] : A[k] with neg[0] = 0; bit k of the result = neg[k]
+static __device__ __forceinline__ u64 chain_neg(u64 A, u64 B){
+	if(__builtin_expect((A & ~B) == 0ull, 1)) return (A + B) ^ A ^ B;
+	u64 C = 0, c = 0;
+	for(int k = 0; k < 63; k++){ c = c ? (B >> k) & 1ull : (A >> k) & 1ull; C |= c << (k + 1); }
+	return C;
+}
+
+template<int WPL>
+__global__ void __launch_bounds__(256) k_edit_fwd_wide(const EditArgs a){
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+	if(g >= a.count) return;
+	const uint32_t ppos = a.first + g, pair = a.order[ppos];
+	if(a.status[pair] != 0u) return;
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const int type = a.mode & 3;
+	const uint32_t BW = bsa_edit_bw_eff(qlen, tlen, type, a.bandwidth), NW = BW / 64u;
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+	if(BW != qround || NW > 64u * WPL || (WPL > 1 && NW <= 32u * WPL)) return;      // moving or other-size band: another kernel of this launch
+	const u64 *Q0m = a.qbits + a.qboff[pair];
+	const u64 *Q1m = Q0m + a.qwords[pair];
+	const uint8_t *tp = a.tst + a.tpoff[pair];
+	u64 *rows = (u64*)(a.rows + a.slot_off[ppos]);
+	const bool overlap = type == BSA_MODE_OVERLAP;
+	const uint32_t w0 = lane * WPL;
+	u64 q0[WPL], q1[WPL], vm[WPL], pv[WPL], mv[WPL];
+	bool act[WPL];
+#pragma unroll
+	for(int j = 0; j < WPL; j++){
+		const uint32_t w = w0 + j;
+		act[j] = w < NW;
+		q0[j] = act[j] ? Q0m[w] : 0ull; q1[j] = act[j] ? Q1m[w] : 0ull;
+		vm[j] = (qlen > w * 64u) ? lowmask(qlen - w * 64u) : 0ull;          // band cells that are real query columns (:1112 nvalid)
+		pv[j] = ~0ull; mv[j] = 0ull;
+		if(act[j]){ rows[w] = 0ull; rows[NW + w] = ~0ull; }                    // row_init (:653-656)
+	}
+	const u64 hin0_pos = overlap ? 0ull : 1ull;                                // left of the band v = +1, 0 in overlap mode (:770)
+	u64 tw = 0;
+	for(uint32_t i = 0; i < tlen; i++){
+		if((i & 7u) == 0){
+			const u64 *wp = (const u64*)(tp + i);                                // staged 16-byte aligned with >= 8 bytes of padding
+			u64 v = *wp;
+			tw = uniform64(v);
+		}
+		const uint32_t tb = (uint32_t)(tw >> (8u * (i & 7u))) & 3u;
+		const u64 x0 = (tb & 1u) ? 0ull : ~0ull, x1 = (tb & 2u) ? 0ull : ~0ull;
+		u64 Xv[WPL], t[2][WPL];
+		bool n[2][WPL + 1], pz[2][WPL];          // n[s][j]: a negative delta enters word j when one enters the lane (s = 1) or not (s = 0)
+		n[0][0] = false; n[1][0] = true;
+#pragma unroll
+		for(int j = 0; j < WPL; j++){
+			const u64 Eq = (q0[j] ^ x0) & (q1[j] ^ x1) & vm[j];
+			Xv[j] = Eq | mv[j];
+			const u64 e1 = Eq | 1ull;
+			const u64 t0 = (((Eq & pv[j]) + pv[j]) ^ pv[j]) | Eq;
+			const u64 t1 = (((e1 & pv[j]) + pv[j]) ^ pv[j]) | e1;
+#pragma unroll
+			for(int sI = 0; sI < 2; sI++){
+				const u64 xh = n[sI][j] ? t1 : t0;
+				t[sI][j] = xh;
+				const uint32_t ph = (uint32_t)((mv[j] | ~(xh | pv[j])) >> 63), mh = (uint32_t)((pv[j] & xh) >> 63);
+				n[sI][j + 1] = act[j] ? (mh > ph) : n[sI][j];      // idle words pass the delta through (never used)
+				pz[sI][j] = ph > mh;
+			}
+		}
+		const u64 A = __ballot(n[0][WPL]), B = __ballot(n[1][WPL]);
+		const u64 C = uniform64(chain_neg(A, B));                                // bit l: a negative delta enters lane l
+		// the delta leaving each lane, as masks, for the shift-in of the next lane's first word
+		const u64 PA = __ballot(pz[0][WPL - 1]), PB = __ballot(pz[1][WPL - 1]);
+		const u64 Ppos = uniform64(((PA & ~C) | (PB & C)) << 1 | hin0_pos);    // bit l: a positive delta enters lane l
+#pragma unroll
+		for(int j = 0; j < WPL; j++){
+			const u64 Xh = mask_pick64(t[0][j], t[1][j], C);
+			u64 Ph = mv[j] | ~(Xh | pv[j]);
+			u64 Mh = pv[j] & Xh;
+			u64 hneg, hpos;
+			if(j == 0){ hneg = mask_pick(0u, 1u, C); hpos = mask_pick(0u, 1u, Ppos); }
+			else { hneg = mask_pick((uint32_t)n[0][j], (uint32_t)n[1][j], C); hpos = mask_pick((uint32_t)pz[0][j - 1], (uint32_t)pz[1][j - 1], C); }
+			Ph = (Ph << 1) | hpos;
+			Mh = (Mh << 1) | hneg;
+			pv[j] = Mh | ~(Xv[j] | Ph);
+			mv[j] = Ph & Xv[j];
+		}
+		u64 *rp = rows + (size_t)(i + 1) * (2 * NW);
+		if(WPL == 1){ if(act[0]){ rp[w0] = mv[0]; rp[NW + w0] = pv[0]; } }
+		else {
+#pragma unroll
+			for(int j = 0; j < WPL; j++) if(act[j]){ rp[w0 + j] = mv[j]; rp[NW + w0 + j] = pv[j]; }
+		}
+	}
+	if(lane == 0) a.fwd_sbeg[ppos] = overlap ? 0 : (int)tlen;                     // no band motion: H at the band start grows by one per row (:667-676)
+}
+
 // ---------------------------------------------------------------------------------------------
 // traceback (bsalign.h:965-1044) + end-cell / score selection of the driver (:1124-1139, 1180-1203)
 // one pair per lane
@@ -259,7 +378,7 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
 	if(a.status[pair] != 0u){ out[pair] = rs; cig_cnt[ppos] = 0; return; }
 	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
-	const uint32_t NW = a.bw / 64u, BW = a.bw;
+	const uint32_t BW = a.bw ? a.bw : bsa_edit_bw_eff(qlen, tlen, a.mode & 3, a.bandwidth), NW = BW / 64u;
 	const uint8_t *qs = a.qst + a.qpoff[pair];
 	const uint8_t *ts = a.tst + a.tpoff[pair];
 	const u64 *rows = (const u64*)(a.rows + a.slot_off[ppos]);
@@ -440,7 +559,6 @@ hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, cons
 
 hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
-	const uint32_t blocks = (a.count + 63) / 64;
 	// pairs per wave of the register kernels (BSA_EDIT_FWD_LANES overrides, for measurements).  64 is best: a wave's time
 	// is its own serial chain (~600 instructions per row of 64-bit funnel shifts and block updates) whatever its lane
 	// count -- 16384 pairs x 100 kbp, ms per launch: 64 lanes 102, 32 -> 104, 16 -> 136, 8 -> 261, 4 -> 374
@@ -451,7 +569,18 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 	switch(a.bw / 64){
 		EDIT_CASE(1) EDIT_CASE(2) EDIT_CASE(3) EDIT_CASE(4) EDIT_CASE(5) EDIT_CASE(6) EDIT_CASE(7) EDIT_CASE(8)
 		EDIT_CASE(9) EDIT_CASE(10) EDIT_CASE(11) EDIT_CASE(12) EDIT_CASE(13) EDIT_CASE(14) EDIT_CASE(15) EDIT_CASE(16)
-		default: hipLaunchKernelGGL(k_edit_fwd_gen, dim3(blocks), dim3(64), 0, st, a); break;
+		default: {
+			// bands above 1024: static ones (overlap / extend / bandwidth 0) one pair per wave, the rest one pair per lane
+			if(a.wide == 1u) hipLaunchKernelGGL((k_edit_fwd_wide<1>), dim3((a.count + 3) / 4), dim3(256), 0, st, a);
+			else if(a.wide == 2u) hipLaunchKernelGGL((k_edit_fwd_wide<2>), dim3((a.count + 3) / 4), dim3(256), 0, st, a);
+			else if(a.wide == 4u) hipLaunchKernelGGL((k_edit_fwd_wide<4>), dim3((a.count + 3) / 4), dim3(256), 0, st, a);
+			if(a.wide == 0u || ((a.mode & 3) == BSA_MODE_GLOBAL && a.bandwidth != 0u)){
+				uint32_t gl = 64;
+				while(gl > 2u && (a.count + gl / 2 - 1) / (gl / 2) <= 8192u) gl >>= 1;
+				if(const char *e = getenv("BSA_EDIT_GEN_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64) gl = (uint32_t)v; }
+				hipLaunchKernelGGL(k_edit_fwd_gen, dim3((a.count + gl - 1) / gl), dim3(64), 0, st, a, gl);
+			}
+		} break;
 	}
 #undef EDIT_CASE
 	return hipGetLastError();

@@ -8,7 +8,7 @@
  * only between consecutive anchors: the head in front of the first anchor as a reversed EXTEND alignment, the gaps as
  * GLOBAL alignments, the tail as an EXTEND alignment.  Every one of those small alignments is independent of the
  * others, so here the host does the chaining (threads over pairs) and ALL segments of ALL pairs of a batch go to the
- * GPU as three bsa_edit_batch calls (reversed heads, gaps, tails); the per-pair CIGAR is then stitched on the host.
+ * GPU as two bsa_edit_batch calls (EXTEND: reversed heads and tails; GLOBAL: gaps); the per-pair CIGAR is then stitched on the host.
  *
  * Host pieces are exported on their own (bsa_kmer_chain / bsa_kmer_segments / bsa_kmer_assemble) so that the chaining
  * and stitching can be checked without a GPU.  There is no CPU alignment in this file.
@@ -16,6 +16,8 @@
 #include "../../include/bsalign_hip.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -23,13 +25,18 @@
 
 namespace {
 
-struct Kmer { uint32_t kmer; uint32_t off; uint8_t flg, dir; };      /* flg: 0 query, 1 target; dir: 1 = reverse strand is the canonical one */
 struct Hit  { uint32_t qoff, toff; uint8_t keep; };
 
 const uint32_t NONE = 0xFFFFFFFFu;
 
+/* one k-mer occurrence in 64 bits: canonical k-mer (30) | offset (32) | from the target (1) | reverse strand is canonical (1) */
+inline uint32_t km_kmer(uint64_t x){ return (uint32_t)(x >> 34); }
+inline uint32_t km_off(uint64_t x){ return (uint32_t)(x >> 2); }
+inline uint32_t km_flg(uint64_t x){ return (uint32_t)(x >> 1) & 1u; }
+inline uint32_t km_dir(uint64_t x){ return (uint32_t)x & 1u; }
+
 /* all canonical k-mers of one sequence (bsalign.h:1236-1256) */
-void kmers_of(std::vector<Kmer> &dst, const uint8_t *seq, uint32_t len, uint32_t ksz, uint8_t flg){
+void kmers_of(std::vector<uint64_t> &dst, const uint8_t *seq, uint32_t len, uint32_t ksz, uint32_t flg){
 	const uint32_t mask = 0xFFFFFFFFu >> ((16 - ksz) << 1), top = (ksz - 1) << 1;
 	uint32_t fwd = 0, rev = 0, i;
 	for(i = 0; i + 1 < ksz && i < len; i++){
@@ -41,13 +48,31 @@ void kmers_of(std::vector<Kmer> &dst, const uint8_t *seq, uint32_t len, uint32_t
 		const uint32_t b = seq[i];
 		fwd = ((fwd << 2) | b) & mask;
 		rev = (rev >> 2) | (((~b) & 3u) << top);
-		Kmer k;
-		k.dir = rev < fwd;
-		k.kmer = (k.dir ? rev : fwd) & 0x3FFFFFFFu;
-		k.flg = flg;
-		k.off = i + 1 - ksz;
-		dst.push_back(k);
+		const uint32_t dir = rev < fwd;
+		const uint64_t kmer = (dir ? rev : fwd) & 0x3FFFFFFFu;
+		dst.push_back(kmer << 34 | (uint64_t)(i + 1 - ksz) << 2 | flg << 1 | dir);
 	}
+}
+
+/* LSD radix sort on the k-mer bits only (2 * ksz of them); the order inside a run of equal k-mers is not used */
+void sort_by_kmer(std::vector<uint64_t> &a, std::vector<uint64_t> &tmp, uint32_t ksz){
+	const size_t n = a.size();
+	if(n < 256){ std::sort(a.begin(), a.end()); return; }
+	tmp.resize(n);
+	uint64_t *src = a.data(), *dst = tmp.data();
+	const uint32_t bits = 2 * ksz;
+	const uint32_t passes = (bits + 10) / 11;
+	const uint32_t per = (bits + passes - 1) / passes;
+	for(uint32_t p = 0; p < passes; p++){
+		const uint32_t sh = 34 + p * per, m = (1u << per) - 1;
+		uint32_t cnt[2049];
+		memset(cnt, 0, sizeof(uint32_t) * ((size_t)m + 2));
+		for(size_t i = 0; i < n; i++) cnt[((src[i] >> sh) & m) + 1] ++;
+		for(uint32_t v = 0; v < m; v++) cnt[v + 1] += cnt[v];
+		for(size_t i = 0; i < n; i++) dst[cnt[(src[i] >> sh) & m] ++] = src[i];
+		std::swap(src, dst);
+	}
+	if(src != a.data()) memcpy(a.data(), src, n * sizeof(uint64_t));
 }
 
 /* coverage threshold (bsalign.h:1220-1221) */
@@ -62,20 +87,18 @@ void chain(uint32_t ksz, const uint8_t *q, uint32_t qlen, const uint8_t *t, uint
 	if(ksz > 15) ksz = 15;
 	if(ksz == 0) return;
 	const uint32_t cmin = min_cover(qlen, tlen, ksz);
-	std::vector<Kmer> km;
+	std::vector<uint64_t> km, tmp;
 	km.reserve((size_t)qlen + tlen + 1);
 	kmers_of(km, q, qlen, ksz, 0);
 	kmers_of(km, t, tlen, ksz, 1);
-	/* only groups of exactly two are used below, so the order inside a group of equal k-mers does not matter */
-	std::sort(km.begin(), km.end(), [](const Kmer &a, const Kmer &b){ return a.kmer < b.kmer; });
+	sort_by_kmer(km, tmp, ksz);
 	const uint32_t cnt = (uint32_t)km.size();
-	Kmer zero; memset(&zero, 0, sizeof(zero));
-	km.push_back(zero);                                   /* the reference's zeroed sentinel: a run of k-mer 0 that reaches the end is never closed (bsalign.h:1259-1262) */
+	km.push_back(0);                                      /* the reference's zeroed sentinel: a run of k-mer 0 that reaches the end is never closed (bsalign.h:1259-1262) */
 	for(uint32_t b = 0, i = 0; i <= cnt; i++){
-		if(km[i].kmer == km[b].kmer) continue;
-		if(i - b == 2 && km[b].flg != km[b + 1].flg && km[b].dir == km[b + 1].dir){
-			const Kmer &kq = km[b].flg ? km[b + 1] : km[b], &kt = km[b].flg ? km[b] : km[b + 1];
-			Hit h; h.qoff = kq.off; h.toff = kt.off; h.keep = 0;
+		if(km_kmer(km[i]) == km_kmer(km[b])) continue;
+		if(i - b == 2 && km_flg(km[b]) != km_flg(km[b + 1]) && km_dir(km[b]) == km_dir(km[b + 1])){
+			const uint64_t kq = km_flg(km[b]) ? km[b + 1] : km[b], kt = km_flg(km[b]) ? km[b] : km[b + 1];
+			Hit h; h.qoff = km_off(kq); h.toff = km_off(kt); h.keep = 0;
 			hits.push_back(h);
 		}
 		b = i;
@@ -261,6 +284,10 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 	const uint32_t ksz = par->ksz > 15 ? 15 : par->ksz;
 	for(size_t k = 0; k < n; k++)
 		if(qoff[k] + qlen[k] > seqs_bytes || toff[k] + tlen[k] > seqs_bytes) return BSA_E_ARG;
+	const bool timing = getenv("BSA_KMER_TIMING") != nullptr;          /* phase times on stderr */
+	auto now = [](){ return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b){ return std::chrono::duration<double, std::milli>(b - a).count(); };
+	auto t0 = now();
 	/* 1. chains and segment lists, threads over pairs */
 	std::vector<std::vector<bsa_kmer_seg_t>> segs(n);
 	parallel_for(n, par->threads, [&](size_t k){
@@ -271,9 +298,11 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 		segs[k].resize(hits.size() + 1);
 		segs[k].resize(segments(ksz, maps.data(), (uint32_t)maps.size(), qlen[k], tlen[k], segs[k].data()));
 	});
-	/* 2. three device batches: reversed heads (own blob), gaps and tails (views into the caller's blob) */
+	auto t1 = now();
+	/* 2. two device batches: EXTEND for the reversed heads and the tails (copied into one blob), GLOBAL for the gaps
+	 *    (views into the caller's blob) */
 	struct Job { std::vector<uint64_t> qo, to; std::vector<uint32_t> ql, tl, pair, seg; std::vector<bsa_result_t> rs; std::vector<uint32_t> cig; std::vector<uint64_t> coff; std::vector<uint32_t> st; size_t cap = 8; };
-	Job job[3];
+	Job job[2];
 	std::vector<uint8_t> heads;
 	std::vector<size_t> seg_base(n + 1, 0);
 	for(size_t k = 0; k < n; k++) seg_base[k + 1] = seg_base[k] + segs[k].size();
@@ -283,13 +312,18 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 			const bsa_kmer_seg_t &s = segs[k][j];
 			const uint32_t ql = s.qe - s.qb, tl = s.te - s.tb;
 			if(ql == 0 || tl == 0) continue;                  /* an empty side gives the all-zero result (bsalign.h:1051-1054) */
-			const int w = (s.mode & BSA_KMER_SEG_REVERSED) ? 0 : ((s.mode & 3) == BSA_MODE_GLOBAL ? 1 : 2);
+			const int w = ((s.mode & 3) == BSA_MODE_GLOBAL) ? 1 : 0;
 			Job &J = job[w];
 			if(w == 0){
 				const size_t base = heads.size();
 				heads.resize(base + ql + tl);
-				std::reverse_copy(seqs + qoff[k], seqs + qoff[k] + s.qe, heads.begin() + base);
-				std::reverse_copy(seqs + toff[k], seqs + toff[k] + s.te, heads.begin() + base + ql);
+				if(s.mode & BSA_KMER_SEG_REVERSED){
+					std::reverse_copy(seqs + qoff[k], seqs + qoff[k] + s.qe, heads.begin() + base);
+					std::reverse_copy(seqs + toff[k], seqs + toff[k] + s.te, heads.begin() + base + ql);
+				} else {
+					memcpy(heads.data() + base, seqs + qoff[k] + s.qb, ql);
+					memcpy(heads.data() + base + ql, seqs + toff[k] + s.tb, tl);
+				}
 				J.qo.push_back(base); J.to.push_back(base + ql);
 			} else {
 				J.qo.push_back(qoff[k] + s.qb); J.to.push_back(toff[k] + s.tb);
@@ -300,7 +334,8 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 			seg_idx[seg_base[k] + j] = (uint32_t)J.ql.size() - 1;
 		}
 	}
-	for(int w = 0; w < 3; w++){
+	auto t2 = now();
+	for(int w = 0; w < 2; w++){
 		Job &J = job[w];
 		const size_t m = J.ql.size();
 		if(m == 0) continue;
@@ -313,7 +348,14 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 		const int rc = bsa_edit_batch(ctx, blob, bytes, J.qo.data(), J.ql.data(), J.to.data(), J.tl.data(), m, &ep,
 			J.rs.data(), J.cig.data(), J.cap, J.coff.data(), J.st.data());
 		if(rc != BSA_OK) return rc;
+		if(timing){
+			uint64_t sq = 0, st = 0; uint32_t mq = 0, mt = 0;
+			for(size_t x = 0; x < m; x++){ sq += J.ql[x]; st += J.tl[x]; mq = std::max(mq, J.ql[x]); mt = std::max(mt, J.tl[x]); }
+			fprintf(stderr, "[bsa_kmer]   batch %d: %zu segments, query %llu bases (max %u), target %llu (max %u), done at %.1f ms\n", w, m,
+				(unsigned long long)sq, mq, (unsigned long long)st, mt, ms(t2, now()));
+		}
 	}
+	auto t3 = now();
 	/* 3. stitch per pair */
 	std::vector<uint64_t> need(n + 1, 0);
 	for(size_t k = 0; k < n; k++){
@@ -351,6 +393,8 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 		if(status) status[k] = st;
 	});
 	if(bad != BSA_OK) return bad;
+	if(timing) fprintf(stderr, "[bsa_kmer] %zu pairs: chain %.1f ms, pack %.1f ms (%zu heads and tails, %zu gaps), device %.1f ms, stitch %.1f ms\n",
+		n, ms(t0, t1), ms(t1, t2), job[0].ql.size(), job[1].ql.size(), ms(t2, t3), ms(t3, now()));
 	if(want_cig){
 		/* close the gaps left by merged match runs so that pair k owns cigar[cigar_off[k] .. cigar_off[k+1]) */
 		uint64_t w = 0;

@@ -146,8 +146,8 @@ int  bsa_edit_run(bsa_edit_plan_t *plan, const uint8_t *d_seqs,
 
 /* ---- k-mer anchored edit alignment (reference: kmer_striped_seqedit_pairwise, bsalign.h:1209-1536; CLI `edit -m kmer`) ---
  * Unique same-strand k-mers (ksz <= 15) shared by the two sequences are chained on the host; only the stretches
- * between consecutive anchors are aligned, every one of them by the device edit path (three bsa_edit_batch calls for
- * the whole batch: reversed heads, gaps, tails), and the CIGAR of each pair is stitched together exactly as the
+ * between consecutive anchors are aligned, every one of them by the device edit path (two bsa_edit_batch calls for
+ * the whole batch: reversed heads and tails in EXTEND mode, gaps in GLOBAL mode), and the CIGAR of each pair is stitched together exactly as the
  * reference does it (including where it puts the anchor matches).  A pair without a usable chain is aligned globally.
  * All pointers are HOST memory; cigar/cigar_off/status follow bsa_edit_batch. */
 typedef struct {

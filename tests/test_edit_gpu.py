@@ -78,8 +78,9 @@ def test_golden_edit_cases(ctx):
 
 
 @pytest.mark.parametrize("mode", [S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND])
-def test_wide_bands_use_the_generic_kernel(ctx, mode):
-    """full-width bands of queries longer than 1024 bp (overlap / extend, bandwidth 0) and banded widths above 1024"""
+def test_wide_bands(ctx, mode):
+    """full-width bands of queries longer than 1024 bp (overlap / extend, bandwidth 0: the wave-per-pair kernel) and
+    banded widths above 1024 (moving band: the generic kernel), mixed in one batch"""
     rng = np.random.default_rng(77 + mode)
     pairs = [_mk(rng, int(rng.choice([1100, 1500, 2500, 4000])), float(rng.choice([0.02, 0.1, 0.2])), float(rng.choice([1.0, 0.8, 1.2])))
              for _ in range(24)]
@@ -87,3 +88,35 @@ def test_wide_bands_use_the_generic_kernel(ctx, mode):
     if mode == S.MODE_GLOBAL:
         _check(ctx, pairs, mode, 2048)
         _check(ctx, pairs, mode, 1088)
+
+
+@pytest.mark.parametrize("mode", [S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND])
+def test_wide_band_classes(ctx, mode):
+    """every launch class above 1024 columns in one batch: 1 / 2 / 4 words per lane of the wave-per-pair kernel
+    (up to 4096 / 8192 / 16384 columns), the generic kernel beyond, and short pairs of the register kernels beside them;
+    query lengths on both sides of the word and class borders"""
+    rng = np.random.default_rng(177 + mode)
+    lens = [70, 1000, 1024, 1025, 1088, 2047, 2048, 4032, 4096, 4097, 4160, 6000, 8192, 8193, 9000, 12000, 16384, 16390, 17000]
+    pairs = []
+    for L in lens:
+        T = rng.integers(0, 4, size=max(8, int(L * float(rng.choice([0.3, 1.0, 1.1]))))).astype(np.uint8)
+        Q = rng.integers(0, 4, size=L).astype(np.uint8)
+        M = S.mutate(rng, T, 0.08)[:L]                # related over the common prefix, so the alignment is not trivial
+        Q[:len(M)] = M
+        pairs.append((Q, T))
+    _check(ctx, pairs, mode, 0)
+    if mode == S.MODE_GLOBAL:
+        _check(ctx, pairs, mode, 3000)                # moving wide bands for the long queries, full width for the short ones
+
+
+def test_wide_kernel_with_extreme_rows(ctx):
+    """rows of the wave-per-pair kernel where the delta chain runs through many words: identical sequences (all
+    matches), homopolymers against each other and a query that only matches at its very end"""
+    rng = np.random.default_rng(5)
+    T = rng.integers(0, 4, size=3000).astype(np.uint8)
+    z = np.zeros(3000, dtype=np.uint8)
+    pairs = [(T.copy(), T), (z, z.copy()), (z, T), (T, z), (np.concatenate([z[:2900], T[:100]]), T[:100].copy()),
+             (T[:2500].copy(), np.concatenate([rng.integers(0, 4, size=400).astype(np.uint8), T[:2500]])),
+             (np.tile(np.array([0, 1], dtype=np.uint8), 1500), np.tile(np.array([1, 0], dtype=np.uint8), 1400))]
+    for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+        _check(ctx, pairs, mode, 0)

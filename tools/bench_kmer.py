@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 import bsalign_amd as B
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -14,7 +14,7 @@ ksz = int(sys.argv[3]) if len(sys.argv) > 3 else 13
 pairs = B.synth_pairs_host(n, L)
 ctx = B.Context(0)
 ctx.kmer_edit_batch(pairs[:64], ksz=ksz)
-for threads in (0, 1):
+for threads in (0, 0, 1):
     t0 = time.time()
     out, cigs, st = ctx.kmer_edit_batch(pairs, ksz=ksz, threads=threads)
     dt = time.time() - t0
