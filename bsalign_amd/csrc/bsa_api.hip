@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -222,13 +223,16 @@ __global__ void __launch_bounds__(256) k_cigar_final(const uint32_t *tmp, const 
 // ------------------------------------------------------------------------------------------------
 // plans: metadata + staging buffers shared by both paths, chunk pipeline
 // ------------------------------------------------------------------------------------------------
-struct Chunk { uint32_t first, count, bw; size_t bytes; };
+struct Sub   { uint32_t first, count, bw; };               // a run of one launch class inside a chunk (forward launches)
+struct Chunk { uint32_t first, count, bw; size_t bytes; uint32_t sub0 = 0, nsub = 0; };      // bw = BSA_MIXED_BW when the chunk holds several classes
+#define BSA_MIXED_BW 0xFFFFFFFFu
 
 struct PlanBase {
 	bsa_ctx *ctx = nullptr;
 	size_t n = 0;
 	double cells = 0;
 	std::vector<Chunk> chunks;
+	std::vector<Sub> subs;          // edit plans: forward launches per class, one traceback per chunk
 	size_t half_bytes = 0;          // size of one workspace half (0 or 1 chunk in flight per half)
 	bool two_halves = false;
 	// device metadata
@@ -265,10 +269,32 @@ static void plan_free(PlanBase *p){
 	delete p;
 }
 
+// order[] (initially 0..n-1) sorted by key, stable: LSD radix sort on 16-bit digits, digits that are the same for all
+// keys are skipped (batches of millions of short pairs: a comparison sort costs more than the kernels)
+static void radix_sort_order(std::vector<uint64_t> &key, std::vector<uint32_t> &order){
+	const size_t n = key.size();
+	if(n < 2) return;
+	uint64_t all_or = 0, all_and = ~0ull;
+	for(size_t k = 0; k < n; k++){ all_or |= key[k]; all_and &= key[k]; }
+	const uint64_t varying = all_or ^ all_and;
+	std::vector<uint64_t> k2(n); std::vector<uint32_t> o2(n);
+	std::vector<uint32_t> cnt(65537);
+	uint64_t *ks = key.data(), *kd = k2.data(); uint32_t *os = order.data(), *od = o2.data();
+	for(int sh = 0; sh < 64; sh += 16){
+		if(((varying >> sh) & 0xFFFFull) == 0) continue;
+		std::fill(cnt.begin(), cnt.end(), 0u);
+		for(size_t k = 0; k < n; k++) cnt[((ks[k] >> sh) & 0xFFFFull) + 1] ++;
+		for(size_t v = 0; v < 65536; v++) cnt[v + 1] += cnt[v];
+		for(size_t k = 0; k < n; k++){ const uint32_t d = cnt[(ks[k] >> sh) & 0xFFFFull] ++; kd[d] = ks[k]; od[d] = os[k]; }
+		std::swap(ks, kd); std::swap(os, od);
+	}
+	if(os != order.data()) memcpy(order.data(), os, n * sizeof(uint32_t));
+}
+
 // cut the processing order into chunks: every chunk fits one workspace half, has a single bandwidth, and large
 // batches are cut into >= 4 chunks so that the traceback of one chunk hides behind the forward pass of the next
 static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const std::vector<size_t> &need, const std::vector<uint32_t> &bwv,
-		std::vector<uint64_t> &slot, std::vector<uint64_t> &slot_end){
+		std::vector<uint64_t> &slot, std::vector<uint64_t> &slot_end, bool mix_classes = false){
 	bsa_ctx *c = p->ctx;
 	const size_t n = order.size();
 	const size_t budget = ctx_ws_budget(c);
@@ -296,15 +322,31 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 	if(const char *ce = getenv("BSA_CHUNK_PAIRS")){ const long v = atol(ce); if(v > 0) cap_pairs = (size_t)v; }
 	slot.assign(n, 0); slot_end.assign(n, 0);
 	size_t acc = 0, maxacc = 0; uint32_t first = 0;
+	// mix_classes (edit plans): a chunk is whatever fits the workspace; its launch classes become forward launches
+	// (subs) and the whole chunk is traced in one launch -- many small classes would otherwise each pay the latency of
+	// a row-serial kernel of their own
+	auto close = [&](uint32_t end){
+		Chunk ch{first, end - first, bwv[first], acc};
+		ch.sub0 = (uint32_t)p->subs.size();
+		for(uint32_t b = first; b < end; ){
+			uint32_t e = b + 1;
+			while(e < end && bwv[e] == bwv[b]) e++;
+			p->subs.push_back({b, e - b, bwv[b]});
+			b = e;
+		}
+		ch.nsub = (uint32_t)p->subs.size() - ch.sub0;
+		if(ch.nsub > 1) ch.bw = BSA_MIXED_BW;
+		p->chunks.push_back(ch);
+		maxacc = std::max(maxacc, acc);
+	};
 	for(size_t pos = 0; pos < n; pos++){
-		if(pos > first && (acc + need[pos] > cap || bwv[pos] != bwv[first] || pos - first >= cap_pairs)){
-			p->chunks.push_back({first, (uint32_t)(pos - first), bwv[first], acc});
-			maxacc = std::max(maxacc, acc);
+		if(pos > first && (acc + need[pos] > cap || (!mix_classes && bwv[pos] != bwv[first]) || pos - first >= cap_pairs)){
+			close((uint32_t)pos);
 			first = (uint32_t)pos; acc = 0;
 		}
 		slot[pos] = acc; acc += need[pos]; slot_end[pos] = acc;
 	}
-	if(n > first){ p->chunks.push_back({first, (uint32_t)(n - first), bwv[first], acc}); maxacc = std::max(maxacc, acc); }
+	if(n > first) close((uint32_t)n);
 	p->half_bytes = (maxacc + 255) & ~(size_t)255;
 	if(p->chunks.size() < 2) p->two_halves = false;
 	return BSA_OK;
@@ -685,6 +727,7 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 	(void)hipSetDevice(c->device);
 	bsa_edit_plan *p = new bsa_edit_plan();
 	p->ctx = c; p->n = n; p->par = *par;
+	const auto tp0 = std::chrono::steady_clock::now();
 	std::vector<uint32_t> bwk(n), order(n), qwords(n);
 	double cells = 0;
 	for(size_t k = 0; k < n; k++){
@@ -697,7 +740,33 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 		order[k] = (uint32_t)k;
 	}
 	p->cells = cells;
-	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y){ return bwk[x] != bwk[y] ? bwk[x] < bwk[y] : tlen[x] > tlen[y]; });
+	// launch class of every pair.  A static band (the band is the whole rounded query: overlap / extend / bandwidth 0)
+	// can also run on the wave-per-pair kernel, which is much the faster one while its waves all fit the chip: the
+	// widest sparsely populated register classes are moved there, together at most 16384 pairs.
+	std::vector<uint32_t> cls(n);
+	{
+		size_t cnt[17] = {0};
+		auto is_static = [&](size_t k){ return bwk[k] == (qlen[k] + 63u) / 64u * 64u; };
+		for(size_t k = 0; k < n; k++) if(bwk[k] <= BSA_EDIT_REG_BW && is_static(k) && qlen[k] && tlen[k]) cnt[bwk[k] / 64u] ++;
+		bool moved[17] = {false};
+		size_t total = 0;
+		for(int w = 16; w >= 2; w--) if(cnt[w] && cnt[w] <= 8192 && total + cnt[w] <= 16384){ moved[w] = true; total += cnt[w]; }
+		if(getenv("BSA_EDIT_NO_MERGE")) for(int w = 0; w < 17; w++) moved[w] = false;
+		for(size_t k = 0; k < n; k++){
+			cls[k] = bsa_edit_class(bwk[k]);
+			if(bwk[k] <= BSA_EDIT_REG_BW && moved[bwk[k] / 64u] && is_static(k) && qlen[k] && tlen[k]) cls[k] = bsa_edit_class(64u * 64u);
+		}
+	}
+	// processing order: by class, then band, then longest target first (ties keep the caller's order)
+	{
+		std::vector<uint64_t> key(n);
+		for(size_t k = 0; k < n; k++){
+			const uint32_t rank = cls[k] <= BSA_EDIT_REG_BW ? cls[k] / 64u : 17u + ((cls[k] & 0xFFu) == 0u ? 0u : (cls[k] & 0xFFu) == 1u ? 1u : (cls[k] & 0xFFu) == 2u ? 2u : 3u);
+			key[k] = (uint64_t)rank << 56 | (uint64_t)(bwk[k] / 64u) << 32 | (uint64_t)(0xFFFFFFFFu - tlen[k]);
+		}
+		radix_sort_order(key, order);
+	}
+	const auto tp1 = std::chrono::steady_clock::now();
 	std::vector<uint64_t> qpoff(n), tpoff(n), qboff(n), slot, slot_end;
 	std::vector<size_t> need(n); std::vector<uint32_t> bwv(n);
 	size_t qacc = 0, tacc = 0, bacc = 0;
@@ -709,17 +778,22 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 	}
 	for(size_t pos = 0; pos < n; pos++){
 		const uint32_t k = order[pos];
-		bwv[pos] = bsa_edit_class(bwk[k]);     // bands wider than the register kernels: a few classes, each one launch
+		bwv[pos] = cls[k];
 		need[pos] = ((size_t)tlen[k] + 1 + p->pad_rows) * (size_t)(bwk[k] / 64u) * 16;
 	}
-	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
+	int rc = plan_chunks(p, order, need, bwv, slot, slot_end, true);
+	const auto tp2 = std::chrono::steady_clock::now();
 	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
 	if(rc == BSA_OK) rc = dev_upload(c, &p->d_qboff, qboff);
 	if(rc == BSA_OK) rc = dev_upload(c, &p->d_qwords, qwords);
 	if(rc == BSA_OK) rc = dev_alloc(c, &p->d_qbits, bacc);
-	if(rc == BSA_OK) rc = dev_alloc(c, &p->d_sbeg, n);
+	if(rc == BSA_OK) rc = dev_alloc(c, &p->d_sbeg, 3 * n);      // sbeg | smin | ry
 	p->extra = { p->d_qboff, p->d_qwords, p->d_qbits, p->d_sbeg };
 	if(rc != BSA_OK){ plan_free(p); return rc; }
+	if(getenv("BSA_BATCH_TIMING")){
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b){ return std::chrono::duration<double, std::milli>(b - a).count(); };
+		fprintf(stderr, "[bsa_edit_plan] %zu pairs: classes + order %.1f ms, layout + chunks %.1f ms, device metadata %.1f ms\n", n, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, std::chrono::steady_clock::now()));
+	}
 	*out = p;
 	return BSA_OK;
 }
@@ -746,17 +820,20 @@ extern "C" int bsa_edit_run(bsa_edit_plan_t *p, const uint8_t *d_seqs, bsa_resul
 	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
 	a.qbits = p->d_qbits; a.qboff = p->d_qboff; a.qwords = p->d_qwords;
 	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
-	a.status = status; a.fwd_sbeg = p->d_sbeg; a.pad_rows = p->pad_rows; a.mode = p->par.mode; a.bandwidth = p->par.bandwidth;
+	a.status = status; a.fwd_sbeg = p->d_sbeg; a.fwd_smin = p->d_sbeg + n; a.fwd_ry = p->d_sbeg + 2 * (size_t)n; a.pad_rows = p->pad_rows; a.mode = p->par.mode; a.bandwidth = p->par.bandwidth;
 	uint32_t *cnt = p->d_cnt_pos;
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
-		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
-		b.bw = ch.bw <= BSA_EDIT_REG_BW ? ch.bw : 0u; b.wide = ch.bw <= BSA_EDIT_REG_BW ? 0u : (ch.bw & 0xFFu);
-		HIPCHK(c, bsa_launch_edit_fwd(b, s));
+		for(uint32_t x = ch.sub0; x < ch.sub0 + ch.nsub; x++){      // one forward launch per class
+			const Sub &sb = p->subs[x];
+			EditArgs b = a; b.first = sb.first; b.count = sb.count; b.rows = half;
+			b.bw = sb.bw <= BSA_EDIT_REG_BW ? sb.bw : 0u; b.wide = sb.bw <= BSA_EDIT_REG_BW ? 0u : (sb.bw & 0xFFu);
+			HIPCHK(c, bsa_launch_edit_fwd(b, s));
+		}
 		return BSA_OK;
 	};
 	auto trace = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
-		b.bw = ch.bw <= BSA_EDIT_REG_BW ? ch.bw : 0u; b.wide = ch.bw <= BSA_EDIT_REG_BW ? 0u : (ch.bw & 0xFFu);
+		b.bw = ch.bw <= BSA_EDIT_REG_BW ? ch.bw : 0u;               // several classes or wide bands: every pair works out its own
 		HIPCHK(c, bsa_launch_edit_trace(b, d_out, cnt, s));
 		return BSA_OK;
 	};
@@ -772,10 +849,18 @@ extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_byt
 	if(!seqs) return BSA_E_ARG;
 	(void)hipSetDevice(c->device);
 	bsa_edit_plan_t *p = nullptr;
+	const bool timing = getenv("BSA_BATCH_TIMING") != nullptr;        // host-side phase times on stderr
+	const auto t0 = std::chrono::steady_clock::now();
 	int rc = bsa_edit_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
 	if(rc != BSA_OK) return rc;
+	const auto t1 = std::chrono::steady_clock::now();
 	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, status,
 		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_edit_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });
+	const auto t2 = std::chrono::steady_clock::now();
+	const size_t nch = p->chunks.size(), nsub = p->subs.size();
 	bsa_edit_plan_destroy(p);
+	if(timing) fprintf(stderr, "[bsa_edit_batch] %zu pairs: plan %.1f ms (%zu chunks, %zu forward launches), copy + run + copy %.1f ms, destroy %.1f ms\n", n,
+		std::chrono::duration<double, std::milli>(t1 - t0).count(), nch, nsub, std::chrono::duration<double, std::milli>(t2 - t1).count(),
+		std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
 	return rc;
 }

@@ -116,6 +116,8 @@ struct EditArgs {
 	uint8_t        *rows;
 	uint32_t       *status;         // [n] per original pair
 	int32_t        *fwd_sbeg;       // [n] by processing position: H at the band start of the last row
+	int32_t        *fwd_smin, *fwd_ry;  // [n] overlap / extend: min over rows of H at the last query column and its (first) row,
+	                                //   followed while the row is in registers (bsalign.h:1124-1139)
 	uint32_t first, count;
 	uint32_t bw;                    // effective bandwidth of this launch (multiple of 64); 0 = wide class, every pair has its own
 	                                //   (bsa_edit_bw_eff of its lengths), all above 1024 -- one launch of the generic kernel

@@ -29,7 +29,8 @@ static __device__ __forceinline__ u64 fsr(u64 lo, u64 hi, uint32_t m){   // (hi:
 static __device__ __forceinline__ u64 lowmask(uint32_t n){ return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
 
 // row records: row r (r = 0 is the initial row, r = i+1 the row of target base i): [plane0: NW u64][plane1: NW u64]
-template<int NW>
+// TRACK (overlap / extend): also follow H at the last query column from row to row (its minimum picks the end cell)
+template<int NW, bool TRACK>
 __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lanes){
 	constexpr uint32_t BW = NW * 64;
 	const uint32_t g = blockIdx.x * lanes + threadIdx.x;      // `lanes` pairs per wave (bsa_launch_edit_fwd)
@@ -64,6 +65,9 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lane
 	load_window(0);
 	int sbeg = 0;
 	uint32_t rb0 = 0;
+	// overlap / extend (the band never moves): H(qlen-1, row), its minimum over the rows and the first row that has it
+	const uint32_t lastw = (qlen - 1u) >> 6, lastb = (qlen - 1u) & 63u;
+	int slast = (int)qlen, smin = 0x7FFFFFFF, ry = (int)tlen - 1;
 	// i*qlen/tlen kept incrementally: quo = floor(i*qlen/tlen), rem = (i*qlen) % tlen
 	u64 quo = 0, rem = 0;
 	const u64 qstep = qlen / tlen, rstep = qlen % tlen;
@@ -144,6 +148,7 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lane
 			const u64 Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
 			u64 Ph = mv | ~(Xh | pv);
 			u64 Mh = pv & Xh;
+			if(TRACK && (uint32_t)k == lastw) slast += (int)((Ph >> lastb) & 1ull) - (int)((Mh >> lastb) & 1ull);
 			hin = (int)(Ph >> 63) - (int)(Mh >> 63);
 			Ph = (Ph << 1) | hpos;
 			Mh = (Mh << 1) | hneg;
@@ -153,13 +158,15 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lane
 		u64 *rp = rows + (size_t)(i + 1) * (2 * NW);
 #pragma unroll
 		for(int k = 0; k < NW; k++){ rp[k] = Mv[k]; rp[NW + k] = Pv[k]; }
-		// per-row score at the last query column (overlap / extend, :1124-1139) is evaluated by the traceback kernel
+		// score at the last query column (overlap / extend, :1124-1139): slast followed the row-to-row delta there
+		if(TRACK && slast < smin){ smin = slast; ry = (int)i; }
 		rb0 = rb1;
 		quo += qstep; rem += rstep;
 		if(rem >= tlen){ rem -= tlen; quo++; }
 	}
 	// H at the band start of the last row; the traceback kernel derives the scores from it
 	a.fwd_sbeg[ppos] = sbeg;
+	a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry;
 }
 
 
@@ -187,6 +194,8 @@ __global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a, uint32_t 
 	for(uint32_t k = 0; k < NW; k++){ rows[k] = 0ull; rows[NW + k] = ~0ull; }      // row_init (:653-656)
 	int sbeg = 0;
 	uint32_t rb0 = 0;
+	const uint32_t lastw = (qlen - 1u) >> 6, lastb = (qlen - 1u) & 63u;
+	int slast = (int)qlen, smin = 0x7FFFFFFF, ry = (int)tlen - 1;
 	u64 quo = 0, rem = 0;
 	const u64 qstep = qlen / tlen, rstep = qlen % tlen;
 	for(uint32_t i = 0; i < tlen; i++){
@@ -230,6 +239,7 @@ __global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a, uint32_t 
 			const u64 Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
 			u64 Ph = mv | ~(Xh | pv);
 			u64 Mh = pv & Xh;
+			if(type != BSA_MODE_GLOBAL && k == lastw) slast += (int)((Ph >> lastb) & 1ull) - (int)((Mh >> lastb) & 1ull);
 			hin = (int)(Ph >> 63) - (int)(Mh >> 63);
 			Ph = (Ph << 1) | hpos;
 			Mh = (Mh << 1) | hneg;
@@ -237,11 +247,13 @@ __global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a, uint32_t 
 			nm[k] = Ph & Xv;
 			plo = phi; mlo = mhi; q0lo = q0hi; q1lo = q1hi;
 		}
+		if(type != BSA_MODE_GLOBAL && slast < smin){ smin = slast; ry = (int)i; }
 		rb0 = rb1;
 		quo += qstep; rem += rstep;
 		if(rem >= tlen){ rem -= tlen; quo++; }
 	}
 	a.fwd_sbeg[ppos] = sbeg;
+	a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry;
 }
 
 // ---- wide static bands: one pair per WAVE -----------------------------------------------------------------------
@@ -305,6 +317,9 @@ __global__ void __launch_bounds__(256) k_edit_fwd_wide(const EditArgs a){
 		pv[j] = ~0ull; mv[j] = 0ull;
 		if(act[j]){ rows[w] = 0ull; rows[NW + w] = ~0ull; }                    // row_init (:653-656)
 	}
+	const uint32_t lastw = (qlen - 1u) >> 6, lastb = (qlen - 1u) & 63u;      // H(qlen-1, row) is followed by the lane that owns that column
+	const int lastj = (int)(lastw % WPL);
+	int slast = (int)qlen, smin = 0x7FFFFFFF, ry = (int)tlen - 1;
 	const u64 hin0_pos = overlap ? 0ull : 1ull;                                // left of the band v = +1, 0 in overlap mode (:770)
 	u64 tw = 0;
 	for(uint32_t i = 0; i < tlen; i++){
@@ -344,6 +359,7 @@ __global__ void __launch_bounds__(256) k_edit_fwd_wide(const EditArgs a){
 			const u64 Xh = mask_pick64(t[0][j], t[1][j], C);
 			u64 Ph = mv[j] | ~(Xh | pv[j]);
 			u64 Mh = pv[j] & Xh;
+			if(type != BSA_MODE_GLOBAL && j == lastj) slast += (int)((Ph >> lastb) & 1ull) - (int)((Mh >> lastb) & 1ull);    // only the owner lane's value is used
 			u64 hneg, hpos;
 			if(j == 0){ hneg = mask_pick(0u, 1u, C); hpos = mask_pick(0u, 1u, Ppos); }
 			else { hneg = mask_pick((uint32_t)n[0][j], (uint32_t)n[1][j], C); hpos = mask_pick((uint32_t)pz[0][j - 1], (uint32_t)pz[1][j - 1], C); }
@@ -358,7 +374,9 @@ __global__ void __launch_bounds__(256) k_edit_fwd_wide(const EditArgs a){
 #pragma unroll
 			for(int j = 0; j < WPL; j++) if(act[j]){ rp[w0 + j] = mv[j]; rp[NW + w0 + j] = pv[j]; }
 		}
+		if(type != BSA_MODE_GLOBAL && slast < smin){ smin = slast; ry = (int)i; }
 	}
+	if(lane == lastw / WPL){ a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry; }
 	if(lane == 0) a.fwd_sbeg[ppos] = overlap ? 0 : (int)tlen;                     // no band motion: H at the band start grows by one per row (:667-676)
 }
 
@@ -409,16 +427,9 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 			score += plane_bit(tlen, 0, (long)(k - 1 - rbl)) - plane_bit(tlen, 1, (long)(k - 1 - rbl));
 		}
 	} else {
-		// full band, rbeg == 0: H(qlen-1, i) per row, then (extend) the first strict minimum of the last row
-		for(uint32_t i = 0; i < tlen; i++){
-			const u64 *lr = rows + (size_t)(i + 1) * (2 * NW);
-			int srow = (type == BSA_MODE_OVERLAP) ? 0 : (int)(i + 1);
-			for(uint32_t k = 0; k < NW; k++){
-				u64 mk = (qlen >= (k + 1) * 64u) ? ~0ull : ((qlen > k * 64u) ? lowmask(qlen - k * 64u) : 0ull);
-				srow += __popcll(lr[NW + k] & mk) - __popcll(lr[k] & mk);
-			}
-			if(srow < smin){ smin = srow; rx = (int)qlen - 1; ry = (int)i; }
-		}
+		// full band, rbeg == 0: the minimum over the rows of H(qlen-1, i) and its first row come from the forward kernel
+		// (:1124-1139), then (extend) the first strict minimum of the last row
+		smin = a.fwd_smin[ppos]; rx = (int)qlen - 1; ry = a.fwd_ry[ppos];
 		if(type == BSA_MODE_EXTEND){     // striped_seqedit_rowmin (:813-963)
 			const u64 *lr = rows + (size_t)tlen * (2 * NW);
 			int sc = (int)tlen, best = sc; uint32_t pmin = 0;
@@ -565,7 +576,9 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 	uint32_t lanes = 64;
 	if(const char *e = getenv("BSA_EDIT_FWD_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64) lanes = (uint32_t)v; }
 	const uint32_t fblocks = (a.count + lanes - 1) / lanes;
-#define EDIT_CASE(N) case N: hipLaunchKernelGGL((k_edit_fwd<N>), dim3(fblocks), dim3(64), 0, st, a, lanes); break;
+#define EDIT_CASE(N) case N: if(track) hipLaunchKernelGGL((k_edit_fwd<N, true>), dim3(fblocks), dim3(64), 0, st, a, lanes); \
+		else hipLaunchKernelGGL((k_edit_fwd<N, false>), dim3(fblocks), dim3(64), 0, st, a, lanes); break;
+	const bool track = (a.mode & 3) != BSA_MODE_GLOBAL;
 	switch(a.bw / 64){
 		EDIT_CASE(1) EDIT_CASE(2) EDIT_CASE(3) EDIT_CASE(4) EDIT_CASE(5) EDIT_CASE(6) EDIT_CASE(7) EDIT_CASE(8)
 		EDIT_CASE(9) EDIT_CASE(10) EDIT_CASE(11) EDIT_CASE(12) EDIT_CASE(13) EDIT_CASE(14) EDIT_CASE(15) EDIT_CASE(16)

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -301,7 +302,7 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 	auto t1 = now();
 	/* 2. two device batches: EXTEND for the reversed heads and the tails (copied into one blob), GLOBAL for the gaps
 	 *    (views into the caller's blob) */
-	struct Job { std::vector<uint64_t> qo, to; std::vector<uint32_t> ql, tl, pair, seg; std::vector<bsa_result_t> rs; std::vector<uint32_t> cig; std::vector<uint64_t> coff; std::vector<uint32_t> st; size_t cap = 8; };
+	struct Job { std::vector<uint64_t> qo, to; std::vector<uint32_t> ql, tl; std::vector<bsa_result_t> rs; std::unique_ptr<uint32_t[]> cig; std::vector<uint64_t> coff; std::vector<uint32_t> st; size_t cap = 8; };
 	Job job[2];
 	std::vector<uint8_t> heads;
 	std::vector<size_t> seg_base(n + 1, 0);
@@ -339,14 +340,14 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 		Job &J = job[w];
 		const size_t m = J.ql.size();
 		if(m == 0) continue;
-		J.rs.resize(m); J.cig.resize(J.cap); J.coff.resize(m + 1); J.st.assign(m, 0);
+		J.rs.resize(m); J.cig.reset(new uint32_t[J.cap]); J.coff.resize(m + 1); J.st.assign(m, 0);       // the arena is not zero-filled
 		bsa_edit_params_t ep;
 		ep.mode = (w == 1) ? BSA_MODE_GLOBAL : BSA_MODE_EXTEND;
 		ep.bandwidth = 0;
 		const uint8_t *blob = (w == 0) ? heads.data() : seqs;
 		const size_t bytes = (w == 0) ? heads.size() : seqs_bytes;
 		const int rc = bsa_edit_batch(ctx, blob, bytes, J.qo.data(), J.ql.data(), J.to.data(), J.tl.data(), m, &ep,
-			J.rs.data(), J.cig.data(), J.cap, J.coff.data(), J.st.data());
+			J.rs.data(), J.cig.get(), J.cap, J.coff.data(), J.st.data());
 		if(rc != BSA_OK) return rc;
 		if(timing){
 			uint64_t sq = 0, st = 0; uint32_t mq = 0, mt = 0;
@@ -385,7 +386,7 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 			if(seg_job[g] == 0xFF){ memset(&rs[j], 0, sizeof(bsa_result_t)); ptr[j] = nullptr; cnt[j] = 0; continue; }
 			const Job &J = job[seg_job[g]];
 			const uint32_t x = seg_idx[g];
-			rs[j] = J.rs[x]; ptr[j] = J.cig.data() + J.coff[x]; cnt[j] = J.coff[x + 1] - J.coff[x];
+			rs[j] = J.rs[x]; ptr[j] = J.cig.get() + J.coff[x]; cnt[j] = J.coff[x + 1] - J.coff[x];
 			st |= J.st[x];
 		}
 		const int rc = assemble(segs[k].data(), (uint32_t)ns, rs.data(), ptr.data(), cnt.data(), &out[k], work + need[k], need[k + 1] - need[k], &used[k]);
