@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--workload", default="align8", choices=["align8", "edit", "poa"])
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: 100000 for align8, 16384 for edit; poa: POA windows, 16384)")
     ap.add_argument("--length", type=int, default=0, help="target length (default 10000 / 100000; poa: graph positions per window, 10000)")
-    ap.add_argument("--bw", type=int, default=0, help="bandwidth (default 128 / 256 / 128)")
+    ap.add_argument("--bw", type=int, default=0, help="bandwidth (default 128 / 256 / 128); -1 = the reference's bandwidth 0, the whole query")
+    ap.add_argument("--mode", default="global", choices=["global", "overlap", "extend"], help="pairwise workloads only (the headline configurations are global)")
     ap.add_argument("--eps", type=float, default=0.10)
     ap.add_argument("--scoring", default="2,-6,-3,-2,0,0", help="M,X,O,E,Q,P (reference CLI defaults, main.c:264)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs of the CPU baseline sample (0 = auto, -1 = skip)")
@@ -71,8 +72,17 @@ def cpu_baseline(args, L, bw, sc, mode):
             secs = S.oracle().orc_align_batch_time(S.ptr(seqs, S.u8p), S.ptr(qoff, S.u64p), S.ptr(qlen, S.u32p), S.ptr(toff, S.u64p),
                                                    S.ptr(tlen, S.u32p), npairs, mode, bw, S.ptr(m, S.i8p), sc[2], sc[3], sc[4], sc[5], C.byref(cs))
     else:
-        bw_eff = (bw + 63) // 64 * 64
-        cells = float(L) * bw_eff * npairs
+        def bw_eff(ql, tl):                                    # bsalign.h:1055-1067
+            qr = (int(ql) + 63) // 64 * 64
+            if mode != B.MODE_GLOBAL:
+                return qr
+            b = (bw + 63) // 64 * 64
+            if b == 0 or b > ql:
+                b = qr
+            if b < ql and b < (int(ql) + int(tl) - 1) // int(tl) + 1:
+                b = ((int(ql) + int(tl) - 1) // int(tl) + 1 + 63) // 64 * 64
+            return b
+        cells = float(sum(int(tl) * bw_eff(ql, tl) for ql, tl in zip(qlen, tlen)))
         if kind == "reference":
             lib = S.ref()
             secs = lib.ref_edit_batch_time(lib._ctx, S.ptr(seqs, S.u8p), S.ptr(qoff, S.u64p), S.ptr(qlen, S.u32p), S.ptr(toff, S.u64p),
@@ -266,7 +276,7 @@ def main():
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sc = tuple(int(x) for x in args.scoring.split(","))
-    mode = B.MODE_GLOBAL
+    mode = {"global": B.MODE_GLOBAL, "overlap": B.MODE_OVERLAP, "extend": B.MODE_EXTEND}[args.mode]
     if args.workload == "align8":
         n = args.pairs or 100000
         L = args.length or 10000
@@ -275,6 +285,8 @@ def main():
         n = args.pairs or 16384
         L = args.length or 100000
         bw = args.bw or 256
+    if bw < 0:
+        bw = 0
 
     ctx = B.Context(local, int(args.workspace_gb * (1 << 30)))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -368,11 +380,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i8" if args.workload == "align8" else "u64-bitplanes",
             "data": "synthetic (splitmix64 pairs, eps=%.2f, sub:ins:del=23:31:46, seed %d)" % (args.eps, SEED),
-            "config": {"workload": "%s: %d pairs/GPU x %d bp, mode global, bandwidth %d, scoring M,X,O,E,Q,P=%s" % (args.workload, n, L, bw, args.scoring),
+            "config": {"workload": "%s: %d pairs/GPU x %d bp, mode %s, bandwidth %d, scoring M,X,O,E,Q,P=%s" % (args.workload, n, L, args.mode, bw, args.scoring),
                        "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "forward DP (k_align8_fwd_pk, 4-bit traceback codes)" if args.workload == "align8" else "forward DP (k_edit_fwd)",
+                         "kernel": "forward DP (k_align8_fwd_pk, 4-bit traceback codes)" if args.workload == "align8" else "forward DP (k_edit_fwd / k_edit_fwd_wide)",
                          "kernel_ms_avg": round(kms, 3), "launches_per_step": klaunch,
                          "algorithmic_bytes_per_launch": round(balg / max(klaunch, 1), 1),
                          "kernel_gcups": round(kcells / max(klaunch, 1) / (kms / 1e3) / 1e9, 2) if kms > 0 else None},

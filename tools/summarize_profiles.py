@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"align8": "k_align8_fwd", "edit": "k_edit_fwd", "poa": "k_sweep"}
+DOMINANT = {"align8": "k_align8_fwd", "edit": "k_edit_fwd", "poa": "k_sweep", "editfull": "k_edit_fwd_wide"}
 
 
 def pmc_sum(path, kernel_prefix):
@@ -66,13 +66,16 @@ def main():
             c = cfg["config"]
             n = c.get("pairs_per_gpu", c.get("windows_per_gpu"))
             L = c.get("length", c.get("positions"))
-            key = "%s_n%d_L%d_bw%d" % (wl, n, L, c["bandwidth"])
+            key = "%s_n%d_L%d_bw%d" % (c["workload"].split(":")[0] if ":" in c.get("workload", "") else wl, n, L, c["bandwidth"])
             nd = vals["FETCH_SIZE"][1]
             fetch, write = vals["FETCH_SIZE"][0] / nd, vals["WRITE_SIZE"][0] / vals["WRITE_SIZE"][1]
             traffic[key] = {"kernel": kern, "dispatches_measured": nd, "bytes_per_launch": 2.0 * fetch + write,
                             "fetch_size_raw_bytes_per_launch": fetch, "write_size_bytes_per_launch": write,
                             "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s_%s_pmc_*.csv); counters in KB; "
                                     "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)" % (tag, wl)}
+    for name in ("kmer_kernel_stats.csv", "kmer_timing.log"):
+        for f in glob.glob(os.path.join(src, "**", name), recursive=True):
+            shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, name)))
     json.dump(traffic, open(tpath, "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
