@@ -388,13 +388,7 @@ __global__ void __launch_bounds__(256) k_edit_fwd_wide(const EditArgs a){
 // lanes of every wave carry a pair: as few as still let ALL waves of the launch be resident at once (8 per SIMD).
 // Measured on MI355X, 16384 pairs x 100 kbp (ms per launch): 32 lanes 151, 16 lanes 155, 8 lanes 137, 4 lanes 121,
 // 2 lanes 114 (8192 waves = 8 per SIMD); one lane per wave would need two rounds.
-// The walk goes up one row per step (or stays), and the band position it looks at drifts slowly, so the two words it may
-// need from each of the next rows are known in advance: `ring_rows` (a power of two) rows ahead are fetched in one go --
-// independent loads, one latency -- into a per-lane LDS ring, tagged with the word index they were fetched for; a lookup
-// that the ring cannot serve (another word: the walk crossed a 64-column border) falls back to the plain load, so the
-// ring only ever changes when something is read, never what.  The two sequence windows are double-buffered the same way.
-__global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt, uint32_t lanes, uint32_t ring_rows){
-	extern __shared__ u64 edit_ring[];
+__global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt, uint32_t lanes){
 	const uint32_t g = blockIdx.x * lanes + threadIdx.x;
 	if(threadIdx.x >= lanes || g >= a.count) return;
 	const uint32_t ppos = a.first + g, pair = a.order[ppos];
@@ -462,57 +456,13 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 	// 8 bases of each sequence in a register window: the common step (equal bases, no plane lookup) then touches
 	// memory once per 8 steps instead of twice per step
 	u64 qwin = 0, twin = 0; int qwb = -1000, twb = -1000;
-	u64 qnext = 0, tnext = 0; int qnb = -1000, tnb = -1000;      // the 8 bases below each window, requested when the window was installed
 	auto qbase_at = [&](int idx) -> int {
-		if(idx < qwb || idx >= qwb + 8){
-			qwb = max(idx - 7, 0);
-			if(qwb == qnb) qwin = qnext; else __builtin_memcpy(&qwin, qs + qwb, 8);
-			qnb = max(qwb - 8, 0); __builtin_memcpy(&qnext, qs + qnb, 8);
-		}
+		if(idx < qwb || idx >= qwb + 8){ qwb = max(idx - 7, 0); __builtin_memcpy(&qwin, qs + qwb, 8); }
 		return (int)((qwin >> (8 * (idx - qwb))) & 0xffu);
 	};
 	auto tbase_at = [&](int idx) -> int {
-		if(idx < twb || idx >= twb + 8){
-			twb = max(idx - 7, 0);
-			if(twb == tnb) twin = tnext; else __builtin_memcpy(&twin, ts + twb, 8);
-			tnb = max(twb - 8, 0); __builtin_memcpy(&tnext, ts + tnb, 8);
-		}
+		if(idx < twb || idx >= twb + 8){ twb = max(idx - 7, 0); __builtin_memcpy(&twin, ts + twb, 8); }
 		return (int)((twin >> (8 * (idx - twb))) & 0xffu);
-	};
-	// row ring: planes 0 and 1 of word ring_wi of rows ring_lo..ring_hi, slot = row & (ring_rows - 1)
-	u64 *ring = edit_ring + (size_t)threadIdx.x * ring_rows * 2u;
-	int ring_lo = 1, ring_hi = 0; uint32_t ring_wi = 0;
-	const uint32_t rmask = ring_rows - 1u;
-	auto two_bits = [&](uint32_t row, long pos, bool primary, int &bit0, int &bit1){
-		const uint32_t pu = (uint32_t)pos;                       // see plane_bit
-		const uint32_t p = ((pu / NW) & 63u) * NW + (pu % NW);
-		const uint32_t wi = p >> 6, sh = p & 63u;
-		const bool hit = (int)row >= ring_lo && (int)row <= ring_hi && wi == ring_wi;
-		u64 w0, w1;
-		if(!hit && primary && ring_rows > 1u){
-			ring_hi = (int)row; ring_lo = max((int)row - (int)ring_rows + 1, 0); ring_wi = wi;
-			for(uint32_t b = 0; b < ring_rows; b += 8u){
-				u64 t0[8], t1[8];
-#pragma unroll
-				for(int j = 0; j < 8; j++){
-					const uint32_t r = (uint32_t)max((int)row - (int)(b + j), 0);
-					const u64 *rp = rows + (size_t)r * (2 * NW) + wi;
-					t0[j] = rp[0]; t1[j] = rp[NW];
-				}
-#pragma unroll
-				for(int j = 0; j < 8; j++){
-					const uint32_t r = (uint32_t)max((int)row - (int)(b + j), 0);
-					ring[(r & rmask) * 2u] = t0[j]; ring[(r & rmask) * 2u + 1u] = t1[j];
-				}
-			}
-			w0 = ring[(row & rmask) * 2u]; w1 = ring[(row & rmask) * 2u + 1u];
-		} else if(hit){
-			w0 = ring[(row & rmask) * 2u]; w1 = ring[(row & rmask) * 2u + 1u];
-		} else {
-			const u64 *rp = rows + (size_t)row * (2 * NW) + wi;
-			w0 = rp[0]; w1 = rp[NW];
-		}
-		bit0 = (int)((w0 >> sh) & 1ull); bit1 = (int)((w1 >> sh) & 1ull);
 	};
 	while(!bad && x >= 0 && y >= 0){
 		if(y != cached_y){
@@ -529,13 +479,11 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 		if(qbase_at(x) == tbase_at(y)){ rs.mat++; op = 0; x--; y--; }
 		else {
 			const long p1 = (long)x - (long)b1;
-			int u3, u4;
-			two_bits((uint32_t)y + 1u, p1, true, u3, u4);
+			const int u3 = plane_bit((uint32_t)y + 1u, 0, p1), u4 = plane_bit((uint32_t)y + 1u, 1, p1);
 			if(u3 == 0 && u4 == 1){ rs.ins++; op = 1; x--; }
 			else {
 				const long p0 = (long)x - (long)b0;
-				int u1, u2;
-				two_bits((uint32_t)y, p0, false, u1, u2);
+				const int u1 = plane_bit((uint32_t)y, 0, p0), u2 = plane_bit((uint32_t)y, 1, p0);
 				if(u1 == 1 && u2 == 0){ rs.del++; op = 2; y--; }
 				else { rs.mis++; op = 0; x--; y--; }
 			}
@@ -663,9 +611,6 @@ hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t 
 	uint32_t lanes = 2;
 	while(lanes < 64u && (a.count + lanes - 1) / lanes > slots) lanes <<= 1;
 	const uint32_t blocks = (a.count + lanes - 1) / lanes;
-	// rows fetched ahead per pair: as many as the LDS of a fully occupied CU allows (32 waves: 4 KB each)
-	uint32_t ring_rows = lanes <= 8u ? 32u : lanes <= 16u ? 16u : lanes <= 32u ? 8u : 4u;
-	if(const char *e = getenv("BSA_EDIT_TRACE_RING")){ const int v = atoi(e); if(v >= 1 && v <= 64 && (v & (v - 1)) == 0 && (v == 1 || v >= 8)) ring_rows = (uint32_t)v; }
-	hipLaunchKernelGGL(k_edit_trace, dim3(blocks), dim3(64), lanes * ring_rows * 16u, st, a, out, cig_cnt, lanes, ring_rows);
+	hipLaunchKernelGGL(k_edit_trace, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt, lanes);
 	return hipGetLastError();
 }
