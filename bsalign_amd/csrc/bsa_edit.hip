@@ -388,13 +388,28 @@ __global__ void __launch_bounds__(256) k_edit_fwd_wide(const EditArgs a){
 // lanes of every wave carry a pair: as few as still let ALL waves of the launch be resident at once (8 per SIMD).
 // Measured on MI355X, 16384 pairs x 100 kbp (ms per launch): 32 lanes 151, 16 lanes 155, 8 lanes 137, 4 lanes 121,
 // 2 lanes 114 (8192 waves = 8 per SIMD); one lane per wave would need two rounds.
+// COOP (few pairs per wave, lanes <= 8): the lanes that carry no pair fetch rows for those that do.  Whenever a walker
+// has moved RR - 1 rows (RR = 64 / lanes) the whole wave stops at a service point: each walker publishes the row it will look at next and a
+// 64-column window centred on its column (a banded alignment runs along the middle of its band, which is a word border
+// whenever the band has an even number of words), RR lanes per walker load one row each -- one load instruction, one
+// latency for the next RR rows -- and leave the window's bits of both planes in an LDS ring.  A lookup the ring cannot
+// serve (the walk left the window) takes the plain load, so the ring changes when data is read, never what is read.
+template<bool COOP>
 __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt, uint32_t lanes){
-	const uint32_t g = blockIdx.x * lanes + threadIdx.x;
-	if(threadIdx.x >= lanes || g >= a.count) return;
+	__shared__ u64 ring[COOP ? 128 : 2];                 // [walker][RR rows][plane]
+	__shared__ u64 sh_ptr[8], sh_qp[8], sh_tp[8];
+	__shared__ int sh_hi[8];
+	__shared__ uint32_t sh_s[8], sh_nw[8], sh_ql[8], sh_tl[8];
+	__shared__ __attribute__((aligned(8))) uint8_t sh_seq[COOP ? 8 : 1][64];      // per walker: 32 query bases up to x, 32 target bases up to y
+	const uint32_t g0 = blockIdx.x * lanes + threadIdx.x;
+	const bool walker = threadIdx.x < lanes && g0 < a.count;
+	if(!COOP && !walker) return;
+	const uint32_t g = walker ? g0 : blockIdx.x * lanes;    // COOP: the other lanes shadow the block's first pair and never step
 	const uint32_t ppos = a.first + g, pair = a.order[ppos];
 	bsa_result_t rs;
 	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
-	if(a.status[pair] != 0u){ out[pair] = rs; cig_cnt[ppos] = 0; return; }
+	const bool skip = a.status[pair] != 0u;                // flagged by an earlier stage: zero result
+	if(!COOP && skip){ out[pair] = rs; cig_cnt[ppos] = 0; return; }
 	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
 	const uint32_t BW = a.bw ? a.bw : bsa_edit_bw_eff(qlen, tlen, a.mode & 3, a.bandwidth), NW = BW / 64u;
 	const uint8_t *qs = a.qst + a.qpoff[pair];
@@ -449,9 +464,9 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 	rs.qe = x + 1; rs.te = y + 1;
 	// begs[y+1], begs[y] kept incrementally (y only ever decreases by one): (bq, br) = divmod((y-1)*qlen, tlen)
 	uint32_t b1 = beg_of_row((uint32_t)y + 1u), b0 = beg_of_row((uint32_t)y);
-	const u64 qstep = qlen / tlen, rstep = qlen % tlen;
-	u64 bq = 0, br = 0;
-	if(y >= 1){ const u64 pr = (u64)(y - 1) * qlen; bq = pr / tlen; br = pr % tlen; }
+	const uint32_t qstep = qlen / tlen, rstep = qlen % tlen;
+	uint32_t bq = 0, br = 0;                              // quotient < qlen, remainder < tlen
+	if(y >= 1){ const u64 pr = (u64)(y - 1) * qlen; bq = (uint32_t)(pr / tlen); br = (uint32_t)(pr % tlen); }
 	int cached_y = y;
 	// 8 bases of each sequence in a register window: the common step (equal bases, no plane lookup) then touches
 	// memory once per 8 steps instead of twice per step
@@ -464,33 +479,123 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 		if(idx < twb || idx >= twb + 8){ twb = max(idx - 7, 0); __builtin_memcpy(&twin, ts + twb, 8); }
 		return (int)((twin >> (8 * (idx - twb))) & 0xffu);
 	};
-	while(!bad && x >= 0 && y >= 0){
-		if(y != cached_y){
-			b1 = b0; cached_y = y;
-			if(y >= 1 && type == BSA_MODE_GLOBAL){
-				bq -= qstep;
-				if(br < rstep){ br += tlen; bq--; }
-				br -= rstep;
-				uint32_t c = (uint32_t)bq;
-				c = (c < BW / 2) ? 0u : c - BW / 2;
-				b0 = (c + BW > qround) ? qround - BW : c;
-			} else b0 = 0;
+	// COOP service state
+	// RR rows (one per lane) and 32 bases of each sequence per service point: a walker may move SVC rows / bases before
+	// the next one (the lookups of a step touch rows y + 1 and y)
+	const uint32_t RR = COOP ? 64u / lanes : 1u, SVC = COOP ? min(RR, 32u) - 1u : 1u;
+	const uint32_t hw = threadIdx.x / RR, hl = threadIdx.x % RR;
+	int ring_lo = 1, ring_hi = 0; uint32_t ring_s = 0;
+	int sq0 = 0, st0 = 0;                                    // first base of the LDS sequence windows
+	auto map_pos = [&](long pos) -> uint32_t {               // see plane_bit; the identity for positions inside the band
+		const uint32_t pu = (uint32_t)pos;
+		return pu < BW ? pu : ((pu / NW) & 63u) * NW + (pu % NW);
+	};
+	auto two_bits = [&](uint32_t row, long pos, int &bit0, int &bit1){
+		const uint32_t p = map_pos(pos);
+		u64 w0, w1; uint32_t sh;
+		if(COOP && (int)row >= ring_lo && (int)row <= ring_hi && p >= ring_s && p < ring_s + 64u){
+			const uint32_t slot = (threadIdx.x * RR + (row & (RR - 1u))) * 2u;
+			w0 = ring[slot]; w1 = ring[slot + 1u]; sh = p - ring_s;
+		} else {
+			const u64 *rp = rows + (size_t)row * (2 * NW) + (p >> 6);
+			w0 = rp[0]; w1 = rp[NW]; sh = p & 63u;
 		}
-		if(qbase_at(x) == tbase_at(y)){ rs.mat++; op = 0; x--; y--; }
-		else {
-			const long p1 = (long)x - (long)b1;
-			const int u3 = plane_bit((uint32_t)y + 1u, 0, p1), u4 = plane_bit((uint32_t)y + 1u, 1, p1);
-			if(u3 == 0 && u4 == 1){ rs.ins++; op = 1; x--; }
-			else {
-				const long p0 = (long)x - (long)b0;
-				const int u1 = plane_bit((uint32_t)y, 0, p0), u2 = plane_bit((uint32_t)y, 1, p0);
-				if(u1 == 1 && u2 == 0){ rs.del++; op = 2; y--; }
-				else { rs.mis++; op = 0; x--; y--; }
+		bit0 = (int)((w0 >> sh) & 1ull); bit1 = (int)((w1 >> sh) & 1ull);
+	};
+	bool active = walker && !skip && !bad && x >= 0 && y >= 0;
+	uint32_t svc_left = 0, step = 1;      // svc_left: rows / bases a walker may still move before the next service point
+	while(COOP ? __any(active) : active){
+		if(active && type == BSA_MODE_GLOBAL){           // a run of matches moves several rows at once
+			while(cached_y != y){
+				b1 = b0; cached_y--;
+				if(cached_y >= 1){
+					bq -= qstep;
+					if(br < rstep){ br += tlen; bq--; }
+					br -= rstep;
+					uint32_t c = bq;
+					c = (c < BW / 2) ? 0u : c - BW / 2;
+					b0 = (c + BW > qround) ? qround - BW : c;
+				} else b0 = 0;
 			}
 		}
-		if(op == (cg & 0xf)) cg += 0x10;
-		else { if(cg) cig_push(cg); cg = 0x10 | op; }
+		if(COOP && __any(active && svc_left == 0u)){     // service point, the whole wave (some walker has used up its window)
+			if(threadIdx.x < lanes){
+				const uint32_t p = map_pos((long)x - (long)b1);
+				ring_s = (p < 32u) ? 0u : min(p - 32u, BW - 64u);
+				ring_hi = active ? y + 1 : -1; ring_lo = max(ring_hi - (int)RR + 1, 0);
+				sq0 = max(x - 31, 0); st0 = max(y - 31, 0);
+				sh_hi[threadIdx.x] = ring_hi; sh_s[threadIdx.x] = ring_s; sh_nw[threadIdx.x] = NW; sh_ptr[threadIdx.x] = (u64)(uintptr_t)rows;
+				sh_qp[threadIdx.x] = (u64)(uintptr_t)(qs + sq0); sh_tp[threadIdx.x] = (u64)(uintptr_t)(ts + st0);
+				sh_ql[threadIdx.x] = active ? qlen + 8u - (uint32_t)sq0 : 0u; sh_tl[threadIdx.x] = active ? tlen + 8u - (uint32_t)st0 : 0u;   // bytes that may be read
+			}
+			__syncthreads();
+			if(hl < 8u){         // eight lanes per walker bring the 32 bases of each sequence up to (x, y)
+				const bool isq = hl < 4u;
+				const uint32_t off = (hl & 3u) * 8u, lim = isq ? sh_ql[hw] : sh_tl[hw];
+				if(off <= lim && lim != 0u){
+					const uint8_t *src = (const uint8_t*)(uintptr_t)(isq ? sh_qp[hw] : sh_tp[hw]) + off;     // staged with >= 16 bytes of padding
+					u64 v; __builtin_memcpy(&v, src, 8);
+					*(u64*)&sh_seq[hw][(isq ? 0u : 32u) + off] = v;
+				}
+			}
+			{                    // and every lane one row: the window's two words of both planes
+				const int hi = sh_hi[hw], r = hi - (int)hl;
+				if(hi >= 0 && r >= 0){
+					const uint32_t nw = sh_nw[hw], ws = sh_s[hw], wa = ws >> 6, fs = ws & 63u;
+					const u64 *rp = (const u64*)(uintptr_t)sh_ptr[hw] + (size_t)r * (2 * nw) + wa;
+					const bool two = wa + 1u < nw;
+					const u64 l0 = rp[0], l1 = rp[nw], h0 = two ? rp[1] : 0ull, h1 = two ? rp[nw + 1u] : 0ull;
+					const uint32_t slot = (hw * RR + ((uint32_t)r & (RR - 1u))) * 2u;
+					ring[slot] = fsr(l0, h0, fs); ring[slot + 1u] = fsr(l1, h1, fs);
+				}
+			}
+			__syncthreads();
+			svc_left = SVC;
+		}
+		if(active){
+			// the bases at (x, y) and up to seven before them, most recent in the top byte: equal top bytes = a match, and the
+			// number of equal leading bytes is how far the diagonal run of matches goes (as far as both windows reach)
+			u64 qv, tv; uint32_t reach;
+			if(COOP){
+				const uint32_t eq = (uint32_t)(x - sq0), et = (uint32_t)(y - st0);
+				const u64 *sq = (const u64*)&sh_seq[threadIdx.x][0], *st = (const u64*)&sh_seq[threadIdx.x][32];
+				const u64 q1 = sq[eq >> 3], q0 = (eq >> 3) ? sq[(eq >> 3) - 1u] : 0ull, t1 = st[et >> 3], t0 = (et >> 3) ? st[(et >> 3) - 1u] : 0ull;
+				const uint32_t sq_ = 8u * (7u - (eq & 7u)), st_ = 8u * (7u - (et & 7u));
+				qv = (q1 << sq_) | (sq_ ? q0 >> (64u - sq_) : 0ull);
+				tv = (t1 << st_) | (st_ ? t0 >> (64u - st_) : 0ull);
+				reach = min(min(eq, et) + 1u, svc_left);
+			} else {
+				(void)qbase_at(x); (void)tbase_at(y);        // windows now hold [qwb, qwb + 8) with x inside, same for y
+				qv = qwin << (8u * (7u - (uint32_t)(x - qwb))); tv = twin << (8u * (7u - (uint32_t)(y - twb)));
+				reach = (uint32_t)min(x - qwb, y - twb) + 1u;
+			}
+			const u64 df = qv ^ tv;
+			if((df >> 56) == 0ull){
+				const uint32_t lead = df ? (uint32_t)__clzll((long long)df) >> 3 : 8u;
+				const uint32_t run = min(lead, reach);
+				rs.mat += (int)run; op = 0; x -= (int)run; y -= (int)run; step = run;
+			}
+			else {
+				step = 1u;
+				const long p1 = (long)x - (long)b1;
+				int u3, u4;
+				two_bits((uint32_t)y + 1u, p1, u3, u4);
+				if(u3 == 0 && u4 == 1){ rs.ins++; op = 1; x--; }
+				else {
+					const long p0 = (long)x - (long)b0;
+					int u1, u2;
+					two_bits((uint32_t)y, p0, u1, u2);
+					if(u1 == 1 && u2 == 0){ rs.del++; op = 2; y--; }
+					else { rs.mis++; op = 0; x--; y--; }
+				}
+			}
+			if(op == (cg & 0xf)) cg += 0x10u * step;
+			else { if(cg) cig_push(cg); cg = (0x10u * step) | op; }
+			active = x >= 0 && y >= 0;
+			svc_left -= min(step, svc_left);
+		}
 	}
+	if(COOP && (!walker || skip)){ if(walker){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
 	if(!bad){
 		rs.qb = x + 1; rs.tb = y + 1;
 		if(rs.qb){
@@ -601,16 +706,28 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 
 hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
-	// fewest pairs per wave that keep every wave resident (8 waves per SIMD, 4 SIMDs per CU), a power of two in [2, 64]
+	// fewest pairs per wave that keep every wave resident, a power of two in [2, 64]; up to 8 pairs per wave the idle
+	// lanes prefetch rows for the walking ones (COOP)
 	int dev = 0, cus = 256;
 	if(hipGetDevice(&dev) == hipSuccess){
 		int v = 0;
 		if(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
 	}
-	const uint32_t slots = (uint32_t)cus * 4u * 8u;
+	static int per_cu[2] = {0, 0};         // resident blocks (= waves) per CU of the two variants
+	if(per_cu[0] == 0){
+		int v = 0;
+		per_cu[0] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_edit_trace<false>, 64, 0) == hipSuccess && v > 0) ? v : 32;
+		per_cu[1] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_edit_trace<true>, 64, 0) == hipSuccess && v > 0) ? v : 32;
+		(void)hipGetLastError();
+	}
+	const char *ce = getenv("BSA_EDIT_TRACE_COOP");
+	const bool coop_ok = !(ce && ce[0] == '0');
 	uint32_t lanes = 2;
-	while(lanes < 64u && (a.count + lanes - 1) / lanes > slots) lanes <<= 1;
+	const uint32_t slots_c = (uint32_t)cus * (uint32_t)per_cu[1], slots_p = (uint32_t)cus * (uint32_t)per_cu[0];
+	while(lanes < 64u && (a.count + lanes - 1) / lanes > (lanes <= 8u && coop_ok ? slots_c : slots_p)) lanes <<= 1;
+	if(const char *e = getenv("BSA_EDIT_TRACE_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) lanes = (uint32_t)v; }
 	const uint32_t blocks = (a.count + lanes - 1) / lanes;
-	hipLaunchKernelGGL(k_edit_trace, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt, lanes);
+	if(lanes <= 8u && lanes >= 2u && coop_ok) hipLaunchKernelGGL(k_edit_trace<true>, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt, lanes);
+	else hipLaunchKernelGGL(k_edit_trace<false>, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt, lanes);
 	return hipGetLastError();
 }
