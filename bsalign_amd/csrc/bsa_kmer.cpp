@@ -291,7 +291,12 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 	auto t0 = now();
 	/* 1. chains and segment lists, threads over pairs */
 	std::vector<std::vector<bsa_kmer_seg_t>> segs(n);
+	std::vector<uint32_t> flag(n, 0);                      // a base code above 3 on an anchor column never reaches the device: look here
 	parallel_for(n, par->threads, [&](size_t k){
+		uint8_t any = 0;
+		for(uint32_t i = 0; i < qlen[k]; i++) any |= seqs[qoff[k] + i];
+		for(uint32_t i = 0; i < tlen[k]; i++) any |= seqs[toff[k] + i];
+		if(any > 3) flag[k] = BSA_ST_BAD_BASE;
 		std::vector<Hit> hits;
 		chain(ksz, seqs + qoff[k], qlen[k], seqs + toff[k], tlen[k], hits);
 		std::vector<uint64_t> maps(hits.size());
@@ -380,7 +385,7 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 	parallel_for(n, par->threads, [&](size_t k){
 		const size_t ns = segs[k].size();
 		std::vector<bsa_result_t> rs(ns); std::vector<const uint32_t*> ptr(ns); std::vector<uint64_t> cnt(ns);
-		uint32_t st = 0;
+		uint32_t st = flag[k];
 		for(size_t j = 0; j < ns; j++){
 			const size_t g = seg_base[k] + j;
 			if(seg_job[g] == 0xFF){ memset(&rs[j], 0, sizeof(bsa_result_t)); ptr[j] = nullptr; cnt[j] = 0; continue; }

@@ -102,3 +102,29 @@ def test_compat_function_equals_reference_fixture():
         n = cigars.contents.size
         assert np.array_equal(np.ctypeslib.as_array(cigars.contents.buffer, shape=(max(n, 1),))[:n], cig), k
         assert np.array_equal(q, q0) and np.array_equal(t, t0)
+
+
+def test_degenerate_batches(ctx):
+    import bsalign_amd as B
+    # nothing to do
+    out, cigs, st = ctx.kmer_edit_batch([], ksz=13)
+    assert len(out) == 0 and len(cigs) == 0
+    # pairs with an empty side give the zero result (bsalign.h:1051-1054 through :1436-1438); a base code above 3 is flagged
+    rng = np.random.default_rng(1)
+    t = rng.integers(0, 4, 500).astype(np.uint8)
+    bad = S.mutate(rng, t, 0.05)
+    bad[17] = 7
+    pairs = [(np.zeros(0, np.uint8), t), (t, np.zeros(0, np.uint8)), (t.copy(), t), (bad, t)]
+    out, cigs, st = ctx.kmer_edit_batch(pairs, ksz=11)
+    assert all(out[0][f] == 0 for f in out.dtype.names) and len(cigs[0]) == 0
+    assert all(out[1][f] == 0 for f in out.dtype.names) and len(cigs[1]) == 0
+    # identical sequences: every k-mer is an anchor; the reference appends segment CIGARs without merging (bsalign.h:974-975)
+    assert out[2]["mat"] == 500 and out[2]["score"] == 0 and S.cigar_str(cigs[2]) == "5M490M5M"
+    assert st[3] & B.ST_BAD_BASE if hasattr(B, "ST_BAD_BASE") else st[3] != 0
+    # k-mer size 0 is refused
+    par = B.KmerParams()
+    par.ksz, par.threads = 0, 1
+    seqs, qoff, qlen, toff, tlen = B.pack_pairs(pairs[2:3])
+    o = np.zeros(1, dtype=B.RESULT_DTYPE)
+    assert B.lib().bsa_kmer_edit_batch(ctx.h, B._p(seqs), seqs.size, B._p(qoff), B._p(qlen), B._p(toff), B._p(tlen), 1, C.byref(par),
+                                       B._p(o), None, 0, None, None) == -2
