@@ -384,7 +384,7 @@ def main():
                        "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "forward DP (k_align8_fwd_pk, 4-bit traceback codes)" if args.workload == "align8" else "forward DP (k_edit_fwd / k_edit_fwd_wide)",
+                         "kernel": "forward DP (k_align8_fwd_pk, 4-bit traceback codes)" if args.workload == "align8" else "forward DP (k_edit_fwd_grp / k_edit_fwd / k_edit_fwd_wide)",
                          "kernel_ms_avg": round(kms, 3), "launches_per_step": klaunch,
                          "algorithmic_bytes_per_launch": round(balg / max(klaunch, 1), 1),
                          "kernel_gcups": round(kcells / max(klaunch, 1) / (kms / 1e3) / 1e9, 2) if kms > 0 else None},

@@ -18,6 +18,7 @@
 // Mapping: one pair per lane (64 pairs per wave), all state in VGPRs, no cross-lane traffic; the kernel is
 // HBM-bound: per row and pair it writes the two planes (W*16 bytes = 2 bits per band cell), nothing else.
 #include "bsa_common.h"
+#include "bsa_dpp.h"
 
 typedef uint64_t u64;
 
@@ -27,7 +28,6 @@ static __device__ __forceinline__ u64 fsr(u64 lo, u64 hi, uint32_t m){   // (hi:
 	return (lo >> m) | (hi << (64 - m));
 }
 static __device__ __forceinline__ u64 lowmask(uint32_t n){ return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
-
 // row records: row r (r = 0 is the initial row, r = i+1 the row of target base i): [plane0: NW u64][plane1: NW u64]
 // TRACK (overlap / extend): also follow H at the last query column from row to row (its minimum picks the end cell)
 template<int NW, bool TRACK>
@@ -53,12 +53,12 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lane
 		const uint32_t w0 = rb >> 6, sh = rb & 63u;
 #pragma unroll
 		for(int k = 0; k < NW; k++){
-			Q0[k] = fsr(Q0m[w0 + k], Q0m[w0 + k + 1], sh);
-			Q1[k] = fsr(Q1m[w0 + k], Q1m[w0 + k + 1], sh);
+			Q0[k] = fsr(*(Q0m + w0 + k), *(Q0m + w0 + k + 1), sh);
+			Q1[k] = fsr(*(Q1m + w0 + k), *(Q1m + w0 + k + 1), sh);
 		}
 		const uint32_t lp = rb + BW;
 		lword = lp >> 6; lbit = lp & 63u;
-		l0c = Q0m[lword]; l0n = Q0m[lword + 1]; l1c = Q1m[lword]; l1n = Q1m[lword + 1];
+		l0c = *(Q0m + lword); l0n = *(Q0m + lword + 1); l1c = *(Q1m + lword); l1n = *(Q1m + lword + 1);
 	};
 #pragma unroll
 	for(int k = 0; k < NW; k++){ Pv[k] = ~0ull; Mv[k] = 0ull; rows[k] = 0ull; rows[NW + k] = ~0ull; }   // row_init (:653-656)
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lane
 			if(lbit >= 64u){
 				lbit -= 64u; lword++;
 				l0c = l0n; l1c = l1n;
-				l0n = Q0m[lword + 1]; l1n = Q1m[lword + 1];
+				l0n = *(Q0m + lword + 1); l1n = *(Q1m + lword + 1);
 			}
 		} else {
 			while(movx){
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64) k_edit_fwd(const EditArgs a, uint32_t lane
 				if(lbit >= 64u){
 					lbit -= 64u; lword++;
 					l0c = l0n; l1c = l1n;
-					l0n = Q0m[lword + 1]; l1n = Q1m[lword + 1];
+					l0n = *(Q0m + lword + 1); l1n = *(Q1m + lword + 1);
 				}
 				movx -= m;
 			}
@@ -378,6 +378,131 @@ __global__ void __launch_bounds__(256) k_edit_fwd_wide(const EditArgs a){
 	}
 	if(lane == lastw / WPL){ a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry; }
 	if(lane == 0) a.fwd_sbeg[ppos] = overlap ? 0 : (int)tlen;                     // no band motion: H at the band start grows by one per row (:667-676)
+}
+
+// ---- bands up to 1024 columns, few pairs: G lanes per pair ------------------------------------------------------------
+// The pair-per-lane kernel above walks its NW words one after the other, a dependent chain of some 75 instructions per
+// word, and a batch that does not fill the chip (16384 pairs = one wave per CU) is bound by exactly that chain.  Here the
+// words of a pair sit side by side in G = 2, 4, 8 or 16 lanes (lane gl owns word gl, 64 / G pairs per wave) and the chain
+// across them is resolved as in k_edit_fwd_wide, per group: the top word of a group and idle lanes neither generate nor
+// propagate, so no carry crosses into the next pair.  The band moves (global mode): the words shift right by movx bits
+// with the next lane's word coming in through a DPP row shift (+1 cells shifted in on the right), lane 0 keeps H at the
+// band start, and the query planes shift the same way, the top lane feeding them from a 128-bit look-ahead.
+static __device__ __forceinline__ u64 dpp_next_lane64(u64 x){        // lane j <- lane j + 1 inside its row of 16
+	const int lo = DPP_SHL(0, (int)(uint32_t)x, 1), hi = DPP_SHL(0, (int)(uint32_t)(x >> 32), 1);
+	return (u64)(uint32_t)hi << 32 | (u64)(uint32_t)lo;
+}
+
+template<int G>
+__global__ void __launch_bounds__(256) k_edit_fwd_grp(const EditArgs a){
+	constexpr uint32_t PPW = 64u / G;
+	constexpr u64 GS = G == 2 ? 0x5555555555555555ull : G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;   // first lane of every group
+	const uint32_t lane = threadIdx.x & 63u, gl = lane % G, grp = lane / G;
+	const uint32_t g = (blockIdx.x * 4u + (threadIdx.x >> 6)) * PPW + grp;
+	const bool valid = g < a.count;
+	const uint32_t ppos = a.first + (valid ? g : 0u), pair = a.order[ppos];
+	const bool live = valid && a.status[pair] == 0u;
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint32_t BW = a.bw, NW = BW / 64u;
+	const u64 *Q0m = a.qbits + a.qboff[pair];
+	const u64 *Q1m = Q0m + a.qwords[pair];
+	const uint8_t *tp = a.tst + a.tpoff[pair];
+	u64 *rows = (u64*)(a.rows + a.slot_off[ppos]);
+	const int type = a.mode & 3;
+	const bool overlap = type == BSA_MODE_OVERLAP;
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+	const bool word = gl < NW, top = gl + 1u == NW;
+	const uint32_t tl = live ? tlen : 0u;
+	u64 pv = ~0ull, mv = 0ull;
+	if(live && word){ rows[gl] = 0ull; rows[NW + gl] = ~0ull; }            // row_init (:653-656)
+	u64 q0 = word ? Q0m[gl] : 0ull, q1 = word ? Q1m[gl] : 0ull;            // query planes at band offset 0
+	// the top lane keeps the query bits behind the band end: position lpos sits in (l?c, l?n) at bit lpos & 63
+	uint32_t lpos = BW;
+	u64 l0c = 0, l0n = 0, l1c = 0, l1n = 0;
+	if(top){ l0c = Q0m[NW]; l0n = Q0m[NW + 1u]; l1c = Q1m[NW]; l1n = Q1m[NW + 1u]; }
+	int sbeg = 0;                                                           // lane 0 of the group: H at the band start
+	uint32_t rb0 = 0;
+	u64 quo = 0, rem = 0;
+	const u64 qstep = qlen / (tlen ? tlen : 1u), rstep = qlen % (tlen ? tlen : 1u);
+	const uint32_t lastw = (qlen - 1u) >> 6, lastb = (qlen - 1u) & 63u;
+	int slast = (int)qlen, smin = 0x7FFFFFFF, ry = (int)tlen - 1;
+	const u64 hin0_mask = overlap ? 0ull : GS;
+	u64 tw = 0;
+	for(uint32_t i = 0; __any(i < tl); i++){
+		const bool on = i < tl;
+		if(on && (i & 7u) == 0u) tw = *(const u64*)(tp + i);      // staged 16-byte aligned with >= 8 bytes of padding
+		const uint32_t tb = (uint32_t)(tw >> (8u * (i & 7u))) & 3u;
+		uint32_t rb1 = 0;
+		if(type == BSA_MODE_GLOBAL){                                         // fixed diagonal band (:1112-1114)
+			uint32_t c = (uint32_t)quo;
+			c = (c < BW / 2) ? 0u : c - BW / 2;
+			rb1 = (c + BW > qround) ? qround - BW : c;
+		}
+		uint32_t movx = on ? rb1 - rb0 : 0u;
+		// ---- row_movx (:658-721)
+		if(overlap) sbeg = 0; else if(on) sbeg += 1;
+		if(__any(movx != 0u)){
+			while(__any(movx >= 64u)){                                        // whole words (rare)
+				u64 np = dpp_next_lane64(pv), nm = dpp_next_lane64(mv), nq0 = dpp_next_lane64(q0), nq1 = dpp_next_lane64(q1);
+				if(top){ np = ~0ull; nm = 0ull; nq0 = fsr(l0c, l0n, lpos & 63u); nq1 = fsr(l1c, l1n, lpos & 63u); }
+				if(movx >= 64u){
+					if(!overlap) sbeg += __popcll(pv) - __popcll(mv);
+					pv = np; mv = nm; q0 = nq0; q1 = nq1; movx -= 64u;
+					lpos += 64u;
+					if(top){ l0c = l0n; l1c = l1n; l0n = *(Q0m + (lpos >> 6) + 1u); l1n = *(Q1m + (lpos >> 6) + 1u); }
+				}
+			}
+			u64 np = dpp_next_lane64(pv), nm = dpp_next_lane64(mv), nq0 = dpp_next_lane64(q0), nq1 = dpp_next_lane64(q1);
+			if(top){ np = ~0ull; nm = 0ull; nq0 = fsr(l0c, l0n, lpos & 63u); nq1 = fsr(l1c, l1n, lpos & 63u); }
+			if(movx){
+				const u64 mk = (1ull << movx) - 1ull;
+				const uint32_t r = 64u - movx;
+				if(!overlap) sbeg += __popcll(pv & mk) - __popcll(mv & mk);
+				pv = (pv >> movx) | (np << r);
+				mv = (mv >> movx) | (nm << r);
+				q0 = (q0 >> movx) | (nq0 << r);
+				q1 = (q1 >> movx) | (nq1 << r);
+				const uint32_t lw = lpos >> 6;
+				lpos += movx;
+				if(top && (lpos >> 6) != lw){ l0c = l0n; l1c = l1n; l0n = *(Q0m + (lpos >> 6) + 1u); l1n = *(Q1m + (lpos >> 6) + 1u); }
+			}
+		}
+		// ---- row_cal (:766-810): this lane's word for both signs of the delta entering it, then the chain per group
+		const bool act = on && word;
+		const u64 x0 = (tb & 1u) ? 0ull : ~0ull, x1 = (tb & 2u) ? 0ull : ~0ull;
+		const uint32_t nvalid = (rb1 < qlen) ? qlen - rb1 : 0u, lo = gl * 64u;
+		const u64 vm = (nvalid > lo) ? lowmask(nvalid - lo) : 0ull;
+		const u64 Eq = (q0 ^ x0) & (q1 ^ x1) & vm;
+		const u64 Xv = Eq | mv;
+		const u64 e1 = Eq | 1ull;
+		const u64 t0 = (((Eq & pv) + pv) ^ pv) | Eq;
+		const u64 t1 = (((e1 & pv) + pv) ^ pv) | e1;
+		const uint32_t ph0 = (uint32_t)((mv | ~(t0 | pv)) >> 63), mh0 = (uint32_t)((pv & t0) >> 63);
+		const uint32_t ph1 = (uint32_t)((mv | ~(t1 | pv)) >> 63), mh1 = (uint32_t)((pv & t1) >> 63);
+		const bool link = act && !top;                                        // the top word's outgoing delta leaves the band
+		const u64 A = __ballot(link && mh0 > ph0), B = __ballot(link && mh1 > ph1);
+		const u64 C = uniform64(chain_neg(A, B));                             // bit l: a negative delta enters lane l
+		const u64 PA = __ballot(link && ph0 > mh0), PB = __ballot(link && ph1 > mh1);
+		const u64 Ppos = uniform64(((((PA & ~C) | (PB & C)) << 1) & ~GS) | hin0_mask);   // left of the band v = +1, 0 in overlap mode (:770)
+		const u64 Xh = mask_pick64(t0, t1, C);
+		u64 Ph = mv | ~(Xh | pv);
+		u64 Mh = pv & Xh;
+		if(type != BSA_MODE_GLOBAL && gl == lastw) slast += (int)((Ph >> lastb) & 1ull) - (int)((Mh >> lastb) & 1ull);
+		Ph = (Ph << 1) | (u64)mask_pick(0u, 1u, Ppos);
+		Mh = (Mh << 1) | (u64)mask_pick(0u, 1u, C);
+		if(act){
+			pv = Mh | ~(Xv | Ph);
+			mv = Ph & Xv;
+			u64 *rp = rows + (size_t)(i + 1) * (2 * NW);
+			rp[gl] = mv; rp[NW + gl] = pv;
+			if(type != BSA_MODE_GLOBAL && slast < smin){ smin = slast; ry = (int)i; }
+		}
+		rb0 = on ? rb1 : rb0;
+		quo += qstep; rem += rstep;
+		if(rem >= tlen){ rem -= tlen; quo++; }
+	}
+	if(live && gl == 0u) a.fwd_sbeg[ppos] = sbeg;
+	if(live && gl == (type != BSA_MODE_GLOBAL ? lastw : 0u)){ a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -684,6 +809,23 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 #define EDIT_CASE(N) case N: if(track) hipLaunchKernelGGL((k_edit_fwd<N, true>), dim3(fblocks), dim3(64), 0, st, a, lanes); \
 		else hipLaunchKernelGGL((k_edit_fwd<N, false>), dim3(fblocks), dim3(64), 0, st, a, lanes); break;
 	const bool track = (a.mode & 3) != BSA_MODE_GLOBAL;
+	// few pairs: G lanes per pair (waves stay few, every row is a third of the serial chain); many pairs: one per lane
+	{
+		const uint32_t nw = a.bw / 64u;
+		const uint32_t G = nw <= 2u ? 2u : nw <= 4u ? 4u : nw <= 8u ? 8u : 16u;
+		bool grp = a.bw != 0u && nw >= 2u && nw <= 16u && (uint64_t)a.count * G / 64u <= 4096u;
+		if(const char *e = getenv("BSA_EDIT_GRP")) grp = a.bw != 0u && nw >= 2u && nw <= 16u && e[0] == '1';
+		if(grp){
+			const uint32_t ppw = 64u / G, gblocks = ((a.count + ppw - 1) / ppw + 3) / 4;
+			switch(G){
+				case 2: hipLaunchKernelGGL((k_edit_fwd_grp<2>), dim3(gblocks), dim3(256), 0, st, a); break;
+				case 4: hipLaunchKernelGGL((k_edit_fwd_grp<4>), dim3(gblocks), dim3(256), 0, st, a); break;
+				case 8: hipLaunchKernelGGL((k_edit_fwd_grp<8>), dim3(gblocks), dim3(256), 0, st, a); break;
+				default: hipLaunchKernelGGL((k_edit_fwd_grp<16>), dim3(gblocks), dim3(256), 0, st, a); break;
+			}
+			return hipGetLastError();
+		}
+	}
 	switch(a.bw / 64){
 		EDIT_CASE(1) EDIT_CASE(2) EDIT_CASE(3) EDIT_CASE(4) EDIT_CASE(5) EDIT_CASE(6) EDIT_CASE(7) EDIT_CASE(8)
 		EDIT_CASE(9) EDIT_CASE(10) EDIT_CASE(11) EDIT_CASE(12) EDIT_CASE(13) EDIT_CASE(14) EDIT_CASE(15) EDIT_CASE(16)
