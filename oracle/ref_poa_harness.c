@@ -18,9 +18,41 @@
  * Recorded per read: the seqalign_result_t of align_rd_bspoa, the program (tasks), the best end cell and a hash of
  * the reference's row blocks -- tests/golden/make_golden_poa.py turns these into the committed fixtures.
  */
-#include "bspoa.h"
-#include "../include/bsalign_poa_adapter.h"
 #include <stdint.h>
+#include "bsalign.h"
+/* The POA places the band of a long read by a k-mer anchored edit alignment against the current consensus
+ * (bspoa.h:2087-2090, 4360-4361).  When a GPU test has attached the product's batch entry (ref_poa_set_kmer), those
+ * calls go to the device instead -- a batch of one through bsa_kmer_edit_batch, the CIGAR pushed into the reference's
+ * own vector -- so that the whole end_bspoa can be checked with BOTH of its alignment steps on the MI355X. */
+typedef int (*kmer_batch_fn)(void *ctx, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *qoff, const uint32_t *qlen,
+		const uint64_t *toff, const uint32_t *tlen, size_t n, const void *par, void *out, uint32_t *cigar, size_t cap, uint64_t *cigar_off, uint32_t *status);
+static kmer_batch_fn g_kmer_batch = NULL;
+static void *g_kmer_ctx = NULL;
+static long g_kmer_calls = 0, g_kmer_device_calls = 0;
+void ref_poa_set_kmer(void *kmer_batch_addr, void *ctx){ g_kmer_batch = (kmer_batch_fn)kmer_batch_addr; g_kmer_ctx = ctx; }
+long ref_poa_kmer_calls(int device){ return device ? g_kmer_device_calls : g_kmer_calls; }
+static inline seqalign_result_t harness_kmer_edit(u1i ksz, u1i *qseq, u4i qlen, u1i *tseq, u4i tlen, b1v *mempool, u4v *cigars, int verbose){
+	g_kmer_calls ++;
+	if(g_kmer_batch == NULL || qlen == 0 || tlen == 0) return kmer_striped_seqedit_pairwise(ksz, qseq, qlen, tseq, tlen, mempool, cigars, verbose);
+	seqalign_result_t rs;
+	uint32_t par[2] = { ksz, 1 }, status = 0;
+	uint64_t qoff = 0, toff = qlen, off[2] = {0, 0};
+	size_t cap = (size_t)qlen + tlen + 8, k;
+	uint8_t *seqs = (uint8_t*)malloc((size_t)qlen + tlen + 1);
+	uint32_t *cig = (uint32_t*)malloc(cap * sizeof(uint32_t));
+	memcpy(seqs, qseq, qlen); memcpy(seqs + qlen, tseq, tlen);
+	int rc = g_kmer_batch(g_kmer_ctx, seqs, (size_t)qlen + tlen, &qoff, &qlen, &toff, &tlen, 1, par, &rs, cig, cap, off, &status);
+	if(rc != 0 || status != 0){ fprintf(stderr, " -- device k-mer alignment failed (%d, status %u) --\n", rc, status); abort(); }
+	clear_u4v(cigars);
+	for(k = 0; k < off[1]; k++) push_u4v(cigars, cig[k]);
+	free(seqs); free(cig);
+	g_kmer_device_calls ++;
+	return rs;
+}
+#define kmer_striped_seqedit_pairwise harness_kmer_edit
+#include "bspoa.h"
+#undef kmer_striped_seqedit_pairwise
+#include "../include/bsalign_poa_adapter.h"
 #include <time.h>
 
 /* the adapter's two link-time dependencies on libbsalign_hip.so, satisfied locally: this library must load without HIP.

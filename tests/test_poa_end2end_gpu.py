@@ -49,3 +49,31 @@ def test_c4_scaled_wall_time(ctx, capsys):
     assert r3["bad"] == 0 and np.array_equal(r0["cns"], r3["cns"]) and r0["msa"] == r3["msa"]
     with capsys.disabled():
         print("\n[C4 scaled] end_bspoa 32 x 4 kbp: reference %.2f s, sweep on the device %.2f s (includes the harness re-running the reference sweep for comparison)" % (t1 - t0, t2 - t1))
+
+
+def test_end_bspoa_with_sweep_and_kmer_alignment_on_the_device(ctx):
+    """both alignment steps of a POA read on the MI355X: the k-mer anchored edit alignment against the consensus that
+    places the band (bspoa.h:2087-2090 -> bsa_kmer_edit_batch) and the sweep (align_rd_bspoacore -> bsa_sweep_host);
+    consensus, qualities and MSA must equal the untouched reference run"""
+    import bsalign_amd as B
+    _attach(ctx)
+    r = P.ref_poa()
+    r.ref_poa_set_kmer.argtypes = [C.c_void_p, C.c_void_p]
+    r.ref_poa_set_kmer.restype = None
+    r.ref_poa_kmer_calls.argtypes = [C.c_int]
+    r.ref_poa_kmer_calls.restype = C.c_long
+    p = P.par()
+    reads = P.synth_reads(777, 1500, 12, eps=(0.1,))
+    r0 = P.run_ref_poa(reads, 0, p, record=False)
+    r.ref_poa_set_kmer(C.cast(B.lib().bsa_kmer_edit_batch, C.c_void_p), ctx.h)
+    try:
+        before = r.ref_poa_kmer_calls(1)
+        r3 = P.run_ref_poa(reads, 3, p, record=False)
+        used = r.ref_poa_kmer_calls(1) - before
+    finally:
+        r.ref_poa_set_kmer(None, None)
+    assert used >= len(reads) - 2, "the k-mer alignments did not go to the device"
+    assert r3["bad"] == 0
+    for k in ("cns", "qlt", "alt"):
+        assert np.array_equal(r0[k], r3[k]), k
+    assert r0["msa"] == r3["msa"]
