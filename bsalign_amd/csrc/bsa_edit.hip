@@ -422,19 +422,20 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp(const EditArgs a){
 	if(top){ l0c = Q0m[NW]; l0n = Q0m[NW + 1u]; l1c = Q1m[NW]; l1n = Q1m[NW + 1u]; }
 	int sbeg = 0;                                                           // lane 0 of the group: H at the band start
 	uint32_t rb0 = 0;
-	u64 quo = 0, rem = 0;
-	const u64 qstep = qlen / (tlen ? tlen : 1u), rstep = qlen % (tlen ? tlen : 1u);
+	uint32_t quo = 0, rem = 0;                                              // floor(i * qlen / tlen) and the remainder, kept incrementally
+	const uint32_t qstep = qlen / (tlen ? tlen : 1u), rstep = qlen % (tlen ? tlen : 1u);
 	const uint32_t lastw = (qlen - 1u) >> 6, lastb = (qlen - 1u) & 63u;
 	int slast = (int)qlen, smin = 0x7FFFFFFF, ry = (int)tlen - 1;
 	const u64 hin0_mask = overlap ? 0ull : GS;
 	u64 tw = 0;
+	u64 *rp = rows + 2u * NW + gl;                                          // this lane's word of the row being written
 	for(uint32_t i = 0; __any(i < tl); i++){
 		const bool on = i < tl;
 		if(on && (i & 7u) == 0u) tw = *(const u64*)(tp + i);      // staged 16-byte aligned with >= 8 bytes of padding
-		const uint32_t tb = (uint32_t)(tw >> (8u * (i & 7u))) & 3u;
+		const uint32_t tb = (((i & 4u) ? (uint32_t)(tw >> 32) : (uint32_t)tw) >> (8u * (i & 3u))) & 3u;
 		uint32_t rb1 = 0;
 		if(type == BSA_MODE_GLOBAL){                                         // fixed diagonal band (:1112-1114)
-			uint32_t c = (uint32_t)quo;
+			uint32_t c = quo;
 			c = (c < BW / 2) ? 0u : c - BW / 2;
 			rb1 = (c + BW > qround) ? qround - BW : c;
 		}
@@ -470,9 +471,9 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp(const EditArgs a){
 		// ---- row_cal (:766-810): this lane's word for both signs of the delta entering it, then the chain per group
 		const bool act = on && word;
 		const u64 x0 = (tb & 1u) ? 0ull : ~0ull, x1 = (tb & 2u) ? 0ull : ~0ull;
-		const uint32_t nvalid = (rb1 < qlen) ? qlen - rb1 : 0u, lo = gl * 64u;
-		const u64 vm = (nvalid > lo) ? lowmask(nvalid - lo) : 0ull;
-		const u64 Eq = (q0 ^ x0) & (q1 ^ x1) & vm;
+		const uint32_t nvalid = (rb1 < qlen) ? qlen - rb1 : 0u;          // band cells that are real query columns
+		u64 Eq = (q0 ^ x0) & (q1 ^ x1);
+		if(__any(nvalid < BW)){ const uint32_t lo = gl * 64u; Eq &= (nvalid > lo) ? lowmask(nvalid - lo) : 0ull; }
 		const u64 Xv = Eq | mv;
 		const u64 e1 = Eq | 1ull;
 		const u64 t0 = (((Eq & pv) + pv) ^ pv) | Eq;
@@ -493,13 +494,13 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp(const EditArgs a){
 		if(act){
 			pv = Mh | ~(Xv | Ph);
 			mv = Ph & Xv;
-			u64 *rp = rows + (size_t)(i + 1) * (2 * NW);
-			rp[gl] = mv; rp[NW + gl] = pv;
+			rp[0] = mv; rp[NW] = pv;
 			if(type != BSA_MODE_GLOBAL && slast < smin){ smin = slast; ry = (int)i; }
 		}
 		rb0 = on ? rb1 : rb0;
-		quo += qstep; rem += rstep;
-		if(rem >= tlen){ rem -= tlen; quo++; }
+		quo += qstep;
+		if(rem >= tlen - rstep){ rem -= tlen - rstep; quo++; } else rem += rstep;     // no 33-bit sum
+		rp += 2u * NW;
 	}
 	if(live && gl == 0u) a.fwd_sbeg[ppos] = sbeg;
 	if(live && gl == (type != BSA_MODE_GLOBAL ? lastw : 0u)){ a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry; }
