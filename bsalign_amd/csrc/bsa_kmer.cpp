@@ -313,32 +313,58 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 	std::vector<size_t> seg_base(n + 1, 0);
 	for(size_t k = 0; k < n; k++) seg_base[k + 1] = seg_base[k] + segs[k].size();
 	std::vector<uint8_t> seg_job(seg_base[n], 0xFF); std::vector<uint32_t> seg_idx(seg_base[n], 0);
-	for(size_t k = 0; k < n; k++){
-		for(size_t j = 0; j < segs[k].size(); j++){
-			const bsa_kmer_seg_t &s = segs[k][j];
-			const uint32_t ql = s.qe - s.qb, tl = s.te - s.tb;
-			if(ql == 0 || tl == 0) continue;                  /* an empty side gives the all-zero result (bsalign.h:1051-1054) */
-			const int w = ((s.mode & 3) == BSA_MODE_GLOBAL) ? 1 : 0;
-			Job &J = job[w];
-			if(w == 0){
-				const size_t base = heads.size();
-				heads.resize(base + ql + tl);
-				if(s.mode & BSA_KMER_SEG_REVERSED){
-					std::reverse_copy(seqs + qoff[k], seqs + qoff[k] + s.qe, heads.begin() + base);
-					std::reverse_copy(seqs + toff[k], seqs + toff[k] + s.te, heads.begin() + base + ql);
-				} else {
-					memcpy(heads.data() + base, seqs + qoff[k] + s.qb, ql);
-					memcpy(heads.data() + base + ql, seqs + toff[k] + s.tb, tl);
-				}
-				J.qo.push_back(base); J.to.push_back(base + ql);
-			} else {
-				J.qo.push_back(qoff[k] + s.qb); J.to.push_back(toff[k] + s.tb);
+	{
+		/* where every pair's segments go: counts per pair, prefix sums, then all pairs fill their own ranges in parallel */
+		std::vector<size_t> cnt0(n + 1, 0), cnt1(n + 1, 0), hb(n + 1, 0);
+		parallel_for(n, par->threads, [&](size_t k){
+			size_t c0 = 0, c1 = 0, h = 0;
+			for(const bsa_kmer_seg_t &s : segs[k]){
+				const uint32_t ql = s.qe - s.qb, tl = s.te - s.tb;
+				if(ql == 0 || tl == 0) continue;              /* an empty side gives the all-zero result (bsalign.h:1051-1054) */
+				if((s.mode & 3) == BSA_MODE_GLOBAL) c1 ++; else { c0 ++; h += (size_t)ql + tl; }
 			}
-			J.ql.push_back(ql); J.tl.push_back(tl);
-			J.cap += (size_t)ql + tl + 2;
-			seg_job[seg_base[k] + j] = (uint8_t)w;
-			seg_idx[seg_base[k] + j] = (uint32_t)J.ql.size() - 1;
+			cnt0[k + 1] = c0; cnt1[k + 1] = c1; hb[k + 1] = h;
+		});
+		for(size_t k = 0; k < n; k++){ cnt0[k + 1] += cnt0[k]; cnt1[k + 1] += cnt1[k]; hb[k + 1] += hb[k]; }
+		if(cnt0[n] > 0xFFFFFFF0ull || cnt1[n] > 0xFFFFFFF0ull) return BSA_E_ARG;
+		heads.resize(hb[n]);
+		for(int w = 0; w < 2; w++){
+			const size_t m = w ? cnt1[n] : cnt0[n];
+			job[w].qo.resize(m); job[w].to.resize(m); job[w].ql.resize(m); job[w].tl.resize(m);
 		}
+		std::vector<size_t> caps0(n, 0), caps1(n, 0);
+		parallel_for(n, par->threads, [&](size_t k){
+			size_t i0 = cnt0[k], i1 = cnt1[k], base = hb[k], cap0 = 0, cap1 = 0;
+			for(size_t j = 0; j < segs[k].size(); j++){
+				const bsa_kmer_seg_t &s = segs[k][j];
+				const uint32_t ql = s.qe - s.qb, tl = s.te - s.tb;
+				if(ql == 0 || tl == 0) continue;
+				const int w = ((s.mode & 3) == BSA_MODE_GLOBAL) ? 1 : 0;
+				Job &J = job[w];
+				size_t &ix = w ? i1 : i0;
+				if(w == 0){
+					if(s.mode & BSA_KMER_SEG_REVERSED){
+						std::reverse_copy(seqs + qoff[k], seqs + qoff[k] + s.qe, heads.begin() + base);
+						std::reverse_copy(seqs + toff[k], seqs + toff[k] + s.te, heads.begin() + base + ql);
+					} else {
+						memcpy(heads.data() + base, seqs + qoff[k] + s.qb, ql);
+						memcpy(heads.data() + base + ql, seqs + toff[k] + s.tb, tl);
+					}
+					J.qo[ix] = base; J.to[ix] = base + ql;
+					base += (size_t)ql + tl;
+					cap0 += (size_t)ql + tl + 2;
+				} else {
+					J.qo[ix] = qoff[k] + s.qb; J.to[ix] = toff[k] + s.tb;
+					cap1 += (size_t)ql + tl + 2;
+				}
+				J.ql[ix] = ql; J.tl[ix] = tl;
+				seg_job[seg_base[k] + j] = (uint8_t)w;
+				seg_idx[seg_base[k] + j] = (uint32_t)ix;
+				ix ++;
+			}
+			caps0[k] = cap0; caps1[k] = cap1;
+		});
+		for(size_t k = 0; k < n; k++){ job[0].cap += caps0[k]; job[1].cap += caps1[k]; }
 	}
 	auto t2 = now();
 	for(int w = 0; w < 2; w++){
