@@ -120,3 +120,40 @@ def test_wide_kernel_with_extreme_rows(ctx):
              (np.tile(np.array([0, 1], dtype=np.uint8), 1500), np.tile(np.array([1, 0], dtype=np.uint8), 1400))]
     for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
         _check(ctx, pairs, mode, 0)
+
+
+def _golden_groups(name):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+    groups = {}
+    for k in range(int(g["n"][0])):
+        mode, bw = [int(x) for x in g["meta_%d" % k]]
+        groups.setdefault((mode, bw), []).append(k)
+    return g, groups
+
+
+def test_golden_wide_bands_from_the_reference(ctx):
+    """results of the real reference (tests/golden/edit_wide.npz) on bands above 1024 columns: every launch class of
+    the wave-per-pair kernel, the generic kernel, overlap / extend / bandwidth 0 and a moving wide band"""
+    g, groups = _golden_groups("edit_wide.npz")
+    for (mode, bw), ks in groups.items():
+        out, cigs, status = ctx.edit_batch([(g["q_%d" % k], g["t_%d" % k]) for k in ks], mode, bw)
+        for i, k in enumerate(ks):
+            got = np.array([out[i][f] for f in out.dtype.names], dtype=np.int32)
+            assert status[i] == 0 and np.array_equal(got, g["res_%d" % k]) and np.array_equal(cigs[i], g["cig_%d" % k]), (mode, bw, k)
+
+
+@pytest.mark.parametrize("env", [{"BSA_EDIT_GRP": "0"}, {"BSA_EDIT_GRP": "1"}, {"BSA_EDIT_TRACE_COOP": "0"}, {"BSA_EDIT_TRACE_LANES": "16"},
+                                 {"BSA_EDIT_NO_MERGE": "1"}], ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
+def test_golden_cases_on_every_kernel_variant(ctx, monkeypatch, env):
+    """the launchers pick kernels by batch size; force each alternative (pair-per-lane / grouped forward kernels, plain /
+    cooperative traceback, many pairs per wave, no class merging) and replay the reference's results"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("edit.npz", "edit_wide.npz"):
+        g, groups = _golden_groups(name)
+        for (mode, bw), ks in groups.items():
+            out, cigs, status = ctx.edit_batch([(g["q_%d" % k], g["t_%d" % k]) for k in ks], mode, bw)
+            for i, k in enumerate(ks):
+                got = np.array([out[i][f] for f in out.dtype.names], dtype=np.int32)
+                assert status[i] == 0 and np.array_equal(got, g["res_%d" % k]) and np.array_equal(cigs[i], g["cig_%d" % k]), (name, mode, bw, k)

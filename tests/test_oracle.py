@@ -37,6 +37,18 @@ def test_edit_golden():
         assert np.array_equal(cig, g["cig_%d" % k]), "case %d cigar" % k
 
 
+def test_edit_wide_golden():
+    """the oracle against the reference's results on bands above 1024 columns (tests/golden/make_golden_edit_wide.py)"""
+    g = _load("edit_wide.npz")
+    n = int(g["n"][0])
+    assert n >= 29
+    for k in range(n):
+        mode, bw = [int(x) for x in g["meta_%d" % k]]
+        res, cig, cnt = S.oracle_edit(g["q_%d" % k], g["t_%d" % k], mode, bw)
+        assert np.array_equal(res, g["res_%d" % k]), "case %d result %s != %s" % (k, res, g["res_%d" % k])
+        assert np.array_equal(cig, g["cig_%d" % k]), "case %d cigar" % k
+
+
 def test_golden_conventions():
     """result conventions of the reference: half-open spans, aln = mat+mis+ins+del, CIGAR covers the spans"""
     g = _load("align8.npz")
