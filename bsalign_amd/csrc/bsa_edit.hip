@@ -721,7 +721,13 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 			svc_left -= min(step, svc_left);
 		}
 	}
-	if(COOP && (!walker || skip)){ if(walker){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
+	if(COOP && (!walker || skip)){                     // flagged by an earlier stage: the zero result
+		if(walker){
+			rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+			out[pair] = rs; cig_cnt[ppos] = 0;
+		}
+		return;
+	}
 	if(!bad){
 		rs.qb = x + 1; rs.tb = y + 1;
 		if(rs.qb){

@@ -157,3 +157,28 @@ def test_golden_cases_on_every_kernel_variant(ctx, monkeypatch, env):
             for i, k in enumerate(ks):
                 got = np.array([out[i][f] for f in out.dtype.names], dtype=np.int32)
                 assert status[i] == 0 and np.array_equal(got, g["res_%d" % k]) and np.array_equal(cigs[i], g["cig_%d" % k]), (name, mode, bw, k)
+
+
+@pytest.mark.parametrize("mode,bw", [(S.MODE_GLOBAL, 256), (S.MODE_EXTEND, 0), (S.MODE_GLOBAL, 0)])
+def test_flagged_pairs_do_not_disturb_their_neighbours(ctx, mode, bw):
+    """a base code above 3 and empty sequences inside a batch: those pairs come back flagged with the zero result, the
+    pairs around them (same wave, same group of lanes) are unaffected -- for the grouped, the pair-per-lane and the
+    wave-per-pair kernels"""
+    import bsalign_amd as B
+    rng = np.random.default_rng(31 + mode + bw)
+    pairs = [_mk(rng, int(rng.choice([300, 900, 1500, 2600])), 0.1, 1.0) for _ in range(24)]
+    bad = pairs[5][0].copy()
+    bad[len(bad) // 2] = 9
+    pairs[5] = (bad, pairs[5][1])
+    pairs[11] = (np.zeros(0, np.uint8), pairs[11][1])
+    pairs[12] = (pairs[12][0], np.zeros(0, np.uint8))
+    out, cigs, status = ctx.edit_batch(pairs, mode, bw)
+    assert status[5] & B.ST_BAD_BASE and status[11] & B.ST_EMPTY and status[12] & B.ST_EMPTY
+    for k in (5, 11, 12):
+        assert all(out[k][f] == 0 for f in out.dtype.names) and len(cigs[k]) == 0
+    for k, (q, t) in enumerate(pairs):
+        if k in (5, 11, 12):
+            continue
+        res, cig, n = S.oracle_edit(q, t, mode, bw)
+        got = np.array([out[k][f] for f in out.dtype.names], dtype=np.int32)
+        assert status[k] == 0 and np.array_equal(got, res) and np.array_equal(cigs[k], cig), k
