@@ -182,3 +182,25 @@ def test_flagged_pairs_do_not_disturb_their_neighbours(ctx, mode, bw):
         res, cig, n = S.oracle_edit(q, t, mode, bw)
         got = np.array([out[k][f] for f in out.dtype.names], dtype=np.int32)
         assert status[k] == 0 and np.array_equal(got, res) and np.array_equal(cigs[k], cig), k
+
+
+@pytest.mark.parametrize("mode", [S.MODE_GLOBAL, S.MODE_EXTEND])
+def test_chunked_batches_with_mixed_band_classes(mode):
+    """a workspace limit cuts a batch of many different band widths into several chunks (each with several forward
+    launches and one traceback): results must not depend on the chunking"""
+    import bsalign_amd as B
+    rng = np.random.default_rng(91 + mode)
+    pairs = [_mk(rng, int(rng.choice([40, 200, 700, 1300, 2100, 4200, 5000])), float(rng.choice([0.05, 0.15])), float(rng.choice([1.0, 0.9, 1.1])))
+             for _ in range(120)]
+    big = B.Context(0)
+    out0, cig0, st0 = big.edit_batch(pairs, mode, 0)
+    big.close()
+    small = B.Context(0, workspace_limit=48 << 20)
+    out1, cig1, st1 = small.edit_batch(pairs, mode, 0)
+    small.close()
+    assert (st0 == 0).all() and np.array_equal(st0, st1) and np.array_equal(out0, out1)
+    for k in range(len(pairs)):
+        assert np.array_equal(cig0[k], cig1[k]), k
+    for k in range(0, len(pairs), 7):
+        res, cig, n = S.oracle_edit(pairs[k][0], pairs[k][1], mode, 0)
+        assert np.array_equal(np.array([out0[k][f] for f in out0.dtype.names], dtype=np.int32), res) and np.array_equal(cig0[k], cig)
