@@ -72,10 +72,22 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 	// tile record of this lane's block: written straight from LDS (generic path: no register tile buffer; W >= 1 any)
 	auto store_row = [&](const int8_t *row, uint32_t rr, uint32_t rbeg_v){
 		uint8_t *bp = rowp + ((size_t)(rr / tg) * 16u + (uint32_t)j) * tileb + (rr % tg) * blk;
-		for(uint32_t k = 0; k < W; k++){
-			bp[k] = (uint8_t)row[j * W + k];
-			if(PW >= 1) bp[W + k] = (uint8_t)row[BW + j * W + k];
-			if(PW == 2) bp[2 * W + k] = (uint8_t)row[2 * BW + j * W + k];
+		// the record is the byte stream u[0..W) | e[0..W) | q[0..W) (padded to `cells`): gathered from LDS four bytes at a
+		// time and written as dwords -- byte stores to HBM were the whole run time of this kernel
+		{
+			uint32_t plane = 0, cell = 0;
+			const int8_t *pl = row + (size_t)j * W;
+			for(uint32_t d = 0; d < cells / 4u; d++){
+				uint32_t v = 0;
+#pragma unroll
+				for(uint32_t b = 0; b < 4u; b++){
+					if(plane <= (uint32_t)PW){
+						v |= (uint32_t)(uint8_t)pl[cell] << (8u * b);
+						if(++cell == W){ cell = 0; plane++; pl += BW; }
+					}
+				}
+				((uint32_t*)bp)[d] = v;
+			}
 		}
 		*(int*)(bp + cells) = ubA;
 		if(j == 0) begs[rr] = (int)rbeg_v;
@@ -147,8 +159,11 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 		const int tb = act ? (int)tp[i] : 0;
 		const uint32_t mr = (tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3];
 		const uint8_t *qc = qp + rbeg + (size_t)j * W;
+		// query codes four at a time (the staged sequence is padded; unaligned dword loads are fine in global memory)
+		uint32_t qcw = 0, qcw_at = 0xFFFFFFFFu;
 		auto score = [&](uint32_t k) -> int {
-			const uint32_t c = act ? (uint32_t)qc[k] : 4u;
+			if((k >> 2) != qcw_at){ qcw_at = k >> 2; if(act) __builtin_memcpy(&qcw, qc + (k & ~3u), 4); }
+			const uint32_t c = act ? (qcw >> (8u * (k & 3u))) & 0xffu : 4u;
 			return (c >= 4u) ? BSA_EPI8_MIN : __builtin_amdgcn_sbfe((int)mr, 8u * c, 8u);
 		};
 		const uint32_t base = j * W;
@@ -163,30 +178,44 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 		int f = BSA_EPI8_MIN, gq = BSA_EPI8_MIN;
 		{
 			int hc = (j == 0) ? h0 : score(0);
-			for(uint32_t k = 0; k < W; k++){
-				const int uk = src[base + k];
-				int h;
-				if(PW == 0){
-					const int ee = sat8(uk + GapE);
-					h = max(max(ee, hc), f);
-					f = sat8(sat8(h + GapE) - uk);
-				} else if(PW == 1){
-					const int ee = sat8(src[BW + base + k] + uk);
-					h = max(max(ee, hc), f);
-					f = sat8(f + GapE);
-					h = sat8(h + GapOE);
-					f = sat8(max(f, h) - uk);
-				} else {
-					const int ee = sat8(src[BW + base + k] + uk), qq = sat8(src[2 * BW + base + k] + uk);
-					h = max(max(ee, hc), max(qq, max(f, gq)));
-					f = sat8(f + GapE);
-					h = sat8(h + GapOE);
-					f = sat8(max(f, h) - uk);
-					gq = sat8(gq + GapP);
-					h = sat8(h - GapOQ);
-					gq = sat8(max(gq, h) - uk);
+			// four cells per trip: their LDS bytes are requested together, so the trip waits for LDS once instead of per cell
+			for(uint32_t k0 = 0; k0 < W; k0 += 4u){
+				int u4[4], e4[4], q4[4];
+#pragma unroll
+				for(uint32_t b = 0; b < 4u; b++){
+					// up to three bytes past the block are read and not used: still inside this pair's LDS (68 spare bytes follow)
+					u4[b] = (int)src[base + k0 + b];
+					e4[b] = (PW >= 1) ? (int)src[BW + base + k0 + b] : 0;
+					q4[b] = (PW == 2) ? (int)src[2 * BW + base + k0 + b] : 0;
 				}
-				if(k + 1 < W) hc = score(k + 1);
+#pragma unroll
+				for(uint32_t b = 0; b < 4u; b++){
+					const uint32_t k = k0 + b;
+					if(k >= W) break;
+					const int uk = u4[b];
+					int h;
+					if(PW == 0){
+						const int ee = sat8(uk + GapE);
+						h = max(max(ee, hc), f);
+						f = sat8(sat8(h + GapE) - uk);
+					} else if(PW == 1){
+						const int ee = sat8(e4[b] + uk);
+						h = max(max(ee, hc), f);
+						f = sat8(f + GapE);
+						h = sat8(h + GapOE);
+						f = sat8(max(f, h) - uk);
+					} else {
+						const int ee = sat8(e4[b] + uk), qq = sat8(q4[b] + uk);
+						h = max(max(ee, hc), max(qq, max(f, gq)));
+						f = sat8(f + GapE);
+						h = sat8(h + GapOE);
+						f = sat8(max(f, h) - uk);
+						gq = sat8(gq + GapP);
+						h = sat8(h - GapOQ);
+						gq = sat8(max(gq, h) - uk);
+					}
+					if(k + 1 < W) hc = score(k + 1);
+				}
 			}
 		}
 		f = fpen(f, ubA, ubB, (int)W * gape1, j);
@@ -194,44 +223,57 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 		int htail, ulast = 0, unew0 = 0;
 		{
 			int v = 0, z = (j == 0) ? h0 : score(0), h = 0;
-			for(uint32_t k = 0; k < W; k++){
-				const int uk = src[base + k];
-				int un;
-				if(PW == 0){
-					const int ee = sat8(uk + GapE);
-					h = max(max(ee, z), f);
-					un = sat8(h - v);
-					v = sat8(h - uk);
-					f = sat8(sat8(h + GapE) - uk);
-				} else if(PW == 1){
-					int ee = sat8(src[BW + base + k] + uk);
-					h = max(max(ee, z), f);
-					un = sat8(h - v);
-					v = sat8(h - uk);
-					ee = sat8(ee + GapE); ee = sat8(ee - h);
-					if(act) src[BW + base + k] = (int8_t)max(ee, GapOE);
-					f = sat8(f + GapE);
-					h = sat8(h + GapOE);
-					f = sat8(max(f, h) - uk);
-				} else {
-					int ee = sat8(src[BW + base + k] + uk), qq = sat8(src[2 * BW + base + k] + uk);
-					h = max(max(ee, z), max(qq, max(f, gq)));
-					un = sat8(h - v);
-					v = sat8(h - uk);
-					ee = sat8(ee + GapE); ee = sat8(ee - h);
-					if(act) src[BW + base + k] = (int8_t)max(ee, GapOE);
-					qq = sat8(qq + GapP); qq = sat8(qq - h);
-					if(act) src[2 * BW + base + k] = (int8_t)max(qq, GapQP);
-					f = sat8(f + GapE);
-					h = sat8(h + GapOE);
-					f = sat8(max(f, h) - uk);
-					gq = sat8(gq + GapP);
-					h = sat8(h - GapOQ);
-					gq = sat8(max(gq, h) - uk);
+			for(uint32_t k0 = 0; k0 < W; k0 += 4u){
+				int u4[4], e4[4], q4[4];
+#pragma unroll
+				for(uint32_t b = 0; b < 4u; b++){
+					// up to three bytes past the block are read and not used: still inside this pair's LDS (68 spare bytes follow)
+					u4[b] = (int)src[base + k0 + b];
+					e4[b] = (PW >= 1) ? (int)src[BW + base + k0 + b] : 0;
+					q4[b] = (PW == 2) ? (int)src[2 * BW + base + k0 + b] : 0;
 				}
-				if(k == 0) unew0 = un; else if(act) src[base + k] = (int8_t)un;
-				ulast = uk;
-				if(k + 1 < W) z = score(k + 1);
+#pragma unroll
+				for(uint32_t b = 0; b < 4u; b++){
+					const uint32_t k = k0 + b;
+					if(k >= W) break;
+					const int uk = u4[b];
+					int un;
+					if(PW == 0){
+						const int ee = sat8(uk + GapE);
+						h = max(max(ee, z), f);
+						un = sat8(h - v);
+						v = sat8(h - uk);
+						f = sat8(sat8(h + GapE) - uk);
+					} else if(PW == 1){
+						int ee = sat8(e4[b] + uk);
+						h = max(max(ee, z), f);
+						un = sat8(h - v);
+						v = sat8(h - uk);
+						ee = sat8(ee + GapE); ee = sat8(ee - h);
+						if(act) src[BW + base + k] = (int8_t)max(ee, GapOE);
+						f = sat8(f + GapE);
+						h = sat8(h + GapOE);
+						f = sat8(max(f, h) - uk);
+					} else {
+						int ee = sat8(e4[b] + uk), qq = sat8(q4[b] + uk);
+						h = max(max(ee, z), max(qq, max(f, gq)));
+						un = sat8(h - v);
+						v = sat8(h - uk);
+						ee = sat8(ee + GapE); ee = sat8(ee - h);
+						if(act) src[BW + base + k] = (int8_t)max(ee, GapOE);
+						qq = sat8(qq + GapP); qq = sat8(qq - h);
+						if(act) src[2 * BW + base + k] = (int8_t)max(qq, GapQP);
+						f = sat8(f + GapE);
+						h = sat8(h + GapOE);
+						f = sat8(max(f, h) - uk);
+						gq = sat8(gq + GapP);
+						h = sat8(h - GapOQ);
+						gq = sat8(max(gq, h) - uk);
+					}
+					if(k == 0) unew0 = un; else if(act) src[base + k] = (int8_t)un;
+					ulast = uk;
+					if(k + 1 < W) z = score(k + 1);
+				}
 			}
 			htail = (PW == 0) ? h : (PW == 1) ? sat8(h - GapOE) : sat8(h - GapQP);
 		}
