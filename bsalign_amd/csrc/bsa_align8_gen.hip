@@ -158,12 +158,25 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 		// ---- row_cal (bsalign.h:2727-2793 / 2885-2960 / 3084-3179), S(x, base) from the staged codes
 		const int tb = act ? (int)tp[i] : 0;
 		const uint32_t mr = (tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3];
-		const uint8_t *qc = qp + rbeg + (size_t)j * W;
-		// query codes four at a time (the staged sequence is padded; unaligned dword loads are fine in global memory)
-		uint32_t qcw = 0, qcw_at = 0xFFFFFFFFu;
+		// The query codes of this lane's block sit in LDS behind the exchange area and are re-read from the staged sequence
+		// only when the band has moved (never with the whole query as band): a global load inside the cell loops costs its
+		// full latency every time (measured: two thirds of this kernel's run time).
+		int8_t *qcl = buf0 + 2 * (size_t)(PW + 1) * BW + 80 + (size_t)j * W;
+		if(act && (i == 0u || mov)){
+			const uint8_t *qc = qp + rbeg + (size_t)j * W;
+			for(uint32_t k0 = 0; k0 < W; k0 += 32u){
+				uint32_t w8[8];
+#pragma unroll
+				for(uint32_t b = 0; b < 8u; b++) if(k0 + 4u * b < W) __builtin_memcpy(&w8[b], qc + k0 + 4u * b, 4);      // the staged sequence is padded
+#pragma unroll
+				for(uint32_t b = 0; b < 8u; b++){
+#pragma unroll
+					for(uint32_t c = 0; c < 4u; c++) if(k0 + 4u * b + c < W) qcl[k0 + 4u * b + c] = (int8_t)(w8[b] >> (8u * c));
+				}
+			}
+		}
 		auto score = [&](uint32_t k) -> int {
-			if((k >> 2) != qcw_at){ qcw_at = k >> 2; if(act) __builtin_memcpy(&qcw, qc + (k & ~3u), 4); }
-			const uint32_t c = act ? (qcw >> (8u * (k & 3u))) & 0xffu : 4u;
+			const uint32_t c = act ? (uint32_t)(uint8_t)qcl[k] : 4u;
 			return (c >= 4u) ? BSA_EPI8_MIN : __builtin_amdgcn_sbfe((int)mr, 8u * c, 8u);
 		};
 		const uint32_t base = j * W;
@@ -323,7 +336,8 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 }
 
 // LDS needed by one pair: two row buffers + the 17-int ubegs exchange area
-size_t bsa_align8_gen_lds(uint32_t bw, int pw){ return (2 * (size_t)(pw + 1) * bw + 17 * 4 + 15) & ~(size_t)15; }
+// two row buffers, the 17-int ubegs exchange area (padded to 80 bytes), the query codes of the band
+size_t bsa_align8_gen_lds(uint32_t bw, int pw){ return (2 * (size_t)(pw + 1) * bw + 80 + bw + 15) & ~(size_t)15; }
 
 hipError_t bsa_launch_align8_fwd_gen(const Align8Args &a, int pw, uint32_t max_bw, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
