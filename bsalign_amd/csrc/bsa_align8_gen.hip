@@ -191,43 +191,46 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 		int f = BSA_EPI8_MIN, gq = BSA_EPI8_MIN;
 		{
 			int hc = (j == 0) ? h0 : score(0);
-			// four cells per trip: their LDS bytes are requested together, so the trip waits for LDS once instead of per cell
-			for(uint32_t k0 = 0; k0 < W; k0 += 4u){
-				int u4[4], e4[4], q4[4];
+			// Four cells per trip.  Everything a trip needs from LDS -- the cells' bytes and the query codes of the cells after
+			// them -- is requested up front, so a trip waits for LDS once, and cells beyond the block's end are computed and
+			// thrown away by selects rather than skipped by branches (W differs between the pairs of a wave).
+			for(uint32_t k0 = 0; __any(k0 < W); k0 += 4u){
+				int u4[4], e4[4], q4[4], s4[4];
 #pragma unroll
 				for(uint32_t b = 0; b < 4u; b++){
-					// up to three bytes past the block are read and not used: still inside this pair's LDS (68 spare bytes follow)
+					// up to four bytes past the block are read and not used: still inside this pair's LDS
 					u4[b] = (int)src[base + k0 + b];
 					e4[b] = (PW >= 1) ? (int)src[BW + base + k0 + b] : 0;
 					q4[b] = (PW == 2) ? (int)src[2 * BW + base + k0 + b] : 0;
+					s4[b] = score(k0 + b + 1u);
 				}
 #pragma unroll
 				for(uint32_t b = 0; b < 4u; b++){
-					const uint32_t k = k0 + b;
-					if(k >= W) break;
+					const bool ok = k0 + b < W;
 					const int uk = u4[b];
-					int h;
+					int h, fn, gn = gq;
 					if(PW == 0){
 						const int ee = sat8(uk + GapE);
 						h = max(max(ee, hc), f);
-						f = sat8(sat8(h + GapE) - uk);
+						fn = sat8(sat8(h + GapE) - uk);
 					} else if(PW == 1){
 						const int ee = sat8(e4[b] + uk);
 						h = max(max(ee, hc), f);
-						f = sat8(f + GapE);
+						fn = sat8(f + GapE);
 						h = sat8(h + GapOE);
-						f = sat8(max(f, h) - uk);
+						fn = sat8(max(fn, h) - uk);
 					} else {
 						const int ee = sat8(e4[b] + uk), qq = sat8(q4[b] + uk);
 						h = max(max(ee, hc), max(qq, max(f, gq)));
-						f = sat8(f + GapE);
+						fn = sat8(f + GapE);
 						h = sat8(h + GapOE);
-						f = sat8(max(f, h) - uk);
-						gq = sat8(gq + GapP);
+						fn = sat8(max(fn, h) - uk);
+						gn = sat8(gq + GapP);
 						h = sat8(h - GapOQ);
-						gq = sat8(max(gq, h) - uk);
+						gn = sat8(max(gn, h) - uk);
 					}
-					if(k + 1 < W) hc = score(k + 1);
+					f = ok ? fn : f; gq = ok ? gn : gq;
+					hc = s4[b];                                   // only used by a cell that exists
 				}
 			}
 		}
@@ -236,56 +239,62 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 		int htail, ulast = 0, unew0 = 0;
 		{
 			int v = 0, z = (j == 0) ? h0 : score(0), h = 0;
-			for(uint32_t k0 = 0; k0 < W; k0 += 4u){
-				int u4[4], e4[4], q4[4];
+			for(uint32_t k0 = 0; __any(k0 < W); k0 += 4u){
+				int u4[4], e4[4], q4[4], s4[4];
 #pragma unroll
 				for(uint32_t b = 0; b < 4u; b++){
-					// up to three bytes past the block are read and not used: still inside this pair's LDS (68 spare bytes follow)
 					u4[b] = (int)src[base + k0 + b];
 					e4[b] = (PW >= 1) ? (int)src[BW + base + k0 + b] : 0;
 					q4[b] = (PW == 2) ? (int)src[2 * BW + base + k0 + b] : 0;
+					s4[b] = score(k0 + b + 1u);
 				}
 #pragma unroll
 				for(uint32_t b = 0; b < 4u; b++){
 					const uint32_t k = k0 + b;
-					if(k >= W) break;
+					const bool ok = k < W;
 					const int uk = u4[b];
-					int un;
+					int hn, un, vn, fn, gn = gq, en = 0, qn = 0;
 					if(PW == 0){
 						const int ee = sat8(uk + GapE);
-						h = max(max(ee, z), f);
-						un = sat8(h - v);
-						v = sat8(h - uk);
-						f = sat8(sat8(h + GapE) - uk);
+						hn = max(max(ee, z), f);
+						un = sat8(hn - v);
+						vn = sat8(hn - uk);
+						fn = sat8(sat8(hn + GapE) - uk);
 					} else if(PW == 1){
 						int ee = sat8(e4[b] + uk);
-						h = max(max(ee, z), f);
-						un = sat8(h - v);
-						v = sat8(h - uk);
-						ee = sat8(ee + GapE); ee = sat8(ee - h);
-						if(act) src[BW + base + k] = (int8_t)max(ee, GapOE);
-						f = sat8(f + GapE);
-						h = sat8(h + GapOE);
-						f = sat8(max(f, h) - uk);
+						hn = max(max(ee, z), f);
+						un = sat8(hn - v);
+						vn = sat8(hn - uk);
+						ee = sat8(ee + GapE); ee = sat8(ee - hn);
+						en = max(ee, GapOE);
+						fn = sat8(f + GapE);
+						hn = sat8(hn + GapOE);
+						fn = sat8(max(fn, hn) - uk);
 					} else {
 						int ee = sat8(e4[b] + uk), qq = sat8(q4[b] + uk);
-						h = max(max(ee, z), max(qq, max(f, gq)));
-						un = sat8(h - v);
-						v = sat8(h - uk);
-						ee = sat8(ee + GapE); ee = sat8(ee - h);
-						if(act) src[BW + base + k] = (int8_t)max(ee, GapOE);
-						qq = sat8(qq + GapP); qq = sat8(qq - h);
-						if(act) src[2 * BW + base + k] = (int8_t)max(qq, GapQP);
-						f = sat8(f + GapE);
-						h = sat8(h + GapOE);
-						f = sat8(max(f, h) - uk);
-						gq = sat8(gq + GapP);
-						h = sat8(h - GapOQ);
-						gq = sat8(max(gq, h) - uk);
+						hn = max(max(ee, z), max(qq, max(f, gq)));
+						un = sat8(hn - v);
+						vn = sat8(hn - uk);
+						ee = sat8(ee + GapE); ee = sat8(ee - hn);
+						en = max(ee, GapOE);
+						qq = sat8(qq + GapP); qq = sat8(qq - hn);
+						qn = max(qq, GapQP);
+						fn = sat8(f + GapE);
+						hn = sat8(hn + GapOE);
+						fn = sat8(max(fn, hn) - uk);
+						gn = sat8(gq + GapP);
+						hn = sat8(hn - GapOQ);
+						gn = sat8(max(gn, hn) - uk);
 					}
-					if(k == 0) unew0 = un; else if(act) src[base + k] = (int8_t)un;
-					ulast = uk;
-					if(k + 1 < W) z = score(k + 1);
+					if(act && ok){
+						if(PW >= 1) src[BW + base + k] = (int8_t)en;
+						if(PW == 2) src[2 * BW + base + k] = (int8_t)qn;
+						if(k != 0) src[base + k] = (int8_t)un;
+					}
+					unew0 = (k == 0) ? un : unew0;
+					h = ok ? hn : h; v = ok ? vn : v; f = ok ? fn : f; gq = ok ? gn : gq;
+					ulast = ok ? uk : ulast;
+					z = s4[b];
 				}
 			}
 			htail = (PW == 0) ? h : (PW == 1) ? sat8(h - GapOE) : sat8(h - GapQP);
