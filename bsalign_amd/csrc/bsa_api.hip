@@ -761,7 +761,7 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 	{
 		std::vector<uint64_t> key(n);
 		for(size_t k = 0; k < n; k++){
-			const uint32_t rank = cls[k] <= BSA_EDIT_REG_BW ? cls[k] / 64u : 17u + ((cls[k] & 0xFFu) == 0u ? 0u : (cls[k] & 0xFFu) == 1u ? 1u : (cls[k] & 0xFFu) == 2u ? 2u : 3u);
+			const uint32_t rank = cls[k] <= BSA_EDIT_REG_BW ? cls[k] / 64u : 17u + ((cls[k] & 0xFFu) == 0u ? 0u : (cls[k] & 0xFFu) == 1u ? 1u : (cls[k] & 0xFFu) == 2u ? 2u : (cls[k] & 0xFFu) == 4u ? 3u : 4u);
 			key[k] = (uint64_t)rank << 56 | (uint64_t)(bwk[k] / 64u) << 32 | (uint64_t)(0xFFFFFFFFu - tlen[k]);
 		}
 		radix_sort_order(key, order);

@@ -97,11 +97,11 @@ static inline uint32_t bsa_edit_bw_eff(uint32_t qlen, uint32_t tlen, int type, u
 }
 #define BSA_EDIT_REG_BW 1024u       // widest band of the register kernels (16 words)
 // launch classes of the edit plan: the band itself up to BSA_EDIT_REG_BW; above, by the words per lane the wave-per-pair
-// kernel needs (64 lanes x WPL words x 64 columns), 0 = only the generic kernel is left
+// kernel needs (64 lanes x WPL words x 64 columns, WPL = 1, 2, 4, 8: up to 32768 columns), 0 = only the generic kernel is left
 static inline uint32_t bsa_edit_class(uint32_t bw){
 	if(bw <= BSA_EDIT_REG_BW) return bw;
 	const uint32_t nw = bw / 64u;
-	return nw <= 64u ? 0xFFFFFF01u : nw <= 128u ? 0xFFFFFF02u : nw <= 256u ? 0xFFFFFF04u : 0xFFFFFF00u;
+	return nw <= 64u ? 0xFFFFFF01u : nw <= 128u ? 0xFFFFFF02u : nw <= 256u ? 0xFFFFFF04u : nw <= 512u ? 0xFFFFFF08u : 0xFFFFFF00u;
 }
 
 struct EditArgs {
@@ -122,7 +122,7 @@ struct EditArgs {
 	uint32_t bw;                    // effective bandwidth of this launch (multiple of 64); 0 = wide class, every pair has its own
 	                                //   (bsa_edit_bw_eff of its lengths), all above 1024 -- one launch of the generic kernel
 	uint32_t bandwidth;             // the caller's bandwidth parameter, for bsa_edit_bw_eff
-	uint32_t wide;                  // bw == 0 only: words per lane of the wave-per-pair kernel for static bands (1, 2, 4), 0 = none
+	uint32_t wide;                  // bw == 0 only: words per lane of the wave-per-pair kernel for static bands (1, 2, 4, 8), 0 = none
 	uint32_t pad_rows;              // spare row records at the end of every slot (CIGAR scratch)
 	int32_t  mode;
 };

@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(64) k_edit_fwd_gen(const EditArgs a, uint32_t 
 // ---- wide static bands: one pair per WAVE -----------------------------------------------------------------------
 // Overlap / extend mode and `bandwidth 0` make the band the whole (rounded) query, so it never moves: no row_movx, the
 // query planes of a word are the same for every row and the whole band state fits the wave's registers -- lane l owns
-// words l*WPL .. l*WPL+WPL-1 (up to 64*WPL*64 = 16384 query columns for WPL = 4).  What is left of the serial chain
+// words l*WPL .. l*WPL+WPL-1 (up to 64*WPL*64 = 32768 query columns for WPL = 8).  What is left of the serial chain
 // across words is one number per word, the horizontal delta hin in {-1, 0, +1} entering it, and the block update only
 // looks at its sign: Xh takes (hin < 0) as bit 0 of Eq, (hin > 0) is just shifted into Ph afterwards.  So every lane
 // evaluates its words for both cases (a negative delta entering or not), the wave resolves the chain in scalar code
@@ -841,6 +841,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 			if(a.wide == 1u) hipLaunchKernelGGL((k_edit_fwd_wide<1>), dim3((a.count + 3) / 4), dim3(256), 0, st, a);
 			else if(a.wide == 2u) hipLaunchKernelGGL((k_edit_fwd_wide<2>), dim3((a.count + 3) / 4), dim3(256), 0, st, a);
 			else if(a.wide == 4u) hipLaunchKernelGGL((k_edit_fwd_wide<4>), dim3((a.count + 3) / 4), dim3(256), 0, st, a);
+			else if(a.wide == 8u) hipLaunchKernelGGL((k_edit_fwd_wide<8>), dim3((a.count + 3) / 4), dim3(256), 0, st, a);
 			if(a.wide == 0u || ((a.mode & 3) == BSA_MODE_GLOBAL && a.bandwidth != 0u)){
 				uint32_t gl = 64;
 				while(gl > 2u && (a.count + gl / 2 - 1) / (gl / 2) <= 8192u) gl >>= 1;

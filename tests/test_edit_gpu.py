@@ -92,11 +92,11 @@ def test_wide_bands(ctx, mode):
 
 @pytest.mark.parametrize("mode", [S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND])
 def test_wide_band_classes(ctx, mode):
-    """every launch class above 1024 columns in one batch: 1 / 2 / 4 words per lane of the wave-per-pair kernel
-    (up to 4096 / 8192 / 16384 columns), the generic kernel beyond, and short pairs of the register kernels beside them;
+    """every launch class above 1024 columns in one batch: 1 / 2 / 4 / 8 words per lane of the wave-per-pair kernel
+    (up to 4096 / 8192 / 16384 / 32768 columns), the generic kernel beyond, and short pairs of the register kernels beside them;
     query lengths on both sides of the word and class borders"""
     rng = np.random.default_rng(177 + mode)
-    lens = [70, 1000, 1024, 1025, 1088, 2047, 2048, 4032, 4096, 4097, 4160, 6000, 8192, 8193, 9000, 12000, 16384, 16390, 17000]
+    lens = [70, 1000, 1024, 1025, 1088, 2047, 2048, 4032, 4096, 4097, 4160, 6000, 8192, 8193, 9000, 12000, 16384, 16390, 17000, 24000, 32768, 32790]
     pairs = []
     for L in lens:
         T = rng.integers(0, 4, size=max(8, int(L * float(rng.choice([0.3, 1.0, 1.1]))))).astype(np.uint8)
