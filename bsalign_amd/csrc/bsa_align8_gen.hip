@@ -11,7 +11,7 @@
 #include <algorithm>
 
 template<int PW>
-__global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint32_t lds_per_group, uint32_t gpb){
+__global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint32_t lds_per_group, uint32_t gpb, uint32_t nbuf){
 	extern __shared__ __attribute__((aligned(16))) int8_t gsm[];
 	const int lt = threadIdx.x, j = lt & 15;
 	const uint32_t grp = (uint32_t)(lt >> 4);
@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 	uint8_t *rowp = (uint8_t*)begs + bsa_begs_bytes(tlen);
 	if(!live || a.status[pair] != 0u || W == 0u) tlen = 0;
 	int8_t *buf0 = gsm + (size_t)(live ? grp : 0u) * lds_per_group;   // [PW+1][BW]
-	int8_t *buf1 = buf0 + (size_t)(PW + 1) * BW;
+	int8_t *buf1 = buf0 + (size_t)(nbuf - 1u) * (PW + 1) * BW;      // nbuf == 1: the band is the whole query and never moves, no second row
 	const uint32_t cells = ((uint32_t)(PW + 1) * W + 3u) & ~3u, blk = cells + 4u;
 	const uint32_t tg = (64u / blk) ? (64u / blk) : 1u, tileb = (tg * blk + 15u) & ~15u;
 	const int mode = a.mode & 3;
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 		else rh = max(gapo1 + gape1 * (int)i, gapo2 + gape2 * (int)i);
 		// ---- row_movx (bsalign.h:2244-2392): cur -> nxt, then roles swap
 		// ubegs exchange area: 17 ints after the two row buffers (other lanes' block scores are needed by row_movx)
-		int *sub = (int*)(buf0 + 2 * (size_t)(PW + 1) * BW);
+		int *sub = (int*)(buf0 + (size_t)nbuf * (PW + 1) * BW);
 		if(act){ sub[j] = ubA; if(j == 15) sub[16] = ubB; }
 		wave_sync();
 		if(act && mov){
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 		// The query codes of this lane's block sit in LDS behind the exchange area and are re-read from the staged sequence
 		// only when the band has moved (never with the whole query as band): a global load inside the cell loops costs its
 		// full latency every time (measured: two thirds of this kernel's run time).
-		int8_t *qcl = buf0 + 2 * (size_t)(PW + 1) * BW + 80 + (size_t)j * W;
+		int8_t *qcl = buf0 + (size_t)nbuf * (PW + 1) * BW + 80 + (size_t)j * W;
 		if(act && (i == 0u || mov)){
 			const uint8_t *qc = qp + rbeg + (size_t)j * W;
 			for(uint32_t k0 = 0; k0 < W; k0 += 32u){
@@ -346,11 +346,12 @@ __global__ void __launch_bounds__(256) k_align8_fwd_gen(const Align8Args a, uint
 
 // LDS needed by one pair: two row buffers + the 17-int ubegs exchange area
 // two row buffers, the 17-int ubegs exchange area (padded to 80 bytes), the query codes of the band
-size_t bsa_align8_gen_lds(uint32_t bw, int pw){ return (2 * (size_t)(pw + 1) * bw + 80 + bw + 15) & ~(size_t)15; }
+size_t bsa_align8_gen_lds(uint32_t bw, int pw, uint32_t nbuf){ return ((size_t)nbuf * (pw + 1) * bw + 80 + bw + 15) & ~(size_t)15; }
 
 hipError_t bsa_launch_align8_fwd_gen(const Align8Args &a, int pw, uint32_t max_bw, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
-	const size_t per = bsa_align8_gen_lds(max_bw, pw);
+	const uint32_t nbuf = (a.bw == 0u) ? 1u : 2u;              // bandwidth 0: every pair's band is its whole query
+	const size_t per = bsa_align8_gen_lds(max_bw, pw, nbuf);
 	if(per > 160 * 1024) return hipErrorInvalidValue;
 	const size_t budget = (per > 64 * 1024) ? 160 * 1024 : 64 * 1024;
 	uint32_t gpb = (uint32_t)std::min<size_t>(16, budget / per);
@@ -364,8 +365,8 @@ hipError_t bsa_launch_align8_fwd_gen(const Align8Args &a, int pw, uint32_t max_b
 		e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if(e != hipSuccess) return e;
 	}
-	if(pw == 0) hipLaunchKernelGGL((k_align8_fwd_gen<0>), dim3(blocks), dim3(threads), lds, st, a, (uint32_t)per, gpb);
-	else if(pw == 1) hipLaunchKernelGGL((k_align8_fwd_gen<1>), dim3(blocks), dim3(threads), lds, st, a, (uint32_t)per, gpb);
-	else hipLaunchKernelGGL((k_align8_fwd_gen<2>), dim3(blocks), dim3(threads), lds, st, a, (uint32_t)per, gpb);
+	if(pw == 0) hipLaunchKernelGGL((k_align8_fwd_gen<0>), dim3(blocks), dim3(threads), lds, st, a, (uint32_t)per, gpb, nbuf);
+	else if(pw == 1) hipLaunchKernelGGL((k_align8_fwd_gen<1>), dim3(blocks), dim3(threads), lds, st, a, (uint32_t)per, gpb, nbuf);
+	else hipLaunchKernelGGL((k_align8_fwd_gen<2>), dim3(blocks), dim3(threads), lds, st, a, (uint32_t)per, gpb, nbuf);
 	return hipGetLastError();
 }

@@ -176,7 +176,7 @@ struct TileWriter {
 hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st);
 hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);
 bool bsa_align8_supported_bw(uint32_t bw);
-size_t bsa_align8_gen_lds(uint32_t bw, int pw);
+size_t bsa_align8_gen_lds(uint32_t bw, int pw, uint32_t nbuf = 2u);
 hipError_t bsa_launch_align8_fwd_gen(const Align8Args &a, int pw, uint32_t max_bw, hipStream_t st);
 bool bsa_align8_pk_supported(const Align8Args &a, int pw);
 hipError_t bsa_launch_align8_fwd_pk(const Align8Args &a, int pw, hipStream_t st);
