@@ -128,8 +128,17 @@ static __device__ __forceinline__ void rows_merge(RowRegs<W> &R, const int8_t *b
 template<int W>
 static __device__ __forceinline__ void rows_fetch_codes(const uint8_t *qp, uint32_t qlen, uint32_t qoff_dst, int (&qc)[W + 1], const int j){
 	const uint32_t x0 = qoff_dst + (uint32_t)j * W;
+	constexpr int ND = (W + 4) / 4;                          // dwords that cover the W + 1 codes
+	if(x0 + 4u * ND <= qlen){                                // the whole window lies inside the read: a few unaligned dword loads
+		uint32_t w[ND];
 #pragma unroll
-	for(int k = 0; k <= W; k++) qc[k] = (x0 + k < qlen) ? (int)qp[x0 + k] : 4;
+		for(int i = 0; i < ND; i++) __builtin_memcpy(&w[i], qp + x0 + 4 * i, 4);
+#pragma unroll
+		for(int k = 0; k <= W; k++) qc[k] = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+	} else {
+#pragma unroll
+		for(int k = 0; k <= W; k++) qc[k] = (x0 + k < qlen) ? (int)qp[x0 + k] : 4;
+	}
 }
 
 // update: R = row_cal(row_movx(R, qoff_dst - qoff_src)) (bspoa.h:2232-2261); qc = rows_fetch_codes for this task
