@@ -1,5 +1,5 @@
 """debug tool (not a test): run a few pairs on the GPU, fetch the stored DP rows and report the first
-row / field that differs from the oracle's rows.  usage: python tests/debug_rows.py [mode bw L npairs]"""
+row / field that differs from the oracle's rows.  usage: python tools/debug_rows.py [mode bw L npairs]"""
 import ctypes as C
 import sys
 
