@@ -1,0 +1,505 @@
+// bsa_align8_x.hip -- forward pass of the compact (4-bit code) path of the 8-bit banded DP in EXACT arithmetic.
+//
+// Same results as k_align8_fwd_pk<W, 1, true> (bsa_align8_pk.hip): the same code rows, band offsets and final score,
+// bit for bit -- the traceback kernels (bsa_align8_codes.hip) do not know which forward kernel ran.  It is only
+// dispatched inside a guard (bsa_align8_x_supported) under which none of the reference's int8-saturating operations
+// can clamp (bsalign.h:2885-2960 row_cal, :2639-2652 F-penetration, :2618-2636 tail, :2244-2392 row_movx), so the
+// recurrence may be restated freely.  What changed against the packed kernel, and why (tools/valu_rate_probe.hip:
+// every packed / VOP3 / DPP instruction occupies its SIMD for 4 cycles and the old kernel issued 631 of them per row
+// of 8 pairs, at 100 % of that rate):
+//   * ONE pair per 8 lanes, both 16-bit halves of a register belong to the SAME pair: lane l owns the reference's
+//     running blocks l (low half) and l + 8 (high half).  Per-pair scalars (band offset, steering, ubegs[0]) are
+//     computed once, not once per half.
+//   * frame shifted by the gap extension: with H~(x, y) = H(x, y) - gape * (x + y) extending a gap is free, which
+//     removes the "+ gape" of e' and f' (U = u - gape, NE = gape - e, S~ = S - 2 gape, h~ = h - 2 gape, f~ = f - 2 gape):
+//         ee = U - NE          m = max(ee, S~)          mg = m + gapo
+//         pass 1:  f = max(f, mg) - U                                  (2 dependent ops per cell)
+//         pass 2:  h = max(m, f)   fm = max(f, mg)   f = fm - U   n = h - ee   NE' = min(n, -gapo)   U' = h - v   v = h - U
+//     and the four flags of a cell are differences the recurrence has anyway: M: h - S~ == 0, D: n == 0,
+//     R: fm - mg == 0, Od: NE' == -gapo, each one packed min / saturating subtract + one v_pk_mad_u16.
+//   * F-penetration as a prefix maximum: in the shifted frame an F value travels along the row unchanged, so with
+//     X[b] = H~ at the end of block b (relative, int16) the value entering block b is max_{i<b}(fout[i] + X[i]) - X[b-1]:
+//     a 3-step max scan over the 8 lanes plus one step from the low halves to the high ones, instead of the max-plus scan.
+//   * the band slide is speculated: 96 % of the rows move the band by one cell, so pass 2 writes cell k of the new row
+//     into slot k - 1 and the first cell of every block travels to the previous block's last slot with one DPP move.
+//     Rows that do not move (or move by more) are corrected afterwards, under a wave-level branch.
+//   * ubegs are kept as PN[b] = ubegs[b+1] - ubegs[0] - (b+1) W gape in packed int16 plus ubegs[0] in an int32.
+// Values are value << 8 in each int16 half (as in the packed kernel), so S~ comes out of v_perm_b32 byte lookups.
+#include "bsa_common.h"
+#include "bsa_dpp.h"
+#include <algorithm>
+
+typedef short xv2s __attribute__((ext_vector_type(2)));
+typedef unsigned short xv2u __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ uint32_t x_add(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, (xv2u)(__builtin_bit_cast(xv2u, a) + __builtin_bit_cast(xv2u, b))); }
+static __device__ __forceinline__ uint32_t x_sub(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, (xv2u)(__builtin_bit_cast(xv2u, a) - __builtin_bit_cast(xv2u, b))); }
+static __device__ __forceinline__ uint32_t x_max(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(xv2s, a), __builtin_bit_cast(xv2s, b))); }
+static __device__ __forceinline__ uint32_t x_minu(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(xv2u, a), __builtin_bit_cast(xv2u, b))); }
+static __device__ __forceinline__ uint32_t x_satsubu(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(xv2u, a), __builtin_bit_cast(xv2u, b))); }
+static __device__ __forceinline__ uint32_t x_acc(uint32_t acc, uint32_t flag){          // acc * 2 + flag per half
+	uint32_t r;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "s"(0x00020002u), "v"(flag));
+	return r;
+}
+static __device__ __forceinline__ uint32_t x_ashr8(uint32_t a){ uint32_t r; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "s"(0x00080008u), "v"(a)); return r; }
+static __device__ __forceinline__ uint32_t x_shl8(uint32_t a){ uint32_t r; asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(r) : "s"(0x00080008u), "v"(a)); return r; }
+static __device__ __forceinline__ uint32_t x_q8(int v){ return (((uint32_t)v & 0xffu) << 8) * 0x00010001u; }        // value << 8 in both halves
+static __device__ __forceinline__ uint32_t x_i16(int v){ return ((uint32_t)v & 0xffffu) * 0x00010001u; }            // plain int16 in both halves
+static __device__ __forceinline__ int x_lo8(uint32_t x){ return __builtin_amdgcn_sbfe((int)x, 8, 8); }              // value of the low half (value << 8 form)
+static __device__ __forceinline__ int x_hi8(uint32_t x){ return (int)x >> 24; }
+static __device__ __forceinline__ int x_lo16(uint32_t x){ return __builtin_amdgcn_sbfe((int)x, 0, 16); }
+static __device__ __forceinline__ int x_hi16(uint32_t x){ return (int)x >> 16; }
+
+#define XDPP(old, x, ctrl, bank) ((uint32_t)dpp_keep(__builtin_amdgcn_update_dpp((int)(old), (int)(x), (ctrl), 0xf, (bank), false)))
+#define XQP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define XROW_SHL(n) (0x100 + (n))
+#define XROW_SHR(n) (0x110 + (n))
+#define XHALF_MIRROR 0x141
+
+// value of lane 0 / lane 7 of every group of 8 lanes, in all 8 lanes
+static __device__ __forceinline__ uint32_t x_bcast_first(uint32_t x){
+	const uint32_t s = XDPP(0, x, XQP(0, 0, 0, 0), 0xf);
+	return XDPP(s, s, XROW_SHR(4), 0xA);                 // lanes 4..7 <- lanes 0..3
+}
+static __device__ __forceinline__ uint32_t x_bcast_last(uint32_t x){
+	const uint32_t s = XDPP(0, x, XQP(3, 3, 3, 3), 0xf);
+	return XDPP(s, s, XROW_SHL(4), 0x5);                 // lanes 0..3 <- lanes 4..7
+}
+// block b receives the value of block b - 1 (low half: block l, high half: block l + 8); block 0 receives fill_lo
+static __device__ __forceinline__ uint32_t x_shift_down(uint32_t x, uint32_t fill_lo, bool first){
+	const uint32_t s = XDPP(0, x, XROW_SHR(1), 0xf);
+	const uint32_t w = XDPP(0, x, XROW_SHL(7), 0xf);      // lane 0 <- lane 7
+	const uint32_t fix = (w << 16) | (fill_lo & 0xffffu);
+	return first ? fix : s;
+}
+// block b receives the value of block b + 1; block 15 receives fill_hi (given in both halves)
+static __device__ __forceinline__ uint32_t x_shift_up(uint32_t x, uint32_t fill, bool last){
+	const uint32_t s = XDPP(0, x, XROW_SHL(1), 0xf);
+	const uint32_t w = XDPP(0, x, XROW_SHR(7), 0xf);      // lane 7 <- lane 0
+	const uint32_t fix = __builtin_amdgcn_alignbit(fill, w, 16);        // {fill.lo, w.hi}
+	return last ? fix : s;
+}
+// inclusive prefix maximum over the 8 lanes of a group, per half (Sklansky: nothing crosses a group)
+static __device__ __forceinline__ uint32_t x_scan_max8(uint32_t x){
+	uint32_t y = XDPP(x, x, XQP(0, 0, 2, 2), 0xf); x = x_max(x, y);
+	y = XDPP(x, x, XQP(0, 1, 1, 1), 0xf); x = x_max(x, y);
+	const uint32_t z = XDPP(x, x, XQP(3, 3, 3, 3), 0xf);
+	y = XDPP(x, z, XROW_SHR(4), 0xA); x = x_max(x, y);
+	return x;
+}
+
+template<int W>
+static __device__ __forceinline__ void x_load_qcodes(const uint8_t *p, uint32_t *w){
+	if constexpr (W >= 4) __builtin_memcpy(w, p, W);
+	else if constexpr (W == 2){ uint16_t v; __builtin_memcpy(&v, p, 2); w[0] = v | 0x04040000u; }
+	else w[0] = p[0] | 0x04040400u;
+}
+
+template<int W>
+__global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
+	constexpr int BW = W * 16;
+	constexpr int NQ = (W + 3) / 4;
+	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
+	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
+	const int lt = threadIdx.x;
+	const int jl = lt & 7;
+	const bool first = jl == 0, last = jl == 7;
+	const uint32_t g = (blockIdx.x * 256u + lt) >> 3;
+	const bool live = g < a.count;
+	const uint32_t ppos = a.first + (live ? g : 0u);
+	const uint32_t pair = a.order[ppos];
+	const uint32_t qlen = a.qlen[pair];
+	uint32_t tlen = a.tlen[pair];
+	const uint8_t *qp = a.qst + a.qpoff[pair], *tp = a.tst + a.tpoff[pair];
+	int *begs = (int*)(a.rows + a.slot_off[ppos]);
+	uint8_t *rowp = (uint8_t*)begs + bsa_begs_bytes(tlen);
+	if(!live || a.status[pair] != 0u) tlen = 0;
+
+	const int mode = a.mode & 3;
+	const int gapo1 = a.gapo1, gape1 = a.gape1;
+	const int GE = gape1, GO = gapo1;                      // GO <= 0, GE <= 0 (bsa_align8_x_supported)
+	const uint32_t GOQ = x_q8(GO);                         // gapo, value << 8
+	const uint32_t NGOQ = x_q8(-GO), NGOQ1 = x_q8(-GO - 1);
+	const uint32_t ONE = 0x01000100u;
+	const uint32_t MINF = x_q8(BSA_EPI8_MIN - 2 * GE);     // the -63 sentinel of f in the shifted frame
+	const uint32_t NGEQ = x_q8(-GE);                       // a cell with u = 0
+	const int cfirst = min(a.smin, gapo1 + gape1) - 1 - a.smax + (gapo1 + gape1);      // bsalign.h:2362
+	// cells entering at the band end (bsalign.h:2357-2389): u = cfirst for the first one, gape1 after it, e = 0
+	const uint32_t NEWU0 = x_q8(cfirst - GE), NEWU1 = 0u, NEWNE = x_q8(GE);
+	const uint32_t GE16 = x_i16(GE), WGE16 = x_i16(W * GE);
+	const uint32_t PADS = (uint32_t)((BSA_EPI8_MIN - 2 * GE) & 0xff) * 0x01010101u;    // S~ beyond the query end
+	uint32_t mrs[4];                                       // S~ rows per target base
+#pragma unroll
+	for(int t = 0; t < 4; t++){
+		uint32_t w = 0;
+#pragma unroll
+		for(int q = 0; q < 4; q++) w |= (uint32_t)(((int)a.matrix[q * 4 + t] - 2 * GE) & 0xff) << (8 * q);
+		mrs[t] = w;
+	}
+
+	uint32_t U[W], NE[W];
+	uint32_t PN;                  // packed int16: ubegs[b+1] - ubegs[0] - (b+1) W gape for b = jl (low) and jl + 8 (high)
+	int HB;                       // ubegs[0]
+	// ---- row -1 (bsalign.h:2094-2140)
+	{
+		const int first_u = (int)(int8_t)(gapo1 + gape1 + a.smin - a.smax);
+#pragma unroll
+		for(int k = 0; k < W; k++){
+			int vlo, vhi;
+			if(mode == BSA_MODE_OVERLAP){ vlo = 0; vhi = 0; }
+			else { vlo = (jl * W + k == 0) ? first_u : gape1; vhi = gape1; }
+			U[k] = (((uint32_t)(vlo - GE) & 0xffu) << 8) | (((uint32_t)(vhi - GE) & 0xffu) << 24);
+			NE[k] = x_q8(GE - BSA_EPI8_MIN);
+		}
+		if(mode == BSA_MODE_OVERLAP){
+			PN = ((uint32_t)(-(jl + 1) * W * GE) & 0xffffu) | ((uint32_t)(-(jl + 9) * W * GE) << 16);
+			HB = 0;
+		} else {
+			PN = x_i16(first_u - GE);
+			HB = a.smax - a.smin;
+		}
+	}
+	uint32_t svU, svNE;           // first cell of the row before the speculative slide (lane 0, low half: band position 0)
+	// bring row -1 into the loop's form: slid by one cell, ubegs[0] not advanced
+	{
+		const uint32_t t0u = U[0], t0e = NE[0];
+#pragma unroll
+		for(int k = 0; k + 1 < W; k++){ U[k] = U[k + 1]; NE[k] = NE[k + 1]; }
+		const uint32_t inu = x_shift_up(t0u, NEWU0, last), inne = x_shift_up(t0e, NEWNE, last);
+		U[W - 1] = inu; NE[W - 1] = inne;
+		PN = x_add(x_add(PN, x_ashr8(inu)), GE16);
+		svU = t0u; svNE = t0e;
+	}
+
+	uint32_t rbeg = 0, mov = 0, i = 0;
+	int begq = 0;
+	if(tlen != 0u && first) begs[0] = 0;
+	uint64_t twin = 0;
+	if(tlen) __builtin_memcpy(&twin, tp, 8);
+	const int rbz = 2 * max((int)(tlen / max(qlen, 1u)), 1);          // bsalign.h:4008
+	const bool rush32 = (unsigned long long)(uint32_t)rbz * tlen + qlen + (uint32_t)BW + (uint32_t)rbz < 0xFFFFFFFFull;
+	int rby_tab = 0;
+	const int rby_lane = (lt & 56) << 2;                   // byte address of lane 0 of this group for ds_bpermute
+	const uint32_t kd1 = last ? 0x01000000u : 0u;          // band cell bw - 1 after a slide by one: x == bw, no deletion there (bsalign.h:3672-3678)
+
+	while(__any(i < tlen)){
+		const bool act = i < tlen;
+		if(mode == BSA_MODE_GLOBAL && (i & 7u) == 0u)
+			rby_tab = (int)((1.0 * (double)(i + (uint32_t)jl) / (double)tlen) * (double)qlen);      // bsalign.h:4009, row i + jl
+		// ---- band offset of this row (bsalign.h:3932-3946)
+		{
+			const bool moved = (mov != 0u) && (rbeg + BW < qlen);
+			const uint32_t room = qlen - (rbeg + BW);
+			mov = moved ? min(mov, room) : 0u;
+			rbeg += mov;
+		}
+		int rh;
+		if(rbeg) rh = BSA_SCORE_MIN;
+		else if(mode == BSA_MODE_OVERLAP || i == 0) rh = 0;
+		else rh = gapo1 + gape1 * (int)i;
+		// ---- row_movx (bsalign.h:2244-2392): the row is held slid by one cell; correct what did not move that way
+		if(__any(act && mov != 1u)){
+			if(__any(act && mov >= (uint32_t)BW)){
+				// the band jumped past everything it held: zero rows, every ubegs = SCORE_MIN (bsalign.h:2253-2259);
+				// rh = H at the last cell of the previous row (getscore(bw - 1))
+				const bool z = act && mov >= (uint32_t)BW;
+				const uint32_t bc = x_bcast_last(PN);
+				const int rhz = HB + (x_hi16(bc) - cfirst) + BW * GE;
+				if(z){
+					rh = rhz;
+#pragma unroll
+					for(int k = 0; k < W; k++){ U[k] = NGEQ; NE[k] = NEWNE; }
+					HB = BSA_SCORE_MIN;
+					PN = ((uint32_t)(-(jl + 1) * W * GE) & 0xffffu) | ((uint32_t)(-(jl + 9) * W * GE) << 16);
+				}
+			}
+			if(__any(act && mov == 0u)){
+				// undo the slide
+				const bool d = act && mov == 0u;
+				const uint32_t outu = U[W - 1];
+				const uint32_t pu = x_shift_down(outu, svU, first), pe = x_shift_down(NE[W - 1], svNE, first);
+				const uint32_t npn = x_sub(x_sub(PN, x_ashr8(outu)), GE16);
+				PN = d ? npn : PN;
+#pragma unroll
+				for(int k = W - 1; k >= 1; k--){ U[k] = d ? U[k - 1] : U[k]; NE[k] = d ? NE[k - 1] : NE[k]; }
+				U[0] = d ? pu : U[0]; NE[0] = d ? pe : NE[0];
+			}
+			// one more cell at a time for steps of two and more (the first new cell went in with the speculative slide)
+			for(uint32_t s = 1; __any(act && mov < (uint32_t)BW && s < mov); s++){
+				const bool d = act && mov < (uint32_t)BW && s < mov;
+				const uint32_t bc = x_bcast_first(U[0]);
+				const uint32_t D0 = __builtin_amdgcn_perm(bc, bc, 0x01000100u);
+				const uint32_t inu = x_shift_up(U[0], NEWU1, last), inne = x_shift_up(NE[0], NEWNE, last);
+				const uint32_t npn = x_add(PN, x_ashr8(x_sub(inu, D0)));
+				PN = d ? npn : PN;
+				HB += d ? (x_lo8(bc) + GE) : 0;
+#pragma unroll
+				for(int k = 0; k + 1 < W; k++){ U[k] = d ? U[k + 1] : U[k]; NE[k] = d ? NE[k + 1] : NE[k]; }
+				U[W - 1] = d ? inu : U[W - 1]; NE[W - 1] = d ? inne : NE[W - 1];
+			}
+		}
+		if(mov != 0u && mov < (uint32_t)BW) rh = HB;              // getscore(mov - 1) of the previous row
+		// ---- sequences, S~(x, y)
+		uint32_t S[W];
+		{
+			const int tb = (int)((twin >> (8u * (i & 7u))) & 3u);
+			uint32_t qlo[NQ], qhi[NQ];
+			if(act){ x_load_qcodes<W>(qp + rbeg + jl * W, qlo); x_load_qcodes<W>(qp + rbeg + (jl + 8) * W, qhi); }
+			else {
+#pragma unroll
+				for(int n = 0; n < NQ; n++){ qlo[n] = 0x04040404u; qhi[n] = 0x04040404u; }
+			}
+			const uint32_t mr = (tb == 0) ? mrs[0] : (tb == 1) ? mrs[1] : (tb == 2) ? mrs[2] : mrs[3];
+			uint32_t slo[NQ], shi[NQ];
+#pragma unroll
+			for(int n = 0; n < NQ; n++){ slo[n] = __builtin_amdgcn_perm(PADS, mr, qlo[n]); shi[n] = __builtin_amdgcn_perm(PADS, mr, qhi[n]); }
+#pragma unroll
+			for(int k = 0; k < W; k++){
+				const uint32_t sel = 0x000C000Cu | ((uint32_t)(k & 3) << 8) | ((uint32_t)(4 + (k & 3)) << 24);   // {0, lo.byte[k], 0, hi.byte[k]}
+				S[k] = __builtin_amdgcn_perm(shi[k >> 2], slo[k >> 2], sel);
+			}
+		}
+		// ---- first cell of the band (bsalign.h:2899-2907): h0 = rh - ubegs[0] + S, kept if >= u + e, else -63.  After a
+		// slide inside the band rh == ubegs[0] and the rule changes neither h nor any flag, so only rows that stayed
+		// (or jumped past the whole band: ubegs[0] = SCORE_MIN) need it.
+		uint32_t hc0 = S[0];
+		uint32_t q0m = 0, q0d = 0;          // rows starting at query column 0: what h is compared with for M and D (bsalign.h:3763-3767)
+		if(__any(act && (mov == 0u || mov >= (uint32_t)BW))){
+			const int s0 = x_lo8(S[0]) + 2 * GE, u0 = x_lo8(U[0]) + GE, e0 = GE - x_lo8(NE[0]);
+			const int t0 = u0 + e0;
+			int hh = (rh - HB) + s0;
+			hh = (hh >= t0) ? min(hh, BSA_EPI8_MAX) : BSA_EPI8_MIN;
+			if(first && (mov == 0u || mov >= (uint32_t)BW)) hc0 = (hc0 & 0xffff0000u) | (((uint32_t)(hh - 2 * GE) & 0xffu) << 8);
+			// compare values of the quirk, in the shifted frame; out of int8 range = never equal
+			const int cm = rh - HB + s0 - 2 * GE, cd = t0 + rh - HB - 2 * GE;
+			q0m = (cm >= -128 && cm <= 127) ? (((uint32_t)cm & 0xffu) << 8) : 0x00ffu;
+			q0d = (cd >= -128 && cd <= 127) ? (((uint32_t)cd & 0xffu) << 8) : 0x00ffu;
+		}
+		// ---- row_cal, pass 1 (bsalign.h:2911-2930): F leaving every block when nothing but the sentinel enters it
+		uint32_t ee[W], m[W], mg[W];
+		uint32_t f = MINF;
+#pragma unroll
+		for(int k = 0; k < W; k++){
+			ee[k] = x_sub(U[k], NE[k]);
+			m[k] = x_max(ee[k], (k == 0) ? hc0 : S[k]);
+			mg[k] = x_add(m[k], GOQ);
+			f = x_sub(x_max(f, mg[k]), U[k]);
+		}
+		// ---- F-penetration (bsalign.h:2639-2652) as a prefix maximum over the blocks
+		{
+			const uint32_t Fa = x_add(x_ashr8(f), PN);
+			const uint32_t P = x_scan_max8(Fa);
+			const uint32_t bc = x_bcast_last(P);
+			const uint32_t Thi = (bc << 16) | 0x8000u;              // {-32768, max over blocks 0..7}
+			const uint32_t G = x_sub(x_max(P, Thi), PN);
+			f = x_shl8(x_shift_down(G, x_i16(BSA_EPI8_MIN - 2 * GE), first));
+		}
+#ifdef BSA_XDEBUG
+		const int dbg_fin[2] = { x_lo8(f) + 2 * GE, x_hi8(f) + 2 * GE };
+#endif
+		// ---- pass 2 (bsalign.h:2932-2957), flags, new row written one slot to the left
+		uint32_t accM[NACC], accD[NACC], accR[NACC], accO[NACC];
+#pragma unroll
+		for(int n = 0; n < NACC; n++){ accM[n] = 0; accD[n] = 0; accR[n] = 0; accO[n] = 0; }
+		uint32_t tmpU0 = 0, tmpNE0 = 0, hfirst = 0;
+#ifdef BSA_XDEBUG
+		uint32_t dbg_u7 = 0, dbg_h7 = 0;
+#endif
+		uint32_t v = 0;
+#pragma unroll
+		for(int k = 0; k < W; k++){
+			const uint32_t uk = U[k];
+			const uint32_t h = x_max(m[k], f);
+			const uint32_t fm = x_max(f, mg[k]);
+			f = x_sub(fm, uk);
+			accR[k >> 3] = x_acc(accR[k >> 3], x_minu(x_sub(fm, mg[k]), ONE));
+			const uint32_t n = x_sub(h, ee[k]);
+			accD[k >> 3] = x_acc(accD[k >> 3], x_minu(n, ONE));
+			const uint32_t ne = x_minu(n, NGOQ);
+			accO[k >> 3] = x_acc(accO[k >> 3], x_satsubu(ne, NGOQ1));
+			accM[k >> 3] = x_acc(accM[k >> 3], x_minu(x_sub(h, S[k]), ONE));
+			const uint32_t un = x_sub(h, v);
+			v = x_sub(h, uk);
+#ifdef BSA_XDEBUG
+			if(k == W - 1){ dbg_u7 = uk; dbg_h7 = h; }
+			if(g == BSA_XDEBUG && i == 8 && jl == 7) printf("k %d uk %d ne %d S %d ee %d m %d mg %d h %d fnext %d un %d v %d\n", k, x_lo8(uk) + GE, GE - x_lo8(NE[k]), x_lo8(S[k]) + 2 * GE, x_lo8(ee[k]) + 2 * GE,
+				x_lo8(m[k]) + 2 * GE, x_lo8(mg[k]) + 2 * GE, x_lo8(h) + 2 * GE, x_lo8(f) + 2 * GE, x_lo8(un) + GE, x_lo8(v) + GE);
+#endif
+			if(k == 0){ tmpU0 = un; tmpNE0 = ne; hfirst = h; }
+			else { U[k - 1] = un; NE[k - 1] = ne; }
+		}
+		// ---- tail (bsalign.h:2618-2636): u of every block's first cell, ubegs of the new row, ubegs[0] re-based on cell 0
+		const uint32_t vlast = v;
+		tmpU0 = x_sub(tmpU0, x_shift_down(vlast, NGEQ, first));
+		const uint32_t bc0 = x_bcast_first(tmpU0);
+		{
+			const uint32_t D0 = __builtin_amdgcn_perm(bc0, bc0, 0x01000100u);
+			HB += x_lo8(bc0) + GE;
+			PN = x_add(PN, x_ashr8(x_sub(vlast, D0)));
+		}
+		if(first) tmpU0 = (tmpU0 & 0xffff0000u) | (NGEQ & 0xffffu);
+		const uint32_t Psh = x_shift_down(PN, 0u, first);           // ubegs[b] - ubegs[0] - b W gape of the block's own start
+#ifdef BSA_XDEBUG
+		if(g == BSA_XDEBUG && i >= 5 && i < 9 && (jl == 0 || jl >= 6)){
+			for(int hf = 0; hf < 2; hf++){
+				int uu[W], en[W];
+				for(int k = 0; k < W; k++){
+					const uint32_t a1 = (k == 0) ? tmpU0 : U[k - 1], a2 = (k == 0) ? tmpNE0 : NE[k - 1];
+					uu[k] = (hf ? x_hi8(a1) : x_lo8(a1)) + GE; en[k] = GE - (hf ? x_hi8(a2) : x_lo8(a2));
+				}
+				const int b = jl + 8 * hf;
+				printf("row %u blk %2d u [%d %d %d %d %d %d %d %d] e [%d %d %d %d %d %d %d %d] ub %d  fin %d mov %u vlast %d uold7 %d h7 %d\n", i, b, uu[0], uu[1], uu[2], uu[3], uu[4], uu[5], uu[6], uu[7],
+					en[0], en[1], en[2], en[3], en[4], en[5], en[6], en[7], HB + (hf ? x_hi16(Psh) : x_lo16(Psh)) + b * W * GE, dbg_fin[hf], mov, (hf ? x_hi8(vlast) : x_lo8(vlast)) + GE, (hf ? x_hi8(dbg_u7) : x_lo8(dbg_u7)) + GE, (hf ? x_hi8(dbg_h7) : x_lo8(dbg_h7)) + 2 * GE);
+			}
+		}
+#endif
+		// ---- flags of special cells, then the code row (bsa_common.h "COMPACT slot"); M, D, R were accumulated inverted
+		if(__any(act && rbeg == 0u)){
+			if(first && rbeg == 0u){
+				const uint32_t hl = hfirst & 0xffffu;
+				const uint32_t b0 = 1u << TOPBIT;
+				accM[0] = (accM[0] & ~b0) | ((hl == q0m) ? 0u : b0);
+				accD[0] = (accD[0] & ~b0) | ((hl == q0d) ? 0u : b0);
+			}
+		}
+		if(__any(act && mov > 1u)){          // (the general form covers mov == 1 of the other pairs of the wave)
+			// cells at / beyond the end of the previous row's band: x == bw decides M or I only, x > bw is always I
+#pragma unroll
+			for(int hf = 0; hf < 2; hf++){
+				const int lim = BW - (int)mov - (jl + 8 * hf) * W;                 // cells k < lim have x < bw
+				const int nd = min(max(lim, 0), W), nm = min(max(lim + 1, 0), W);
+#pragma unroll
+				for(int n = 0; n < NACC; n++){
+					constexpr int CN = (W < 8) ? W : 8;
+					// accumulator n holds cells 8n .. 8n + CN - 1, cell c at bit 8 + CN - 1 - (c - 8n)
+					const int cd = min(max(nd - 8 * n, 0), CN), cm = min(max(nm - 8 * n, 0), CN);
+					const uint32_t md = (((1u << (CN - cd)) - 1u) << 8) << (16 * hf), mm = (((1u << (CN - cm)) - 1u) << 8) << (16 * hf);
+					if(mov != 0u){ accD[n] |= md; accM[n] |= mm; }
+				}
+			}
+		} else accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u;
+		if(act){
+			if constexpr (W == 8){
+				const uint32_t t1 = __builtin_amdgcn_perm(accD[0], accM[0], 0x07030501u);   // {M.lo, D.lo, M.hi, D.hi}
+				const uint32_t t2 = __builtin_amdgcn_perm(accO[0], accR[0], 0x07030501u);
+				const uint32_t dlo = __builtin_amdgcn_perm(t2, t1, 0x05040100u) ^ 0x00FFFFFFu;
+				const uint32_t dhi = __builtin_amdgcn_perm(t2, t1, 0x07060302u) ^ 0x00FFFFFFu;
+				uint32_t *rp = (uint32_t*)(rowp + (size_t)i * 64u);
+				rp[jl] = dlo; rp[jl + 8] = dhi;
+			} else if constexpr (W == 4){
+				const uint32_t pk = ((accM[0] >> 8) | (accD[0] >> 4) | accR[0] | (accO[0] << 4)) ^ 0x0FFF0FFFu;
+				uint32_t *rp = (uint32_t*)(rowp + (size_t)i * 64u);
+				rp[jl] = pk & 0xFFFFu; rp[jl + 8] = pk >> 16;
+			} else {
+				static_assert(W == 16 || W == 8 || W == 4, "code row layouts");
+				// 16 cells per block: dword 0 = M | D << 16, dword 1 = R | Od << 16, cell k at bit 15 - k
+				const uint32_t xm = __builtin_amdgcn_perm(accM[0], accM[NACC - 1], 0x07030501u) ^ 0xFFFFFFFFu;   // {M16 of the low block, M16 of the high block}
+				const uint32_t xd = __builtin_amdgcn_perm(accD[0], accD[NACC - 1], 0x07030501u) ^ 0xFFFFFFFFu;
+				const uint32_t xr = __builtin_amdgcn_perm(accR[0], accR[NACC - 1], 0x07030501u) ^ 0xFFFFFFFFu;
+				const uint32_t xo = __builtin_amdgcn_perm(accO[0], accO[NACC - 1], 0x07030501u);
+				uint32_t *rp = (uint32_t*)(rowp + (size_t)i * 128u);
+				uint2 lo, hi;
+				lo.x = __builtin_amdgcn_perm(xd, xm, 0x05040100u); lo.y = __builtin_amdgcn_perm(xo, xr, 0x05040100u);
+				hi.x = __builtin_amdgcn_perm(xd, xm, 0x07060302u); hi.y = __builtin_amdgcn_perm(xo, xr, 0x07060302u);
+				*(uint2*)(rp + 2 * jl) = lo; *(uint2*)(rp + 2 * (jl + 8)) = hi;
+			}
+			// band offsets: lane (i mod 8) keeps the offset of row i, the group stores them together
+			if((i & 7u) == (uint32_t)jl) begq = (int)rbeg;
+			const bool lastrow = i + 1u == tlen;
+			if(((i & 7u) == 7u || lastrow) && (uint32_t)jl <= (i & 7u)) begs[(i & ~7u) + 1u + (uint32_t)jl] = begq;
+			if(lastrow){
+				// global score = H at query column qlen - 1 of the last row (bsalign.h:4034-4037), kept in begs[tlen + 1]
+				const uint32_t pos = qlen - 1u - rbeg;
+				if(pos >= (uint32_t)BW){ if(first) begs[tlen + 1u] = (int)0x80000000u; }        // band never reached the query end
+				else {
+					const uint32_t b = pos / W, kk = pos % W;
+					if((b & 7u) == (uint32_t)jl){
+						const bool hi = b >= 8u;
+						int sc = HB + (hi ? x_hi16(Psh) : x_lo16(Psh)) + (int)b * W * GE;
+#pragma unroll
+						for(int k = 0; k < W; k++){
+							const uint32_t uu = (k == 0) ? tmpU0 : U[k - 1];
+							sc += ((uint32_t)k <= kk) ? ((hi ? x_hi8(uu) : x_lo8(uu)) + GE) : 0;
+						}
+						begs[tlen + 1u] = sc;
+					}
+				}
+			}
+		}
+		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
+		{
+			uint32_t x;
+			{
+				const uint32_t dl = x_add(x_sub(PN, Psh), WGE16);             // ubegs[b+1] - ubegs[b]
+				x = x_max(dl, x_sub(0u, dl));
+				x = x_add(x, XDPP(0, x, XQP(1, 0, 3, 2), 0xf));
+				x = x_add(x, XDPP(0, x, XQP(2, 3, 0, 1), 0xf));
+				x = x_add(x, XDPP(0, x, XHALF_MIRROR, 0xf));
+			}
+			const int nzsum = (int)((x & 0xffffu) + (x >> 16));
+			const int d16 = x_hi16(x_bcast_last(PN)) + BW * GE;             // ubegs[16] - ubegs[0]
+			uint32_t nz = (uint32_t)(nzsum / 16);
+			nz = nz / (uint32_t)W * 16u / 2u;
+			const int noisy = (int)((16u > nz) ? 16u : nz);
+			int rbx;
+			if(i <= (uint32_t)BW / 4u) rbx = 0;
+			else if(rbeg + BW >= qlen) rbx = 0;
+			else if(noisy < d16) rbx = 2;
+			else if(d16 < -noisy) rbx = 0;
+			else rbx = 1;
+			if(mode == BSA_MODE_GLOBAL){
+				const int rby = __builtin_amdgcn_ds_bpermute(rby_lane + (int)((i & 7u) << 2), rby_tab);
+				const uint32_t left = tlen - i - 1u;
+				bool rush;
+				if(rush32) rush = act && rbeg + (uint32_t)rbz * left + (uint32_t)BW <= qlen + (uint32_t)rbz - 1u;
+				else {
+					const unsigned long long lhs = (unsigned long long)rbeg + (unsigned long long)(uint32_t)rbz * left + (unsigned long long)BW;
+					rush = act && lhs <= (unsigned long long)(uint32_t)(qlen + (uint32_t)rbz - 1u);
+				}
+				if((int)rbeg < rby - BW) mov = (uint32_t)(rbx + 1);
+				else if((int)rbeg > rby) mov = (uint32_t)max(0, rbx - 1);
+				else mov = (uint32_t)rbx;
+				if(rush) mov = 1u + (uint32_t)(qlen - (rbeg + BW)) / max(left, 1u);
+			} else mov = (uint32_t)rbx;
+		}
+		// ---- speculative slide by one cell: the first cell of every block becomes the last cell of the block before it
+		{
+			const uint32_t nxt = XDPP(0, tmpU0, XROW_SHL(1), 0xf);          // (a DPP move must not sit in an arm of ?: -- only one arm runs)
+			const uint32_t inu = last ? __builtin_amdgcn_alignbit(NEWU0, bc0, 16) : nxt;
+			const uint32_t inne = x_shift_up(tmpNE0, NEWNE, last);
+			U[W - 1] = inu; NE[W - 1] = inne;
+			PN = x_add(x_add(PN, x_ashr8(inu)), GE16);
+			svU = tmpU0; svNE = tmpNE0;
+		}
+		i++;
+		if((i & 7u) == 0u && i < tlen) __builtin_memcpy(&twin, tp + i, 8);
+	}
+}
+
+// Exact arithmetic is the reference's arithmetic only while nothing saturates: the guard of the compact path
+// (bsa_align8_codes_supported) plus room for the frame shift by 2 |gape| and for the int16 block offsets.
+bool bsa_align8_x_supported(const Align8Args &a, int pw){
+	if(pw != 1 || !bsa_align8_codes_supported(a, pw)) return false;
+	if((a.mode & 3) != BSA_MODE_GLOBAL) return false;
+	const uint32_t W = a.bw / 16;
+	if(!(W == 4 || W == 8 || W == 16)) return false;
+	const int ge = -(int)(int8_t)a.gape1, go = -(int)(int8_t)a.gapo1, m = a.smax, n = -a.smin;
+	if(ge < 0 || go <= 0) return false;
+	const int g = go + ge;
+	const int cfirst = std::min(a.smin, -g) - 1 - a.smax - g;
+	if(cfirst < -100) return false;
+	return m + 3 * g + 2 * ge <= 100 && n + m + g + 2 * ge <= 110 && 63 + 2 * ge + n + m + 2 * g <= 125;
+}
+
+hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
+	(void)pw;
+	const uint32_t blocks = (a.count + 31u) / 32u;
+	if(blocks == 0) return hipSuccess;
+	switch(a.bw / 16){
+		case 4:  hipLaunchKernelGGL((k_align8_fwd_x<4>), dim3(blocks), dim3(256), 0, st, a); break;
+		case 8:  hipLaunchKernelGGL((k_align8_fwd_x<8>), dim3(blocks), dim3(256), 0, st, a); break;
+		case 16: hipLaunchKernelGGL((k_align8_fwd_x<16>), dim3(blocks), dim3(256), 0, st, a); break;
+		default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}

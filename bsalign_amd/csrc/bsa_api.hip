@@ -584,9 +584,18 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	const int pw = p->pw;
 	uint32_t *cnt = p->d_cnt_pos;
 	const bool generic = p->generic, codes = p->codes; const uint32_t max_bw = p->max_bw;
+	// forward kernel of the compact path: the exact-arithmetic one wherever its guard holds (BSA_ALIGN8_FWD=pk keeps the
+	// saturating packed kernel: same code rows, the reference point of the tests)
+	bool fwd_x = false;
+	if(codes){
+		const char *fe = getenv("BSA_ALIGN8_FWD");
+		const bool force_pk = fe && fe[0] == 'p';
+		fwd_x = !force_pk && bsa_align8_x_supported(a, pw);
+	}
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
-		if(codes) HIPCHK(c, bsa_launch_align8_fwd_codes(b, pw, s));
+		if(codes && fwd_x) HIPCHK(c, bsa_launch_align8_fwd_x(b, pw, s));
+		else if(codes) HIPCHK(c, bsa_launch_align8_fwd_codes(b, pw, s));
 		else if(generic) HIPCHK(c, bsa_launch_align8_fwd_gen(b, pw, max_bw, s));
 		else HIPCHK(c, bsa_launch_align8_fwd(b, pw, s));
 		return BSA_OK;
