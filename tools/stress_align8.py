@@ -26,6 +26,13 @@ def main():
         mode = int(rng.integers(3))
         bw = int(rng.choice([0, 16, 32, 48, 64, 128, 256]))
         sc = SCORINGS[int(rng.integers(len(SCORINGS)))]
+        # STRESS_MODE / STRESS_BW / STRESS_SC (indices into SCORINGS) narrow the campaign, e.g. to one forward kernel's domain
+        if os.environ.get("STRESS_MODE"):
+            mode = int(rng.choice([int(x) for x in os.environ["STRESS_MODE"].split(",")]))
+        if os.environ.get("STRESS_BW"):
+            bw = int(rng.choice([int(x) for x in os.environ["STRESS_BW"].split(",")]))
+        if os.environ.get("STRESS_SC"):
+            sc = SCORINGS[int(rng.choice([int(x) for x in os.environ["STRESS_SC"].split(",")]))]
         pairs = []
         for _ in range(int(rng.integers(100, 400))):
             L = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 100, 300, 700, 1500, 3000]))
