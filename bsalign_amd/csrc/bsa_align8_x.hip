@@ -56,35 +56,47 @@ static __device__ __forceinline__ int x_hi16(uint32_t x){ return (int)x >> 16; }
 #define XROW_SHR(n) (0x110 + (n))
 #define XHALF_MIRROR 0x141
 
-// value of lane 0 / lane 7 of every group of 8 lanes, in all 8 lanes
-static __device__ __forceinline__ uint32_t x_bcast_first(uint32_t x){
+// A pair owns a group of L = 8 or 4 consecutive lanes (two or four groups per 16-lane DPP row).
+// value of the first / last lane of every group, in all its lanes
+template<int L> static __device__ __forceinline__ uint32_t x_bcast_first(uint32_t x){
 	const uint32_t s = XDPP(0, x, XQP(0, 0, 0, 0), 0xf);
-	return XDPP(s, s, XROW_SHR(4), 0xA);                 // lanes 4..7 <- lanes 0..3
+	if constexpr (L == 4) return s;
+	else return XDPP(s, s, XROW_SHR(4), 0xA);          // lanes 4..7 <- lanes 0..3
 }
-static __device__ __forceinline__ uint32_t x_bcast_last(uint32_t x){
+template<int L> static __device__ __forceinline__ uint32_t x_bcast_last(uint32_t x){
 	const uint32_t s = XDPP(0, x, XQP(3, 3, 3, 3), 0xf);
-	return XDPP(s, s, XROW_SHL(4), 0x5);                 // lanes 0..3 <- lanes 4..7
+	if constexpr (L == 4) return s;
+	else return XDPP(s, s, XROW_SHL(4), 0x5);          // lanes 0..3 <- lanes 4..7
 }
-// block b receives the value of block b - 1 (low half: block l, high half: block l + 8); block 0 receives fill_lo
-static __device__ __forceinline__ uint32_t x_shift_down(uint32_t x, uint32_t fill_lo, bool first){
+// block b receives the value of block b - 1 (low half: block l, high half: block l + L); block 0 receives fill_lo
+template<int L> static __device__ __forceinline__ uint32_t x_shift_down(uint32_t x, uint32_t fill_lo, bool first){
 	const uint32_t s = XDPP(0, x, XROW_SHR(1), 0xf);
-	const uint32_t w = XDPP(0, x, XROW_SHL(7), 0xf);      // lane 0 <- lane 7
+	const uint32_t w = XDPP(0, x, XROW_SHL(L - 1), 0xf);  // first lane <- last lane
 	const uint32_t fix = (w << 16) | (fill_lo & 0xffffu);
 	return first ? fix : s;
 }
-// block b receives the value of block b + 1; block 15 receives fill_hi (given in both halves)
-static __device__ __forceinline__ uint32_t x_shift_up(uint32_t x, uint32_t fill, bool last){
+// block b receives the value of block b + 1; block 2L - 1 receives fill (given in both halves)
+template<int L> static __device__ __forceinline__ uint32_t x_shift_up(uint32_t x, uint32_t fill, bool last){
 	const uint32_t s = XDPP(0, x, XROW_SHL(1), 0xf);
-	const uint32_t w = XDPP(0, x, XROW_SHR(7), 0xf);      // lane 7 <- lane 0
+	const uint32_t w = XDPP(0, x, XROW_SHR(L - 1), 0xf);  // last lane <- first lane
 	const uint32_t fix = __builtin_amdgcn_alignbit(fill, w, 16);        // {fill.lo, w.hi}
 	return last ? fix : s;
 }
-// inclusive prefix maximum over the 8 lanes of a group, per half (Sklansky: nothing crosses a group)
-static __device__ __forceinline__ uint32_t x_scan_max8(uint32_t x){
+// inclusive prefix maximum over the lanes of a group, per half (Sklansky: nothing crosses a group)
+template<int L> static __device__ __forceinline__ uint32_t x_scan_max(uint32_t x){
 	uint32_t y = XDPP(x, x, XQP(0, 0, 2, 2), 0xf); x = x_max(x, y);
 	y = XDPP(x, x, XQP(0, 1, 1, 1), 0xf); x = x_max(x, y);
-	const uint32_t z = XDPP(x, x, XQP(3, 3, 3, 3), 0xf);
-	y = XDPP(x, z, XROW_SHR(4), 0xA); x = x_max(x, y);
+	if constexpr (L == 8){
+		const uint32_t z = XDPP(x, x, XQP(3, 3, 3, 3), 0xf);
+		y = XDPP(x, z, XROW_SHR(4), 0xA); x = x_max(x, y);
+	}
+	return x;
+}
+// sum over the lanes of a group, per half, in every lane
+template<int L> static __device__ __forceinline__ uint32_t x_sum(uint32_t x){
+	x = x_add(x, XDPP(0, x, XQP(1, 0, 3, 2), 0xf));
+	x = x_add(x, XDPP(0, x, XQP(2, 3, 0, 1), 0xf));
+	if constexpr (L == 8) x = x_add(x, XDPP(0, x, XHALF_MIRROR, 0xf));
 	return x;
 }
 
@@ -95,16 +107,20 @@ static __device__ __forceinline__ void x_load_qcodes(const uint8_t *p, uint32_t 
 	else w[0] = p[0] | 0x04040400u;
 }
 
-template<int W>
+// W cells per lane and half, L lanes per pair: 2 L blocks of W cells; the reference's 16 running blocks have WR = 2 L W / 16
+// cells, so a block here holds CR = 8 / L of them
+template<int W, int L>
 __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
-	constexpr int BW = W * 16;
+	constexpr int BW = 2 * L * W;
+	constexpr int WR = BW / 16, CR = 8 / L;
+	static_assert((L == 8 || L == 4) && W * L / 8 == WR && (CR == 1 || (CR == 2 && W == 16)), "supported shapes");
 	constexpr int NQ = (W + 3) / 4;
 	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
 	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
 	const int lt = threadIdx.x;
-	const int jl = lt & 7;
-	const bool first = jl == 0, last = jl == 7;
-	const uint32_t g = (blockIdx.x * 256u + lt) >> 3;
+	const int jl = lt & (L - 1);
+	const bool first = jl == 0, last = jl == L - 1;
+	const uint32_t g = (blockIdx.x * 256u + lt) / (uint32_t)L;
 	const bool live = g < a.count;
 	const uint32_t ppos = a.first + (live ? g : 0u);
 	const uint32_t pair = a.order[ppos];
@@ -138,7 +154,8 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	}
 
 	uint32_t U[W], NE[W];
-	uint32_t PN;                  // packed int16: ubegs[b+1] - ubegs[0] - (b+1) W gape for b = jl (low) and jl + 8 (high)
+	uint32_t PN;                  // packed int16: ubegs[b+1] - ubegs[0] - (b+1) W gape for b = jl (low) and jl + L (high)
+	uint32_t PM = 0;              // CR == 2: the same for the middle of the block (the end of its first reference block)
 	int HB;                       // ubegs[0]
 	// ---- row -1 (bsalign.h:2094-2140)
 	{
@@ -152,10 +169,12 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 			NE[k] = x_q8(GE - BSA_EPI8_MIN);
 		}
 		if(mode == BSA_MODE_OVERLAP){
-			PN = ((uint32_t)(-(jl + 1) * W * GE) & 0xffffu) | ((uint32_t)(-(jl + 9) * W * GE) << 16);
+			PN = ((uint32_t)(-(jl + 1) * W * GE) & 0xffffu) | ((uint32_t)(-(jl + L + 1) * W * GE) << 16);
+			PM = x_add(PN, x_i16((W / 2) * GE));
 			HB = 0;
 		} else {
 			PN = x_i16(first_u - GE);
+			PM = PN;
 			HB = a.smax - a.smin;
 		}
 	}
@@ -165,9 +184,10 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 		const uint32_t t0u = U[0], t0e = NE[0];
 #pragma unroll
 		for(int k = 0; k + 1 < W; k++){ U[k] = U[k + 1]; NE[k] = NE[k + 1]; }
-		const uint32_t inu = x_shift_up(t0u, NEWU0, last), inne = x_shift_up(t0e, NEWNE, last);
+		const uint32_t inu = x_shift_up<L>(t0u, NEWU0, last), inne = x_shift_up<L>(t0e, NEWNE, last);
 		U[W - 1] = inu; NE[W - 1] = inne;
 		PN = x_add(x_add(PN, x_ashr8(inu)), GE16);
+		if constexpr (CR == 2) PM = x_add(x_add(PM, x_ashr8(U[W / 2 - 1])), GE16);
 		svU = t0u; svNE = t0e;
 	}
 
@@ -179,12 +199,12 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	const int rbz = 2 * max((int)(tlen / max(qlen, 1u)), 1);          // bsalign.h:4008
 	const bool rush32 = (unsigned long long)(uint32_t)rbz * tlen + qlen + (uint32_t)BW + (uint32_t)rbz < 0xFFFFFFFFull;
 	int rby_tab = 0;
-	const int rby_lane = (lt & 56) << 2;                   // byte address of lane 0 of this group for ds_bpermute
+	const int rby_lane = (lt & (64 - L)) << 2;                   // byte address of lane 0 of this group for ds_bpermute
 	const uint32_t kd1 = last ? 0x01000000u : 0u;          // band cell bw - 1 after a slide by one: x == bw, no deletion there (bsalign.h:3672-3678)
 
 	while(__any(i < tlen)){
 		const bool act = i < tlen;
-		if(mode == BSA_MODE_GLOBAL && (i & 7u) == 0u)
+		if(mode == BSA_MODE_GLOBAL && (i & (uint32_t)(L - 1)) == 0u)
 			rby_tab = (int)((1.0 * (double)(i + (uint32_t)jl) / (double)tlen) * (double)qlen);      // bsalign.h:4009, row i + jl
 		// ---- band offset of this row (bsalign.h:3932-3946)
 		{
@@ -203,23 +223,25 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 				// the band jumped past everything it held: zero rows, every ubegs = SCORE_MIN (bsalign.h:2253-2259);
 				// rh = H at the last cell of the previous row (getscore(bw - 1))
 				const bool z = act && mov >= (uint32_t)BW;
-				const uint32_t bc = x_bcast_last(PN);
+				const uint32_t bc = x_bcast_last<L>(PN);
 				const int rhz = HB + (x_hi16(bc) - cfirst) + BW * GE;
 				if(z){
 					rh = rhz;
 #pragma unroll
 					for(int k = 0; k < W; k++){ U[k] = NGEQ; NE[k] = NEWNE; }
 					HB = BSA_SCORE_MIN;
-					PN = ((uint32_t)(-(jl + 1) * W * GE) & 0xffffu) | ((uint32_t)(-(jl + 9) * W * GE) << 16);
+					PN = ((uint32_t)(-(jl + 1) * W * GE) & 0xffffu) | ((uint32_t)(-(jl + L + 1) * W * GE) << 16);
+					PM = x_add(PN, x_i16((W / 2) * GE));
 				}
 			}
 			if(__any(act && mov == 0u)){
 				// undo the slide
 				const bool d = act && mov == 0u;
 				const uint32_t outu = U[W - 1];
-				const uint32_t pu = x_shift_down(outu, svU, first), pe = x_shift_down(NE[W - 1], svNE, first);
+				const uint32_t pu = x_shift_down<L>(outu, svU, first), pe = x_shift_down<L>(NE[W - 1], svNE, first);
 				const uint32_t npn = x_sub(x_sub(PN, x_ashr8(outu)), GE16);
 				PN = d ? npn : PN;
+				if constexpr (CR == 2){ const uint32_t npm = x_sub(x_sub(PM, x_ashr8(U[W / 2 - 1])), GE16); PM = d ? npm : PM; }
 #pragma unroll
 				for(int k = W - 1; k >= 1; k--){ U[k] = d ? U[k - 1] : U[k]; NE[k] = d ? NE[k - 1] : NE[k]; }
 				U[0] = d ? pu : U[0]; NE[0] = d ? pe : NE[0];
@@ -227,11 +249,12 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 			// one more cell at a time for steps of two and more (the first new cell went in with the speculative slide)
 			for(uint32_t s = 1; __any(act && mov < (uint32_t)BW && s < mov); s++){
 				const bool d = act && mov < (uint32_t)BW && s < mov;
-				const uint32_t bc = x_bcast_first(U[0]);
+				const uint32_t bc = x_bcast_first<L>(U[0]);
 				const uint32_t D0 = __builtin_amdgcn_perm(bc, bc, 0x01000100u);
-				const uint32_t inu = x_shift_up(U[0], NEWU1, last), inne = x_shift_up(NE[0], NEWNE, last);
+				const uint32_t inu = x_shift_up<L>(U[0], NEWU1, last), inne = x_shift_up<L>(NE[0], NEWNE, last);
 				const uint32_t npn = x_add(PN, x_ashr8(x_sub(inu, D0)));
 				PN = d ? npn : PN;
+				if constexpr (CR == 2){ const uint32_t npm = x_add(PM, x_ashr8(x_sub(U[W / 2], D0))); PM = d ? npm : PM; }
 				HB += d ? (x_lo8(bc) + GE) : 0;
 #pragma unroll
 				for(int k = 0; k + 1 < W; k++){ U[k] = d ? U[k + 1] : U[k]; NE[k] = d ? NE[k + 1] : NE[k]; }
@@ -244,7 +267,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 		{
 			const int tb = (int)((twin >> (8u * (i & 7u))) & 3u);
 			uint32_t qlo[NQ], qhi[NQ];
-			if(act){ x_load_qcodes<W>(qp + rbeg + jl * W, qlo); x_load_qcodes<W>(qp + rbeg + (jl + 8) * W, qhi); }
+			if(act){ x_load_qcodes<W>(qp + rbeg + jl * W, qlo); x_load_qcodes<W>(qp + rbeg + (jl + L) * W, qhi); }
 			else {
 #pragma unroll
 				for(int n = 0; n < NQ; n++){ qlo[n] = 0x04040404u; qhi[n] = 0x04040404u; }
@@ -288,24 +311,18 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 		// ---- F-penetration (bsalign.h:2639-2652) as a prefix maximum over the blocks
 		{
 			const uint32_t Fa = x_add(x_ashr8(f), PN);
-			const uint32_t P = x_scan_max8(Fa);
-			const uint32_t bc = x_bcast_last(P);
+			const uint32_t P = x_scan_max<L>(Fa);
+			const uint32_t bc = x_bcast_last<L>(P);
 			const uint32_t Thi = (bc << 16) | 0x8000u;              // {-32768, max over blocks 0..7}
 			const uint32_t G = x_sub(x_max(P, Thi), PN);
-			f = x_shl8(x_shift_down(G, x_i16(BSA_EPI8_MIN - 2 * GE), first));
+			f = x_shl8(x_shift_down<L>(G, x_i16(BSA_EPI8_MIN - 2 * GE), first));
 		}
-#ifdef BSA_XDEBUG
-		const int dbg_fin[2] = { x_lo8(f) + 2 * GE, x_hi8(f) + 2 * GE };
-#endif
 		// ---- pass 2 (bsalign.h:2932-2957), flags, new row written one slot to the left
 		uint32_t accM[NACC], accD[NACC], accR[NACC], accO[NACC];
 #pragma unroll
 		for(int n = 0; n < NACC; n++){ accM[n] = 0; accD[n] = 0; accR[n] = 0; accO[n] = 0; }
 		uint32_t tmpU0 = 0, tmpNE0 = 0, hfirst = 0;
-#ifdef BSA_XDEBUG
-		uint32_t dbg_u7 = 0, dbg_h7 = 0;
-#endif
-		uint32_t v = 0;
+		uint32_t v = 0, vmid = 0;
 #pragma unroll
 		for(int k = 0; k < W; k++){
 			const uint32_t uk = U[k];
@@ -320,39 +337,22 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 			accM[k >> 3] = x_acc(accM[k >> 3], x_minu(x_sub(h, S[k]), ONE));
 			const uint32_t un = x_sub(h, v);
 			v = x_sub(h, uk);
-#ifdef BSA_XDEBUG
-			if(k == W - 1){ dbg_u7 = uk; dbg_h7 = h; }
-			if(g == BSA_XDEBUG && i == 8 && jl == 7) printf("k %d uk %d ne %d S %d ee %d m %d mg %d h %d fnext %d un %d v %d\n", k, x_lo8(uk) + GE, GE - x_lo8(NE[k]), x_lo8(S[k]) + 2 * GE, x_lo8(ee[k]) + 2 * GE,
-				x_lo8(m[k]) + 2 * GE, x_lo8(mg[k]) + 2 * GE, x_lo8(h) + 2 * GE, x_lo8(f) + 2 * GE, x_lo8(un) + GE, x_lo8(v) + GE);
-#endif
+			if(CR == 2 && k == W / 2 - 1) vmid = v;
 			if(k == 0){ tmpU0 = un; tmpNE0 = ne; hfirst = h; }
 			else { U[k - 1] = un; NE[k - 1] = ne; }
 		}
 		// ---- tail (bsalign.h:2618-2636): u of every block's first cell, ubegs of the new row, ubegs[0] re-based on cell 0
 		const uint32_t vlast = v;
-		tmpU0 = x_sub(tmpU0, x_shift_down(vlast, NGEQ, first));
-		const uint32_t bc0 = x_bcast_first(tmpU0);
+		tmpU0 = x_sub(tmpU0, x_shift_down<L>(vlast, NGEQ, first));
+		const uint32_t bc0 = x_bcast_first<L>(tmpU0);
 		{
 			const uint32_t D0 = __builtin_amdgcn_perm(bc0, bc0, 0x01000100u);
 			HB += x_lo8(bc0) + GE;
 			PN = x_add(PN, x_ashr8(x_sub(vlast, D0)));
+			if constexpr (CR == 2) PM = x_add(PM, x_ashr8(x_sub(vmid, D0)));
 		}
 		if(first) tmpU0 = (tmpU0 & 0xffff0000u) | (NGEQ & 0xffffu);
-		const uint32_t Psh = x_shift_down(PN, 0u, first);           // ubegs[b] - ubegs[0] - b W gape of the block's own start
-#ifdef BSA_XDEBUG
-		if(g == BSA_XDEBUG && i >= 5 && i < 9 && (jl == 0 || jl >= 6)){
-			for(int hf = 0; hf < 2; hf++){
-				int uu[W], en[W];
-				for(int k = 0; k < W; k++){
-					const uint32_t a1 = (k == 0) ? tmpU0 : U[k - 1], a2 = (k == 0) ? tmpNE0 : NE[k - 1];
-					uu[k] = (hf ? x_hi8(a1) : x_lo8(a1)) + GE; en[k] = GE - (hf ? x_hi8(a2) : x_lo8(a2));
-				}
-				const int b = jl + 8 * hf;
-				printf("row %u blk %2d u [%d %d %d %d %d %d %d %d] e [%d %d %d %d %d %d %d %d] ub %d  fin %d mov %u vlast %d uold7 %d h7 %d\n", i, b, uu[0], uu[1], uu[2], uu[3], uu[4], uu[5], uu[6], uu[7],
-					en[0], en[1], en[2], en[3], en[4], en[5], en[6], en[7], HB + (hf ? x_hi16(Psh) : x_lo16(Psh)) + b * W * GE, dbg_fin[hf], mov, (hf ? x_hi8(vlast) : x_lo8(vlast)) + GE, (hf ? x_hi8(dbg_u7) : x_lo8(dbg_u7)) + GE, (hf ? x_hi8(dbg_h7) : x_lo8(dbg_h7)) + 2 * GE);
-			}
-		}
-#endif
+		const uint32_t Psh = x_shift_down<L>(PN, 0u, first);           // ubegs[b] - ubegs[0] - b W gape of the block's own start
 		// ---- flags of special cells, then the code row (bsa_common.h "COMPACT slot"); M, D, R were accumulated inverted
 		if(__any(act && rbeg == 0u)){
 			if(first && rbeg == 0u){
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 			// cells at / beyond the end of the previous row's band: x == bw decides M or I only, x > bw is always I
 #pragma unroll
 			for(int hf = 0; hf < 2; hf++){
-				const int lim = BW - (int)mov - (jl + 8 * hf) * W;                 // cells k < lim have x < bw
+				const int lim = BW - (int)mov - (jl + L * hf) * W;                 // cells k < lim have x < bw
 				const int nd = min(max(lim, 0), W), nm = min(max(lim + 1, 0), W);
 #pragma unroll
 				for(int n = 0; n < NACC; n++){
@@ -379,19 +379,29 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 			}
 		} else accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u;
 		if(act){
-			if constexpr (W == 8){
-				const uint32_t t1 = __builtin_amdgcn_perm(accD[0], accM[0], 0x07030501u);   // {M.lo, D.lo, M.hi, D.hi}
-				const uint32_t t2 = __builtin_amdgcn_perm(accO[0], accR[0], 0x07030501u);
-				const uint32_t dlo = __builtin_amdgcn_perm(t2, t1, 0x05040100u) ^ 0x00FFFFFFu;
-				const uint32_t dhi = __builtin_amdgcn_perm(t2, t1, 0x07060302u) ^ 0x00FFFFFFu;
+			if constexpr (WR == 8){
+				// one dword per reference block: M | D << 8 | R << 16 | Od << 24, cell k at bit 7 - k
+				uint32_t dlo[NACC], dhi[NACC];
+#pragma unroll
+				for(int n = 0; n < NACC; n++){
+					const uint32_t t1 = __builtin_amdgcn_perm(accD[n], accM[n], 0x07030501u);   // {M.lo, D.lo, M.hi, D.hi}
+					const uint32_t t2 = __builtin_amdgcn_perm(accO[n], accR[n], 0x07030501u);
+					dlo[n] = __builtin_amdgcn_perm(t2, t1, 0x05040100u) ^ 0x00FFFFFFu;
+					dhi[n] = __builtin_amdgcn_perm(t2, t1, 0x07060302u) ^ 0x00FFFFFFu;
+				}
 				uint32_t *rp = (uint32_t*)(rowp + (size_t)i * 64u);
-				rp[jl] = dlo; rp[jl + 8] = dhi;
-			} else if constexpr (W == 4){
+				if constexpr (NACC == 1){ rp[jl] = dlo[0]; rp[jl + L] = dhi[0]; }
+				else {
+					uint2 lo, hi;
+					lo.x = dlo[0]; lo.y = dlo[NACC - 1]; hi.x = dhi[0]; hi.y = dhi[NACC - 1];
+					*(uint2*)(rp + 2 * jl) = lo; *(uint2*)(rp + 2 * (jl + L)) = hi;
+				}
+			} else if constexpr (WR == 4){
 				const uint32_t pk = ((accM[0] >> 8) | (accD[0] >> 4) | accR[0] | (accO[0] << 4)) ^ 0x0FFF0FFFu;
 				uint32_t *rp = (uint32_t*)(rowp + (size_t)i * 64u);
-				rp[jl] = pk & 0xFFFFu; rp[jl + 8] = pk >> 16;
+				rp[jl] = pk & 0xFFFFu; rp[jl + L] = pk >> 16;
 			} else {
-				static_assert(W == 16 || W == 8 || W == 4, "code row layouts");
+				static_assert(WR == 16 || WR == 8 || WR == 4, "code row layouts");
 				// 16 cells per block: dword 0 = M | D << 16, dword 1 = R | Od << 16, cell k at bit 15 - k
 				const uint32_t xm = __builtin_amdgcn_perm(accM[0], accM[NACC - 1], 0x07030501u) ^ 0xFFFFFFFFu;   // {M16 of the low block, M16 of the high block}
 				const uint32_t xd = __builtin_amdgcn_perm(accD[0], accD[NACC - 1], 0x07030501u) ^ 0xFFFFFFFFu;
@@ -401,20 +411,21 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 				uint2 lo, hi;
 				lo.x = __builtin_amdgcn_perm(xd, xm, 0x05040100u); lo.y = __builtin_amdgcn_perm(xo, xr, 0x05040100u);
 				hi.x = __builtin_amdgcn_perm(xd, xm, 0x07060302u); hi.y = __builtin_amdgcn_perm(xo, xr, 0x07060302u);
-				*(uint2*)(rp + 2 * jl) = lo; *(uint2*)(rp + 2 * (jl + 8)) = hi;
+				*(uint2*)(rp + 2 * jl) = lo; *(uint2*)(rp + 2 * (jl + L)) = hi;
 			}
-			// band offsets: lane (i mod 8) keeps the offset of row i, the group stores them together
-			if((i & 7u) == (uint32_t)jl) begq = (int)rbeg;
+			// band offsets: lane (i mod L) keeps the offset of row i, the group stores them together
+			constexpr uint32_t LM = (uint32_t)(L - 1);
+			if((i & LM) == (uint32_t)jl) begq = (int)rbeg;
 			const bool lastrow = i + 1u == tlen;
-			if(((i & 7u) == 7u || lastrow) && (uint32_t)jl <= (i & 7u)) begs[(i & ~7u) + 1u + (uint32_t)jl] = begq;
+			if(((i & LM) == LM || lastrow) && (uint32_t)jl <= (i & LM)) begs[(i & ~LM) + 1u + (uint32_t)jl] = begq;
 			if(lastrow){
 				// global score = H at query column qlen - 1 of the last row (bsalign.h:4034-4037), kept in begs[tlen + 1]
 				const uint32_t pos = qlen - 1u - rbeg;
 				if(pos >= (uint32_t)BW){ if(first) begs[tlen + 1u] = (int)0x80000000u; }        // band never reached the query end
 				else {
 					const uint32_t b = pos / W, kk = pos % W;
-					if((b & 7u) == (uint32_t)jl){
-						const bool hi = b >= 8u;
+					if((b & (uint32_t)(L - 1)) == (uint32_t)jl){
+						const bool hi = b >= (uint32_t)L;
 						int sc = HB + (hi ? x_hi16(Psh) : x_lo16(Psh)) + (int)b * W * GE;
 #pragma unroll
 						for(int k = 0; k < W; k++){
@@ -430,16 +441,20 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 		{
 			uint32_t x;
 			{
-				const uint32_t dl = x_add(x_sub(PN, Psh), WGE16);             // ubegs[b+1] - ubegs[b]
-				x = x_max(dl, x_sub(0u, dl));
-				x = x_add(x, XDPP(0, x, XQP(1, 0, 3, 2), 0xf));
-				x = x_add(x, XDPP(0, x, XQP(2, 3, 0, 1), 0xf));
-				x = x_add(x, XDPP(0, x, XHALF_MIRROR, 0xf));
+				if constexpr (CR == 1){
+					const uint32_t dl = x_add(x_sub(PN, Psh), WGE16);         // ubegs[b+1] - ubegs[b]
+					x = x_max(dl, x_sub(0u, dl));
+				} else {
+					const uint32_t HGE16 = x_i16((W / 2) * GE);
+					const uint32_t da = x_add(x_sub(PM, Psh), HGE16), db = x_add(x_sub(PN, PM), HGE16);     // the two reference blocks of this block
+					x = x_add(x_max(da, x_sub(0u, da)), x_max(db, x_sub(0u, db)));
+				}
+				x = x_sum<L>(x);
 			}
 			const int nzsum = (int)((x & 0xffffu) + (x >> 16));
-			const int d16 = x_hi16(x_bcast_last(PN)) + BW * GE;             // ubegs[16] - ubegs[0]
+			const int d16 = x_hi16(x_bcast_last<L>(PN)) + BW * GE;             // ubegs[16] - ubegs[0]
 			uint32_t nz = (uint32_t)(nzsum / 16);
-			nz = nz / (uint32_t)W * 16u / 2u;
+			nz = nz / (uint32_t)WR * 16u / 2u;
 			const int noisy = (int)((16u > nz) ? 16u : nz);
 			int rbx;
 			if(i <= (uint32_t)BW / 4u) rbx = 0;
@@ -448,7 +463,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 			else if(d16 < -noisy) rbx = 0;
 			else rbx = 1;
 			if(mode == BSA_MODE_GLOBAL){
-				const int rby = __builtin_amdgcn_ds_bpermute(rby_lane + (int)((i & 7u) << 2), rby_tab);
+				const int rby = __builtin_amdgcn_ds_bpermute(rby_lane + (int)((i & (uint32_t)(L - 1)) << 2), rby_tab);
 				const uint32_t left = tlen - i - 1u;
 				bool rush;
 				if(rush32) rush = act && rbeg + (uint32_t)rbz * left + (uint32_t)BW <= qlen + (uint32_t)rbz - 1u;
@@ -466,9 +481,10 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 		{
 			const uint32_t nxt = XDPP(0, tmpU0, XROW_SHL(1), 0xf);          // (a DPP move must not sit in an arm of ?: -- only one arm runs)
 			const uint32_t inu = last ? __builtin_amdgcn_alignbit(NEWU0, bc0, 16) : nxt;
-			const uint32_t inne = x_shift_up(tmpNE0, NEWNE, last);
+			const uint32_t inne = x_shift_up<L>(tmpNE0, NEWNE, last);
 			U[W - 1] = inu; NE[W - 1] = inne;
 			PN = x_add(x_add(PN, x_ashr8(inu)), GE16);
+			if constexpr (CR == 2) PM = x_add(x_add(PM, x_ashr8(U[W / 2 - 1])), GE16);
 			svU = tmpU0; svNE = tmpNE0;
 		}
 		i++;
@@ -493,12 +509,18 @@ bool bsa_align8_x_supported(const Align8Args &a, int pw){
 
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	(void)pw;
-	const uint32_t blocks = (a.count + 31u) / 32u;
-	if(blocks == 0) return hipSuccess;
+	if(a.count == 0) return hipSuccess;
+	// BSA_ALIGN8_X_LANES=8: eight lanes per pair also at bandwidth 128 (default four: twice the pairs per wave)
+	const char *le = getenv("BSA_ALIGN8_X_LANES");
+	const bool l8 = le && le[0] == '8';
+	const uint32_t b8 = (a.count + 31u) / 32u, b4 = (a.count + 63u) / 64u;
 	switch(a.bw / 16){
-		case 4:  hipLaunchKernelGGL((k_align8_fwd_x<4>), dim3(blocks), dim3(256), 0, st, a); break;
-		case 8:  hipLaunchKernelGGL((k_align8_fwd_x<8>), dim3(blocks), dim3(256), 0, st, a); break;
-		case 16: hipLaunchKernelGGL((k_align8_fwd_x<16>), dim3(blocks), dim3(256), 0, st, a); break;
+		case 4:  hipLaunchKernelGGL((k_align8_fwd_x<4, 8>), dim3(b8), dim3(256), 0, st, a); break;
+		case 8:
+			if(l8) hipLaunchKernelGGL((k_align8_fwd_x<8, 8>), dim3(b8), dim3(256), 0, st, a);
+			else hipLaunchKernelGGL((k_align8_fwd_x<16, 4>), dim3(b4), dim3(256), 0, st, a);
+			break;
+		case 16: hipLaunchKernelGGL((k_align8_fwd_x<16, 8>), dim3(b8), dim3(256), 0, st, a); break;
 		default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError();
