@@ -36,13 +36,16 @@ static __device__ __forceinline__ uint32_t x_sub(uint32_t a, uint32_t b){ return
 static __device__ __forceinline__ uint32_t x_max(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(xv2s, a), __builtin_bit_cast(xv2s, b))); }
 static __device__ __forceinline__ uint32_t x_minu(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(xv2u, a), __builtin_bit_cast(xv2u, b))); }
 static __device__ __forceinline__ uint32_t x_satsubu(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(xv2u, a), __builtin_bit_cast(xv2u, b))); }
-static __device__ __forceinline__ uint32_t x_acc(uint32_t acc, uint32_t flag){          // acc * 2 + flag per half
-	uint32_t r;
-	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "s"(0x00020002u), "v"(flag));
-	return r;
+// acc * 2 + flag per half: one v_pk_mad_u16 as long as the compiler cannot see that `two` is the constant 0x00020002 (it
+// would turn the product into a shift and need a second instruction).  No inline asm in the row loop: on gfx950 the
+// hazard recognizer puts a wait state behind every asm statement whose result a VALU instruction reads.
+static __device__ __forceinline__ uint32_t x_acc(uint32_t acc, uint32_t flag, uint32_t two){
+	return __builtin_bit_cast(uint32_t, (xv2u)(__builtin_bit_cast(xv2u, acc) * __builtin_bit_cast(xv2u, two) + __builtin_bit_cast(xv2u, flag)));
 }
-static __device__ __forceinline__ uint32_t x_ashr8(uint32_t a){ uint32_t r; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "s"(0x00080008u), "v"(a)); return r; }
-static __device__ __forceinline__ uint32_t x_shl8(uint32_t a){ uint32_t r; asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(r) : "s"(0x00080008u), "v"(a)); return r; }
+static __device__ __forceinline__ uint32_t x_ashr8(uint32_t a){ return __builtin_bit_cast(uint32_t, (xv2s)(__builtin_bit_cast(xv2s, a) >> 8)); }
+static __device__ __forceinline__ uint32_t x_shl8(uint32_t a){ return __builtin_bit_cast(uint32_t, (xv2u)(__builtin_bit_cast(xv2u, a) << 8)); }
+// x = take ? y : x, in place (the band corrections: a plain C select makes the register allocator copy the whole band)
+static __device__ __forceinline__ void x_sel(uint32_t &x, uint32_t y, uint64_t take){ asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "s"(take)); }
 static __device__ __forceinline__ uint32_t x_q8(int v){ return (((uint32_t)v & 0xffu) << 8) * 0x00010001u; }        // value << 8 in both halves
 static __device__ __forceinline__ uint32_t x_i16(int v){ return ((uint32_t)v & 0xffffu) * 0x00010001u; }            // plain int16 in both halves
 static __device__ __forceinline__ int x_lo8(uint32_t x){ return __builtin_amdgcn_sbfe((int)x, 8, 8); }              // value of the low half (value << 8 form)
@@ -50,7 +53,9 @@ static __device__ __forceinline__ int x_hi8(uint32_t x){ return (int)x >> 24; }
 static __device__ __forceinline__ int x_lo16(uint32_t x){ return __builtin_amdgcn_sbfe((int)x, 0, 16); }
 static __device__ __forceinline__ int x_hi16(uint32_t x){ return (int)x >> 16; }
 
-#define XDPP(old, x, ctrl, bank) ((uint32_t)dpp_keep(__builtin_amdgcn_update_dpp((int)(old), (int)(x), (ctrl), 0xf, (bank), false)))
+// (no dpp_keep here: every consumer of these moves is a packed, a three-operand or a select instruction, none of which can
+// absorb a DPP operand, so the v_subrev_u32_dpp fold that bsa_dpp.h guards against cannot happen)
+#define XDPP(old, x, ctrl, bank) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(x), (ctrl), 0xf, (bank), false))
 #define XQP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 #define XROW_SHL(n) (0x100 + (n))
 #define XROW_SHR(n) (0x110 + (n))
@@ -137,6 +142,8 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	const uint32_t GOQ = x_q8(GO);                         // gapo, value << 8
 	const uint32_t NGOQ = x_q8(-GO), NGOQ1 = x_q8(-GO - 1);
 	const uint32_t ONE = 0x01000100u;
+	uint32_t TWO = 0x00020002u;
+	asm volatile("" : "+s"(TWO));                          // opaque multiplier of x_acc
 	const uint32_t MINF = x_q8(BSA_EPI8_MIN - 2 * GE);     // the -63 sentinel of f in the shifted frame
 	const uint32_t NGEQ = x_q8(-GE);                       // a cell with u = 0
 	const int cfirst = min(a.smin, gapo1 + gape1) - 1 - a.smax + (gapo1 + gape1);      // bsalign.h:2362
@@ -237,18 +244,20 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 			if(__any(act && mov == 0u)){
 				// undo the slide
 				const bool d = act && mov == 0u;
+				const uint64_t dm = __ballot(d);
 				const uint32_t outu = U[W - 1];
 				const uint32_t pu = x_shift_down<L>(outu, svU, first), pe = x_shift_down<L>(NE[W - 1], svNE, first);
 				const uint32_t npn = x_sub(x_sub(PN, x_ashr8(outu)), GE16);
 				PN = d ? npn : PN;
 				if constexpr (CR == 2){ const uint32_t npm = x_sub(x_sub(PM, x_ashr8(U[W / 2 - 1])), GE16); PM = d ? npm : PM; }
 #pragma unroll
-				for(int k = W - 1; k >= 1; k--){ U[k] = d ? U[k - 1] : U[k]; NE[k] = d ? NE[k - 1] : NE[k]; }
-				U[0] = d ? pu : U[0]; NE[0] = d ? pe : NE[0];
+				for(int k = W - 1; k >= 1; k--){ x_sel(U[k], U[k - 1], dm); x_sel(NE[k], NE[k - 1], dm); }
+				x_sel(U[0], pu, dm); x_sel(NE[0], pe, dm);
 			}
 			// one more cell at a time for steps of two and more (the first new cell went in with the speculative slide)
 			for(uint32_t s = 1; __any(act && mov < (uint32_t)BW && s < mov); s++){
 				const bool d = act && mov < (uint32_t)BW && s < mov;
+				const uint64_t dm = __ballot(d);
 				const uint32_t bc = x_bcast_first<L>(U[0]);
 				const uint32_t D0 = __builtin_amdgcn_perm(bc, bc, 0x01000100u);
 				const uint32_t inu = x_shift_up<L>(U[0], NEWU1, last), inne = x_shift_up<L>(NE[0], NEWNE, last);
@@ -257,8 +266,8 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 				if constexpr (CR == 2){ const uint32_t npm = x_add(PM, x_ashr8(x_sub(U[W / 2], D0))); PM = d ? npm : PM; }
 				HB += d ? (x_lo8(bc) + GE) : 0;
 #pragma unroll
-				for(int k = 0; k + 1 < W; k++){ U[k] = d ? U[k + 1] : U[k]; NE[k] = d ? NE[k + 1] : NE[k]; }
-				U[W - 1] = d ? inu : U[W - 1]; NE[W - 1] = d ? inne : NE[W - 1];
+				for(int k = 0; k + 1 < W; k++){ x_sel(U[k], U[k + 1], dm); x_sel(NE[k], NE[k + 1], dm); }
+				x_sel(U[W - 1], inu, dm); x_sel(NE[W - 1], inne, dm);
 			}
 		}
 		if(mov != 0u && mov < (uint32_t)BW) rh = HB;              // getscore(mov - 1) of the previous row
@@ -329,12 +338,12 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 			const uint32_t h = x_max(m[k], f);
 			const uint32_t fm = x_max(f, mg[k]);
 			f = x_sub(fm, uk);
-			accR[k >> 3] = x_acc(accR[k >> 3], x_minu(x_sub(fm, mg[k]), ONE));
+			accR[k >> 3] = x_acc(accR[k >> 3], x_minu(x_sub(fm, mg[k]), ONE), TWO);
 			const uint32_t n = x_sub(h, ee[k]);
-			accD[k >> 3] = x_acc(accD[k >> 3], x_minu(n, ONE));
+			accD[k >> 3] = x_acc(accD[k >> 3], x_minu(n, ONE), TWO);
 			const uint32_t ne = x_minu(n, NGOQ);
-			accO[k >> 3] = x_acc(accO[k >> 3], x_satsubu(ne, NGOQ1));
-			accM[k >> 3] = x_acc(accM[k >> 3], x_minu(x_sub(h, S[k]), ONE));
+			accO[k >> 3] = x_acc(accO[k >> 3], x_satsubu(ne, NGOQ1), TWO);
+			accM[k >> 3] = x_acc(accM[k >> 3], x_minu(x_sub(h, S[k]), ONE), TWO);
 			const uint32_t un = x_sub(h, v);
 			v = x_sub(h, uk);
 			if(CR == 2 && k == W / 2 - 1) vmid = v;
