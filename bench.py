@@ -41,22 +41,19 @@ def parse():
     ap.add_argument("--scoring", default="2,-6,-3,-2,0,0", help="M,X,O,E,Q,P (reference CLI defaults, main.c:264)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs of the CPU baseline sample (0 = auto, -1 = skip)")
     ap.add_argument("--workspace-gb", type=float, default=0.0)
+    ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(args, L, bw, sc, mode):
-    """reference (oracle/_ref, kind 'reference') or own restatement (kind 'port') on ONE host core, bounded sample"""
+def _cpu_sample(args, L, bw, sc, mode, npairs, first_pair, kind):
+    """time the reference (oracle/_ref) or the own restatement on `npairs` synthetic pairs starting at `first_pair`,
+    on the calling thread -> (band cells, seconds)"""
     import support as S
     import bsalign_amd as B
-    kind = "reference" if S.have_ref() else "port"
-    if args.workload == "align8":
-        npairs = args.cpu_pairs if args.cpu_pairs > 0 else (4000 if kind == "reference" else 1200)
-    else:
-        npairs = args.cpu_pairs if args.cpu_pairs > 0 else (1500 if kind == "reference" else 60)
     stride = B.lib().bsa_synth_stride(L)
     seqs = np.zeros(2 * npairs * stride, dtype=np.uint8)
     qlen = np.zeros(npairs, dtype=np.uint32)
-    B.lib().bsa_synth_pairs_host(SEED, 0, npairs, L, int(args.eps * 4294967296.0), seqs.ctypes.data_as(C.c_void_p), qlen.ctypes.data_as(C.c_void_p))
+    B.lib().bsa_synth_pairs_host(SEED, first_pair, npairs, L, int(args.eps * 4294967296.0), seqs.ctypes.data_as(C.c_void_p), qlen.ctypes.data_as(C.c_void_p))
     tlen = np.full(npairs, L, dtype=np.uint32)
     toff = (np.arange(npairs, dtype=np.uint64) * np.uint64(stride))
     qoff = ((np.arange(npairs, dtype=np.uint64) + np.uint64(npairs)) * np.uint64(stride))
@@ -90,9 +87,115 @@ def cpu_baseline(args, L, bw, sc, mode):
         else:
             secs = S.oracle().orc_edit_batch_time(S.ptr(seqs, S.u8p), S.ptr(qoff, S.u64p), S.ptr(qlen, S.u32p), S.ptr(toff, S.u64p),
                                                   S.ptr(tlen, S.u32p), npairs, mode, bw, C.byref(cs))
+    return cells, secs
+
+
+def physical_cores():
+    """one logical CPU per physical core among the CPUs this process may run on (/proc/cpuinfo: physical id, core id)"""
+    allowed = sorted(os.sched_getaffinity(0))
+    core_of = {}
+    try:
+        cpu = phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("processor"):
+                cpu = int(ln.split(":")[1]); phys = core = None
+            elif ln.startswith("physical id"):
+                phys = int(ln.split(":")[1])
+            elif ln.startswith("core id"):
+                core = int(ln.split(":")[1])
+                core_of[cpu] = (phys, core)
+    except OSError:
+        pass
+    seen, out = set(), []
+    for c in allowed:
+        key = core_of.get(c, ("cpu", c))
+        if key not in seen:
+            seen.add(key); out.append(c)
+    return out
+
+
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), None = unlimited"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else max(1, int(float(q) / float(per) + 0.999))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, (q + per - 1) // per)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_worker(args):
+    """hidden mode of the all-core baseline: `--cpu-worker cpu,first_pair,npairs,t_go,L,bw,mode,kind` pins itself to one
+    CPU, prepares its own slice of the synthetic pairs, waits for the common start time and prints what it measured"""
+    import time
+    f = args.cpu_worker.split(",")
+    cpu, first, npairs, t_go, L, bw, mode, kind = int(f[0]), int(f[1]), int(f[2]), float(f[3]), int(f[4]), int(f[5]), int(f[6]), f[7]
+    try:
+        os.sched_setaffinity(0, {cpu})
+    except OSError:
+        pass
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sc = tuple(int(x) for x in args.scoring.split(","))
+    _cpu_sample(args, L, bw, sc, mode, 8, first, kind)          # page in the code and the libraries
+    while time.time() < t_go:
+        pass
+    cells, secs = _cpu_sample(args, L, bw, sc, mode, npairs, first, kind)
+    print(json.dumps({"cells": cells, "secs": secs, "end": time.time()}))
+
+
+def cpu_baseline(args, L, bw, sc, mode):
+    """reference (oracle/_ref, kind 'reference') or own restatement (kind 'port') on the host: one process per physical
+    core over disjoint slices of the synthetic pairs (aggregate = all cells / time from the common start to the last
+    worker's end), and the single-core figure beside it.  Bounded sample, SURVEY.md section 8(d)."""
+    import subprocess
+    import time
+    import support as S
+    kind = "reference" if S.have_ref() else "port"
+    if args.workload == "align8":
+        npairs = args.cpu_pairs if args.cpu_pairs > 0 else (4000 if kind == "reference" else 1200)
+    else:
+        npairs = args.cpu_pairs if args.cpu_pairs > 0 else (1500 if kind == "reference" else 60)
     what = ("the reference's SSE4.2 code (oracle/_ref)" if kind == "reference" else "own scalar C restatement (oracle/), not the reference")
-    return {"value": round(cells / secs / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": kind,
-            "sample": "%d of the same synthetic pairs (L=%d, bw=%d), single thread, %s, %.1f s" % (npairs, L, bw, what, secs)}
+    cells1, secs1 = _cpu_sample(args, L, bw, sc, mode, npairs, 0, kind)
+    one = round(cells1 / secs1 / 1e9, 4)
+    cpus = physical_cores()
+    nphys = len(cpus)
+    quota = cpu_quota()
+    if quota is not None and quota < len(cpus):
+        cpus = cpus[:: max(1, len(cpus) // quota)][:quota]      # spread over the sockets
+    out = {"value": one, "unit": "GCUPS", "cores": 1, "kind": kind,
+           "sample": "%d of the same synthetic pairs (L=%d, bw=%d), single thread, %s, %.1f s" % (npairs, L, bw, what, secs1)}
+    if len(cpus) < 2:
+        return out
+    per = max(8, npairs // 2)                                  # pairs per core: about half of the single-core sample's time each
+    t_go = time.time() + 8.0 + 0.06 * len(cpus)          # common start: every worker has loaded its libraries and made its pairs by then
+    procs = []
+    for k, cpu in enumerate(cpus):
+        spec = "%d,%d,%d,%.3f,%d,%d,%d,%s" % (cpu, npairs + k * per, per, t_go, L, bw, mode, kind)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", spec, "--workload", args.workload, "--eps", str(args.eps), "--scoring", args.scoring]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, BSA_NO_TORCH_PRELOAD="1")))
+    cells = 0.0; end = 0.0; ok = 0; slow = 0.0
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=600)
+            r = json.loads(o.strip().splitlines()[-1])
+            cells += r["cells"]; end = max(end, r["end"]); slow = max(slow, r["secs"]); ok += 1
+        except Exception:
+            pr.kill()
+    if ok == 0 or end <= t_go:
+        return out
+    agg = round(cells / (end - t_go) / 1e9, 3)
+    return {"value": agg, "unit": "GCUPS", "cores": ok, "kind": kind, "per_core": round(agg / ok, 4), "one_core_alone": one,
+            "host_physical_cores": nphys, "cpu_quota": quota,
+            "sample": "%d processes pinned to %d distinct physical cores (the host has %d; this container's CPU quota is %s), %d of the same "
+                      "synthetic pairs each (L=%d, bw=%d), %s; all cells / time from the common start to the last process's end (%.1f s; "
+                      "slowest process %.1f s in the DP); one core alone on %d pairs: %.4f GCUPS"
+                      % (ok, len(cpus), nphys, "%d CPUs" % quota if quota else "unlimited", per, L, bw, what, end - t_go, slow, npairs, one)}
 
 
 def poa_cpu_baseline(args, bw):
@@ -258,6 +361,8 @@ def S_oracle_piecewise(pp, bw):
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        return cpu_worker(args)
     if args.workload == "poa":
         return main_poa(args)
     import torch
@@ -338,6 +443,8 @@ def main():
         elapsed = float(tt.item())
         barrier()
     kms, klaunch, kcells = ctx.last_kernel_ms()
+    tms, tlaunch = ctx.last_trace_ms()
+    fwd_name, trace_name = ctx.last_kernel_names()
 
     out = d_out.cpu().numpy().reshape(n, 10)
     off = d_off.cpu().numpy()
@@ -361,7 +468,11 @@ def main():
         # sequences at 1 B/base + result struct + CIGAR words
         per_cell = 0.5 if args.workload == "align8" else 0.25
         balg = per_cell * cells + float(qlen.sum()) + float(tlen.sum()) + 40.0 * n + 4.0 * ncig
-        achieved = (balg / max(klaunch, 1)) / (kms / 1e3) / 1e9 if kms > 0 else 0.0
+        # the roofline line is about the kernel that takes most of the step: the forward DP or the traceback, whichever
+        # the library's own HIP events (on the streams the kernels run on) say is longer per step
+        dom_trace = tms * tlaunch > kms * klaunch
+        dms, dlaunch, dname = (tms, tlaunch, trace_name) if dom_trace else (kms, klaunch, fwd_name)
+        achieved = (balg / max(dlaunch, 1)) / (dms / 1e3) / 1e9 if dms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -384,10 +495,11 @@ def main():
                        "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "forward DP (k_align8_fwd_pk, 4-bit traceback codes)" if args.workload == "align8" else "forward DP (k_edit_fwd_grp / k_edit_fwd / k_edit_fwd_wide)",
-                         "kernel_ms_avg": round(kms, 3), "launches_per_step": klaunch,
-                         "algorithmic_bytes_per_launch": round(balg / max(klaunch, 1), 1),
-                         "kernel_gcups": round(kcells / max(klaunch, 1) / (kms / 1e3) / 1e9, 2) if kms > 0 else None},
+                         "kernel": dname, "kernel_ms_avg": round(dms, 3), "launches_per_step": dlaunch,
+                         "algorithmic_bytes_per_launch": round(balg / max(dlaunch, 1), 1),
+                         "kernel_gcups": round(kcells / max(dlaunch, 1) / (dms / 1e3) / 1e9, 2) if dms > 0 else None,
+                         "other_kernel": {"kernel": fwd_name if dom_trace else trace_name, "kernel_ms_avg": round(kms if dom_trace else tms, 3),
+                                          "launches_per_step": klaunch if dom_trace else tlaunch}},
             "checks": {"pairs_flagged": nbad, "cigar_words": ncig, "oracle_identical_first8": ident},
         }
         if world == 1 and args.cpu_pairs >= 0:

@@ -7,6 +7,7 @@ raises.  The host-side drop-in for C callers is include/bsalign_compat.h.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -80,6 +81,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libbsalign_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                "there is no CPU fallback")
+        # PyTorch ships its own copy of the HIP runtime: when torch is imported AFTER this library has loaded the system's
+        # libamdhip64 the process ends up with two runtimes and torch finds no GPU.  Loading torch first makes the
+        # library bind to the copy torch uses (BSA_NO_TORCH_PRELOAD=1 skips this, e.g. for host-only helper processes).
+        if "torch" not in sys.modules and not os.environ.get("BSA_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         vp, u8p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
         L.bsa_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -91,6 +100,9 @@ def lib():
         L.bsa_last_error.argtypes = [vp]
         L.bsa_last_error.restype = C.c_char_p
         L.bsa_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+        L.bsa_ctx_last_trace_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+        L.bsa_ctx_last_kernel_name.argtypes = [vp, C.c_int]
+        L.bsa_ctx_last_kernel_name.restype = C.c_char_p
         L.bsa_set_score_matrix.argtypes = [C.POINTER(C.c_int8), C.c_int8, C.c_int8]
         L.bsa_set_score_matrix.restype = None
         L.bsa_align_batch.argtypes = [vp, u8p, C.c_size_t, u64p, u32p, u64p, u32p, C.c_size_t, C.POINTER(AlignParams),
@@ -204,6 +216,14 @@ class Context:
         ms, n, cells = C.c_double(), C.c_long(), C.c_double()
         self._chk(lib().bsa_ctx_last_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(cells)))
         return ms.value, n.value, cells.value
+
+    def last_trace_ms(self):
+        ms, n = C.c_double(), C.c_long()
+        self._chk(lib().bsa_ctx_last_trace_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_kernel_names(self):
+        return lib().bsa_ctx_last_kernel_name(self.h, 0).decode(), lib().bsa_ctx_last_kernel_name(self.h, 1).decode()
 
     def _batch(self, fn, pairs, par, cigar_cap=None):
         seqs, qoff, qlen, toff, tlen = pack_pairs(pairs)

@@ -519,16 +519,35 @@ bool bsa_align8_x_supported(const Align8Args &a, int pw){
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	(void)pw;
 	if(a.count == 0) return hipSuccess;
-	// BSA_ALIGN8_X_LANES=8: eight lanes per pair also at bandwidth 128 (default four: twice the pairs per wave)
-	const char *le = getenv("BSA_ALIGN8_X_LANES");
-	const bool l8 = le && le[0] == '8';
-	const uint32_t b8 = (a.count + 31u) / 32u, b4 = (a.count + 63u) / 64u;
+	const uint32_t b8 = (a.count + 31u) / 32u;
 	switch(a.bw / 16){
 		case 4:  hipLaunchKernelGGL((k_align8_fwd_x<4, 8>), dim3(b8), dim3(256), 0, st, a); break;
-		case 8:
-			if(l8) hipLaunchKernelGGL((k_align8_fwd_x<8, 8>), dim3(b8), dim3(256), 0, st, a);
-			else hipLaunchKernelGGL((k_align8_fwd_x<16, 4>), dim3(b4), dim3(256), 0, st, a);
+		case 8: {
+			// Four lanes per pair (16 pairs per wave) cost 620 instructions per row of a wave, eight lanes per pair 387.
+			// Pairs of one length finish together, so what counts is the largest number of waves any SIMD gets: whole
+			// rounds of one four-lane wave per SIMD, and a remainder of at most half a round as eight-lane waves (0.62 of
+			// a round instead of a whole one).  BSA_ALIGN8_X_LANES=4 / 8 forces one shape.
+			static const int cus = [](){
+				int dev = 0, v = 0;
+				if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+				return v;
+			}();
+			const char *le = getenv("BSA_ALIGN8_X_LANES");
+			const uint32_t round4 = (uint32_t)cus * 4u * 16u;
+			uint32_t n4 = a.count / round4 * round4;
+			if(a.count - n4 > round4 / 2u) n4 = a.count;
+			if(le && le[0] == '8') n4 = 0;
+			if(le && le[0] == '4') n4 = a.count;
+			if(n4){
+				Align8Args b = a; b.count = n4;
+				hipLaunchKernelGGL((k_align8_fwd_x<16, 4>), dim3((n4 + 63u) / 64u), dim3(256), 0, st, b);
+			}
+			if(a.count > n4){
+				Align8Args b = a; b.first = a.first + n4; b.count = a.count - n4;
+				hipLaunchKernelGGL((k_align8_fwd_x<8, 8>), dim3((b.count + 31u) / 32u), dim3(256), 0, st, b);
+			}
 			break;
+		}
 		case 16: hipLaunchKernelGGL((k_align8_fwd_x<16, 8>), dim3(b8), dim3(256), 0, st, a); break;
 		default: return hipErrorInvalidValue;
 	}

@@ -29,6 +29,9 @@ struct bsa_ctx {
 	std::vector<hipEvent_t> ev;      // pairs (start, stop)
 	size_t ev_used = 0;
 	double last_cells = 0;
+	std::vector<hipEvent_t> tev;     // the same for the traceback launches (on the stream they run on)
+	size_t tev_used = 0;
+	std::string fwd_name, trace_name;    // kernels behind those two timings
 };
 
 #define HIPCHK(ctx, call) do { hipError_t _e = (call); if(_e != hipSuccess){ (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e); return BSA_E_HIP; } } while(0)
@@ -59,6 +62,7 @@ extern "C" void bsa_ctx_destroy(bsa_ctx_t *c){
 	(void)hipStreamSynchronize(c->aux_stream);
 	for(hipEvent_t e : c->ev) (void)hipEventDestroy(e);
 	for(hipEvent_t e : c->sev) (void)hipEventDestroy(e);
+	for(hipEvent_t e : c->tev) (void)hipEventDestroy(e);
 	if(c->ws) (void)hipFree(c->ws);
 	if(c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
 	if(c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -83,6 +87,34 @@ extern "C" int bsa_ctx_last_kernel_ms(bsa_ctx_t *c, double *ms, long *launches, 
 	if(ms) *ms = n ? tot / (double)n : 0.0;
 	if(launches) *launches = n;
 	if(cells) *cells = c->last_cells;
+	return BSA_OK;
+}
+
+extern "C" int bsa_ctx_last_trace_ms(bsa_ctx_t *c, double *ms, long *launches){
+	if(!c) return BSA_E_ARG;
+	(void)hipSetDevice(c->device);
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+	double tot = 0; long n = 0;
+	for(size_t i = 0; i + 1 < c->tev_used; i += 2){
+		float t = 0;
+		HIPCHK(c, hipEventElapsedTime(&t, c->tev[i], c->tev[i + 1]));
+		tot += t; n++;
+	}
+	if(ms) *ms = n ? tot / (double)n : 0.0;
+	if(launches) *launches = n;
+	return BSA_OK;
+}
+extern "C" const char *bsa_ctx_last_kernel_name(bsa_ctx_t *c, int traceback){ return !c ? "" : traceback ? c->trace_name.c_str() : c->fwd_name.c_str(); }
+
+static int ctx_trace_event_pair(bsa_ctx *c, hipEvent_t *a, hipEvent_t *b){
+	while(c->tev.size() < c->tev_used + 2){
+		hipEvent_t e;
+		HIPCHK(c, hipEventCreate(&e));
+		c->tev.push_back(e);
+	}
+	*a = c->tev[c->tev_used]; *b = c->tev[c->tev_used + 1];
+	c->tev_used += 2;
 	return BSA_OK;
 }
 
@@ -235,6 +267,7 @@ struct PlanBase {
 	std::vector<Sub> subs;          // edit plans: forward launches per class, one traceback per chunk
 	size_t half_bytes = 0;          // size of one workspace half (0 or 1 chunk in flight per half)
 	bool two_halves = false;
+	uint32_t nbuf = 1;              // workspace regions of half_bytes each; chunk k uses region k % nbuf
 	// device metadata
 	uint64_t *d_qoff = nullptr, *d_toff = nullptr, *d_qpoff = nullptr, *d_tpoff = nullptr, *d_slot = nullptr, *d_slot_end = nullptr;
 	uint32_t *d_qlen = nullptr, *d_tlen = nullptr, *d_order = nullptr;
@@ -294,7 +327,7 @@ static void radix_sort_order(std::vector<uint64_t> &key, std::vector<uint32_t> &
 // cut the processing order into chunks: every chunk fits one workspace half, has a single bandwidth, and large
 // batches are cut into >= 4 chunks so that the traceback of one chunk hides behind the forward pass of the next
 static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const std::vector<size_t> &need, const std::vector<uint32_t> &bwv,
-		std::vector<uint64_t> &slot, std::vector<uint64_t> &slot_end, bool mix_classes = false){
+		std::vector<uint64_t> &slot, std::vector<uint64_t> &slot_end, bool mix_classes = false, bool pipe_default = false){
 	bsa_ctx *c = p->ctx;
 	const size_t n = order.size();
 	const size_t budget = ctx_ws_budget(c);
@@ -311,15 +344,22 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 	// changes nothing.  The mode stays opt-in (BSA_PIPELINE=1); BSA_CHUNK_PAIRS caps the pairs per chunk (tuning knob).
 	size_t cap;            // bytes per chunk
 	const char *pe = getenv("BSA_PIPELINE");
-	const bool want_pipe = pe && pe[0] == '1';
-	if(total <= budget || !want_pipe){ cap = std::max(std::min(total, budget), biggest); p->two_halves = false; }
+	const bool want_pipe = pipe_default ? !(pe && pe[0] == '0') : (pe && pe[0] == '1');
+	size_t pipe_chunks = 4;
+	if(const char *ke = getenv("BSA_PIPE_CHUNKS")){ const long v = atol(ke); if(v > 0) pipe_chunks = (size_t)v; }
+	size_t cap_pairs = n ? n : 1;
+	if(const char *ce = getenv("BSA_CHUNK_PAIRS")){ const long v = atol(ce); if(v > 0) cap_pairs = (size_t)v; }
+	bool all_resident = false;      // pipelined and everything fits: every chunk gets a region of its own
+	if(!want_pipe){ cap = std::max(std::min(total, budget), biggest); p->two_halves = false; }
+	else if(total + (total / std::max<size_t>(n, 1)) * 64 <= budget && pipe_chunks > 1 && n >= 4096){
+		cap = total; p->two_halves = true; all_resident = true;
+		if(cap_pairs >= n) cap_pairs = (n + pipe_chunks - 1) / pipe_chunks;
+	} else if(total <= budget){ cap = std::max(total, biggest); p->two_halves = false; }
 	else {
 		cap = std::max(budget / 2, biggest);
 		p->two_halves = (2 * cap <= budget);
 		if(!p->two_halves) cap = std::max(budget, biggest);
 	}
-	size_t cap_pairs = n ? n : 1;
-	if(const char *ce = getenv("BSA_CHUNK_PAIRS")){ const long v = atol(ce); if(v > 0) cap_pairs = (size_t)v; }
 	slot.assign(n, 0); slot_end.assign(n, 0);
 	size_t acc = 0, maxacc = 0; uint32_t first = 0;
 	// mix_classes (edit plans): a chunk is whatever fits the workspace; its launch classes become forward launches
@@ -349,6 +389,7 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 	if(n > first) close((uint32_t)n);
 	p->half_bytes = (maxacc + 255) & ~(size_t)255;
 	if(p->chunks.size() < 2) p->two_halves = false;
+	p->nbuf = !p->two_halves ? 1u : all_resident ? (uint32_t)p->chunks.size() : 2u;
 	return BSA_OK;
 }
 
@@ -366,7 +407,7 @@ static int plan_common_alloc(PlanBase *p, const uint64_t *qoff, const uint32_t *
 	TRY(dev_alloc(c, &p->d_qst, qst_bytes)); TRY(dev_alloc(c, &p->d_tst, tst_bytes));
 	TRY(dev_alloc(c, &p->d_cnt_pos, n)); TRY(dev_alloc(c, &p->d_cnt_pair, n)); TRY(dev_alloc(c, &p->d_status_own, n));
 	TRY(dev_alloc(c, &p->d_off_pos, n + 1)); TRY(dev_alloc(c, &p->d_src_pair, n)); TRY(dev_alloc(c, &p->d_carry, 1));
-	TRY(ctx_ws_reserve(c, p->half_bytes * (p->two_halves ? 2 : 1)));
+	TRY(ctx_ws_reserve(c, p->half_bytes * p->nbuf));
 #undef TRY
 	return BSA_OK;
 }
@@ -389,15 +430,19 @@ static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t ci
 	}
 	for(size_t k = 0; k < p->chunks.size(); k++){
 		const Chunk &ch = p->chunks[k];
-		uint8_t *half = c->ws + (p->two_halves ? (k & 1) * p->half_bytes : 0);
-		if(p->two_halves && k >= 2) HIPCHK(c, hipStreamWaitEvent(sf, trace_done[k - 2], 0));
+		uint8_t *half = c->ws + (k % p->nbuf) * p->half_bytes;
+		if(p->two_halves && k >= p->nbuf) HIPCHK(c, hipStreamWaitEvent(sf, trace_done[k - p->nbuf], 0));
 		hipEvent_t e0, e1;
 		rc = ctx_event_pair(c, &e0, &e1); if(rc != BSA_OK) return rc;
 		HIPCHK(c, hipEventRecord(e0, sf));
 		rc = fwd(ch, half, sf); if(rc != BSA_OK) return rc;
 		HIPCHK(c, hipEventRecord(e1, sf));
 		if(p->two_halves) HIPCHK(c, hipStreamWaitEvent(stt, e1, 0));
+		hipEvent_t t0, t1;
+		rc = ctx_trace_event_pair(c, &t0, &t1); if(rc != BSA_OK) return rc;
+		HIPCHK(c, hipEventRecord(t0, stt));
 		rc = trace(ch, half, stt); if(rc != BSA_OK) return rc;
+		HIPCHK(c, hipEventRecord(t1, stt));
 		if(want_cig){
 			hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, stt, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry);
 			HIPCHK(c, hipGetLastError());
@@ -411,8 +456,8 @@ static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t ci
 		}
 	}
 	if(p->two_halves && !p->chunks.empty()){
-		HIPCHK(c, hipStreamWaitEvent(sf, trace_done.back(), 0));
-		if(p->chunks.size() >= 2) HIPCHK(c, hipStreamWaitEvent(sf, trace_done[p->chunks.size() - 2], 0));
+		for(size_t k = p->chunks.size() > p->nbuf ? p->chunks.size() - p->nbuf : 0; k < p->chunks.size(); k++)
+			HIPCHK(c, hipStreamWaitEvent(sf, trace_done[k], 0));
 	}
 	c->last_cells = p->cells;
 	if(want_cig){
@@ -431,8 +476,8 @@ static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t ci
 static int run_prologue(PlanBase *p, bool want_cig, size_t cigar_cap_words){
 	bsa_ctx *c = p->ctx;
 	(void)hipSetDevice(c->device);
-	c->ev_used = 0; c->last_cells = 0;
-	int rc = ctx_ws_reserve(c, p->half_bytes * (p->two_halves ? 2 : 1));
+	c->ev_used = 0; c->tev_used = 0; c->last_cells = 0;
+	int rc = ctx_ws_reserve(c, p->half_bytes * p->nbuf);
 	if(rc != BSA_OK) return rc;
 	if(want_cig && p->tmp_words < cigar_cap_words){
 		if(p->d_tmp){ HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->aux_stream)); (void)hipFree(p->d_tmp); p->d_tmp = nullptr; }
@@ -507,7 +552,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	if(bw == 0) for(size_t k = 0; k < n; k++) max_bw = std::max(max_bw, (qlen[k] + 15u) / 16u * 16u);
 	p->max_bw = max_bw;
 	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)std::max(max_bw, 16u));
-	if(p->generic && bsa_align8_gen_lds(max_bw, p->pw) > 160 * 1024){
+	if(p->generic && bsa_align8_gen_lds(max_bw, p->pw, bw == 0 ? 1u : 2u) > 160 * 1024){        // a whole-query band never moves: one row buffer
 		c->err = "bandwidth too large for the device's generic kernel (two band rows must fit 160 KB of LDS)";
 		delete p; return BSA_E_UNSUPPORTED;
 	}
@@ -592,6 +637,9 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		const bool force_pk = fe && fe[0] == 'p';
 		fwd_x = !force_pk && bsa_align8_x_supported(a, pw);
 	}
+	c->fwd_name = fwd_x ? "k_align8_fwd_x (exact-arithmetic forward DP, 4-bit traceback codes)" : codes ? "k_align8_fwd_pk<.,.,true> (packed forward DP, 4-bit traceback codes)"
+		: generic ? "k_align8_fwd_gen (run-time bandwidth, row records)" : "k_align8_fwd_pk / k_align8_fwd (row records)";
+	c->trace_name = codes ? "k_align8_trace_codes_lds" : "k_align8_backcal";
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
 		if(codes && fwd_x) HIPCHK(c, bsa_launch_align8_fwd_x(b, pw, s));
@@ -615,7 +663,9 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 		uint64_t *cigar_off, uint32_t *status){
 	if(!c || !out || !par) return BSA_E_ARG;
 	if(n == 0){ if(cigar_off) cigar_off[0] = 0; return BSA_OK; }
-	if(!seqs) return BSA_E_ARG;
+	if(!seqs || !qoff || !qlen || !toff || !tlen) return BSA_E_ARG;
+	for(size_t k = 0; k < n; k++)            // the staging kernel reads seqs + qoff[k] .. + qlen[k] unconditionally
+		if(qoff[k] + qlen[k] > seqs_bytes || toff[k] + tlen[k] > seqs_bytes){ c->err = "sequence offsets outside the blob"; return BSA_E_ARG; }
 	(void)hipSetDevice(c->device);
 	bsa_align_plan_t *p = nullptr;
 	int rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
@@ -846,6 +896,8 @@ extern "C" int bsa_edit_run(bsa_edit_plan_t *p, const uint8_t *d_seqs, bsa_resul
 		HIPCHK(c, bsa_launch_edit_trace(b, d_out, cnt, s));
 		return BSA_OK;
 	};
+	c->fwd_name = "k_edit_fwd_grp / k_edit_fwd / k_edit_fwd_wide / k_edit_fwd_gen (forward DP, by band class)";
+	c->trace_name = "k_edit_trace";
 	return run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);
 }
 
@@ -855,7 +907,9 @@ extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_byt
 		uint64_t *cigar_off, uint32_t *status){
 	if(!c || !out || !par) return BSA_E_ARG;
 	if(n == 0){ if(cigar_off) cigar_off[0] = 0; return BSA_OK; }
-	if(!seqs) return BSA_E_ARG;
+	if(!seqs || !qoff || !qlen || !toff || !tlen) return BSA_E_ARG;
+	for(size_t k = 0; k < n; k++)
+		if(qoff[k] + qlen[k] > seqs_bytes || toff[k] + tlen[k] > seqs_bytes){ c->err = "sequence offsets outside the blob"; return BSA_E_ARG; }
 	(void)hipSetDevice(c->device);
 	bsa_edit_plan_t *p = nullptr;
 	const bool timing = getenv("BSA_BATCH_TIMING") != nullptr;        // host-side phase times on stderr

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -243,16 +244,20 @@ template <typename F> void parallel_for(size_t n, unsigned threads, F body){
 	if(threads > n) threads = (unsigned)(n ? n : 1);
 	if(threads <= 1){ for(size_t k = 0; k < n; k++) body(k); return; }
 	std::atomic<size_t> next(0);
+	std::atomic<bool> failed(false);           // an exception in a worker (bad_alloc) must not reach std::terminate
 	std::vector<std::thread> pool;
 	for(unsigned w = 0; w < threads; w++) pool.emplace_back([&](){
-		for(;;){
-			const size_t b = next.fetch_add(64);
-			if(b >= n) break;
-			const size_t e = std::min(n, b + 64);
-			for(size_t k = b; k < e; k++) body(k);
-		}
+		try {
+			for(;;){
+				const size_t b = next.fetch_add(64);
+				if(b >= n || failed.load()) break;
+				const size_t e = std::min(n, b + 64);
+				for(size_t k = b; k < e; k++) body(k);
+			}
+		} catch(...){ failed.store(true); }
 	});
 	for(auto &th : pool) th.join();
+	if(failed.load()) throw std::bad_alloc();  // re-raised on the calling thread, mapped to BSA_E_NOMEM by the entry points
 }
 
 } // namespace
@@ -277,7 +282,21 @@ extern "C" int bsa_kmer_assemble(const bsa_kmer_seg_t *segs, uint32_t nseg, cons
 	return assemble(segs, nseg, seg_out, ptr.data(), cnt.data(), out, cigar, cigar_cap_words, cigar_words);
 }
 
+static int kmer_edit_batch_impl(bsa_ctx_t *ctx, const uint8_t *seqs, size_t seqs_bytes,
+		const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen, size_t n,
+		const bsa_kmer_params_t *par, bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status);
+
 extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t seqs_bytes,
+		const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen, size_t n,
+		const bsa_kmer_params_t *par, bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status){
+	try {
+		return kmer_edit_batch_impl(ctx, seqs, seqs_bytes, qoff, qlen, toff, tlen, n, par, out, cigar, cigar_cap_words, cigar_off, status);
+	} catch(...){                               // host allocations (vectors, worker threads): no exception crosses the C ABI
+		return BSA_E_NOMEM;
+	}
+}
+
+static int kmer_edit_batch_impl(bsa_ctx_t *ctx, const uint8_t *seqs, size_t seqs_bytes,
 		const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen, size_t n,
 		const bsa_kmer_params_t *par, bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status){
 	if(!ctx || !par || !out || (n && (!seqs || !qoff || !qlen || !toff || !tlen))) return BSA_E_ARG;
@@ -403,7 +422,7 @@ extern "C" int bsa_kmer_edit_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t s
 	std::vector<uint32_t> scratch;
 	uint32_t *work = cigar;
 	if(!want_cig || need[n] > cigar_cap_words){
-		if(want_cig) return BSA_E_CIGAR_CAP;
+		if(want_cig){ cigar_off[n] = need[n]; return BSA_E_CIGAR_CAP; }      // the words a retry needs (bsalign_hip.h)
 		scratch.resize(need[n] + 1); work = scratch.data();
 	}
 	std::vector<uint64_t> used(n, 0);

@@ -679,6 +679,10 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepArgs a){
 	auto blkp = [&](uint32_t idx) -> int8_t* { return (int8_t*)(rows + (size_t)idx * a.r.blk); };
 	// software pipeline: tk = current task, tk1 = next (already in registers), tk2 = the one after (load in flight);
 	// the query codes of tk1 are requested while tk computes
+	if(pg.ntasks == 0u){                         // nothing to do (whole DPP rows leave together: one program per row)
+		if(j == 0){ bsa_sweep_result_t rs; rs.maxscr = BSA_SCORE_MIN; rs.maxidx = -1; rs.maxoff = -1; rs.reserved = 0; a.results[g] = rs; }
+		return;
+	}
 	const uint32_t last = pg.ntasks - 1u;
 	bsa_row_task_t tk = a.r.tasks[pg.first_task];
 	bsa_row_task_t tk1 = a.r.tasks[pg.first_task + min(1u, last)];
@@ -895,8 +899,12 @@ extern "C" int bsa_sweep_host(bsa_ctx_t *ctx, const bsa_row_task_t *tasks, size_
 	const size_t blk = bsa_rows_block_bytes(rp->bandwidth, rp->gapo1, rp->gape1, rp->gapo2, rp->gape2);
 	size_t qbytes = 0;
 	for(size_t k = 0; k < nqueries; k++) qbytes = std::max(qbytes, (size_t)qoff[k] + qlen[k]);
+	// every program has at least one task, stays inside the task array and only touches row blocks inside rows_out
 	for(size_t k = 0; k < nprogs; k++){
-		if((size_t)progs[k].first_task + progs[k].ntasks > ntasks || progs[k].first_block >= nblocks) return BSA_E_ARG;
+		if(progs[k].ntasks == 0 || (size_t)progs[k].first_task + progs[k].ntasks > ntasks || progs[k].first_block >= nblocks) return BSA_E_ARG;
+		const size_t room = nblocks - progs[k].first_block;
+		for(size_t t = progs[k].first_task; t < (size_t)progs[k].first_task + progs[k].ntasks; t++)
+			if(tasks[t].src >= room || tasks[t].dst >= room) return BSA_E_ARG;
 	}
 	for(size_t k = 0; k < ntasks; k++) if(tasks[k].query >= nqueries) return BSA_E_ARG;
 	DevBuf d_rows, d_tasks, d_progs, d_q, d_qoff, d_qlen, d_res;

@@ -8,7 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-static bsa_ctx_t *g_ctx = NULL;
+/* one context per calling thread: the reference's functions are re-entrant given distinct mempools, and a bsa_ctx_t
+ * (error string, events, workspace) is not shared between threads (include/bsalign_hip.h) */
+static __thread bsa_ctx_t *g_ctx = NULL;
 static int g_device = 0;
 
 void bsalign_compat_set_device(int device){ g_device = device; }

@@ -96,6 +96,10 @@ const char *bsa_last_error(bsa_ctx_t *ctx);
 /* average duration (ms) of the dominant kernel's launches in the last *_run call, measured with HIP
  * events on the launch stream; *launches = number of launches averaged, *cells = band cells they covered */
 int         bsa_ctx_last_kernel_ms(bsa_ctx_t *ctx, double *ms, long *launches, double *cells);
+/* the same for the traceback launches of the last *_run call, and the names of the kernels behind the two timings
+ * (traceback = 0: forward DP, 1: traceback) */
+int         bsa_ctx_last_trace_ms(bsa_ctx_t *ctx, double *ms, long *launches);
+const char *bsa_ctx_last_kernel_name(bsa_ctx_t *ctx, int traceback);
 void        bsa_set_score_matrix(int8_t matrix[16], int8_t mat, int8_t mis);   /* bsalign.h:323 */
 
 /* ---- 8-bit banded striped pairwise alignment (A-rows) ------------------------------------------
@@ -236,6 +240,9 @@ typedef struct {
 	int32_t T;                    /* par->T: bonus for reaching the read end */
 } bsa_sweep_params_t;
 /* all pointers are DEVICE memory; asynchronous on the context stream */
+/* Preconditions of the device-pointer entries (bsa_rows_run, bsa_sweep_run; bsa_sweep_host checks them and returns
+ * BSA_E_ARG): every program has ntasks >= 1; first_task + ntasks stays inside the task array; first_block + src and
+ * first_block + dst address row blocks inside d_rows; query indexes the query table.  A program with ntasks == 0 is skipped. */
 int bsa_sweep_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task_t *d_tasks, const bsa_sweep_prog_t *d_progs,
                   size_t nprogs, const uint8_t *d_queries, const uint64_t *d_qoff, const uint32_t *d_qlen,
                   const bsa_sweep_params_t *par, bsa_sweep_result_t *d_results);
