@@ -22,7 +22,7 @@
 // maximum inside the winning chunk (bsalign.h:3213-3329).
 template<int W>
 static __device__ void codes_end_cell(const uint8_t *rows, uint32_t RB, uint32_t qlen, uint32_t tlen, int &score, int &qe, int &te){
-	const bsa_code_end_t *er = (const bsa_code_end_t*)(rows + (size_t)tlen * RB);
+	const bsa_code_end_t *er = (const bsa_code_end_t*)(rows + (size_t)bsa_code_rows(tlen) * RB);
 	const int8_t *us = (const int8_t*)(er + 1);           // natural band order: lane l, cell x at l * W + x
 	int best = BSA_SCORE_MIN, bte = 0;
 	for(int l = 0; l < 16; l++){
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 	const uint8_t *tseq = a.tst + a.tpoff[pair];
 	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
 	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
-	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)tlen + BSA_CODE_SPARE_ROWS) * RB);
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * RB);
 	uint32_t ncig = 0;
 	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
 	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
@@ -117,29 +117,41 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 	};
 	auto base_for = [&](uint32_t y) -> uint32_t { return (y == 0u) ? 0u : ((y >= 14u) ? 13u : y - 1u); };
 	auto slot = [&](int r) -> uint4& { return ring[((uint32_t)r & (CODE_RING_ROWS - 1u)) * (uint32_t)LPW + (live ? lane : 0u)]; };
-	// rows requested at the last service point, still in registers
-	uint32_t p0[CODE_SVC], p1[CODE_SVC], p2[CODE_SVC], p3[CODE_SVC];
-	int pend_top = 0; bool pend = false;
+	// requested at the last service point, still in registers: two row groups (bsa_common.h: four rows of a block are 16
+	// adjacent bytes) of the blocks base .. base+2 -- 48 contiguous bytes each --, their band offsets and target bases
+	uint4 pt[2][3], pb[2];
+	uint32_t ptq[2] = {0, 0}, pend_base = 0;
+	int pend_gtop = 0; bool pend = false;
 	int have_lo = 0x7FFFFFFF;                     // lowest row filed in the ring (rows have_lo .. are readable)
 	uint4 qc0 = {0, 0, 0, 0}, qc1 = {0, 0, 0, 0}, qc2 = {0, 0, 0, 0}, qp0 = {0, 0, 0, 0}, qp1 = {0, 0, 0, 0}, qp2 = {0, 0, 0, 0};
 	int qc_ch = -1000, qp_ch = -1000;             // qc0 = chunk qc_ch, qc1 = qc_ch - 1, qc2 = qc_ch - 2
-	auto request = [&](int top, uint32_t base){
+	auto request = [&](int gtop, uint32_t base){        // row groups gtop and gtop - 1 = rows 4 gtop + 3 .. 4 gtop - 4
 #pragma unroll
-		for(int k = 0; k < CODE_SVC; k++){
-			const int rr = max(top - k, 0);
-			const uint32_t *rp = (const uint32_t*)(rows + (size_t)rr * RB) + base;
-			p0[k] = rp[0]; p1[k] = rp[1]; p2[k] = rp[2];
-			p3[k] = (uint32_t)begs[rr + 1] | ((uint32_t)tseq[rr] << 26) | (base << 28);
+		for(int u = 0; u < 2; u++){
+			const uint32_t gg = (uint32_t)max(gtop - u, 0);
+			const uint4 *tp4 = (const uint4*)((const uint32_t*)rows + bsa_code_off(4u * gg, base, 1u));
+			pt[u][0] = tp4[0]; pt[u][1] = tp4[1]; pt[u][2] = tp4[2];
+			__builtin_memcpy(&pb[u], begs + 4u * gg + 1u, 16);
+			__builtin_memcpy(&ptq[u], tseq + 4u * gg, 4);
 		}
-		pend_top = top; pend = true;
+		pend_gtop = gtop; pend_base = base; pend = true;
 	};
+	auto comp = [](const uint4 &v, int k) -> uint32_t { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; };
 	auto file = [&](){
 		if(pend){
 #pragma unroll
-			for(int k = 0; k < CODE_SVC; k++){
-				if(pend_top - k >= 0){ uint4 e; e.x = p0[k]; e.y = p1[k]; e.z = p2[k]; e.w = p3[k]; slot(pend_top - k) = e; }
+			for(int u = 0; u < 2; u++){
+				if(pend_gtop - u >= 0){
+#pragma unroll
+					for(int k = 0; k < 4; k++){
+						uint4 e;
+						e.x = comp(pt[u][0], k); e.y = comp(pt[u][1], k); e.z = comp(pt[u][2], k);
+						e.w = comp(pb[u], k) | (((ptq[u] >> (8 * k)) & 3u) << 26) | (pend_base << 28);
+						slot(4 * (pend_gtop - u) + k) = e;
+					}
+				}
 			}
-			have_lo = max(pend_top - (CODE_SVC - 1), 0);
+			have_lo = 4 * max(pend_gtop - 1, 0);
 			pend = false;
 		}
 	};
@@ -163,8 +175,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 		rs.tb = rs.te; rs.te++;
 		cury = (uint32_t)max(min(rs.qb - lastbeg, bw - 1), 0) / W;
 		// prologue: two windows, filed immediately
-		request(rs.tb, base_for(cury)); file();
-		{ const int lo = have_lo; if(lo > 0){ request(lo - 1, base_for(cury)); file(); } }
+		request(rs.tb >> 2, base_for(cury)); file();
+		{ const int lo = have_lo; if(lo > 0){ request((lo - 1) >> 2, base_for(cury)); file(); } }
 		qc_ch = rs.qb >> 4; qc0 = chunk(qc_ch); qc1 = chunk(qc_ch - 1); qc2 = chunk(qc_ch - 2);
 	}
 	int prior_match = 0, dlen = 0;                // dlen != 0: inside a deletion run
@@ -182,7 +194,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 			file();
 			if(qp_ch != -1000){ qc0 = qp0; qc1 = qp1; qc2 = qp2; qc_ch = qp_ch; qp_ch = -1000; }
 			if(!done){
-				if(have_lo > 0 && rs.tb - have_lo + 1 < 3 * CODE_SVC) request(have_lo - 1, base_for(cury));   // ring holds 32 rows: at most 23 live + 8 new
+				if(have_lo > 0 && rs.tb - have_lo + 1 < 3 * CODE_SVC) request((have_lo - 1) >> 2, base_for(cury));   // ring holds 32 rows: at most 23 live + 8 new
 				if(rs.qb >= 0 && (rs.qb >> 4) != qc_ch){ qp_ch = rs.qb >> 4; qp0 = chunk(qp_ch); qp1 = chunk(qp_ch - 1); qp2 = chunk(qp_ch - 2); }
 			}
 		}
@@ -253,7 +265,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 		cury = y;
 		uint32_t wc;
 		if(y >= wbase && y <= wbase + 2u){ const uint32_t off = y - wbase; wc = off == 0u ? e.x : off == 1u ? e.y : e.z; }
-		else wc = ((const uint32_t*)(rows + (size_t)rs.tb * RB))[y];           // drifted two blocks inside one ring: plain load
+		else wc = ((const uint32_t*)rows)[bsa_code_off((uint32_t)rs.tb, y, 1u)];           // drifted two blocks inside one ring: plain load
 		const uint32_t pm = wc & FULL, pd = (wc >> W) & FULL, pr = (wc >> (2 * W)) & FULL, po = (wc >> (3 * W)) & FULL;
 		if(dlen){
 			// deletion run (bsalign.h:3730-3744), counted row by row: this row ends it if its stored e is a fresh opening
@@ -286,7 +298,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 					for(int yy = (int)y - 1; yy >= 0 && sz == 0; yy--){
 						uint32_t wl;
 						if(yy >= (int)wbase && yy <= (int)wbase + 2) wl = ((uint32_t)yy == wbase) ? e.x : ((uint32_t)yy == wbase + 1u) ? e.y : e.z;
-						else wl = ((const uint32_t*)(rows + (size_t)rs.tb * RB))[yy];
+						else wl = ((const uint32_t*)rows)[bsa_code_off((uint32_t)rs.tb, (uint32_t)yy, 1u)];
 						const uint32_t r2 = (wl >> (2 * W)) & FULL;
 						if(r2) sz = left + 1 + (int)__builtin_ctz(r2);
 						else left += W;
@@ -342,7 +354,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 	const uint8_t *tseq = a.tst + a.tpoff[pair];
 	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
 	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
-	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)tlen + BSA_CODE_SPARE_ROWS) * RB);
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * RB);
 	const int bw = W * 16;
 	uint32_t ncig = 0;
 	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
@@ -370,7 +382,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 		return c;
 	};
 	auto load_code = [&](int r, uint32_t y) -> Code {
-		const uint32_t *rp = (const uint32_t*)(rows + (size_t)r * RB) + y * CW;
+		const uint32_t *rp = (const uint32_t*)rows + bsa_code_off((uint32_t)r, y, CW);
 		return unpack(rp[0], (CW > 1) ? rp[CW - 1] : 0u);
 	};
 	bool bad = false;

@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 #pragma unroll
 			for(int hf = 0; hf < 2; hf++){
 				if(act[hf]){
-					uint32_t *rp = (uint32_t*)(rowp[hf] + (size_t)i * (64u * CW)) + (uint32_t)j * CW;
+					uint32_t *rp = (uint32_t*)rowp[hf] + bsa_code_off(i, (uint32_t)j, CW);
 					rp[0] = hf ? dB0 : dA0; if constexpr (CW > 1) rp[1] = hf ? dB1 : dA1;
 					if((i & 15u) == (uint32_t)j) begq[hf] = (int)rbeg[hf];
 					const bool lastrow = i + 1u == tlen[hf];
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(256, (W <= 8 && PW <= 1) ? 4 : 2) k_align8_fwd
 							else if((uint32_t)j == pos / W) begs[hf][tlen[hf] + 1u] = sc;
 						} else {
 							// end record: the candidates and the last row itself (row_max is taken by the traceback kernel)
-							bsa_code_end_t *er = (bsa_code_end_t*)(rowp[hf] + (size_t)tlen[hf] * (64u * CW));
+							bsa_code_end_t *er = (bsa_code_end_t*)(rowp[hf] + (size_t)bsa_code_rows(tlen[hf]) * (64u * CW));
 							er->cand_sc[j] = cand_sc[hf]; er->cand_te[j] = cand_te[hf];
 							er->ubegs[j] = ubA[hf];
 							if(j == 15){ er->ubegs[16] = ubB[hf]; er->rbeg_last = (int)rbeg[hf]; }

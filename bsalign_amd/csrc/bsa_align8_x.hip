@@ -122,6 +122,8 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	constexpr int NQ = (W + 3) / 4;
 	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
 	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
+	constexpr int CWD = (WR >= 8) ? WR / 8 : 1;           // code dwords per reference block and row
+	constexpr int ND = (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : 2;      // code dwords per lane and row
 	const int lt = threadIdx.x;
 	const int jl = lt & (L - 1);
 	const bool first = jl == 0, last = jl == L - 1;
@@ -199,6 +201,9 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	}
 
 	uint32_t rbeg = 0, mov = 0, i = 0;
+	uint32_t hist[3][ND];         // code dwords of the earlier rows of the current group of four
+#pragma unroll
+	for(int r = 0; r < 3; r++){ for(int q = 0; q < ND; q++) hist[r][q] = 0u; }
 	int begq = 0;
 	if(tlen != 0u && first) begs[0] = 0;
 	uint64_t twin = 0;
@@ -387,28 +392,22 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 				}
 			}
 		} else accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u;
-		if(act){
+		// The code dwords of this row: ND per lane.  Rows are stored in groups of four (bsa_common.h): the lane keeps the
+		// dwords of the group's rows in registers and stores whole 16-byte pieces when the group (or the pair) ends.
+		{
+			uint32_t cur[ND];
 			if constexpr (WR == 8){
 				// one dword per reference block: M | D << 8 | R << 16 | Od << 24, cell k at bit 7 - k
-				uint32_t dlo[NACC], dhi[NACC];
 #pragma unroll
 				for(int n = 0; n < NACC; n++){
 					const uint32_t t1 = __builtin_amdgcn_perm(accD[n], accM[n], 0x07030501u);   // {M.lo, D.lo, M.hi, D.hi}
 					const uint32_t t2 = __builtin_amdgcn_perm(accO[n], accR[n], 0x07030501u);
-					dlo[n] = __builtin_amdgcn_perm(t2, t1, 0x05040100u) ^ 0x00FFFFFFu;
-					dhi[n] = __builtin_amdgcn_perm(t2, t1, 0x07060302u) ^ 0x00FFFFFFu;
-				}
-				uint32_t *rp = (uint32_t*)(rowp + (size_t)i * 64u);
-				if constexpr (NACC == 1){ rp[jl] = dlo[0]; rp[jl + L] = dhi[0]; }
-				else {
-					uint2 lo, hi;
-					lo.x = dlo[0]; lo.y = dlo[NACC - 1]; hi.x = dhi[0]; hi.y = dhi[NACC - 1];
-					*(uint2*)(rp + 2 * jl) = lo; *(uint2*)(rp + 2 * (jl + L)) = hi;
+					cur[n] = __builtin_amdgcn_perm(t2, t1, 0x05040100u) ^ 0x00FFFFFFu;            // block NACC jl + n
+					cur[NACC + n] = __builtin_amdgcn_perm(t2, t1, 0x07060302u) ^ 0x00FFFFFFu;     // block NACC (jl + L) + n
 				}
 			} else if constexpr (WR == 4){
 				const uint32_t pk = ((accM[0] >> 8) | (accD[0] >> 4) | accR[0] | (accO[0] << 4)) ^ 0x0FFF0FFFu;
-				uint32_t *rp = (uint32_t*)(rowp + (size_t)i * 64u);
-				rp[jl] = pk & 0xFFFFu; rp[jl + L] = pk >> 16;
+				cur[0] = pk & 0xFFFFu; cur[1] = pk >> 16;
 			} else {
 				static_assert(WR == 16 || WR == 8 || WR == 4, "code row layouts");
 				// 16 cells per block: dword 0 = M | D << 16, dword 1 = R | Od << 16, cell k at bit 15 - k
@@ -416,12 +415,39 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 				const uint32_t xd = __builtin_amdgcn_perm(accD[0], accD[NACC - 1], 0x07030501u) ^ 0xFFFFFFFFu;
 				const uint32_t xr = __builtin_amdgcn_perm(accR[0], accR[NACC - 1], 0x07030501u) ^ 0xFFFFFFFFu;
 				const uint32_t xo = __builtin_amdgcn_perm(accO[0], accO[NACC - 1], 0x07030501u);
-				uint32_t *rp = (uint32_t*)(rowp + (size_t)i * 128u);
-				uint2 lo, hi;
-				lo.x = __builtin_amdgcn_perm(xd, xm, 0x05040100u); lo.y = __builtin_amdgcn_perm(xo, xr, 0x05040100u);
-				hi.x = __builtin_amdgcn_perm(xd, xm, 0x07060302u); hi.y = __builtin_amdgcn_perm(xo, xr, 0x07060302u);
-				*(uint2*)(rp + 2 * jl) = lo; *(uint2*)(rp + 2 * (jl + L)) = hi;
+				cur[0] = __builtin_amdgcn_perm(xd, xm, 0x05040100u); cur[1] = __builtin_amdgcn_perm(xo, xr, 0x05040100u);     // block jl
+				cur[2] = __builtin_amdgcn_perm(xd, xm, 0x07060302u); cur[3] = __builtin_amdgcn_perm(xo, xr, 0x07060302u);     // block jl + L
 			}
+			const uint32_t ri = i & 3u;                       // (uniform over the wave: all pairs are at row i)
+			if(ri == 0u){ for(int q = 0; q < ND; q++) hist[0][q] = cur[q]; }
+			else if(ri == 1u){ for(int q = 0; q < ND; q++) hist[1][q] = cur[q]; }
+			else if(ri == 2u){ for(int q = 0; q < ND; q++) hist[2][q] = cur[q]; }
+			if(act && (ri == 3u || i + 1u == tlen)){
+				uint32_t *gp = (uint32_t*)rowp + bsa_code_off(i & ~3u, 0u, CWD);       // block y of this group: gp[4 CWD y], rows then dwords
+				if constexpr (CWD == 1){
+#pragma unroll
+					for(int q = 0; q < ND; q++){
+						const uint32_t blk = (WR == 8) ? (uint32_t)(NACC * (jl + L * (q / NACC)) + q % NACC) : (uint32_t)(jl + L * q);
+						uint4 t; t.x = hist[0][q]; t.y = hist[1][q]; t.z = hist[2][q]; t.w = cur[q];
+						if(ri == 0u) t.x = cur[q]; else if(ri == 1u) t.y = cur[q]; else if(ri == 2u) t.z = cur[q];
+						*(uint4*)(gp + 4u * blk) = t;
+					}
+				} else {
+#pragma unroll
+					for(int hf = 0; hf < 2; hf++){
+						const uint32_t blk = (uint32_t)(jl + L * hf);
+						uint4 t0, t1;              // rows 0, 1 and rows 2, 3 of the block, two dwords each
+						t0.x = hist[0][2 * hf]; t0.y = hist[0][2 * hf + 1]; t0.z = hist[1][2 * hf]; t0.w = hist[1][2 * hf + 1];
+						t1.x = hist[2][2 * hf]; t1.y = hist[2][2 * hf + 1]; t1.z = cur[2 * hf]; t1.w = cur[2 * hf + 1];
+						if(ri == 0u){ t0.x = cur[2 * hf]; t0.y = cur[2 * hf + 1]; }
+						else if(ri == 1u){ t0.z = cur[2 * hf]; t0.w = cur[2 * hf + 1]; }
+						else if(ri == 2u){ t1.x = cur[2 * hf]; t1.y = cur[2 * hf + 1]; }
+						*(uint4*)(gp + 8u * blk) = t0; *(uint4*)(gp + 8u * blk + 4u) = t1;
+					}
+				}
+			}
+		}
+		if(act){
 			// band offsets: lane (i mod L) keeps the offset of row i, the group stores them together
 			constexpr uint32_t LM = (uint32_t)(L - 1);
 			if((i & LM) == (uint32_t)jl) begq = (int)rbeg;

@@ -61,17 +61,25 @@ static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t 
 //   int32 begs[tlen + 2]  (begs[tlen + 1] = final score, global mode)  |  code rows 0 .. tlen-1  |  BSA_CODE_SPARE_ROWS
 //   spare rows: CIGAR scratch of the traceback and, in overlap / extend mode, the end record the forward pass leaves
 //   at the start of the spare area (bsa_code_end_t followed by the last row's u bytes in natural band order)
-// Code row = 16 lanes x CW dwords (CW = max(1, W / 8)); lane y owns running block y.  The 4W bits of a lane are four
-// planes of W bits, plane n at bit n*W: M, D, R (insert opens here for the next cell), Od (stored e is a fresh
-// opening); inside a plane cell k of the block is bit W-1-k.
+// Code row = 16 blocks x CW dwords (CW = max(1, W / 8)), running block y of the row = dwords y*CW ...  The 4W bits of a
+// block are four planes of W bits, plane n at bit n*W: M, D, R (insert opens here for the next cell), Od (stored e is
+// a fresh opening); inside a plane cell k of the block is bit W-1-k.
+// TILING: the traceback walks up the rows while its position inside the band drifts slowly (the band follows the
+// diagonal), so it wants a few blocks of many rows, not whole rows.  Rows are stored in groups of four; inside a
+// group the four rows of ONE block are adjacent (16 CW bytes), blocks follow each other:
+//   dword offset of (row r, block y, dword d) = ((r / 4) * 64 + y * 4 + (r % 4)) * CW + d          (bsa_code_off)
+// Three neighbouring blocks of four rows are then 48 contiguous bytes (one or two 64-byte lines instead of four), and
+// the row count of a slot is rounded up to a multiple of four (bsa_code_rows).
 static inline __host__ __device__ uint32_t bsa_code_words(uint32_t W){ return W >= 8u ? W / 8u : 1u; }
 static inline __host__ __device__ uint32_t bsa_code_row_bytes(uint32_t W){ return 64u * bsa_code_words(W); }
 #define BSA_CODE_SPARE_ROWS 7u
+static inline __host__ __device__ size_t bsa_code_off(uint32_t r, uint32_t y, uint32_t CW){ return ((size_t)(r >> 2) * 64u + y * 4u + (r & 3u)) * CW; }
+static inline __host__ __device__ uint32_t bsa_code_rows(uint32_t tlen){ return (tlen + 3u) & ~3u; }       // stored rows: whole groups of four
 // end record of the non-global modes: per lane the best end-of-query score seen while the band touched the query end
 // and its row (bsalign.h:4023-4032), and the last row itself for row_max (bsalign.h:4038-4046)
 struct bsa_code_end_t { int32_t cand_sc[16], cand_te[16], ubegs[17], rbeg_last; };
 static inline __host__ __device__ size_t bsa_code_slot_bytes(uint32_t tlen, uint32_t W){
-	return bsa_begs_bytes(tlen) + ((size_t)tlen + BSA_CODE_SPARE_ROWS) * bsa_code_row_bytes(W);
+	return bsa_begs_bytes(tlen) + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * bsa_code_row_bytes(W);
 }
 
 static inline __host__ __device__ int bsa_get_piecewise(int gapo1, int gape1, int gapo2, int gape2, int bandwidth){ // bsalign.h:2084-2092
