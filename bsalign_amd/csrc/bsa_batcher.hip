@@ -1,0 +1,227 @@
+// bsa_batcher.hip -- many POA windows, one device sweep per read index.
+//
+// A single POA (end_bspoa, bspoa.h:4722-4776) aligns its reads one after the other: read r needs the graph that reads
+// 0..r-1 built, so one window gives the device ONE sweep program at a time (3 us per row update against 0.28 us on a
+// CPU core).  Windows are independent of each other, though, and a caller that has many of them
+// (the reference's `bsalign poa` over a file of windows, a polisher over a genome) can advance all of them in lock-step.
+// The batcher is the rendezvous for that: every window runs the reference's own host code on a host thread of its own
+// (node selection, band placement, traceback into the graph stay the reference's C); where that code would call
+// align_rd_bspoacore (bspoa.h:2515-2618) it calls bsa_sweep_batcher_submit() -- same arguments as the single-window
+// backend of include/bsalign_poa_adapter.h -- and blocks.  When every participating window is waiting, the last
+// arrival packs all programs into one task / query table, runs ONE bsa_sweep_run per distinct parameter set (band
+// width differs between the first read of a window and the later ones), copies results and row blocks back and wakes
+// everybody.  No window ever waits for a window that has finished: bsa_sweep_batcher_leave() takes a participant out.
+#include "bsa_common.h"
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *c, hipStream_t *st);
+
+namespace {
+struct Sub {
+	const bsa_row_task_t *tasks; size_t ntasks;
+	const uint8_t *query; uint32_t slen;
+	bsa_sweep_params_t par;
+	uint8_t *rows_out; size_t nblocks;
+	bsa_sweep_result_t *res;
+	int *rc;
+	const uint8_t **rows_src;      // where the submitter finds its row blocks (pinned staging) after the batch ran
+	size_t *rows_bytes;
+};
+struct Pinned {
+	void *p = nullptr; size_t cap = 0;
+	~Pinned(){ if(p) (void)hipHostFree(p); }
+	bool need(size_t n){
+		if(n <= cap) return true;
+		if(p) (void)hipHostFree(p);
+		p = nullptr; cap = 0;
+		const size_t want = n + n / 4 + 4096;
+		if(hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess){ p = nullptr; (void)hipGetLastError(); return false; }
+		cap = want; return true;
+	}
+};
+struct Dev {
+	void *p = nullptr; size_t cap = 0;
+	~Dev(){ if(p) (void)hipFree(p); }
+	bool need(size_t n){
+		if(n <= cap) return true;
+		if(p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		const size_t want = n + n / 4 + 4096;
+		if(hipMalloc(&p, want) != hipSuccess){ p = nullptr; (void)hipGetLastError(); return false; }
+		cap = want; return true;
+	}
+};
+}
+
+struct bsa_sweep_batcher {
+	bsa_ctx_t *ctx = nullptr;
+	std::mutex m;
+	std::condition_variable cv;
+	uint32_t active = 0;
+	uint64_t gen = 0;                   // batches completed
+	std::vector<Sub> pend;
+	Pinned h_in, h_rows;                // upload staging (tasks | progs | qoff | qlen | queries), download staging (results | rows)
+	Dev d_in, d_rows, d_res;
+	// statistics
+	uint64_t batches = 0, launches = 0, programs = 0, tasks = 0, bytes_up = 0, bytes_down = 0;
+	double device_ms = 0, wall_ms = 0;
+};
+
+static size_t align16(size_t x){ return (x + 15) & ~(size_t)15; }
+
+// run everything in b->pend (caller holds the lock; every other participant is blocked)
+static void run_batch(bsa_sweep_batcher *b){
+	const auto w0 = std::chrono::steady_clock::now();
+	std::vector<Sub> &P = b->pend;
+	const size_t n = P.size();
+	// groups of equal parameters, in order of first appearance
+	std::vector<int> grp(n, -1);
+	std::vector<size_t> first;
+	for(size_t k = 0; k < n; k++){
+		for(size_t g = 0; g < first.size(); g++) if(memcmp(&P[first[g]].par, &P[k].par, sizeof(bsa_sweep_params_t)) == 0){ grp[k] = (int)g; break; }
+		if(grp[k] < 0){ grp[k] = (int)first.size(); first.push_back(k); }
+	}
+	hipStream_t st = nullptr;
+	int rc0 = bsa_ctx_get_stream_internal(b->ctx, &st);
+	// the download staging holds every program's row blocks until its submitter has copied them out
+	size_t rows_total = 0;
+	std::vector<size_t> rows_off(n, 0);
+	for(size_t k = 0; k < n; k++){
+		const bsa_rows_params_t *rp = &P[k].par.rows;
+		const size_t blk = bsa_rows_block_bytes(rp->bandwidth, rp->gapo1, rp->gape1, rp->gapo2, rp->gape2);
+		rows_off[k] = rows_total;
+		if(P[k].rows_out) rows_total += align16(P[k].nblocks * blk);
+	}
+	if(rc0 == BSA_OK && !b->h_rows.need(rows_total + 64)) rc0 = BSA_E_NOMEM;
+	for(size_t g = 0; g < first.size(); g++){
+		int rc = rc0;
+		std::vector<size_t> mem;
+		for(size_t k = 0; k < n; k++) if(grp[k] == (int)g) mem.push_back(k);
+		const size_t np = mem.size();
+		const bsa_sweep_params_t par = P[first[g]].par;
+		const bsa_rows_params_t *rp = &par.rows;
+		const size_t blk = bsa_rows_block_bytes(rp->bandwidth, rp->gapo1, rp->gape1, rp->gapo2, rp->gape2);
+		size_t ntasks = 0, qbytes = 0, nblocks = 0;
+		for(size_t i = 0; i < np; i++){ const Sub &s = P[mem[i]]; ntasks += s.ntasks; qbytes += align16((size_t)s.slen + 64); nblocks += s.nblocks; }
+		// upload staging: tasks | progs | qoff | qlen | queries
+		const size_t o_tasks = 0, o_progs = align16(o_tasks + ntasks * sizeof(bsa_row_task_t)), o_qoff = align16(o_progs + np * sizeof(bsa_sweep_prog_t)),
+			o_qlen = align16(o_qoff + np * 8), o_q = align16(o_qlen + np * 4), in_bytes = o_q + qbytes + 64;
+		if(rc == BSA_OK && (!b->h_in.need(in_bytes) || !b->d_in.need(in_bytes) || !b->d_rows.need(nblocks * blk + 64) || !b->d_res.need(np * sizeof(bsa_sweep_result_t)))) rc = BSA_E_NOMEM;
+		std::vector<size_t> blk0(np, 0);
+		if(rc == BSA_OK){
+			uint8_t *h = (uint8_t*)b->h_in.p;
+			bsa_row_task_t *ht = (bsa_row_task_t*)(h + o_tasks);
+			bsa_sweep_prog_t *hp = (bsa_sweep_prog_t*)(h + o_progs);
+			uint64_t *hqo = (uint64_t*)(h + o_qoff);
+			uint32_t *hql = (uint32_t*)(h + o_qlen);
+			uint8_t *hq = h + o_q;
+			size_t t0 = 0, q0 = 0, b0 = 0;
+			for(size_t i = 0; i < np && rc == BSA_OK; i++){
+				const Sub &s = P[mem[i]];
+				if(s.ntasks == 0 || s.nblocks == 0 || t0 + s.ntasks > 0xFFFFFFF0ull || b0 + s.nblocks > 0xFFFFFFF0ull){ rc = BSA_E_ARG; break; }
+				memcpy(ht + t0, s.tasks, s.ntasks * sizeof(bsa_row_task_t));
+				for(size_t t = t0; t < t0 + s.ntasks; t++){
+					if(ht[t].src >= s.nblocks || ht[t].dst >= s.nblocks){ rc = BSA_E_ARG; break; }
+					ht[t].query = (uint32_t)i;
+				}
+				hp[i].first_task = (uint32_t)t0; hp[i].ntasks = (uint32_t)s.ntasks; hp[i].first_block = (uint32_t)b0; hp[i].reserved = 0;
+				hqo[i] = q0; hql[i] = s.slen;
+				memcpy(hq + q0, s.query, s.slen);
+				blk0[i] = b0;
+				t0 += s.ntasks; q0 += align16((size_t)s.slen + 64); b0 += s.nblocks;
+			}
+		}
+#define BCHK(x) do { if(rc == BSA_OK && (x) != hipSuccess){ rc = BSA_E_HIP; (void)hipGetLastError(); } } while(0)
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
+		BCHK(hipMemcpyAsync(b->d_in.p, b->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
+		BCHK(hipMemsetAsync(b->d_rows.p, 0, nblocks * blk, st));
+		BCHK(hipEventRecord(e0, st));
+		if(rc == BSA_OK){
+			const uint8_t *d = (const uint8_t*)b->d_in.p;
+			rc = bsa_sweep_run(b->ctx, (uint8_t*)b->d_rows.p, (const bsa_row_task_t*)(d + o_tasks), (const bsa_sweep_prog_t*)(d + o_progs), np,
+				d + o_q, (const uint64_t*)(d + o_qoff), (const uint32_t*)(d + o_qlen), &par, (bsa_sweep_result_t*)b->d_res.p);
+		}
+		BCHK(hipEventRecord(e1, st));
+		std::vector<bsa_sweep_result_t> hres(np);
+		BCHK(hipMemcpyAsync(hres.data(), b->d_res.p, np * sizeof(bsa_sweep_result_t), hipMemcpyDeviceToHost, st));
+		size_t down = 0;
+		for(size_t i = 0; i < np; i++){
+			const Sub &s = P[mem[i]];
+			if(!s.rows_out) continue;
+			BCHK(hipMemcpyAsync((uint8_t*)b->h_rows.p + rows_off[mem[i]], (const uint8_t*)b->d_rows.p + blk0[i] * blk, s.nblocks * blk, hipMemcpyDeviceToHost, st));
+			down += s.nblocks * blk;
+		}
+		BCHK(hipStreamSynchronize(st));
+		if(rc == BSA_OK){ float ms = 0; if(hipEventElapsedTime(&ms, e0, e1) == hipSuccess) b->device_ms += ms; }
+		if(e0) (void)hipEventDestroy(e0);
+		if(e1) (void)hipEventDestroy(e1);
+#undef BCHK
+		for(size_t i = 0; i < np; i++){
+			const Sub &s = P[mem[i]];
+			*s.rc = rc;
+			if(rc == BSA_OK){
+				*s.res = hres[i];
+				*s.rows_src = s.rows_out ? (const uint8_t*)b->h_rows.p + rows_off[mem[i]] : nullptr;
+				*s.rows_bytes = s.rows_out ? s.nblocks * blk : 0;
+			}
+		}
+		b->launches++; b->programs += np; b->tasks += ntasks; b->bytes_up += in_bytes; b->bytes_down += down + np * sizeof(bsa_sweep_result_t);
+	}
+	b->batches++;
+	b->wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+	P.clear();
+	b->gen++;
+}
+
+extern "C" int bsa_sweep_batcher_create(bsa_ctx_t *ctx, uint32_t participants, bsa_sweep_batcher_t **out){
+	if(!ctx || !out || participants == 0) return BSA_E_ARG;
+	bsa_sweep_batcher *b = new (std::nothrow) bsa_sweep_batcher();
+	if(!b) return BSA_E_NOMEM;
+	b->ctx = ctx; b->active = participants;
+	*out = b;
+	return BSA_OK;
+}
+
+extern "C" void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b){ delete b; }
+
+extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
+		const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *res){
+	bsa_sweep_batcher *b = (bsa_sweep_batcher*)vb;
+	if(!b || !tasks || !query || !par || !res) return BSA_E_ARG;
+	int rc = BSA_E_HIP;
+	const uint8_t *src = nullptr; size_t nbytes = 0;
+	{
+		std::unique_lock<std::mutex> lk(b->m);
+		if(b->active == 0) return BSA_E_ARG;
+		const uint64_t my = b->gen;
+		Sub s{tasks, ntasks, query, slen, *par, rows_out, nblocks, res, &rc, &src, &nbytes};
+		b->pend.push_back(s);
+		if(b->pend.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
+		else b->cv.wait(lk, [&]{ return b->gen > my; });
+	}
+	// the row blocks are copied out here, by every window's own thread (the staging is not reused before all of them
+	// have come back with their next program)
+	if(rc == BSA_OK && rows_out && src) memcpy(rows_out, src, nbytes);
+	return rc;
+}
+
+extern "C" void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *b){
+	if(!b) return;
+	std::unique_lock<std::mutex> lk(b->m);
+	if(b->active) b->active--;
+	if(!b->pend.empty() && b->pend.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
+}
+
+// out[0..7] = batches, launches, programs, tasks, bytes uploaded, bytes downloaded, device microseconds, wall microseconds inside the batches
+extern "C" void bsa_sweep_batcher_stats(bsa_sweep_batcher_t *b, uint64_t out[8]){
+	if(!b || !out) return;
+	std::unique_lock<std::mutex> lk(b->m);
+	out[0] = b->batches; out[1] = b->launches; out[2] = b->programs; out[3] = b->tasks; out[4] = b->bytes_up; out[5] = b->bytes_down;
+	out[6] = (uint64_t)(b->device_ms * 1000.0); out[7] = (uint64_t)(b->wall_ms * 1000.0);
+}

@@ -246,6 +246,22 @@ typedef struct {
 int bsa_sweep_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task_t *d_tasks, const bsa_sweep_prog_t *d_progs,
                   size_t nprogs, const uint8_t *d_queries, const uint64_t *d_qoff, const uint32_t *d_qlen,
                   const bsa_sweep_params_t *par, bsa_sweep_result_t *d_results);
+/* ---- many windows in lock-step (bsalign_amd/csrc/bsa_batcher.hip) ----------------------------
+ * One POA (end_bspoa, bspoa.h:4722-4776) is sequential in its reads, but windows are independent: a caller with many
+ * of them runs each on a host thread of its own and lets every thread's sweep go through a batcher.  submit() has the
+ * signature of the single-window backend of include/bsalign_poa_adapter.h (pass the batcher as `user`), is thread-safe
+ * and BLOCKS until every participant that has not left is waiting in it; the last arrival executes all programs as one
+ * device launch per distinct parameter set, then everybody returns with its results and row blocks.  A window that
+ * has aligned its last read calls leave().  participants = number of windows (threads) that will submit. */
+typedef struct bsa_sweep_batcher bsa_sweep_batcher_t;
+int  bsa_sweep_batcher_create(bsa_ctx_t *ctx, uint32_t participants, bsa_sweep_batcher_t **out);
+void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b);
+int  bsa_sweep_batcher_submit(void *batcher, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
+                              const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *res);
+void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *b);
+/* out[0..7] = batches, device launches, programs, tasks, bytes uploaded, bytes downloaded, device microseconds, microseconds inside batches */
+void bsa_sweep_batcher_stats(bsa_sweep_batcher_t *b, uint64_t out[8]);
+
 /* HOST buffers in, HOST buffers out (uploads, runs, downloads, synchronises): what a single-window caller such as
  * the adapter uses.  rows_out (nblocks * bsa_rows_block_bytes, may be NULL) receives every row block so that host
  * traceback code (alignment2graph_bspoa, bspoa.h:2274) can read them as if the CPU had computed them. */

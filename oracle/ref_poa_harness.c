@@ -14,6 +14,10 @@
  *           state and its row blocks / best end cell are compared with what the backend returned.
  *   mode 3  as mode 2 with the DEVICE as backend: bsa_poa_backend_hip -> bsa_sweep_host of libbsalign_hip.so, whose
  *           address the GPU test hands in (ref_poa_set_device) -- the real end_bspoa with its sweep on the MI355X.
+ *   mode 4  MANY windows in lock-step (ref_poa_run_many): every window runs the mode-1 orchestration on a host thread of
+ *           its own, its sweeps go to the product's batcher (bsa_sweep_batcher_submit, attached with
+ *           ref_poa_set_batcher), which runs read r of all windows as one device launch.  No re-run of the reference's
+ *           core here: the test compares every window's consensus / MSA with a mode-0 run of the same reads.
  *
  * Recorded per read: the seqalign_result_t of align_rd_bspoa, the program (tasks), the best end cell and a hash of
  * the reference's row blocks -- tests/golden/make_golden_poa.py turns these into the committed fixtures.
@@ -72,6 +76,15 @@ __attribute__((visibility("hidden"))) int bsa_sweep_host(bsa_ctx_t *ctx, const b
 		const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *results){
 	if(g_sweep_host) return g_sweep_host(ctx, tasks, ntasks, progs, nprogs, queries, qoff, qlen, nqueries, par, rows_out, nblocks, results);
 	return BSA_E_UNSUPPORTED;       /* no device library attached */
+}
+
+/* the product's batcher (bsalign_hip.h: bsa_sweep_batcher_submit / _leave), attached by the GPU test */
+typedef void (*batch_leave_fn)(void *batcher);
+static bsa_poa_backend_fn g_batch_submit = NULL;
+static batch_leave_fn g_batch_leave = NULL;
+static void *g_batcher = NULL;
+void ref_poa_set_batcher(void *submit_addr, void *leave_addr, void *batcher){
+	g_batch_submit = (bsa_poa_backend_fn)submit_addr; g_batch_leave = (batch_leave_fn)leave_addr; g_batcher = batcher;
 }
 
 typedef void (*orc_sweep_fn)(uint8_t *rows, const void *tasks, const void *progs, size_t nprogs,
@@ -189,7 +202,9 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
 	sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
 	prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
-	if(p->mode >= 2){
+	if(p->mode == 4){
+		score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
+	} else if(p->mode >= 2){
 		int a_scr, a_idx, a_off;
 		const size_t used = (size_t)g->bandwidth * (g->piecewise + 1) + (WORDSIZE + 1) * sizeof(int);
 		b1i *mine;
@@ -296,6 +311,7 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 	p->sweep = (orc_sweep_fn)sweep_fn;
 	bsa_poa_adapter_free(&p->ad);
 	if(mode == 3) bsa_poa_adapter_init(&p->ad, bsa_poa_backend_hip, g_device_ctx);
+	else if(mode == 4) bsa_poa_adapter_init(&p->ad, g_batch_submit, g_batcher);
 	else bsa_poa_adapter_init(&p->ad, backend_oracle, p);
 	for(k = 0; k < nreads; k++) if(lens[k] > maxlen) maxlen = lens[k];
 	buf = (char*)malloc(maxlen + 1);
@@ -309,6 +325,58 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 	if(mode == 0) end_bspoa(g);
 	else poa_finish(p);
 	for(i = 0; i < p->nrec; i++) if(p->recs[i].mismatch) bad ++;
+	return bad;
+}
+
+/* ---- many windows in lock-step (mode 4) ---- */
+#include <pthread.h>
+typedef struct {
+	void *handle;
+	const uint8_t *reads; const uint64_t *offs; const uint32_t *lens;
+	int nreads, mode, rc;
+} many_job_t;
+
+static void *many_thread(void *vp){
+	many_job_t *j = (many_job_t*)vp;
+	j->rc = ref_poa_run(j->handle, j->reads, j->offs, j->lens, j->nreads, j->mode, NULL, 0);
+	if(j->mode == 4 && g_batch_leave) g_batch_leave(g_batcher);       /* this window submits nothing more */
+	return NULL;
+}
+
+typedef struct { many_job_t *jobs; int nwin, t, nt; } pool_arg_t;
+static void *pool_thread(void *vp){
+	pool_arg_t *a = (pool_arg_t*)vp; int k;
+	for(k = a->t; k < a->nwin; k += a->nt) many_thread(&a->jobs[k]);
+	return NULL;
+}
+
+/* window w aligns reads first[w] .. first[w] + count[w] - 1 (indices into offs / lens); handles[w] from ref_poa_create.
+ * mode 4: device batcher (one thread per window, all alive at once); mode 0 / 1: the same windows on `threads` host
+ * threads with the reference's own core, for the CPU side of the comparison.  Returns 0 or the number of windows that failed. */
+int ref_poa_run_many(void **handles, int nwin, const uint8_t *reads, const uint64_t *offs, const uint32_t *lens,
+		const int *first, const int *count, int mode, int threads){
+	many_job_t *jobs = (many_job_t*)calloc((size_t)nwin, sizeof(many_job_t));
+	pthread_t *th = (pthread_t*)calloc((size_t)nwin, sizeof(pthread_t));
+	int w, bad = 0;
+	if(mode == 4 && (!g_batch_submit || !g_batcher)){ free(jobs); free(th); return -1; }
+	cal_permutation_bspoa(MAX_LOG_CACHE, 0);                             /* fill the reference's lazily built log table before any thread reads it (bspoa.h:3391-3401) */
+	for(w = 0; w < nwin; w++){
+		jobs[w].handle = handles[w]; jobs[w].reads = reads; jobs[w].offs = offs + first[w]; jobs[w].lens = lens + first[w];
+		jobs[w].nreads = count[w]; jobs[w].mode = mode;
+	}
+	if(mode == 4 || threads >= nwin){
+		for(w = 0; w < nwin; w++) pthread_create(&th[w], NULL, many_thread, &jobs[w]);
+		for(w = 0; w < nwin; w++) pthread_join(th[w], NULL);
+	} else {
+		/* a bounded pool: thread t takes windows t, t + threads, ... */
+		int t, nt = threads > 0 ? threads : 1;
+		pool_arg_t *pa = (pool_arg_t*)calloc((size_t)nt, sizeof(pool_arg_t));
+		for(t = 0; t < nt; t++){ pa[t].jobs = jobs; pa[t].nwin = nwin; pa[t].t = t; pa[t].nt = nt; pthread_create(&th[t], NULL, pool_thread, &pa[t]); }
+		for(t = 0; t < nt; t++) pthread_join(th[t], NULL);
+		free(pa);
+	}
+	for(w = 0; w < nwin; w++) if(jobs[w].rc) bad ++;
+	free(jobs); free(th);
 	return bad;
 }
 

@@ -92,6 +92,39 @@ def run_ref_poa(reads, mode, p, record=True):
     return dict(core_seconds=secs.value, core_updates=nu.value, core_merges=nm.value, bad=bad, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, tasks=tasks, queries=queries)
 
 
+def run_many(windows, mode, p, threads=8, batcher=None):
+    """many POA windows through the harness (ref_poa_run_many): mode 0 / 1 on `threads` host threads with the reference's
+    own sweep, mode 4 in lock-step through the product's batcher (attach it first, see tests/test_poa_batched_gpu.py).
+    windows = list of read lists.  -> (per-window dicts with cns / qlt / alt / msa, wall seconds)"""
+    import time
+    r = ref_poa()
+    r.ref_poa_run_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    nwin = len(windows)
+    hs = (C.c_void_p * nwin)(*[r.ref_poa_create(*[int(p[k]) for k in PAR_ORDER]) for _ in range(nwin)])
+    allreads = [x for w in windows for x in w]
+    lens = np.array([len(x) for x in allreads], dtype=np.uint32)
+    offs = np.zeros(len(allreads), dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)[:-1]
+    blob = np.concatenate(allreads).astype(np.uint8)
+    count = np.array([len(w) for w in windows], dtype=np.int32)
+    first = np.zeros(nwin, dtype=np.int32)
+    first[1:] = np.cumsum(count)[:-1]
+    t0 = time.time()
+    bad = r.ref_poa_run_many(hs, nwin, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, first.ctypes.data, count.ctypes.data, mode, threads)
+    secs = time.time() - t0
+    assert bad == 0, "ref_poa_run_many: %d windows failed" % bad
+    out = []
+    for h in hs:
+        n = r.ref_poa_cns_len(h)
+        cns, qlt, alt = (np.zeros(n, np.uint8) for _ in range(3))
+        r.ref_poa_cns(h, cns.ctypes.data, qlt.ctypes.data, alt.ctypes.data)
+        nc, nr = C.c_uint32(), C.c_uint32()
+        mh = r.ref_poa_msa_hash(h, C.byref(nc), C.byref(nr))
+        out.append(dict(cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value)))
+        r.ref_poa_destroy(h)
+    return out, secs
+
+
 def block_bytes(bw, pw):
     return (bw * (pw + 1) + 68 + 15) & ~15
 
