@@ -170,7 +170,7 @@ static void record_read(ref_poa_t *p, seqalign_result_t rs, int mismatch, uint64
 	r->bandwidth = g->bandwidth; r->slen = g->slen; r->qb = g->qb; r->nblocks = (uint32_t)g->mmcnt; r->piecewise = (uint32_t)g->piecewise;
 	r->rows_hash = rows_hash; r->mismatch = mismatch;
 	r->task_off = p->ntasks; r->query_off = p->nq;
-	if(p->mode >= 2 && p->record_programs){
+	if(p->mode >= 1 && p->record_programs){      /* (mode 1: the program the adapter would submit, recorded beside the reference's own sweep) */
 		r->ntasks = (uint32_t)p->ad.ntasks;
 		if(p->ntasks + p->ad.ntasks > p->captasks){
 			p->captasks = (p->ntasks + p->ad.ntasks) * 2;
@@ -333,12 +333,12 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 typedef struct {
 	void *handle;
 	const uint8_t *reads; const uint64_t *offs; const uint32_t *lens;
-	int nreads, mode, rc;
+	int nreads, mode, record, rc;
 } many_job_t;
 
 static void *many_thread(void *vp){
 	many_job_t *j = (many_job_t*)vp;
-	j->rc = ref_poa_run(j->handle, j->reads, j->offs, j->lens, j->nreads, j->mode, NULL, 0);
+	j->rc = ref_poa_run(j->handle, j->reads, j->offs, j->lens, j->nreads, j->mode, NULL, j->record);
 	if(j->mode == 4 && g_batch_leave) g_batch_leave(g_batcher);       /* this window submits nothing more */
 	return NULL;
 }
@@ -354,7 +354,7 @@ static void *pool_thread(void *vp){
  * mode 4: device batcher (one thread per window, all alive at once); mode 0 / 1: the same windows on `threads` host
  * threads with the reference's own core, for the CPU side of the comparison.  Returns 0 or the number of windows that failed. */
 int ref_poa_run_many(void **handles, int nwin, const uint8_t *reads, const uint64_t *offs, const uint32_t *lens,
-		const int *first, const int *count, int mode, int threads){
+		const int *first, const int *count, int mode, int threads, int record){
 	many_job_t *jobs = (many_job_t*)calloc((size_t)nwin, sizeof(many_job_t));
 	pthread_t *th = (pthread_t*)calloc((size_t)nwin, sizeof(pthread_t));
 	int w, bad = 0;
@@ -362,7 +362,7 @@ int ref_poa_run_many(void **handles, int nwin, const uint8_t *reads, const uint6
 	cal_permutation_bspoa(MAX_LOG_CACHE, 0);                             /* fill the reference's lazily built log table before any thread reads it (bspoa.h:3391-3401) */
 	for(w = 0; w < nwin; w++){
 		jobs[w].handle = handles[w]; jobs[w].reads = reads; jobs[w].offs = offs + first[w]; jobs[w].lens = lens + first[w];
-		jobs[w].nreads = count[w]; jobs[w].mode = mode;
+		jobs[w].nreads = count[w]; jobs[w].mode = mode; jobs[w].record = record;
 	}
 	if(mode == 4 || threads >= nwin){
 		for(w = 0; w < nwin; w++) pthread_create(&th[w], NULL, many_thread, &jobs[w]);

@@ -92,13 +92,13 @@ def run_ref_poa(reads, mode, p, record=True):
     return dict(core_seconds=secs.value, core_updates=nu.value, core_merges=nm.value, bad=bad, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, tasks=tasks, queries=queries)
 
 
-def run_many(windows, mode, p, threads=8, batcher=None):
+def run_many(windows, mode, p, threads=8, record=False):
     """many POA windows through the harness (ref_poa_run_many): mode 0 / 1 on `threads` host threads with the reference's
     own sweep, mode 4 in lock-step through the product's batcher (attach it first, see tests/test_poa_batched_gpu.py).
     windows = list of read lists.  -> (per-window dicts with cns / qlt / alt / msa, wall seconds)"""
     import time
     r = ref_poa()
-    r.ref_poa_run_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    r.ref_poa_run_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     nwin = len(windows)
     hs = (C.c_void_p * nwin)(*[r.ref_poa_create(*[int(p[k]) for k in PAR_ORDER]) for _ in range(nwin)])
     allreads = [x for w in windows for x in w]
@@ -110,7 +110,7 @@ def run_many(windows, mode, p, threads=8, batcher=None):
     first = np.zeros(nwin, dtype=np.int32)
     first[1:] = np.cumsum(count)[:-1]
     t0 = time.time()
-    bad = r.ref_poa_run_many(hs, nwin, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, first.ctypes.data, count.ctypes.data, mode, threads)
+    bad = r.ref_poa_run_many(hs, nwin, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, first.ctypes.data, count.ctypes.data, mode, threads, int(record))
     secs = time.time() - t0
     assert bad == 0, "ref_poa_run_many: %d windows failed" % bad
     out = []
@@ -120,7 +120,24 @@ def run_many(windows, mode, p, threads=8, batcher=None):
         r.ref_poa_cns(h, cns.ctypes.data, qlt.ctypes.data, alt.ctypes.data)
         nc, nr = C.c_uint32(), C.c_uint32()
         mh = r.ref_poa_msa_hash(h, C.byref(nc), C.byref(nr))
-        out.append(dict(cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value)))
+        d = dict(cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value))
+        if record:
+            # the sweep programs of this window, one per aligned read (mode 1: recorded beside the reference's own sweep)
+            recs = []
+            for k in range(r.ref_poa_nrec(h)):
+                o = np.zeros(20, np.int32)
+                a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+                r.ref_poa_rec(h, k, o.ctypes.data, C.byref(a), C.byref(b), C.byref(c))
+                recs.append(dict(maxscr=int(o[10]), maxidx=int(o[11]), maxoff=int(o[12]), bandwidth=int(o[13]), slen=int(o[14]), nblocks=int(o[16]),
+                                 ntasks=int(o[17]), piecewise=int(o[18]), task_off=b.value, query_off=c.value))
+            tasks = np.zeros(int(r.ref_poa_ntasks(h)), dtype=TASK_DTYPE)
+            queries = np.zeros(int(r.ref_poa_nquery_bytes(h)), dtype=np.uint8)
+            if len(tasks):
+                r.ref_poa_programs(h, tasks.ctypes.data, queries.ctypes.data)
+            secs_c, nu, nm = C.c_double(), C.c_uint64(), C.c_uint64()
+            r.ref_poa_core_stats(h, C.byref(secs_c), C.byref(nu), C.byref(nm))
+            d.update(recs=recs, tasks=tasks, queries=queries, core_seconds=secs_c.value, core_updates=nu.value, core_merges=nm.value)
+        out.append(d)
         r.ref_poa_destroy(h)
     return out, secs
 

@@ -77,3 +77,24 @@ def test_end_bspoa_with_sweep_and_kmer_alignment_on_the_device(ctx):
     for k in ("cns", "qlt", "alt"):
         assert np.array_equal(r0[k], r3[k]), k
     assert r0["msa"] == r3["msa"]
+
+
+def test_c4_full_size(ctx, capsys):
+    """BASELINE config C4 at its stated size: 64 ONT-like reads x 20 kbp, default POA parameters (overlap mode, bandwidth
+    128, 2-piece gaps; the first read is aligned with the whole read as band, i.e. the run-time-W sweep at bw ~ 20000).
+    The real end_bspoa with every sweep on the MI355X gives the untouched run's consensus, qualities and MSA, and after
+    every read the device's row blocks / best end cell equal the reference's own sweep on the same graph."""
+    _attach(ctx)
+    p = P.par()
+    reads = P.synth_reads(20240611 & 0xFFFF, 20000, 64, eps=(0.1,))
+    t0 = time.time()
+    r0 = P.run_ref_poa(reads, 0, p, record=False)
+    t1 = time.time()
+    r3 = P.run_ref_poa(reads, 3, p, record=False)
+    t2 = time.time()
+    assert r3["bad"] == 0
+    for k in ("cns", "qlt", "alt"):
+        assert np.array_equal(r0[k], r3[k]), k
+    assert r0["msa"] == r3["msa"]
+    with capsys.disabled():
+        print("\n[C4 full size] end_bspoa 64 x 20 kbp: reference %.1f s, with the sweeps on the device (one window, plus the harness's re-check of every read) %.1f s" % (t1 - t0, t2 - t1))
