@@ -13,12 +13,9 @@ def partition_pairs(tlen, bw, world):
     w = tlen * float(bw)
     tot = float(w.sum())
     cum = np.concatenate([[0.0], np.cumsum(w)])
-    bounds = [0]
-    for r in range(1, world):
-        target = tot * r / world
-        k = int(np.searchsorted(cum, target, side="left"))
-        k = min(max(k, bounds[-1]), len(tlen))
-        bounds.append(k)
+    targets = tot * np.arange(1, world, dtype=np.float64) / world
+    ks = np.minimum(np.searchsorted(cum, targets, side="left"), len(tlen))
+    bounds = [0] + [int(k) for k in np.maximum.accumulate(ks)]
     bounds.append(len(tlen))
     return bounds
 
@@ -50,49 +47,64 @@ def _dev(device):
     return torch.device(device) if device is not None else torch.device("cpu")
 
 
+def _layout(qlen, tlen, a, b):
+    """offsets of pairs [a, b) inside their shard blob (target k, then query k, each padded to 16 bytes) and its size"""
+    tp = (tlen[a:b].astype(np.uint64) + np.uint64(15)) & ~np.uint64(15)
+    qp = (qlen[a:b].astype(np.uint64) + np.uint64(15)) & ~np.uint64(15)
+    both = tp + qp
+    to = np.zeros(b - a, np.uint64)
+    if b - a > 1:
+        to[1:] = np.cumsum(both)[:-1]
+    return to, to + tp, int(both.sum())
+
+
 def scatter_batch(batch, bw, src=0, device=None, group=None):
     """rank `src` passes batch = dict(seqs uint8 blob, qoff, qlen, toff, tlen as numpy); the others pass None.
     Every rank gets its contiguous shard back as a dict of the same keys (offsets re-based to the shard's own blob,
-    `seqs` a uint8 tensor on `device`) plus `first` (global index of its first pair) and `bounds`."""
+    `seqs` a uint8 tensor on `device`) plus `first` (global index of its first pair) and `bounds`.
+    Lengths travel as two tensor broadcasts, the shards as one grouped set of point-to-point messages; the source packs
+    each shard with the library's C helper (bsa_shard_pack), nothing is done per pair in Python."""
+    import ctypes as C
     import torch
     import torch.distributed as dist
+    from . import lib
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = _dev(device)
-    meta = [None]
+    nt = torch.zeros(1, dtype=torch.int64, device=dev)
     if rank == src:
-        qoff, qlen = np.asarray(batch["qoff"], np.uint64), np.asarray(batch["qlen"], np.uint32)
-        toff, tlen = np.asarray(batch["toff"], np.uint64), np.asarray(batch["tlen"], np.uint32)
-        bounds = partition_pairs(tlen, bw, world)
-        meta = [dict(bounds=bounds, qlen=qlen, tlen=tlen)]
-    dist.broadcast_object_list(meta, src=src, group=group)        # lengths only: a few bytes per pair
-    bounds, qlen, tlen = meta[0]["bounds"], meta[0]["qlen"], meta[0]["tlen"]
+        qoff, qlen = np.ascontiguousarray(batch["qoff"], np.uint64), np.ascontiguousarray(batch["qlen"], np.uint32)
+        toff, tlen = np.ascontiguousarray(batch["toff"], np.uint64), np.ascontiguousarray(batch["tlen"], np.uint32)
+        nt[0] = len(qlen)
+    dist.broadcast(nt, src=src, group=group)
+    n = int(nt.item())
+    lens = torch.zeros(2, max(n, 1), dtype=torch.int64, device=dev)          # lengths only: 16 bytes per pair
+    if rank == src and n:
+        lens[0, :n] = torch.from_numpy(qlen.astype(np.int64)).to(dev)
+        lens[1, :n] = torch.from_numpy(tlen.astype(np.int64)).to(dev)
+    dist.broadcast(lens, src=src, group=group)
+    if rank != src:
+        lh = lens.cpu().numpy()
+        qlen, tlen = lh[0, :n].astype(np.uint32), lh[1, :n].astype(np.uint32)
+    bounds = partition_pairs(tlen, bw, world)
     lo, hi = bounds[rank], bounds[rank + 1]
-    # shard layout: target k then query k, each padded to 16 bytes -- the same on every rank, so sizes are known up front
-    pad = lambda n: (int(n) + 15) & ~15
-
-    def layout(a, b):
-        to, qo, acc = [], [], 0
-        for k in range(a, b):
-            to.append(acc)
-            acc += pad(tlen[k])
-            qo.append(acc)
-            acc += pad(qlen[k])
-        return np.array(to, np.uint64), np.array(qo, np.uint64), acc
-    my_toff, my_qoff, my_bytes = layout(lo, hi)
+    my_toff, my_qoff, my_bytes = _layout(qlen, tlen, lo, hi)
     mine = torch.zeros(max(my_bytes, 1), dtype=torch.uint8, device=dev)
     ops, keep = [], []
     if rank == src:
-        seqs = np.asarray(batch["seqs"], np.uint8)
+        seqs = np.ascontiguousarray(batch["seqs"], np.uint8)
+        L = lib()
+        L.bsa_shard_pack.argtypes = [C.c_void_p] * 5 + [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint]
         for r in range(world):
             a, b = bounds[r], bounds[r + 1]
-            to, qo, nbytes = layout(a, b)
-            blob = np.zeros(max(nbytes, 1), np.uint8)
-            for i, k in enumerate(range(a, b)):
-                blob[int(to[i]):int(to[i]) + int(tlen[k])] = seqs[int(toff[k]):int(toff[k]) + int(tlen[k])]
-                blob[int(qo[i]):int(qo[i]) + int(qlen[k])] = seqs[int(qoff[k]):int(qoff[k]) + int(qlen[k])]
+            to, qo, nbytes = _layout(qlen, tlen, a, b)
+            blob = np.empty(max(nbytes, 1), np.uint8)
+            oq, ot = np.zeros(max(b - a, 1), np.uint64), np.zeros(max(b - a, 1), np.uint64)
+            rc = L.bsa_shard_pack(seqs.ctypes.data, qoff.ctypes.data, qlen.ctypes.data, toff.ctypes.data, tlen.ctypes.data, a, b - a,
+                                  blob.ctypes.data, nbytes, oq.ctypes.data, ot.ctypes.data, 0)
+            assert rc == 0 and (b == a or (np.array_equal(oq[:b - a], qo) and np.array_equal(ot[:b - a], to)))
             t = torch.from_numpy(blob).to(dev)
             if r == src:
-                mine.copy_(t)
+                mine.copy_(t[:mine.numel()])
             elif nbytes:
                 keep.append(t)
                 ops.append(dist.P2POp(dist.isend, t, r, group))

@@ -246,6 +246,14 @@ typedef struct {
 int bsa_sweep_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task_t *d_tasks, const bsa_sweep_prog_t *d_progs,
                   size_t nprogs, const uint8_t *d_queries, const uint64_t *d_qoff, const uint32_t *d_qlen,
                   const bsa_sweep_params_t *par, bsa_sweep_result_t *d_results);
+/* ---- batch scatter, host side (bsalign_amd/csrc/bsa_shard.cpp) ----------------
+ * The pairs of one rank's contiguous range packed into the blob that travels to it: target k, then query k, each
+ * padded to 16 bytes.  bsa_shard_pack fills out[0 .. bsa_shard_bytes) and every pair's offsets inside it (host memory,
+ * `threads` host threads, 0 = as many as the machine has, at most 16). */
+size_t bsa_shard_bytes(const uint32_t *qlen, const uint32_t *tlen, size_t first, size_t count);
+int    bsa_shard_pack(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
+                      size_t first, size_t count, uint8_t *out, size_t out_bytes, uint64_t *out_qoff, uint64_t *out_toff, unsigned threads);
+
 /* ---- many windows in lock-step (bsalign_amd/csrc/bsa_batcher.hip) ----------------------------
  * One POA (end_bspoa, bspoa.h:4722-4776) is sequential in its reads, but windows are independent: a caller with many
  * of them runs each on a host thread of its own and lets every thread's sweep go through a batcher.  submit() has the

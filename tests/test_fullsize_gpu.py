@@ -12,10 +12,9 @@ import support as S
 pytestmark = pytest.mark.gpu
 
 
-def test_c2_full_size_properties():
+def _align8_properties(n, L, bw, sample):
     import torch
     import bsalign_amd as B
-    n, L, bw = 100000, 10000, 128
     sc = (2, -6, -3, -2, 0, 0)
     dev = torch.device("cuda", 0)
     ctx = B.Context(0)
@@ -66,12 +65,23 @@ def test_c2_full_size_properties():
     same[(starts[1:] - 1)] = False
     assert not same.any()
     # a sample spread over the batch (first, last and the tail round of the launch) against the oracle
-    for k in (0, 1, 4999, 33333, 65535, 65536, 98303, 98304, 99998, 99999):
+    for k in sample:
         q, t = S.synth_pair(k, L)
         res, cg, _ = S.oracle_align(q, t, S.MODE_GLOBAL, bw, *sc)
         assert np.array_equal(out[k], res) and np.array_equal(cig[int(off[k]):int(off[k + 1])], cg), k
     plan.close()
     ctx.close()
+
+
+def test_c2_full_size_properties():
+    """configuration C2: 100 000 x 10 kbp, global, bandwidth 128"""
+    _align8_properties(100000, 10000, 128, (0, 1, 4999, 33333, 65535, 65536, 98303, 98304, 99998, 99999))
+
+
+def test_c5_per_gpu_shape_properties():
+    """configuration C5 is 10 M pairs x 15 kbp over 8 GPUs; what one GPU sees of it is a batch of 15 kbp pairs larger than
+    its workspace, run in chunks: 200 000 x 15 kbp here (the 8-GPU run itself needs the hardware)"""
+    _align8_properties(200000, 15000, 128, (0, 1, 65535, 65536, 100000, 131071, 131072, 199998, 199999))
 
 
 def test_c3_full_size_properties():

@@ -119,3 +119,54 @@ def test_scatter_and_gather_exchange_two_ranks():
         qq, tt = S.synth_pair(k, int(L))
         r, cig, _ = S.oracle_align(qq, tt, 0, 64, 2, -6, -3, -2, 0, 0)
         assert np.array_equal(res[k], r) and np.array_equal(words[int(off[k]):int(off[k + 1])], cig), k
+
+
+def _worker_big(rank, world, port, q):
+    """100 k pairs through scatter_batch over gloo: the scatter must not do per-pair work in Python (C2's pair count)"""
+    import time
+    import torch.distributed as dist
+    sys.path.insert(0, S.ROOT)
+    from bsalign_amd import shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    n, batch = 100000, None
+    rng = np.random.default_rng(23)
+    tlen = rng.integers(40, 90, size=n).astype(np.uint32)
+    qlen = rng.integers(40, 90, size=n).astype(np.uint32)
+    toff = np.zeros(n, np.uint64); qoff = np.zeros(n, np.uint64)
+    both = tlen.astype(np.uint64) + qlen.astype(np.uint64)
+    toff[1:] = np.cumsum(both)[:-1]
+    qoff[:] = toff + tlen
+    if rank == 0:
+        seqs = rng.integers(0, 4, size=int(both.sum())).astype(np.uint8)
+        batch = dict(seqs=seqs, qoff=qoff, qlen=qlen, toff=toff, tlen=tlen)
+    t0 = time.time()
+    sh = shard.scatter_batch(batch, 128, src=0)
+    secs = time.time() - t0
+    lo = sh["first"]
+    # spot check: a few pairs of this rank's shard are the right bytes (every rank can regenerate the blob)
+    seqs = rng.integers(0, 4, size=int(both.sum())).astype(np.uint8) if rank else batch["seqs"]
+    mine = sh["seqs"].numpy()
+    ok = True
+    for k in (0, 1, len(sh["qlen"]) // 2, len(sh["qlen"]) - 1):
+        g = lo + k
+        ok &= bool(np.array_equal(mine[int(sh["toff"][k]):int(sh["toff"][k]) + int(tlen[g])], seqs[int(toff[g]):int(toff[g]) + int(tlen[g])]))
+        ok &= bool(np.array_equal(mine[int(sh["qoff"][k]):int(sh["qoff"][k]) + int(qlen[g])], seqs[int(qoff[g]):int(qoff[g]) + int(qlen[g])]))
+    q.put((rank, secs, ok, sh["bounds"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_of_100k_pairs_is_vectorised():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_big, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, secs, ok, bounds in got:
+        assert ok and secs < 5.0, (rank, secs)
+        assert bounds[0] == 0 and bounds[-1] == 100000 and 40000 < bounds[1] < 60000
