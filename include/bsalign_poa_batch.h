@@ -1,0 +1,70 @@
+/*
+ * bsalign_poa_batch.h -- many POA windows at once, reference side.
+ *
+ * For a tree that has the reference's bspoa.h with patches/bspoa_device_sweep.diff applied (the patch adds one field,
+ * BSPOA.devsweep, and makes align_rd_bspoa call include/bsalign_poa_adapter.h's bsa_poa_align_rd_core() when it is set).
+ * Include it after bspoa.h; link libbsalign_hip.so and pthread.
+ *
+ *   beg_bspoa(g); push_bspoa(g, seq, len); ...        for every window, as before (bspoa.h:1775, 961)
+ *   bsa_poa_end_many(gs, n, ctx);                      instead of n calls of end_bspoa (bspoa.h:4722)
+ *   gs[k]->cns / qlt / alt / msacols                   as before
+ *
+ * One POA is sequential in its reads, windows are independent: every window runs the reference's
+ * own end_bspoa on a host thread of its own, and wherever that would sweep the graph (align_rd_bspoacore,
+ * bspoa.h:2515-2618) the program goes to the batcher of libbsalign_hip (bsa_sweep_batcher_submit), which runs read r of
+ * ALL windows as one device launch.  bsa_poa_end_one() is the single-window form (bsa_sweep_host behind it).
+ */
+#ifndef BSALIGN_POA_BATCH_H
+#define BSALIGN_POA_BATCH_H
+
+#include <pthread.h>
+#include "bsalign_hip.h"
+#include "bsalign_poa_adapter.h"
+
+typedef struct {
+	BSPOA *g;
+	bsa_sweep_batcher_t *batcher;
+} bsa_poa_many_job_t;
+
+static void *bsa_poa_many_thread(void *vp){
+	bsa_poa_many_job_t *j = (bsa_poa_many_job_t*)vp;
+	bsa_poa_adapter_t ad;
+	bsa_poa_adapter_init(&ad, bsa_sweep_batcher_submit, j->batcher);
+	j->g->devsweep = &ad;
+	end_bspoa(j->g);
+	j->g->devsweep = NULL;
+	bsa_sweep_batcher_leave(j->batcher);                 /* this window submits nothing more */
+	bsa_poa_adapter_free(&ad);
+	return NULL;
+}
+
+/* end_bspoa for n windows in lock-step on the device.  Returns 0 or a BSA_E_* code (nothing was run then). */
+static inline int bsa_poa_end_many(BSPOA **gs, int n, bsa_ctx_t *ctx){
+	bsa_sweep_batcher_t *b = NULL;
+	bsa_poa_many_job_t *jobs;
+	pthread_t *th;
+	int k, rc;
+	if(n <= 0) return BSA_OK;
+	rc = bsa_sweep_batcher_create(ctx, (uint32_t)n, &b);
+	if(rc != BSA_OK) return rc;
+	jobs = (bsa_poa_many_job_t*)calloc((size_t)n, sizeof(bsa_poa_many_job_t));
+	th = (pthread_t*)calloc((size_t)n, sizeof(pthread_t));
+	cal_permutation_bspoa(MAX_LOG_CACHE, 0);             /* the reference fills this table lazily (bspoa.h:3391-3401): do it before any thread reads it */
+	for(k=0;k<n;k++){ jobs[k].g = gs[k]; jobs[k].batcher = b; pthread_create(&th[k], NULL, bsa_poa_many_thread, &jobs[k]); }
+	for(k=0;k<n;k++) pthread_join(th[k], NULL);
+	free(jobs); free(th);
+	bsa_sweep_batcher_destroy(b);
+	return BSA_OK;
+}
+
+/* end_bspoa of one window with its sweeps on the device */
+static inline void bsa_poa_end_one(BSPOA *g, bsa_ctx_t *ctx){
+	bsa_poa_adapter_t ad;
+	bsa_poa_adapter_init(&ad, bsa_poa_backend_hip, ctx);
+	g->devsweep = &ad;
+	end_bspoa(g);
+	g->devsweep = NULL;
+	bsa_poa_adapter_free(&ad);
+}
+
+#endif

@@ -1,0 +1,81 @@
+"""GPU: the drop-in POA surface.  oracle/_ref/libbsref_patched.so is the reference's own bspoa.h with
+patches/bspoa_device_sweep.diff applied (built by oracle/Makefile from a temporary patched copy) plus
+include/bsalign_poa_batch.h -- what a maintainer who applies the patch ships.  beg_bspoa / push_bspoa as always, then
+  * end_bspoa untouched (devsweep == NULL),
+  * bsa_poa_end_one: the same end_bspoa with every sweep on the MI355X,
+  * bsa_poa_end_many: all windows in lock-step through the batcher,
+must give the same consensus, qualities, alternative bases and MSA."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import poa_support as P
+import support as S
+
+PATCHED = os.path.join(S.ROOT, "oracle", "_ref", "libbsref_patched.so")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref/libbsref_patched.so not built")]
+
+
+def _lib(ctx):
+    import bsalign_amd as B
+    L = C.CDLL(PATCHED)
+    L.refp_create.restype = C.c_void_p
+    L.refp_create.argtypes = [C.c_int] * 16
+    L.refp_destroy.argtypes = [C.c_void_p]
+    L.refp_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.refp_end.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.refp_cns_len.argtypes = [C.c_void_p]
+    L.refp_cns_len.restype = C.c_uint32
+    L.refp_cns.argtypes = [C.c_void_p] * 4
+    L.refp_msa_hash.argtypes = [C.c_void_p] * 3
+    L.refp_msa_hash.restype = C.c_uint64
+    L.refp_attach.argtypes = [C.c_void_p] * 6
+    b = B.lib()
+    L.refp_attach(ctx.h, C.cast(b.bsa_sweep_host, C.c_void_p), C.cast(b.bsa_sweep_batcher_create, C.c_void_p), C.cast(b.bsa_sweep_batcher_destroy, C.c_void_p),
+                  C.cast(b.bsa_sweep_batcher_submit, C.c_void_p), C.cast(b.bsa_sweep_batcher_leave, C.c_void_p))
+    return L
+
+
+def _run(L, windows, p, how):
+    hs = []
+    for reads in windows:
+        h = L.refp_create(*[int(p[k]) for k in P.PAR_ORDER])
+        lens = np.array([len(x) for x in reads], dtype=np.uint32)
+        offs = np.zeros(len(reads), dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)[:-1]
+        blob = np.concatenate(reads).astype(np.uint8)
+        L.refp_push(h, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads))
+        hs.append(h)
+    arr = (C.c_void_p * len(hs))(*hs)
+    assert L.refp_end(arr, len(hs), how) == 0
+    out = []
+    for h in hs:
+        n = L.refp_cns_len(h)
+        cns, qlt, alt = (np.zeros(n, np.uint8) for _ in range(3))
+        L.refp_cns(h, cns.ctypes.data, qlt.ctypes.data, alt.ctypes.data)
+        nc, nr = C.c_uint32(), C.c_uint32()
+        mh = L.refp_msa_hash(h, C.byref(nc), C.byref(nr))
+        out.append((cns, qlt, alt, (mh, nc.value, nr.value)))
+        L.refp_destroy(h)
+    return out
+
+
+def _same(a, b):
+    for w, (x, y) in enumerate(zip(a, b)):
+        assert all(np.array_equal(x[k], y[k]) for k in range(3)) and x[3] == y[3], w
+
+
+def test_patched_end_bspoa_one_window_and_many(ctx):
+    L = _lib(ctx)
+    p = P.par()
+    rng = np.random.default_rng(3)
+    windows = [P.synth_reads(300 + w, int(rng.integers(300, 1200)), int(rng.integers(4, 12)), eps=(0.1,)) for w in range(24)]
+    ref = _run(L, windows, p, 0)
+    _same(ref, _run(L, windows[:3], p, 1))
+    _same(ref, _run(L, windows, p, 2))
+    # and the untouched path of the patched header is the unpatched reference
+    plain, _ = P.run_many(windows, 0, p, threads=4)
+    for (cns, qlt, alt, msa), d in zip(ref, plain):
+        assert np.array_equal(cns, d["cns"]) and np.array_equal(qlt, d["qlt"]) and np.array_equal(alt, d["alt"])
