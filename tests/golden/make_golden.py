@@ -68,6 +68,12 @@ def gen_align(rng):
         # the oracle flags inputs on which the reference does not terminate; those cannot be goldens
         o = S.oracle_align(q, t, mode, bw, *sc)
         if o[2] == S.ORC_ERR_TRACE:
+            # kept in the fixture as dropped_* so that the filter can be audited (tests/test_oracle.py checks that the
+            # oracle still flags every one of them; the reference itself cannot be asked: it would not return)
+            nd = sum(1 for k in out if k.startswith("dropped_q_"))
+            out["dropped_q_%d" % nd] = q
+            out["dropped_t_%d" % nd] = t
+            out["dropped_meta_%d" % nd] = np.array([mode, bw] + list(sc), dtype=np.int32)
             continue
         res, cig, n = S.ref_align(q, t, mode, bw, *sc)
         out["q_%d" % kept] = q
@@ -77,6 +83,7 @@ def gen_align(rng):
         out["cig_%d" % kept] = cig
         kept += 1
     out["n"] = np.array([kept])
+    out["ndropped"] = np.array([sum(1 for k in out if k.startswith("dropped_q_"))])
     return out
 
 

@@ -152,3 +152,15 @@ def test_edit_oracle_vs_reference_random():
         rr = S.ref_edit(Q, T, mode, bw)
         o = S.oracle_edit(Q, T, mode, bw)
         assert np.array_equal(rr[0], o[0]) and np.array_equal(rr[1], o[1]), (it, L, len(Q), bw, mode)
+
+
+def test_golden_filter_is_auditable():
+    """tests/golden/make_golden.py skips candidate inputs on which the oracle says the reference's traceback does not
+    terminate (the reference cannot be asked).  The fixture keeps every skipped input: none was skipped for the committed
+    case list, and any that a future list skips must still be flagged by the oracle."""
+    g = np.load(os.path.join(S.ROOT, "tests", "golden", "align8.npz"))
+    nd = int(g["ndropped"][0])
+    assert nd == 0 or nd < int(g["n"][0]) // 20
+    for k in range(nd):
+        mode, bw, M, X, O, E, Q, P = (int(x) for x in g["dropped_meta_%d" % k])
+        assert S.oracle_align(g["dropped_q_%d" % k], g["dropped_t_%d" % k], mode, bw, M, X, O, E, Q, P)[2] == S.ORC_ERR_TRACE
