@@ -115,7 +115,7 @@ static __device__ __forceinline__ void x_load_qcodes(const uint8_t *p, uint32_t 
 // W cells per lane and half, L lanes per pair: 2 L blocks of W cells; the reference's 16 running blocks have WR = 2 L W / 16
 // cells, so a block here holds CR = 8 / L of them
 template<int W, int L>
-__global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
+static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint32_t first_pos, const uint32_t count, const uint32_t block){
 	constexpr int BW = 2 * L * W;
 	constexpr int WR = BW / 16, CR = 8 / L;
 	static_assert((L == 8 || L == 4) && W * L / 8 == WR && (CR == 1 || (CR == 2 && W == 16)), "supported shapes");
@@ -127,9 +127,9 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	const int lt = threadIdx.x;
 	const int jl = lt & (L - 1);
 	const bool first = jl == 0, last = jl == L - 1;
-	const uint32_t g = (blockIdx.x * 256u + lt) / (uint32_t)L;
-	const bool live = g < a.count;
-	const uint32_t ppos = a.first + (live ? g : 0u);
+	const uint32_t g = (block * 256u + lt) / (uint32_t)L;
+	const bool live = g < count;
+	const uint32_t ppos = first_pos + (live ? g : 0u);
 	const uint32_t pair = a.order[ppos];
 	const uint32_t qlen = a.qlen[pair];
 	uint32_t tlen = a.tlen[pair];
@@ -527,6 +527,20 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	}
 }
 
+template<int W, int L>
+__global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
+	x_forward<W, L>(a, a.first, a.count, blockIdx.x);
+}
+
+// Bandwidth 128, a batch that is not a whole number of four-lane rounds: the first nb8 blocks take the last n8 pairs
+// eight lanes per pair, the others the first a.count - n8 pairs four lanes per pair.  One launch: the short blocks start
+// first and the dispatcher hands the long ones to whichever CU has room, so pairs of one length no longer finish in
+// lock-step rounds with a nearly empty last one.
+__global__ void __launch_bounds__(256) k_align8_fwd_x_mix(const Align8Args a, const uint32_t nb8, const uint32_t n8){
+	if(blockIdx.x < nb8) x_forward<8, 8>(a, a.first + (a.count - n8), n8, blockIdx.x);
+	else x_forward<16, 4>(a, a.first, a.count - n8, blockIdx.x - nb8);
+}
+
 // Exact arithmetic is the reference's arithmetic only while nothing saturates: the guard of the compact path
 // (bsa_align8_codes_supported) plus room for the frame shift by 2 |gape| and for the int16 block offsets.
 bool bsa_align8_x_supported(const Align8Args &a, int pw){
@@ -564,13 +578,12 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 			if(a.count - n4 > round4 / 2u) n4 = a.count;
 			if(le && le[0] == '8') n4 = 0;
 			if(le && le[0] == '4') n4 = a.count;
-			if(n4){
-				Align8Args b = a; b.count = n4;
-				hipLaunchKernelGGL((k_align8_fwd_x<16, 4>), dim3((n4 + 63u) / 64u), dim3(256), 0, st, b);
-			}
-			if(a.count > n4){
-				Align8Args b = a; b.first = a.first + n4; b.count = a.count - n4;
-				hipLaunchKernelGGL((k_align8_fwd_x<8, 8>), dim3((b.count + 31u) / 32u), dim3(256), 0, st, b);
+			if(const char *ne = getenv("BSA_ALIGN8_X_N8")){ const long v = atol(ne); if(v >= 0 && (uint32_t)v <= a.count) n4 = a.count - (uint32_t)v; }      // tuning: pairs that go eight lanes per pair
+			if(n4 == a.count) hipLaunchKernelGGL((k_align8_fwd_x<16, 4>), dim3((n4 + 63u) / 64u), dim3(256), 0, st, a);
+			else if(n4 == 0) hipLaunchKernelGGL((k_align8_fwd_x<8, 8>), dim3(b8), dim3(256), 0, st, a);
+			else {
+				const uint32_t n8 = a.count - n4, nb8 = (n8 + 31u) / 32u;
+				hipLaunchKernelGGL(k_align8_fwd_x_mix, dim3(nb8 + (n4 + 63u) / 64u), dim3(256), 0, st, a, nb8, n8);
 			}
 			break;
 		}
