@@ -481,6 +481,144 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 	cig_cnt[ppos] = ncig;
 }
 
+// two-piece gaps (8 bits per cell, bsa_common.h; bandwidth 128): the plain walker with the nine facts of a cell
+__global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
+	constexpr int W = 8;
+	constexpr uint32_t CW = 2u, RB = 64u * CW;
+	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	if(g >= a.count) return;
+	const uint32_t ppos = a.first + g;
+	const uint32_t pair = a.order[ppos];
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	if(a.status[pair] != 0u){ out[pair] = rs; cig_cnt[ppos] = 0; return; }
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint8_t *qseq = a.qst + a.qpoff[pair];
+	const uint8_t *tseq = a.tst + a.tpoff[pair];
+	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
+	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * RB);
+	const int bw = W * 16;
+	uint32_t ncig = 0;
+	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
+	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
+		if(op == (cg & 0xf)) return cg + (sz << 4);
+		if(cg) cig_push(cg);
+		return (sz << 4) | op;
+	};
+	uint64_t qwin = 0, twin = 0; int qwb = -1000, twb = -1000;     // 8 bases of each sequence in a register window
+	auto qbase_at = [&](int idx) -> int {
+		if(idx < qwb || idx >= qwb + 8){ qwb = max(idx - 7, 0); __builtin_memcpy(&qwin, qseq + qwb, 8); }
+		return (int)((qwin >> (8 * (idx - qwb))) & 0xffu);
+	};
+	auto tbase_at = [&](int idx) -> int {
+		if(idx < twb || idx >= twb + 8){ twb = max(idx - 7, 0); __builtin_memcpy(&twin, tseq + twb, 8); }
+		return (int)((twin >> (8 * (idx - twb))) & 0xffu);
+	};
+	auto load_code = [&](int r, uint32_t y) -> uint2 { return *(const uint2*)((const uint32_t*)rows + bsa_code_off((uint32_t)r, y, CW)); };
+	bool bad = false;
+	rs.score = begs[tlen + 1];
+	if(rs.score == (int)0x80000000u) bad = true;               // band never reached the query end (bsalign.h:4034)
+	rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	if(rs.qe < begs[rs.te + 1] || rs.qe >= begs[rs.te + 1] + bw) bad = true;
+	rs.qb = rs.qe; rs.qe++;
+	rs.tb = rs.te; rs.te++;
+	int prior_match = 0;
+	uint32_t cg = 0;
+	int beg_c = begs[rs.tb + 1], beg_p = begs[rs.tb], beg_pp = (rs.tb >= 1) ? begs[rs.tb - 1] : 0;
+	auto row_up = [&](){ rs.tb--; beg_c = beg_p; beg_p = beg_pp; beg_pp = (rs.tb >= 1) ? begs[rs.tb - 1] : 0; };
+	while(!bad){
+		if(rs.qb < 0 || rs.tb < 0) break;
+		if(rs.qb == beg_p && rs.qb) prior_match = 0;                // bsalign.h:3761-3764
+		const int p = rs.qb - beg_c;
+		if(p < 0 || p >= bw){ bad = true; break; }
+		const uint32_t y = (uint32_t)p / W, k = (uint32_t)p % W, bit = 1u << (W - 1 - k);
+		const uint2 c = load_code(rs.tb, y);
+		const bool fA = (c.x & bit) != 0u, fD = ((c.x >> 8) & bit) != 0u, fD2 = ((c.x >> 16) & bit) != 0u, fB = ((c.x >> 24) & bit) != 0u;
+		const bool fM = (fD || fD2) ? fA : (fA && !fB);
+		const int d = fD ? 1 : fD2 ? 2 : 0;                          // backcal_cell, bsalign.h:3679-3701
+		int bt;                                                       // 0 M, 1 I, 2 D
+		if(prior_match) bt = fM ? 0 : d ? 2 : 1;
+		else bt = d ? 2 : fM ? 0 : 1;
+		prior_match = 1;
+		if(bt == 0){
+			const int qbase = qbase_at(rs.qb), tbase = tbase_at(rs.tb);
+			if(qbase == tbase) rs.mat++; else rs.mis++;
+			rs.qb--; rs.aln++;
+			row_up();
+			cg = cig_add(cg, 0, 1);
+		} else if(bt == 1){
+			if(rs.qb <= 0){
+				cg = cig_add(cg, 1, 1);
+				rs.qb--; rs.ins++; rs.aln++;
+			} else {
+				// the chains that equal h here (only reached with M = D = D2 = 0): the nearest cell to the left at which one of
+				// them was opened (bsalign.h:3798-3814: the smallest length whose cost -- the larger of the two pieces' -- closes the gap)
+				const bool ch1 = fB, ch2 = fA == fB;
+				auto rplane = [&](const uint2 &cc) -> uint32_t { return ((ch1 ? cc.y : 0u) | (ch2 ? (cc.y >> 8) : 0u)) & 0xFFu; };
+				int sz = 0;
+				uint2 hc = c; uint32_t hb = 0;                            // block and bit of the cell the scan stops at
+				const uint32_t cand = rplane(c) & ~((bit << 1) - 1u);
+				if(cand){ hb = cand & (0u - cand); sz = (int)(__builtin_ctz(cand) - (W - 1 - k)); }
+				else {
+					int left = (int)k;
+					for(int yy = (int)y - 1; yy >= 0 && sz == 0; yy--){
+						hc = load_code(rs.tb, (uint32_t)yy);
+						const uint32_t r2 = rplane(hc);
+						if(r2){ hb = r2 & (0u - r2); sz = left + 1 + (int)__builtin_ctz(r2); }
+						else left += W;
+					}
+					if(sz == 0){ bad = true; break; }                     // the reference's scan finds no length either
+				}
+				{
+					// the reference tests H(x - sz) + max(cost1, cost2) == H(x): the chain that is tight here must also have the
+					// larger cost at this length (always true between real DP cells; next to cells that entered the band with
+					// synthetic values it can fail, and the reference's scan then finds no length: literal path)
+					const int c1 = a.gapo1 + sz * a.gape1, c2 = a.gapo2 + sz * a.gape2;
+					const bool h1 = ch1 && (hc.y & hb) != 0u, h2 = ch2 && ((hc.y >> 8) & hb) != 0u;
+					if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))){ bad = true; break; }
+				}
+				cg = cig_add(cg, 1, (uint32_t)sz);
+				rs.qb -= sz; rs.ins += sz; rs.aln += sz;
+			}
+		} else {
+			// deletion run of piece d: up the column until a row whose Od bit of that piece is set (bsalign.h:3730-3760)
+			const uint32_t osh = (d == 2) ? 24u : 16u;
+			int len = 1;
+			for(;;){
+				const int r = rs.tb - len;
+				if(r == -1){ bad = true; break; }                        // row -1: the reference compares real scores there -- literal path
+				const int pr = rs.qb - begs[r + 1];
+				if(pr < 0 || pr >= bw){ bad = true; break; }
+				const uint2 c2 = load_code(r, (uint32_t)pr / W);
+				if((c2.y >> osh) & (1u << (W - 1 - (uint32_t)pr % W))) break;
+				len++;
+			}
+			if(bad) break;
+			cg = cig_add(cg, 2, (uint32_t)len);
+			rs.del += len; rs.aln += len;
+			rs.tb -= len;
+			beg_c = begs[rs.tb + 1]; beg_p = (rs.tb >= 0) ? begs[rs.tb] : 0; beg_pp = (rs.tb >= 1) ? begs[rs.tb - 1] : 0;
+		}
+	}
+	if(!bad){
+		uint32_t op = 0, sz = 0;          // global: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
+		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+		rs.aln += (int)sz;
+		cg = cig_add(cg, op, sz);
+		if(cg) cig_push(cg);
+		rs.qb++; rs.tb++;
+	}
+	if(bad){
+		atomicOr(&a.status[pair], BSA_ST_TRACE);
+		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+		ncig = 0;
+	}
+	out[pair] = rs;
+	cig_cnt[ppos] = ncig;
+}
+
 template<int W>
 static void launch_trace_lds(const Align8Args &a, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	// Pairs per wave: 32 where the batch is large enough (100 k pairs on MI355X, ms per launch: 64 -> 46, 32 -> 31.0,
@@ -504,8 +642,12 @@ static void launch_trace_lds(const Align8Args &a, bsa_result_t *out, uint32_t *c
 }
 
 hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
-	(void)pw;
 	if(a.count == 0) return hipSuccess;
+	if(pw == 2){
+		if(a.bw != 128u) return hipErrorInvalidValue;
+		hipLaunchKernelGGL(k_align8_trace_codes2, dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt);
+		return hipGetLastError();
+	}
 	// BSA_ALIGN8_TRACE_SIMPLE=1: the plain kernel (kept as the reference point)
 	static const bool simple = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
 	const uint32_t blocks = (a.count + 63u) / 64u;

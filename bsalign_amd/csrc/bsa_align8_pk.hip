@@ -669,6 +669,7 @@ static hipError_t launch_fwd_codes(const Align8Args &a, hipStream_t st){
 // scores the reference's own traceback stops terminating on divergent inputs and the two paths can disagree on which
 // pairs get flagged).
 bool bsa_align8_codes_supported(const Align8Args &a, int pw){
+	if(pw == 2) return bsa_align8_x_supported(a, 2);        // two-piece gaps: 8 bits per cell, exact-arithmetic forward kernel only
 	if(!bsa_align8_pk_supported(a, pw) || pw > 1) return false;
 	const int g = -((int)(int8_t)(a.gapo1 + a.gape1)), m = a.smax, n = -a.smin;
 	if(m < 0 || n < 0 || g < 0) return false;

@@ -114,7 +114,10 @@ static __device__ __forceinline__ void x_load_qcodes(const uint8_t *p, uint32_t 
 
 // W cells per lane and half, L lanes per pair: 2 L blocks of W cells; the reference's 16 running blocks have WR = 2 L W / 16
 // cells, so a block here holds CR = 8 / L of them
-template<int W, int L>
+// PW = 2: two-piece gaps.  The frame is shifted by the extension of piece 1, so piece 2 keeps a real step dP = gape2 - gape1 > 0:
+//   qq = U - NQ      m = max(ee, qq, S~)      g = max(g, max(m, f) + gapo2) + dP - U      NQ' = min(h - qq, -gapo2) - dP
+// and a cell has nine facts (bsa_common.h "COMPACT slot", 8 bits): M, D, D2, which chain equals h (I1, I2), R1, R2, Od1, Od2.
+template<int W, int L, int PW = 1>
 static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint32_t first_pos, const uint32_t count, const uint32_t block){
 	constexpr int BW = 2 * L * W;
 	constexpr int WR = BW / 16, CR = 8 / L;
@@ -122,8 +125,9 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	constexpr int NQ = (W + 3) / 4;
 	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
 	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
-	constexpr int CWD = (WR >= 8) ? WR / 8 : 1;           // code dwords per reference block and row
-	constexpr int ND = (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : 2;      // code dwords per lane and row
+	static_assert(PW == 1 || (PW == 2 && W == 8 && L == 8), "two-piece gaps: bandwidth 128, eight lanes per pair");
+	constexpr int CWD = (PW == 2) ? 2 : (WR >= 8) ? WR / 8 : 1;          // code dwords per reference block and row
+	constexpr int ND = (PW == 2) ? 4 : (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : 2;      // code dwords per lane and row
 	const int lt = threadIdx.x;
 	const int jl = lt & (L - 1);
 	const bool first = jl == 0, last = jl == L - 1;
@@ -148,9 +152,14 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	asm volatile("" : "+s"(TWO));                          // opaque multiplier of x_acc
 	const uint32_t MINF = x_q8(BSA_EPI8_MIN - 2 * GE);     // the -63 sentinel of f in the shifted frame
 	const uint32_t NGEQ = x_q8(-GE);                       // a cell with u = 0
-	const int cfirst = min(a.smin, gapo1 + gape1) - 1 - a.smax + (gapo1 + gape1);      // bsalign.h:2362
-	// cells entering at the band end (bsalign.h:2357-2389): u = cfirst for the first one, gape1 after it, e = 0
-	const uint32_t NEWU0 = x_q8(cfirst - GE), NEWU1 = 0u, NEWNE = x_q8(GE);
+	const int gapo2 = a.gapo2, gape2 = a.gape2;
+	const int DP = (PW == 2) ? gape2 - gape1 : 0;          // > 0
+	const int gopen = (PW == 2) ? gapo2 + gape2 : gapo1 + gape1;
+	const int cfirst = min(a.smin, gopen) - 1 - a.smax + gopen;                        // bsalign.h:2362
+	const int dsw = (PW == 2) ? (gapo1 - gapo2) / (gape2 - gape1) : 0x7FFFFFFF;         // new cells beyond this distance extend with piece 2 (bsalign.h:2369-2389)
+	// cells entering at the band end (bsalign.h:2357-2389): u = cfirst for the first one, gape1 (gape2) after it, e = q = 0
+	const uint32_t NEWU0 = x_q8(cfirst - GE), NEWNE = x_q8(GE);
+	const uint32_t GQQ = x_q8(gapo2), NGQQ = x_q8(-gapo2), NGQQ1 = x_q8(-gapo2 - 1), DPQ = x_q8(DP);
 	const uint32_t GE16 = x_i16(GE), WGE16 = x_i16(W * GE);
 	const uint32_t PADS = (uint32_t)((BSA_EPI8_MIN - 2 * GE) & 0xff) * 0x01010101u;    // S~ beyond the query end
 	uint32_t mrs[4];                                       // S~ rows per target base
@@ -162,32 +171,35 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		mrs[t] = w;
 	}
 
-	uint32_t U[W], NE[W];
+	uint32_t U[W], NE[W], NQ2[(PW == 2) ? W : 1];     // NQ2: gape1 - q of piece 2
 	uint32_t PN;                  // packed int16: ubegs[b+1] - ubegs[0] - (b+1) W gape for b = jl (low) and jl + L (high)
 	uint32_t PM = 0;              // CR == 2: the same for the middle of the block (the end of its first reference block)
 	int HB;                       // ubegs[0]
 	// ---- row -1 (bsalign.h:2094-2140)
 	{
 		const int first_u = (int)(int8_t)(gapo1 + gape1 + a.smin - a.smax);
+		const int xp = (PW == 2) ? (gapo2 - gapo1) / (gape1 - gape2) : 0x7FFFFFFF;      // row -1 extends with piece 2 from here on (bsalign.h:2115-2125)
+		auto u_init = [&](int p) -> int { return (mode == BSA_MODE_OVERLAP) ? 0 : (p == 0) ? first_u : (p < xp) ? gape1 : gape2; };
 #pragma unroll
 		for(int k = 0; k < W; k++){
-			int vlo, vhi;
-			if(mode == BSA_MODE_OVERLAP){ vlo = 0; vhi = 0; }
-			else { vlo = (jl * W + k == 0) ? first_u : gape1; vhi = gape1; }
+			const int vlo = u_init(jl * W + k), vhi = u_init((jl + L) * W + k);
 			U[k] = (((uint32_t)(vlo - GE) & 0xffu) << 8) | (((uint32_t)(vhi - GE) & 0xffu) << 24);
 			NE[k] = x_q8(GE - BSA_EPI8_MIN);
+			if constexpr (PW == 2) NQ2[k] = x_q8(GE - BSA_EPI8_MIN);
 		}
 		if(mode == BSA_MODE_OVERLAP){
 			PN = ((uint32_t)(-(jl + 1) * W * GE) & 0xffffu) | ((uint32_t)(-(jl + L + 1) * W * GE) << 16);
 			PM = x_add(PN, x_i16((W / 2) * GE));
 			HB = 0;
 		} else {
-			PN = x_i16(first_u - GE);
+			// sum of (u - gape1) over the cells in front of the block's end
+			auto pn_init = [&](int b) -> int { return (first_u - GE) + DP * max(0, (b + 1) * W - max(xp, 1)); };
+			PN = ((uint32_t)pn_init(jl) & 0xffffu) | ((uint32_t)pn_init(jl + L) << 16);
 			PM = PN;
 			HB = a.smax - a.smin;
 		}
 	}
-	uint32_t svU, svNE;           // first cell of the row before the speculative slide (lane 0, low half: band position 0)
+	uint32_t svU, svNE, svNQ = 0; // first cell of the row before the speculative slide (lane 0, low half: band position 0)
 	// bring row -1 into the loop's form: slid by one cell, ubegs[0] not advanced
 	{
 		const uint32_t t0u = U[0], t0e = NE[0];
@@ -195,6 +207,12 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		for(int k = 0; k + 1 < W; k++){ U[k] = U[k + 1]; NE[k] = NE[k + 1]; }
 		const uint32_t inu = x_shift_up<L>(t0u, NEWU0, last), inne = x_shift_up<L>(t0e, NEWNE, last);
 		U[W - 1] = inu; NE[W - 1] = inne;
+		if constexpr (PW == 2){
+			svNQ = NQ2[0];
+#pragma unroll
+			for(int k = 0; k + 1 < W; k++) NQ2[k] = NQ2[k + 1];
+			NQ2[W - 1] = x_shift_up<L>(svNQ, NEWNE, last);
+		}
 		PN = x_add(x_add(PN, x_ashr8(inu)), GE16);
 		if constexpr (CR == 2) PM = x_add(x_add(PM, x_ashr8(U[W / 2 - 1])), GE16);
 		svU = t0u; svNE = t0e;
@@ -228,7 +246,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		int rh;
 		if(rbeg) rh = BSA_SCORE_MIN;
 		else if(mode == BSA_MODE_OVERLAP || i == 0) rh = 0;
-		else rh = gapo1 + gape1 * (int)i;
+		else if(PW < 2) rh = gapo1 + gape1 * (int)i;
+		else rh = max(gapo1 + gape1 * (int)i, gapo2 + gape2 * (int)i);
 		// ---- row_movx (bsalign.h:2244-2392): the row is held slid by one cell; correct what did not move that way
 		if(__any(act && mov != 1u)){
 			if(__any(act && mov >= (uint32_t)BW)){
@@ -240,7 +259,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				if(z){
 					rh = rhz;
 #pragma unroll
-					for(int k = 0; k < W; k++){ U[k] = NGEQ; NE[k] = NEWNE; }
+					for(int k = 0; k < W; k++){ U[k] = NGEQ; NE[k] = NEWNE; if constexpr (PW == 2) NQ2[k] = NEWNE; }
 					HB = BSA_SCORE_MIN;
 					PN = ((uint32_t)(-(jl + 1) * W * GE) & 0xffffu) | ((uint32_t)(-(jl + L + 1) * W * GE) << 16);
 					PM = x_add(PN, x_i16((W / 2) * GE));
@@ -258,6 +277,12 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 #pragma unroll
 				for(int k = W - 1; k >= 1; k--){ x_sel(U[k], U[k - 1], dm); x_sel(NE[k], NE[k - 1], dm); }
 				x_sel(U[0], pu, dm); x_sel(NE[0], pe, dm);
+				if constexpr (PW == 2){
+					const uint32_t pq = x_shift_down<L>(NQ2[W - 1], svNQ, first);
+#pragma unroll
+					for(int k = W - 1; k >= 1; k--) x_sel(NQ2[k], NQ2[k - 1], dm);
+					x_sel(NQ2[0], pq, dm);
+				}
 			}
 			// one more cell at a time for steps of two and more (the first new cell went in with the speculative slide)
 			for(uint32_t s = 1; __any(act && mov < (uint32_t)BW && s < mov); s++){
@@ -265,6 +290,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				const uint64_t dm = __ballot(d);
 				const uint32_t bc = x_bcast_first<L>(U[0]);
 				const uint32_t D0 = __builtin_amdgcn_perm(bc, bc, 0x01000100u);
+				const uint32_t NEWU1 = ((int)s >= dsw) ? DPQ : 0u;          // u = gape1, or gape2 beyond the switch distance
 				const uint32_t inu = x_shift_up<L>(U[0], NEWU1, last), inne = x_shift_up<L>(NE[0], NEWNE, last);
 				const uint32_t npn = x_add(PN, x_ashr8(x_sub(inu, D0)));
 				PN = d ? npn : PN;
@@ -273,6 +299,12 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 #pragma unroll
 				for(int k = 0; k + 1 < W; k++){ x_sel(U[k], U[k + 1], dm); x_sel(NE[k], NE[k + 1], dm); }
 				x_sel(U[W - 1], inu, dm); x_sel(NE[W - 1], inne, dm);
+				if constexpr (PW == 2){
+					const uint32_t innq = x_shift_up<L>(NQ2[0], NEWNE, last);
+#pragma unroll
+					for(int k = 0; k + 1 < W; k++) x_sel(NQ2[k], NQ2[k + 1], dm);
+					x_sel(NQ2[W - 1], innq, dm);
+				}
 			}
 		}
 		if(mov != 0u && mov < (uint32_t)BW) rh = HB;              // getscore(mov - 1) of the previous row
@@ -300,25 +332,33 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		// slide inside the band rh == ubegs[0] and the rule changes neither h nor any flag, so only rows that stayed
 		// (or jumped past the whole band: ubegs[0] = SCORE_MIN) need it.
 		uint32_t hc0 = S[0];
-		uint32_t q0m = 0, q0d = 0;          // rows starting at query column 0: what h is compared with for M and D (bsalign.h:3763-3767)
+		uint32_t q0m = 0, q0d = 0, q0d2 = 0;          // rows starting at query column 0: what h is compared with for M and D (bsalign.h:3763-3767)
 		if(__any(act && (mov == 0u || mov >= (uint32_t)BW))){
 			const int s0 = x_lo8(S[0]) + 2 * GE, u0 = x_lo8(U[0]) + GE, e0 = GE - x_lo8(NE[0]);
-			const int t0 = u0 + e0;
+			const int qq0 = (PW == 2) ? GE - x_lo8(NQ2[0]) : e0;
+			const int t0 = u0 + max(e0, qq0);
 			int hh = (rh - HB) + s0;
 			hh = (hh >= t0) ? min(hh, BSA_EPI8_MAX) : BSA_EPI8_MIN;
 			if(first && (mov == 0u || mov >= (uint32_t)BW)) hc0 = (hc0 & 0xffff0000u) | (((uint32_t)(hh - 2 * GE) & 0xffu) << 8);
 			// compare values of the quirk, in the shifted frame; out of int8 range = never equal
-			const int cm = rh - HB + s0 - 2 * GE, cd = t0 + rh - HB - 2 * GE;
+			const int cm = rh - HB + s0 - 2 * GE, cd = u0 + e0 + rh - HB - 2 * GE, cd2 = u0 + qq0 + rh - HB - 2 * GE;
 			q0m = (cm >= -128 && cm <= 127) ? (((uint32_t)cm & 0xffu) << 8) : 0x00ffu;
 			q0d = (cd >= -128 && cd <= 127) ? (((uint32_t)cd & 0xffu) << 8) : 0x00ffu;
+			q0d2 = (cd2 >= -128 && cd2 <= 127) ? (((uint32_t)cd2 & 0xffu) << 8) : 0x00ffu;
 		}
 		// ---- row_cal, pass 1 (bsalign.h:2911-2930): F leaving every block when nothing but the sentinel enters it
-		uint32_t ee[W], m[W], mg[W];
-		uint32_t f = MINF;
+		uint32_t ee[W], m[W], mg[W], qq[(PW == 2) ? W : 1], Ud[(PW == 2) ? W : 1];
+		uint32_t f = MINF, g2 = MINF;
 #pragma unroll
 		for(int k = 0; k < W; k++){
 			ee[k] = x_sub(U[k], NE[k]);
-			m[k] = x_max(ee[k], (k == 0) ? hc0 : S[k]);
+			if constexpr (PW == 2){
+				qq[k] = x_sub(U[k], NQ2[k]);
+				Ud[k] = x_sub(U[k], DPQ);
+				m[k] = x_max(x_max(ee[k], qq[k]), (k == 0) ? hc0 : S[k]);
+				const uint32_t t = x_add(x_max(m[k], f), GQQ);
+				g2 = x_sub(x_max(g2, t), Ud[k]);
+			} else m[k] = x_max(ee[k], (k == 0) ? hc0 : S[k]);
 			mg[k] = x_add(m[k], GOQ);
 			f = x_sub(x_max(f, mg[k]), U[k]);
 		}
@@ -330,17 +370,42 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			const uint32_t Thi = (bc << 16) | 0x8000u;              // {-32768, max over blocks 0..7}
 			const uint32_t G = x_sub(x_max(P, Thi), PN);
 			f = x_shl8(x_shift_down<L>(G, x_i16(BSA_EPI8_MIN - 2 * GE), first));
+			if constexpr (PW == 2){
+				// the chain of piece 2 gains dP per cell on its way: the same scan on X - (b + 1) W dP
+				const uint32_t PN2 = x_sub(PN, ((uint32_t)((jl + 1) * W * DP) & 0xffffu) | ((uint32_t)((jl + L + 1) * W * DP) << 16));
+				const uint32_t Fb = x_add(x_ashr8(g2), PN2);
+				const uint32_t P2 = x_scan_max<L>(Fb);
+				const uint32_t bc2 = x_bcast_last<L>(P2);
+				const uint32_t G2 = x_sub(x_max(P2, (bc2 << 16) | 0x8000u), PN2);
+				g2 = x_shl8(x_shift_down<L>(G2, x_i16(BSA_EPI8_MIN - 2 * GE), first));
+			}
 		}
 		// ---- pass 2 (bsalign.h:2932-2957), flags, new row written one slot to the left
 		uint32_t accM[NACC], accD[NACC], accR[NACC], accO[NACC];
+		uint32_t accD2 = 0, accI1 = 0, accI2 = 0, accR2 = 0, accO2 = 0;          // PW == 2 (one accumulator: W == 8)
 #pragma unroll
 		for(int n = 0; n < NACC; n++){ accM[n] = 0; accD[n] = 0; accR[n] = 0; accO[n] = 0; }
-		uint32_t tmpU0 = 0, tmpNE0 = 0, hfirst = 0;
+		uint32_t tmpU0 = 0, tmpNE0 = 0, tmpNQ0 = 0, hfirst = 0;
 		uint32_t v = 0, vmid = 0;
 #pragma unroll
 		for(int k = 0; k < W; k++){
 			const uint32_t uk = U[k];
-			const uint32_t h = x_max(m[k], f);
+			uint32_t h = x_max(m[k], f);
+			uint32_t nq = 0;
+			if constexpr (PW == 2){
+				const uint32_t t = x_add(h, GQQ);                  // max(m, f) + gapo2
+				h = x_max(h, g2);
+				accI1 = x_acc(accI1, x_minu(x_sub(h, f), ONE), TWO);
+				accI2 = x_acc(accI2, x_minu(x_sub(h, g2), ONE), TWO);
+				const uint32_t gm = x_max(g2, t);
+				g2 = x_sub(gm, Ud[k]);
+				accR2 = x_acc(accR2, x_minu(x_sub(gm, t), ONE), TWO);
+				const uint32_t n2 = x_sub(h, qq[k]);
+				accD2 = x_acc(accD2, x_minu(n2, ONE), TWO);
+				const uint32_t nqd = x_minu(n2, NGQQ);
+				accO2 = x_acc(accO2, x_satsubu(nqd, NGQQ1), TWO);
+				nq = x_sub(nqd, DPQ);
+			}
 			const uint32_t fm = x_max(f, mg[k]);
 			f = x_sub(fm, uk);
 			accR[k >> 3] = x_acc(accR[k >> 3], x_minu(x_sub(fm, mg[k]), ONE), TWO);
@@ -352,8 +417,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			const uint32_t un = x_sub(h, v);
 			v = x_sub(h, uk);
 			if(CR == 2 && k == W / 2 - 1) vmid = v;
-			if(k == 0){ tmpU0 = un; tmpNE0 = ne; hfirst = h; }
-			else { U[k - 1] = un; NE[k - 1] = ne; }
+			if(k == 0){ tmpU0 = un; tmpNE0 = ne; tmpNQ0 = nq; hfirst = h; }
+			else { U[k - 1] = un; NE[k - 1] = ne; if constexpr (PW == 2) NQ2[k - 1] = nq; }
 		}
 		// ---- tail (bsalign.h:2618-2636): u of every block's first cell, ubegs of the new row, ubegs[0] re-based on cell 0
 		const uint32_t vlast = v;
@@ -374,6 +439,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				const uint32_t b0 = 1u << TOPBIT;
 				accM[0] = (accM[0] & ~b0) | ((hl == q0m) ? 0u : b0);
 				accD[0] = (accD[0] & ~b0) | ((hl == q0d) ? 0u : b0);
+				if constexpr (PW == 2) accD2 = (accD2 & ~b0) | ((hl == q0d2) ? 0u : b0);
 			}
 		}
 		if(__any(act && mov > 1u)){          // (the general form covers mov == 1 of the other pairs of the wave)
@@ -388,15 +454,28 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					// accumulator n holds cells 8n .. 8n + CN - 1, cell c at bit 8 + CN - 1 - (c - 8n)
 					const int cd = min(max(nd - 8 * n, 0), CN), cm = min(max(nm - 8 * n, 0), CN);
 					const uint32_t md = (((1u << (CN - cd)) - 1u) << 8) << (16 * hf), mm = (((1u << (CN - cm)) - 1u) << 8) << (16 * hf);
-					if(mov != 0u){ accD[n] |= md; accM[n] |= mm; }
+					if(mov != 0u){ accD[n] |= md; accM[n] |= mm; if constexpr (PW == 2) accD2 |= md; }
 				}
 			}
-		} else accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u;
+		} else { accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u; if constexpr (PW == 2) accD2 |= (mov == 1u) ? kd1 : 0u; }
 		// The code dwords of this row: ND per lane.  Rows are stored in groups of four (bsa_common.h): the lane keeps the
 		// dwords of the group's rows in registers and stores whole 16-byte pieces when the group (or the pair) ends.
 		{
 			uint32_t cur[ND];
-			if constexpr (WR == 8){
+			if constexpr (PW == 2){
+				// two dwords per reference block (bsa_common.h): A | D << 8 | D2 << 16 | B << 24 and R1 | R2 << 8 | Od1 << 16 | Od2 << 24.
+				// M, D, D2, I1, I2, R1, R2 were accumulated inverted; the decision facts fold into A = M or (no D, no D2, I1 and I2),
+				// B = not M and I1 (bit-wise on the planes, after the special cells were set above)
+				const uint32_t F8 = 0xFF00FF00u;
+				const uint32_t nA = accM[0] & (accI1 | accI2 | (~(accD[0] & accD2) & F8));
+				const uint32_t nB = (~accM[0] & F8) | accI1;
+				const uint32_t t1 = __builtin_amdgcn_perm(accD[0], nA, 0x07030501u);        // {A.lo, D.lo, A.hi, D.hi}
+				const uint32_t t2 = __builtin_amdgcn_perm(nB, accD2, 0x07030501u);          // {D2.lo, B.lo, D2.hi, B.hi}
+				const uint32_t t3 = __builtin_amdgcn_perm(accR2, accR[0], 0x07030501u);
+				const uint32_t t4 = __builtin_amdgcn_perm(accO2, accO[0], 0x07030501u);
+				cur[0] = ~__builtin_amdgcn_perm(t2, t1, 0x05040100u); cur[1] = __builtin_amdgcn_perm(t4, t3, 0x05040100u) ^ 0x0000FFFFu;     // block jl
+				cur[2] = ~__builtin_amdgcn_perm(t2, t1, 0x07060302u); cur[3] = __builtin_amdgcn_perm(t4, t3, 0x07060302u) ^ 0x0000FFFFu;     // block jl + L
+			} else if constexpr (WR == 8){
 				// one dword per reference block: M | D << 8 | R << 16 | Od << 24, cell k at bit 7 - k
 #pragma unroll
 				for(int n = 0; n < NACC; n++){
@@ -518,6 +597,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			const uint32_t inu = last ? __builtin_amdgcn_alignbit(NEWU0, bc0, 16) : nxt;
 			const uint32_t inne = x_shift_up<L>(tmpNE0, NEWNE, last);
 			U[W - 1] = inu; NE[W - 1] = inne;
+			if constexpr (PW == 2){ NQ2[W - 1] = x_shift_up<L>(tmpNQ0, NEWNE, last); svNQ = tmpNQ0; }
 			PN = x_add(x_add(PN, x_ashr8(inu)), GE16);
 			if constexpr (CR == 2) PM = x_add(x_add(PM, x_ashr8(U[W / 2 - 1])), GE16);
 			svU = tmpU0; svNE = tmpNE0;
@@ -530,6 +610,10 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 template<int W, int L>
 __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	x_forward<W, L>(a, a.first, a.count, blockIdx.x);
+}
+// two-piece gaps (bandwidth 128): 8 bits per band cell
+__global__ void __launch_bounds__(256) k_align8_fwd_x2(const Align8Args a){
+	x_forward<8, 8, 2>(a, a.first, a.count, blockIdx.x);
 }
 
 // Bandwidth 128, a batch that is not a whole number of four-lane rounds: the first nb8 blocks take the last n8 pairs
@@ -544,22 +628,36 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x_mix(const Align8Args a, co
 // Exact arithmetic is the reference's arithmetic only while nothing saturates: the guard of the compact path
 // (bsa_align8_codes_supported) plus room for the frame shift by 2 |gape| and for the int16 block offsets.
 bool bsa_align8_x_supported(const Align8Args &a, int pw){
-	if(pw != 1 || !bsa_align8_codes_supported(a, pw)) return false;
 	if((a.mode & 3) != BSA_MODE_GLOBAL) return false;
 	const uint32_t W = a.bw / 16;
-	if(!(W == 4 || W == 8 || W == 16)) return false;
 	const int ge = -(int)(int8_t)a.gape1, go = -(int)(int8_t)a.gapo1, m = a.smax, n = -a.smin;
-	if(ge < 0 || go <= 0) return false;
-	const int g = go + ge;
+	if(ge < 0 || go <= 0 || m < 0 || n < 0) return false;
+	int g = go + ge;
+	if(pw == 2){
+		// two pieces: bandwidth 128 only; piece 2 opens dearer and extends cheaper (bsalign.h:2084-2092 guarantees it),
+		// the bound is taken with the dearer opening
+		if(W != 8) return false;
+		const int ge2 = -(int)(int8_t)a.gape2, go2 = -(int)(int8_t)a.gapo2;
+		if(ge2 < 0 || go2 <= go || ge2 >= ge) return false;
+		g = std::max(g, go2 + ge2);
+		if(m + 3 * g > 64 || n + m + g > 100) return false;      // the compact path's own bound (bsa_align8_codes_supported)
+	} else {
+		if(pw != 1 || !bsa_align8_codes_supported(a, pw)) return false;
+		if(!(W == 4 || W == 8 || W == 16)) return false;
+	}
 	const int cfirst = std::min(a.smin, -g) - 1 - a.smax - g;
 	if(cfirst < -100) return false;
 	return m + 3 * g + 2 * ge <= 100 && n + m + g + 2 * ge <= 110 && 63 + 2 * ge + n + m + 2 * g <= 125;
 }
 
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
-	(void)pw;
 	if(a.count == 0) return hipSuccess;
 	const uint32_t b8 = (a.count + 31u) / 32u;
+	if(pw == 2){
+		if(a.bw != 128u) return hipErrorInvalidValue;
+		hipLaunchKernelGGL(k_align8_fwd_x2, dim3(b8), dim3(256), 0, st, a);
+		return hipGetLastError();
+	}
 	switch(a.bw / 16){
 		case 4:  hipLaunchKernelGGL((k_align8_fwd_x<4, 8>), dim3(b8), dim3(256), 0, st, a); break;
 		case 8: {

@@ -585,7 +585,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw_of(k);
 	}
 	for(size_t pos = 0; pos < n; pos++)
-		need[pos] = p->codes ? bsa_code_slot_bytes(tlen[order[pos]], bw / 16u) : bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
+		need[pos] = p->codes ? bsa_code_slot_bytes(tlen[order[pos]], bw / 16u, p->pw) : bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
 	p->cells = cells;
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
 	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
@@ -635,11 +635,12 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	if(codes){
 		const char *fe = getenv("BSA_ALIGN8_FWD");
 		const bool force_pk = fe && fe[0] == 'p';
-		fwd_x = !force_pk && bsa_align8_x_supported(a, pw);
+		fwd_x = (pw == 2) || (!force_pk && bsa_align8_x_supported(a, pw));       // (two-piece gaps: the only forward kernel of the compact path)
 	}
-	c->fwd_name = fwd_x ? "k_align8_fwd_x (exact-arithmetic forward DP, 4-bit traceback codes)" : codes ? "k_align8_fwd_pk<.,.,true> (packed forward DP, 4-bit traceback codes)"
+	c->fwd_name = (fwd_x && pw == 2) ? "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)"
+		: fwd_x ? "k_align8_fwd_x (exact-arithmetic forward DP, 4-bit traceback codes)" : codes ? "k_align8_fwd_pk<.,.,true> (packed forward DP, 4-bit traceback codes)"
 		: generic ? "k_align8_fwd_gen (run-time bandwidth, row records)" : "k_align8_fwd_pk / k_align8_fwd (row records)";
-	c->trace_name = codes ? "k_align8_trace_codes_lds" : "k_align8_backcal";
+	c->trace_name = (codes && pw == 2) ? "k_align8_trace_codes2" : codes ? "k_align8_trace_codes_lds" : "k_align8_backcal";
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
 		if(codes && fwd_x) HIPCHK(c, bsa_launch_align8_fwd_x(b, pw, s));

@@ -64,22 +64,28 @@ static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t 
 // Code row = 16 blocks x CW dwords (CW = max(1, W / 8)), running block y of the row = dwords y*CW ...  The 4W bits of a
 // block are four planes of W bits, plane n at bit n*W: M, D, R (insert opens here for the next cell), Od (stored e is
 // a fresh opening); inside a plane cell k of the block is bit W-1-k.
+// Two-piece gaps (W = 8 only): two dwords per block, eight byte planes --
+//   dword 0: A | D << 8 | D2 << 16 | B << 24        dword 1: R1 | R2 << 8 | Od1 << 16 | Od2 << 24
+// D / D2: h == u + e / h == u + q.  A and B fold M and "which insertion chain equals h" (I1: h == f, I2: h == g), which are
+// only consulted where D = D2 = 0:  D or D2 set: A is M.  Else (A, B) = (1, 0) M; (1, 1) not M, both chains; (0, 1) chain 1
+// only; (0, 0) chain 2 only.  R1 / R2, Od1 / Od2: the flags R, Od of the two pieces (oracle/bsalign_oracle.c states the rules).
 // TILING: the traceback walks up the rows while its position inside the band drifts slowly (the band follows the
 // diagonal), so it wants a few blocks of many rows, not whole rows.  Rows are stored in groups of four; inside a
 // group the four rows of ONE block are adjacent (16 CW bytes), blocks follow each other:
 //   dword offset of (row r, block y, dword d) = ((r / 4) * 64 + y * 4 + (r % 4)) * CW + d          (bsa_code_off)
 // Three neighbouring blocks of four rows are then 48 contiguous bytes (one or two 64-byte lines instead of four), and
 // the row count of a slot is rounded up to a multiple of four (bsa_code_rows).
-static inline __host__ __device__ uint32_t bsa_code_words(uint32_t W){ return W >= 8u ? W / 8u : 1u; }
-static inline __host__ __device__ uint32_t bsa_code_row_bytes(uint32_t W){ return 64u * bsa_code_words(W); }
+// (two-piece gaps: 8 bits per cell -- A, D, D2, B | R1, R2, Od1, Od2, one byte plane each at W = 8 -- twice the words)
+static inline __host__ __device__ uint32_t bsa_code_words(uint32_t W, int pw = 1){ return (W >= 8u ? W / 8u : 1u) * (pw == 2 ? 2u : 1u); }
+static inline __host__ __device__ uint32_t bsa_code_row_bytes(uint32_t W, int pw = 1){ return 64u * bsa_code_words(W, pw); }
 #define BSA_CODE_SPARE_ROWS 7u
 static inline __host__ __device__ size_t bsa_code_off(uint32_t r, uint32_t y, uint32_t CW){ return ((size_t)(r >> 2) * 64u + y * 4u + (r & 3u)) * CW; }
 static inline __host__ __device__ uint32_t bsa_code_rows(uint32_t tlen){ return (tlen + 3u) & ~3u; }       // stored rows: whole groups of four
 // end record of the non-global modes: per lane the best end-of-query score seen while the band touched the query end
 // and its row (bsalign.h:4023-4032), and the last row itself for row_max (bsalign.h:4038-4046)
 struct bsa_code_end_t { int32_t cand_sc[16], cand_te[16], ubegs[17], rbeg_last; };
-static inline __host__ __device__ size_t bsa_code_slot_bytes(uint32_t tlen, uint32_t W){
-	return bsa_begs_bytes(tlen) + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * bsa_code_row_bytes(W);
+static inline __host__ __device__ size_t bsa_code_slot_bytes(uint32_t tlen, uint32_t W, int pw = 1){
+	return bsa_begs_bytes(tlen) + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * bsa_code_row_bytes(W, pw);
 }
 
 static inline __host__ __device__ int bsa_get_piecewise(int gapo1, int gape1, int gapo2, int gape2, int bandwidth){ // bsalign.h:2084-2092

@@ -186,7 +186,14 @@ static void f_penetrate(uint32_t W, int f[NL], const int32_t *ub, int gape){
  *   bit 2  R   the insertion reaching cell p+1 is opened at p (h + gapoe >= f + gape): the insert-length scan
  *              bsalign.h:3798-3814 stops at the first such cell to the left
  *   bit 3  Od  the stored e of this cell equals gapo+gape: the delete-length scan bsalign.h:3730-3744 stops here
- * Sound only when no saturation fires anywhere (stored differences exact); piecewise <= 1. */
+ * Sound only when no saturation fires anywhere (stored differences exact).
+ * piecewise == 2 (8 bits per cell): backcal needs nine facts there -- M, D (h == u + e), D2 (h == u + q), which of the two
+ * insertion chains equals h (I1: h == f, I2: h == g; only consulted when none of M, D, D2 holds), R1 / R2 (the chain of piece
+ * 1 / 2 reaching cell p+1 is opened at p) and Od1 / Od2 (the stored e / q is a fresh opening).  The five decision facts fold
+ * into four bits because I1 / I2 matter only where M = D = D2 = 0 and at least one of the five always holds:
+ *   bit 0  A   M, or (no D, no D2, I1 and I2)          bit 1  D          bit 2  D2          bit 3  B   not M and I1
+ *   D or D2 set: A is M.  Else (A, B) = (1, 0) M; (1, 1) both chains; (0, 1) chain 1 only; (0, 0) chain 2 only.
+ *   bit 4  R1      bit 5  R2      bit 6  Od1      bit 7  Od2 */
 static __thread uint8_t *tl_codes = NULL;   /* bw bytes for the row being computed, natural band order */
 static __thread uint32_t tl_mov = 0;
 
@@ -288,6 +295,26 @@ int orc_row_cal(uint32_t rbeg, uint8_t base,
 				hh = imax(e, z[j]);
 				q = sat8(qs0[i * NL + j] + u);
 				hh = imax(q, hh); hh = imax(f[j], hh); hh = imax(g[j], hh);
+				if(tl_codes){
+					const uint32_t pp = (uint32_t)j * W + i, xx = pp + tl_mov;
+					const int sraw = score_at(qy, (uint64_t)rbeg + pp, base);
+					int lhs = hh, zc = sraw, code = 0;
+					int fM, fD, fD2, fI1, fI2;
+					if(pp == 0 && rbeg == 0){ zc = rh - ub0[0] + sraw; lhs = ub0[0] + hh - rh; }
+					fM = xx <= W * NL && hh == zc;
+					fD = xx < W * NL && lhs == (int)u + (int)es0[i * NL + j];
+					fD2 = xx < W * NL && lhs == (int)u + (int)qs0[i * NL + j];
+					fI1 = hh == f[j]; fI2 = hh == g[j];
+					if(fM || (!fD && !fD2 && fI1 && fI2)) code |= 1;
+					if(fD) code |= 2;
+					if(fD2) code |= 4;
+					if(!fM && fI1) code |= 8;
+					if(sat8(hh + GapOE) >= sat8(f[j] + GapE)) code |= 16;
+					if(sat8(hh + GapQP) >= sat8(g[j] + GapP)) code |= 32;
+					if(imax(sat8(sat8(e + GapE) - hh), GapOE) == GapOE) code |= 64;
+					if(imax(sat8(sat8(q + GapP) - hh), GapQP) == GapQP) code |= 128;
+					tl_codes[pp] = (uint8_t)code;
+				}
 				v[j] = sat8(hh - v[j]); us1[i * NL + j] = (int8_t)v[j];
 				v[j] = sat8(hh - u);
 				e = sat8(e + GapE); e = sat8(e - hh); e = imax(e, GapOE);
@@ -717,6 +744,7 @@ static long align_core(const uint8_t *q, uint32_t qlen, const uint8_t *tq, uint3
  * by the bit the forward pass recorded.  codes[(r + 1) * bw + p] = code of band cell p of row r; begs[r + 1] = band
  * offset of row r (begs[0] = 0 for row -1).  Returns 0, or -1 where the literal traceback is needed (a scan leaves the
  * band, or the situation in which the reference itself does not terminate). */
+static __thread int g_gapo1, g_gape1, g_gapo2, g_gape2;     /* gap costs of the alignment backcal_codes is walking */
 static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t *codes, const int32_t *begs, uint32_t bw,
 		int type, int pw, orc_result_t *rs, cigv_t *cv){
 	int prior_match = 0;
@@ -731,7 +759,17 @@ static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t
 		p = rs->qb - begs[rs->tb + 1];                       /* position in row tb's own band */
 		if(p < 0 || p >= (int)bw) return -1;
 		code = codes[((size_t)rs->tb + 1) * bw + (size_t)p];
-		if(prior_match) bt = (code & 1) ? BT_M : (code & 2) ? BT_D : BT_I;
+		int chains = 1;                                      /* insertion: which chains equal h (bit 0: piece 1, bit 1: piece 2) */
+		int dtype = 8;                                       /* deletion: the Od bit that ends the run */
+		if(pw == 2){
+			const int fD = (code >> 1) & 1, fD2 = (code >> 2) & 1, fA = code & 1, fB = (code >> 3) & 1;
+			const int fM = (fD || fD2) ? fA : (fA && !fB);
+			int d = fD ? 1 : fD2 ? 2 : 0;                    /* backcal_cell, bsalign.h:3679-3701 */
+			if(prior_match) bt = fM ? BT_M : d ? BT_D : BT_I;
+			else bt = d ? BT_D : fM ? BT_M : BT_I;
+			dtype = (d == 2) ? 128 : 64;
+			chains = fA ? (fB ? 3 : 0) : (fB ? 1 : 2);       /* (only read when bt == BT_I, where M = D = D2 = 0) */
+		} else if(prior_match) bt = (code & 1) ? BT_M : (code & 2) ? BT_D : BT_I;
 		else bt = (code & 2) ? BT_D : (code & 1) ? BT_M : BT_I;
 		prior_match = 1;
 		if(bt == BT_M){
@@ -744,10 +782,21 @@ static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t
 				rs->qb--; rs->ins++; rs->aln++;
 			} else {
 				int sz, found = 0;
+				/* the nearest cell to the left at which a chain that equals h here was opened (bsalign.h:3798-3814: the smallest
+				 * length whose cost, the larger of the two pieces', closes the gap) */
+				const int rmask = (pw == 2) ? (((chains & 1) ? 16 : 0) | ((chains & 2) ? 32 : 0)) : 4;
 				for(sz = 1; sz <= p; sz++){
-					if(codes[((size_t)rs->tb + 1) * bw + (size_t)(p - sz)] & 4){ found = 1; break; }
+					if(codes[((size_t)rs->tb + 1) * bw + (size_t)(p - sz)] & rmask){ found = 1; break; }
 				}
 				if(!found) return -1;
+				if(pw == 2){
+					/* the reference tests H(x - sz) + max(cost1(sz), cost2(sz)) == H(x): the chain that is tight here must also be the
+					 * one with the larger (less negative) cost at this length.  Between real DP cells that always holds; next to cells
+					 * that entered the band with synthetic values it can fail, and the reference's scan then finds no length at all */
+					const int hit = codes[((size_t)rs->tb + 1) * bw + (size_t)(p - sz)] & rmask;
+					const int c1 = g_gapo1 + sz * g_gape1, c2 = g_gapo2 + sz * g_gape2;
+					if(!(((hit & 16) && c1 >= c2) || ((hit & 32) && c2 >= c1))) return -1;
+				}
 				cg = cig_add(cv, cg, 1, (uint32_t)sz);
 				rs->qb -= sz; rs->ins += sz; rs->aln += sz;
 			}
@@ -765,7 +814,7 @@ static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t
 				}
 				pr = rs->qb - begs[r + 1];
 				if(pr < 0 || pr >= (int)bw) return -1;
-				if(codes[((size_t)r + 1) * bw + (size_t)pr] & 8) break;
+				if(codes[((size_t)r + 1) * bw + (size_t)pr] & dtype) break;
 				len++;
 			}
 			cg = cig_add(cv, cg, BT_D, (uint32_t)len);
@@ -818,7 +867,6 @@ long orc_align_pairwise_codes_mode(const uint8_t *q, uint32_t qlen, const uint8_
 	bw = (bw + NL - 1) / NL * NL;
 	W = bw / NL;
 	pw = orc_get_piecewise(gapo1, gape1, gapo2, gape2, (int)bw);
-	if(pw == 2) return ORC_ERR_INPUT;
 	for(i = 0; i < 16; i++){ smax = imax(smax, mtx[i]); smin = imin(smin, mtx[i]); }
 	rowbuf = (int8_t*)calloc((size_t)bw * 9, 1);
 	codes = (uint8_t*)calloc((size_t)bw * ((size_t)tlen + 1), 1);
@@ -842,7 +890,8 @@ long orc_align_pairwise_codes_mode(const uint8_t *q, uint32_t qlen, const uint8_
 				mov = 0;
 				if(rbeg) rh = ORC_SCORE_MIN;
 				else if(type == ORC_MODE_OVERLAP || i == 0) rh = 0;
-				else rh = gapo1 + gape1 * (int)i;
+				else if(pw < 2) rh = gapo1 + gape1 * (int)i;
+				else rh = imax(gapo1 + gape1 * (int)i, gapo2 + gape2 * (int)i);
 			}
 			orc_row_movx(mu, me, mq, ub0, pu, pe, pq, pb, W, mov, pw, smax, smin, gapo1, gape1, gapo2, gape2);
 			tl_codes = codes + ((size_t)i + 1) * bw; tl_mov = mov;
@@ -880,6 +929,7 @@ long orc_align_pairwise_codes_mode(const uint8_t *q, uint32_t qlen, const uint8_
 	{
 		int bad = 0;
 		if(rs.qe < begs[rs.te + 1] || rs.qe >= begs[rs.te + 1] + (int)bw) bad = 1;
+		g_gapo1 = gapo1; g_gape1 = gape1; g_gapo2 = gapo2; g_gape2 = gape2;
 		if(!bad) bad = backcal_codes(q, tq, codes, begs, bw, type, pw, &rs, &cv);
 		free(rowbuf); free(codes); free(begs);
 		if(bad){ memset(&rs, 0, sizeof(rs)); if(res) *res = rs; return ORC_ERR_TRACE; }

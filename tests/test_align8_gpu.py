@@ -172,6 +172,24 @@ def test_compact_path_band_and_ratio_corners(ctx):
             _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS[sc])
 
 
+def test_two_piece_gaps_take_the_compact_path(ctx):
+    """2-piece gaps (POA default and others), global, bandwidth 128: 8-bit traceback codes written by k_align8_fwd_x2 and walked by
+    k_align8_trace_codes2 -- results identical to the oracle's literal backcal, corners included, and the plan really is compact"""
+    import bsalign_amd as B
+    rng = np.random.default_rng(2025)
+    pairs = _mk_pairs(rng, 160, [1, 2, 15, 16, 17, 63, 64, 65, 100, 300, 1000, 2500])
+    for _ in range(60):                                      # length mismatches: steering rushes, band jumps
+        Lt = int(rng.choice([5, 33, 80, 200, 600]))
+        Lq = max(1, int(Lt * float(rng.choice([0.5, 0.3, 2.0, 3.0, 1.1]))))
+        T = rng.integers(0, 4, size=Lt).astype(np.uint8)
+        Q = S.mutate(rng, T, float(rng.choice([0.0, 0.1, 0.4])))
+        Q = Q[:Lq] if Lq <= len(Q) else np.concatenate([Q, rng.integers(0, 4, size=Lq - len(Q)).astype(np.uint8)])
+        pairs.append((Q if len(Q) else np.array([2], np.uint8), T))
+    for sc in ((2, -6, -3, -2, -8, -1), (2, -4, -4, -2, -12, -1), (3, -5, -2, -3, -9, -1), (1, -3, -2, -2, -6, -1)):
+        _check(ctx, pairs, S.MODE_GLOBAL, 128, sc)
+        assert "k_align8_fwd_x2" in ctx.last_kernel_names()[0] and ctx.last_kernel_names()[1] == "k_align8_trace_codes2"
+
+
 def test_handover_to_literal_path_merges_results(ctx, monkeypatch):
     """bsa_align_batch re-runs pairs the compact traceback flags through the row-record kernels and splices their
     results and CIGARs back; the debug hook declares every 3rd pair undecided so that the merge is exercised"""
