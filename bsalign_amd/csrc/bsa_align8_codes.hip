@@ -81,7 +81,9 @@ static __device__ void codes_end_cell(const uint8_t *rows, uint32_t RB, uint32_t
 // The query is held as three 16-byte chunks refreshed on the same schedule.  A lane that outruns its ring (a long
 // insertion or deletion) simply idles until the next service point.
 #define CODE_SVC 8
+#ifndef CODE_RING_ROWS
 #define CODE_RING_ROWS 32
+#endif
 
 // LPW = pairs (active lanes) per wave: the walk is a chain of dependent ALU ops, so a SIMD needs several waves to keep
 // issuing; fewer lanes per wave = more waves for the same batch
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 			file();
 			if(qp_ch != -1000){ qc0 = qp0; qc1 = qp1; qc2 = qp2; qc_ch = qp_ch; qp_ch = -1000; }
 			if(!done){
-				if(have_lo > 0 && rs.tb - have_lo + 1 < 3 * CODE_SVC) request((have_lo - 1) >> 2, base_for(cury));   // ring holds 32 rows: at most 23 live + 8 new
+				if(have_lo > 0 && rs.tb - have_lo + 1 < CODE_RING_ROWS - CODE_SVC) request((have_lo - 1) >> 2, base_for(cury));   // the ring holds the live rows + the 8 new ones
 				if(rs.qb >= 0 && (rs.qb >> 4) != qc_ch){ qp_ch = rs.qb >> 4; qp0 = chunk(qp_ch); qp1 = chunk(qp_ch - 1); qp2 = chunk(qp_ch - 2); }
 			}
 		}
