@@ -125,7 +125,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	constexpr int NQ = (W + 3) / 4;
 	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
 	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
-	static_assert(PW == 1 || (PW == 2 && W == 8 && L == 8), "two-piece gaps: bandwidth 128, eight lanes per pair");
+	static_assert(PW == 0 || PW == 1 || (PW == 2 && W == 8 && L == 8), "two-piece gaps: bandwidth 128, eight lanes per pair");
 	constexpr int CWD = (PW == 2) ? 2 : (WR >= 8) ? WR / 8 : 1;          // code dwords per reference block and row
 	constexpr int ND = (PW == 2) ? 4 : (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : 2;      // code dwords per lane and row
 	const int lt = threadIdx.x;
@@ -158,7 +158,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	const int cfirst = min(a.smin, gopen) - 1 - a.smax + gopen;                        // bsalign.h:2362
 	const int dsw = (PW == 2) ? (gapo1 - gapo2) / (gape2 - gape1) : 0x7FFFFFFF;         // new cells beyond this distance extend with piece 2 (bsalign.h:2369-2389)
 	// cells entering at the band end (bsalign.h:2357-2389): u = cfirst for the first one, gape1 (gape2) after it, e = q = 0
-	const uint32_t NEWU0 = x_q8(cfirst - GE), NEWNE = x_q8(GE);
+	const uint32_t NEWU0 = x_q8(cfirst - GE), NEWNE = (PW == 0) ? 0u : x_q8(GE);
 	const uint32_t GQQ = x_q8(gapo2), NGQQ = x_q8(-gapo2), NGQQ1 = x_q8(-gapo2 - 1), DPQ = x_q8(DP);
 	const uint32_t GE16 = x_i16(GE), WGE16 = x_i16(W * GE);
 	const uint32_t PADS = (uint32_t)((BSA_EPI8_MIN - 2 * GE) & 0xff) * 0x01010101u;    // S~ beyond the query end
@@ -184,7 +184,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		for(int k = 0; k < W; k++){
 			const int vlo = u_init(jl * W + k), vhi = u_init((jl + L) * W + k);
 			U[k] = (((uint32_t)(vlo - GE) & 0xffu) << 8) | (((uint32_t)(vhi - GE) & 0xffu) << 24);
-			NE[k] = x_q8(GE - BSA_EPI8_MIN);
+			NE[k] = (PW == 0) ? 0u : x_q8(GE - BSA_EPI8_MIN);      // linear gaps: e is the constant gape1 (bsalign.h:2779), NE stays 0
 			if constexpr (PW == 2) NQ2[k] = x_q8(GE - BSA_EPI8_MIN);
 		}
 		if(mode == BSA_MODE_OVERLAP){
@@ -223,6 +223,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 #pragma unroll
 	for(int r = 0; r < 3; r++){ for(int q = 0; q < ND; q++) hist[r][q] = 0u; }
 	int begq = 0;
+	int cand_sc = BSA_SCORE_MIN, cand_te = 0;       // overlap / extend: best end-of-query score this lane has seen, and its row
 	if(tlen != 0u && first) begs[0] = 0;
 	uint64_t twin = 0;
 	if(tlen) __builtin_memcpy(&twin, tp, 8);
@@ -408,11 +409,11 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			}
 			const uint32_t fm = x_max(f, mg[k]);
 			f = x_sub(fm, uk);
-			accR[k >> 3] = x_acc(accR[k >> 3], x_minu(x_sub(fm, mg[k]), ONE), TWO);
+			if constexpr (PW != 0) accR[k >> 3] = x_acc(accR[k >> 3], x_minu(x_sub(fm, mg[k]), ONE), TWO);
 			const uint32_t n = x_sub(h, ee[k]);
 			accD[k >> 3] = x_acc(accD[k >> 3], x_minu(n, ONE), TWO);
-			const uint32_t ne = x_minu(n, NGOQ);
-			accO[k >> 3] = x_acc(accO[k >> 3], x_satsubu(ne, NGOQ1), TWO);
+			const uint32_t ne = (PW == 0) ? 0u : x_minu(n, NGOQ);
+			if constexpr (PW != 0) accO[k >> 3] = x_acc(accO[k >> 3], x_satsubu(ne, NGOQ1), TWO);
 			accM[k >> 3] = x_acc(accM[k >> 3], x_minu(x_sub(h, S[k]), ONE), TWO);
 			const uint32_t un = x_sub(h, v);
 			v = x_sub(h, uk);
@@ -458,6 +459,11 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				}
 			}
 		} else { accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u; if constexpr (PW == 2) accD2 |= (mov == 1u) ? kd1 : 0u; }
+		if constexpr (PW == 0){
+			// linear gaps: every gap is opened at length 1 (R and Od always set); accR is kept inverted, accO is not
+#pragma unroll
+			for(int n = 0; n < NACC; n++){ accR[n] = 0u; accO[n] = (W >= 8) ? 0xFF00FF00u : (((1u << W) - 1u) << 8) * 0x00010001u; }
+		}
 		// The code dwords of this row: ND per lane.  Rows are stored in groups of four (bsa_common.h): the lane keeps the
 		// dwords of the group's rows in registers and stores whole 16-byte pieces when the group (or the pair) ends.
 		{
@@ -532,23 +538,52 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			if((i & LM) == (uint32_t)jl) begq = (int)rbeg;
 			const bool lastrow = i + 1u == tlen;
 			if(((i & LM) == LM || lastrow) && (uint32_t)jl <= (i & LM)) begs[(i & ~LM) + 1u + (uint32_t)jl] = begq;
-			if(lastrow){
+			// H at band position pos of the new row: ubegs of its block + the block's u up to it (getscore, bsalign.h:3187-3197);
+			// meaningful in the lane that owns the block
+			auto score_at = [&](uint32_t pos) -> int {
+				const uint32_t b = pos / W, kk = pos % W;
+				const bool hi = b >= (uint32_t)L;
+				int sc = HB + (hi ? x_hi16(Psh) : x_lo16(Psh)) + (int)b * W * GE;
+#pragma unroll
+				for(int k = 0; k < W; k++){
+					const uint32_t uu = (k == 0) ? tmpU0 : U[k - 1];
+					sc += ((uint32_t)k <= kk) ? ((hi ? x_hi8(uu) : x_lo8(uu)) + GE) : 0;
+				}
+				return sc;
+			};
+			if(mode != BSA_MODE_GLOBAL && rbeg + BW >= qlen){
+				// overlap / extend: while the band touches the query end, H at query column qlen - 1 is a candidate end
+				// (bsalign.h:4023-4032); the lane that owns that cell keeps the best one it has seen (strictly greater wins)
+				const uint32_t pos = qlen - 1u - rbeg;
+				if(((pos / W) & (uint32_t)(L - 1)) == (uint32_t)jl){
+					const int sc = score_at(pos);
+					if(sc > cand_sc){ cand_sc = sc; cand_te = (int)i; }
+				}
+			}
+			if(lastrow && mode == BSA_MODE_GLOBAL){
 				// global score = H at query column qlen - 1 of the last row (bsalign.h:4034-4037), kept in begs[tlen + 1]
 				const uint32_t pos = qlen - 1u - rbeg;
 				if(pos >= (uint32_t)BW){ if(first) begs[tlen + 1u] = (int)0x80000000u; }        // band never reached the query end
-				else {
-					const uint32_t b = pos / W, kk = pos % W;
-					if((b & (uint32_t)(L - 1)) == (uint32_t)jl){
-						const bool hi = b >= (uint32_t)L;
-						int sc = HB + (hi ? x_hi16(Psh) : x_lo16(Psh)) + (int)b * W * GE;
+				else if(((pos / W) & (uint32_t)(L - 1)) == (uint32_t)jl) begs[tlen + 1u] = score_at(pos);
+			} else if(lastrow){
+				// end record (bsa_common.h bsa_code_end_t): the candidates and the last row itself, per reference block, in natural
+				// band order (row_max is taken by the traceback kernel)
+				bsa_code_end_t *er = (bsa_code_end_t*)(rowp + (size_t)bsa_code_rows(tlen) * (64u * CWD));
 #pragma unroll
-						for(int k = 0; k < W; k++){
-							const uint32_t uu = (k == 0) ? tmpU0 : U[k - 1];
-							sc += ((uint32_t)k <= kk) ? ((hi ? x_hi8(uu) : x_lo8(uu)) + GE) : 0;
-						}
-						begs[tlen + 1u] = sc;
+				for(int q = 0; q < 16 / L; q++){ er->cand_sc[jl + L * q] = q ? BSA_SCORE_MIN : cand_sc; er->cand_te[jl + L * q] = q ? 0 : cand_te; }
+				int8_t *ub = (int8_t*)(er + 1);
+#pragma unroll
+				for(int hf = 0; hf < 2; hf++){
+					const int b = jl + L * hf;
+					er->ubegs[b * CR] = HB + (hf ? x_hi16(Psh) : x_lo16(Psh)) + b * W * GE;
+					if constexpr (CR == 2) er->ubegs[b * CR + 1] = HB + (hf ? x_hi16(PM) : x_lo16(PM)) + (b * W + W / 2) * GE;
+#pragma unroll
+					for(int k = 0; k < W; k++){
+						const uint32_t uu = (k == 0) ? tmpU0 : U[k - 1];
+						ub[b * W + k] = (int8_t)((hf ? x_hi8(uu) : x_lo8(uu)) + GE);
 					}
 				}
+				if(last){ er->ubegs[16] = HB + x_hi16(PN) + BW * GE; er->rbeg_last = (int)rbeg; }
 			}
 		}
 		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
@@ -611,6 +646,11 @@ template<int W, int L>
 __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
 	x_forward<W, L>(a, a.first, a.count, blockIdx.x);
 }
+// linear gaps (piecewise 0)
+template<int W, int L>
+__global__ void __launch_bounds__(256) k_align8_fwd_x0(const Align8Args a){
+	x_forward<W, L, 0>(a, a.first, a.count, blockIdx.x);
+}
 // two-piece gaps (bandwidth 128): 8 bits per band cell
 __global__ void __launch_bounds__(256) k_align8_fwd_x2(const Align8Args a){
 	x_forward<8, 8, 2>(a, a.first, a.count, blockIdx.x);
@@ -628,21 +668,20 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x_mix(const Align8Args a, co
 // Exact arithmetic is the reference's arithmetic only while nothing saturates: the guard of the compact path
 // (bsa_align8_codes_supported) plus room for the frame shift by 2 |gape| and for the int16 block offsets.
 bool bsa_align8_x_supported(const Align8Args &a, int pw){
-	if((a.mode & 3) != BSA_MODE_GLOBAL) return false;
 	const uint32_t W = a.bw / 16;
 	const int ge = -(int)(int8_t)a.gape1, go = -(int)(int8_t)a.gapo1, m = a.smax, n = -a.smin;
-	if(ge < 0 || go <= 0 || m < 0 || n < 0) return false;
+	if(ge < 0 || go < 0 || m < 0 || n < 0 || (go == 0) != (pw == 0)) return false;
 	int g = go + ge;
 	if(pw == 2){
 		// two pieces: bandwidth 128 only; piece 2 opens dearer and extends cheaper (bsalign.h:2084-2092 guarantees it),
 		// the bound is taken with the dearer opening
-		if(W != 8) return false;
+		if(W != 8 || (a.mode & 3) != BSA_MODE_GLOBAL) return false;
 		const int ge2 = -(int)(int8_t)a.gape2, go2 = -(int)(int8_t)a.gapo2;
 		if(ge2 < 0 || go2 <= go || ge2 >= ge) return false;
 		g = std::max(g, go2 + ge2);
 		if(m + 3 * g > 64 || n + m + g > 100) return false;      // the compact path's own bound (bsa_align8_codes_supported)
 	} else {
-		if(pw != 1 || !bsa_align8_codes_supported(a, pw)) return false;
+		if(pw > 1 || !bsa_align8_codes_supported(a, pw)) return false;
 		if(!(W == 4 || W == 8 || W == 16)) return false;
 	}
 	const int cfirst = std::min(a.smin, -g) - 1 - a.smax - g;
@@ -656,6 +695,15 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;
 		hipLaunchKernelGGL(k_align8_fwd_x2, dim3(b8), dim3(256), 0, st, a);
+		return hipGetLastError();
+	}
+	if(pw == 0){
+		switch(a.bw / 16){
+			case 4:  hipLaunchKernelGGL((k_align8_fwd_x0<4, 8>), dim3(b8), dim3(256), 0, st, a); break;
+			case 8:  hipLaunchKernelGGL((k_align8_fwd_x0<16, 4>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a); break;
+			case 16: hipLaunchKernelGGL((k_align8_fwd_x0<16, 8>), dim3(b8), dim3(256), 0, st, a); break;
+			default: return hipErrorInvalidValue;
+		}
 		return hipGetLastError();
 	}
 	switch(a.bw / 16){
