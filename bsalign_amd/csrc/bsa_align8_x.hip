@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x2(const Align8Args a){
 // eight lanes per pair, the others the first a.count - n8 pairs four lanes per pair.  One launch: the short blocks start
 // first and the dispatcher hands the long ones to whichever CU has room, so pairs of one length no longer finish in
 // lock-step rounds with a nearly empty last one.
-__global__ void __launch_bounds__(256) k_align8_fwd_x_mix(const Align8Args a, const uint32_t nb8, const uint32_t n8){
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_x_mix(const Align8Args a, const uint32_t nb8, const uint32_t n8){
 	if(blockIdx.x < nb8) x_forward<8, 8>(a, a.first + (a.count - n8), n8, blockIdx.x);
 	else x_forward<16, 4>(a, a.first, a.count - n8, blockIdx.x - nb8);
 }

@@ -756,6 +756,219 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 	cig_cnt[ppos] = ncig;
 }
 
+// ---------------------------------------------------------------------------------------------
+// traceback, ONE walk per wave (few long pairs: C3 has 16 walks per SIMD, far too few to hide a lane-per-walk chain)
+// ---------------------------------------------------------------------------------------------
+// Every decision of striped_seqedit_backtrace (bsalign.h:986-1010) is a function of the cell alone, so the 64 lanes
+// evaluate the 63 cells that FOLLOW the walker on its diagonal -- lane i looks at (x - i, y - i): bases equal? if not,
+// the two plane bits of rows y - i + 1 and y - i at that column -- and one ballot finds the first cell that is an
+// insertion or a deletion.  Everything before it is a run of matches / mismatches taken in one step (a CIGAR run of op 0
+// of that length), then the I or D moves the diagonal and the lanes behind it re-evaluate.  Steps per walk = indels +
+// tiles instead of one per column.  The walker's state (x, y, CIGAR word, counters) is wave-uniform and lives in SGPRs.
+// A tile = 64 consecutive rows (lane i owns row R_hi - i), a window of EW_WW words per plane of each row in LDS -- the
+// whole row for bands up to 256 columns, else 256 columns centred on the diagonal -- 4 KB per tile; the target base of a
+// lane's row is fixed for the tile; the query bases sit in a 512-byte LDS window refilled every few tiles.  A lookup
+// outside the band (the reference's unsigned position arithmetic, plane_bit above) or outside the window takes the
+// literal per-lane path with plain loads.
+#define EW_WW 4
+#define EW_QWIN 512
+__global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt){
+	__shared__ u64 tile[64][2][EW_WW];
+	__shared__ uint32_t s_beg[64], s_ws[64];
+	__shared__ __attribute__((aligned(8))) uint8_t s_q[EW_QWIN];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t ppos = a.first + blockIdx.x, pair = a.order[ppos];
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	if(a.status[pair] != 0u){ if(lane == 0){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint32_t BW = a.bw ? a.bw : bsa_edit_bw_eff(qlen, tlen, a.mode & 3, a.bandwidth), NW = BW / 64u;
+	const uint8_t *qs = a.qst + a.qpoff[pair];
+	const uint8_t *ts = a.tst + a.tpoff[pair];
+	const u64 *rows = (const u64*)(a.rows + a.slot_off[ppos]);
+	const int type = a.mode & 3;
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+	auto plane_bit = [&](uint32_t row, int plane, long pos) -> int {         // as in k_edit_trace
+		const uint32_t pu = (uint32_t)pos;
+		const uint32_t p = ((pu / NW) & 63u) * NW + (pu % NW);
+		return (int)((rows[(size_t)row * (2 * NW) + (size_t)plane * NW + (p >> 6)] >> (p & 63u)) & 1ull);
+	};
+	auto beg_of_row = [&](uint32_t r) -> uint32_t {
+		if(r == 0 || type != BSA_MODE_GLOBAL) return 0u;
+		uint32_t c = (uint32_t)(((u64)(r - 1) * qlen) / tlen);
+		c = (c < BW / 2) ? 0u : c - BW / 2;
+		return (c + BW > qround) ? qround - BW : c;
+	};
+	// ---- end cell and score (uniform; the same statements as k_edit_trace, the row scans spread over the lanes)
+	int rx = (int)qlen - 1, ry = (int)tlen - 1, smin = 0x7FFFFFFF, score = 0;
+	if(type == BSA_MODE_GLOBAL){
+		const uint32_t rbl = beg_of_row(tlen);
+		const u64 *lr = rows + (size_t)tlen * (2 * NW);
+		int part = 0;
+		for(uint32_t k = lane; k < NW; k += 64u) part += __popcll(lr[NW + k]) - __popcll(lr[k]);
+		for(uint32_t k = qlen + 1u + lane; k <= rbl + BW; k += 64u) part += plane_bit(tlen, 0, (long)(k - 1 - rbl)) - plane_bit(tlen, 1, (long)(k - 1 - rbl));
+		for(int o = 32; o; o >>= 1) part += __shfl_xor(part, o);
+		score = a.fwd_sbeg[ppos] + part;
+	} else {
+		smin = a.fwd_smin[ppos]; ry = a.fwd_ry[ppos];
+		if(type == BSA_MODE_EXTEND){     // striped_seqedit_rowmin (:813-963): first strict minimum of the prefix sums of the last row
+			const u64 *lr = rows + (size_t)tlen * (2 * NW);
+			// lane l owns words l, l + 64, ... : word totals first, then the scan inside the words
+			int best = (int)tlen; uint32_t pmin = 0; int base = (int)tlen;
+			for(uint32_t w0 = 0; w0 < NW; w0 += 64u){
+				const uint32_t w = w0 + lane;
+				const u64 pl0 = w < NW ? lr[w] : 0ull, pl1 = w < NW ? lr[NW + w] : 0ull;
+				int tot = __popcll(pl1) - __popcll(pl0), pre = tot;         // inclusive prefix over the lanes
+				for(int o = 1; o < 64; o <<= 1){ const int v = __shfl_up(pre, o); if((int)lane >= o) pre += v; }
+				int sc = base + pre - tot, lb = 0x7FFFFFFF; uint32_t lp = 0;
+				if(w < NW){
+					for(uint32_t b = 0; b < 64u; b++){
+						sc += (int)((pl1 >> b) & 1ull) - (int)((pl0 >> b) & 1ull);
+						if(sc < lb){ lb = sc; lp = w * 64u + b; }
+					}
+				}
+				for(int o = 1; o < 64; o <<= 1){            // first strict minimum over the lanes: smaller value, then smaller position
+					const int vb = __shfl_xor(lb, o); const uint32_t vp = __shfl_xor(lp, o);
+					if(vb < lb || (vb == lb && vp < lp)){ lb = vb; lp = vp; }
+				}
+				if(lb < best){ best = lb; pmin = lp; }
+				base += __shfl(pre, 63);
+			}
+			if(best < smin){ smin = best; rx = (int)pmin; ry = (int)tlen - 1; }
+		}
+	}
+	rx = __builtin_amdgcn_readfirstlane(rx); ry = __builtin_amdgcn_readfirstlane(ry);
+	// ---- backtrace
+	uint32_t *cig_end = (uint32_t*)((uint8_t*)rows + (size_t)(tlen + 1 + a.pad_rows) * (2 * NW) * 8);
+	uint32_t ncig = 0, cg = 0;
+	auto cig_push = [&](uint32_t w){ ncig++; if(lane == 0) *(cig_end - ncig) = w; };
+	auto emit = [&](uint32_t op, uint32_t len){
+		if(op == (cg & 0xfu)) cg += 0x10u * len;
+		else { if(cg) cig_push(cg); cg = (0x10u * len) | op; }
+	};
+	int x = rx, y = ry;
+	const bool bad = (rx >= (int)qlen);
+	rs.qe = x + 1; rs.te = y + 1;
+	const bool dbl_ok = (u64)tlen * (u64)qlen < (1ull << 52);
+	const double inv_t = 1.0 / (double)tlen;
+	int qw_lo = 0, qw_hi = -1;                       // query bases [qw_lo, qw_hi] are in s_q
+	while(!bad && x >= 0 && y >= 0){
+		// ---- tile: lane i owns row r = R_hi - i
+		const int R_hi = y + 1;
+		const int r = R_hi - (int)lane;
+		const bool rvalid = r >= 0;
+		uint32_t beg = 0;
+		if(type == BSA_MODE_GLOBAL && r >= 1){
+			const u64 n = (u64)(uint32_t)(r - 1) * qlen;
+			uint32_t c;
+			if(dbl_ok){
+				u64 qe = (u64)((double)n * inv_t);
+				long rem = (long)(n - qe * (u64)tlen);
+				if(rem < 0) qe--; else if(rem >= (long)tlen) qe++;
+				c = (uint32_t)qe;
+			} else c = (uint32_t)(n / tlen);
+			c = (c < BW / 2) ? 0u : c - BW / 2;
+			beg = (c + BW > qround) ? qround - BW : c;
+		}
+		uint32_t ws = 0;
+		if(NW > EW_WW){
+			const int pe = (x - (int)lane) - (int)beg;
+			int w = (pe >> 6) - 1;
+			w = w < 0 ? 0 : w;
+			ws = (uint32_t)w > NW - EW_WW ? NW - EW_WW : (uint32_t)w;
+		}
+		if(x > qw_hi || x - 128 < qw_lo){              // query window: [qw_lo, qw_lo + 512) with x near its upper end
+			if(!(qw_lo == 0 && x <= qw_hi)){
+				int lo = (x + 8 - EW_QWIN) & ~7;
+				lo = lo < 0 ? 0 : lo;
+				qw_lo = lo; qw_hi = lo + EW_QWIN - 1;
+				__syncthreads();
+				if((uint32_t)lo + 8u * lane < qlen + 8u){ u64 v; __builtin_memcpy(&v, qs + lo + 8 * lane, 8); *(u64*)&s_q[8 * lane] = v; }
+			}
+		}
+		__syncthreads();
+		if(rvalid){
+			const u64 *rp = rows + (size_t)(uint32_t)r * (2 * NW) + ws;
+			if(NW == EW_WW){
+				const uint4 *r4 = (const uint4*)rp;
+				uint4 *t4 = (uint4*)&tile[lane][0][0];
+				const uint4 v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3];
+				t4[0] = v0; t4[1] = v1; t4[2] = v2; t4[3] = v3;
+			} else {
+#pragma unroll
+				for(int w = 0; w < EW_WW; w++){
+					const bool in = ws + (uint32_t)w < NW;
+					tile[lane][0][w] = in ? rp[w] : 0ull;
+					tile[lane][1][w] = in ? rp[NW + w] : 0ull;
+				}
+			}
+		}
+		s_beg[lane] = beg; s_ws[lane] = ws;
+		const uint32_t tb = r >= 1 ? (uint32_t)ts[r - 1] : 0xffu;
+		__syncthreads();
+		const uint32_t begn = s_beg[(lane + 1u) & 63u], wsn = s_ws[(lane + 1u) & 63u];
+		int k0 = 0;
+		// ---- walk inside the tile
+		while(true){
+			const int d = (int)lane - k0;
+			const int xi = x - d, yi = y - d;
+			const bool inr = d >= 0 && lane <= 62u && xi >= 0 && yi >= 0 && xi >= qw_lo;
+			const uint32_t qb = inr ? (uint32_t)s_q[xi - qw_lo] : 0xfeu;
+			const bool eq = qb == tb;
+			const uint32_t p1 = (uint32_t)(xi - (int)beg), p0 = (uint32_t)(xi - (int)begn);
+			const uint32_t w1 = (p1 >> 6) - ws, w0 = (p0 >> 6) - wsn;
+			const bool fast = p1 < BW && p0 < BW && w1 < (uint32_t)EW_WW && w0 < (uint32_t)EW_WW;
+			int u1, u2, u3, u4;
+			{
+				const uint32_t a1 = w1 & (EW_WW - 1u), a0 = w0 & (EW_WW - 1u);
+				const u64 m3 = tile[lane][0][a1], m4 = tile[lane][1][a1];
+				const u64 m1 = tile[(lane + 1u) & 63u][0][a0], m2 = tile[(lane + 1u) & 63u][1][a0];
+				u3 = (int)((m3 >> (p1 & 63u)) & 1ull); u4 = (int)((m4 >> (p1 & 63u)) & 1ull);
+				u1 = (int)((m1 >> (p0 & 63u)) & 1ull); u2 = (int)((m2 >> (p0 & 63u)) & 1ull);
+			}
+			if(__any(inr && !eq && !fast)){
+				if(inr && !eq && !fast){
+					u3 = plane_bit((uint32_t)yi + 1u, 0, (long)xi - (long)beg); u4 = plane_bit((uint32_t)yi + 1u, 1, (long)xi - (long)beg);
+					u1 = plane_bit((uint32_t)yi, 0, (long)xi - (long)begn); u2 = plane_bit((uint32_t)yi, 1, (long)xi - (long)begn);
+				}
+			}
+			const bool isI = inr && !eq && u3 == 0 && u4 == 1;
+			const bool isD = inr && !eq && !isI && u1 == 1 && u2 == 0;
+			const u64 below = (1ull << k0) - 1ull;                  // k0 <= 63
+			const u64 stopm = __ballot(!inr || isI || isD) & ~below;     // lane 63 always stops
+			const int k = __builtin_ctzll(stopm);
+			const int n = k - k0;
+			if(n > 0){
+				const u64 range = ((1ull << k) - 1ull) & ~below;
+				const int mism = __popcll(__ballot(inr && !eq) & range);
+				rs.mat += n - mism; rs.mis += mism;
+				emit(0u, (uint32_t)n);
+				x -= n; y -= n;
+			}
+			const bool kI = (__ballot(isI) >> k) & 1ull, kD = (__ballot(isD) >> k) & 1ull;
+			if(kI){ rs.ins++; emit(1u, 1u); x--; k0 = k; }
+			else if(kD){ rs.del++; emit(2u, 1u); y--; k0 = k + 1; }
+			else break;
+			if(k0 > 62) break;
+		}
+	}
+	if(!bad){
+		rs.qb = x + 1; rs.tb = y + 1;
+		if(rs.qb){ emit(1u, (uint32_t)rs.qb); rs.ins += rs.qb; rs.qb = 0; }
+		if((type == BSA_MODE_GLOBAL || type == BSA_MODE_EXTEND) && rs.tb){ emit(2u, (uint32_t)rs.tb); rs.del += rs.tb; rs.tb = 0; }
+		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
+		if(cg) cig_push(cg);
+		if(type == BSA_MODE_OVERLAP) rs.score = smin + rs.te - rs.tb;
+		else if(type == BSA_MODE_EXTEND) rs.score = smin;
+		else rs.score = score;
+	} else {
+		if(lane == 0) atomicOr(&a.status[pair], BSA_ST_TRACE);
+		rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+		ncig = 0;
+	}
+	if(lane == 0){ out[pair] = rs; cig_cnt[ppos] = ncig; }
+}
+
 // stage one pair per block: query -> two bit planes (bit p of plane b = bit b of base p; zero beyond qlen),
 // query and target bytes copied (the traceback compares bases), codes validated
 __global__ void __launch_bounds__(256) k_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
@@ -869,6 +1082,16 @@ hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t 
 		per_cu[0] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_edit_trace<false>, 64, 0) == hipSuccess && v > 0) ? v : 32;
 		per_cu[1] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_edit_trace<true>, 64, 0) == hipSuccess && v > 0) ? v : 32;
 		(void)hipGetLastError();
+	}
+	// few long walks: one walk per wave (k_edit_trace_wave); BSA_EDIT_TRACE_WAVE=0/1 overrides
+	{
+		bool wave = a.count <= 8u * (uint32_t)cus * 32u;
+		if(const char *e = getenv("BSA_EDIT_TRACE_WAVE")) wave = e[0] == '1';
+		if(getenv("BSA_EDIT_TRACE_LANES") || getenv("BSA_EDIT_TRACE_COOP")) wave = false;
+		if(wave){
+			hipLaunchKernelGGL(k_edit_trace_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
+			return hipGetLastError();
+		}
 	}
 	const char *ce = getenv("BSA_EDIT_TRACE_COOP");
 	const bool coop_ok = !(ce && ce[0] == '0');
