@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 #define EW_WW 4
 #define EW_QWIN 512
 __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt){
-	__shared__ u64 tile[64][2][EW_WW];
+	__shared__ uint32_t tile[64][4 * EW_WW + 1];     // rows padded to 17 dwords: lanes 64 bytes apart would meet in 4 of the 64 banks
 	__shared__ uint32_t s_beg[64], s_ws[64];
 	__shared__ __attribute__((aligned(8))) uint8_t s_q[EW_QWIN];
 	const uint32_t lane = threadIdx.x;
@@ -840,8 +840,15 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	rx = __builtin_amdgcn_readfirstlane(rx); ry = __builtin_amdgcn_readfirstlane(ry);
 	// ---- backtrace
 	uint32_t *cig_end = (uint32_t*)((uint8_t*)rows + (size_t)(tlen + 1 + a.pad_rows) * (2 * NW) * 8);
-	uint32_t ncig = 0, cg = 0;
-	auto cig_push = [&](uint32_t w){ ncig++; if(lane == 0) *(cig_end - ncig) = w; };
+	// CIGAR words (back to front, word m at cig_end - (m + 1)) are collected one per lane and leave as one 256-byte store per
+	// 64 words: a store per word would put a wait for the previous store into every step
+	uint32_t ncig = 0, cg = 0, cigreg = 0;
+	auto cig_push = [&](uint32_t w){
+		const uint32_t j = ncig & 63u;
+		if(lane == j) cigreg = w;
+		ncig++;
+		if(j == 63u) *(cig_end - (ncig - 63u + lane)) = cigreg;
+	};
 	auto emit = [&](uint32_t op, uint32_t len){
 		if(op == (cg & 0xfu)) cg += 0x10u * len;
 		else { if(cg) cig_push(cg); cg = (0x10u * len) | op; }
@@ -852,11 +859,10 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	const bool dbl_ok = (u64)tlen * (u64)qlen < (1ull << 52);
 	const double inv_t = 1.0 / (double)tlen;
 	int qw_lo = 0, qw_hi = -1;                       // query bases [qw_lo, qw_hi] are in s_q
-	while(!bad && x >= 0 && y >= 0){
-		// ---- tile: lane i owns row r = R_hi - i
-		const int R_hi = y + 1;
+	// a tile's rows for lane i: row R_hi - i, window start ws (in words), band offset beg, target base of the row
+	struct TileRegs { u64 w[2][EW_WW]; uint32_t beg, ws, tb; };
+	auto tile_fetch = [&](int R_hi, int xs, TileRegs &t){
 		const int r = R_hi - (int)lane;
-		const bool rvalid = r >= 0;
 		uint32_t beg = 0;
 		if(type == BSA_MODE_GLOBAL && r >= 1){
 			const u64 n = (u64)(uint32_t)(r - 1) * qlen;
@@ -872,11 +878,40 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		}
 		uint32_t ws = 0;
 		if(NW > EW_WW){
-			const int pe = (x - (int)lane) - (int)beg;
+			const int pe = (xs - (int)lane) - (int)beg;
 			int w = (pe >> 6) - 1;
 			w = w < 0 ? 0 : w;
 			ws = (uint32_t)w > NW - EW_WW ? NW - EW_WW : (uint32_t)w;
 		}
+		t.beg = beg; t.ws = ws;
+		t.tb = r >= 1 ? (uint32_t)ts[r - 1] : 0xffu;
+		if(r >= 0){
+			const u64 *rp = rows + (size_t)(uint32_t)r * (2 * NW) + ws;
+			if(NW == EW_WW){
+				const uint4 *r4 = (const uint4*)rp;
+				const uint4 v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3];
+				t.w[0][0] = (u64)v0.x | ((u64)v0.y << 32); t.w[0][1] = (u64)v0.z | ((u64)v0.w << 32);
+				t.w[0][2] = (u64)v1.x | ((u64)v1.y << 32); t.w[0][3] = (u64)v1.z | ((u64)v1.w << 32);
+				t.w[1][0] = (u64)v2.x | ((u64)v2.y << 32); t.w[1][1] = (u64)v2.z | ((u64)v2.w << 32);
+				t.w[1][2] = (u64)v3.x | ((u64)v3.y << 32); t.w[1][3] = (u64)v3.z | ((u64)v3.w << 32);
+			} else {
+#pragma unroll
+				for(int w = 0; w < EW_WW; w++){
+					const bool in = ws + (uint32_t)w < NW;
+					t.w[0][w] = in ? rp[w] : 0ull;
+					t.w[1][w] = in ? rp[NW + w] : 0ull;
+				}
+			}
+		} else {
+#pragma unroll
+			for(int w = 0; w < EW_WW; w++){ t.w[0][w] = 0ull; t.w[1][w] = 0ull; }
+		}
+	};
+	TileRegs pf;
+	int pf_R = -1;                                   // the tile (its R_hi) whose rows are on their way in pf
+	while(!bad && x >= 0 && y >= 0){
+		const int R_hi = y + 1;
+		if(pf_R != R_hi) tile_fetch(R_hi, x, pf);
 		if(x > qw_hi || x - 128 < qw_lo){              // query window: [qw_lo, qw_lo + 512) with x near its upper end
 			if(!(qw_lo == 0 && x <= qw_hi)){
 				int lo = (x + 8 - EW_QWIN) & ~7;
@@ -887,65 +922,59 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 			}
 		}
 		__syncthreads();
-		if(rvalid){
-			const u64 *rp = rows + (size_t)(uint32_t)r * (2 * NW) + ws;
-			if(NW == EW_WW){
-				const uint4 *r4 = (const uint4*)rp;
-				uint4 *t4 = (uint4*)&tile[lane][0][0];
-				const uint4 v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3];
-				t4[0] = v0; t4[1] = v1; t4[2] = v2; t4[3] = v3;
-			} else {
 #pragma unroll
-				for(int w = 0; w < EW_WW; w++){
-					const bool in = ws + (uint32_t)w < NW;
-					tile[lane][0][w] = in ? rp[w] : 0ull;
-					tile[lane][1][w] = in ? rp[NW + w] : 0ull;
-				}
-			}
+		for(int w = 0; w < EW_WW; w++){
+			tile[lane][2 * w] = (uint32_t)pf.w[0][w]; tile[lane][2 * w + 1] = (uint32_t)(pf.w[0][w] >> 32);
+			tile[lane][2 * EW_WW + 2 * w] = (uint32_t)pf.w[1][w]; tile[lane][2 * EW_WW + 2 * w + 1] = (uint32_t)(pf.w[1][w] >> 32);
 		}
-		s_beg[lane] = beg; s_ws[lane] = ws;
-		const uint32_t tb = r >= 1 ? (uint32_t)ts[r - 1] : 0xffu;
+		s_beg[lane] = pf.beg; s_ws[lane] = pf.ws;
+		const uint32_t beg = pf.beg, ws2 = 2u * pf.ws, tb = pf.tb;
+		const int r_own = R_hi - (int)lane;
+		const u64 tilem = __ballot(lane <= 62u && r_own >= 1);       // lanes whose cell lies inside the target (y - d >= 0) with both rows in the tile
 		__syncthreads();
-		const uint32_t begn = s_beg[(lane + 1u) & 63u], wsn = s_ws[(lane + 1u) & 63u];
+		const uint32_t begn = s_beg[(lane + 1u) & 63u], wsn2 = 2u * s_ws[(lane + 1u) & 63u];
+		// the next tile starts 63 rows further up (unless this one ends early): its rows travel while this one is walked
+		pf_R = R_hi - 63;
+		if(pf_R >= 1) tile_fetch(pf_R, x - 63, pf);
+		const int xlo = qw_lo;                           // >= 0
 		int k0 = 0;
 		// ---- walk inside the tile
 		while(true){
-			const int d = (int)lane - k0;
-			const int xi = x - d, yi = y - d;
-			const bool inr = d >= 0 && lane <= 62u && xi >= 0 && yi >= 0 && xi >= qw_lo;
-			const uint32_t qb = inr ? (uint32_t)s_q[xi - qw_lo] : 0xfeu;
-			const bool eq = qb == tb;
+			const int xi = (x + k0) - (int)lane;         // lanes below k0 look at cells in front of the walker: masked out of every ballot
+			const bool inq = xi >= xlo;
+			const uint32_t qb = (uint32_t)s_q[(uint32_t)(xi - qw_lo) & (EW_QWIN - 1u)];
+			const bool ne = qb != tb;
 			const uint32_t p1 = (uint32_t)(xi - (int)beg), p0 = (uint32_t)(xi - (int)begn);
-			const uint32_t w1 = (p1 >> 6) - ws, w0 = (p0 >> 6) - wsn;
-			const bool fast = p1 < BW && p0 < BW && w1 < (uint32_t)EW_WW && w0 < (uint32_t)EW_WW;
-			int u1, u2, u3, u4;
-			{
-				const uint32_t a1 = w1 & (EW_WW - 1u), a0 = w0 & (EW_WW - 1u);
-				const u64 m3 = tile[lane][0][a1], m4 = tile[lane][1][a1];
-				const u64 m1 = tile[(lane + 1u) & 63u][0][a0], m2 = tile[(lane + 1u) & 63u][1][a0];
-				u3 = (int)((m3 >> (p1 & 63u)) & 1ull); u4 = (int)((m4 >> (p1 & 63u)) & 1ull);
-				u1 = (int)((m1 >> (p0 & 63u)) & 1ull); u2 = (int)((m2 >> (p0 & 63u)) & 1ull);
-			}
-			if(__any(inr && !eq && !fast)){
-				if(inr && !eq && !fast){
-					u3 = plane_bit((uint32_t)yi + 1u, 0, (long)xi - (long)beg); u4 = plane_bit((uint32_t)yi + 1u, 1, (long)xi - (long)beg);
-					u1 = plane_bit((uint32_t)yi, 0, (long)xi - (long)begn); u2 = plane_bit((uint32_t)yi, 1, (long)xi - (long)begn);
+			const uint32_t d1 = (p1 >> 5) - ws2, d0 = (p0 >> 5) - wsn2;
+			const bool fast = p1 < BW && p0 < BW && d1 < 2u * EW_WW && d0 < 2u * EW_WW;
+			const uint32_t a1 = d1 & (2u * EW_WW - 1u), a0 = d0 & (2u * EW_WW - 1u);
+			uint32_t m3 = tile[lane][a1] >> (p1 & 31u), m4 = tile[lane][2 * EW_WW + a1] >> (p1 & 31u);
+			uint32_t m1 = tile[(lane + 1u) & 63u][a0] >> (p0 & 31u), m2 = tile[(lane + 1u) & 63u][2 * EW_WW + a0] >> (p0 & 31u);
+			const u64 valid = __ballot(inq) & tilem;
+			const u64 slow = __ballot(ne && !fast) & valid;
+			if(slow){
+				if(ne && !fast && ((slow >> lane) & 1ull)){
+					const int yi = (y + k0) - (int)lane;
+					m3 = (uint32_t)plane_bit((uint32_t)yi + 1u, 0, (long)xi - (long)beg); m4 = (uint32_t)plane_bit((uint32_t)yi + 1u, 1, (long)xi - (long)beg);
+					m1 = (uint32_t)plane_bit((uint32_t)yi, 0, (long)xi - (long)begn); m2 = (uint32_t)plane_bit((uint32_t)yi, 1, (long)xi - (long)begn);
 				}
 			}
-			const bool isI = inr && !eq && u3 == 0 && u4 == 1;
-			const bool isD = inr && !eq && !isI && u1 == 1 && u2 == 0;
+			// I: (u3, u4) == (0, 1); else D: (u1, u2) == (1, 0)
+			const u64 nem = __ballot(ne) & valid;
+			const u64 mI = __ballot(((~m3 & m4) & 1u) != 0u) & nem;
+			const u64 mD = __ballot(((m1 & ~m2) & 1u) != 0u) & nem & ~mI;
 			const u64 below = (1ull << k0) - 1ull;                  // k0 <= 63
-			const u64 stopm = __ballot(!inr || isI || isD) & ~below;     // lane 63 always stops
+			const u64 stopm = (~valid | mI | mD) & ~below;          // lane 63 always stops
 			const int k = __builtin_ctzll(stopm);
 			const int n = k - k0;
 			if(n > 0){
 				const u64 range = ((1ull << k) - 1ull) & ~below;
-				const int mism = __popcll(__ballot(inr && !eq) & range);
+				const int mism = __popcll(nem & range);
 				rs.mat += n - mism; rs.mis += mism;
 				emit(0u, (uint32_t)n);
 				x -= n; y -= n;
 			}
-			const bool kI = (__ballot(isI) >> k) & 1ull, kD = (__ballot(isD) >> k) & 1ull;
+			const bool kI = (mI >> k) & 1ull, kD = (mD >> k) & 1ull;
 			if(kI){ rs.ins++; emit(1u, 1u); x--; k0 = k; }
 			else if(kD){ rs.del++; emit(2u, 1u); y--; k0 = k + 1; }
 			else break;
@@ -958,6 +987,7 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		if((type == BSA_MODE_GLOBAL || type == BSA_MODE_EXTEND) && rs.tb){ emit(2u, (uint32_t)rs.tb); rs.del += rs.tb; rs.tb = 0; }
 		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
 		if(cg) cig_push(cg);
+		if(lane < (ncig & 63u)) *(cig_end - ((ncig & ~63u) + lane + 1u)) = cigreg;
 		if(type == BSA_MODE_OVERLAP) rs.score = smin + rs.te - rs.tb;
 		else if(type == BSA_MODE_EXTEND) rs.score = smin;
 		else rs.score = score;
