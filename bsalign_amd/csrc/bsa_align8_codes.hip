@@ -339,6 +339,227 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 	cig_cnt[ppos] = ncig;
 }
 
+// ---- one walk per wave (bandwidth 128) ---------------------------------------------------------------------------
+// The rules above make a cell's outcome a function of the cell alone once the previous step was a match / mismatch
+// (prior_match set, no deletion run open): lane i evaluates the cell i steps further up the walker's diagonal --
+// (x - i, y - i) -- and one ballot finds the first cell that is not a match.  The run before it is taken in one step;
+// the cell that ended it (an insertion with its length scan, a row of a deletion run, a cell the lanes could not
+// decide) is then handled by the literal single-cell step, executed once for the wave on values read from that lane
+// (the walker's state lives in SGPRs).  Steps per walk = gap events + tiles, not cells.
+// A tile is 64 rows (lane i = row T - i, T = 3 mod 4 so that it is sixteen whole row groups): per row the band offsets
+// of the row and of the row above, the target base, and a window of four blocks (32 cells) of its code row around the
+// diagonal, one coalesced 16-byte load per lane (four rows of one block, bsa_code_off) transposed into LDS (stride 5
+// dwords: conflict-free).  The next tile's codes and the band offsets of the one after travel while a tile is walked.
+// Anything outside the window is read with a plain load; the query bases sit in a 512-byte LDS window.
+#define CWV_QWIN 512
+__global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
+	constexpr int W = 8, bw = 128, STR = 5;
+	constexpr uint32_t RB = 64u;
+	__shared__ uint32_t tile[64 * STR];
+	__shared__ int s_b0[16];
+	__shared__ __attribute__((aligned(8))) uint8_t s_q[CWV_QWIN];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t ppos = a.first + blockIdx.x;
+	const uint32_t pair = a.order[ppos];
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	if(a.status[pair] != 0u){ if(lane == 0){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
+	const int type = a.mode & 3;
+	const bool lin = a.gapo1 == 0;
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint8_t *qseq = a.qst + a.qpoff[pair];
+	const uint8_t *tseq = a.tst + a.tpoff[pair];
+	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
+	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
+	const uint32_t *codes = (const uint32_t*)rows;
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * RB);
+	// CIGAR words: one per lane, a 256-byte store per 64 words (word m at cig_end - (m + 1))
+	uint32_t ncig = 0, cg = 0, cigreg = 0;
+	auto cig_push = [&](uint32_t w){
+		const uint32_t j = ncig & 63u;
+		if(lane == j) cigreg = w;
+		ncig++;
+		if(j == 63u) *(cig_end - (ncig - 63u + lane)) = cigreg;
+	};
+	auto emit = [&](uint32_t op, uint32_t len){
+		if(op == (cg & 0xfu)) cg += len << 4;
+		else { if(cg) cig_push(cg); cg = (len << 4) | op; }
+	};
+	bool bad = false;
+	if(type == BSA_MODE_GLOBAL){
+		rs.score = begs[tlen + 1];
+		if(rs.score == (int)0x80000000u) bad = true;               // band never reached the query end (bsalign.h:4034)
+		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	} else codes_end_cell<W>(rows, RB, qlen, tlen, rs.score, rs.qe, rs.te);
+	rs.score = __builtin_amdgcn_readfirstlane(rs.score); rs.qe = __builtin_amdgcn_readfirstlane(rs.qe); rs.te = __builtin_amdgcn_readfirstlane(rs.te);
+	{ const int lb = begs[rs.te + 1]; if(rs.qe < lb || rs.qe >= lb + bw) bad = true; }
+	int x = rs.qe, y = rs.te;
+	rs.qe++; rs.te++;
+	int prior = 0, dlen = 0;
+	// ---- tiles
+	struct TB { int bc, bp; uint32_t tb; };
+	struct TC { uint4 w; int b0; };
+	auto fetch_begs = [&](int T, TB &t){
+		const int r = T - (int)lane;
+		if(r >= 0){ t.bc = begs[r + 1]; t.bp = begs[r]; t.tb = (uint32_t)tseq[r]; }
+		else { t.bc = 0; t.bp = 0; t.tb = 0xffu; }
+	};
+	const uint32_t gi = lane >> 2, sl4 = lane & 3u;
+	auto fetch_codes = [&](int T, const TB &tb_, int xT, TC &c){      // xT: the diagonal's column at row T
+		const int G = (T >> 2) - (int)gi;
+		const int bcg = __shfl(tb_.bc, (int)(gi * 4u));              // band offset of the group's top row
+		int pp = (xT - 4 * (int)gi) - bcg;
+		pp = pp < 0 ? 0 : pp > bw - 1 ? bw - 1 : pp;
+		int b0 = (pp >> 3) - 1;
+		b0 = b0 < 0 ? 0 : b0 > 12 ? 12 : b0;
+		c.b0 = b0;
+		if(G >= 0) c.w = *(const uint4*)(codes + ((size_t)G * 64u + (size_t)((uint32_t)b0 + sl4) * 4u));
+		else c.w = make_uint4(0, 0, 0, 0);
+	};
+	int qw_lo = 0;
+	auto q_refill = [&](int xx){
+		int lo = (xx + 8 - CWV_QWIN) & ~7;
+		lo = lo < 0 ? 0 : lo;
+		qw_lo = lo;
+		__syncthreads();
+		if((uint32_t)lo + 8u * lane < qlen + 8u){ uint64_t v; __builtin_memcpy(&v, qseq + lo + 8 * lane, 8); *(uint64_t*)&s_q[8 * lane] = v; }
+		__syncthreads();
+	};
+	TB curB, nxtB, nx2B; TC curC, nxtC;
+	int T = y | 3;
+	if(!bad){
+		q_refill(x);
+		fetch_begs(T, curB);
+		fetch_codes(T, curB, x + (T - y), curC);
+		fetch_begs(T - 64, nxtB);
+	}
+	bool walking = !bad && x >= 0 && y >= 0;
+	while(walking){
+		// ---- the tile of rows T - 63 .. T
+		__syncthreads();
+		tile[(4u * gi + 3u) * STR + sl4] = curC.w.x; tile[(4u * gi + 2u) * STR + sl4] = curC.w.y;
+		tile[(4u * gi + 1u) * STR + sl4] = curC.w.z; tile[(4u * gi + 0u) * STR + sl4] = curC.w.w;
+		if(sl4 == 0u) s_b0[gi] = curC.b0;
+		const int bc = curB.bc, bp = curB.bp;
+		const uint32_t tbs = curB.tb;
+		const uint64_t rowm = __ballot(T - (int)lane >= 0);
+		__syncthreads();
+		const int b0 = s_b0[lane >> 2];
+		int k0 = T - y;
+		// the next tile's codes (their band offsets arrived a tile ago) and the band offsets of the one after
+		if(T - 64 >= 0){ fetch_codes(T - 64, nxtB, x + (T - y) - 64, nxtC); fetch_begs(T - 128, nx2B); }
+		const uint32_t *myrow = &tile[lane * STR];
+		while(true){
+			const int xs = x + k0;
+			const int xi = xs - (int)lane;
+			const bool inq = xi >= qw_lo;
+			const uint32_t qb = (uint32_t)s_q[(uint32_t)(xi - qw_lo) & (CWV_QWIN - 1u)];
+			const uint32_t p = (uint32_t)(xi - bc);
+			const uint32_t sl = (p >> 3) - (uint32_t)b0;
+			const uint32_t wc = myrow[sl & 3u];
+			const uint32_t t = (wc >> (7u - (p & 7u))) & 0x01000101u;      // M bit 0, D bit 8, Od bit 24
+			const uint64_t mOK = __ballot(inq && p < (uint32_t)bw && sl < 4u) & rowm;
+			const uint64_t mNE = __ballot(qb != tbs);
+			const uint64_t mFM = __ballot((t & 0xffu) != 0u), mFD = __ballot((t & 0xff00u) != 0u), mFO = __ballot((t >> 24) != 0u);
+			uint64_t mPMoff = __ballot(xi == bp);                              // bsalign.h:3761-3764: ... && qb != 0
+			if((uint32_t)xs < 64u) mPMoff &= ~(1ull << xs);
+			const uint64_t mM = mOK & mFM & ~(mPMoff & mFD);
+			const uint64_t k0bit = 1ull << k0;
+			uint64_t stopm = ~mM & ~(k0bit - 1ull);
+			if(dlen){
+				if(mOK & mFO & k0bit) dlen = 0;                                 // the run ends at this cell, which is then an ordinary one
+				else stopm |= k0bit;
+			}
+			if(!prior) stopm |= k0bit;
+			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
+			const int n = k - k0;
+			if(n > 0){
+				const uint64_t range = (k == 64 ? ~0ull : ((1ull << k) - 1ull)) & ~(k0bit - 1ull);
+				const int mism = __popcll(mNE & range);
+				rs.mat += n - mism; rs.mis += mism;
+				emit(0u, (uint32_t)n);
+				x -= n; y -= n;
+			}
+			if(k == 64) break;
+			if(x < 0 || y < 0){ walking = false; break; }
+			if(x < qw_lo){ q_refill(x); k0 = k; continue; }
+			// ---- the cell at lane k, literally
+			const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)p, k);
+			if(pk >= (uint32_t)bw){ bad = true; walking = false; break; }
+			const int bpk = __builtin_amdgcn_readlane(bp, k);
+			const int b0k = __builtin_amdgcn_readlane(b0, k);
+			const uint32_t yb = pk >> 3, kk = pk & 7u, bit = 1u << (7u - kk);
+			auto code_at = [&](uint32_t blk) -> uint32_t {
+				const uint32_t s_ = blk - (uint32_t)b0k;
+				if(s_ < 4u) return tile[(uint32_t)k * STR + s_];
+				return codes[bsa_code_off((uint32_t)y, blk, 1u)];
+			};
+			const uint32_t wck = (uint32_t)__builtin_amdgcn_readfirstlane((int)code_at(yb));
+			if(dlen){
+				if((wck >> 24) & bit) dlen = 0;
+				else { emit(2u, 1u); rs.del++; y--; k0 = k + 1; if(k0 > 63) break; continue; }
+			}
+			const bool pmatch = prior && !(x == bpk && x != 0);
+			const bool fm = (wck & bit) != 0u, fd = ((wck >> 8) & bit) != 0u;
+			int bt;
+			if(pmatch) bt = fm ? 0 : fd ? 2 : 1;
+			else bt = fd ? 2 : fm ? 0 : 1;
+			prior = 1;
+			if(bt == 0){
+				if((mNE >> k) & 1ull) rs.mis++; else rs.mat++;
+				emit(0u, 1u);
+				x--; y--; k0 = k + 1;
+			} else if(bt == 1){
+				if(x <= 0){ emit(1u, 1u); x--; rs.ins++; }
+				else {
+					int sz = 0;
+					const uint32_t cand = ((wck >> 16) & 0xFFu) & ~((bit << 1) - 1u);
+					if(cand) sz = (int)__builtin_ctz(cand) - (int)(7u - kk);
+					else {
+						int left = (int)kk;
+						for(int yy = (int)yb - 1; yy >= 0 && sz == 0; yy--){
+							const uint32_t r2 = ((uint32_t)__builtin_amdgcn_readfirstlane((int)code_at((uint32_t)yy)) >> 16) & 0xFFu;
+							if(r2) sz = left + 1 + (int)__builtin_ctz(r2);
+							else left += W;
+						}
+						if(sz == 0){ bad = true; walking = false; break; }  // the reference's scan finds no length either
+					}
+					emit(1u, (uint32_t)sz);
+					x -= sz; rs.ins += sz;
+				}
+				k0 = k;
+			} else {
+				emit(2u, 1u); rs.del++;
+				y--; dlen = 1; k0 = k + 1;
+			}
+			if(k0 > 63) break;
+		}
+		if(x < 0 || y < 0) walking = false;
+		T -= 64;
+		curB = nxtB; curC = nxtC; nxtB = nx2B;
+	}
+	if(!bad && dlen && y < 0 && (!lin || x >= bw)) bad = true;        // a deletion run that reached row -1: see the general step of the LDS kernel
+	if(!bad){
+		rs.qb = x; rs.tb = y;
+		if(type == BSA_MODE_OVERLAP){ if(cg) cig_push(cg); }
+		else {
+			uint32_t op = 0, sz = 0;
+			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+			else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+			emit(op, sz);
+			if(cg) cig_push(cg);
+		}
+		rs.qb++; rs.tb++;
+		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
+		if(lane < (ncig & 63u)) *(cig_end - ((ncig & ~63u) + lane + 1u)) = cigreg;
+	} else {
+		if(lane == 0) atomicOr(&a.status[pair], BSA_ST_TRACE);
+		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+		ncig = 0;
+	}
+	if(lane == 0){ out[pair] = rs; cig_cnt[ppos] = ncig; }
+}
+
 // plain version: every access is a load (W = 16, and the reference point for the prefetching kernel)
 template<int W>
 __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
@@ -658,10 +879,14 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
 			else launch_trace_lds<4>(a, out, cig_cnt, st);
 			break;
-		case 8:
+		case 8: {
+			// one walk per wave (BSA_ALIGN8_TRACE_WAVE=0: the pair-per-lane LDS-ring kernel)
+			const char *we = getenv("BSA_ALIGN8_TRACE_WAVE");
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			else launch_trace_lds<8>(a, out, cig_cnt, st);
+			else if(we && we[0] == '0') launch_trace_lds<8>(a, out, cig_cnt, st);
+			else hipLaunchKernelGGL(k_align8_trace_codes_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
 			break;
+		}
 		case 16: hipLaunchKernelGGL((k_align8_trace_codes_simple<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
 		default: return hipErrorInvalidValue;
 	}
