@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const uint64_t mNE = __ballot(qb != tbs);
 			const uint64_t mFM = __ballot((t & 0xffu) != 0u), mFD = __ballot((t & 0xff00u) != 0u), mFO = __ballot((t >> 24) != 0u);
 			uint64_t mPMoff = __ballot(xi == bp);                              // bsalign.h:3761-3764: ... && qb != 0
-			if((uint32_t)xs < 64u) mPMoff &= ~(1ull << xs);
+			if(xs < 64) mPMoff &= ~(1ull << (xs & 63));                       // only near column 0
 			const uint64_t mM = mOK & mFM & ~(mPMoff & mFD);
 			const uint64_t k0bit = 1ull << k0;
 			uint64_t stopm = ~mM & ~(k0bit - 1ull);
@@ -483,7 +483,32 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			if(k == 64) break;
 			if(x < 0 || y < 0){ walking = false; break; }
 			if(x < qw_lo){ q_refill(x); k0 = k; continue; }
-			// ---- the cell at lane k, literally
+			const uint64_t kbit = 1ull << k;
+			// ---- the cell at lane k.  The common cases first: they need nothing but the masks
+			if((mOK & kbit) && prior){
+				if(dlen){                                                   // forced stop of an open deletion run, Od not set: one more row
+					emit(2u, 1u); rs.del++; y--; k0 = k + 1;
+					if(k0 > 63) break;
+					continue;
+				}
+				if(mFD & kbit){                                             // not a match and D set: a deletion opens (both tie orders)
+					emit(2u, 1u); rs.del++; y--; dlen = 1; k0 = k + 1;
+					if(k0 > 63) break;
+					continue;
+				}
+				if(x > 0){                                                  // insertion whose opening cell lies in the same block
+					const uint32_t wck = (uint32_t)__builtin_amdgcn_readlane((int)wc, k), pk = (uint32_t)__builtin_amdgcn_readlane((int)p, k);
+					const uint32_t kk7 = 7u - (pk & 7u);
+					const uint32_t cand = ((wck >> 16) & 0xFFu) >> (kk7 + 1u);
+					if(cand){
+						const int sz = (int)__builtin_ctz(cand) + 1;
+						emit(1u, (uint32_t)sz);
+						x -= sz; rs.ins += sz; k0 = k;
+						continue;
+					}
+				}
+			}
+			// ---- everything else, literally (first cell, cells outside the window, insertions crossing a block, column 0)
 			const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)p, k);
 			if(pk >= (uint32_t)bw){ bad = true; walking = false; break; }
 			const int bpk = __builtin_amdgcn_readlane(bp, k);
@@ -491,10 +516,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const uint32_t yb = pk >> 3, kk = pk & 7u, bit = 1u << (7u - kk);
 			auto code_at = [&](uint32_t blk) -> uint32_t {
 				const uint32_t s_ = blk - (uint32_t)b0k;
-				if(s_ < 4u) return tile[(uint32_t)k * STR + s_];
-				return codes[bsa_code_off((uint32_t)y, blk, 1u)];
+				uint32_t v = tile[(uint32_t)k * STR + (s_ & 3u)];
+				asm volatile("" : "+v"(v));                                 // keeps the LDS read and the (rare) plain load two instructions, not one flat load
+				if(s_ >= 4u) v = codes[bsa_code_off((uint32_t)y, blk, 1u)];
+				return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 			};
-			const uint32_t wck = (uint32_t)__builtin_amdgcn_readfirstlane((int)code_at(yb));
+			const uint32_t wck = code_at(yb);
 			if(dlen){
 				if((wck >> 24) & bit) dlen = 0;
 				else { emit(2u, 1u); rs.del++; y--; k0 = k + 1; if(k0 > 63) break; continue; }
@@ -518,7 +545,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 					else {
 						int left = (int)kk;
 						for(int yy = (int)yb - 1; yy >= 0 && sz == 0; yy--){
-							const uint32_t r2 = ((uint32_t)__builtin_amdgcn_readfirstlane((int)code_at((uint32_t)yy)) >> 16) & 0xFFu;
+							const uint32_t r2 = (code_at((uint32_t)yy) >> 16) & 0xFFu;
 							if(r2) sz = left + 1 + (int)__builtin_ctz(r2);
 							else left += W;
 						}
