@@ -442,39 +442,53 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		if(sl4 == 0u) s_b0[gi] = curC.b0;
 		const int bc = curB.bc, bp = curB.bp;
 		const uint32_t tbs = curB.tb;
-		const uint64_t rowm = __ballot(T - (int)lane >= 0);
 		__syncthreads();
 		const int b0 = s_b0[lane >> 2];
 		int k0 = T - y;
 		// the next tile's codes (their band offsets arrived a tile ago) and the band offsets of the one after
 		if(T - 64 >= 0){ fetch_codes(T - 64, nxtB, x + (T - y) - 64, nxtC); fetch_begs(T - 128, nx2B); }
-		const uint32_t *myrow = &tile[lane * STR];
+		// the lane's row as four 32-bit planes in CELL order (bit c = window cell c = band cell 8 b0 + c): the bytes of a plane
+		// gathered last block first, then all 32 bits reversed (inside a block cell k is bit 7 - k)
+		uint32_t RM, RD, RR, RO;
+		{
+			const uint32_t *mr = &tile[lane * STR];
+			const uint32_t d0 = mr[0], d1 = mr[1], d2 = mr[2], d3 = mr[3];
+			auto plane = [&](uint32_t j) -> uint32_t {
+				const uint32_t lo = __builtin_amdgcn_perm(d2, d3, 0x0c0c0000u | ((4u + j) << 8) | j);
+				const uint32_t hi = __builtin_amdgcn_perm(d0, d1, ((4u + j) << 24) | (j << 16) | 0x0c0cu);
+				return __builtin_bitreverse32(lo | hi);
+			};
+			RM = plane(0); RD = plane(1); RR = plane(2); RO = plane(3);
+		}
+		const int cb = bc + 8 * b0;                                     // column of window cell 0
+		if(T - (int)lane < 0) RM = 0u;                                  // rows above the target: never a match (the walk ends before them)
+		// prior_match is dropped at the first column of the previous row's band (bsalign.h:3761-3764): that cell is taken out of
+		// the M plane and left to the literal step
+		const uint32_t cpm = (uint32_t)(bp - cb);
+		if(cpm < 32u) RM &= ~(1u << cpm);
+		const int shK = 31 + (int)lane + cb;                            // 31 - c = shK - xs for the lane's window cell c = xs - lane - cb
+		if(x + k0 - 63 < qw_lo && qw_lo > 0) q_refill(x);               // the query bases of all 64 cells are in the window
+		int qKr = (int)lane + qw_lo;                                    // index into s_q = xs - qKr
 		while(true){
 			const int xs = x + k0;
-			const int xi = xs - (int)lane;
-			const bool inq = xi >= qw_lo;
-			const uint32_t qb = (uint32_t)s_q[(uint32_t)(xi - qw_lo) & (CWV_QWIN - 1u)];
-			const uint32_t p = (uint32_t)(xi - bc);
-			const uint32_t sl = (p >> 3) - (uint32_t)b0;
-			const uint32_t wc = myrow[sl & 3u];
-			const uint32_t t = (wc >> (7u - (p & 7u))) & 0x01000101u;      // M bit 0, D bit 8, Od bit 24
-			const uint64_t mOK = __ballot(inq && p < (uint32_t)bw && sl < 4u) & rowm;
+			const uint32_t sh = (uint32_t)(shK - xs);                     // 31 - c; c < 32 <=> sh < 32
+			const uint32_t qb = (uint32_t)s_q[xs - qKr];
+			const uint64_t mM = __ballot((int)(RM << (sh & 31u)) < 0) & __ballot(sh < 32u);
 			const uint64_t mNE = __ballot(qb != tbs);
-			const uint64_t mFM = __ballot((t & 0xffu) != 0u), mFD = __ballot((t & 0xff00u) != 0u), mFO = __ballot((t >> 24) != 0u);
-			uint64_t mPMoff = __ballot(xi == bp);                              // bsalign.h:3761-3764: ... && qb != 0
-			if(xs < 64) mPMoff &= ~(1ull << (xs & 63));                       // only near column 0
-			const uint64_t mM = mOK & mFM & ~(mPMoff & mFD);
+			const uint32_t c = (31u - sh) & 31u;
+			const uint32_t info = ((RD >> c) & 1u) | (((RO >> c) & 1u) << 1);      // D, Od of the lane's cell
 			const uint64_t k0bit = 1ull << k0;
-			uint64_t stopm = ~mM & ~(k0bit - 1ull);
+			uint64_t stopm = ~(mM | (k0bit - 1ull));
 			if(dlen){
-				if(mOK & mFO & k0bit) dlen = 0;                                 // the run ends at this cell, which is then an ordinary one
+				const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)info, k0), sh0 = (uint32_t)__builtin_amdgcn_readlane((int)sh, k0);
+				if(sh0 < 32u && (i0 & 2u)) dlen = 0;                         // the run ends at this cell, which is then an ordinary one
 				else stopm |= k0bit;
 			}
 			if(!prior) stopm |= k0bit;
 			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
 			const int n = k - k0;
 			if(n > 0){
-				const uint64_t range = (k == 64 ? ~0ull : ((1ull << k) - 1ull)) & ~(k0bit - 1ull);
+				const uint64_t range = (~0ull >> ((64 - k) & 63)) & ~(k0bit - 1ull);      // lanes k0 .. k-1 (1 <= k <= 64)
 				const int mism = __popcll(mNE & range);
 				rs.mat += n - mism; rs.mis += mism;
 				emit(0u, (uint32_t)n);
@@ -482,34 +496,35 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			}
 			if(k == 64) break;
 			if(x < 0 || y < 0){ walking = false; break; }
-			if(x < qw_lo){ q_refill(x); k0 = k; continue; }
-			const uint64_t kbit = 1ull << k;
-			// ---- the cell at lane k.  The common cases first: they need nothing but the masks
-			if((mOK & kbit) && prior){
-				if(dlen){                                                   // forced stop of an open deletion run, Od not set: one more row
+			// ---- the cell at lane k.  The common cases first: an open deletion run goes on, a deletion opens (not M and D set, in
+			// both tie orders), an insertion whose opening cell lies inside the window
+			const uint32_t shk = (uint32_t)__builtin_amdgcn_readlane((int)sh, k);
+			if(shk < 32u && prior){
+				if(dlen){
 					emit(2u, 1u); rs.del++; y--; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
-				if(mFD & kbit){                                             // not a match and D set: a deletion opens (both tie orders)
+				const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)info, k);
+				if(ik & 1u){
 					emit(2u, 1u); rs.del++; y--; dlen = 1; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
-				if(x > 0){                                                  // insertion whose opening cell lies in the same block
-					const uint32_t wck = (uint32_t)__builtin_amdgcn_readlane((int)wc, k), pk = (uint32_t)__builtin_amdgcn_readlane((int)p, k);
-					const uint32_t kk7 = 7u - (pk & 7u);
-					const uint32_t cand = ((wck >> 16) & 0xFFu) >> (kk7 + 1u);
+				const uint32_t ck = 31u - shk;
+				if(x > 0 && ck != (uint32_t)__builtin_amdgcn_readlane((int)cpm, k)){
+					const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)RR, k) & ((1u << ck) - 1u);
 					if(cand){
-						const int sz = (int)__builtin_ctz(cand) + 1;
+						const int sz = (int)ck - (31 - (int)__builtin_clz(cand));
 						emit(1u, (uint32_t)sz);
 						x -= sz; rs.ins += sz; k0 = k;
+						if(x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 						continue;
 					}
 				}
 			}
-			// ---- everything else, literally (first cell, cells outside the window, insertions crossing a block, column 0)
-			const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)p, k);
+			// ---- everything else, literally (first cell, prior_match column, cells outside the window, insertions leaving it, column 0)
+			const uint32_t pk = (uint32_t)(x - __builtin_amdgcn_readlane(bc, k));
 			if(pk >= (uint32_t)bw){ bad = true; walking = false; break; }
 			const int bpk = __builtin_amdgcn_readlane(bp, k);
 			const int b0k = __builtin_amdgcn_readlane(b0, k);
@@ -555,6 +570,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 					x -= sz; rs.ins += sz;
 				}
 				k0 = k;
+				if(x >= 0 && x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 			} else {
 				emit(2u, 1u); rs.del++;
 				y--; dlen = 1; k0 = k + 1;
