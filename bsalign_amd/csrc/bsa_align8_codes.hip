@@ -885,6 +885,279 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 	cig_cnt[ppos] = ncig;
 }
 
+// ---- two-piece gaps, one walk per wave (the scheme of k_align8_trace_codes_wave with the nine facts of a cell) -------
+// Row = 16 blocks x two dwords (A | D << 8 | D2 << 16 | B << 24, R1 | R2 << 8 | Od1 << 16 | Od2 << 24); a lane's window of four
+// blocks is 32 bytes per row in LDS (stride 9 dwords), turned into eight 32-bit planes in cell order per tile.  A cell is a
+// match iff  M = (D | D2) ? A : (A & ~B);  with prior_match set M decides first, so the run mask is A & (D | D2 | ~B) with the
+// prior_match column taken out.  The cell that ends a run: a deletion of piece 1 / 2 opens where D / D2 is set, an open run
+// of piece d goes on until the row whose Od_d bit is set, everything else is an insertion, decided by the literal rules on
+// the planes of that lane (chains, nearest opening cell, cost comparison) when it closes inside the window, else by the
+// literal single-cell step with plain loads.
+__global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
+	constexpr int W = 8, bw = 128, STR = 9;
+	constexpr uint32_t CW = 2u, RB = 64u * CW;
+	__shared__ uint32_t tile[64 * STR];
+	__shared__ int s_b0[16];
+	__shared__ __attribute__((aligned(8))) uint8_t s_q[CWV_QWIN];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t ppos = a.first + blockIdx.x;
+	const uint32_t pair = a.order[ppos];
+	bsa_result_t rs;
+	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+	if(a.status[pair] != 0u){ if(lane == 0){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint8_t *qseq = a.qst + a.qpoff[pair];
+	const uint8_t *tseq = a.tst + a.tpoff[pair];
+	const int *begs = (const int*)(a.rows + a.slot_off[ppos]);
+	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
+	const uint32_t *codes = (const uint32_t*)rows;
+	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * RB);
+	const int go1 = a.gapo1, ge1 = a.gape1, go2 = a.gapo2, ge2 = a.gape2;
+	uint32_t ncig = 0, cg = 0, cigreg = 0;
+	auto cig_push = [&](uint32_t w){
+		const uint32_t j = ncig & 63u;
+		if(lane == j) cigreg = w;
+		ncig++;
+		if(j == 63u) *(cig_end - (ncig - 63u + lane)) = cigreg;
+	};
+	auto emit = [&](uint32_t op, uint32_t len){
+		if(op == (cg & 0xfu)) cg += len << 4;
+		else { if(cg) cig_push(cg); cg = (len << 4) | op; }
+	};
+	bool bad = false;
+	rs.score = begs[tlen + 1];
+	if(rs.score == (int)0x80000000u) bad = true;                   // band never reached the query end (bsalign.h:4034)
+	rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	{ const int lb = begs[rs.te + 1]; if(rs.qe < lb || rs.qe >= lb + bw) bad = true; }
+	int x = rs.qe, y = rs.te;
+	rs.qe++; rs.te++;
+	int prior = 0, dlen = 0;                                        // dlen: the piece (1, 2) of an open deletion run
+	struct TB { int bc, bp; uint32_t tb; };
+	struct TC { uint32_t v0, v1, v2, v3, v4, v5, v6, v7; int b0; };    // rows 0..3 of one block, two dwords each
+	auto fetch_begs = [&](int T, TB &t){
+		const int r = T - (int)lane;
+		if(r >= 0){ t.bc = begs[r + 1]; t.bp = begs[r]; t.tb = (uint32_t)tseq[r]; }
+		else { t.bc = 0; t.bp = 0; t.tb = 0xffu; }
+	};
+	const uint32_t gi = lane >> 2, sl4 = lane & 3u;
+	auto fetch_codes = [&](int T, const TB &tb_, int xT, TC &c){
+		const int G = (T >> 2) - (int)gi;
+		const int bcg = __shfl(tb_.bc, (int)(gi * 4u));
+		int pp = (xT - 4 * (int)gi) - bcg;
+		pp = pp < 0 ? 0 : pp > bw - 1 ? bw - 1 : pp;
+		int b0 = (pp >> 3) - 1;
+		b0 = b0 < 0 ? 0 : b0 > 12 ? 12 : b0;
+		c.b0 = b0;
+		if(G >= 0){
+			const uint4 *gp = (const uint4*)(codes + ((size_t)G * 64u + (size_t)((uint32_t)b0 + sl4) * 4u) * CW);     // rows 0, 1 | rows 2, 3 of the block
+			const uint4 g0 = gp[0], g1 = gp[1];
+			c.v0 = g0.x; c.v1 = g0.y; c.v2 = g0.z; c.v3 = g0.w; c.v4 = g1.x; c.v5 = g1.y; c.v6 = g1.z; c.v7 = g1.w;
+		} else { c.v0 = c.v1 = c.v2 = c.v3 = c.v4 = c.v5 = c.v6 = c.v7 = 0u; }
+	};
+	int qw_lo = 0;
+	auto q_refill = [&](int xx){
+		int lo = (xx + 8 - CWV_QWIN) & ~7;
+		lo = lo < 0 ? 0 : lo;
+		qw_lo = lo;
+		__syncthreads();
+		if((uint32_t)lo + 8u * lane < qlen + 8u){ uint64_t v; __builtin_memcpy(&v, qseq + lo + 8 * lane, 8); *(uint64_t*)&s_q[8 * lane] = v; }
+		__syncthreads();
+	};
+	TB curB, nxtB, nx2B; TC curC, nxtC;
+	int T = y | 3;
+	if(!bad){
+		q_refill(x);
+		fetch_begs(T, curB);
+		fetch_codes(T, curB, x + (T - y), curC);
+		fetch_begs(T - 64, nxtB);
+	}
+	bool walking = !bad && x >= 0 && y >= 0;
+	while(walking){
+		__syncthreads();
+		{
+			uint32_t *t3 = &tile[(4u * gi + 3u) * STR + 2u * sl4], *t2 = &tile[(4u * gi + 2u) * STR + 2u * sl4];
+			uint32_t *t1 = &tile[(4u * gi + 1u) * STR + 2u * sl4], *t0 = &tile[(4u * gi + 0u) * STR + 2u * sl4];
+			t3[0] = curC.v0; t3[1] = curC.v1; t2[0] = curC.v2; t2[1] = curC.v3;       // row 4G + m sits at lane index 4 gi + 3 - m
+			t1[0] = curC.v4; t1[1] = curC.v5; t0[0] = curC.v6; t0[1] = curC.v7;
+		}
+		if(sl4 == 0u) s_b0[gi] = curC.b0;
+		const int bc = curB.bc, bp = curB.bp;
+		const uint32_t tbs = curB.tb;
+		__syncthreads();
+		const int b0 = s_b0[lane >> 2];
+		int k0 = T - y;
+		if(T - 64 >= 0){ fetch_codes(T - 64, nxtB, x + (T - y) - 64, nxtC); fetch_begs(T - 128, nx2B); }
+		uint32_t PA, PD, PD2, PB, PR1, PR2, PO1, PO2;                  // the lane's row: eight planes in cell order
+		{
+			const uint32_t *mr = &tile[lane * STR];
+			const uint32_t a0 = mr[0], a1 = mr[2], a2 = mr[4], a3 = mr[6], r0 = mr[1], r1 = mr[3], r2 = mr[5], r3 = mr[7];
+			auto plane = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t j) -> uint32_t {
+				const uint32_t lo = __builtin_amdgcn_perm(d2, d3, 0x0c0c0000u | ((4u + j) << 8) | j);
+				const uint32_t hi = __builtin_amdgcn_perm(d0, d1, ((4u + j) << 24) | (j << 16) | 0x0c0cu);
+				return __builtin_bitreverse32(lo | hi);
+			};
+			PA = plane(a0, a1, a2, a3, 0); PD = plane(a0, a1, a2, a3, 1); PD2 = plane(a0, a1, a2, a3, 2); PB = plane(a0, a1, a2, a3, 3);
+			PR1 = plane(r0, r1, r2, r3, 0); PR2 = plane(r0, r1, r2, r3, 1); PO1 = plane(r0, r1, r2, r3, 2); PO2 = plane(r0, r1, r2, r3, 3);
+		}
+		uint32_t RM = PA & (PD | PD2 | ~PB);
+		const int cb = bc + 8 * b0;
+		if(T - (int)lane < 0) RM = 0u;
+		const uint32_t cpm = (uint32_t)(bp - cb);
+		if(cpm < 32u) RM &= ~(1u << cpm);                              // prior_match column (bsalign.h:3761-3764): the literal step
+		const int shK = 31 + (int)lane + cb;
+		if(x + k0 - 63 < qw_lo && qw_lo > 0) q_refill(x);
+		int qKr = (int)lane + qw_lo;
+		while(true){
+			const int xs = x + k0;
+			const uint32_t sh = (uint32_t)(shK - xs);
+			const uint32_t qb = (uint32_t)s_q[xs - qKr];
+			const uint64_t mM = __ballot((int)(RM << (sh & 31u)) < 0) & __ballot(sh < 32u);
+			const uint64_t mNE = __ballot(qb != tbs);
+			const uint32_t c = (31u - sh) & 31u;
+			const uint32_t info = ((PD >> c) & 1u) | (((PD2 >> c) & 1u) << 1) | (((PO1 >> c) & 1u) << 2) | (((PO2 >> c) & 1u) << 3);
+			const uint64_t k0bit = 1ull << k0;
+			uint64_t stopm = ~(mM | (k0bit - 1ull));
+			if(dlen){
+				const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)info, k0), sh0 = (uint32_t)__builtin_amdgcn_readlane((int)sh, k0);
+				if(sh0 < 32u && ((i0 >> (1 + dlen)) & 1u)) dlen = 0;          // Od of the run's piece: the run ends at this cell
+				else stopm |= k0bit;
+			}
+			if(!prior) stopm |= k0bit;
+			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
+			const int n = k - k0;
+			if(n > 0){
+				const uint64_t range = (~0ull >> ((64 - k) & 63)) & ~(k0bit - 1ull);
+				const int mism = __popcll(mNE & range);
+				rs.mat += n - mism; rs.mis += mism;
+				emit(0u, (uint32_t)n);
+				x -= n; y -= n;
+			}
+			if(k == 64) break;
+			if(x < 0 || y < 0){ walking = false; break; }
+			const uint32_t shk = (uint32_t)__builtin_amdgcn_readlane((int)sh, k);
+			if(shk < 32u && prior){
+				if(dlen){
+					emit(2u, 1u); rs.del++; y--; k0 = k + 1;
+					if(k0 > 63) break;
+					continue;
+				}
+				const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)info, k);
+				if(ik & 3u){                                                // not M and D or D2 set: a deletion of that piece opens
+					emit(2u, 1u); rs.del++; y--; dlen = (ik & 1u) ? 1 : 2; k0 = k + 1;
+					if(k0 > 63) break;
+					continue;
+				}
+				const uint32_t ck = 31u - shk;
+				if(x > 0 && ck != (uint32_t)__builtin_amdgcn_readlane((int)cpm, k)){
+					// insertion (M = D = D2 = 0): the chains that equal h, the nearest cell to the left at which one of them opens,
+					// the cost comparison of bsalign.h:3798-3814 (k_align8_trace_codes2 states the rules)
+					const uint32_t cbit = 1u << ck;
+					const bool fA = ((uint32_t)__builtin_amdgcn_readlane((int)PA, k) & cbit) != 0u, fB = ((uint32_t)__builtin_amdgcn_readlane((int)PB, k) & cbit) != 0u;
+					const bool ch1 = fB, ch2 = fA == fB;
+					const uint32_t r1k = (uint32_t)__builtin_amdgcn_readlane((int)PR1, k), r2k = (uint32_t)__builtin_amdgcn_readlane((int)PR2, k);
+					const uint32_t cand = ((ch1 ? r1k : 0u) | (ch2 ? r2k : 0u)) & (cbit - 1u);
+					if(cand){
+						const uint32_t hp = 31u - (uint32_t)__builtin_clz(cand);
+						const int sz = (int)ck - (int)hp;
+						const int c1 = go1 + sz * ge1, c2 = go2 + sz * ge2;
+						const bool h1 = ch1 && ((r1k >> hp) & 1u), h2 = ch2 && ((r2k >> hp) & 1u);
+						if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))){ bad = true; walking = false; break; }
+						emit(1u, (uint32_t)sz);
+						x -= sz; rs.ins += sz; k0 = k;
+						if(x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
+						continue;
+					}
+				}
+			}
+			// ---- everything else, literally
+			const uint32_t pk = (uint32_t)(x - __builtin_amdgcn_readlane(bc, k));
+			if(pk >= (uint32_t)bw){ bad = true; walking = false; break; }
+			const int bpk = __builtin_amdgcn_readlane(bp, k);
+			const int b0k = __builtin_amdgcn_readlane(b0, k);
+			const uint32_t yb = pk >> 3, kk = pk & 7u, bit = 1u << (7u - kk);
+			auto code_at = [&](uint32_t blk) -> uint2 {
+				const uint32_t s_ = blk - (uint32_t)b0k;
+				uint32_t v0 = tile[(uint32_t)k * STR + 2u * (s_ & 3u)], v1 = tile[(uint32_t)k * STR + 2u * (s_ & 3u) + 1u];
+				asm volatile("" : "+v"(v0), "+v"(v1));
+				if(s_ >= 4u){ const uint2 g = *(const uint2*)(codes + bsa_code_off((uint32_t)y, blk, CW)); v0 = g.x; v1 = g.y; }
+				uint2 r; r.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0); r.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)v1);
+				return r;
+			};
+			const uint2 cc = code_at(yb);
+			if(dlen){
+				if((cc.y >> (dlen == 2 ? 24 : 16)) & bit) dlen = 0;
+				else { emit(2u, 1u); rs.del++; y--; k0 = k + 1; if(k0 > 63) break; continue; }
+			}
+			const bool pmatch = prior && !(x == bpk && x != 0);
+			const bool fA = (cc.x & bit) != 0u, fD = ((cc.x >> 8) & bit) != 0u, fD2 = ((cc.x >> 16) & bit) != 0u, fB = ((cc.x >> 24) & bit) != 0u;
+			const bool fM = (fD || fD2) ? fA : (fA && !fB);
+			const int d = fD ? 1 : fD2 ? 2 : 0;
+			int bt;
+			if(pmatch) bt = fM ? 0 : d ? 2 : 1;
+			else bt = d ? 2 : fM ? 0 : 1;
+			prior = 1;
+			if(bt == 0){
+				if((mNE >> k) & 1ull) rs.mis++; else rs.mat++;
+				emit(0u, 1u);
+				x--; y--; k0 = k + 1;
+			} else if(bt == 1){
+				if(x <= 0){ emit(1u, 1u); x--; rs.ins++; }
+				else {
+					const bool ch1 = fB, ch2 = fA == fB;
+					auto rplane = [&](const uint2 &w) -> uint32_t { return ((ch1 ? w.y : 0u) | (ch2 ? (w.y >> 8) : 0u)) & 0xFFu; };
+					int sz = 0;
+					uint2 hc = cc; uint32_t hb = 0;
+					const uint32_t cand = rplane(cc) & ~((bit << 1) - 1u);
+					if(cand){ hb = cand & (0u - cand); sz = (int)__builtin_ctz(cand) - (int)(7u - kk); }
+					else {
+						int left = (int)kk;
+						for(int yy = (int)yb - 1; yy >= 0 && sz == 0; yy--){
+							hc = code_at((uint32_t)yy);
+							const uint32_t r2 = rplane(hc);
+							if(r2){ hb = r2 & (0u - r2); sz = left + 1 + (int)__builtin_ctz(r2); }
+							else left += W;
+						}
+						if(sz == 0){ bad = true; walking = false; break; }
+					}
+					{
+						const int c1 = go1 + sz * ge1, c2 = go2 + sz * ge2;
+						const bool h1 = ch1 && (hc.y & hb) != 0u, h2 = ch2 && ((hc.y >> 8) & hb) != 0u;
+						if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))){ bad = true; walking = false; break; }
+					}
+					emit(1u, (uint32_t)sz);
+					x -= sz; rs.ins += sz;
+				}
+				k0 = k;
+				if(x >= 0 && x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
+			} else {
+				emit(2u, 1u); rs.del++;
+				y--; dlen = d; k0 = k + 1;
+			}
+			if(k0 > 63) break;
+		}
+		if(x < 0 || y < 0) walking = false;
+		T -= 64;
+		curB = nxtB; curC = nxtC; nxtB = nx2B;
+	}
+	if(!bad && dlen && y < 0) bad = true;                            // a deletion run that reached row -1: the reference compares real scores there -- literal path
+	if(!bad){
+		rs.qb = x; rs.tb = y;
+		uint32_t op = 0, sz = 0;
+		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+		emit(op, sz);
+		if(cg) cig_push(cg);
+		rs.qb++; rs.tb++;
+		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
+		if(lane < (ncig & 63u)) *(cig_end - ((ncig & ~63u) + lane + 1u)) = cigreg;
+	} else {
+		if(lane == 0) atomicOr(&a.status[pair], BSA_ST_TRACE);
+		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
+		ncig = 0;
+	}
+	if(lane == 0){ out[pair] = rs; cig_cnt[ppos] = ncig; }
+}
+
 template<int W>
 static void launch_trace_lds(const Align8Args &a, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	// Pairs per wave: 32 where the batch is large enough (100 k pairs on MI355X, ms per launch: 64 -> 46, 32 -> 31.0,
@@ -911,7 +1184,9 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 	if(a.count == 0) return hipSuccess;
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;
-		hipLaunchKernelGGL(k_align8_trace_codes2, dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt);
+		const char *we = getenv("BSA_ALIGN8_TRACE_WAVE");              // =0: the pair-per-lane walker
+		if(we && we[0] == '0') hipLaunchKernelGGL(k_align8_trace_codes2, dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt);
+		else hipLaunchKernelGGL(k_align8_trace_codes2_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
 		return hipGetLastError();
 	}
 	// BSA_ALIGN8_TRACE_SIMPLE=1: the plain kernel (kept as the reference point)
