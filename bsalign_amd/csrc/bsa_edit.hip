@@ -506,6 +506,125 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp(const EditArgs a){
 	if(live && gl == (type != BSA_MODE_GLOBAL ? lastw : 0u)){ a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry; }
 }
 
+// ---- the same with 32-bit words: G = 2 NW lanes per pair (bands up to 512 columns) --------------------------------------
+// gfx950 has no 64-bit integer ALU: every u64 operation of k_edit_fwd_grp is two or three instructions (a funnel shift of the
+// band by movx bits: six), and with one wave per SIMD the row time is the wave's own instruction latency.  With 32-bit words
+// the block step is one instruction per operation, the band shift is one v_alignbit_b32 per plane, and the same batch is
+// twice the waves (C3: two per SIMD), which interleave.  Row records are identical (natural bit order: the 32-bit word h of
+// a plane is the low / high half of the 64-bit word h / 2).
+template<int G>
+__global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
+	constexpr uint32_t PPW = 64u / G;
+	constexpr u64 GS = G == 2 ? 0x5555555555555555ull : G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;   // first lane of every group
+	const uint32_t lane = threadIdx.x & 63u, gl = lane % G, grp = lane / G;
+	const uint32_t g = (blockIdx.x * 4u + (threadIdx.x >> 6)) * PPW + grp;
+	const bool valid = g < a.count;
+	const uint32_t ppos = a.first + (valid ? g : 0u), pair = a.order[ppos];
+	const bool live = valid && a.status[pair] == 0u;
+	const uint32_t qlen = a.qlen[pair], tlen = a.tlen[pair];
+	const uint32_t BW = a.bw, NW = BW / 64u, NH = BW / 32u;                // NH 32-bit words per plane
+	const uint32_t *Q0m = (const uint32_t*)(a.qbits + a.qboff[pair]);
+	const uint32_t *Q1m = Q0m + 2u * a.qwords[pair];
+	const uint8_t *tp = a.tst + a.tpoff[pair];
+	uint32_t *rows = (uint32_t*)(a.rows + a.slot_off[ppos]);
+	const int type = a.mode & 3;
+	const bool overlap = type == BSA_MODE_OVERLAP;
+	const uint32_t qround = (qlen + 63u) / 64u * 64u;
+	const bool word = gl < NH, top = gl + 1u == NH;
+	const uint32_t tl = live ? tlen : 0u;
+	uint32_t pv = ~0u, mv = 0u;
+	if(live && word){ rows[gl] = 0u; rows[NH + gl] = ~0u; }              // row_init (:653-656)
+	uint32_t q0 = word ? Q0m[gl] : 0u, q1 = word ? Q1m[gl] : 0u;           // query planes at band offset 0
+	// the top lane keeps the query bits behind the band end: position lpos sits in (l?c, l?n) at bit lpos & 31
+	uint32_t lpos = BW;
+	uint32_t l0c = 0, l0n = 0, l1c = 0, l1n = 0;
+	if(top){ l0c = Q0m[NH]; l0n = Q0m[NH + 1u]; l1c = Q1m[NH]; l1n = Q1m[NH + 1u]; }
+	int sbeg = 0;                                                           // lane 0 of the group: H at the band start
+	uint32_t rb0 = 0;
+	uint32_t quo = 0, rem = 0;                                              // floor(i * qlen / tlen) and the remainder, kept incrementally
+	const uint32_t qstep = qlen / (tlen ? tlen : 1u), rstep = qlen % (tlen ? tlen : 1u);
+	const uint32_t lastw = (qlen - 1u) >> 5, lastb = (qlen - 1u) & 31u;
+	int slast = (int)qlen, smin = 0x7FFFFFFF, ry = (int)tlen - 1;
+	const u64 hin0_mask = overlap ? 0ull : GS;
+	u64 tw = 0;
+	uint32_t *rp = rows + 2u * NH + gl;                                     // this lane's word of the row being written
+	for(uint32_t i = 0; __any(i < tl); i++){
+		const bool on = i < tl;
+		if(on && (i & 7u) == 0u) tw = *(const u64*)(tp + i);      // staged 16-byte aligned with >= 8 bytes of padding
+		const uint32_t tb = (((i & 4u) ? (uint32_t)(tw >> 32) : (uint32_t)tw) >> (8u * (i & 3u))) & 3u;
+		uint32_t rb1 = 0;
+		if(type == BSA_MODE_GLOBAL){                                         // fixed diagonal band (:1112-1114)
+			uint32_t c = quo;
+			c = (c < BW / 2) ? 0u : c - BW / 2;
+			rb1 = (c + BW > qround) ? qround - BW : c;
+		}
+		uint32_t movx = on ? rb1 - rb0 : 0u;
+		// ---- row_movx (:658-721)
+		if(overlap) sbeg = 0; else if(on) sbeg += 1;
+		if(__any(movx != 0u)){
+			while(__any(movx >= 32u)){                                        // whole words (rare)
+				uint32_t np = (uint32_t)DPP_SHL(0, (int)pv, 1), nm = (uint32_t)DPP_SHL(0, (int)mv, 1), nq0 = (uint32_t)DPP_SHL(0, (int)q0, 1), nq1 = (uint32_t)DPP_SHL(0, (int)q1, 1);
+				if(top){ np = ~0u; nm = 0u; nq0 = __builtin_amdgcn_alignbit(l0n, l0c, lpos & 31u); nq1 = __builtin_amdgcn_alignbit(l1n, l1c, lpos & 31u); }
+				if(movx >= 32u){
+					if(!overlap) sbeg += __popc(pv) - __popc(mv);
+					pv = np; mv = nm; q0 = nq0; q1 = nq1; movx -= 32u;
+					lpos += 32u;
+					if(top){ l0c = l0n; l1c = l1n; l0n = Q0m[(lpos >> 5) + 1u]; l1n = Q1m[(lpos >> 5) + 1u]; }
+				}
+			}
+			uint32_t np = (uint32_t)DPP_SHL(0, (int)pv, 1), nm = (uint32_t)DPP_SHL(0, (int)mv, 1), nq0 = (uint32_t)DPP_SHL(0, (int)q0, 1), nq1 = (uint32_t)DPP_SHL(0, (int)q1, 1);
+			if(top){ np = ~0u; nm = 0u; nq0 = __builtin_amdgcn_alignbit(l0n, l0c, lpos & 31u); nq1 = __builtin_amdgcn_alignbit(l1n, l1c, lpos & 31u); }
+			if(movx){                                                         // 1 .. 31
+				const uint32_t mk = (1u << movx) - 1u;
+				if(!overlap) sbeg += __popc(pv & mk) - __popc(mv & mk);
+				pv = __builtin_amdgcn_alignbit(np, pv, movx);
+				mv = __builtin_amdgcn_alignbit(nm, mv, movx);
+				q0 = __builtin_amdgcn_alignbit(nq0, q0, movx);
+				q1 = __builtin_amdgcn_alignbit(nq1, q1, movx);
+				const uint32_t lw = lpos >> 5;
+				lpos += movx;
+				if(top && (lpos >> 5) != lw){ l0c = l0n; l1c = l1n; l0n = Q0m[(lpos >> 5) + 1u]; l1n = Q1m[(lpos >> 5) + 1u]; }
+			}
+		}
+		// ---- row_cal (:766-810): this lane's word for both signs of the delta entering it, then the chain per group
+		const bool act = on && word;
+		const uint32_t x0 = (tb & 1u) ? 0u : ~0u, x1 = (tb & 2u) ? 0u : ~0u;
+		const uint32_t nvalid = (rb1 < qlen) ? qlen - rb1 : 0u;          // band cells that are real query columns
+		uint32_t Eq = (q0 ^ x0) & (q1 ^ x1);
+		if(__any(nvalid < BW)){ const uint32_t lo = gl * 32u; Eq &= (nvalid > lo) ? (nvalid - lo >= 32u ? ~0u : ((1u << (nvalid - lo)) - 1u)) : 0u; }
+		const uint32_t Xv = Eq | mv;
+		const uint32_t e1 = Eq | 1u;
+		const uint32_t t0 = (((Eq & pv) + pv) ^ pv) | Eq;
+		const uint32_t t1 = (((e1 & pv) + pv) ^ pv) | e1;
+		const uint32_t ph0 = (mv | ~(t0 | pv)) >> 31, mh0 = (pv & t0) >> 31;
+		const uint32_t ph1 = (mv | ~(t1 | pv)) >> 31, mh1 = (pv & t1) >> 31;
+		const bool link = act && !top;                                        // the top word's outgoing delta leaves the band
+		const u64 A = __ballot(link && mh0 > ph0), B = __ballot(link && mh1 > ph1);
+		const u64 C = uniform64(chain_neg(A, B));                             // bit l: a negative delta enters lane l
+		const u64 PA = __ballot(link && ph0 > mh0), PB = __ballot(link && ph1 > mh1);
+		const u64 Ppos = uniform64(((((PA & ~C) | (PB & C)) << 1) & ~GS) | hin0_mask);   // left of the band v = +1, 0 in overlap mode (:770)
+		const uint32_t Xh = mask_pick(t0, t1, C);
+		uint32_t Ph = mv | ~(Xh | pv);
+		uint32_t Mh = pv & Xh;
+		if(type != BSA_MODE_GLOBAL && gl == lastw) slast += (int)((Ph >> lastb) & 1u) - (int)((Mh >> lastb) & 1u);
+		Ph = (Ph << 1) | mask_pick(0u, 1u, Ppos);
+		Mh = (Mh << 1) | mask_pick(0u, 1u, C);
+		if(act){
+			pv = Mh | ~(Xv | Ph);
+			mv = Ph & Xv;
+			rp[0] = mv; rp[NH] = pv;
+			if(type != BSA_MODE_GLOBAL && slast < smin){ smin = slast; ry = (int)i; }
+		}
+		rb0 = on ? rb1 : rb0;
+		quo += qstep;
+		if(rem >= tlen - rstep){ rem -= tlen - rstep; quo++; } else rem += rstep;     // no 33-bit sum
+		rp += 2u * NH;
+	}
+	if(live && gl == 0u) a.fwd_sbeg[ppos] = sbeg;
+	if(live && gl == (type != BSA_MODE_GLOBAL ? lastw : 0u)){ a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry; }
+	(void)NW;
+}
+
 // ---------------------------------------------------------------------------------------------
 // traceback (bsalign.h:965-1044) + end-cell / score selection of the driver (:1124-1139, 1180-1203)
 // one pair per lane
@@ -1065,6 +1184,23 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 		const uint32_t G = nw <= 2u ? 2u : nw <= 4u ? 4u : nw <= 8u ? 8u : 16u;
 		bool grp = a.bw != 0u && nw >= 2u && nw <= 16u && (uint64_t)a.count * G / 64u <= 4096u;
 		if(const char *e = getenv("BSA_EDIT_GRP")) grp = a.bw != 0u && nw >= 2u && nw <= 16u && e[0] == '1';
+		// 32-bit words, twice the lanes per pair (bands up to 512 columns): BSA_EDIT_GRP32=0/1 overrides
+		{
+			const uint32_t G32 = nw <= 1u ? 2u : nw <= 2u ? 4u : nw <= 4u ? 8u : 16u;
+			bool g32 = a.bw != 0u && nw >= 1u && nw <= 8u && (uint64_t)a.count * G32 / 64u <= 16384u;
+			if(const char *e = getenv("BSA_EDIT_GRP32")) g32 = a.bw != 0u && nw >= 1u && nw <= 8u && e[0] == '1';
+			if(getenv("BSA_EDIT_GRP")) g32 = false;
+			if(g32){
+				const uint32_t ppw = 64u / G32, gblocks = ((a.count + ppw - 1) / ppw + 3) / 4;
+				switch(G32){
+					case 2: hipLaunchKernelGGL((k_edit_fwd_grp32<2>), dim3(gblocks), dim3(256), 0, st, a); break;
+					case 4: hipLaunchKernelGGL((k_edit_fwd_grp32<4>), dim3(gblocks), dim3(256), 0, st, a); break;
+					case 8: hipLaunchKernelGGL((k_edit_fwd_grp32<8>), dim3(gblocks), dim3(256), 0, st, a); break;
+					default: hipLaunchKernelGGL((k_edit_fwd_grp32<16>), dim3(gblocks), dim3(256), 0, st, a); break;
+				}
+				return hipGetLastError();
+			}
+		}
 		if(grp){
 			const uint32_t ppw = 64u / G, gblocks = ((a.count + ppw - 1) / ppw + 3) / 4;
 			switch(G){

@@ -144,7 +144,7 @@ def test_golden_wide_bands_from_the_reference(ctx):
 
 
 @pytest.mark.parametrize("env", [{"BSA_EDIT_GRP": "0"}, {"BSA_EDIT_GRP": "1"}, {"BSA_EDIT_TRACE_COOP": "0"}, {"BSA_EDIT_TRACE_LANES": "16"},
-                                 {"BSA_EDIT_NO_MERGE": "1"}, {"BSA_EDIT_TRACE_WAVE": "0"}, {"BSA_EDIT_TRACE_WAVE": "1"}], ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
+                                 {"BSA_EDIT_NO_MERGE": "1"}, {"BSA_EDIT_TRACE_WAVE": "0"}, {"BSA_EDIT_TRACE_WAVE": "1"}, {"BSA_EDIT_GRP32": "0"}, {"BSA_EDIT_GRP32": "1"}], ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
 def test_golden_cases_on_every_kernel_variant(ctx, monkeypatch, env):
     """the launchers pick kernels by batch size; force each alternative (pair-per-lane / grouped forward kernels, plain /
     cooperative traceback, many pairs per wave, one walk per wave or never, no class merging) and replay the reference's results"""
