@@ -550,7 +550,10 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 	uint32_t *rp = rows + 2u * NH + gl;                                     // this lane's word of the row being written
 	for(uint32_t i = 0; __any(i < tl); i++){
 		const bool on = i < tl;
-		if(on && (i & 7u) == 0u) tw = *(const u64*)(tp + i);      // staged 16-byte aligned with >= 8 bytes of padding
+		if((i & 7u) == 0u){                                       // (uniform) the next eight target bases; waited for here, once per eight rows,
+			if(on) tw = *(const u64*)(tp + i);                    // so that no row waits for the previous row's stores (vmcnt counts both)
+			asm volatile("" : "+v"(tw));
+		}
 		const uint32_t tb = (((i & 4u) ? (uint32_t)(tw >> 32) : (uint32_t)tw) >> (8u * (i & 3u))) & 3u;
 		uint32_t rb1 = 0;
 		if(type == BSA_MODE_GLOBAL){                                         // fixed diagonal band (:1112-1114)
@@ -561,7 +564,7 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 		uint32_t movx = on ? rb1 - rb0 : 0u;
 		// ---- row_movx (:658-721)
 		if(overlap) sbeg = 0; else if(on) sbeg += 1;
-		if(__any(movx != 0u)){
+		if(__any(movx >= 32u)){
 			while(__any(movx >= 32u)){                                        // whole words (rare)
 				uint32_t np = (uint32_t)DPP_SHL(0, (int)pv, 1), nm = (uint32_t)DPP_SHL(0, (int)mv, 1), nq0 = (uint32_t)DPP_SHL(0, (int)q0, 1), nq1 = (uint32_t)DPP_SHL(0, (int)q1, 1);
 				if(top){ np = ~0u; nm = 0u; nq0 = __builtin_amdgcn_alignbit(l0n, l0c, lpos & 31u); nq1 = __builtin_amdgcn_alignbit(l1n, l1c, lpos & 31u); }
@@ -572,19 +575,20 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 					if(top){ l0c = l0n; l1c = l1n; l0n = Q0m[(lpos >> 5) + 1u]; l1n = Q1m[(lpos >> 5) + 1u]; }
 				}
 			}
+		}
+		if(type == BSA_MODE_GLOBAL){                                          // 0 .. 31 cells: no branch (a shift by 0 changes nothing)
 			uint32_t np = (uint32_t)DPP_SHL(0, (int)pv, 1), nm = (uint32_t)DPP_SHL(0, (int)mv, 1), nq0 = (uint32_t)DPP_SHL(0, (int)q0, 1), nq1 = (uint32_t)DPP_SHL(0, (int)q1, 1);
-			if(top){ np = ~0u; nm = 0u; nq0 = __builtin_amdgcn_alignbit(l0n, l0c, lpos & 31u); nq1 = __builtin_amdgcn_alignbit(l1n, l1c, lpos & 31u); }
-			if(movx){                                                         // 1 .. 31
-				const uint32_t mk = (1u << movx) - 1u;
-				if(!overlap) sbeg += __popc(pv & mk) - __popc(mv & mk);
-				pv = __builtin_amdgcn_alignbit(np, pv, movx);
-				mv = __builtin_amdgcn_alignbit(nm, mv, movx);
-				q0 = __builtin_amdgcn_alignbit(nq0, q0, movx);
-				q1 = __builtin_amdgcn_alignbit(nq1, q1, movx);
-				const uint32_t lw = lpos >> 5;
-				lpos += movx;
-				if(top && (lpos >> 5) != lw){ l0c = l0n; l1c = l1n; l0n = Q0m[(lpos >> 5) + 1u]; l1n = Q1m[(lpos >> 5) + 1u]; }
-			}
+			const uint32_t la0 = __builtin_amdgcn_alignbit(l0n, l0c, lpos & 31u), la1 = __builtin_amdgcn_alignbit(l1n, l1c, lpos & 31u);
+			np = top ? ~0u : np; nm = top ? 0u : nm; nq0 = top ? la0 : nq0; nq1 = top ? la1 : nq1;
+			const uint32_t mk = ~(~0u << movx);
+			sbeg += __popc(pv & mk) - __popc(mv & mk);
+			pv = __builtin_amdgcn_alignbit(np, pv, movx);
+			mv = __builtin_amdgcn_alignbit(nm, mv, movx);
+			q0 = __builtin_amdgcn_alignbit(nq0, q0, movx);
+			q1 = __builtin_amdgcn_alignbit(nq1, q1, movx);
+			const uint32_t lw = lpos >> 5;
+			lpos += movx;
+			if(top && (lpos >> 5) != lw){ l0c = l0n; l1c = l1n; l0n = Q0m[(lpos >> 5) + 1u]; l1n = Q1m[(lpos >> 5) + 1u]; asm volatile("" : "+v"(l0n), "+v"(l1n)); }
 		}
 		// ---- row_cal (:766-810): this lane's word for both signs of the delta entering it, then the chain per group
 		const bool act = on && word;
