@@ -1032,18 +1032,18 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	};
 	TileRegs pf;
 	int pf_R = -1;                                   // the tile (its R_hi) whose rows are on their way in pf
+	auto q_refill = [&](int xx){                     // query window [qw_lo, qw_lo + 512) with xx near its upper end
+		int lo = (xx + 8 - EW_QWIN) & ~7;
+		lo = lo < 0 ? 0 : lo;
+		qw_lo = lo; qw_hi = lo + EW_QWIN - 1;
+		__syncthreads();
+		if((uint32_t)lo + 8u * lane < qlen + 8u){ u64 v; __builtin_memcpy(&v, qs + lo + 8 * lane, 8); *(u64*)&s_q[8 * lane] = v; }
+		__syncthreads();
+	};
+	if(!bad && x >= 0) q_refill(x);
 	while(!bad && x >= 0 && y >= 0){
 		const int R_hi = y + 1;
 		if(pf_R != R_hi) tile_fetch(R_hi, x, pf);
-		if(x > qw_hi || x - 128 < qw_lo){              // query window: [qw_lo, qw_lo + 512) with x near its upper end
-			if(!(qw_lo == 0 && x <= qw_hi)){
-				int lo = (x + 8 - EW_QWIN) & ~7;
-				lo = lo < 0 ? 0 : lo;
-				qw_lo = lo; qw_hi = lo + EW_QWIN - 1;
-				__syncthreads();
-				if((uint32_t)lo + 8u * lane < qlen + 8u){ u64 v; __builtin_memcpy(&v, qs + lo + 8 * lane, 8); *(u64*)&s_q[8 * lane] = v; }
-			}
-		}
 		__syncthreads();
 #pragma unroll
 		for(int w = 0; w < EW_WW; w++){
@@ -1051,56 +1051,98 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 			tile[lane][2 * EW_WW + 2 * w] = (uint32_t)pf.w[1][w]; tile[lane][2 * EW_WW + 2 * w + 1] = (uint32_t)(pf.w[1][w] >> 32);
 		}
 		s_beg[lane] = pf.beg; s_ws[lane] = pf.ws;
-		const uint32_t beg = pf.beg, ws2 = 2u * pf.ws, tb = pf.tb;
+		const uint32_t beg = pf.beg, ws = pf.ws, tb = pf.tb;
 		const int r_own = R_hi - (int)lane;
 		const u64 tilem = __ballot(lane <= 62u && r_own >= 1);       // lanes whose cell lies inside the target (y - d >= 0) with both rows in the tile
 		__syncthreads();
-		const uint32_t begn = s_beg[(lane + 1u) & 63u], wsn2 = 2u * s_ws[(lane + 1u) & 63u];
-		// the next tile starts 63 rows further up (unless this one ends early): its rows travel while this one is walked
+		const uint32_t begn = s_beg[(lane + 1u) & 63u], wsn = s_ws[(lane + 1u) & 63u];
+		// the next tile starts 63 rows further up: its rows travel while this one is walked
 		pf_R = R_hi - 63;
 		if(pf_R >= 1) tile_fetch(pf_R, x - 63, pf);
-		const int xlo = qw_lo;                           // >= 0
+		// ---- the lane's cells as 32-bit masks over query columns cbase .. cbase + 31 (cbase = its column on the walker's
+		// diagonal - 16): IM = "insertion" (u3, u4) == (0, 1) on the lane's own row, DM = "deletion" (u1, u2) == (1, 0) on the
+		// row above and not IM, VM = both lookups lie inside the band and inside the LDS windows.  A cell stops the diagonal
+		// run when the bases differ and (IM | DM | ~VM); what ~VM stopped is looked up literally.
+		const int cbase = (x - (int)lane) - 16;
+		const bool pow2row = NW <= (uint32_t)EW_WW && (NW & (NW - 1u)) == 0u;
+		uint32_t IM, DM, VM;
+		{
+			auto window = [&](uint32_t row, int o, uint32_t wsr, uint32_t &p0w, uint32_t &p1w) -> uint32_t {   // bits o .. o + 31 of both planes of a row; returns their validity
+				const uint32_t sft = (uint32_t)o & 31u;
+				if(pow2row){
+					// the whole row is in LDS and NW is a power of two: a position outside the band is looked up where the reference's
+					// unsigned arithmetic lands (plane_bit), which is then simply the position modulo BW -- the row read as a ring
+					const uint32_t ia = (uint32_t)(o >> 5) & (2u * NW - 1u), ib = (ia + 1u) & (2u * NW - 1u);
+					p0w = __builtin_amdgcn_alignbit(tile[row][ib], tile[row][ia], sft);
+					p1w = __builtin_amdgcn_alignbit(tile[row][2 * EW_WW + ib], tile[row][2 * EW_WW + ia], sft);
+					return ~0u;
+				}
+				const int d0 = (o >> 5) - 2 * (int)wsr;                    // dword of bit o inside the row's LDS window
+				const bool inA = (uint32_t)d0 < 2u * EW_WW, inB = (uint32_t)(d0 + 1) < 2u * EW_WW;
+				const uint32_t ia = (uint32_t)d0 & (2u * EW_WW - 1u), ib = (uint32_t)(d0 + 1) & (2u * EW_WW - 1u);
+				const uint32_t a0 = inA ? tile[row][ia] : 0u, b0 = inB ? tile[row][ib] : 0u;
+				const uint32_t a1 = inA ? tile[row][2 * EW_WW + ia] : 0u, b1 = inB ? tile[row][2 * EW_WW + ib] : 0u;
+				p0w = __builtin_amdgcn_alignbit(b0, a0, sft); p1w = __builtin_amdgcn_alignbit(b1, a1, sft);
+				// valid c: 0 <= o + c < BW and the bit's dword inside the window
+				int lo = -o, hi = (int)BW - o;
+				const int wl = 64 * (int)wsr - o, wh = wl + 64 * EW_WW;
+				lo = lo > wl ? lo : wl; hi = hi < wh ? hi : wh;
+				lo = lo < 0 ? 0 : lo; hi = hi > 32 ? 32 : hi;
+				if(hi <= lo) return 0u;
+				const uint32_t mh = hi >= 32 ? ~0u : ((1u << hi) - 1u);
+				return mh & ~((1u << lo) - 1u);
+			};
+			uint32_t a3, a4, a1, a2;
+			const uint32_t v1 = window(lane, cbase - (int)beg, ws, a3, a4);
+			const uint32_t v0 = window((lane + 1u) & 63u, cbase - (int)begn, wsn, a1, a2);
+			VM = v1 & v0;
+			IM = ~a3 & a4;
+			DM = a1 & ~a2 & ~IM;
+		}
+		const uint32_t SM = IM | DM | ~VM;
+		const int shK = 31 + (int)lane + cbase;                       // 31 - c = shK - xs
 		int k0 = 0;
+		if(x - 63 < qw_lo && qw_lo > 0) q_refill(x);
+		int qK = (int)lane + qw_lo;
 		// ---- walk inside the tile
 		while(true){
-			const int xi = (x + k0) - (int)lane;         // lanes below k0 look at cells in front of the walker: masked out of every ballot
-			const bool inq = xi >= xlo;
-			const uint32_t qb = (uint32_t)s_q[(uint32_t)(xi - qw_lo) & (EW_QWIN - 1u)];
-			const bool ne = qb != tb;
-			const uint32_t p1 = (uint32_t)(xi - (int)beg), p0 = (uint32_t)(xi - (int)begn);
-			const uint32_t d1 = (p1 >> 5) - ws2, d0 = (p0 >> 5) - wsn2;
-			const bool fast = p1 < BW && p0 < BW && d1 < 2u * EW_WW && d0 < 2u * EW_WW;
-			const uint32_t a1 = d1 & (2u * EW_WW - 1u), a0 = d0 & (2u * EW_WW - 1u);
-			uint32_t m3 = tile[lane][a1] >> (p1 & 31u), m4 = tile[lane][2 * EW_WW + a1] >> (p1 & 31u);
-			uint32_t m1 = tile[(lane + 1u) & 63u][a0] >> (p0 & 31u), m2 = tile[(lane + 1u) & 63u][2 * EW_WW + a0] >> (p0 & 31u);
-			const u64 valid = __ballot(inq) & tilem;
-			const u64 slow = __ballot(ne && !fast) & valid;
-			if(slow){
-				if(ne && !fast && ((slow >> lane) & 1ull)){
-					const int yi = (y + k0) - (int)lane;
-					m3 = (uint32_t)plane_bit((uint32_t)yi + 1u, 0, (long)xi - (long)beg); m4 = (uint32_t)plane_bit((uint32_t)yi + 1u, 1, (long)xi - (long)beg);
-					m1 = (uint32_t)plane_bit((uint32_t)yi, 0, (long)xi - (long)begn); m2 = (uint32_t)plane_bit((uint32_t)yi, 1, (long)xi - (long)begn);
-				}
-			}
-			// I: (u3, u4) == (0, 1); else D: (u1, u2) == (1, 0)
-			const u64 nem = __ballot(ne) & valid;
-			const u64 mI = __ballot(((~m3 & m4) & 1u) != 0u) & nem;
-			const u64 mD = __ballot(((m1 & ~m2) & 1u) != 0u) & nem & ~mI;
+			const int xs = x + k0;
+			const uint32_t sh = (uint32_t)(shK - xs);
+			const uint32_t qb = (uint32_t)s_q[xs - qK];
+			const u64 mNE = __ballot(qb != tb);
+			const u64 mS = __ballot((int)(SM << (sh & 31u)) < 0) | ~__ballot(sh < 32u);
+			const uint32_t c = (31u - sh) & 31u;
+			const uint32_t cls = ((IM >> c) & 1u) | (((VM >> c) & 1u) << 1);      // bit 0: insertion, bit 1: looked up here
 			const u64 below = (1ull << k0) - 1ull;                  // k0 <= 63
-			const u64 stopm = (~valid | mI | mD) & ~below;          // lane 63 always stops
+			u64 stopm = ((mNE & mS) | ~tilem) & ~below;             // lane 63 always stops
+			if(xs < 63) stopm |= ~0ull << (xs + 1);                  // columns left of the query
 			const int k = __builtin_ctzll(stopm);
 			const int n = k - k0;
 			if(n > 0){
 				const u64 range = ((1ull << k) - 1ull) & ~below;
-				const int mism = __popcll(nem & range);
+				const int mism = __popcll(mNE & range);
 				rs.mat += n - mism; rs.mis += mism;
 				emit(0u, (uint32_t)n);
 				x -= n; y -= n;
 			}
-			const bool kI = (mI >> k) & 1ull, kD = (mD >> k) & 1ull;
-			if(kI){ rs.ins++; emit(1u, 1u); x--; k0 = k; }
-			else if(kD){ rs.del++; emit(2u, 1u); y--; k0 = k + 1; }
-			else break;
+			if(!((tilem >> k) & 1ull) || x < 0) break;               // end of the tile / of the walk
+			const uint32_t shk = (uint32_t)__builtin_amdgcn_readlane((int)sh, k);
+			const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cls, k);
+			bool isI, isD;
+			if(shk < 32u && (ck & 2u)){ isI = ck & 1u; isD = !isI; }   // (a stop inside VM is I or D)
+			else {
+				// literally (bsalign.h:986-1010), the lookups as plain loads: outside the band or the windows
+				const long pb1 = (long)x - (long)__builtin_amdgcn_readlane((int)beg, k), pb0 = (long)x - (long)__builtin_amdgcn_readlane((int)begn, k);
+				const int u3 = plane_bit((uint32_t)y + 1u, 0, pb1), u4 = plane_bit((uint32_t)y + 1u, 1, pb1);
+				isI = u3 == 0 && u4 == 1; isD = false;
+				if(!isI){ const int u1 = plane_bit((uint32_t)y, 0, pb0), u2 = plane_bit((uint32_t)y, 1, pb0); isD = u1 == 1 && u2 == 0; }
+			}
+			if(isI){
+				rs.ins++; emit(1u, 1u); x--; k0 = k;
+				if(x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qK = (int)lane + qw_lo; }
+			}
+			else if(isD){ rs.del++; emit(2u, 1u); y--; k0 = k + 1; }
+			else { rs.mis++; emit(0u, 1u); x--; y--; k0 = k + 1; }    // a mismatch the masks could not decide
 			if(k0 > 62) break;
 		}
 	}
