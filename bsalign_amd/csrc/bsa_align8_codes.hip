@@ -1185,13 +1185,14 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;
 		const char *we = getenv("BSA_ALIGN8_TRACE_WAVE");              // =0: the pair-per-lane walker
-		if(we && we[0] == '0') hipLaunchKernelGGL(k_align8_trace_codes2, dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt);
-		else hipLaunchKernelGGL(k_align8_trace_codes2_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
+		if(we && we[0] == '0'){ bsa_last_trace_kernel = "k_align8_trace_codes2"; hipLaunchKernelGGL(k_align8_trace_codes2, dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt); }
+		else { bsa_last_trace_kernel = "k_align8_trace_codes2_wave"; hipLaunchKernelGGL(k_align8_trace_codes2_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt); }
 		return hipGetLastError();
 	}
 	// BSA_ALIGN8_TRACE_SIMPLE=1: the plain kernel (kept as the reference point)
 	static const bool simple = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
 	const uint32_t blocks = (a.count + 63u) / 64u;
+	bsa_last_trace_kernel = simple ? "k_align8_trace_codes_simple" : (a.bw == 256u) ? "k_align8_trace_codes_simple" : "k_align8_trace_codes_lds";
 	switch(a.bw / 16){
 		case 4:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
@@ -1202,7 +1203,7 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 			const char *we = getenv("BSA_ALIGN8_TRACE_WAVE");
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
 			else if(we && we[0] == '0') launch_trace_lds<8>(a, out, cig_cnt, st);
-			else hipLaunchKernelGGL(k_align8_trace_codes_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
+			else { bsa_last_trace_kernel = "k_align8_trace_codes_wave"; hipLaunchKernelGGL(k_align8_trace_codes_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt); }
 			break;
 		}
 		case 16: hipLaunchKernelGGL((k_align8_trace_codes_simple<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;

@@ -105,6 +105,7 @@ extern "C" int bsa_ctx_last_trace_ms(bsa_ctx_t *c, double *ms, long *launches){
 	if(launches) *launches = n;
 	return BSA_OK;
 }
+thread_local const char *bsa_last_fwd_kernel = nullptr, *bsa_last_trace_kernel = nullptr;
 extern "C" const char *bsa_ctx_last_kernel_name(bsa_ctx_t *c, int traceback){ return !c ? "" : traceback ? c->trace_name.c_str() : c->fwd_name.c_str(); }
 
 static int ctx_trace_event_pair(bsa_ctx *c, hipEvent_t *a, hipEvent_t *b){
@@ -640,7 +641,8 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	c->fwd_name = (fwd_x && pw == 2) ? "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)"
 		: fwd_x ? "k_align8_fwd_x (exact-arithmetic forward DP, 4-bit traceback codes)" : codes ? "k_align8_fwd_pk<.,.,true> (packed forward DP, 4-bit traceback codes)"
 		: generic ? "k_align8_fwd_gen (run-time bandwidth, row records)" : "k_align8_fwd_pk / k_align8_fwd (row records)";
-	c->trace_name = (codes && pw == 2) ? "k_align8_trace_codes2" : codes ? "k_align8_trace_codes_lds" : "k_align8_backcal";
+	c->trace_name = codes ? "" : "k_align8_backcal";
+	bsa_last_trace_kernel = nullptr;
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
 		if(codes && fwd_x) HIPCHK(c, bsa_launch_align8_fwd_x(b, pw, s));
@@ -655,7 +657,9 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		else HIPCHK(c, bsa_launch_align8_backcal(b, pw, d_out, cnt, s));
 		return BSA_OK;
 	};
-	return run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);
+	const int rc8 = run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);
+	if(codes && bsa_last_trace_kernel) c->trace_name = bsa_last_trace_kernel;
+	return rc8;
 }
 
 extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_bytes,
@@ -897,9 +901,11 @@ extern "C" int bsa_edit_run(bsa_edit_plan_t *p, const uint8_t *d_seqs, bsa_resul
 		HIPCHK(c, bsa_launch_edit_trace(b, d_out, cnt, s));
 		return BSA_OK;
 	};
-	c->fwd_name = "k_edit_fwd_grp / k_edit_fwd / k_edit_fwd_wide / k_edit_fwd_gen (forward DP, by band class)";
-	c->trace_name = "k_edit_trace";
-	return run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);
+	bsa_last_fwd_kernel = bsa_last_trace_kernel = nullptr;
+	const int rce = run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);
+	c->fwd_name = bsa_last_fwd_kernel ? bsa_last_fwd_kernel : "k_edit_fwd*";         // (the last launch class of the batch)
+	c->trace_name = bsa_last_trace_kernel ? bsa_last_trace_kernel : "k_edit_trace";
+	return rce;
 }
 
 extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_bytes,

@@ -197,6 +197,8 @@ hipError_t bsa_launch_align8_fwd_pk(const Align8Args &a, int pw, hipStream_t st)
 bool bsa_align8_codes_supported(const Align8Args &a, int pw);          // global mode, piecewise <= 1, small scores
 hipError_t bsa_launch_align8_fwd_codes(const Align8Args &a, int pw, hipStream_t st);
 bool bsa_align8_x_supported(const Align8Args &a, int pw);              // exact-arithmetic forward kernel of the compact path (bsa_align8_x.hip)
+// the kernels the launchers picked last (this thread), for bsa_ctx_last_kernel_name
+extern thread_local const char *bsa_last_fwd_kernel, *bsa_last_trace_kernel;
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st);
 hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);
 bool bsa_edit_supported_bw(uint32_t bw);

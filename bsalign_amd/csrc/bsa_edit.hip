@@ -1237,6 +1237,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 			if(const char *e = getenv("BSA_EDIT_GRP32")) g32 = a.bw != 0u && nw >= 1u && nw <= 8u && e[0] == '1';
 			if(getenv("BSA_EDIT_GRP")) g32 = false;
 			if(g32){
+				bsa_last_fwd_kernel = "k_edit_fwd_grp32 (forward DP, 32-bit words, 2 NW lanes per pair)";
 				const uint32_t ppw = 64u / G32, gblocks = ((a.count + ppw - 1) / ppw + 3) / 4;
 				switch(G32){
 					case 2: hipLaunchKernelGGL((k_edit_fwd_grp32<2>), dim3(gblocks), dim3(256), 0, st, a); break;
@@ -1248,6 +1249,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 			}
 		}
 		if(grp){
+			bsa_last_fwd_kernel = "k_edit_fwd_grp (forward DP, NW lanes per pair)";
 			const uint32_t ppw = 64u / G, gblocks = ((a.count + ppw - 1) / ppw + 3) / 4;
 			switch(G){
 				case 2: hipLaunchKernelGGL((k_edit_fwd_grp<2>), dim3(gblocks), dim3(256), 0, st, a); break;
@@ -1258,6 +1260,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 			return hipGetLastError();
 		}
 	}
+	bsa_last_fwd_kernel = a.bw ? "k_edit_fwd (forward DP, one pair per lane)" : "k_edit_fwd_wide / k_edit_fwd_gen (forward DP, bands above 1024 columns)";
 	switch(a.bw / 64){
 		EDIT_CASE(1) EDIT_CASE(2) EDIT_CASE(3) EDIT_CASE(4) EDIT_CASE(5) EDIT_CASE(6) EDIT_CASE(7) EDIT_CASE(8)
 		EDIT_CASE(9) EDIT_CASE(10) EDIT_CASE(11) EDIT_CASE(12) EDIT_CASE(13) EDIT_CASE(14) EDIT_CASE(15) EDIT_CASE(16)
@@ -1301,6 +1304,7 @@ hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t 
 		if(const char *e = getenv("BSA_EDIT_TRACE_WAVE")) wave = e[0] == '1';
 		if(getenv("BSA_EDIT_TRACE_LANES") || getenv("BSA_EDIT_TRACE_COOP")) wave = false;
 		if(wave){
+			bsa_last_trace_kernel = "k_edit_trace_wave";
 			hipLaunchKernelGGL(k_edit_trace_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
 			return hipGetLastError();
 		}
@@ -1312,6 +1316,7 @@ hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t 
 	while(lanes < 64u && (a.count + lanes - 1) / lanes > (lanes <= 8u && coop_ok ? slots_c : slots_p)) lanes <<= 1;
 	if(const char *e = getenv("BSA_EDIT_TRACE_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) lanes = (uint32_t)v; }
 	const uint32_t blocks = (a.count + lanes - 1) / lanes;
+	bsa_last_trace_kernel = "k_edit_trace";
 	if(lanes <= 8u && lanes >= 2u && coop_ok) hipLaunchKernelGGL(k_edit_trace<true>, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt, lanes);
 	else hipLaunchKernelGGL(k_edit_trace<false>, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt, lanes);
 	return hipGetLastError();

@@ -154,8 +154,11 @@ def test_literal_row_record_path_still_matches(ctx, monkeypatch):
     _check(ctx, [S.synth_pair(k, 10000) for k in range(8)], S.MODE_GLOBAL, 128, SCORINGS["affine"])
 
 
-def test_compact_path_band_and_ratio_corners(ctx):
-    """length mismatches (rush-to-end steering, band jumps), tiny inputs and high divergence through the compact path"""
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_compact_path_band_and_ratio_corners(ctx, monkeypatch, wave):
+    """length mismatches (rush-to-end steering, band jumps), tiny inputs and high divergence through the compact path, with
+    the one-walk-per-wave traceback (bandwidth 128) and with the pair-per-lane LDS-ring kernel"""
+    monkeypatch.setenv("BSA_ALIGN8_TRACE_WAVE", wave)
     rng = np.random.default_rng(99)
     pairs = []
     for _ in range(120):
@@ -172,10 +175,13 @@ def test_compact_path_band_and_ratio_corners(ctx):
             _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS[sc])
 
 
-def test_two_piece_gaps_take_the_compact_path(ctx):
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_two_piece_gaps_take_the_compact_path(ctx, monkeypatch, wave):
     """2-piece gaps (POA default and others), global, bandwidth 128: 8-bit traceback codes written by k_align8_fwd_x2 and walked by
-    k_align8_trace_codes2 -- results identical to the oracle's literal backcal, corners included, and the plan really is compact"""
+    k_align8_trace_codes2_wave (one walk per wave) or k_align8_trace_codes2 (one per lane) -- results identical to the oracle's
+    literal backcal, corners included, and the plan really is compact"""
     import bsalign_amd as B
+    monkeypatch.setenv("BSA_ALIGN8_TRACE_WAVE", wave)
     rng = np.random.default_rng(2025)
     pairs = _mk_pairs(rng, 160, [1, 2, 15, 16, 17, 63, 64, 65, 100, 300, 1000, 2500])
     for _ in range(60):                                      # length mismatches: steering rushes, band jumps
@@ -187,7 +193,8 @@ def test_two_piece_gaps_take_the_compact_path(ctx):
         pairs.append((Q if len(Q) else np.array([2], np.uint8), T))
     for sc in ((2, -6, -3, -2, -8, -1), (2, -4, -4, -2, -12, -1), (3, -5, -2, -3, -9, -1), (1, -3, -2, -2, -6, -1)):
         _check(ctx, pairs, S.MODE_GLOBAL, 128, sc)
-        assert "k_align8_fwd_x2" in ctx.last_kernel_names()[0] and ctx.last_kernel_names()[1] == "k_align8_trace_codes2"
+        assert "k_align8_fwd_x2" in ctx.last_kernel_names()[0]
+        assert ctx.last_kernel_names()[1] == ("k_align8_trace_codes2_wave" if wave == "1" else "k_align8_trace_codes2")
 
 
 def test_handover_to_literal_path_merges_results(ctx, monkeypatch):
