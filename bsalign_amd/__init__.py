@@ -69,6 +69,10 @@ RESULT_DTYPE = np.dtype([(n, np.int32) for n in ("score", "qb", "qe", "tb", "te"
 _lib = None
 
 
+DIAGDP_PROB_DTYPE = np.dtype([("seq0", np.uint64), ("seq1", np.uint64), ("mats0", np.uint64, (4,)), ("mats1", np.uint64, (4,)),
+                              ("out0", np.uint64), ("out1", np.uint64), ("mlen", np.uint32), ("mbeg", np.uint32), ("mend", np.uint32), ("W", np.uint32)])
+
+
 def build():
     """compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)"""
     import subprocess
@@ -134,6 +138,9 @@ def lib():
         L.bsa_sweep_run.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(SweepParams), vp]
         L.bsa_sweep_host.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.POINTER(SweepParams), vp, C.c_size_t, vp]
         L.bsa_align_debug_rows.argtypes = [vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.bsa_diagdp_batch.argtypes = [vp, u8p, C.c_size_t, vp, C.c_size_t, u8p, C.c_size_t]
+        L.bsa_diagdp_last_ms.argtypes = [vp]
+        L.bsa_diagdp_last_ms.restype = C.c_double
         _lib = L
     return _lib
 
@@ -262,6 +269,19 @@ class Context:
                               rows.ctypes.data if want_rows else None, nblocks, res.ctypes.data)
         self._chk(rc)
         return rows, res
+
+    def diagdp_batch(self, planes, probs, matrix_bytes):
+        """anti-diagonal u8 DP of the MSA refinement (bsa_diagdp_batch): planes = uint8 blob in the reference's layout,
+        probs = DIAGDP_PROB_DTYPE array; returns the matrix buffer (uint8, rows outside 2 mbeg .. 2 mend - 1 zero)"""
+        L = lib()
+        planes = np.ascontiguousarray(planes, dtype=np.uint8)
+        probs = np.ascontiguousarray(probs, dtype=DIAGDP_PROB_DTYPE)
+        matrix = np.zeros(matrix_bytes, dtype=np.uint8)
+        self._chk(L.bsa_diagdp_batch(self.h, planes.ctypes.data, planes.size, probs.ctypes.data, len(probs), matrix.ctypes.data, matrix.size))
+        return matrix
+
+    def diagdp_last_ms(self):
+        return float(lib().bsa_diagdp_last_ms(self.h))
 
     def edit_batch(self, pairs, mode=MODE_GLOBAL, bandwidth=0, cigar_cap=None):
         p = EditParams()

@@ -32,6 +32,7 @@ struct bsa_ctx {
 	std::vector<hipEvent_t> tev;     // the same for the traceback launches (on the stream they run on)
 	size_t tev_used = 0;
 	std::string fwd_name, trace_name;    // kernels behind those two timings
+	double diagdp_ms = 0;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t _e = (call); if(_e != hipSuccess){ (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e); return BSA_E_HIP; } } while(0)
@@ -932,5 +933,64 @@ extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_byt
 	if(timing) fprintf(stderr, "[bsa_edit_batch] %zu pairs: plan %.1f ms (%zu chunks, %zu forward launches), copy + run + copy %.1f ms, destroy %.1f ms\n", n,
 		std::chrono::duration<double, std::milli>(t1 - t0).count(), nch, nsub, std::chrono::duration<double, std::milli>(t2 - t1).count(),
 		std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
+	return rc;
+}
+
+// ---- anti-diagonal u8 DP of the MSA refinement (bsa_diagdp.hip), host pointers
+extern "C" double bsa_diagdp_last_ms(bsa_ctx_t *c){ return c ? c->diagdp_ms : 0.0; }
+extern "C" int bsa_diagdp_batch(bsa_ctx_t *c, const uint8_t *planes, size_t planes_bytes, const bsa_diagdp_prob_t *probs, size_t n,
+		uint8_t *matrix, size_t matrix_bytes){
+	if(!c) return BSA_E_ARG;
+	if(n == 0) return BSA_OK;
+	if(!planes || !probs || !matrix || n > 0x7fffffffu){ c->err = "bsa_diagdp_batch: null argument"; return BSA_E_ARG; }
+	(void)hipSetDevice(c->device);
+	const uint32_t W = probs[0].W;
+	if(!(W == 1 || W == 2 || W == 4)){ c->err = "bsa_diagdp_batch: W must be 1, 2 or 4"; return BSA_E_ARG; }
+	const uint64_t pad = 8ull * W, rowlen = 16ull * W + 2;
+	std::vector<uint64_t> toff(n);
+	uint64_t tacc = 0; uint32_t max_len = 0;
+	for(size_t k = 0; k < n; k++){
+		const bsa_diagdp_prob_t &p = probs[k];
+		if(p.W != W || p.mbeg > p.mend || p.mend > p.mlen){ c->err = "bsa_diagdp_batch: bad problem"; return BSA_E_ARG; }
+		const uint64_t offs[10] = {p.seq0, p.seq1, p.mats0[0], p.mats0[1], p.mats0[2], p.mats0[3], p.mats1[0], p.mats1[1], p.mats1[2], p.mats1[3]};
+		for(uint64_t o : offs) if(o < pad || o + p.mlen + pad > planes_bytes){ c->err = "bsa_diagdp_batch: plane outside the blob (8 W bytes of padding on both sides)"; return BSA_E_ARG; }
+		const uint64_t rows = 2ull * p.mlen + 1;
+		if(p.out0 + rows * rowlen > matrix_bytes || p.out1 + rows * rowlen > matrix_bytes){ c->err = "bsa_diagdp_batch: matrix plane outside the buffer"; return BSA_E_ARG; }
+		toff[k] = tacc; tacc += 2ull * (p.mlen + 16ull * W);
+		max_len = std::max<uint32_t>(max_len, p.mlen + 16u * W);
+	}
+	uint8_t *d_planes = nullptr, *d_matrix = nullptr; bsa_diagdp_prob_t *d_probs = nullptr; uint32_t *d_T = nullptr; uint64_t *d_toff = nullptr;
+	int rc = BSA_OK;
+	auto fail = [&](const char *what, hipError_t e){ c->err = std::string(what) + ": " + hipGetErrorString(e); rc = (e == hipErrorOutOfMemory) ? BSA_E_NOMEM : BSA_E_HIP; };
+	hipError_t e;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	do {
+		if((e = hipMalloc((void**)&d_planes, planes_bytes)) != hipSuccess){ fail("hipMalloc", e); break; }
+		if((e = hipMalloc((void**)&d_matrix, matrix_bytes)) != hipSuccess){ fail("hipMalloc", e); break; }
+		if((e = hipMalloc((void**)&d_probs, n * sizeof(bsa_diagdp_prob_t))) != hipSuccess){ fail("hipMalloc", e); break; }
+		if((e = hipMalloc((void**)&d_T, tacc * sizeof(uint32_t))) != hipSuccess){ fail("hipMalloc", e); break; }
+		if((e = hipMalloc((void**)&d_toff, n * sizeof(uint64_t))) != hipSuccess){ fail("hipMalloc", e); break; }
+		if((e = hipMemcpyAsync(d_planes, planes, planes_bytes, hipMemcpyHostToDevice, c->stream)) != hipSuccess){ fail("hipMemcpyAsync", e); break; }
+		if((e = hipMemcpyAsync(d_probs, probs, n * sizeof(bsa_diagdp_prob_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess){ fail("hipMemcpyAsync", e); break; }
+		if((e = hipMemcpyAsync(d_toff, toff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess){ fail("hipMemcpyAsync", e); break; }
+		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+		(void)hipEventRecord(ev0, c->stream);
+		if((e = bsa_launch_diagdp(d_planes, d_probs, d_T, d_toff, d_matrix, (uint32_t)n, W, max_len, c->stream)) != hipSuccess){ fail("bsa_launch_diagdp", e); break; }
+		(void)hipEventRecord(ev1, c->stream);
+		// only the rows the DP wrote travel back (the reference never reads others of this read)
+		for(size_t k = 0; k < n && rc == BSA_OK; k++){
+			const bsa_diagdp_prob_t &p = probs[k];
+			if(p.mend == p.mbeg) continue;
+			const uint64_t first = 2ull * p.mbeg * rowlen, bytes = (2ull * (p.mend - p.mbeg)) * rowlen;
+			if((e = hipMemcpyAsync(matrix + p.out0 + first, d_matrix + p.out0 + first, bytes, hipMemcpyDeviceToHost, c->stream)) != hipSuccess){ fail("hipMemcpyAsync", e); break; }
+			if((e = hipMemcpyAsync(matrix + p.out1 + first, d_matrix + p.out1 + first, bytes, hipMemcpyDeviceToHost, c->stream)) != hipSuccess){ fail("hipMemcpyAsync", e); break; }
+		}
+		if(rc != BSA_OK) break;
+		if((e = hipStreamSynchronize(c->stream)) != hipSuccess){ fail("hipStreamSynchronize", e); break; }
+		float ms = 0; if(hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) c->diagdp_ms = ms;
+	} while(0);
+	if(ev0) (void)hipEventDestroy(ev0);
+	if(ev1) (void)hipEventDestroy(ev1);
+	(void)hipFree(d_planes); (void)hipFree(d_matrix); (void)hipFree(d_probs); (void)hipFree(d_T); (void)hipFree(d_toff);
 	return rc;
 }

@@ -197,6 +197,8 @@ hipError_t bsa_launch_align8_fwd_pk(const Align8Args &a, int pw, hipStream_t st)
 bool bsa_align8_codes_supported(const Align8Args &a, int pw);          // global mode, piecewise <= 1, small scores
 hipError_t bsa_launch_align8_fwd_codes(const Align8Args &a, int pw, hipStream_t st);
 bool bsa_align8_x_supported(const Align8Args &a, int pw);              // exact-arithmetic forward kernel of the compact path (bsa_align8_x.hip)
+hipError_t bsa_launch_diagdp(const uint8_t *d_planes, const bsa_diagdp_prob_t *d_probs, uint32_t *d_T, const uint64_t *d_toff, uint8_t *d_matrix,
+		uint32_t n, uint32_t W, uint32_t max_len, hipStream_t st);
 // the kernels the launchers picked last (this thread), for bsa_ctx_last_kernel_name
 extern thread_local const char *bsa_last_fwd_kernel, *bsa_last_trace_kernel;
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st);

@@ -284,6 +284,25 @@ int bsa_sweep_host(bsa_ctx_t *ctx, const bsa_row_task_t *tasks, size_t ntasks, c
  * stride = bsa_synth_stride(L).  *_host fills host memory (no GPU needed); *_dev fills device
  * memory on the context stream and writes qlen to a device array. */
 size_t bsa_synth_stride(uint32_t L);
+/* ---- the anti-diagonal u8 DP of the MSA refinement (reference: maxmat_dp_diag_rowcal bspoa.h:3856-3896, driven by the
+ * fill loop of remsa_pedit_rd_bspoacore bspoa.h:3925-3935; replaces that loop, the traceback that follows it stays the
+ * caller's).  One problem = one read of a POA window against the window's column profile.  `planes` holds the ten byte
+ * planes in the reference's own layout (bspoa.h:4213-4233): the offsets point at LOGICAL index 0 of a plane, which carries
+ * 8 W bytes of padding in front of it and behind index mlen - 1 (seq planes: base codes, >= 4 = no base; mats planes: u8
+ * counts).  `matrix` receives rows 2 mbeg .. 2 mend - 1 of the two difference planes (row r of a plane at out + r (16 W + 2),
+ * cell c at byte 1 + c, guard cells at bytes 0 and 16 W + 1); other rows are not written.  All problems of a call share W
+ * (1, 2 or 4: band of 16, 32 or 64 cells). */
+typedef struct {
+	uint64_t seq0, seq1;            /* read plane (x side), consensus plane (y side, reversed as the reference stores it) */
+	uint64_t mats0[4], mats1[4];    /* mats[0][b], mats[1][b] */
+	uint64_t out0, out1;            /* row 0 of matrix[0], matrix[1] inside `matrix` */
+	uint32_t mlen, mbeg, mend, W;
+} bsa_diagdp_prob_t;
+int bsa_diagdp_batch(bsa_ctx_t *ctx, const uint8_t *planes, size_t planes_bytes, const bsa_diagdp_prob_t *probs, size_t n,
+                     uint8_t *matrix, size_t matrix_bytes);
+/* device time of the last bsa_diagdp_batch (staging + fill kernels), ms */
+double bsa_diagdp_last_ms(bsa_ctx_t *ctx);
+
 int bsa_synth_pairs_host(uint64_t seed, uint64_t first_pair, size_t n, uint32_t L, uint32_t err_q32,
                          uint8_t *seqs, uint32_t *qlen);
 int bsa_synth_pairs_dev(bsa_ctx_t *ctx, uint64_t seed, uint64_t first_pair, size_t n, uint32_t L, uint32_t err_q32,

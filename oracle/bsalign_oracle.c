@@ -1243,3 +1243,43 @@ void orc_sweep_run(uint8_t *rows, const orc_row_task_t *tasks, const orc_sweep_p
 	}
 	free(tmp);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * anti-diagonal u8 DP of remsa_pedits (TEST infrastructure like everything here)
+ * Follows maxmat_dp_diag_rowcal_init bspoa.h:3752-3761, maxmat_dp_diag_rowcal_prepare :3763-3787, maxmat_dp_diag_rowcal
+ * :3856-3896 and the fill loop of remsa_pedit_rd_bspoacore :3925-3935.  Step i = x + y (x == y on even steps, x == y + 1 on odd
+ * ones, so the window always starts at x - half / mlen - 1 - y - half) computes row i + 1 from row i:
+ *   s = sat_u8(mats0[seq1[c]][c] + mats1[seq0[c]][c])      (0 where the base code is >= 4)
+ *   even i ("down"):  u = r0[i][c], v = r1[i][c - 1];   odd i ("left"):  u = r0[i][c + 1], v = r1[i][c]
+ *   h = max(s, u, v);   r0[i + 1][c] = h - v;   r1[i + 1][c] = h - u
+ * and the two guard cells of the new row: odd i: r0[-1] = 255, the other three 0; even i: r1[16 W] = 255, the others 0.
+ * --------------------------------------------------------------------------------------------- */
+void orc_diagdp_fill(const uint8_t *seq0, const uint8_t *seq1, const uint8_t *const mats0[4], const uint8_t *const mats1[4],
+		int mlen, int mbeg, int mend, int W, uint8_t *matrix0, uint8_t *matrix1){
+	const int bw = W * 16, rowlen = bw + 2, half = bw / 2;
+	{       /* init: the row of step 2 mbeg */
+		uint8_t *r0 = matrix0 + (size_t)(2 * mbeg) * rowlen, *r1 = matrix1 + (size_t)(2 * mbeg) * rowlen;
+		memset(r0, 0, (size_t)rowlen); memset(r1, 0, (size_t)rowlen);
+		r0[1 + half - 1] = 255; r1[1 + half] = 255;
+	}
+	int x = mbeg, y = mbeg;
+	for(int i = x + y;; i++){
+		const int dir = i & 1;
+		const int xb = x - half, yb = mlen - 1 - (y + half);
+		const uint8_t *p0 = matrix0 + (size_t)i * rowlen + 1, *p1 = matrix1 + (size_t)i * rowlen + 1;
+		uint8_t *n0 = matrix0 + (size_t)(i + 1) * rowlen + 1, *n1 = matrix1 + (size_t)(i + 1) * rowlen + 1;
+		for(int c = 0; c < bw; c++){
+			const int b1 = seq1[yb + c], b0 = seq0[xb + c];
+			int s = (b1 < 4 ? mats0[b1][xb + c] : 0) + (b0 < 4 ? mats1[b0][yb + c] : 0);
+			if(s > 255) s = 255;
+			const int u = dir ? p0[c + 1] : p0[c], v = dir ? p1[c] : p1[c - 1];
+			int h = s > u ? s : u;
+			if(v > h) h = v;
+			n0[c] = (uint8_t)(h - v); n1[c] = (uint8_t)(h - u);
+		}
+		if(dir){ n0[-1] = 255; n1[-1] = 0; n0[bw] = 0; n1[bw] = 0; }
+		else { n0[-1] = 0; n1[-1] = 0; n0[bw] = 0; n1[bw] = 255; }
+		if(dir) y++; else x++;
+		if(x >= mend) break;
+	}
+}

@@ -128,3 +128,8 @@ double   orc_edit_batch_time(const uint8_t *seqs, const uint64_t *qoff, const ui
 }
 #endif
 #endif
+
+/* anti-diagonal u8 DP of remsa_pedits (bspoa.h:3752-3896, loop :3925-3935): fills rows 2 mbeg .. 2 mend - 1 of the two planes
+ * (row = 16 W + 2 bytes, cell c at byte 1 + c) */
+void orc_diagdp_fill(const uint8_t *seq0, const uint8_t *seq1, const uint8_t *const mats0[4], const uint8_t *const mats1[4],
+		int mlen, int mbeg, int mend, int W, uint8_t *matrix0, uint8_t *matrix1);

@@ -418,3 +418,25 @@ void ref_poa_core_stats(void *vp, double *seconds, uint64_t *updates, uint64_t *
 	ref_poa_t *p = (ref_poa_t*)vp;
 	*seconds = p->core_seconds; *updates = p->core_updates; *merges = p->core_merges;
 }
+
+/* ---- the anti-diagonal u8 DP of remsa_pedits: the REAL maxmat_dp_diag_rowcal_init / _prepare /
+ * maxmat_dp_diag_rowcal (bspoa.h:3752-3896) driven by the loop of remsa_pedit_rd_bspoacore (bspoa.h:3925-3935) on arrays the
+ * caller supplies in the layout of remsa_pedits_bspoa (bspoa.h:4213-4233): seq0 / seq1 / mats[s][b] point at logical index 0
+ * of planes that carry bandwidth / 2 bytes of padding in front and behind; matrix[p] holds (2 mlen + 1) rows of
+ * 16 W + 2 bytes.  Only the rows the loop writes (2 mbeg .. 2 mend - 1) are touched. */
+void ref_diagdp_fill(uint8_t *seq0, uint8_t *seq1, uint8_t *m00, uint8_t *m01, uint8_t *m02, uint8_t *m03,
+		uint8_t *m10, uint8_t *m11, uint8_t *m12, uint8_t *m13, int mlen, int mbeg, int mend, int W, uint8_t *matrix0, uint8_t *matrix1){
+	u1i *matrix[2] = {matrix0, matrix1}, *_seqs[2] = {seq0, seq1}, *_mats[2][4] = {{m00, m01, m02, m03}, {m10, m11, m12, m13}};
+	u1i *rows[2][2], *seqs[2], *mats[2][4];
+	int i, x, y, dir;
+	MM_EPI8_ALL0 = mm_set1_epi8(0); MM_EPI8_ALL1 = mm_set1_epi8(1); MM_EPI8_ALL2 = mm_set1_epi8(2); MM_EPI8_ALL3 = mm_set1_epi8(3);   /* bspoa.h:4192-4195 */
+	maxmat_dp_diag_rowcal_init(W, mbeg, matrix);
+	x = y = mbeg;
+	for(i = x + y;; i++){
+		dir = (i & 0x1);
+		maxmat_dp_diag_rowcal_prepare(x, y, mlen, W, matrix, _seqs, _mats, rows, seqs, mats);
+		maxmat_dp_diag_rowcal(W, dir, rows, seqs, mats);
+		if(dir) y ++; else x ++;
+		if(x >= mend) break;
+	}
+}
