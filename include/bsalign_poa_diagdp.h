@@ -1,0 +1,115 @@
+/*
+ * bsalign_poa_diagdp.h -- reference-side binding of the MSA refinement's DP (libbsalign_hip: bsa_diagdp_batch).
+ *
+ * Compiled INSIDE the reference's tree: patches/bspoa_device_diagdp.diff includes it in front of remsa_pedits_bspoa
+ * (bspoa.h:4178) and adds one field to BSPOA (devdiag).  With g->devdiag set, remsa_pedits_bspoa calls
+ * bsa_poa_diagdp_window() once per window, before its loop over the reads: the planes of EVERY read of the window are
+ * built here the way the loop builds them one read at a time (bspoa.h:4424-4440: the read's bases at their MSA
+ * positions, the homopolymer counter behind each base; reading the nodes only -- the loop still cuts, traces and
+ * reconnects every read in the reference's order), the window's shared planes (consensus, column profile,
+ * bspoa.h:4236-4247, 4339-4345) are copied, and ONE bsa_diagdp_batch call fills the two difference planes of all reads
+ * (maxmat_dp_diag_rowcal, bspoa.h:3856-3896).  The loop then hands remsa_pedit_rd_bspoacore (bspoa.h:3916) the read's
+ * planes with `filled` set, which skips the fill (bspoa.h:3925-3935) and goes straight to the traceback.
+ * Reads that were not part of the graph yet (rid >= nrds, the `all` pass) keep the host fill.
+ */
+#ifndef BSALIGN_POA_DIAGDP_H
+#define BSALIGN_POA_DIAGDP_H
+
+#include "bsalign_hip.h"
+
+typedef int (*bsa_poa_diagdp_fn)(void *user, const uint8_t *planes, size_t planes_bytes, const bsa_diagdp_prob_t *probs, size_t n,
+		uint8_t *matrix, size_t matrix_bytes);
+
+typedef struct {
+	bsa_poa_diagdp_fn run;           /* bsa_diagdp_batch with user = bsa_ctx_t* */
+	void *user;
+	uint8_t *planes, *matrix;        /* grown as needed, kept between windows */
+	size_t planes_cap, matrix_cap;
+	bsa_diagdp_prob_t *probs;
+	uint8_t **ptrs;                  /* [2 * nseq]: the two planes of every read inside `matrix` (NULL: host fill) */
+	size_t cap;
+	/* statistics */
+	uint64_t calls, reads, steps;
+} bsa_poa_diagdp_t;
+
+static inline int bsa_poa_diagdp_hip(void *user, const uint8_t *planes, size_t planes_bytes, const bsa_diagdp_prob_t *probs, size_t n,
+		uint8_t *matrix, size_t matrix_bytes){
+	return bsa_diagdp_batch((bsa_ctx_t*)user, planes, planes_bytes, probs, n, matrix, matrix_bytes);
+}
+static inline void bsa_poa_diagdp_init(bsa_poa_diagdp_t *dd, bsa_poa_diagdp_fn run, void *user){ memset(dd, 0, sizeof(*dd)); dd->run = run; dd->user = user; }
+static inline void bsa_poa_diagdp_free(bsa_poa_diagdp_t *dd){ free(dd->planes); free(dd->matrix); free(dd->probs); free(dd->ptrs); memset(dd, 0, sizeof(*dd)); }
+
+/* seq1 / mats1: the window's shared planes as remsa_pedits_bspoa holds them (logical index 0, bandwidth / 2 bytes of
+ * padding in front).  Returns dd->ptrs, or NULL when the band is not one the device kernel takes (the caller then fills
+ * on the host, as without the patch). */
+static inline uint8_t** bsa_poa_diagdp_window(BSPOA *g, bsa_poa_diagdp_t *dd, u1i *seq1, u1i *mats1[4], u4i mlen, u4i bandwidth, u4i nseq){
+	const u4i W = bandwidth / WORDSIZE, HW = bandwidth / 2;
+	const size_t PS = roundup_times(mlen + bandwidth, WORDSIZE);                       /* one plane */
+	const size_t MS = roundup_times((size_t)(2 * mlen + 1) * (bandwidth + 2), WORDSIZE);    /* one matrix plane */
+	size_t need_p, need_m, n = 0, slack;
+	uint8_t stale[4 * WORDSIZE];
+	u4i rid, rdlen, b, i;
+	bspoanode_t *v;
+	if(!(W == 1 || W == 2 || W == 4) || nseq == 0 || mlen == 0) return NULL;
+	need_p = PS * 5 * ((size_t)nseq + 1);
+	need_m = MS * 2 * (size_t)nseq;
+	if(need_p > dd->planes_cap){ free(dd->planes); dd->planes = (uint8_t*)malloc(need_p); dd->planes_cap = need_p; }
+	if(need_m > dd->matrix_cap){ free(dd->matrix); dd->matrix = (uint8_t*)malloc(need_m); dd->matrix_cap = need_m; }
+	if(nseq > dd->cap){
+		free(dd->probs); free(dd->ptrs);
+		dd->probs = (bsa_diagdp_prob_t*)malloc(sizeof(bsa_diagdp_prob_t) * nseq);
+		dd->ptrs = (uint8_t**)malloc(sizeof(uint8_t*) * 2 * nseq);
+		dd->cap = nseq;
+	}
+	if(dd->planes == NULL || dd->matrix == NULL || dd->probs == NULL || dd->ptrs == NULL){ fprintf(stderr, " -- out of memory in %s -- %s:%d --\n", __FUNCTION__, __FILE__, __LINE__); abort(); }
+	memcpy(dd->planes, seq1 - HW, PS);
+	for(b=0;b<4;b++) memcpy(dd->planes + PS * (1 + b), mats1[b] - HW, PS);
+	/* The reference clears its four mats[0] planes with ONE memset of 4 * (mlen + bandwidth) bytes (bspoa.h:4349) although the
+	 * planes lie roundup(mlen + bandwidth, 16) bytes apart: the last 4 * slack bytes of plane 3 are never cleared, and what an
+	 * earlier read of the loop wrote there (counts behind T bases in the last columns) is still there for the later ones.  The
+	 * DP reads those bytes, so they are carried from read to read here exactly as they survive there. */
+	slack = PS - (mlen + bandwidth);
+	memset(stale, 0, sizeof(stale));
+	for(rid=0;rid<nseq;rid++){
+		uint8_t *rp = dd->planes + PS * 5 * ((size_t)rid + 1);
+		bsa_diagdp_prob_t *pb;
+		u1i lc = 4, cc = 0;
+		dd->ptrs[2 * rid] = dd->ptrs[2 * rid + 1] = NULL;
+		rdlen = g->seqs->rdlens->buffer[rid];
+		if(rdlen == 0) continue;
+		memset(rp, 4, PS);
+		memset(rp + PS, 0, 4 * PS);
+		memcpy(rp + PS * 5 - 4 * slack, stale, 4 * slack);
+		for(i=rdlen;i>0;i--){                                  /* bspoa.h:4426-4436, without the cut */
+			v = get_rdnode_bspoa(g, rid, i - 1);
+			rp[HW + v->mpos] = v->base;
+			if(v->base == lc){
+				if(cc < MAX_U1) cc ++;
+				rp[PS * (1 + v->base) + HW + v->mpos] = cc;
+			} else {
+				lc = v->base;
+				cc = 0;
+			}
+		}
+		memcpy(stale, rp + PS * 5 - 4 * slack, 4 * slack);
+		pb = dd->probs + n;
+		pb->seq0 = PS * 5 * ((size_t)rid + 1) + HW;
+		pb->seq1 = HW;
+		for(b=0;b<4;b++){ pb->mats0[b] = PS * 5 * ((size_t)rid + 1) + PS * (1 + b) + HW; pb->mats1[b] = PS * (1 + b) + HW; }
+		pb->out0 = MS * 2 * (size_t)rid; pb->out1 = pb->out0 + MS;
+		pb->mlen = mlen; pb->W = W;
+		pb->mbeg = get_rdnode_bspoa(g, rid, 0)->mpos;
+		pb->mend = get_rdnode_bspoa(g, rid, rdlen - 1)->mpos + 1;
+		dd->ptrs[2 * rid] = dd->matrix + pb->out0; dd->ptrs[2 * rid + 1] = dd->matrix + pb->out1;
+		dd->steps += 2 * (uint64_t)(pb->mend - pb->mbeg) - 1;
+		n ++;
+	}
+	if(n && dd->run(dd->user, dd->planes, need_p, dd->probs, n, dd->matrix, need_m) != 0){
+		fprintf(stderr, " -- device DP failed in %s -- %s:%d --\n", __FUNCTION__, __FILE__, __LINE__);
+		abort();                                               /* the reference's error convention */
+	}
+	dd->calls ++; dd->reads += n;
+	return dd->ptrs;
+}
+
+#endif

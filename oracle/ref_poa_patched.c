@@ -15,6 +15,9 @@ typedef void (*fn_bvoid)(bsa_sweep_batcher_t*);
 typedef int (*fn_bsubmit)(void*, const bsa_row_task_t*, size_t, const uint8_t*, uint32_t, const bsa_sweep_params_t*, uint8_t*, size_t, bsa_sweep_result_t*);
 static fn_sweep_host p_sweep_host; static fn_bcreate p_bcreate; static fn_bvoid p_bdestroy, p_bleave; static fn_bsubmit p_bsubmit;
 static bsa_ctx_t *p_ctx;
+typedef int (*fn_diagdp)(bsa_ctx_t*, const uint8_t*, size_t, const bsa_diagdp_prob_t*, size_t, uint8_t*, size_t);
+static fn_diagdp p_diagdp;
+void refp_attach_diagdp(void *diagdp){ p_diagdp = (fn_diagdp)diagdp; }
 void refp_attach(void *ctx, void *sweep_host, void *bcreate, void *bdestroy, void *bsubmit, void *bleave){
 	p_ctx = (bsa_ctx_t*)ctx; p_sweep_host = (fn_sweep_host)sweep_host; p_bcreate = (fn_bcreate)bcreate; p_bdestroy = (fn_bvoid)bdestroy;
 	p_bsubmit = (fn_bsubmit)bsubmit; p_bleave = (fn_bvoid)bleave;
@@ -29,6 +32,10 @@ HID void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b){ if(p_bdestroy) p_bde
 HID void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *b){ if(p_bleave) p_bleave(b); }
 HID int bsa_sweep_batcher_submit(void *b, const bsa_row_task_t *t, size_t nt, const uint8_t *q, uint32_t sl, const bsa_sweep_params_t *par, uint8_t *rows, size_t nb, bsa_sweep_result_t *res){
 	return p_bsubmit ? p_bsubmit(b, t, nt, q, sl, par, rows, nb, res) : BSA_E_UNSUPPORTED;
+}
+
+HID int bsa_diagdp_batch(bsa_ctx_t *c, const uint8_t *planes, size_t pb, const bsa_diagdp_prob_t *probs, size_t n, uint8_t *m, size_t mb){
+	return p_diagdp ? p_diagdp(c, planes, pb, probs, n, m, mb) : BSA_E_UNSUPPORTED;
 }
 
 #include "bsalign.h"
@@ -62,13 +69,22 @@ void refp_push(void *vg, const uint8_t *reads, const uint64_t *offs, const uint3
 	}
 	free(buf);
 }
-/* how = 0: the reference's end_bspoa untouched; 1: bsa_poa_end_one on every window; 2: bsa_poa_end_many */
+/* how = 0: the reference's end_bspoa untouched; 1: bsa_poa_end_one on every window; 2: bsa_poa_end_many;
+ * 3: end_bspoa with the MSA refinement's DP on the device (devdiag); 4: devdiag and the sweeps (bsa_poa_end_one) */
+static uint64_t g_dd_calls, g_dd_reads, g_dd_steps;
 int refp_end(void **gs, int n, int how){
 	int k;
 	if(how == 2) return bsa_poa_end_many((BSPOA**)gs, n, p_ctx);
-	for(k = 0; k < n; k++){ if(how == 1) bsa_poa_end_one((BSPOA*)gs[k], p_ctx); else end_bspoa((BSPOA*)gs[k]); }
+	for(k = 0; k < n; k++){
+		BSPOA *g = (BSPOA*)gs[k];
+		bsa_poa_diagdp_t dd;
+		if(how >= 3){ bsa_poa_diagdp_init(&dd, bsa_poa_diagdp_hip, p_ctx); g->devdiag = &dd; }
+		if(how == 1 || how == 4) bsa_poa_end_one(g, p_ctx); else end_bspoa(g);
+		if(how >= 3){ g->devdiag = NULL; g_dd_calls += dd.calls; g_dd_reads += dd.reads; g_dd_steps += dd.steps; bsa_poa_diagdp_free(&dd); }
+	}
 	return 0;
 }
+void refp_diagdp_stats(uint64_t *calls, uint64_t *reads, uint64_t *steps){ *calls = g_dd_calls; *reads = g_dd_reads; *steps = g_dd_steps; }
 uint32_t refp_cns_len(void *g){ return (uint32_t)((BSPOA*)g)->cns->size; }
 void refp_cns(void *vg, uint8_t *cns, uint8_t *qlt, uint8_t *alt){
 	BSPOA *g = (BSPOA*)vg;

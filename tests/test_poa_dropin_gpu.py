@@ -79,3 +79,30 @@ def test_patched_end_bspoa_one_window_and_many(ctx):
     plain, _ = P.run_many(windows, 0, p, threads=4)
     for (cns, qlt, alt, msa), d in zip(ref, plain):
         assert np.array_equal(cns, d["cns"]) and np.array_equal(qlt, d["qlt"]) and np.array_equal(alt, d["alt"])
+
+
+def test_refinement_dp_on_the_device_inside_end_bspoa(ctx):
+    """patches/bspoa_device_diagdp.diff + include/bsalign_poa_diagdp.h: end_bspoa with remsa_pedits filling the DP matrices of
+    all reads of a window in one bsa_diagdp_batch call (how = 3), and with the graph sweeps on the device as well (how = 4):
+    consensus, qualities, alternative bases and MSA of the untouched run"""
+    import time
+    import bsalign_amd as B
+    L = _lib(ctx)
+    L.refp_attach_diagdp.argtypes = [C.c_void_p]
+    L.refp_diagdp_stats.argtypes = [C.c_void_p] * 3
+    L.refp_attach_diagdp(C.cast(B.lib().bsa_diagdp_batch, C.c_void_p))
+    p = P.par()
+    rng = np.random.default_rng(8)
+    windows = [P.synth_reads(700 + w, int(rng.integers(300, 1500)), int(rng.integers(4, 16)), eps=(0.1,)) for w in range(12)]
+    ref = _run(L, windows, p, 0)
+    _same(ref, _run(L, windows, p, 3))
+    _same(ref, _run(L, windows[:3], p, 4))
+    calls, reads, steps = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    L.refp_diagdp_stats(C.byref(calls), C.byref(reads), C.byref(steps))
+    assert calls.value >= 15 and reads.value >= sum(len(w) for w in windows)
+    # one C4-shaped window (64 reads x 20 kbp): wall time of end_bspoa with and without the device DP
+    big = [P.synth_reads(4242, 20000, 64, eps=(0.1,))]
+    t0 = time.time(); a = _run(L, big, p, 0); t_ref = time.time() - t0
+    t0 = time.time(); b = _run(L, big, p, 3); t_dev = time.time() - t0
+    _same(a, b)
+    print("\n[C4 full size] end_bspoa 64 x 20 kbp: reference %.2f s, with the MSA refinement's DP on the device %.2f s" % (t_ref, t_dev))
