@@ -373,17 +373,43 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	const uint8_t *rows = (const uint8_t*)begs + bsa_begs_bytes(tlen);
 	const uint32_t *codes = (const uint32_t*)rows;
 	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * RB);
-	// CIGAR words: one per lane, a 256-byte store per 64 words (word m at cig_end - (m + 1))
-	uint32_t ncig = 0, cg = 0, cigreg = 0;
-	auto cig_push = [&](uint32_t w){
-		const uint32_t j = ncig & 63u;
-		if(lane == j) cigreg = w;
-		ncig++;
-		if(j == 63u) *(cig_end - (ncig - 63u + lane)) = cigreg;
+	// CIGAR.  The walker does not merge runs step by step (that logic was a third of the scalar instructions of a step): it records
+	// one TOKEN per gap event -- (matches / mismatches since the last event, op, length), one token per lane -- and a gap that simply
+	// goes on (no match in between, same op: the rows of a deletion run, consecutive insertions) extends its own token, so that
+	// neighbouring tokens never carry the same op.  Every 64 tokens (the last one stays: it may still grow) the lanes turn their
+	// tokens into words side by side: an M word when the run is not empty, then the gap's word, positions from two prefix popcounts
+	// (word m at cig_end - (m + 1)).  The word sequence is the reference's run-length merge (bsalign.h:409-417) of the same op stream.
+	uint32_t ncig = 0, tokN = 0, tokB = 0;            // words written; the lane's token: run length, len << 2 | op (op 0: none)
+	uint32_t ntok = 0, lastop = 0, carryM = 0;        // (uniform) tokens held, op of the last one, matches since the last event
+	auto tok_flush = [&](uint32_t cnt){
+		const bool in = lane < cnt;
+		const bool hasA = in && tokN != 0u, hasB = in && (tokB & 3u) != 0u;
+		const uint64_t mA = __ballot(hasA), mB = __ballot(hasB);
+		const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u))
+			+ __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
+		uint32_t *wp = cig_end - (ncig + below + 1u);
+		if(hasA){ *wp = tokN << 4; wp--; }
+		if(hasB) *wp = ((tokB >> 2) << 4) | (tokB & 3u);
+		ncig += (uint32_t)(__popcll(mA) + __popcll(mB));
 	};
 	auto emit = [&](uint32_t op, uint32_t len){
-		if(op == (cg & 0xfu)) cg += len << 4;
-		else { if(cg) cig_push(cg); cg = (len << 4) | op; }
+		if(op == 0u){ carryM += len; return; }
+		if(carryM == 0u && op == lastop){ if(lane + 1u == ntok) tokB += len << 2; return; }
+		if(ntok == 64u){
+			tok_flush(63u);
+			tokN = (uint32_t)__builtin_amdgcn_readlane((int)tokN, 63); tokB = (uint32_t)__builtin_amdgcn_readlane((int)tokB, 63);
+			ntok = 1u;
+		}
+		if(lane == ntok){ tokN = carryM; tokB = (len << 2) | op; }
+		ntok++; lastop = op; carryM = 0u;
+	};
+	auto cig_finish = [&](){                          // the matches behind the last event, then everything out
+		if(carryM){
+			if(ntok == 64u){ tok_flush(64u); ntok = 0u; }
+			if(lane == ntok){ tokN = carryM; tokB = 0u; }
+			ntok++; carryM = 0u; lastop = 0u;
+		}
+		tok_flush(ntok); ntok = 0u;
 	};
 	bool bad = false;
 	if(type == BSA_MODE_GLOBAL){
@@ -584,17 +610,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	if(!bad && dlen && y < 0 && (!lin || x >= bw)) bad = true;        // a deletion run that reached row -1: see the general step of the LDS kernel
 	if(!bad){
 		rs.qb = x; rs.tb = y;
-		if(type == BSA_MODE_OVERLAP){ if(cg) cig_push(cg); }
-		else {
+		if(type != BSA_MODE_OVERLAP){
 			uint32_t op = 0, sz = 0;
 			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
 			else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
-			emit(op, sz);
-			if(cg) cig_push(cg);
+			if(sz) emit(op, sz);
 		}
+		cig_finish();
 		rs.qb++; rs.tb++;
 		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
-		if(lane < (ncig & 63u)) *(cig_end - ((ncig & ~63u) + lane + 1u)) = cigreg;
 	} else {
 		if(lane == 0) atomicOr(&a.status[pair], BSA_ST_TRACE);
 		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
@@ -913,16 +937,43 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 	const uint32_t *codes = (const uint32_t*)rows;
 	uint32_t *cig_end = (uint32_t*)(rows + ((size_t)bsa_code_rows(tlen) + BSA_CODE_SPARE_ROWS) * RB);
 	const int go1 = a.gapo1, ge1 = a.gape1, go2 = a.gapo2, ge2 = a.gape2;
-	uint32_t ncig = 0, cg = 0, cigreg = 0;
-	auto cig_push = [&](uint32_t w){
-		const uint32_t j = ncig & 63u;
-		if(lane == j) cigreg = w;
-		ncig++;
-		if(j == 63u) *(cig_end - (ncig - 63u + lane)) = cigreg;
+	// CIGAR.  The walker does not merge runs step by step (that logic was a third of the scalar instructions of a step): it records
+	// one TOKEN per gap event -- (matches / mismatches since the last event, op, length), one token per lane -- and a gap that simply
+	// goes on (no match in between, same op: the rows of a deletion run, consecutive insertions) extends its own token, so that
+	// neighbouring tokens never carry the same op.  Every 64 tokens (the last one stays: it may still grow) the lanes turn their
+	// tokens into words side by side: an M word when the run is not empty, then the gap's word, positions from two prefix popcounts
+	// (word m at cig_end - (m + 1)).  The word sequence is the reference's run-length merge (bsalign.h:409-417) of the same op stream.
+	uint32_t ncig = 0, tokN = 0, tokB = 0;            // words written; the lane's token: run length, len << 2 | op (op 0: none)
+	uint32_t ntok = 0, lastop = 0, carryM = 0;        // (uniform) tokens held, op of the last one, matches since the last event
+	auto tok_flush = [&](uint32_t cnt){
+		const bool in = lane < cnt;
+		const bool hasA = in && tokN != 0u, hasB = in && (tokB & 3u) != 0u;
+		const uint64_t mA = __ballot(hasA), mB = __ballot(hasB);
+		const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u))
+			+ __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
+		uint32_t *wp = cig_end - (ncig + below + 1u);
+		if(hasA){ *wp = tokN << 4; wp--; }
+		if(hasB) *wp = ((tokB >> 2) << 4) | (tokB & 3u);
+		ncig += (uint32_t)(__popcll(mA) + __popcll(mB));
 	};
 	auto emit = [&](uint32_t op, uint32_t len){
-		if(op == (cg & 0xfu)) cg += len << 4;
-		else { if(cg) cig_push(cg); cg = (len << 4) | op; }
+		if(op == 0u){ carryM += len; return; }
+		if(carryM == 0u && op == lastop){ if(lane + 1u == ntok) tokB += len << 2; return; }
+		if(ntok == 64u){
+			tok_flush(63u);
+			tokN = (uint32_t)__builtin_amdgcn_readlane((int)tokN, 63); tokB = (uint32_t)__builtin_amdgcn_readlane((int)tokB, 63);
+			ntok = 1u;
+		}
+		if(lane == ntok){ tokN = carryM; tokB = (len << 2) | op; }
+		ntok++; lastop = op; carryM = 0u;
+	};
+	auto cig_finish = [&](){                          // the matches behind the last event, then everything out
+		if(carryM){
+			if(ntok == 64u){ tok_flush(64u); ntok = 0u; }
+			if(lane == ntok){ tokN = carryM; tokB = 0u; }
+			ntok++; carryM = 0u; lastop = 0u;
+		}
+		tok_flush(ntok); ntok = 0u;
 	};
 	bool bad = false;
 	rs.score = begs[tlen + 1];
@@ -1145,11 +1196,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 		uint32_t op = 0, sz = 0;
 		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
 		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
-		emit(op, sz);
-		if(cg) cig_push(cg);
+		if(sz) emit(op, sz);
+		cig_finish();
 		rs.qb++; rs.tb++;
 		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
-		if(lane < (ncig & 63u)) *(cig_end - ((ncig & ~63u) + lane + 1u)) = cigreg;
 	} else {
 		if(lane == 0) atomicOr(&a.status[pair], BSA_ST_TRACE);
 		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;

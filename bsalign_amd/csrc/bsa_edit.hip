@@ -963,18 +963,41 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	rx = __builtin_amdgcn_readfirstlane(rx); ry = __builtin_amdgcn_readfirstlane(ry);
 	// ---- backtrace
 	uint32_t *cig_end = (uint32_t*)((uint8_t*)rows + (size_t)(tlen + 1 + a.pad_rows) * (2 * NW) * 8);
-	// CIGAR words (back to front, word m at cig_end - (m + 1)) are collected one per lane and leave as one 256-byte store per
-	// 64 words: a store per word would put a wait for the previous store into every step
-	uint32_t ncig = 0, cg = 0, cigreg = 0;
-	auto cig_push = [&](uint32_t w){
-		const uint32_t j = ncig & 63u;
-		if(lane == j) cigreg = w;
-		ncig++;
-		if(j == 63u) *(cig_end - (ncig - 63u + lane)) = cigreg;
+	// CIGAR: one token per gap event (matches / mismatches since the last event, op, length), one token per lane; a gap that goes
+	// on (same op, no match in between) extends its own token, so neighbouring tokens never carry the same op and every 64 tokens
+	// the lanes turn them into words side by side (an M word when the run is not empty, then the gap's word; positions from two
+	// prefix popcounts; word m at cig_end - (m + 1)).  The same scheme as k_align8_trace_codes_wave (bsa_align8_codes.hip).
+	uint32_t ncig = 0, tokN = 0, tokB = 0;            // words written; the lane's token: run length, len << 2 | op (op 0: none)
+	uint32_t ntok = 0, lastop = 0, carryM = 0;        // (uniform) tokens held, op of the last one, matches since the last event
+	auto tok_flush = [&](uint32_t cnt){
+		const bool in = lane < cnt;
+		const bool hasA = in && tokN != 0u, hasB = in && (tokB & 3u) != 0u;
+		const u64 mA = __ballot(hasA), mB = __ballot(hasB);
+		const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u))
+			+ __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
+		uint32_t *wp = cig_end - (ncig + below + 1u);
+		if(hasA){ *wp = tokN << 4; wp--; }
+		if(hasB) *wp = ((tokB >> 2) << 4) | (tokB & 3u);
+		ncig += (uint32_t)(__popcll(mA) + __popcll(mB));
 	};
 	auto emit = [&](uint32_t op, uint32_t len){
-		if(op == (cg & 0xfu)) cg += 0x10u * len;
-		else { if(cg) cig_push(cg); cg = (0x10u * len) | op; }
+		if(op == 0u){ carryM += len; return; }
+		if(carryM == 0u && op == lastop){ if(lane + 1u == ntok) tokB += len << 2; return; }
+		if(ntok == 64u){
+			tok_flush(63u);
+			tokN = (uint32_t)__builtin_amdgcn_readlane((int)tokN, 63); tokB = (uint32_t)__builtin_amdgcn_readlane((int)tokB, 63);
+			ntok = 1u;
+		}
+		if(lane == ntok){ tokN = carryM; tokB = (len << 2) | op; }
+		ntok++; lastop = op; carryM = 0u;
+	};
+	auto cig_finish = [&](){
+		if(carryM){
+			if(ntok == 64u){ tok_flush(64u); ntok = 0u; }
+			if(lane == ntok){ tokN = carryM; tokB = 0u; }
+			ntok++; carryM = 0u; lastop = 0u;
+		}
+		tok_flush(ntok); ntok = 0u;
 	};
 	int x = rx, y = ry;
 	const bool bad = (rx >= (int)qlen);
@@ -1151,8 +1174,7 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		if(rs.qb){ emit(1u, (uint32_t)rs.qb); rs.ins += rs.qb; rs.qb = 0; }
 		if((type == BSA_MODE_GLOBAL || type == BSA_MODE_EXTEND) && rs.tb){ emit(2u, (uint32_t)rs.tb); rs.del += rs.tb; rs.tb = 0; }
 		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
-		if(cg) cig_push(cg);
-		if(lane < (ncig & 63u)) *(cig_end - ((ncig & ~63u) + lane + 1u)) = cigreg;
+		cig_finish();
 		if(type == BSA_MODE_OVERLAP) rs.score = smin + rs.te - rs.tb;
 		else if(type == BSA_MODE_EXTEND) rs.score = smin;
 		else rs.score = score;
