@@ -631,7 +631,8 @@ def main():
             "dtype": "i8" if args.workload == "align8" else "u64-bitplanes",
             "data": "synthetic (splitmix64 pairs, eps=%.2f, sub:ins:del=23:31:46, seed %d)" % (args.eps, SEED),
             "config": {"workload": "%s: %d pairs/GPU x %d bp, mode %s, bandwidth %d, scoring M,X,O,E,Q,P=%s" % (args.workload, n, L, args.mode, bw, args.scoring),
-                       "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world},
+                       "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world,
+                       "timed": "stage + forward + traceback + CIGAR compaction on device-resident inputs; plan creation (host planning, slot layout) and PCIe are outside the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": dname, "kernel_ms_avg": round(dms, 3), "launches_per_step": dlaunch,
