@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		// prior_match is dropped at the first column of the previous row's band (bsalign.h:3761-3764): that cell is taken out of
 		// the M plane and left to the literal step
 		const uint32_t cpm = (uint32_t)(bp - cb);
-		if(cpm < 32u) RM &= ~(1u << cpm);
+		if(cpm < 32u && bp != 0) RM &= ~(1u << cpm);                    // (column 0 keeps prior_match: `... && qb`)
 		const int shK = 31 + (int)lane + cb;                            // 31 - c = shK - xs for the lane's window cell c = xs - lane - cb
 		if(x + k0 - 63 < qw_lo && qw_lo > 0) q_refill(x);               // the query bases of all 64 cells are in the window
 		int qKr = (int)lane + qw_lo;                                    // index into s_q = xs - qKr
@@ -1054,7 +1054,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 		const int cb = bc + 8 * b0;
 		if(T - (int)lane < 0) RM = 0u;
 		const uint32_t cpm = (uint32_t)(bp - cb);
-		if(cpm < 32u) RM &= ~(1u << cpm);                              // prior_match column (bsalign.h:3761-3764): the literal step
+		if(cpm < 32u && bp != 0) RM &= ~(1u << cpm);                    // (column 0 keeps prior_match: `... && qb`)                              // prior_match column (bsalign.h:3761-3764): the literal step
 		const int shK = 31 + (int)lane + cb;
 		if(x + k0 - 63 < qw_lo && qw_lo > 0) q_refill(x);
 		int qKr = (int)lane + qw_lo;

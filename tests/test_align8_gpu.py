@@ -250,3 +250,22 @@ def test_sharded_flow_over_rccl_single_rank():
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
     assert "identical to the oracle: True" in r.stdout
+
+
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_ties_at_column_zero(ctx, monkeypatch, wave):
+    """scorings full of ties (match == -mismatch == -gap) on short, very divergent pairs: cells of query column 0 where both the
+    M and the D flag are set keep prior_match (`... && qb`, bsalign.h:3761-3764), so M wins there although the column is the first
+    of the previous row's band -- a randomised campaign found the one-walk-per-wave kernel taking D; all three modes, 1- and 2-piece"""
+    monkeypatch.setenv("BSA_ALIGN8_TRACE_WAVE", wave)
+    rng = np.random.default_rng(5)
+    pairs = []
+    for _ in range(600):
+        L = int(rng.choice([4, 10, 14, 17, 20, 33, 70]))
+        T = rng.integers(0, 4, size=L).astype(np.uint8)
+        Q = S.mutate(rng, T, 0.4)
+        pairs.append((Q if len(Q) else np.array([1], np.uint8), T))
+    for sc in ((1, -1, -1, -1, 0, 0), (2, -2, -4, -2, 0, 0), (3, -4, -6, -1, 0, 0)):
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+            _check(ctx, pairs, mode, 128, sc)
+    _check(ctx, pairs, S.MODE_GLOBAL, 128, (1, -3, -2, -2, -6, -1))
