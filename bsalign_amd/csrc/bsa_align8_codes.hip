@@ -1054,7 +1054,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 		const int cb = bc + 8 * b0;
 		if(T - (int)lane < 0) RM = 0u;
 		const uint32_t cpm = (uint32_t)(bp - cb);
-		if(cpm < 32u && bp != 0) RM &= ~(1u << cpm);                    // (column 0 keeps prior_match: `... && qb`)                              // prior_match column (bsalign.h:3761-3764): the literal step
+		if(cpm < 32u && bp != 0) RM &= ~(1u << cpm);                    // prior_match column (bsalign.h:3761-3764): the literal step; column 0 keeps prior_match (`... && qb`)
 		const int shK = 31 + (int)lane + cb;
 		if(x + k0 - 63 < qw_lo && qw_lo > 0) q_refill(x);
 		int qKr = (int)lane + qw_lo;
