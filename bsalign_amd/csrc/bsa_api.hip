@@ -171,16 +171,30 @@ __global__ void __launch_bounds__(256) k_stage(const uint8_t *seqs, const uint64
 	const uint8_t *q = seqs + qoff[k], *t = seqs + toff[k];
 	uint8_t *dq = qst + qpoff[k], *dt = tst + tpoff[k];
 	uint32_t bad = 0;
-	for(uint32_t i = threadIdx.x; i < ql + qpad; i += 256){
-		uint8_t c = (i < ql) ? q[i] : (uint8_t)BSA_QPAD_CODE;
-		if(i < ql && c > 3){ bad = 1; c &= 3; }
-		dq[i] = c;
-	}
-	for(uint32_t i = threadIdx.x; i < tl + tpad; i += 256){
-		uint8_t c = (i < tl) ? t[i] : (uint8_t)0;
-		if(c > 3){ bad = 1; c &= 3; }
-		dt[i] = c;
-	}
+	// 16 bytes per thread and trip (the staged regions are 16-byte aligned and a whole number of 16-byte pieces, the source is
+	// not aligned and ends with the sequence): whole pieces with two 8-byte loads, the piece that holds the end byte by byte
+	auto copy = [&](const uint8_t *src, uint8_t *dst, uint32_t len, uint32_t pad, uint8_t padcode){
+		const uint32_t total = (len + pad + 15u) & ~15u;
+		for(uint32_t i = threadIdx.x * 16u; i < total; i += 256u * 16u){
+			uint64_t v0, v1;
+			if(i + 16u <= len){
+				__builtin_memcpy(&v0, src + i, 8); __builtin_memcpy(&v1, src + i + 8, 8);
+				if((v0 | v1) & 0xFCFCFCFCFCFCFCFCull){ bad = 1; v0 &= 0x0303030303030303ull; v1 &= 0x0303030303030303ull; }
+			} else {
+				v0 = v1 = 0;
+#pragma unroll
+				for(uint32_t b = 0; b < 16u; b++){
+					uint8_t c = (i + b < len) ? src[i + b] : padcode;
+					if(i + b < len && c > 3){ bad = 1; c &= 3; }
+					if(b < 8u) v0 |= (uint64_t)c << (8u * b); else v1 |= (uint64_t)c << (8u * (b - 8u));
+				}
+			}
+			uint4 o; o.x = (uint32_t)v0; o.y = (uint32_t)(v0 >> 32); o.z = (uint32_t)v1; o.w = (uint32_t)(v1 >> 32);
+			*(uint4*)(dst + i) = o;
+		}
+	};
+	copy(q, dq, ql, qpad, (uint8_t)BSA_QPAD_CODE);
+	copy(t, dt, tl, tpad, (uint8_t)0);
 	uint32_t st = 0;
 	if(__syncthreads_or((int)bad)) st |= BSA_ST_BAD_BASE;
 	if(ql == 0 || tl == 0) st |= BSA_ST_EMPTY;
