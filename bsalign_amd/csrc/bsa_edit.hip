@@ -1198,24 +1198,38 @@ __global__ void __launch_bounds__(256) k_edit_stage(const uint8_t *seqs, const u
 	uint8_t *dq = qst + qpoff[k], *dt = tst + tpoff[k];
 	u64 *p0 = qbits + qboff[k], *p1 = p0 + nw;
 	uint32_t bad = 0;
-	for(uint32_t w = threadIdx.x; w < nw; w += 256){
-		u64 b0 = 0, b1 = 0;
-		for(uint32_t b = 0; b < 64; b++){
-			uint32_t i = w * 64u + b;
-			if(i < ql){
-				uint8_t c = q[i];
+	// 16 bases per thread and trip: two 8-byte loads (the piece that holds the end byte by byte), the staged bytes as one 16-byte
+	// store, the two planes as 16 bits each (bit 0 / bit 1 of eight bytes gathered by a multiplication)
+	auto piece = [&](const uint8_t *src, uint32_t len, uint32_t i, u64 &v0, u64 &v1){
+		if(i + 16u <= len){
+			__builtin_memcpy(&v0, src + i, 8); __builtin_memcpy(&v1, src + i + 8, 8);
+			if((v0 | v1) & 0xFCFCFCFCFCFCFCFCull){ bad = 1; v0 &= 0x0303030303030303ull; v1 &= 0x0303030303030303ull; }
+		} else {
+			v0 = v1 = 0;
+#pragma unroll
+			for(uint32_t b = 0; b < 16u; b++){
+				uint8_t c = (i + b < len) ? src[i + b] : (uint8_t)0;
 				if(c > 3){ bad = 1; c &= 3; }
-				b0 |= (u64)(c & 1u) << b;
-				b1 |= (u64)((c >> 1) & 1u) << b;
+				if(b < 8u) v0 |= (u64)c << (8u * b); else v1 |= (u64)c << (8u * (b - 8u));
 			}
 		}
-		p0[w] = b0; p1[w] = b1;
+	};
+	auto gather = [](u64 v) -> uint32_t { return (uint32_t)(((v & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); };   // bit 0 of byte j -> bit j
+	const uint32_t qbytes = (ql + 16u + 15u) & ~15u, qplane = nw * 64u;
+	for(uint32_t i = threadIdx.x * 16u; i < max(qbytes, qplane); i += 256u * 16u){
+		u64 v0, v1;
+		piece(q, ql, i, v0, v1);
+		if(i < qbytes){ uint4 o; o.x = (uint32_t)v0; o.y = (uint32_t)(v0 >> 32); o.z = (uint32_t)v1; o.w = (uint32_t)(v1 >> 32); *(uint4*)(dq + i) = o; }
+		if(i < qplane){
+			((uint16_t*)p0)[i >> 4] = (uint16_t)(gather(v0) | (gather(v1) << 8));
+			((uint16_t*)p1)[i >> 4] = (uint16_t)(gather(v0 >> 1) | (gather(v1 >> 1) << 8));
+		}
 	}
-	for(uint32_t i = threadIdx.x; i < ql + 16; i += 256) dq[i] = (i < ql) ? (uint8_t)(q[i] & 3) : (uint8_t)0;
-	for(uint32_t i = threadIdx.x; i < tl + 16; i += 256){
-		uint8_t c = (i < tl) ? t[i] : (uint8_t)0;
-		if(c > 3){ bad = 1; c &= 3; }
-		dt[i] = c;
+	const uint32_t tbytes = (tl + 16u + 15u) & ~15u;
+	for(uint32_t i = threadIdx.x * 16u; i < tbytes; i += 256u * 16u){
+		u64 v0, v1;
+		piece(t, tl, i, v0, v1);
+		uint4 o; o.x = (uint32_t)v0; o.y = (uint32_t)(v0 >> 32); o.z = (uint32_t)v1; o.w = (uint32_t)(v1 >> 32); *(uint4*)(dt + i) = o;
 	}
 	uint32_t st = 0;
 	if(__syncthreads_or((int)bad)) st |= BSA_ST_BAD_BASE;
