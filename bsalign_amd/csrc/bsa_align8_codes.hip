@@ -352,9 +352,14 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 // dwords: conflict-free).  The next tile's codes and the band offsets of the one after travel while a tile is walked.
 // Anything outside the window is read with a plain load; the query bases sit in a 512-byte LDS window.
 #define CWV_QWIN 512
+// W = 4, 8, 16 (bandwidth 64, 128, 256).  The window is always 32 cells: eight blocks of one code dword at W = 4 (two 16-byte
+// loads per lane), four at W = 8, two blocks of two dwords at W = 16; ND dwords per row in LDS, stride ND + 1.
+template<int W>
 __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
-	constexpr int W = 8, bw = 128, STR = 5;
-	constexpr uint32_t RB = 64u;
+	static_assert(W == 4 || W == 8 || W == 16, "bandwidth 64, 128, 256");
+	constexpr int bw = 16 * W, ND = (W == 4) ? 8 : 4, STR = ND + 1;
+	constexpr uint32_t CW = (W == 16) ? 2u : 1u, RB = 64u * CW, FULL = (W == 16) ? 0xFFFFu : ((1u << W) - 1u);
+	constexpr int NB = 32 / W, B0MAX = 16 - NB;                        // blocks in the window, last window start
 	__shared__ uint32_t tile[64 * STR];
 	__shared__ int s_b0[16];
 	__shared__ __attribute__((aligned(8))) uint8_t s_q[CWV_QWIN];
@@ -424,7 +429,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	int prior = 0, dlen = 0;
 	// ---- tiles
 	struct TB { int bc, bp; uint32_t tb; };
-	struct TC { uint4 w; int b0; };
+	struct TC { uint32_t v0, v1, v2, v3, v4, v5, v6, v7; int b0; };    // W = 8: rows 0..3 of one block; W = 4: of two blocks; W = 16: two rows x two dwords
 	auto fetch_begs = [&](int T, TB &t){
 		const int r = T - (int)lane;
 		if(r >= 0){ t.bc = begs[r + 1]; t.bp = begs[r]; t.tb = (uint32_t)tseq[r]; }
@@ -436,11 +441,24 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		const int bcg = __shfl(tb_.bc, (int)(gi * 4u));              // band offset of the group's top row
 		int pp = (xT - 4 * (int)gi) - bcg;
 		pp = pp < 0 ? 0 : pp > bw - 1 ? bw - 1 : pp;
-		int b0 = (pp >> 3) - 1;
-		b0 = b0 < 0 ? 0 : b0 > 12 ? 12 : b0;
+		int b0 = (W == 16) ? (pp - 8) >> 4 : (W == 8) ? (pp >> 3) - 1 : (pp >> 2) - 3;       // the diagonal in the middle of the window
+		b0 = b0 < 0 ? 0 : b0 > B0MAX ? B0MAX : b0;
 		c.b0 = b0;
-		if(G >= 0) c.w = *(const uint4*)(codes + ((size_t)G * 64u + (size_t)((uint32_t)b0 + sl4) * 4u));
-		else c.w = make_uint4(0, 0, 0, 0);
+		c.v0 = c.v1 = c.v2 = c.v3 = c.v4 = c.v5 = c.v6 = c.v7 = 0u;
+		if(G >= 0){
+			if constexpr (W == 8){
+				const uint4 g0 = *(const uint4*)(codes + ((size_t)G * 64u + (size_t)((uint32_t)b0 + sl4) * 4u));
+				c.v0 = g0.x; c.v1 = g0.y; c.v2 = g0.z; c.v3 = g0.w;
+			} else if constexpr (W == 4){
+				const uint4 *gp = (const uint4*)(codes + ((size_t)G * 64u + (size_t)((uint32_t)b0 + 2u * sl4) * 4u));     // blocks b0 + 2 s, b0 + 2 s + 1
+				const uint4 g0 = gp[0], g1 = gp[1];
+				c.v0 = g0.x; c.v1 = g0.y; c.v2 = g0.z; c.v3 = g0.w; c.v4 = g1.x; c.v5 = g1.y; c.v6 = g1.z; c.v7 = g1.w;
+			} else {
+				// two dwords per block and row: block b0 + (s >> 1), rows 2 (s & 1) and 2 (s & 1) + 1
+				const uint4 g0 = *(const uint4*)(codes + ((size_t)G * 128u + (size_t)((uint32_t)b0 + (sl4 >> 1)) * 8u + (size_t)(sl4 & 1u) * 4u));
+				c.v0 = g0.x; c.v1 = g0.y; c.v2 = g0.z; c.v3 = g0.w;
+			}
+		}
 	};
 	int qw_lo = 0;
 	auto q_refill = [&](int xx){
@@ -463,8 +481,19 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	while(walking){
 		// ---- the tile of rows T - 63 .. T
 		__syncthreads();
-		tile[(4u * gi + 3u) * STR + sl4] = curC.w.x; tile[(4u * gi + 2u) * STR + sl4] = curC.w.y;
-		tile[(4u * gi + 1u) * STR + sl4] = curC.w.z; tile[(4u * gi + 0u) * STR + sl4] = curC.w.w;
+		if constexpr (W == 8){               // row 4 G + m sits at lane index 4 gi + 3 - m
+			tile[(4u * gi + 3u) * STR + sl4] = curC.v0; tile[(4u * gi + 2u) * STR + sl4] = curC.v1;
+			tile[(4u * gi + 1u) * STR + sl4] = curC.v2; tile[(4u * gi + 0u) * STR + sl4] = curC.v3;
+		} else if constexpr (W == 4){
+			tile[(4u * gi + 3u) * STR + 2u * sl4] = curC.v0; tile[(4u * gi + 2u) * STR + 2u * sl4] = curC.v1;
+			tile[(4u * gi + 1u) * STR + 2u * sl4] = curC.v2; tile[(4u * gi + 0u) * STR + 2u * sl4] = curC.v3;
+			tile[(4u * gi + 3u) * STR + 2u * sl4 + 1u] = curC.v4; tile[(4u * gi + 2u) * STR + 2u * sl4 + 1u] = curC.v5;
+			tile[(4u * gi + 1u) * STR + 2u * sl4 + 1u] = curC.v6; tile[(4u * gi + 0u) * STR + 2u * sl4 + 1u] = curC.v7;
+		} else {
+			const uint32_t ra = 4u * gi + 3u - 2u * (sl4 & 1u), co = 2u * (sl4 >> 1);
+			tile[ra * STR + co] = curC.v0; tile[ra * STR + co + 1u] = curC.v1;
+			tile[(ra - 1u) * STR + co] = curC.v2; tile[(ra - 1u) * STR + co + 1u] = curC.v3;
+		}
 		if(sl4 == 0u) s_b0[gi] = curC.b0;
 		const int bc = curB.bc, bp = curB.bp;
 		const uint32_t tbs = curB.tb;
@@ -478,15 +507,32 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		uint32_t RM, RD, RR, RO;
 		{
 			const uint32_t *mr = &tile[lane * STR];
-			const uint32_t d0 = mr[0], d1 = mr[1], d2 = mr[2], d3 = mr[3];
-			auto plane = [&](uint32_t j) -> uint32_t {
-				const uint32_t lo = __builtin_amdgcn_perm(d2, d3, 0x0c0c0000u | ((4u + j) << 8) | j);
-				const uint32_t hi = __builtin_amdgcn_perm(d0, d1, ((4u + j) << 24) | (j << 16) | 0x0c0cu);
-				return __builtin_bitreverse32(lo | hi);
-			};
-			RM = plane(0); RD = plane(1); RR = plane(2); RO = plane(3);
+			if constexpr (W == 8){
+				const uint32_t d0 = mr[0], d1 = mr[1], d2 = mr[2], d3 = mr[3];
+				auto plane = [&](uint32_t j) -> uint32_t {
+					const uint32_t lo = __builtin_amdgcn_perm(d2, d3, 0x0c0c0000u | ((4u + j) << 8) | j);
+					const uint32_t hi = __builtin_amdgcn_perm(d0, d1, ((4u + j) << 24) | (j << 16) | 0x0c0cu);
+					return __builtin_bitreverse32(lo | hi);
+				};
+				RM = plane(0); RD = plane(1); RR = plane(2); RO = plane(3);
+			} else if constexpr (W == 4){
+				// eight blocks of four cells: nibble j of block b goes to nibble 7 - b, then all 32 bits reversed (cell k is bit 3 - k)
+				uint32_t xm = 0, xd = 0, xr = 0, xo = 0;
+#pragma unroll
+				for(int b = 0; b < 8; b++){
+					const uint32_t d = mr[b];
+					xm |= (d & 0xFu) << (4 * (7 - b)); xd |= ((d >> 4) & 0xFu) << (4 * (7 - b));
+					xr |= ((d >> 8) & 0xFu) << (4 * (7 - b)); xo |= ((d >> 12) & 0xFu) << (4 * (7 - b));
+				}
+				RM = __builtin_bitreverse32(xm); RD = __builtin_bitreverse32(xd); RR = __builtin_bitreverse32(xr); RO = __builtin_bitreverse32(xo);
+			} else {
+				// two blocks of sixteen cells: dword 0 = M | D << 16, dword 1 = R | Od << 16, cell k at bit 15 - k
+				const uint32_t a0 = mr[0], a1 = mr[1], c0 = mr[2], c1 = mr[3];
+				RM = __builtin_bitreverse32(__builtin_amdgcn_perm(a0, c0, 0x05040100u)); RD = __builtin_bitreverse32(__builtin_amdgcn_perm(a0, c0, 0x07060302u));
+				RR = __builtin_bitreverse32(__builtin_amdgcn_perm(a1, c1, 0x05040100u)); RO = __builtin_bitreverse32(__builtin_amdgcn_perm(a1, c1, 0x07060302u));
+			}
 		}
-		const int cb = bc + 8 * b0;                                     // column of window cell 0
+		const int cb = bc + W * b0;                                     // column of window cell 0
 		if(T - (int)lane < 0) RM = 0u;                                  // rows above the target: never a match (the walk ends before them)
 		// prior_match is dropped at the first column of the previous row's band (bsalign.h:3761-3764): that cell is taken out of
 		// the M plane and left to the literal step
@@ -553,22 +599,24 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const uint32_t pk = (uint32_t)(x - __builtin_amdgcn_readlane(bc, k));
 			if(pk >= (uint32_t)bw){ bad = true; walking = false; break; }
 			const int bpk = __builtin_amdgcn_readlane(bp, k);
-			const int b0k = __builtin_amdgcn_readlane(b0, k);
-			const uint32_t yb = pk >> 3, kk = pk & 7u, bit = 1u << (7u - kk);
-			auto code_at = [&](uint32_t blk) -> uint32_t {
-				const uint32_t s_ = blk - (uint32_t)b0k;
-				uint32_t v = tile[(uint32_t)k * STR + (s_ & 3u)];
-				asm volatile("" : "+v"(v));                                 // keeps the LDS read and the (rare) plain load two instructions, not one flat load
-				if(s_ >= 4u) v = codes[bsa_code_off((uint32_t)y, blk, 1u)];
-				return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+			const uint32_t yb = pk / W, kk = pk % W, bit = 1u << (W - 1 - kk);
+			struct Code { uint32_t m, d, r, o; };
+			auto code_at = [&](uint32_t blk) -> Code {                       // the four planes of block blk of row y, plain loads (uniform)
+				const uint32_t *rp = codes + bsa_code_off((uint32_t)y, blk, CW);
+				const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rp[0]);
+				Code cc;
+				if constexpr (W == 4){ cc.m = w0 & 0xFu; cc.d = (w0 >> 4) & 0xFu; cc.r = (w0 >> 8) & 0xFu; cc.o = (w0 >> 12) & 0xFu; }
+				else if constexpr (W == 8){ cc.m = w0 & 0xFFu; cc.d = (w0 >> 8) & 0xFFu; cc.r = (w0 >> 16) & 0xFFu; cc.o = w0 >> 24; }
+				else { const uint32_t w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rp[1]); cc.m = w0 & 0xFFFFu; cc.d = w0 >> 16; cc.r = w1 & 0xFFFFu; cc.o = w1 >> 16; }
+				return cc;
 			};
-			const uint32_t wck = code_at(yb);
+			const Code wck = code_at(yb);
 			if(dlen){
-				if((wck >> 24) & bit) dlen = 0;
+				if(wck.o & bit) dlen = 0;
 				else { emit(2u, 1u); rs.del++; y--; k0 = k + 1; if(k0 > 63) break; continue; }
 			}
 			const bool pmatch = prior && !(x == bpk && x != 0);
-			const bool fm = (wck & bit) != 0u, fd = ((wck >> 8) & bit) != 0u;
+			const bool fm = (wck.m & bit) != 0u, fd = (wck.d & bit) != 0u;
 			int bt;
 			if(pmatch) bt = fm ? 0 : fd ? 2 : 1;
 			else bt = fd ? 2 : fm ? 0 : 1;
@@ -581,12 +629,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 				if(x <= 0){ emit(1u, 1u); x--; rs.ins++; }
 				else {
 					int sz = 0;
-					const uint32_t cand = ((wck >> 16) & 0xFFu) & ~((bit << 1) - 1u);
-					if(cand) sz = (int)__builtin_ctz(cand) - (int)(7u - kk);
+					const uint32_t cand = wck.r & ~((bit << 1) - 1u) & FULL;
+					if(cand) sz = (int)__builtin_ctz(cand) - (int)(W - 1 - kk);
 					else {
 						int left = (int)kk;
 						for(int yy = (int)yb - 1; yy >= 0 && sz == 0; yy--){
-							const uint32_t r2 = (code_at((uint32_t)yy) >> 16) & 0xFFu;
+							const uint32_t r2 = code_at((uint32_t)yy).r & FULL;
 							if(r2) sz = left + 1 + (int)__builtin_ctz(r2);
 							else left += W;
 						}
@@ -1243,20 +1291,25 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 	static const bool simple = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
 	const uint32_t blocks = (a.count + 63u) / 64u;
 	bsa_last_trace_kernel = simple ? "k_align8_trace_codes_simple" : (a.bw == 256u) ? "k_align8_trace_codes_simple" : "k_align8_trace_codes_lds";
+	// one walk per wave (BSA_ALIGN8_TRACE_WAVE=0: the pair-per-lane kernels)
+	const char *we = getenv("BSA_ALIGN8_TRACE_WAVE");
+	const bool wave = !simple && !(we && we[0] == '0');
+	if(wave) bsa_last_trace_kernel = "k_align8_trace_codes_wave";
 	switch(a.bw / 16){
 		case 4:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<4>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			else if(wave) hipLaunchKernelGGL((k_align8_trace_codes_wave<4>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
 			else launch_trace_lds<4>(a, out, cig_cnt, st);
 			break;
-		case 8: {
-			// one walk per wave (BSA_ALIGN8_TRACE_WAVE=0: the pair-per-lane LDS-ring kernel)
-			const char *we = getenv("BSA_ALIGN8_TRACE_WAVE");
+		case 8:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
-			else if(we && we[0] == '0') launch_trace_lds<8>(a, out, cig_cnt, st);
-			else { bsa_last_trace_kernel = "k_align8_trace_codes_wave"; hipLaunchKernelGGL(k_align8_trace_codes_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt); }
+			else if(wave) hipLaunchKernelGGL((k_align8_trace_codes_wave<8>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
+			else launch_trace_lds<8>(a, out, cig_cnt, st);
 			break;
-		}
-		case 16: hipLaunchKernelGGL((k_align8_trace_codes_simple<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt); break;
+		case 16:
+			if(wave) hipLaunchKernelGGL((k_align8_trace_codes_wave<16>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
+			else hipLaunchKernelGGL((k_align8_trace_codes_simple<16>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			break;
 		default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError();
