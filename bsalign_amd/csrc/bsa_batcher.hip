@@ -13,6 +13,7 @@
 // everybody.  No window ever waits for a window that has finished: bsa_sweep_batcher_leave() takes a participant out.
 #include "bsa_common.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -58,7 +59,9 @@ struct Dev {
 };
 }
 
-struct bsa_sweep_batcher {
+struct bsa_sweep_batcher;
+struct Group {
+	bsa_sweep_batcher *parent = nullptr;
 	bsa_ctx_t *ctx = nullptr;
 	std::mutex m;
 	std::condition_variable cv;
@@ -71,11 +74,31 @@ struct bsa_sweep_batcher {
 	uint64_t batches = 0, launches = 0, programs = 0, tasks = 0, bytes_up = 0, bytes_down = 0;
 	double device_ms = 0, wall_ms = 0;
 };
+// The windows are dealt into G groups (BSA_POA_GROUPS, default 2 from 32 windows on), each of which advances in lock-step on
+// its own; the device part of a batch runs under one mutex.  While one group's sweep is on the device (its host threads
+// blocked) the other groups' host threads have the cores: with one group the host and the device simply take turns.
+struct bsa_sweep_batcher {
+	std::vector<Group*> groups;
+	std::mutex dev;                       // one batch on the device at a time (a bsa_ctx_t is not shared between threads)
+	std::mutex am; uint32_t next = 0;     // group assignment, in order of first appearance
+	uint64_t key = 0;                     // identifies this batcher in the threads' assignment slots
+	~bsa_sweep_batcher(){ for(Group *g : groups) delete g; }
+};
+static std::atomic<uint64_t> g_batcher_keys{1};
+static Group *group_of_this_thread(bsa_sweep_batcher *b){
+	thread_local uint64_t t_key = 0; thread_local Group *t_grp = nullptr;
+	if(t_key != b->key){
+		std::lock_guard<std::mutex> lk(b->am);
+		t_grp = b->groups[b->next % b->groups.size()]; b->next++;
+		t_key = b->key;
+	}
+	return t_grp;
+}
 
 static size_t align16(size_t x){ return (x + 15) & ~(size_t)15; }
 
 // run everything in b->pend (caller holds the lock; every other participant is blocked)
-static void run_batch(bsa_sweep_batcher *b){
+static void run_batch(Group *b){
 	const auto w0 = std::chrono::steady_clock::now();
 	std::vector<Sub> &P = b->pend;
 	const size_t n = P.size();
@@ -138,6 +161,7 @@ static void run_batch(bsa_sweep_batcher *b){
 		}
 #define BCHK(x) do { if(rc == BSA_OK && (x) != hipSuccess){ rc = BSA_E_HIP; (void)hipGetLastError(); } } while(0)
 		hipEvent_t e0 = nullptr, e1 = nullptr;
+		std::unique_lock<std::mutex> devlk(b->parent->dev);
 		BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
 		BCHK(hipMemcpyAsync(b->d_in.p, b->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
 		BCHK(hipMemsetAsync(b->d_rows.p, 0, nblocks * blk, st));
@@ -158,6 +182,7 @@ static void run_batch(bsa_sweep_batcher *b){
 			down += s.nblocks * blk;
 		}
 		BCHK(hipStreamSynchronize(st));
+		devlk.unlock();
 		if(rc == BSA_OK){ float ms = 0; if(hipEventElapsedTime(&ms, e0, e1) == hipSuccess) b->device_ms += ms; }
 		if(e0) (void)hipEventDestroy(e0);
 		if(e1) (void)hipEventDestroy(e1);
@@ -183,7 +208,17 @@ extern "C" int bsa_sweep_batcher_create(bsa_ctx_t *ctx, uint32_t participants, b
 	if(!ctx || !out || participants == 0) return BSA_E_ARG;
 	bsa_sweep_batcher *b = new (std::nothrow) bsa_sweep_batcher();
 	if(!b) return BSA_E_NOMEM;
-	b->ctx = ctx; b->active = participants;
+	uint32_t G = participants >= 32u ? 2u : 1u;
+	if(const char *e = getenv("BSA_POA_GROUPS")){ const int v = atoi(e); if(v >= 1 && v <= 64) G = (uint32_t)v; }
+	if(G > participants) G = participants;
+	b->key = g_batcher_keys.fetch_add(1);
+	for(uint32_t g = 0; g < G; g++){
+		Group *gr = new (std::nothrow) Group();
+		if(!gr){ delete b; return BSA_E_NOMEM; }
+		gr->parent = b; gr->ctx = ctx;
+		gr->active = participants / G + (g < participants % G ? 1u : 0u);     // threads are dealt round-robin in order of first appearance
+		b->groups.push_back(gr);
+	}
 	*out = b;
 	return BSA_OK;
 }
@@ -192,8 +227,9 @@ extern "C" void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b){ delete b; }
 
 extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
 		const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *res){
-	bsa_sweep_batcher *b = (bsa_sweep_batcher*)vb;
-	if(!b || !tasks || !query || !par || !res) return BSA_E_ARG;
+	bsa_sweep_batcher *bb = (bsa_sweep_batcher*)vb;
+	if(!bb || !tasks || !query || !par || !res) return BSA_E_ARG;
+	Group *b = group_of_this_thread(bb);
 	int rc = BSA_E_HIP;
 	const uint8_t *src = nullptr; size_t nbytes = 0;
 	{
@@ -211,17 +247,21 @@ extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, s
 	return rc;
 }
 
-extern "C" void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *b){
-	if(!b) return;
+extern "C" void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *bb){
+	if(!bb) return;
+	Group *b = group_of_this_thread(bb);
 	std::unique_lock<std::mutex> lk(b->m);
 	if(b->active) b->active--;
 	if(!b->pend.empty() && b->pend.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
 }
 
 // out[0..7] = batches, launches, programs, tasks, bytes uploaded, bytes downloaded, device microseconds, wall microseconds inside the batches
-extern "C" void bsa_sweep_batcher_stats(bsa_sweep_batcher_t *b, uint64_t out[8]){
-	if(!b || !out) return;
-	std::unique_lock<std::mutex> lk(b->m);
-	out[0] = b->batches; out[1] = b->launches; out[2] = b->programs; out[3] = b->tasks; out[4] = b->bytes_up; out[5] = b->bytes_down;
-	out[6] = (uint64_t)(b->device_ms * 1000.0); out[7] = (uint64_t)(b->wall_ms * 1000.0);
+extern "C" void bsa_sweep_batcher_stats(bsa_sweep_batcher_t *bb, uint64_t out[8]){
+	if(!bb || !out) return;
+	for(int k = 0; k < 8; k++) out[k] = 0;
+	for(Group *b : bb->groups){
+		std::unique_lock<std::mutex> lk(b->m);
+		out[0] += b->batches; out[1] += b->launches; out[2] += b->programs; out[3] += b->tasks; out[4] += b->bytes_up; out[5] += b->bytes_down;
+		out[6] += (uint64_t)(b->device_ms * 1000.0); out[7] += (uint64_t)(b->wall_ms * 1000.0);
+	}
 }
