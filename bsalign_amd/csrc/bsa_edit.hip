@@ -1269,7 +1269,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 		// 32-bit words, twice the lanes per pair (bands up to 512 columns): BSA_EDIT_GRP32=0/1 overrides
 		{
 			const uint32_t G32 = nw <= 1u ? 2u : nw <= 2u ? 4u : nw <= 4u ? 8u : 16u;
-			bool g32 = a.bw != 0u && nw >= 1u && nw <= 8u && (uint64_t)a.count * G32 / 64u <= 16384u;
+			bool g32 = a.bw != 0u && nw >= 1u && nw <= 8u && (uint64_t)a.count * G32 / 64u <= 65536u;      // (faster than the other two kernels on every shape of tools/edit_shapes.sh)
 			if(const char *e = getenv("BSA_EDIT_GRP32")) g32 = a.bw != 0u && nw >= 1u && nw <= 8u && e[0] == '1';
 			if(getenv("BSA_EDIT_GRP")) g32 = false;
 			if(g32){
@@ -1336,7 +1336,10 @@ hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t 
 	}
 	// few long walks: one walk per wave (k_edit_trace_wave); BSA_EDIT_TRACE_WAVE=0/1 overrides
 	{
-		bool wave = a.count <= 8u * (uint32_t)cus * 32u;
+		// (measured, tools/edit_shapes.sh: 65536 x 20 kbp at bandwidth 256 16.9 ms against 23.5 pair-per-lane, at bandwidth 512 -- rows
+		// wider than the LDS window -- 43 against 22; 262144 x 3 kbp 10.1 against 8.5)
+		const bool narrow = a.bw != 0u && a.bw <= 64u * EW_WW;
+		bool wave = a.count <= (narrow ? 8u : 2u) * (uint32_t)cus * 32u;
 		if(const char *e = getenv("BSA_EDIT_TRACE_WAVE")) wave = e[0] == '1';
 		if(getenv("BSA_EDIT_TRACE_LANES") || getenv("BSA_EDIT_TRACE_COOP")) wave = false;
 		if(wave){
