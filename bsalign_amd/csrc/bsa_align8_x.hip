@@ -121,13 +121,13 @@ template<int W, int L, int PW = 1>
 static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint32_t first_pos, const uint32_t count, const uint32_t block){
 	constexpr int BW = 2 * L * W;
 	constexpr int WR = BW / 16, CR = 8 / L;
-	static_assert((L == 8 || L == 4) && W * L / 8 == WR && (CR == 1 || (CR == 2 && W == 16)), "supported shapes");
+	static_assert((L == 8 || L == 4) && W * L / 8 == WR && (CR == 1 || (CR == 2 && (W == 16 || W == 8))), "supported shapes");
 	constexpr int NQ = (W + 3) / 4;
 	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
 	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
 	static_assert(PW == 0 || PW == 1 || (PW == 2 && W == 8 && L == 8), "two-piece gaps: bandwidth 128, eight lanes per pair");
 	constexpr int CWD = (PW == 2) ? 2 : (WR >= 8) ? WR / 8 : 1;          // code dwords per reference block and row
-	constexpr int ND = (PW == 2) ? 4 : (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : 2;      // code dwords per lane and row
+	constexpr int ND = (PW == 2) ? 4 : (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : (W == 8) ? 4 : 2;      // code dwords per lane and row
 	const int lt = threadIdx.x;
 	const int jl = lt & (L - 1);
 	const bool first = jl == 0, last = jl == L - 1;
@@ -490,6 +490,12 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					cur[n] = __builtin_amdgcn_perm(t2, t1, 0x05040100u) ^ 0x00FFFFFFu;            // block NACC jl + n
 					cur[NACC + n] = __builtin_amdgcn_perm(t2, t1, 0x07060302u) ^ 0x00FFFFFFu;     // block NACC (jl + L) + n
 				}
+			} else if constexpr (WR == 4 && W == 8){
+				// four lanes per pair at bandwidth 64: a half holds two reference blocks of four cells, the first in bits 15..12 of the
+				// accumulators, the second in bits 11..8; one dword per reference block: M | D << 4 | R << 8 | Od << 12
+				const uint32_t pa = (((accM[0] >> 12) & 0x000F000Fu) | ((accD[0] >> 8) & 0x00F000F0u) | ((accR[0] >> 4) & 0x0F000F00u) | (accO[0] & 0xF000F000u)) ^ 0x0FFF0FFFu;
+				const uint32_t pb = (((accM[0] >> 8) & 0x000F000Fu) | ((accD[0] >> 4) & 0x00F000F0u) | (accR[0] & 0x0F000F00u) | ((accO[0] << 4) & 0xF000F000u)) ^ 0x0FFF0FFFu;
+				cur[0] = pa & 0xFFFFu; cur[1] = pb & 0xFFFFu; cur[2] = pa >> 16; cur[3] = pb >> 16;      // blocks 2 jl, 2 jl + 1, 2 (jl + L), 2 (jl + L) + 1
 			} else if constexpr (WR == 4){
 				const uint32_t pk = ((accM[0] >> 8) | (accD[0] >> 4) | accR[0] | (accO[0] << 4)) ^ 0x0FFF0FFFu;
 				cur[0] = pk & 0xFFFFu; cur[1] = pk >> 16;
@@ -512,7 +518,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				if constexpr (CWD == 1){
 #pragma unroll
 					for(int q = 0; q < ND; q++){
-						const uint32_t blk = (WR == 8) ? (uint32_t)(NACC * (jl + L * (q / NACC)) + q % NACC) : (uint32_t)(jl + L * q);
+						constexpr int RBH = (WR == 8) ? NACC : (WR == 4 && W == 8) ? 2 : 0;      // reference blocks (= code dwords) per half, where a half holds whole ones
+						const uint32_t blk = RBH ? (uint32_t)(RBH * (jl + L * (q / RBH)) + q % RBH) : (uint32_t)(jl + L * q);
 						uint4 t; t.x = hist[0][q]; t.y = hist[1][q]; t.z = hist[2][q]; t.w = cur[q];
 						if(ri == 0u) t.x = cur[q]; else if(ri == 1u) t.y = cur[q]; else if(ri == 2u) t.z = cur[q];
 						*(uint4*)(gp + 4u * blk) = t;
@@ -689,6 +696,7 @@ bool bsa_align8_x_supported(const Align8Args &a, int pw){
 	return m + 3 * g + 2 * ge <= 100 && n + m + g + 2 * ge <= 110 && 63 + 2 * ge + n + m + 2 * g <= 125;
 }
 
+static bool x8_at_64(){ const char *e = getenv("BSA_ALIGN8_X_LANES"); return e && e[0] == '8'; }
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
 	const uint32_t b8 = (a.count + 31u) / 32u;
@@ -699,7 +707,10 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	}
 	if(pw == 0){
 		switch(a.bw / 16){
-			case 4:  hipLaunchKernelGGL((k_align8_fwd_x0<4, 8>), dim3(b8), dim3(256), 0, st, a); break;
+			case 4:
+				if(x8_at_64()) hipLaunchKernelGGL((k_align8_fwd_x0<4, 8>), dim3(b8), dim3(256), 0, st, a);
+				else hipLaunchKernelGGL((k_align8_fwd_x0<8, 4>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a);
+				break;
 			case 8:  hipLaunchKernelGGL((k_align8_fwd_x0<16, 4>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a); break;
 			case 16: hipLaunchKernelGGL((k_align8_fwd_x0<16, 8>), dim3(b8), dim3(256), 0, st, a); break;
 			default: return hipErrorInvalidValue;
@@ -707,7 +718,10 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 		return hipGetLastError();
 	}
 	switch(a.bw / 16){
-		case 4:  hipLaunchKernelGGL((k_align8_fwd_x<4, 8>), dim3(b8), dim3(256), 0, st, a); break;
+		case 4:      // bandwidth 64: four lanes per pair (16 pairs per wave, eight cells per half); BSA_ALIGN8_X_LANES=8: eight lanes
+			if(x8_at_64()) hipLaunchKernelGGL((k_align8_fwd_x<4, 8>), dim3(b8), dim3(256), 0, st, a);
+			else hipLaunchKernelGGL((k_align8_fwd_x<8, 4>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a);
+			break;
 		case 8: {
 			// Four lanes per pair (16 pairs per wave) cost 620 instructions per row of a wave, eight lanes per pair 387.
 			// Pairs of one length finish together, so what counts is the largest number of waves any SIMD gets: whole
