@@ -70,6 +70,35 @@ KERNEL(k_add_nop, \
 	"v_add_u32 %4, %4, %8\n s_nop 0\n v_add_u32 %5, %5, %8\n s_nop 0\n v_add_u32 %6, %6, %8\n s_nop 0\n v_add_u32 %7, %7, %8\n s_nop 0\n", \
 	"v_add_u32 %0, %0, %1\n s_nop 1\n")
 
+// round 2, second pass: which instructions are in the 2-cycle class (packed f16, plain VOP2 logic / shifts, f32)?
+KERNEL(k_pk_add_f16,  I8("v_pk_add_f16", "%8"),        "v_pk_add_f16 %0, %0, %1\n")
+KERNEL(k_pk_max_f16,  I8("v_pk_max_f16", "%8"),        "v_pk_max_f16 %0, %0, %1\n")
+KERNEL(k_pk_min_f16,  I8("v_pk_min_f16", "%8"),        "v_pk_min_f16 %0, %0, %1\n")
+KERNEL(k_pk_fma_f16,  I8("v_pk_fma_f16", "%8, %9"),    "v_pk_fma_f16 %0, %0, %1, %2\n")
+KERNEL(k_pk_mul_f16,  I8("v_pk_mul_f16", "%8"),        "v_pk_mul_f16 %0, %0, %1\n")
+KERNEL(k_pk_add_u16,  I8("v_pk_add_u16", "%8"),        "v_pk_add_u16 %0, %0, %1\n")
+KERNEL(k_pk_max_u16,  I8("v_pk_max_u16", "%8"),        "v_pk_max_u16 %0, %0, %1\n")
+KERNEL(k_pk_lshr_b16, I8("v_pk_lshrrev_b16", "%8"),    "v_pk_lshrrev_b16 %0, %1, %0\n")
+KERNEL(k_or_b32,      I8("v_or_b32", "%8"),            "v_or_b32 %0, %0, %1\n")
+KERNEL(k_xor_b32,     I8("v_xor_b32", "%8"),           "v_xor_b32 %0, %0, %1\n")
+KERNEL(k_sub_u32,     I8("v_sub_u32", "%8"),           "v_sub_u32 %0, %0, %1\n")
+KERNEL(k_lshrrev_b32, I8("v_lshrrev_b32", "%8"),       "v_lshrrev_b32 %0, %1, %0\n")
+KERNEL(k_lshlrev_b32, I8("v_lshlrev_b32", "%8"),       "v_lshlrev_b32 %0, %1, %0\n")
+KERNEL(k_ashrrev_i32, I8("v_ashrrev_i32", "%8"),       "v_ashrrev_i32 %0, %1, %0\n")
+KERNEL(k_cndmask,     I8("v_cndmask_b32", "%8, vcc"),  "v_cndmask_b32 %0, %0, %1, vcc\n")
+KERNEL(k_min_u32,     I8("v_min_u32", "%8"),           "v_min_u32 %0, %0, %1\n")
+KERNEL(k_max_f32,     I8("v_max_f32", "%8"),           "v_max_f32 %0, %0, %1\n")
+KERNEL(k_add_f32,     I8("v_add_f32", "%8"),           "v_add_f32 %0, %0, %1\n")
+KERNEL(k_max_f16,     I8("v_max_f16", "%8"),           "v_max_f16 %0, %0, %1\n")
+KERNEL(k_add_u16,     I8("v_add_u16", "%8"),           "v_add_u16 %0, %0, %1\n")
+KERNEL(k_max_u16,     I8("v_max_u16", "%8"),           "v_max_u16 %0, %0, %1\n")
+KERNEL(k_mul_u32_u24, I8("v_mul_u32_u24", "%8"),       "v_mul_u32_u24 %0, %0, %1\n")
+KERNEL(k_and_or_b32,  I8("v_and_or_b32", "%8, %9"),    "v_and_or_b32 %0, %0, %1, %2\n")
+KERNEL(k_alignbit,    I8("v_alignbit_b32", "%8, 8"),   "v_alignbit_b32 %0, %0, %1, 8\n")
+KERNEL(k_bfe_u32,     I8("v_bfe_u32", "8, 8"),         "v_bfe_u32 %0, %0, 8, 8\n")
+KERNEL(k_or3_b32,     I8("v_or3_b32", "%8, %9"),       "v_or3_b32 %0, %0, %1, %2\n")
+KERNEL(k_cvt_f32_f16, I8("v_cvt_f32_f16", ""),         "v_cvt_f32_f16 %0, %0\n")
+
 typedef void (*kern_t)(int, unsigned*, unsigned long long*);
 struct Case { const char *name; kern_t k; int per_block_indep; };
 
@@ -89,6 +118,13 @@ int main(){
 		{"v_add3_u32", k_add3_u32, 8}, {"v_lshl_or_b32", k_lshl_or, 8}, {"v_fma_f32", k_fma_f32, 8},
 		{"v_mov_b32_dpp row_shr:1", k_mov_dpp_shr1, 8}, {"v_max_i32_dpp row_shr:1", k_max_i32_dpp, 8},
 		{"pk add/max/sub mix", k_chain_mix, 8}, {"v_add_u32 + s_nop 0 (per pair)", k_add_nop, 8},
+		{"v_pk_add_f16", k_pk_add_f16, 8}, {"v_pk_max_f16", k_pk_max_f16, 8}, {"v_pk_min_f16", k_pk_min_f16, 8}, {"v_pk_fma_f16", k_pk_fma_f16, 8},
+		{"v_pk_mul_f16", k_pk_mul_f16, 8}, {"v_pk_add_u16", k_pk_add_u16, 8}, {"v_pk_max_u16", k_pk_max_u16, 8}, {"v_pk_lshrrev_b16", k_pk_lshr_b16, 8},
+		{"v_or_b32", k_or_b32, 8}, {"v_xor_b32", k_xor_b32, 8}, {"v_sub_u32", k_sub_u32, 8}, {"v_lshrrev_b32", k_lshrrev_b32, 8},
+		{"v_lshlrev_b32", k_lshlrev_b32, 8}, {"v_ashrrev_i32", k_ashrrev_i32, 8}, {"v_cndmask_b32", k_cndmask, 8}, {"v_min_u32", k_min_u32, 8},
+		{"v_max_f32", k_max_f32, 8}, {"v_add_f32", k_add_f32, 8}, {"v_max_f16", k_max_f16, 8}, {"v_add_u16", k_add_u16, 8}, {"v_max_u16", k_max_u16, 8},
+		{"v_mul_u32_u24", k_mul_u32_u24, 8}, {"v_and_or_b32", k_and_or_b32, 8}, {"v_alignbit_b32", k_alignbit, 8}, {"v_bfe_u32", k_bfe_u32, 8},
+		{"v_or3_b32", k_or3_b32, 8}, {"v_cvt_f32_f16", k_cvt_f32_f16, 8},
 	};
 	printf("%-34s %6s %10s %10s %12s\n", "instruction", "w/SIMD", "indep cyc", "dep cyc", "ns/instr(i)");
 	for(const Case &c : cases){
