@@ -99,6 +99,24 @@ KERNEL(k_bfe_u32,     I8("v_bfe_u32", "8, 8"),         "v_bfe_u32 %0, %0, 8, 8\n
 KERNEL(k_or3_b32,     I8("v_or3_b32", "%8, %9"),       "v_or3_b32 %0, %0, %1, %2\n")
 KERNEL(k_cvt_f32_f16, I8("v_cvt_f32_f16", ""),         "v_cvt_f32_f16 %0, %0\n")
 
+// mixed streams: does a 2-cycle instruction between 4-cycle ones still cost 2?
+KERNEL(k_mix_pk_sub, \
+	"v_pk_max_i16 %0, %0, %8\n v_sub_u32 %1, %1, %9\n v_pk_max_i16 %2, %2, %8\n v_sub_u32 %3, %3, %9\n" \
+	"v_pk_max_i16 %4, %4, %8\n v_sub_u32 %5, %5, %9\n v_pk_max_i16 %6, %6, %8\n v_sub_u32 %7, %7, %9\n", \
+	"v_pk_max_i16 %0, %0, %1\n v_sub_u32 %0, %0, %2\n")
+KERNEL(k_mix_pk_pk_sub_sub, \
+	"v_pk_max_i16 %0, %0, %8\n v_pk_min_u16 %1, %1, %9\n v_sub_u32 %2, %2, %8\n v_sub_u32 %3, %3, %9\n" \
+	"v_pk_max_i16 %4, %4, %8\n v_pk_min_u16 %5, %5, %9\n v_sub_u32 %6, %6, %8\n v_sub_u32 %7, %7, %9\n", \
+	"v_pk_max_i16 %0, %0, %1\n v_sub_u32 %0, %0, %2\n")
+KERNEL(k_mix_dep_chain, \
+	"v_pk_max_u16 %0, %0, %8\n v_sub_u32 %0, %0, %9\n v_pk_max_u16 %1, %1, %8\n v_sub_u32 %1, %1, %9\n" \
+	"v_pk_max_u16 %2, %2, %8\n v_sub_u32 %2, %2, %9\n v_pk_max_u16 %3, %3, %8\n v_sub_u32 %3, %3, %9\n", \
+	"v_pk_max_u16 %0, %0, %1\n v_sub_u32 %0, %0, %2\n")
+KERNEL(k_mix_dep_chain_pk, \
+	"v_pk_max_u16 %0, %0, %8\n v_pk_sub_i16 %0, %0, %9\n v_pk_max_u16 %1, %1, %8\n v_pk_sub_i16 %1, %1, %9\n" \
+	"v_pk_max_u16 %2, %2, %8\n v_pk_sub_i16 %2, %2, %9\n v_pk_max_u16 %3, %3, %8\n v_pk_sub_i16 %3, %3, %9\n", \
+	"v_pk_max_u16 %0, %0, %1\n v_pk_sub_i16 %0, %0, %2\n")
+
 typedef void (*kern_t)(int, unsigned*, unsigned long long*);
 struct Case { const char *name; kern_t k; int per_block_indep; };
 
@@ -125,6 +143,8 @@ int main(){
 		{"v_max_f32", k_max_f32, 8}, {"v_add_f32", k_add_f32, 8}, {"v_max_f16", k_max_f16, 8}, {"v_add_u16", k_add_u16, 8}, {"v_max_u16", k_max_u16, 8},
 		{"v_mul_u32_u24", k_mul_u32_u24, 8}, {"v_and_or_b32", k_and_or_b32, 8}, {"v_alignbit_b32", k_alignbit, 8}, {"v_bfe_u32", k_bfe_u32, 8},
 		{"v_or3_b32", k_or3_b32, 8}, {"v_cvt_f32_f16", k_cvt_f32_f16, 8},
+		{"mix pk_max, sub_u32 alternating", k_mix_pk_sub, 8}, {"mix pk, pk, sub, sub", k_mix_pk_pk_sub_sub, 8},
+		{"chains: pk_max_u16 -> sub_u32 (x4)", k_mix_dep_chain, 8}, {"chains: pk_max_u16 -> pk_sub_i16 (x4)", k_mix_dep_chain_pk, 8},
 	};
 	printf("%-34s %6s %10s %10s %12s\n", "instruction", "w/SIMD", "indep cyc", "dep cyc", "ns/instr(i)");
 	for(const Case &c : cases){
