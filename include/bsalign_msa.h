@@ -1,0 +1,53 @@
+/* bsalign_msa.h -- the POA's MSA formats on plain arrays (the data formats behind the path).
+ *
+ * The reference keeps a finished window's MSA as `msacols` (mrow = nseq + 3 bytes per column: one byte per read --
+ * base 0..3, 4 = gap, 5 / 6 = outside the read --, then consensus, consensus quality, alternative-allele quality) and
+ * `msaidxs` (the order of the columns), bspoa.h:131-132.  These functions take exactly those two arrays and produce /
+ * parse the reference's two formats byte for byte; nothing here touches a BSPOA.
+ *
+ *   binary container   dump_binary_msa_bspoa        bspoa.h:1555-1586
+ *                      load_binary_msa_bspoa_core   bspoa.h:1588-1650, post_load_binary_msa_bspoa :1652-1685
+ *   text               print_msa_bspoa              bspoa.h:1491-1553 with its row builders :1329-1483 (colorful = 0)
+ *
+ * All functions return 0 or a negative BSA_E_* code (bsalign_hip.h); writers report the bytes they need in *need and
+ * return BSA_E_CIGAR_CAP-style BSA_E_ARG only for bad arguments: a too small buffer is BSA_E_NOMEM with *need set.
+ */
+#ifndef BSALIGN_MSA_H
+#define BSALIGN_MSA_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Binary container: [0x81, u32 metalen, meta]  0x22, u32 mlen, u32 nseq, mlen x (nseq + 1) bytes (reads + consensus of
+ * every column, in msaidxs order), mlen consensus qualities, mlen alternative qualities, 0xFF.  `cols` / `idxs` as the
+ * reference holds them (idxs == NULL: columns in storage order); mrow = nseq + 3. */
+int bsa_msa_binary_write(const uint8_t *cols, const uint32_t *idxs, uint32_t nseq, uint32_t mlen,
+                         const char *meta, uint32_t metalen, uint8_t *out, size_t cap, size_t *need);
+
+/* Parses one container (records up to and including the 0xFF terminator).  Outputs are optional; `cols` receives
+ * mlen x (nseq + 3) bytes in file order (the reference's loader sets msaidxs to the identity).  Returns 0, BSA_E_ARG on
+ * a truncated / malformed stream, BSA_E_NOMEM when cols_cap or meta_cap is too small (sizes still reported). */
+int bsa_msa_binary_read(const uint8_t *in, size_t len, size_t *consumed, uint32_t *nseq, uint32_t *mlen,
+                        uint8_t *cols, size_t cols_cap, char *meta, size_t meta_cap, uint32_t *metalen);
+
+/* What post_load_binary_msa_bspoa derives from a loaded MSA: the consensus with its two quality strings (columns
+ * whose consensus is a base), and optionally every read's bases (rdseqs: concatenated, rdoffs[nseq + 1]). */
+int bsa_msa_consensus(const uint8_t *cols, const uint32_t *idxs, uint32_t nseq, uint32_t mlen,
+                      uint8_t *cns, uint8_t *qlt, uint8_t *alt, uint32_t *clen,
+                      uint8_t *rdseqs, uint64_t *rdoffs);
+
+/* print_msa_bspoa(g, label, mbeg, mend, linewidth, colorful = 0, out) into a buffer.  var_mpos: the MSA columns the
+ * reference marks with '~' in the ruler (g->var, ascending; NULL / 0 = none).  cns / qlt / alt: the consensus arrays
+ * (g->cns, g->qlt, g->alt) the trailer lines print. */
+int bsa_msa_text(const uint8_t *cols, const uint32_t *idxs, uint32_t nseq, uint32_t mlen,
+                 const uint8_t *cns, const uint8_t *qlt, const uint8_t *alt,
+                 const uint32_t *var_mpos, uint32_t nvar,
+                 const char *label, uint32_t mbeg, uint32_t mend, uint32_t linewidth,
+                 char *out, size_t cap, size_t *need);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -440,3 +440,64 @@ void ref_diagdp_fill(uint8_t *seq0, uint8_t *seq1, uint8_t *m00, uint8_t *m01, u
 		if(x >= mend) break;
 	}
 }
+
+/* ---- the reference's MSA writers on a finished window (tests of bsa_msa_* in include/bsalign_msa.h) ----
+ * dump_binary_msa_bspoa bspoa.h:1555-1586, print_msa_bspoa bspoa.h:1491-1553, through open_memstream */
+void ref_poa_msa_dims(void *vp, uint32_t *mlen, uint32_t *mrow, uint32_t *nrds, uint64_t *cols_bytes, uint32_t *nvar){
+	BSPOA *g = ((ref_poa_t*)vp)->g;
+	if(mlen) *mlen = (uint32_t)g->msaidxs->size;
+	if(mrow) *mrow = (uint32_t)g->seqs->nseq + 3;
+	if(nrds) *nrds = (uint32_t)g->nrds;
+	if(cols_bytes) *cols_bytes = (uint64_t)g->msacols->size;
+	if(nvar) *nvar = (uint32_t)g->var->size;
+}
+void ref_poa_msa_cols(void *vp, uint8_t *cols, uint32_t *idxs, uint32_t *var_mpos){
+	BSPOA *g = ((ref_poa_t*)vp)->g; u4i i;
+	if(cols) memcpy(cols, g->msacols->buffer, g->msacols->size);
+	if(idxs) memcpy(idxs, g->msaidxs->buffer, g->msaidxs->size * sizeof(u4i));
+	if(var_mpos) for(i = 0; i < g->var->size; i++) var_mpos[i] = ref_bspoavarv(g->var, i)->mpos;
+}
+uint64_t ref_poa_msa_binary(void *vp, const char *meta, uint32_t metalen, uint8_t *out, uint64_t cap){
+	BSPOA *g = ((ref_poa_t*)vp)->g;
+	char *buf = NULL; size_t len = 0;
+	FILE *f = open_memstream(&buf, &len);
+	dump_binary_msa_bspoa(g, (char*)meta, metalen, f);
+	fclose(f);
+	if(out && len <= cap) memcpy(out, buf, len);
+	free(buf);
+	return (uint64_t)len;
+}
+uint64_t ref_poa_msa_text(void *vp, const char *label, uint32_t mbeg, uint32_t mend, uint32_t linewidth, uint8_t *out, uint64_t cap){
+	BSPOA *g = ((ref_poa_t*)vp)->g;
+	char *buf = NULL; size_t len = 0;
+	FILE *f = open_memstream(&buf, &len);
+	print_msa_bspoa(g, label, mbeg, mend, linewidth, 0, f);
+	fclose(f);
+	if(out && len <= cap) memcpy(out, buf, len);
+	free(buf);
+	return (uint64_t)len;
+}
+/* the reference's loader on a binary MSA: returns its return code, and what post_load_binary_msa_bspoa derives */
+int ref_msa_load_binary(const uint8_t *in, uint64_t len, uint32_t *nrds, uint32_t *mlen, uint8_t *cols, uint64_t cols_cap,
+		uint8_t *cns, uint8_t *qlt, uint8_t *alt, uint32_t *clen, char *meta, uint32_t meta_cap, uint32_t *metalen){
+	BSPOAPar par = DEFAULT_BSPOA_PAR;
+	BSPOA *g = init_bspoa(par);
+	String *md = init_string(64);
+	FILE *f = fmemopen((void*)in, (size_t)len, "rb");
+	int rc = load_binary_msa_bspoa(g, f, md);
+	fclose(f);
+	if(rc == 0){
+		if(nrds) *nrds = g->nrds;
+		if(mlen) *mlen = (uint32_t)g->msaidxs->size;
+		if(cols && g->msacols->size <= cols_cap) memcpy(cols, g->msacols->buffer, g->msacols->size);
+		if(clen) *clen = (uint32_t)g->cns->size;
+		if(cns) memcpy(cns, g->cns->buffer, g->cns->size);
+		if(qlt) memcpy(qlt, g->qlt->buffer, g->qlt->size);
+		if(alt) memcpy(alt, g->alt->buffer, g->alt->size);
+		if(metalen) *metalen = (uint32_t)md->size;
+		if(meta && md->size <= meta_cap) memcpy(meta, md->string, md->size);
+	}
+	free_string(md);
+	free_bspoa(g);
+	return rc;
+}
