@@ -560,12 +560,40 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	const int type = par->mode & 3;
 	if(type != BSA_MODE_GLOBAL && type != BSA_MODE_OVERLAP && type != BSA_MODE_EXTEND){ c->err = "bad mode"; return BSA_E_ARG; }
 	(void)hipSetDevice(c->device);
-	const uint32_t bw = (par->bandwidth + 15u) / 16u * 16u;   // bsalign.h:3862; 0 = per pair roundup(qlen, 16) (bsalign.h:3861)
+	const uint32_t bw_req = (par->bandwidth + 15u) / 16u * 16u;   // bsalign.h:3862; 0 = per pair roundup(qlen, 16) (bsalign.h:3861)
+	uint32_t bw = bw_req;
+	uint32_t max_bw = bw;
+	if(bw == 0) for(size_t k = 0; k < n; k++) max_bw = std::max(max_bw, (qlen[k] + 15u) / 16u * 16u);
+	// Whole-query bands in global mode (the reference CLI's default `-W 0`, or a bandwidth no shorter than any query): the band
+	// never moves (bsalign.h:3338: qoff + bw >= qlen), cells beyond the query end hold the -63 padding and nothing flows from them
+	// to the cells in front, so inside the exact-arithmetic guard the result does not depend on how wide the band is or how it is
+	// striped.  Such a batch runs at the next width the register kernels have (64 / 128 / 256) on the compact path instead of the
+	// LDS-resident run-time-width kernel; `cells` keeps the reference's own band widths.  (Overlap / extend: row_max breaks ties in
+	// striped order, bsalign.h:3213-3329, so the width matters there.)  BSA_ALIGN8_WIDEN=0 keeps the old dispatch.
+	bool widened = false;
+	{
+		const char *we = getenv("BSA_ALIGN8_WIDEN");
+		const char *le = getenv("BSA_ALIGN8_LITERAL");
+		bool full = type == BSA_MODE_GLOBAL && !(par->mode & BSA_MODE_ROWRECORDS) && !(we && we[0] == '0') && !(le && le[0] == '1')
+			&& (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw <= 256u && n > 0;
+		if(full && bw != 0) for(size_t k = 0; k < n && full; k++) full = qlen[k] <= bw;
+		// the gap model must not depend on the width (bsalign.h:2084-2092 compares a ratio of the penalties with it)
+		const int pwa = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 16);
+		const int pwb = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 256);
+		if(full && pwa == pwb && pwa <= 1){
+			const uint32_t kbw = max_bw <= 64u ? 64u : max_bw <= 128u ? 128u : 256u;
+			Align8Args t;
+			memset(&t, 0, sizeof(t));
+			t.bw = kbw; t.mode = par->mode; t.gapo1 = par->gapo1; t.gape1 = par->gape1; t.gapo2 = par->gapo2; t.gape2 = par->gape2;
+			int smax = -127, smin = 127;
+			for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
+			t.smax = smax; t.smin = smin;
+			if(bsa_align8_codes_supported(t, pwa) && bsa_align8_x_supported(t, pwa)){ bw = kbw; max_bw = kbw; widened = true; }
+		}
+	}
 	bsa_align_plan *p = new bsa_align_plan();
 	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
 	p->generic = (bw == 0) || !bsa_align8_supported_bw(bw);
-	uint32_t max_bw = bw;
-	if(bw == 0) for(size_t k = 0; k < n; k++) max_bw = std::max(max_bw, (qlen[k] + 15u) / 16u * 16u);
 	p->max_bw = max_bw;
 	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)std::max(max_bw, 16u));
 	if(p->generic && bsa_align8_gen_lds(max_bw, p->pw, bw == 0 ? 1u : 2u) > 160 * 1024){        // a whole-query band never moves: one row buffer
@@ -594,11 +622,13 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	std::vector<size_t> need(n); std::vector<uint32_t> bwv(n, bw);
 	size_t qacc = 0, tacc = 0;
 	double cells = 0;
-	auto bw_of = [&](size_t k) -> uint32_t { return bw ? bw : std::max(16u, (qlen[k] + 15u) / 16u * 16u); };
+	auto bw_of = [&](size_t k) -> uint32_t { return bw ? bw : std::max(16u, (qlen[k] + 15u) / 16u * 16u); };                 // the width the kernels run
+	auto bw_ref = [&](size_t k) -> uint32_t { return bw_req ? bw_req : std::max(16u, (qlen[k] + 15u) / 16u * 16u); };       // the reference's own width (cells)
+	(void)widened;
 	for(size_t k = 0; k < n; k++){
 		qpoff[k] = qacc; qacc += ((size_t)qlen[k] + p->qpad + 15) & ~(size_t)15;
 		tpoff[k] = tacc; tacc += ((size_t)tlen[k] + p->tpad + 15) & ~(size_t)15;
-		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw_of(k);
+		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw_ref(k);
 	}
 	for(size_t pos = 0; pos < n; pos++)
 		need[pos] = p->codes ? bsa_code_slot_bytes(tlen[order[pos]], bw / 16u, p->pw) : bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
