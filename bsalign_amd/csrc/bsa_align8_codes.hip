@@ -20,10 +20,16 @@
 // end-of-query candidate (strictly greater wins, in row order) against the maximum of the last row, whose tie rules are
 // the reference's: per lane the first best 32-vector chunk, lanes reduced in its register order, then the first
 // maximum inside the winning chunk (bsalign.h:3213-3329).
-template<int W>
-static __device__ void codes_end_cell(const uint8_t *rows, uint32_t RB, uint32_t qlen, uint32_t tlen, int &score, int &qe, int &te){
+// ref_bw != 0 (a whole-query band run at a wider register-kernel width, bsa_api.hip): the row maximum is taken over the
+// REFERENCE's band -- ref_bw columns, or roundup(qlen, 16) when ref_bw == 1 -- in the reference's striping of it (WR cells per
+// lane), whose tie rules depend on that striping; the end record is in natural order, so only the lane boundaries move.
+template<int WK>
+static __device__ void codes_end_cell(const uint8_t *rows, uint32_t RB, uint32_t qlen, uint32_t tlen, uint32_t ref_bw, int &score, int &qe, int &te){
 	const bsa_code_end_t *er = (const bsa_code_end_t*)(rows + (size_t)bsa_code_rows(tlen) * RB);
 	const int8_t *us = (const int8_t*)(er + 1);           // natural band order: lane l, cell x at l * W + x
+	const uint32_t W = ref_bw == 0u ? (uint32_t)WK : ref_bw == 1u ? (max(qlen, 1u) + 15u) / 16u : ref_bw / 16u;
+	// H in front of band position p, from the kernel's own 16 block starts
+	auto before = [&](uint32_t p) -> int { const uint32_t b = p / (uint32_t)WK; int h = er->ubegs[b]; for(uint32_t i = b * (uint32_t)WK; i < p; i++) h += us[i]; return h; };
 	int best = BSA_SCORE_MIN, bte = 0;
 	for(int l = 0; l < 16; l++){
 		const int sc = er->cand_sc[l], t = er->cand_te[l];
@@ -31,7 +37,7 @@ static __device__ void codes_end_cell(const uint8_t *rows, uint32_t RB, uint32_t
 	}
 	int lmax[16]; uint32_t lchunk[16];
 	for(uint32_t l = 0; l < 16; l++){
-		int base = er->ubegs[l];
+		int base = (W == (uint32_t)WK) ? er->ubegs[l] : before(l * W);
 		lmax[l] = BSA_SCORE_MIN; lchunk[l] = 0;
 		for(uint32_t i = 0, c = 0; i < (uint32_t)W; i += 32, c++){
 			const uint32_t n = (i + 32 < (uint32_t)W) ? 32 : (uint32_t)W - i;
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 			rs.score = begs[tlen + 1];
 			if(rs.score == (int)0x80000000u) bad = true;            // band never reached the query end (bsalign.h:4034)
 			rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
-		} else codes_end_cell<W>(rows, RB, qlen, tlen, rs.score, rs.qe, rs.te);
+		} else codes_end_cell<W>(rows, RB, qlen, tlen, a.ref_bw, rs.score, rs.qe, rs.te);
 		if(qlen >= (1u << 26)) bad = true;                          // band offsets are kept in 26 bits here
 		const int lastbeg = begs[rs.te + 1];
 		if(rs.qe < lastbeg || rs.qe >= lastbeg + bw) bad = true;    // end cell outside the stored band
@@ -421,7 +427,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		rs.score = begs[tlen + 1];
 		if(rs.score == (int)0x80000000u) bad = true;               // band never reached the query end (bsalign.h:4034)
 		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
-	} else codes_end_cell<W>(rows, RB, qlen, tlen, rs.score, rs.qe, rs.te);
+	} else codes_end_cell<W>(rows, RB, qlen, tlen, a.ref_bw, rs.score, rs.qe, rs.te);
 	rs.score = __builtin_amdgcn_readfirstlane(rs.score); rs.qe = __builtin_amdgcn_readfirstlane(rs.qe); rs.te = __builtin_amdgcn_readfirstlane(rs.te);
 	{ const int lb = begs[rs.te + 1]; if(rs.qe < lb || rs.qe >= lb + bw) bad = true; }
 	int x = rs.qe, y = rs.te;
@@ -730,7 +736,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 		rs.score = begs[tlen + 1];
 		if(rs.score == (int)0x80000000u) bad = true;               // band never reached the query end (bsalign.h:4034)
 		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
-	} else codes_end_cell<W>(rows, RB, qlen, tlen, rs.score, rs.qe, rs.te);
+	} else codes_end_cell<W>(rows, RB, qlen, tlen, a.ref_bw, rs.score, rs.qe, rs.te);
 	if(rs.qe < begs[rs.te + 1] || rs.qe >= begs[rs.te + 1] + bw) bad = true;
 	rs.qb = rs.qe; rs.qe++;
 	rs.tb = rs.te; rs.te++;

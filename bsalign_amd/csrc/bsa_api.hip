@@ -546,6 +546,7 @@ struct bsa_align_plan : PlanBase {
 	bool generic = false;                        // run the LDS-resident generic kernels
 	bool codes = false;                          // compact 4-bit-code traceback (global mode, bsa_align8_pk.hip CODES)
 	uint32_t max_bw = 0;
+	uint32_t ref_bw = 0;                         // a whole-query band widened to bw: the reference's own bandwidth (1 = per pair), see bsa_align_plan_create
 	uint32_t qpad = 0, tpad = 16;
 };
 
@@ -568,13 +569,14 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	// never moves (bsalign.h:3338: qoff + bw >= qlen), cells beyond the query end hold the -63 padding and nothing flows from them
 	// to the cells in front, so inside the exact-arithmetic guard the result does not depend on how wide the band is or how it is
 	// striped.  Such a batch runs at the next width the register kernels have (64 / 128 / 256) on the compact path instead of the
-	// LDS-resident run-time-width kernel; `cells` keeps the reference's own band widths.  (Overlap / extend: row_max breaks ties in
-	// striped order, bsalign.h:3213-3329, so the width matters there.)  BSA_ALIGN8_WIDEN=0 keeps the old dispatch.
+	// LDS-resident run-time-width kernel; `cells` keeps the reference's own band widths.  Overlap / extend: the one thing that sees
+	// the striping is row_max on the last row (its tie rules, bsalign.h:3213-3329) -- the traceback kernel takes it over the
+	// reference's band in the reference's striping (Align8Args::ref_bw, codes_end_cell).  BSA_ALIGN8_WIDEN=0 keeps the old dispatch.
 	bool widened = false;
 	{
 		const char *we = getenv("BSA_ALIGN8_WIDEN");
 		const char *le = getenv("BSA_ALIGN8_LITERAL");
-		bool full = type == BSA_MODE_GLOBAL && !(par->mode & BSA_MODE_ROWRECORDS) && !(we && we[0] == '0') && !(le && le[0] == '1')
+		bool full = !(par->mode & BSA_MODE_ROWRECORDS) && !(we && we[0] == '0') && !(le && le[0] == '1')
 			&& (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw <= 256u && n > 0;
 		if(full && bw != 0) for(size_t k = 0; k < n && full; k++) full = qlen[k] <= bw;
 		// the gap model must not depend on the width (bsalign.h:2084-2092 compares a ratio of the penalties with it)
@@ -593,6 +595,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	}
 	bsa_align_plan *p = new bsa_align_plan();
 	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
+	p->ref_bw = widened ? (bw_req ? bw_req : 1u) : 0u;
 	p->generic = (bw == 0) || !bsa_align8_supported_bw(bw);
 	p->max_bw = max_bw;
 	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)std::max(max_bw, 16u));
@@ -662,7 +665,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	memset(&a, 0, sizeof(a));
 	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
 	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
-	a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode;
+	a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode; a.ref_bw = p->ref_bw;
 	a.gapo1 = p->par.gapo1; a.gape1 = p->par.gape1; a.gapo2 = p->par.gapo2; a.gape2 = p->par.gape2;
 	int smax = -127, smin = 127;
 	for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)p->par.matrix[i]); smin = std::min(smin, (int)p->par.matrix[i]); a.matrix[i] = p->par.matrix[i]; }

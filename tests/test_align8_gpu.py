@@ -273,26 +273,32 @@ def test_ties_at_column_zero(ctx, monkeypatch, wave):
 
 @pytest.mark.parametrize("bw", [0, 48, 80, 112, 176, 208])
 def test_whole_query_bands_run_widened_on_the_compact_path(ctx, bw, monkeypatch):
-    """global mode, a band that covers every query (the reference CLI's `-W 0`, or a bandwidth no shorter than any query, of a
-    width the register kernels do not have): the band never moves and the result does not depend on its width inside the
-    exact-arithmetic guard, so the batch runs at the next register-kernel width on the compact path -- same results as the
-    reference's own width (the oracle runs the requested one), and as the run-time-width kernel (BSA_ALIGN8_WIDEN=0)"""
+    """a band that covers every query (the reference CLI's `-W 0`, or a bandwidth no shorter than any query, of a width the
+    register kernels do not have): the band never moves and the DP does not depend on its width inside the exact-arithmetic
+    guard, so the batch runs at the next register-kernel width on the compact path -- same results as the reference's own
+    width (the oracle runs the requested one), and as the run-time-width kernel (BSA_ALIGN8_WIDEN=0); in overlap / extend mode
+    the maximum of the last row is taken in the reference's striping of its own band"""
     import bsalign_amd as B
     rng = np.random.default_rng(4242 + bw)
     top = bw if bw else 256
     lens = [l for l in (1, 2, 15, 16, 17, 31, 33, 47, 48, 63, 64, 65, 79, 100, 111, 112, 127, 129, 150, 176, 200, 208, 240, 255, 256) if l <= top]
     pairs = [(q[:top] if len(q) > top else q, t) for q, t in _mk_pairs(rng, 160, lens, eps_list=(0.0, 0.05, 0.2, 0.4), ratios=(1.0, 1.0, 0.5, 0.9))]
     for scname in ("affine", "paper", "linear"):
-        _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS[scname])
-        assert "k_align8_fwd_x" in ctx.last_kernel_names()[0], ctx.last_kernel_names()
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):        # (overlap / extend: row_max in the reference's striping)
+            _check(ctx, pairs, mode, bw, SCORINGS[scname])
+            assert "k_align8_fwd_x" in ctx.last_kernel_names()[0], ctx.last_kernel_names()
     out_w, cig_w, st_w = ctx.align_batch(pairs, B.make_params(S.MODE_GLOBAL, bw, *SCORINGS["affine"]))
     monkeypatch.setenv("BSA_ALIGN8_WIDEN", "0")
     out_g, cig_g, st_g = ctx.align_batch(pairs, B.make_params(S.MODE_GLOBAL, bw, *SCORINGS["affine"]))
     assert "gen" in ctx.last_kernel_names()[0]
     assert np.array_equal(out_w, out_g) and np.array_equal(st_w, st_g) and all(np.array_equal(a, b) for a, b in zip(cig_w, cig_g))
     monkeypatch.delenv("BSA_ALIGN8_WIDEN")
-    # a scoring outside the guard, the other modes and queries longer than 256 keep the run-time-width kernel
-    _check(ctx, pairs[:32], S.MODE_OVERLAP, bw, SCORINGS["affine"])
-    assert "gen" in ctx.last_kernel_names()[0]
+    for mode in (S.MODE_OVERLAP, S.MODE_EXTEND):
+        out_w, cig_w, st_w = ctx.align_batch(pairs, B.make_params(mode, bw, *SCORINGS["paper"]))
+        monkeypatch.setenv("BSA_ALIGN8_WIDEN", "0")
+        out_g, cig_g, st_g = ctx.align_batch(pairs, B.make_params(mode, bw, *SCORINGS["paper"]))
+        monkeypatch.delenv("BSA_ALIGN8_WIDEN")
+        assert np.array_equal(out_w, out_g) and np.array_equal(st_w, st_g) and all(np.array_equal(a, b) for a, b in zip(cig_w, cig_g))
+    # a scoring outside the guard keeps the run-time-width kernel
     _check(ctx, pairs[:32], S.MODE_GLOBAL, bw, (10, -30, -20, -10, 0, 0))
     assert "k_align8_fwd_x" not in ctx.last_kernel_names()[0]

@@ -46,6 +46,9 @@ def main():
                 Q = Q[int(len(Q) * 0.3):]
             if len(Q) == 0:
                 Q = np.array([1], np.uint8)
+            if os.environ.get("STRESS_MAXQ"):          # cap the query length (whole-query bands of at most 256 columns run widened, bsa_api.hip)
+                Q = Q[:int(os.environ["STRESS_MAXQ"])]
+                T = T[:4 * int(os.environ["STRESS_MAXQ"])]
             pairs.append((Q, T))
         out, cigs, status = ctx.align_batch(pairs, B.make_params(mode, bw, *sc))
         nb = nf = 0
