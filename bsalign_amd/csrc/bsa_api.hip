@@ -582,8 +582,9 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		// the gap model must not depend on the width (bsalign.h:2084-2092 compares a ratio of the penalties with it)
 		const int pwa = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 16);
 		const int pwb = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 256);
-		if(full && pwa == pwb && pwa <= 1){
-			const uint32_t kbw = max_bw <= 64u ? 64u : max_bw <= 128u ? 128u : 256u;
+		if(full && pwa == pwb){
+			// (two-piece gaps: the compact path exists at bandwidth 128 in global mode only -- the checks below say so)
+			const uint32_t kbw = (max_bw <= 64u && pwa <= 1) ? 64u : max_bw <= 128u ? 128u : 256u;
 			Align8Args t;
 			memset(&t, 0, sizeof(t));
 			t.bw = kbw; t.mode = par->mode; t.gapo1 = par->gapo1; t.gape1 = par->gape1; t.gapo2 = par->gapo2; t.gape2 = par->gape2;
