@@ -553,6 +553,28 @@ struct bsa_align_plan : PlanBase {
 extern "C" void bsa_align_plan_destroy(bsa_align_plan_t *p){ plan_free(p); }
 extern "C" double bsa_align_plan_cells(const bsa_align_plan_t *p){ return p ? p->cells : 0.0; }
 
+// Can a whole-query band of `cols` columns (a multiple of 16, at most 256) run at a register-kernel width on the compact path?
+// Returns that width, or 0.  (See bsa_align_plan_create.)
+static uint32_t align8_widened_bw(const bsa_align_params_t *par, uint32_t cols){
+	const int type = par->mode & 3;
+	const char *we = getenv("BSA_ALIGN8_WIDEN");
+	const char *le = getenv("BSA_ALIGN8_LITERAL");
+	if((par->mode & BSA_MODE_ROWRECORDS) || (we && we[0] == '0') || (le && le[0] == '1') || cols == 0u || cols > 256u) return 0u;
+	// the gap model must not depend on the width (bsalign.h:2084-2092 compares a ratio of the penalties with it)
+	const int pwa = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 16);
+	const int pwb = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 256);
+	if(pwa != pwb) return 0u;
+	// (two-piece gaps: the compact path exists at bandwidth 128 in global mode only -- the checks below say so)
+	const uint32_t kbw = (cols <= 64u && pwa <= 1) ? 64u : cols <= 128u ? 128u : 256u;
+	Align8Args t;
+	memset(&t, 0, sizeof(t));
+	t.bw = kbw; t.mode = type; t.gapo1 = par->gapo1; t.gape1 = par->gape1; t.gapo2 = par->gapo2; t.gape2 = par->gape2;
+	int smax = -127, smin = 127;
+	for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
+	t.smax = smax; t.smin = smin;
+	return (bsa_align8_codes_supported(t, pwa) && bsa_align8_x_supported(t, pwa)) ? kbw : 0u;
+}
+
 extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const uint32_t *qlen,
 		const uint64_t *toff, const uint32_t *tlen, size_t n, const bsa_align_params_t *par, bsa_align_plan_t **out){
 	if(!c || !out || !par || (n && (!qoff || !qlen || !toff || !tlen))) return BSA_E_ARG;
@@ -574,25 +596,10 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	// reference's band in the reference's striping (Align8Args::ref_bw, codes_end_cell).  BSA_ALIGN8_WIDEN=0 keeps the old dispatch.
 	bool widened = false;
 	{
-		const char *we = getenv("BSA_ALIGN8_WIDEN");
-		const char *le = getenv("BSA_ALIGN8_LITERAL");
-		bool full = !(par->mode & BSA_MODE_ROWRECORDS) && !(we && we[0] == '0') && !(le && le[0] == '1')
-			&& (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw <= 256u && n > 0;
+		bool full = (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw <= 256u && n > 0;
 		if(full && bw != 0) for(size_t k = 0; k < n && full; k++) full = qlen[k] <= bw;
-		// the gap model must not depend on the width (bsalign.h:2084-2092 compares a ratio of the penalties with it)
-		const int pwa = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 16);
-		const int pwb = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 256);
-		if(full && pwa == pwb){
-			// (two-piece gaps: the compact path exists at bandwidth 128 in global mode only -- the checks below say so)
-			const uint32_t kbw = (max_bw <= 64u && pwa <= 1) ? 64u : max_bw <= 128u ? 128u : 256u;
-			Align8Args t;
-			memset(&t, 0, sizeof(t));
-			t.bw = kbw; t.mode = par->mode; t.gapo1 = par->gapo1; t.gape1 = par->gape1; t.gapo2 = par->gapo2; t.gape2 = par->gape2;
-			int smax = -127, smin = 127;
-			for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
-			t.smax = smax; t.smin = smin;
-			if(bsa_align8_codes_supported(t, pwa) && bsa_align8_x_supported(t, pwa)){ bw = kbw; max_bw = kbw; widened = true; }
-		}
+		const uint32_t kbw = full ? align8_widened_bw(par, max_bw) : 0u;
+		if(kbw){ bw = kbw; max_bw = kbw; widened = true; }
 	}
 	bsa_align_plan *p = new bsa_align_plan();
 	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
@@ -721,6 +728,55 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	for(size_t k = 0; k < n; k++)            // the staging kernel reads seqs + qoff[k] .. + qlen[k] unconditionally
 		if(qoff[k] + qlen[k] > seqs_bytes || toff[k] + tlen[k] > seqs_bytes){ c->err = "sequence offsets outside the blob"; return BSA_E_ARG; }
 	(void)hipSetDevice(c->device);
+	// Whole-query bands (bandwidth 0, or one the register kernels do not have): a plan runs at ONE width, so a batch whose pairs
+	// fall into different width classes of the widened dispatch (bsa_align_plan_create) -- or some of whose queries are too long
+	// for it -- goes down as one sub-batch per class: a single long query must not send a million short ones to the
+	// run-time-width kernel.  (Host-pointer entry only; with device pointers the caller groups its pairs.)
+	{
+		const uint32_t bw_req = (par->bandwidth + 15u) / 16u * 16u;
+		if(n >= 2 && (bw_req == 0 || !bsa_align8_supported_bw(bw_req))){
+			const uint32_t wide[3] = {align8_widened_bw(par, 64u), align8_widened_bw(par, 128u), align8_widened_bw(par, 256u)};
+			auto klass = [&](size_t k) -> uint32_t {           // the width the pair would run at alone; 0 = run-time-width kernel
+				const uint32_t cols = bw_req ? (qlen[k] <= bw_req ? bw_req : 0u) : (std::max(qlen[k], 1u) + 15u) / 16u * 16u;
+				return cols == 0u || cols > 256u ? 0u : cols <= 64u ? wide[0] : cols <= 128u ? wide[1] : wide[2];
+			};
+			size_t cnt[4] = {0, 0, 0, 0};
+			auto slot_of = [](uint32_t w) -> int { return w == 64u ? 1 : w == 128u ? 2 : w == 256u ? 3 : 0; };
+			if(wide[0] | wide[1] | wide[2]) for(size_t k = 0; k < n; k++) cnt[slot_of(klass(k))]++;
+			const int present = (cnt[0] != 0) + (cnt[1] != 0) + (cnt[2] != 0) + (cnt[3] != 0);
+			if(present > 1){
+				std::vector<std::vector<uint32_t>> pc(n);          // per pair CIGAR words
+				for(int cl = 0; cl < 4; cl++){
+					if(!cnt[cl]) continue;
+					const size_t m = cnt[cl];
+					std::vector<size_t> idx; idx.reserve(m);
+					for(size_t k = 0; k < n; k++) if(slot_of(klass(k)) == cl) idx.push_back(k);
+					std::vector<uint64_t> sq(m), stt(m), soff(m + 1);
+					std::vector<uint32_t> sql(m), stl(m), sst(m);
+					std::vector<bsa_result_t> sout(m);
+					size_t scap = 16;
+					for(size_t j = 0; j < m; j++){ sq[j] = qoff[idx[j]]; stt[j] = toff[idx[j]]; sql[j] = qlen[idx[j]]; stl[j] = tlen[idx[j]]; scap += (size_t)sql[j] + stl[j] + 2; }
+					std::vector<uint32_t> scig(cigar ? scap : 0);
+					const int rcs = bsa_align_batch(c, seqs, seqs_bytes, sq.data(), sql.data(), stt.data(), stl.data(), m, par, sout.data(),
+						cigar ? scig.data() : nullptr, scap, (cigar && cigar_off) ? soff.data() : nullptr, sst.data());
+					if(rcs != BSA_OK) return rcs;
+					for(size_t j = 0; j < m; j++){
+						out[idx[j]] = sout[j];
+						if(status) status[idx[j]] = sst[j];
+						if(cigar && cigar_off) pc[idx[j]].assign(scig.begin() + soff[j], scig.begin() + soff[j + 1]);
+					}
+				}
+				if(cigar && cigar_off){
+					uint64_t w = 0;
+					for(size_t k = 0; k < n; k++){ cigar_off[k] = w; w += pc[k].size(); }
+					cigar_off[n] = w;
+					if(w > cigar_cap_words){ c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
+					for(size_t k = 0; k < n; k++) if(!pc[k].empty()) memcpy(cigar + cigar_off[k], pc[k].data(), pc[k].size() * 4);
+				}
+				return BSA_OK;
+			}
+		}
+	}
 	bsa_align_plan_t *p = nullptr;
 	int rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
 	if(rc != BSA_OK) return rc;

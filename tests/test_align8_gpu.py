@@ -311,3 +311,32 @@ def test_whole_query_bands_run_widened_on_the_compact_path(ctx, bw, monkeypatch)
     # a scoring outside the guard keeps the run-time-width kernel
     _check(ctx, pairs[:32], S.MODE_GLOBAL, bw, (10, -30, -20, -10, 0, 0))
     assert "k_align8_fwd_x" not in ctx.last_kernel_names()[0]
+
+
+@pytest.mark.parametrize("bw", [0, 112])
+def test_mixed_whole_query_batch_runs_one_sub_batch_per_width_class(ctx, bw):
+    """bandwidth 0 (or an odd one) over queries of very different lengths: the host-pointer entry sends every width class of the
+    widened dispatch down as a sub-batch of its own and the rest to the run-time-width kernel; results, status words and the
+    CIGAR arena come back in the caller's order"""
+    rng = np.random.default_rng(515 + bw)
+    pairs = _mk_pairs(rng, 240, [1, 5, 30, 60, 64, 65, 100, 128, 129, 200, 256, 257, 300, 700, 1200], eps_list=(0.0, 0.05, 0.2), ratios=(1.0, 1.0, 0.7))
+    order = rng.permutation(len(pairs))
+    pairs = [pairs[i] for i in order]
+    for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+        _check(ctx, pairs, mode, bw, SCORINGS["affine"])
+    _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS["twopiece"])
+    # the arena too small: the required number of words is reported (bsalign_hip.h)
+    import bsalign_amd as B
+    import ctypes as C
+    seqs, qoff, qlen, toff, tlen = B.pack_pairs(pairs)
+    n = len(pairs)
+    out = np.zeros(n, dtype=B.RESULT_DTYPE)
+    cig = np.zeros(8, dtype=np.uint32)
+    coff = np.zeros(n + 1, dtype=np.uint64)
+    st = np.zeros(n, dtype=np.uint32)
+    par = B.make_params(S.MODE_GLOBAL, bw, *SCORINGS["affine"])
+    rc = B.lib().bsa_align_batch(ctx.h, seqs.ctypes.data, seqs.size, qoff.ctypes.data, qlen.ctypes.data, toff.ctypes.data, tlen.ctypes.data, n,
+                                 C.byref(par), out.ctypes.data, cig.ctypes.data, cig.size, coff.ctypes.data, st.ctypes.data)
+    assert rc == -5 and coff[n] > 8
+    full_out, full_cigs, _ = ctx.align_batch(pairs, par)
+    assert int(coff[n]) == sum(len(c) for c in full_cigs)
