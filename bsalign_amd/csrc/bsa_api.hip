@@ -291,6 +291,7 @@ struct PlanBase {
 	uint32_t *d_cnt_pos = nullptr, *d_cnt_pair = nullptr, *d_status_own = nullptr;
 	uint64_t *d_off_pos = nullptr, *d_src_pair = nullptr, *d_carry = nullptr;
 	uint32_t *d_tmp = nullptr; size_t tmp_words = 0;
+	void *pool = nullptr;           // one allocation behind all the metadata pointers above (plan_common_alloc)
 	std::vector<void*> extra;       // path-specific device allocations
 	virtual ~PlanBase(){}
 };
@@ -311,9 +312,12 @@ static void plan_free(PlanBase *p){
 	(void)hipSetDevice(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
 	(void)hipStreamSynchronize(p->ctx->aux_stream);
-	void *ptrs[] = { p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_slot_end, p->d_qlen, p->d_tlen, p->d_order, p->d_qst, p->d_tst,
-	                 p->d_cnt_pos, p->d_cnt_pair, p->d_status_own, p->d_off_pos, p->d_src_pair, p->d_carry, p->d_tmp };
-	for(void *q : ptrs) if(q) (void)hipFree(q);
+	if(p->pool){ (void)hipFree(p->pool); if(p->d_tmp) (void)hipFree(p->d_tmp); }
+	else {
+		void *ptrs[] = { p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_slot_end, p->d_qlen, p->d_tlen, p->d_order, p->d_qst, p->d_tst,
+		                 p->d_cnt_pos, p->d_cnt_pair, p->d_status_own, p->d_off_pos, p->d_src_pair, p->d_carry, p->d_tmp };
+		for(void *q : ptrs) if(q) (void)hipFree(q);
+	}
 	for(void *q : p->extra) if(q) (void)hipFree(q);
 	delete p;
 }
@@ -413,19 +417,30 @@ static int plan_common_alloc(PlanBase *p, const uint64_t *qoff, const uint32_t *
 		const std::vector<uint64_t> &qpoff, const std::vector<uint64_t> &tpoff, const std::vector<uint64_t> &slot,
 		const std::vector<uint64_t> &slot_end, const std::vector<uint32_t> &order, size_t qst_bytes, size_t tst_bytes){
 	bsa_ctx *c = p->ctx; const size_t n = p->n; int rc;
-	std::vector<uint64_t> vqoff(qoff, qoff + n), vtoff(toff, toff + n);
-	std::vector<uint32_t> vqlen(qlen, qlen + n), vtlen(tlen, tlen + n);
-#define TRY(x) do { rc = (x); if(rc != BSA_OK) return rc; } while(0)
-	TRY(dev_upload(c, &p->d_qoff, vqoff)); TRY(dev_upload(c, &p->d_toff, vtoff));
-	TRY(dev_upload(c, &p->d_qlen, vqlen)); TRY(dev_upload(c, &p->d_tlen, vtlen));
-	TRY(dev_upload(c, &p->d_qpoff, qpoff)); TRY(dev_upload(c, &p->d_tpoff, tpoff));
-	TRY(dev_upload(c, &p->d_slot, slot)); TRY(dev_upload(c, &p->d_slot_end, slot_end)); TRY(dev_upload(c, &p->d_order, order));
-	TRY(dev_alloc(c, &p->d_qst, qst_bytes)); TRY(dev_alloc(c, &p->d_tst, tst_bytes));
-	TRY(dev_alloc(c, &p->d_cnt_pos, n)); TRY(dev_alloc(c, &p->d_cnt_pair, n)); TRY(dev_alloc(c, &p->d_status_own, n));
-	TRY(dev_alloc(c, &p->d_off_pos, n + 1)); TRY(dev_alloc(c, &p->d_src_pair, n)); TRY(dev_alloc(c, &p->d_carry, 1));
-	TRY(ctx_ws_reserve(c, p->half_bytes * p->nbuf));
-#undef TRY
-	return BSA_OK;
+	// ONE device allocation and ONE copy for all of a plan's metadata (a batch of one pair -- the reference-named single-pair
+	// functions, the POA's per-read calls -- used to pay seventeen hipMalloc and nine hipMemcpy calls here)
+	struct Part { void **dst; const void *src; size_t bytes, off; };
+	const size_t m = std::max<size_t>(n, 1);
+	Part parts[] = {
+		{(void**)&p->d_qoff, qoff, n * 8, 0}, {(void**)&p->d_toff, toff, n * 8, 0}, {(void**)&p->d_qlen, qlen, n * 4, 0}, {(void**)&p->d_tlen, tlen, n * 4, 0},
+		{(void**)&p->d_qpoff, qpoff.data(), n * 8, 0}, {(void**)&p->d_tpoff, tpoff.data(), n * 8, 0}, {(void**)&p->d_slot, slot.data(), n * 8, 0},
+		{(void**)&p->d_slot_end, slot_end.data(), n * 8, 0}, {(void**)&p->d_order, order.data(), n * 4, 0},
+		// (no content to upload from here on)
+		{(void**)&p->d_qst, nullptr, std::max<size_t>(qst_bytes, 1), 0}, {(void**)&p->d_tst, nullptr, std::max<size_t>(tst_bytes, 1), 0},
+		{(void**)&p->d_cnt_pos, nullptr, m * 4, 0}, {(void**)&p->d_cnt_pair, nullptr, m * 4, 0}, {(void**)&p->d_status_own, nullptr, m * 4, 0},
+		{(void**)&p->d_off_pos, nullptr, (m + 1) * 8, 0}, {(void**)&p->d_src_pair, nullptr, m * 8, 0}, {(void**)&p->d_carry, nullptr, 8, 0},
+	};
+	size_t total = 0, upload = 0;
+	for(Part &q : parts){ q.off = total; total += (std::max<size_t>(q.bytes, 8) + 255) & ~(size_t)255; if(q.src) upload = total; }
+	if(hipMalloc(&p->pool, total) != hipSuccess){ p->pool = nullptr; c->err = "metadata allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
+	if(n){
+		std::vector<uint8_t> stage(upload);
+		for(const Part &q : parts) if(q.src && q.bytes) memcpy(stage.data() + q.off, q.src, q.bytes);
+		HIPCHK(c, hipMemcpy(p->pool, stage.data(), upload, hipMemcpyHostToDevice));
+	}
+	for(Part &q : parts) *q.dst = (uint8_t*)p->pool + q.off;
+	rc = ctx_ws_reserve(c, p->half_bytes * p->nbuf);
+	return rc;
 }
 
 // The chunk pipeline.  fwd(chunk, ws_half, stream) launches the forward DP; trace(chunk, ws_half, stream) launches the
@@ -508,18 +523,17 @@ template<class RunFn>
 static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t n, bsa_result_t *out, uint32_t *cigar,
 		size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status, RunFn run){
 	uint8_t *d_seqs = nullptr; bsa_result_t *d_out = nullptr; uint32_t *d_cig = nullptr, *d_status = nullptr; uint64_t *d_off = nullptr;
-	auto cleanup = [&](){
-		if(d_seqs) (void)hipFree(d_seqs); if(d_out) (void)hipFree(d_out); if(d_cig) (void)hipFree(d_cig);
-		if(d_status) (void)hipFree(d_status); if(d_off) (void)hipFree(d_off);
-	};
+	uint8_t *pool = nullptr;            // one allocation for the five buffers
+	auto cleanup = [&](){ if(pool) (void)hipFree(pool); pool = nullptr; };
 	const bool want_cig = cigar && cigar_off;
 #define TRYH(call) do { hipError_t _e = (call); if(_e != hipSuccess){ c->err = std::string(#call) + ": " + hipGetErrorString(_e); cleanup(); return BSA_E_HIP; } } while(0)
-	TRYH(hipMalloc((void**)&d_seqs, std::max<size_t>(seqs_bytes, 1)));
-	TRYH(hipMalloc((void**)&d_out, n * sizeof(bsa_result_t)));
-	TRYH(hipMalloc((void**)&d_status, n * sizeof(uint32_t)));
-	if(want_cig){
-		TRYH(hipMalloc((void**)&d_cig, std::max<size_t>(cigar_cap_words, 1) * 4));
-		TRYH(hipMalloc((void**)&d_off, (n + 1) * sizeof(uint64_t)));
+	{
+		auto up = [](size_t b){ return (std::max<size_t>(b, 8) + 255) & ~(size_t)255; };
+		const size_t o_seqs = 0, o_out = o_seqs + up(seqs_bytes), o_st = o_out + up(n * sizeof(bsa_result_t)), o_off = o_st + up(n * sizeof(uint32_t));
+		const size_t o_cig = o_off + (want_cig ? up((n + 1) * sizeof(uint64_t)) : 0), total = o_cig + (want_cig ? up(cigar_cap_words * 4) : 0);
+		TRYH(hipMalloc((void**)&pool, total));
+		d_seqs = pool + o_seqs; d_out = (bsa_result_t*)(pool + o_out); d_status = (uint32_t*)(pool + o_st);
+		if(want_cig){ d_off = (uint64_t*)(pool + o_off); d_cig = (uint32_t*)(pool + o_cig); }
 	}
 	TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
 	int rc = run(d_seqs, d_out, d_cig, d_off, d_status);
