@@ -33,7 +33,33 @@ struct bsa_ctx {
 	size_t tev_used = 0;
 	std::string fwd_name, trace_name;    // kernels behind those two timings
 	double diagdp_ms = 0;
+	// small device buffers kept between calls (slot 0: a plan's metadata pool, slot 1: the host-pointer wrapper's buffers): a batch
+	// of one pair otherwise spends more time in hipMalloc / hipFree than in its kernels
+	size_t budget_last = 0;          // last answer of ctx_ws_budget
+	void *keep[2] = {nullptr, nullptr}; size_t keep_bytes[2] = {0, 0}; bool keep_busy[2] = {false, false};
 };
+
+static const size_t BSA_KEEP_MAX = (size_t)64 << 20;      // larger requests are plain allocations
+// a device buffer of at least `bytes`; *kept says whether it is the context's (released with ctx_buf_put) or the caller's to free
+static hipError_t ctx_buf_get(bsa_ctx *c, int slot, size_t bytes, void **out, bool *kept){
+	*kept = false;
+	if(bytes <= BSA_KEEP_MAX && !c->keep_busy[slot]){
+		if(c->keep_bytes[slot] < bytes){
+			if(c->keep[slot]){ (void)hipFree(c->keep[slot]); c->keep[slot] = nullptr; c->keep_bytes[slot] = 0; }
+			const size_t want = std::max<size_t>(bytes * 2, (size_t)1 << 20);
+			const hipError_t e = hipMalloc(&c->keep[slot], std::min(want, BSA_KEEP_MAX));
+			if(e != hipSuccess){ c->keep[slot] = nullptr; return e; }
+			c->keep_bytes[slot] = std::min(want, BSA_KEEP_MAX);
+		}
+		c->keep_busy[slot] = true; *kept = true; *out = c->keep[slot];
+		return hipSuccess;
+	}
+	return hipMalloc(out, bytes);
+}
+static void ctx_buf_put(bsa_ctx *c, int slot, void *ptr, bool kept){
+	if(!ptr) return;
+	if(kept) c->keep_busy[slot] = false; else (void)hipFree(ptr);
+}
 
 #define HIPCHK(ctx, call) do { hipError_t _e = (call); if(_e != hipSuccess){ (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e); return BSA_E_HIP; } } while(0)
 
@@ -65,6 +91,7 @@ extern "C" void bsa_ctx_destroy(bsa_ctx_t *c){
 	for(hipEvent_t e : c->sev) (void)hipEventDestroy(e);
 	for(hipEvent_t e : c->tev) (void)hipEventDestroy(e);
 	if(c->ws) (void)hipFree(c->ws);
+	for(int k = 0; k < 2; k++) if(c->keep[k]) (void)hipFree(c->keep[k]);
 	if(c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
 	if(c->own_stream) (void)hipStreamDestroy(c->own_stream);
 	delete c;
@@ -141,12 +168,16 @@ static int ctx_sync_event(bsa_ctx *c, hipEvent_t *e){
 	return BSA_OK;
 }
 
-static size_t ctx_ws_budget(bsa_ctx *c){
+// `need`: what the plan will ask for in total; a plan that needs less than an eighth of the last answer takes that answer
+// (hipMemGetInfo costs more than all the kernels of a one-pair batch)
+static size_t ctx_ws_budget(bsa_ctx *c, size_t need = ~(size_t)0){
 	if(c->ws_limit) return c->ws_limit;
+	if(c->budget_last && need < c->budget_last / 8) return c->budget_last;
 	size_t fr = 0, tot = 0;
 	if(hipMemGetInfo(&fr, &tot) != hipSuccess) return (size_t)8 << 30;
 	// what is free now plus what the context already holds, keep 20% headroom for the caller
-	return (size_t)((double)(fr + c->ws_bytes) * 0.8);
+	c->budget_last = (size_t)((double)(fr + c->ws_bytes) * 0.8);
+	return c->budget_last;
 }
 
 static int ctx_ws_reserve(bsa_ctx *c, size_t bytes){
@@ -292,6 +323,7 @@ struct PlanBase {
 	uint64_t *d_off_pos = nullptr, *d_src_pair = nullptr, *d_carry = nullptr;
 	uint32_t *d_tmp = nullptr; size_t tmp_words = 0;
 	void *pool = nullptr;           // one allocation behind all the metadata pointers above (plan_common_alloc)
+	bool pool_kept = false;         // ... which is the context's kept buffer (ctx_buf_get)
 	std::vector<void*> extra;       // path-specific device allocations
 	virtual ~PlanBase(){}
 };
@@ -312,7 +344,7 @@ static void plan_free(PlanBase *p){
 	(void)hipSetDevice(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
 	(void)hipStreamSynchronize(p->ctx->aux_stream);
-	if(p->pool){ (void)hipFree(p->pool); if(p->d_tmp) (void)hipFree(p->d_tmp); }
+	if(p->pool){ ctx_buf_put(p->ctx, 0, p->pool, p->pool_kept); if(p->d_tmp) (void)hipFree(p->d_tmp); }
 	else {
 		void *ptrs[] = { p->d_qoff, p->d_toff, p->d_qpoff, p->d_tpoff, p->d_slot, p->d_slot_end, p->d_qlen, p->d_tlen, p->d_order, p->d_qst, p->d_tst,
 		                 p->d_cnt_pos, p->d_cnt_pair, p->d_status_own, p->d_off_pos, p->d_src_pair, p->d_carry, p->d_tmp };
@@ -350,9 +382,9 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 		std::vector<uint64_t> &slot, std::vector<uint64_t> &slot_end, bool mix_classes = false, bool pipe_default = false){
 	bsa_ctx *c = p->ctx;
 	const size_t n = order.size();
-	const size_t budget = ctx_ws_budget(c);
 	size_t total = 0, biggest = 0;
 	for(size_t pos = 0; pos < n; pos++){ total += need[pos]; biggest = std::max(biggest, need[pos]); }
+	const size_t budget = ctx_ws_budget(c, total);
 	if(biggest > budget){ c->err = "workspace limit too small for one pair"; return BSA_E_NOMEM; }
 	// Both kernels are row-serial per pair, so throughput = pairs in flight / per-pair latency: chunks are made as
 	// large as memory allows and run back to back on the context stream.  Splitting the workspace in two halves and
@@ -432,7 +464,7 @@ static int plan_common_alloc(PlanBase *p, const uint64_t *qoff, const uint32_t *
 	};
 	size_t total = 0, upload = 0;
 	for(Part &q : parts){ q.off = total; total += (std::max<size_t>(q.bytes, 8) + 255) & ~(size_t)255; if(q.src) upload = total; }
-	if(hipMalloc(&p->pool, total) != hipSuccess){ p->pool = nullptr; c->err = "metadata allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
+	if(ctx_buf_get(c, 0, total, &p->pool, &p->pool_kept) != hipSuccess){ p->pool = nullptr; c->err = "metadata allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
 	if(n){
 		std::vector<uint8_t> stage(upload);
 		for(const Part &q : parts) if(q.src && q.bytes) memcpy(stage.data() + q.off, q.src, q.bytes);
@@ -523,21 +555,34 @@ template<class RunFn>
 static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t n, bsa_result_t *out, uint32_t *cigar,
 		size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status, RunFn run){
 	uint8_t *d_seqs = nullptr; bsa_result_t *d_out = nullptr; uint32_t *d_cig = nullptr, *d_status = nullptr; uint64_t *d_off = nullptr;
-	uint8_t *pool = nullptr;            // one allocation for the five buffers
-	auto cleanup = [&](){ if(pool) (void)hipFree(pool); pool = nullptr; };
+	uint8_t *pool = nullptr; bool pool_kept = false;            // one allocation for the five buffers
+	auto cleanup = [&](){ ctx_buf_put(c, 1, pool, pool_kept); pool = nullptr; };
 	const bool want_cig = cigar && cigar_off;
 #define TRYH(call) do { hipError_t _e = (call); if(_e != hipSuccess){ c->err = std::string(#call) + ": " + hipGetErrorString(_e); cleanup(); return BSA_E_HIP; } } while(0)
-	{
-		auto up = [](size_t b){ return (std::max<size_t>(b, 8) + 255) & ~(size_t)255; };
-		const size_t o_seqs = 0, o_out = o_seqs + up(seqs_bytes), o_st = o_out + up(n * sizeof(bsa_result_t)), o_off = o_st + up(n * sizeof(uint32_t));
-		const size_t o_cig = o_off + (want_cig ? up((n + 1) * sizeof(uint64_t)) : 0), total = o_cig + (want_cig ? up(cigar_cap_words * 4) : 0);
-		TRYH(hipMalloc((void**)&pool, total));
-		d_seqs = pool + o_seqs; d_out = (bsa_result_t*)(pool + o_out); d_status = (uint32_t*)(pool + o_st);
-		if(want_cig){ d_off = (uint64_t*)(pool + o_off); d_cig = (uint32_t*)(pool + o_cig); }
-	}
+	auto up = [](size_t b){ return (std::max<size_t>(b, 8) + 255) & ~(size_t)255; };
+	const size_t o_seqs = 0, o_out = o_seqs + up(seqs_bytes), o_st = o_out + up(n * sizeof(bsa_result_t)), o_off = o_st + up(n * sizeof(uint32_t));
+	const size_t o_cig = o_off + (want_cig ? up((n + 1) * sizeof(uint64_t)) : 0), total = o_cig + (want_cig ? up(cigar_cap_words * 4) : 0);
+	TRYH(ctx_buf_get(c, 1, total, (void**)&pool, &pool_kept));
+	d_seqs = pool + o_seqs; d_out = (bsa_result_t*)(pool + o_out); d_status = (uint32_t*)(pool + o_st);
+	if(want_cig){ d_off = (uint64_t*)(pool + o_off); d_cig = (uint32_t*)(pool + o_cig); }
 	TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
 	int rc = run(d_seqs, d_out, d_cig, d_off, d_status);
 	if(rc != BSA_OK){ cleanup(); return rc; }
+	if(total - o_out <= ((size_t)1 << 20)){
+		// a small batch: everything that goes back in ONE copy (results, status, offsets, the whole arena), then handed out
+		std::vector<uint8_t> back(total - o_out);
+		TRYH(hipMemcpyAsync(back.data(), pool + o_out, back.size(), hipMemcpyDeviceToHost, c->stream));
+		TRYH(hipStreamSynchronize(c->stream));
+		memcpy(out, back.data(), n * sizeof(bsa_result_t));
+		if(status) memcpy(status, back.data() + (o_st - o_out), n * sizeof(uint32_t));
+		if(want_cig){
+			memcpy(cigar_off, back.data() + (o_off - o_out), (n + 1) * sizeof(uint64_t));
+			if(cigar_off[n] > cigar_cap_words){ cleanup(); c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
+			memcpy(cigar, back.data() + (o_cig - o_out), cigar_off[n] * 4);
+		}
+		cleanup();
+		return BSA_OK;
+	}
 	TRYH(hipMemcpyAsync(out, d_out, n * sizeof(bsa_result_t), hipMemcpyDeviceToHost, c->stream));
 	if(status) TRYH(hipMemcpyAsync(status, d_status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	if(want_cig) TRYH(hipMemcpyAsync(cigar_off, d_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
