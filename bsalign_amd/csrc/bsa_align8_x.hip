@@ -117,7 +117,9 @@ static __device__ __forceinline__ void x_load_qcodes(const uint8_t *p, uint32_t 
 // PW = 2: two-piece gaps.  The frame is shifted by the extension of piece 1, so piece 2 keeps a real step dP = gape2 - gape1 > 0:
 //   qq = U - NQ      m = max(ee, qq, S~)      g = max(g, max(m, f) + gapo2) + dP - U      NQ' = min(h - qq, -gapo2) - dP
 // and a cell has nine facts (bsa_common.h "COMPACT slot", 8 bits): M, D, D2, which chain equals h (I1, I2), R1, R2, Od1, Od2.
-template<int W, int L, int PW = 1>
+// STATIC: every pair of the launch has a band that covers its whole query (Align8Args::static_band): the band never moves, so
+// the row is kept in place -- no speculative slide, no corrections of it, no band steering.
+template<int W, int L, int PW = 1, bool STATIC = false>
 static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint32_t first_pos, const uint32_t count, const uint32_t block){
 	constexpr int BW = 2 * L * W;
 	constexpr int WR = BW / 16, CR = 8 / L;
@@ -199,9 +201,9 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			HB = a.smax - a.smin;
 		}
 	}
-	uint32_t svU, svNE, svNQ = 0; // first cell of the row before the speculative slide (lane 0, low half: band position 0)
+	uint32_t svU = 0, svNE = 0, svNQ = 0; // first cell of the row before the speculative slide (lane 0, low half: band position 0)
 	// bring row -1 into the loop's form: slid by one cell, ubegs[0] not advanced
-	{
+	if constexpr (!STATIC){
 		const uint32_t t0u = U[0], t0e = NE[0];
 #pragma unroll
 		for(int k = 0; k + 1 < W; k++){ U[k] = U[k + 1]; NE[k] = NE[k + 1]; }
@@ -235,10 +237,10 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 
 	while(__any(i < tlen)){
 		const bool act = i < tlen;
-		if(mode == BSA_MODE_GLOBAL && (i & (uint32_t)(L - 1)) == 0u)
+		if(!STATIC && mode == BSA_MODE_GLOBAL && (i & (uint32_t)(L - 1)) == 0u)
 			rby_tab = (int)((1.0 * (double)(i + (uint32_t)jl) / (double)tlen) * (double)qlen);      // bsalign.h:4009, row i + jl
 		// ---- band offset of this row (bsalign.h:3932-3946)
-		{
+		if constexpr (!STATIC){
 			const bool moved = (mov != 0u) && (rbeg + BW < qlen);
 			const uint32_t room = qlen - (rbeg + BW);
 			mov = moved ? min(mov, room) : 0u;
@@ -250,7 +252,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		else if(PW < 2) rh = gapo1 + gape1 * (int)i;
 		else rh = max(gapo1 + gape1 * (int)i, gapo2 + gape2 * (int)i);
 		// ---- row_movx (bsalign.h:2244-2392): the row is held slid by one cell; correct what did not move that way
-		if(__any(act && mov != 1u)){
+		if(!STATIC && __any(act && mov != 1u)){
 			if(__any(act && mov >= (uint32_t)BW)){
 				// the band jumped past everything it held: zero rows, every ubegs = SCORE_MIN (bsalign.h:2253-2259);
 				// rh = H at the last cell of the previous row (getscore(bw - 1))
@@ -308,7 +310,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				}
 			}
 		}
-		if(mov != 0u && mov < (uint32_t)BW) rh = HB;              // getscore(mov - 1) of the previous row
+		if(!STATIC && mov != 0u && mov < (uint32_t)BW) rh = HB;   // getscore(mov - 1) of the previous row
 		// ---- sequences, S~(x, y)
 		uint32_t S[W];
 		{
@@ -419,6 +421,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			v = x_sub(h, uk);
 			if(CR == 2 && k == W / 2 - 1) vmid = v;
 			if(k == 0){ tmpU0 = un; tmpNE0 = ne; tmpNQ0 = nq; hfirst = h; }
+			else if constexpr (STATIC){ U[k] = un; NE[k] = ne; if constexpr (PW == 2) NQ2[k] = nq; }       // in place (U[k] was read above)
 			else { U[k - 1] = un; NE[k - 1] = ne; if constexpr (PW == 2) NQ2[k - 1] = nq; }
 		}
 		// ---- tail (bsalign.h:2618-2636): u of every block's first cell, ubegs of the new row, ubegs[0] re-based on cell 0
@@ -553,7 +556,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				int sc = HB + (hi ? x_hi16(Psh) : x_lo16(Psh)) + (int)b * W * GE;
 #pragma unroll
 				for(int k = 0; k < W; k++){
-					const uint32_t uu = (k == 0) ? tmpU0 : U[k - 1];
+					const uint32_t uu = (k == 0) ? tmpU0 : U[STATIC ? k : k - 1];
 					sc += ((uint32_t)k <= kk) ? ((hi ? x_hi8(uu) : x_lo8(uu)) + GE) : 0;
 				}
 				return sc;
@@ -586,7 +589,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					if constexpr (CR == 2) er->ubegs[b * CR + 1] = HB + (hf ? x_hi16(PM) : x_lo16(PM)) + (b * W + W / 2) * GE;
 #pragma unroll
 					for(int k = 0; k < W; k++){
-						const uint32_t uu = (k == 0) ? tmpU0 : U[k - 1];
+						const uint32_t uu = (k == 0) ? tmpU0 : U[STATIC ? k : k - 1];
 						ub[b * W + k] = (int8_t)((hf ? x_hi8(uu) : x_lo8(uu)) + GE);
 					}
 				}
@@ -594,7 +597,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			}
 		}
 		// ---- adaptive band (bsalign.h:3331-3349) + global steering (bsalign.h:4006-4021)
-		{
+		if constexpr (!STATIC){
 			uint32_t x;
 			{
 				if constexpr (CR == 1){
@@ -633,8 +636,9 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				if(rush) mov = 1u + (uint32_t)(qlen - (rbeg + BW)) / max(left, 1u);
 			} else mov = (uint32_t)rbx;
 		}
+		if constexpr (STATIC){ U[0] = tmpU0; NE[0] = tmpNE0; if constexpr (PW == 2) NQ2[0] = tmpNQ0; }
 		// ---- speculative slide by one cell: the first cell of every block becomes the last cell of the block before it
-		{
+		else {
 			const uint32_t nxt = XDPP(0, tmpU0, XROW_SHL(1), 0xf);          // (a DPP move must not sit in an arm of ?: -- only one arm runs)
 			const uint32_t inu = last ? __builtin_amdgcn_alignbit(NEWU0, bc0, 16) : nxt;
 			const uint32_t inne = x_shift_up<L>(tmpNE0, NEWNE, last);
@@ -661,6 +665,11 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x0(const Align8Args a){
 // two-piece gaps (bandwidth 128): 8 bits per band cell
 __global__ void __launch_bounds__(256) k_align8_fwd_x2(const Align8Args a){
 	x_forward<8, 8, 2>(a, a.first, a.count, blockIdx.x);
+}
+// bands that cover their whole queries (Align8Args::static_band): the row stays in place, no steering
+template<int W, int L, int PW>
+__global__ void __launch_bounds__(256) k_align8_fwd_x_static(const Align8Args a){
+	x_forward<W, L, PW, true>(a, a.first, a.count, blockIdx.x);
 }
 
 // Bandwidth 128, a batch that is not a whole number of four-lane rounds: the first nb8 blocks take the last n8 pairs
@@ -700,6 +709,16 @@ static bool x8_at_64(){ const char *e = getenv("BSA_ALIGN8_X_LANES"); return e &
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
 	const uint32_t b8 = (a.count + 31u) / 32u;
+	if(a.static_band && !getenv("BSA_ALIGN8_NO_STATIC")){
+		const uint32_t b4 = (a.count + 63u) / 64u;
+		if(pw == 2 && a.bw == 128u){ hipLaunchKernelGGL((k_align8_fwd_x_static<8, 8, 2>), dim3(b8), dim3(256), 0, st, a); return hipGetLastError(); }
+		if(pw == 1 && a.bw == 64u){ hipLaunchKernelGGL((k_align8_fwd_x_static<8, 4, 1>), dim3(b4), dim3(256), 0, st, a); return hipGetLastError(); }
+		if(pw == 1 && a.bw == 128u){ hipLaunchKernelGGL((k_align8_fwd_x_static<16, 4, 1>), dim3(b4), dim3(256), 0, st, a); return hipGetLastError(); }
+		if(pw == 1 && a.bw == 256u){ hipLaunchKernelGGL((k_align8_fwd_x_static<16, 8, 1>), dim3(b8), dim3(256), 0, st, a); return hipGetLastError(); }
+		if(pw == 0 && a.bw == 64u){ hipLaunchKernelGGL((k_align8_fwd_x_static<8, 4, 0>), dim3(b4), dim3(256), 0, st, a); return hipGetLastError(); }
+		if(pw == 0 && a.bw == 128u){ hipLaunchKernelGGL((k_align8_fwd_x_static<16, 4, 0>), dim3(b4), dim3(256), 0, st, a); return hipGetLastError(); }
+		if(pw == 0 && a.bw == 256u){ hipLaunchKernelGGL((k_align8_fwd_x_static<16, 8, 0>), dim3(b8), dim3(256), 0, st, a); return hipGetLastError(); }
+	}
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;
 		hipLaunchKernelGGL(k_align8_fwd_x2, dim3(b8), dim3(256), 0, st, a);

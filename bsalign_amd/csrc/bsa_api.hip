@@ -606,6 +606,7 @@ struct bsa_align_plan : PlanBase {
 	bool codes = false;                          // compact 4-bit-code traceback (global mode, bsa_align8_pk.hip CODES)
 	uint32_t max_bw = 0;
 	uint32_t ref_bw = 0;                         // a whole-query band widened to bw: the reference's own bandwidth (1 = per pair), see bsa_align_plan_create
+	bool static_band = false;                    // no query is longer than the band: it never moves
 	uint32_t qpad = 0, tpad = 16;
 };
 
@@ -663,6 +664,8 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	bsa_align_plan *p = new bsa_align_plan();
 	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
 	p->ref_bw = widened ? (bw_req ? bw_req : 1u) : 0u;
+	p->static_band = bw != 0 && n > 0;
+	for(size_t k = 0; k < n && p->static_band; k++) p->static_band = qlen[k] <= bw;
 	p->generic = (bw == 0) || !bsa_align8_supported_bw(bw);
 	p->max_bw = max_bw;
 	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)std::max(max_bw, 16u));
@@ -732,7 +735,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	memset(&a, 0, sizeof(a));
 	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
 	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
-	a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode; a.ref_bw = p->ref_bw;
+	a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode; a.ref_bw = p->ref_bw; a.static_band = p->static_band ? 1u : 0u;
 	a.gapo1 = p->par.gapo1; a.gape1 = p->par.gape1; a.gapo2 = p->par.gapo2; a.gape2 = p->par.gape2;
 	int smax = -127, smin = 127;
 	for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)p->par.matrix[i]); smin = std::min(smin, (int)p->par.matrix[i]); a.matrix[i] = p->par.matrix[i]; }

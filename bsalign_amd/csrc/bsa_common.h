@@ -27,6 +27,7 @@ struct Align8Args {
 	uint32_t first, count;      // processing positions [first, first+count) handled by this launch
 	uint32_t bw;                // effective bandwidth (multiple of 16), uniform over the chunk; 0 = per pair roundup(qlen, 16)
 	uint32_t rowb;              // bytes of one row group = 16 tiles (see the layout note below)
+	uint32_t static_band;       // every pair's band covers its whole query (qlen <= bw): the band never moves (k_align8_fwd_x_static)
 	uint32_t ref_bw;            // compact path, a whole-query band widened to `bw` (bsa_api.hip): the reference's own bandwidth (1 = per pair roundup(qlen, 16)); 0 = bw
 	int32_t  mode;
 	int32_t  gapo1, gape1, gapo2, gape2;
