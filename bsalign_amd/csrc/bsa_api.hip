@@ -192,11 +192,12 @@ static int ctx_ws_reserve(bsa_ctx *c, size_t bytes){
 // small utility kernels
 // ------------------------------------------------------------------------------------------------
 
-// stage one pair per block: copy query codes (padded with BSA_QPAD_CODE) and target bytes, validate codes
+// stage one pair per wave (a block per pair spent most of its time being launched on batches of short pairs): copy query codes
+// (padded with BSA_QPAD_CODE) and target bytes, validate codes
 __global__ void __launch_bounds__(256) k_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
 		const uint64_t *toff, const uint32_t *tlen, const uint64_t *qpoff, const uint64_t *tpoff,
 		uint8_t *qst, uint8_t *tst, uint32_t qpad, uint32_t tpad, uint32_t *status, uint32_t n){
-	const uint32_t k = blockIdx.x;
+	const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
 	if(k >= n) return;
 	const uint32_t ql = qlen[k], tl = tlen[k];
 	const uint8_t *q = seqs + qoff[k], *t = seqs + toff[k];
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(256) k_stage(const uint8_t *seqs, const uint64
 	// not aligned and ends with the sequence): whole pieces with two 8-byte loads, the piece that holds the end byte by byte
 	auto copy = [&](const uint8_t *src, uint8_t *dst, uint32_t len, uint32_t pad, uint8_t padcode){
 		const uint32_t total = (len + pad + 15u) & ~15u;
-		for(uint32_t i = threadIdx.x * 16u; i < total; i += 256u * 16u){
+		for(uint32_t i = lane * 16u; i < total; i += 64u * 16u){
 			uint64_t v0, v1;
 			if(i + 16u <= len){
 				__builtin_memcpy(&v0, src + i, 8); __builtin_memcpy(&v1, src + i + 8, 8);
@@ -227,9 +228,9 @@ __global__ void __launch_bounds__(256) k_stage(const uint8_t *seqs, const uint64
 	copy(q, dq, ql, qpad, (uint8_t)BSA_QPAD_CODE);
 	copy(t, dt, tl, tpad, (uint8_t)0);
 	uint32_t st = 0;
-	if(__syncthreads_or((int)bad)) st |= BSA_ST_BAD_BASE;
+	if(__any((int)bad)) st |= BSA_ST_BAD_BASE;
 	if(ql == 0 || tl == 0) st |= BSA_ST_EMPTY;
-	if(threadIdx.x == 0) status[k] = st;
+	if(lane == 0) status[k] = st;
 }
 
 // single-block exclusive scan of cnt[0..n) into off[0..n], off[n] = total; *carry (optional) is a running base
@@ -264,6 +265,69 @@ __global__ void __launch_bounds__(1024) k_excl_scan(const uint32_t *cnt, uint64_
 		__syncthreads();
 	}
 	if(t == 0){ off[n] = base; if(carry) *carry = base; }
+}
+
+// The same scan over many blocks for batches of millions of pairs (one block reads 4 bytes per pair at the speed of one CU: 2 ms
+// for 2 M pairs, twice per step): sums of tiles of SCAN_TILE counts, a scan of the sums by one block, then every tile scanned with
+// its base.  tmp: (tiles + 1) uint64.
+#define SCAN_TILE 4096u
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *cnt, uint32_t n, uint64_t *tmp){
+	__shared__ uint64_t red[4];
+	const uint32_t b = blockIdx.x, t = threadIdx.x;
+	uint64_t s = 0;
+	for(uint32_t i = t; i < SCAN_TILE; i += 256u){ const uint32_t idx = b * SCAN_TILE + i; s += (idx < n) ? cnt[idx] : 0u; }
+	for(int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
+	if((t & 63u) == 0u) red[t >> 6] = s;
+	__syncthreads();
+	if(t == 0) tmp[b] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(1024) k_scan_tile_bases(uint64_t *tmp, uint32_t tiles, uint64_t *carry){
+	__shared__ uint64_t part[1024];
+	__shared__ uint64_t base;
+	const uint32_t t = threadIdx.x;
+	if(t == 0) base = carry ? *carry : 0ull;
+	__syncthreads();
+	for(uint32_t s = 0; s < tiles; s += 1024u){
+		const uint64_t v = (s + t < tiles) ? tmp[s + t] : 0ull;
+		part[t] = v;
+		__syncthreads();
+		for(uint32_t d = 1; d < 1024; d <<= 1){
+			const uint64_t w = (t >= d) ? part[t - d] : 0ull;
+			__syncthreads();
+			part[t] += w;
+			__syncthreads();
+		}
+		if(s + t < tiles) tmp[s + t] = part[t] - v + base;
+		__syncthreads();
+		if(t == 1023) base += part[1023];
+		__syncthreads();
+	}
+	if(t == 0){ tmp[tiles] = base; if(carry) *carry = base; }
+}
+__global__ void __launch_bounds__(256) k_scan_tile_apply(const uint32_t *cnt, uint64_t *off, uint32_t n, const uint64_t *tmp, uint32_t tiles){
+	__shared__ uint64_t wsum[4];
+	const uint32_t b = blockIdx.x, t = threadIdx.x;
+	const uint32_t i0 = b * SCAN_TILE + t * 16u;            // 16 consecutive counts per thread
+	uint32_t loc[16]; uint64_t s = 0;
+	for(int k = 0; k < 16; k++){ const uint32_t idx = i0 + k; loc[k] = (uint32_t)s; s += (idx < n) ? cnt[idx] : 0u; }
+	uint64_t inc = s;                                       // inclusive scan of the thread sums inside the wave, then across the four waves
+	for(int d = 1; d < 64; d <<= 1){ const uint64_t v = __shfl_up(inc, d); if((t & 63u) >= (uint32_t)d) inc += v; }
+	if((t & 63u) == 63u) wsum[t >> 6] = inc;
+	__syncthreads();
+	uint64_t wb = 0;
+	for(uint32_t w = 0; w < (t >> 6); w++) wb += wsum[w];
+	const uint64_t excl = tmp[b] + wb + inc - s;
+	for(int k = 0; k < 16; k++){ const uint32_t idx = i0 + k; if(idx < n) off[idx] = excl + loc[k]; }
+	if(b == tiles - 1u && t == 0) off[n] = tmp[tiles];
+}
+
+static hipError_t launch_excl_scan(hipStream_t st, const uint32_t *cnt, uint64_t *off, uint32_t n, uint64_t *carry, uint64_t *tmp){
+	if(n <= 262144u || !tmp){ hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, cnt, off, n, carry); return hipGetLastError(); }
+	const uint32_t tiles = (n + SCAN_TILE - 1u) / SCAN_TILE;
+	hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(256), 0, st, cnt, n, tmp);
+	hipLaunchKernelGGL(k_scan_tile_bases, dim3(1), dim3(1024), 0, st, tmp, tiles, carry);
+	hipLaunchKernelGGL(k_scan_tile_apply, dim3(tiles), dim3(256), 0, st, cnt, off, n, (const uint64_t*)tmp, tiles);
+	return hipGetLastError();
 }
 
 // one wave per pair: copy the CIGAR words a traceback kernel left at the tail of the pair's row slot
@@ -320,7 +384,7 @@ struct PlanBase {
 	uint32_t *d_qlen = nullptr, *d_tlen = nullptr, *d_order = nullptr;
 	uint8_t *d_qst = nullptr, *d_tst = nullptr;
 	uint32_t *d_cnt_pos = nullptr, *d_cnt_pair = nullptr, *d_status_own = nullptr;
-	uint64_t *d_off_pos = nullptr, *d_src_pair = nullptr, *d_carry = nullptr;
+	uint64_t *d_off_pos = nullptr, *d_src_pair = nullptr, *d_carry = nullptr, *d_scan_tmp = nullptr;
 	uint32_t *d_tmp = nullptr; size_t tmp_words = 0;
 	void *pool = nullptr;           // one allocation behind all the metadata pointers above (plan_common_alloc)
 	bool pool_kept = false;         // ... which is the context's kept buffer (ctx_buf_get)
@@ -461,6 +525,7 @@ static int plan_common_alloc(PlanBase *p, const uint64_t *qoff, const uint32_t *
 		{(void**)&p->d_qst, nullptr, std::max<size_t>(qst_bytes, 1), 0}, {(void**)&p->d_tst, nullptr, std::max<size_t>(tst_bytes, 1), 0},
 		{(void**)&p->d_cnt_pos, nullptr, m * 4, 0}, {(void**)&p->d_cnt_pair, nullptr, m * 4, 0}, {(void**)&p->d_status_own, nullptr, m * 4, 0},
 		{(void**)&p->d_off_pos, nullptr, (m + 1) * 8, 0}, {(void**)&p->d_src_pair, nullptr, m * 8, 0}, {(void**)&p->d_carry, nullptr, 8, 0},
+		{(void**)&p->d_scan_tmp, nullptr, (m / SCAN_TILE + 2) * 8, 0},
 	};
 	size_t total = 0, upload = 0;
 	for(Part &q : parts){ q.off = total; total += (std::max<size_t>(q.bytes, 8) + 255) & ~(size_t)255; if(q.src) upload = total; }
@@ -507,8 +572,7 @@ static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t ci
 		rc = trace(ch, half, stt); if(rc != BSA_OK) return rc;
 		HIPCHK(c, hipEventRecord(t1, stt));
 		if(want_cig){
-			hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, stt, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry);
-			HIPCHK(c, hipGetLastError());
+			HIPCHK(c, launch_excl_scan(stt, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry, p->d_scan_tmp));
 			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, stt, half, p->d_slot_end,
 				ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
 			HIPCHK(c, hipGetLastError());
@@ -526,8 +590,7 @@ static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t ci
 	if(want_cig){
 		hipLaunchKernelGGL(k_cnt_by_pair, dim3((n + 255) / 256), dim3(256), 0, sf, p->d_order, p->d_cnt_pos, p->d_off_pos, p->d_cnt_pair, p->d_src_pair, n);
 		HIPCHK(c, hipGetLastError());
-		hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, sf, p->d_cnt_pair, d_cigar_off, n, (uint64_t*)nullptr);
-		HIPCHK(c, hipGetLastError());
+		HIPCHK(c, launch_excl_scan(sf, p->d_cnt_pair, d_cigar_off, n, (uint64_t*)nullptr, p->d_scan_tmp));
 		hipLaunchKernelGGL(k_cigar_final, dim3((n + 3) / 4), dim3(256), 0, sf, p->d_tmp, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
 		HIPCHK(c, hipGetLastError());
 	} else if(d_cigar_off){
@@ -728,7 +791,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	}
 	if(!d_seqs) return BSA_E_ARG;
 	uint32_t *status = d_status ? d_status : p->d_status_own;
-	hipLaunchKernelGGL(k_stage, dim3(n), dim3(256), 0, st, d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen,
+	hipLaunchKernelGGL(k_stage, dim3((n + 3u) / 4u), dim3(256), 0, st, d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen,
 		p->d_qpoff, p->d_tpoff, p->d_qst, p->d_tst, p->qpad, p->tpad, status, n);
 	HIPCHK(c, hipGetLastError());
 	Align8Args a;
