@@ -340,3 +340,33 @@ def test_mixed_whole_query_batch_runs_one_sub_batch_per_width_class(ctx, bw):
     assert rc == -5 and coff[n] > 8
     full_out, full_cigs, _ = ctx.align_batch(pairs, par)
     assert int(coff[n]) == sum(len(c) for c in full_cigs)
+
+
+def test_many_short_pairs_take_the_multi_block_scan(ctx):
+    """more than 262144 pairs per batch: the exclusive scans of the CIGAR compaction run over many blocks (k_scan_tile_*) and the
+    staging kernel handles a pair per wave -- the batch as a whole gives what its thirds give on their own (single-block scan),
+    and a sample equals the oracle"""
+    import bsalign_amd as B
+    rng = np.random.default_rng(31337)
+    n = 300000
+    lens = rng.integers(20, 61, size=n)
+    pairs = []
+    for k in range(n):
+        T = rng.integers(0, 4, size=int(lens[k])).astype(np.uint8)
+        Q = T.copy()
+        if k % 3:
+            Q[int(rng.integers(len(Q)))] ^= 1
+        if k % 5 == 0 and len(Q) > 25:
+            Q = np.delete(Q, int(rng.integers(5, 20)))
+        pairs.append((Q, T))
+    par = B.make_params(S.MODE_GLOBAL, 0, *SCORINGS["affine"])
+    out, cigs, st = ctx.align_batch(pairs, par)
+    assert not st.any()
+    for lo in range(0, n, 100000):
+        o2, c2, s2 = ctx.align_batch(pairs[lo:lo + 100000], par)
+        assert np.array_equal(out[lo:lo + 100000], o2)
+        assert all(np.array_equal(a, b) for a, b in zip(cigs[lo:lo + 100000], c2))
+    for k in rng.integers(0, n, size=300):
+        res, cig, m = S.oracle_align(pairs[k][0], pairs[k][1], S.MODE_GLOBAL, 0, *SCORINGS["affine"])
+        got = np.array([out[k][f] for f in out.dtype.names], dtype=np.int32)
+        assert np.array_equal(got, res) and np.array_equal(cigs[k], cig), k
