@@ -192,12 +192,13 @@ static int ctx_ws_reserve(bsa_ctx *c, size_t bytes){
 // small utility kernels
 // ------------------------------------------------------------------------------------------------
 
-// stage one pair per wave (a block per pair spent most of its time being launched on batches of short pairs): copy query codes
-// (padded with BSA_QPAD_CODE) and target bytes, validate codes
+// stage one pair per TPP threads -- a wave for short pairs (a block per pair spent most of its time being launched), the whole block
+// for long ones: copy query codes (padded with BSA_QPAD_CODE) and target bytes, validate codes
+template<int TPP>
 __global__ void __launch_bounds__(256) k_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
 		const uint64_t *toff, const uint32_t *tlen, const uint64_t *qpoff, const uint64_t *tpoff,
 		uint8_t *qst, uint8_t *tst, uint32_t qpad, uint32_t tpad, uint32_t *status, uint32_t n){
-	const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	const uint32_t k = (TPP == 64) ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x, lane = threadIdx.x & (uint32_t)(TPP - 1);
 	if(k >= n) return;
 	const uint32_t ql = qlen[k], tl = tlen[k];
 	const uint8_t *q = seqs + qoff[k], *t = seqs + toff[k];
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(256) k_stage(const uint8_t *seqs, const uint64
 	// not aligned and ends with the sequence): whole pieces with two 8-byte loads, the piece that holds the end byte by byte
 	auto copy = [&](const uint8_t *src, uint8_t *dst, uint32_t len, uint32_t pad, uint8_t padcode){
 		const uint32_t total = (len + pad + 15u) & ~15u;
-		for(uint32_t i = lane * 16u; i < total; i += 64u * 16u){
+		for(uint32_t i = lane * 16u; i < total; i += (uint32_t)TPP * 16u){
 			uint64_t v0, v1;
 			if(i + 16u <= len){
 				__builtin_memcpy(&v0, src + i, 8); __builtin_memcpy(&v1, src + i + 8, 8);
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(256) k_stage(const uint8_t *seqs, const uint64
 	copy(q, dq, ql, qpad, (uint8_t)BSA_QPAD_CODE);
 	copy(t, dt, tl, tpad, (uint8_t)0);
 	uint32_t st = 0;
-	if(__any((int)bad)) st |= BSA_ST_BAD_BASE;
+	if((TPP == 64) ? __any((int)bad) : __syncthreads_or((int)bad)) st |= BSA_ST_BAD_BASE;
 	if(ql == 0 || tl == 0) st |= BSA_ST_EMPTY;
 	if(lane == 0) status[k] = st;
 }
@@ -670,6 +671,7 @@ struct bsa_align_plan : PlanBase {
 	uint32_t max_bw = 0;
 	uint32_t ref_bw = 0;                         // a whole-query band widened to bw: the reference's own bandwidth (1 = per pair), see bsa_align_plan_create
 	bool static_band = false;                    // no query is longer than the band: it never moves
+	size_t stage_bytes = 0;                      // staged bytes of all pairs (which staging kernel)
 	uint32_t qpad = 0, tpad = 16;
 };
 
@@ -769,6 +771,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	for(size_t pos = 0; pos < n; pos++)
 		need[pos] = p->codes ? bsa_code_slot_bytes(tlen[order[pos]], bw / 16u, p->pw) : bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
 	p->cells = cells;
+	p->stage_bytes = qacc + tacc;
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
 	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
 	if(rc != BSA_OK){ plan_free(p); return rc; }
@@ -791,8 +794,12 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	}
 	if(!d_seqs) return BSA_E_ARG;
 	uint32_t *status = d_status ? d_status : p->d_status_own;
-	hipLaunchKernelGGL(k_stage, dim3((n + 3u) / 4u), dim3(256), 0, st, d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen,
-		p->d_qpoff, p->d_tpoff, p->d_qst, p->d_tst, p->qpad, p->tpad, status, n);
+	if(p->stage_bytes / std::max<size_t>(n, 1) >= 8192)         // long pairs: a block per pair
+		hipLaunchKernelGGL(k_stage<256>, dim3(n), dim3(256), 0, st, d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen,
+			p->d_qpoff, p->d_tpoff, p->d_qst, p->d_tst, p->qpad, p->tpad, status, n);
+	else
+		hipLaunchKernelGGL(k_stage<64>, dim3((n + 3u) / 4u), dim3(256), 0, st, d_seqs, p->d_qoff, p->d_qlen, p->d_toff, p->d_tlen,
+			p->d_qpoff, p->d_tpoff, p->d_qst, p->d_tst, p->qpad, p->tpad, status, n);
 	HIPCHK(c, hipGetLastError());
 	Align8Args a;
 	memset(&a, 0, sizeof(a));
