@@ -1188,10 +1188,12 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 
 // stage one pair per block: query -> two bit planes (bit p of plane b = bit b of base p; zero beyond qlen),
 // query and target bytes copied (the traceback compares bases), codes validated
+// (TPP threads per pair: the block for few long pairs, a wave for batches of many -- the k-mer path stages 1.5 M pieces of ~26 bp)
+template<int TPP>
 __global__ void __launch_bounds__(256) k_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
 		const uint64_t *toff, const uint32_t *tlen, const uint64_t *qpoff, const uint64_t *tpoff,
 		const uint64_t *qboff, const uint32_t *qwords, uint8_t *qst, uint8_t *tst, u64 *qbits, uint32_t *status, uint32_t n){
-	const uint32_t k = blockIdx.x;
+	const uint32_t k = (TPP == 64) ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x, lane = threadIdx.x & (uint32_t)(TPP - 1);
 	if(k >= n) return;
 	const uint32_t ql = qlen[k], tl = tlen[k], nw = qwords[k];
 	const uint8_t *q = seqs + qoff[k], *t = seqs + toff[k];
@@ -1216,7 +1218,7 @@ __global__ void __launch_bounds__(256) k_edit_stage(const uint8_t *seqs, const u
 	};
 	auto gather = [](u64 v) -> uint32_t { return (uint32_t)(((v & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); };   // bit 0 of byte j -> bit j
 	const uint32_t qbytes = (ql + 16u + 15u) & ~15u, qplane = nw * 64u;
-	for(uint32_t i = threadIdx.x * 16u; i < max(qbytes, qplane); i += 256u * 16u){
+	for(uint32_t i = lane * 16u; i < max(qbytes, qplane); i += (uint32_t)TPP * 16u){
 		u64 v0, v1;
 		piece(q, ql, i, v0, v1);
 		if(i < qbytes){ uint4 o; o.x = (uint32_t)v0; o.y = (uint32_t)(v0 >> 32); o.z = (uint32_t)v1; o.w = (uint32_t)(v1 >> 32); *(uint4*)(dq + i) = o; }
@@ -1226,15 +1228,15 @@ __global__ void __launch_bounds__(256) k_edit_stage(const uint8_t *seqs, const u
 		}
 	}
 	const uint32_t tbytes = (tl + 16u + 15u) & ~15u;
-	for(uint32_t i = threadIdx.x * 16u; i < tbytes; i += 256u * 16u){
+	for(uint32_t i = lane * 16u; i < tbytes; i += (uint32_t)TPP * 16u){
 		u64 v0, v1;
 		piece(t, tl, i, v0, v1);
 		uint4 o; o.x = (uint32_t)v0; o.y = (uint32_t)(v0 >> 32); o.z = (uint32_t)v1; o.w = (uint32_t)(v1 >> 32); *(uint4*)(dt + i) = o;
 	}
 	uint32_t st = 0;
-	if(__syncthreads_or((int)bad)) st |= BSA_ST_BAD_BASE;
+	if((TPP == 64) ? __any((int)bad) : __syncthreads_or((int)bad)) st |= BSA_ST_BAD_BASE;
 	if(ql == 0 || tl == 0) st |= BSA_ST_EMPTY;
-	if(threadIdx.x == 0) status[k] = st;
+	if(lane == 0) status[k] = st;
 }
 
 bool bsa_edit_supported_bw(uint32_t bw){       // register kernels up to 16 words, the generic kernel beyond
@@ -1245,7 +1247,8 @@ hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, cons
 		const uint64_t *qpoff, const uint64_t *tpoff, const uint64_t *qboff, const uint32_t *qwords,
 		uint8_t *qst, uint8_t *tst, uint64_t *qbits, uint32_t *status, uint32_t n, hipStream_t st){
 	if(n == 0) return hipSuccess;
-	hipLaunchKernelGGL(k_edit_stage, dim3(n), dim3(256), 0, st, seqs, qoff, qlen, toff, tlen, qpoff, tpoff, qboff, qwords, qst, tst, (u64*)qbits, status, n);
+	if(n >= 65536u) hipLaunchKernelGGL(k_edit_stage<64>, dim3((n + 3u) / 4u), dim3(256), 0, st, seqs, qoff, qlen, toff, tlen, qpoff, tpoff, qboff, qwords, qst, tst, (u64*)qbits, status, n);
+	else hipLaunchKernelGGL(k_edit_stage<256>, dim3(n), dim3(256), 0, st, seqs, qoff, qlen, toff, tlen, qpoff, tpoff, qboff, qwords, qst, tst, (u64*)qbits, status, n);
 	return hipGetLastError();
 }
 
