@@ -111,7 +111,13 @@ void        bsa_set_score_matrix(int8_t matrix[16], int8_t mat, int8_t mis);   /
  * bsa_align_batch      : every pointer is HOST memory (copies in, runs, copies out, synchronises).
  * bsa_align_plan_*     : two-phase form for resident data -- the plan takes the HOST metadata
  *                        (offsets, lengths) once; bsa_align_run takes DEVICE pointers for the
- *                        sequence blob and all outputs and is asynchronous on the context stream. */
+ *                        sequence blob and all outputs and is asynchronous on the context stream.
+ *
+ * Whole-query bands (bandwidth 0, the reference CLI's default, or a bandwidth no shorter than any query): a plan
+ * runs at ONE kernel width; when no query of the plan is longer than 256 bases it runs at 64 / 128 / 256 columns on
+ * the fast path (same results as the reference's own width), otherwise on the slower run-time-width kernel.
+ * bsa_align_batch groups the pairs of a mixed batch by width class itself; with bsa_align_plan_* group short and long
+ * queries into separate plans. */
 int bsa_align_batch(bsa_ctx_t *ctx, const uint8_t *seqs, size_t seqs_bytes,
                     const uint64_t *qoff, const uint32_t *qlen,
                     const uint64_t *toff, const uint32_t *tlen, size_t n,
