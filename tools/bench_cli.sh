@@ -21,6 +21,9 @@ REF=oracle/_ref/bsalign_ref_cli; HIP=bsalign_amd/bsalign-hip
 echo "== 100000 pairs x 150 bp, global, whole-query band (the CLI default)"
 t $HIP align -m global $D/short.fa
 [ -x $REF ] && t $REF align -m global $D/short.fa
+echo "== the same pairs with no option at all (overlap mode, whole-query band: main.c:262-266)"
+t $HIP align $D/short.fa
+[ -x $REF ] && t $REF align $D/short.fa
 head -c 3100000 $D/short.fa > $D/short_10k.fa
 t $HIP align -m global -B 1 $D/short_10k.fa
 echo "== 2000 pairs x 10 kbp, global, -W 128"
