@@ -211,9 +211,11 @@ static void queue_flush(queue_t *Q, bsa_ctx_t *ctx, const opts_t *o, u4v *cigars
 		seqalign_result_t rs;
 		uint64_t w;
 		if(status[k] & BSA_ST_TRACE){
+			/* the reference's own traceback does not terminate (or crashes) on this pair: say so and go on with the next one */
 			fflush(stdout);
-			fprintf(stderr, " -- %s / %s: traceback left the band (the reference does not terminate on this input) -- %s:%d --\n", Q->qtag[k], Q->ttag[k], __FILE__, __LINE__);
-			exit(1);
+			fprintf(stderr, " -- %s / %s: no alignment -- the traceback leaves the band (the reference does not terminate on this input) -- %s:%d --\n", Q->qtag[k], Q->ttag[k], __FILE__, __LINE__);
+			free(Q->qtag[k]); free(Q->ttag[k]);
+			continue;
 		}
 		memcpy(&rs, &out[k], sizeof(rs));
 		clear_u4v(cigars);
