@@ -229,6 +229,13 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	if(tlen != 0u && first) begs[0] = 0;
 	uint64_t twin = 0;
 	if(tlen) __builtin_memcpy(&twin, tp, 8);
+	// STATIC: the band never moves, so a lane's query codes are the same on every row -- loaded once
+	uint32_t sqlo[STATIC ? NQ : 1], sqhi[STATIC ? NQ : 1];
+	if constexpr (STATIC){
+#pragma unroll
+		for(int n = 0; n < NQ; n++){ sqlo[n] = 0x04040404u; sqhi[n] = 0x04040404u; }
+		if(tlen){ x_load_qcodes<W>(qp + jl * W, sqlo); x_load_qcodes<W>(qp + (jl + L) * W, sqhi); }
+	}
 	const int rbz = 2 * max((int)(tlen / max(qlen, 1u)), 1);          // bsalign.h:4008
 	const bool rush32 = (unsigned long long)(uint32_t)rbz * tlen + qlen + (uint32_t)BW + (uint32_t)rbz < 0xFFFFFFFFull;
 	int rby_tab = 0;
@@ -316,7 +323,10 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		{
 			const int tb = (int)((twin >> (8u * (i & 7u))) & 3u);
 			uint32_t qlo[NQ], qhi[NQ];
-			if(act){ x_load_qcodes<W>(qp + rbeg + jl * W, qlo); x_load_qcodes<W>(qp + rbeg + (jl + L) * W, qhi); }
+			if constexpr (STATIC){
+#pragma unroll
+				for(int n = 0; n < NQ; n++){ qlo[n] = act ? sqlo[n] : 0x04040404u; qhi[n] = act ? sqhi[n] : 0x04040404u; }
+			} else if(act){ x_load_qcodes<W>(qp + rbeg + jl * W, qlo); x_load_qcodes<W>(qp + rbeg + (jl + L) * W, qhi); }
 			else {
 #pragma unroll
 				for(int n = 0; n < NQ; n++){ qlo[n] = 0x04040404u; qhi[n] = 0x04040404u; }
@@ -668,7 +678,7 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x2(const Align8Args a){
 }
 // bands that cover their whole queries (Align8Args::static_band): the row stays in place, no steering
 template<int W, int L, int PW>
-__global__ void __launch_bounds__(256) k_align8_fwd_x_static(const Align8Args a){
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_x_static(const Align8Args a){
 	x_forward<W, L, PW, true>(a, a.first, a.count, blockIdx.x);
 }
 
