@@ -4,3 +4,10 @@ for shape in "--pairs 1000000 --length 1000" "--pairs 400000 --length 2500" "--p
   echo "== $shape"
   for w in 0 1; do echo -n "wave=$w: "; BSA_ALIGN8_TRACE_WAVE=$w run $shape; done
 done
+# whole-query bands of short reads (the reference CLI's default -W 0): widened dispatch + static-band kernels against the run-time-width kernel
+for shape in "--pairs 2000000 --length 150 --bw -1" "--pairs 2000000 --length 100 --bw -1" "--pairs 4000000 --length 50 --bw -1"; do
+  echo "== $shape"
+  echo -n "default:           "; run $shape
+  echo -n "moving-band kernel: "; BSA_ALIGN8_NO_STATIC=1 run $shape
+  echo -n "run-time width:     "; BSA_ALIGN8_WIDEN=0 run $shape
+done
