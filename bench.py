@@ -44,7 +44,72 @@ def parse():
     ap.add_argument("--poa-source", default="synthetic", choices=["synthetic", "recorded"], help="poa workload: synthetic sweep programs (poa_synth) or "
                     "programs recorded from the reference's end_bspoa on synthetic reads (needs oracle/_ref)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, count them over the process group and print {n_gpus}: "
+                    "the launcher's own test (gloo when there is no GPU)")
     return ap.parse_args()
+
+
+def ensure_ranks(args):
+    """`--gpus N` is a promise about the number of ranks.  Started by torch.distributed.run (WORLD_SIZE set) the world
+    size must equal N; started plainly with N > 1 this process replaces itself by that launcher, one rank per GPU,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    ws = os.environ.get("WORLD_SIZE", "")
+    if ws:
+        if int(ws) != args.gpus:
+            sys.exit("bench.py: --gpus %d but the launcher started %s ranks" % (args.gpus, ws))
+        return
+    if args.gpus <= 1 or args.cpu_worker:
+        return
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def init_ranks(args):
+    """-> (rank, world, local, dist or None); the process group is RCCL (backend "nccl") on a GPU box, gloo without one
+    (launch check only).  The number of ranks the group itself counts is what the JSON line reports as n_gpus."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    have_gpu = torch.cuda.is_available()
+    if have_gpu:
+        if local >= torch.cuda.device_count():
+            sys.exit("bench.py: rank %d has no GPU (%d visible)" % (local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+    if world <= 1:
+        return rank, 1, local, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if have_gpu:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo")
+    one = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local) if have_gpu else "cpu")
+    dist.all_reduce(one)
+    seen = int(one.item())
+    if seen != args.gpus:
+        sys.exit("bench.py: --gpus %d but the process group counts %d ranks" % (args.gpus, seen))
+    return rank, seen, local, dist
+
+
+def launch_check(args):
+    rank, world, local, dist = init_ranks(args)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": dist.get_backend() if dist is not None else None}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def _cpu_sample(args, L, bw, sc, mode, npairs, first_pair, kind):
@@ -356,16 +421,7 @@ def main_poa(args):
     import torch
     import bsalign_amd as B
     from bsalign_amd import poa_synth as PS
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch.cuda.set_device(local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rank, world, local, dist = init_ranks(args)
     dev = torch.device("cuda", local)
     nwin = args.pairs or 16384                                 # 4 programs per wave: 4096 waves = 4 per SIMD
     npos = args.length or 10000
@@ -502,22 +558,14 @@ def main():
     args = parse()
     if args.cpu_worker:
         return cpu_worker(args)
+    ensure_ranks(args)
+    if args.launch_check:
+        return launch_check(args)
     if args.workload == "poa":
         return main_poa(args)
     import torch
     import bsalign_amd as B
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist = None
-        torch.cuda.set_device(local)
+    rank, world, local, dist = init_ranks(args)
     dev = torch.device("cuda", local)
     sc = tuple(int(x) for x in args.scoring.split(","))
     mode = {"global": B.MODE_GLOBAL, "overlap": B.MODE_OVERLAP, "extend": B.MODE_EXTEND}[args.mode]
