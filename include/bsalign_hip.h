@@ -252,6 +252,79 @@ typedef struct {
 int bsa_sweep_run(bsa_ctx_t *ctx, uint8_t *d_rows, const bsa_row_task_t *d_tasks, const bsa_sweep_prog_t *d_progs,
                   size_t nprogs, const uint8_t *d_queries, const uint64_t *d_qoff, const uint32_t *d_qlen,
                   const bsa_sweep_params_t *par, bsa_sweep_result_t *d_results);
+/* ---- the per-read seq->graph DP as an anti-diagonal wavefront with the traceback on the device (P5 + P6) --------------------
+ * Second form of the sweep (align_rd_bspoacore bspoa.h:2515-2618) that also replaces alignment2graph_bspoa's walk
+ * (bspoa.h:2274-2513): the row blocks never leave the device, what comes back per read is the best end cell and the list
+ * of traceback steps.  The band offset of every node is fixed before the sweep (prepare_rd_align_bspoa, bspoa.h:2168-2174),
+ * so -- unlike the pairwise DP, whose band moves with the scores -- the dependencies between rows are known up front: one
+ * wave runs one read, lane l owns node i (nodes in the order the reference completes them), walks its row cell by cell and
+ * trails the rows it depends on by movx + 1 cells; rows of the nodes in flight live in an LDS ring, finished rows are
+ * drained to HBM in 4-byte cells (H relative to the row's first cell, e, q) for the traceback.  Scores are absolute
+ * integers: inside bsa_poa_graph_supported()'s guard none of the reference's int8 operations saturates, and the rows
+ * equal the reference's block for block (tests/test_poa_graph_gpu.py through bsa_poa_graph_host's rows_out).
+ *
+ * A program = the selected sub-graph of one read:
+ *   nodes   in completion order (node 0 = the head; every input of a node has a lower index).  A node carries two views:
+ *           FORWARD: at most two inputs in[0..1]; an input is the row of node `src` moved by movx = rpos - rpos(src) and
+ *           extended by one DP row (dpalign_row_update_bspoa, bspoa.h:2232), or -- kind MERGE -- the finished row of a
+ *           PARTIAL node at the same rpos taken as it is (dpalign_row_merge_bspoa, bspoa.h:2263: the cell-wise maximum).
+ *           A graph node with more than two selected in-edges is preceded by partial nodes (gnode = 0xFFFFFFFF) that
+ *           fold its first in-edges, two at a time.
+ *           TRACEBACK: its selected in-edges in the order of the reference's erev list with their coverage (edges[]).
+ *   cands   the places where the reference samples an end-of-alignment score, in its visiting order (bspoa.h:2549-2603)
+ * include/bsalign_poa_adapter.h builds programs from the reference's own graph. */
+#define BSA_POA_IN_PRESENT 0x80000000u
+#define BSA_POA_IN_MERGE   0x40000000u
+#define BSA_POA_IN_SAME    0x20000000u   /* v->base == u->base: the profile without the homopolymer bonus (bspoa.h:2588) */
+#define BSA_POA_IN_TOFF    0x0FFFFFFFu   /* v->mpos when the reference took the edge (left-boundary score, bspoa.h:2246-2248) */
+typedef struct { uint32_t src, movx, toff_kind; } bsa_poa_input_t;
+typedef struct {
+	uint32_t rpos;                /* u->rpos */
+	uint32_t gnode;               /* index of the node in the caller's graph; 0xFFFFFFFF for a partial node */
+	uint32_t first_in;            /* traceback view: first in-edge record, relative to the program's edges */
+	uint16_t n_in;
+	uint8_t  base;                /* u->base (0..3; 4 = HEAD / TAIL sentinel) */
+	uint8_t  flags;               /* bit 0: u->bonus */
+	bsa_poa_input_t in[2];        /* forward view */
+	uint32_t reserved[2];
+} bsa_poa_node_t;                 /* 48 bytes */
+typedef struct { uint32_t src, cov, src_rpos, reserved; } bsa_poa_edge_t;     /* local index of the predecessor, e->cov */
+typedef struct { uint32_t node, kind; } bsa_poa_cand_t;                       /* kind 0: edge node -> tail, 1: node complete and its band reaches the read end */
+typedef struct { uint32_t node; int32_t x; uint32_t bt; } bsa_poa_event_t;    /* one step of alignment2graph_bspoa: bt 0 M, 1 I, 2 D, 4 D2 (bsalign.h:40-50) */
+typedef struct {
+	uint32_t first_node, nnodes, first_edge, nedges, first_cand, ncands;
+	uint32_t slen;                /* g->slen */
+	uint32_t event_cap;           /* room for this program's events */
+	uint64_t query_off;           /* its read (one base per byte, g->qseq + g->qb) inside the query blob */
+	uint64_t first_event;
+} bsa_poa_prog_t;                 /* 48 bytes */
+#define BSA_POA_ST_OK     0
+#define BSA_POA_ST_TRACE  1       /* the walk left the stored band / found no predecessor: the reference reads outside its rows or does not terminate there */
+#define BSA_POA_ST_EVENTS 2       /* event_cap too small */
+#define BSA_POA_ST_NOCAND 3       /* no end-of-alignment candidate (the reference would start its walk at node -1) */
+typedef struct {
+	int32_t maxscr, maxidx, maxoff;   /* g->maxscr, LOCAL index of g->maxidx, g->maxoff */
+	int32_t status;                   /* BSA_POA_ST_* */
+	int32_t nevents;
+	int32_t fin_node, fin_x;          /* where the walk stopped: rs.tb = cpos of that node, rs.qb = fin_x (bspoa.h:2307-2311) */
+	int32_t reserved;
+} bsa_poa_result_t;
+typedef struct { int32_t h; int8_t e, q; uint16_t tag; } bsa_poa_cell_t;      /* a row cell as rows_out returns it: absolute H, e = E - H, q = Q - H */
+/* lanes a read of `max_slen` bases can use at this parameter set (a power of two up to 64), 0 = not supported: bandwidth above 256,
+ * scores outside the exactness guard, or a read too long for the LDS.  Callers fall back to bsa_sweep_* then. */
+int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen);
+/* all pointers DEVICE memory, asynchronous on the context stream.  d_rows: (total nodes) x bw uint32 cells, d_u0: total nodes int32
+ * (scratch the traceback reads; pass NULL for both to use the context's own buffer). */
+int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, size_t nnodes, const bsa_poa_edge_t *d_edges, const bsa_poa_cand_t *d_cands,
+                      const bsa_poa_prog_t *d_progs, size_t nprogs, const uint8_t *d_queries, uint32_t max_slen, const bsa_sweep_params_t *par,
+                      bsa_poa_result_t *d_results, bsa_poa_event_t *d_events, uint32_t *d_rows, int32_t *d_u0);
+/* HOST buffers in and out (uploads, runs, downloads, synchronises).  rows_out / u0_out (optional, tests): every node's row as
+ * absolute cells, nnodes x bw, and its ubegs[0]. */
+int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, size_t nnodes, const bsa_poa_edge_t *edges, size_t nedges,
+                       const bsa_poa_cand_t *cands, size_t ncands, const bsa_poa_prog_t *progs, size_t nprogs,
+                       const uint8_t *queries, size_t query_bytes, const bsa_sweep_params_t *par,
+                       bsa_poa_result_t *results, bsa_poa_event_t *events, size_t events_cap, bsa_poa_cell_t *rows_out, int32_t *u0_out);
+
 /* ---- batch scatter, host side (bsalign_amd/csrc/bsa_shard.cpp) ----------------
  * The pairs of one rank's contiguous range packed into the blob that travels to it: target k, then query k, each
  * padded to 16 bytes.  bsa_shard_pack fills out[0 .. bsa_shard_bytes) and every pair's offsets inside it (host memory,

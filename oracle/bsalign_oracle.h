@@ -116,6 +116,31 @@ void     orc_sweep_run(uint8_t *rows, const orc_row_task_t *tasks, const orc_swe
                        int mode, uint32_t bandwidth, int M, int X, int refbonus, int gapo1, int gape1, int gapo2, int gape2, int T,
                        orc_sweep_result_t *results);
 
+
+/* ---- POA sweep, second formulation (bsalign_oracle_wf.c): absolute scores on a node / in-edge description of the selected
+ * sub-graph, plus the traceback into the graph as a list of steps.  Structs are layout-identical to bsa_poa_node_t /
+ * bsa_poa_edge_t / bsa_poa_cand_t / bsa_poa_cell_t / bsa_poa_event_t / bsa_poa_params_t of include/bsalign_hip.h. */
+typedef struct { int32_t h; int8_t e, q; uint16_t tag; } orc_wf_cell_t;
+#define ORC_WF_IN_PRESENT 0x80000000u
+#define ORC_WF_IN_MERGE   0x40000000u
+#define ORC_WF_IN_SAME    0x20000000u
+#define ORC_WF_IN_TOFF    0x0FFFFFFFu
+typedef struct { uint32_t src, movx, toff_kind; } orc_wf_input_t;
+typedef struct { uint32_t rpos, gnode, first_in; uint16_t n_in; uint8_t base, flags; orc_wf_input_t in[2]; uint32_t reserved[2]; } orc_wf_node_t;
+typedef struct { uint32_t src, cov, src_rpos, reserved; } orc_wf_edge_t;
+typedef struct { uint32_t node, kind; } orc_wf_cand_t;                         /* kind 0: edge node -> tail, 1: node reaches the read end */
+typedef struct { uint32_t node; int32_t x; uint32_t bt; } orc_wf_event_t;
+typedef struct { int32_t mode; uint32_t bandwidth; int8_t M, X, refbonus, gapo1, gape1, gapo2, gape2, pad; int32_t T; } orc_wf_params_t;   /* == bsa_sweep_params_t */
+void orc_wf_init_row(const orc_wf_params_t *par, orc_wf_cell_t *row, int32_t *u0);
+void orc_wf_forward(const orc_wf_node_t *nodes, uint32_t nnodes, const uint8_t *query, uint32_t slen,
+		const orc_wf_params_t *par, orc_wf_cell_t *rows, int32_t *u0);
+void orc_wf_row_to_block(const orc_wf_cell_t *row, int32_t u0, uint32_t bandwidth, int pw, uint8_t *block);
+void orc_wf_best(const orc_wf_node_t *nodes, const orc_wf_cand_t *cands, uint32_t ncands, uint32_t slen, const orc_wf_params_t *par,
+		const orc_wf_cell_t *rows, orc_sweep_result_t *res);
+long orc_wf_trace(const orc_wf_node_t *nodes, const orc_wf_edge_t *edges, const uint8_t *query, uint32_t slen,
+		const orc_wf_params_t *par, const orc_wf_cell_t *rows, const int32_t *u0, uint32_t head, uint32_t midx, int xe,
+		orc_wf_event_t *ev, long cap, int32_t fin[2]);
+
 /* timing helper for bench.py's cpu_baseline (kind = "port") */
 double   orc_align_batch_time(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen,
                               const uint64_t *toff, const uint32_t *tlen, long n, int mode, uint32_t bandwidth,

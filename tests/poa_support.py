@@ -202,3 +202,141 @@ def load_golden():
                               tasks=tasks[int(m[20]):int(m[20]) + int(m[17])], query=queries[int(m[21]):int(m[21]) + int(m[14])]))
         cases.append(dict(par=p, programs=progs, cns=g["cns_%d" % c]))
     return cases
+
+
+# ---- second formulation of the sweep (oracle/bsalign_oracle_wf.c, device: bsa_poa_wf.hip): nodes / inputs / in-edges / candidates ----
+WF_CELL = np.dtype([("h", np.int32), ("e", np.int8), ("q", np.int8), ("tag", np.uint16)])
+WF_NODE = np.dtype([("rpos", np.uint32), ("gnode", np.uint32), ("first_in", np.uint32), ("n_in", np.uint16), ("base", np.uint8), ("flags", np.uint8),
+                    ("in0_src", np.uint32), ("in0_movx", np.uint32), ("in0_tk", np.uint32), ("in1_src", np.uint32), ("in1_movx", np.uint32), ("in1_tk", np.uint32),
+                    ("r0", np.uint32), ("r1", np.uint32)])
+WF_EDGE = np.dtype([("src", np.uint32), ("cov", np.uint32), ("src_rpos", np.uint32), ("reserved", np.uint32)])
+WF_CAND = np.dtype([("node", np.uint32), ("kind", np.uint32)])
+WF_EVENT = np.dtype([("node", np.uint32), ("x", np.int32), ("bt", np.uint32)])
+WF_PROG = np.dtype([("first_node", np.uint32), ("nnodes", np.uint32), ("first_edge", np.uint32), ("nedges", np.uint32), ("first_cand", np.uint32), ("ncands", np.uint32),
+                    ("slen", np.uint32), ("event_cap", np.uint32), ("query_off", np.uint64), ("first_event", np.uint64)])
+WF_RESULT = np.dtype([("maxscr", np.int32), ("maxidx", np.int32), ("maxoff", np.int32), ("status", np.int32), ("nevents", np.int32),
+                      ("fin_node", np.int32), ("fin_x", np.int32), ("reserved", np.int32)])
+WF_PARAMS = np.dtype([("mode", np.int32), ("bandwidth", np.uint32), ("M", np.int8), ("X", np.int8), ("refbonus", np.int8),
+                      ("gapo1", np.int8), ("gape1", np.int8), ("gapo2", np.int8), ("gape2", np.int8), ("pad", np.int8), ("T", np.int32)])   # == bsa_sweep_params_t
+IN_PRESENT, IN_MERGE, IN_SAME = 0x80000000, 0x40000000, 0x20000000
+assert WF_NODE.itemsize == 48 and WF_PROG.itemsize == 48 and WF_PARAMS.itemsize == 20
+
+
+def wf_params(p, bandwidth):
+    a = np.zeros(1, WF_PARAMS)
+    a[0] = (p["alnmode"], bandwidth, p["M"], p["X"], p["refbonus"], p["O"], p["E"], p["Q"], p["P"], 0, p["T"])
+    return a
+
+
+def tasks_to_graph(tasks):
+    """a recorded task program (include/bsalign_hip.h bsa_row_task_t) in the node form of bsa_poa_node_t: graph nodes in completion
+    order, every node's in-edges folded two at a time through partial nodes in front of it, candidates in visiting order.  The
+    traceback view comes out in visiting order with cov 1 (the tasks carry no edge coverage): good for the forward pass only.
+    -> nodes, edges, cands, block_of_node (mmidx per local index, 0 for partial nodes)"""
+    last, ins, rpos, base, bonus, cands, gn = {}, {}, {}, {}, {}, [], {}
+    pend = None
+    for i, t in enumerate(tasks):
+        op = int(t["op"])
+        if op == 2:
+            last[int(t["dst"])] = i; ins.setdefault(int(t["dst"]), []); rpos[int(t["dst"])] = 0; base[int(t["dst"])] = 4; bonus[int(t["dst"])] = 0
+        elif op == 0:
+            d = int(t["dst"])
+            rpos[int(t["src"])] = int(t["qoff_src"])
+            if d == 1:
+                pend = t
+            else:
+                last[d] = i; ins.setdefault(d, []).append(t); rpos[d] = int(t["qoff_dst"]); base[d] = int(t["base"]); bonus[d] = int(t["prof"]) & 1
+        elif op == 1:
+            d = int(t["dst"])
+            last[d] = i; ins.setdefault(d, []).append(pend); rpos[d] = int(pend["qoff_dst"]); base[d] = int(pend["base"]); bonus[d] = int(pend["prof"]) & 1
+        else:
+            cands.append((int(t["src"]), 0 if op == 3 else 1)); gn[int(t["src"])] = int(t["toff"]); rpos[int(t["src"])] = int(t["qoff_src"])
+    order = sorted(last, key=lambda m: last[m])
+    loc, recs, edges, blocks = {}, [], [], []
+
+    def upd(t):
+        return (loc[int(t["src"])], int(t["qoff_dst"]) - int(t["qoff_src"]), IN_PRESENT | (IN_SAME if int(t["prof"]) & 2 else 0) | int(t["toff"]))
+
+    for m in order:
+        tl = ins[m]
+        first_edge = len(edges)
+        for t in tl:
+            edges.append((loc[int(t["src"])], 1, int(t["qoff_src"]), 0))
+        none = (0, 0, 0)
+        if len(tl) <= 2:
+            a = upd(tl[0]) if len(tl) > 0 else none
+            b = upd(tl[1]) if len(tl) > 1 else none
+        else:
+            recs.append((rpos[m], 0xFFFFFFFF, 0, 0, base[m], bonus[m]) + upd(tl[0]) + upd(tl[1]) + (0, 0)); blocks.append(0)
+            for t in tl[2:-1]:
+                recs.append((rpos[m], 0xFFFFFFFF, 0, 0, base[m], bonus[m]) + (len(recs) - 1, 0, IN_PRESENT | IN_MERGE) + upd(t) + (0, 0)); blocks.append(0)
+            a = (len(recs) - 1, 0, IN_PRESENT | IN_MERGE)
+            b = upd(tl[-1])
+        loc[m] = len(recs)
+        recs.append((rpos[m], gn.get(m, 0x80000000 | m), first_edge, len(tl), base[m], bonus[m]) + a + b + (0, 0)); blocks.append(m)
+    nodes = np.array(recs, dtype=WF_NODE)
+    e = np.array(edges, dtype=WF_EDGE) if edges else np.zeros(0, WF_EDGE)
+    c = np.array([(loc[m], k) for m, k in cands], dtype=WF_CAND) if cands else np.zeros(0, WF_CAND)
+    return nodes, e, c, np.array(blocks, dtype=np.uint32)
+
+
+def _wf_lib():
+    o = S.oracle()
+    if not getattr(o, "_wf_ready", False):
+        o.orc_wf_forward.restype = None
+        o.orc_wf_forward.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        o.orc_wf_row_to_block.restype = None
+        o.orc_wf_row_to_block.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_int, C.c_void_p]
+        o.orc_wf_best.restype = None
+        o.orc_wf_best.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        o.orc_wf_trace.restype = C.c_long
+        o.orc_wf_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
+                                   C.c_void_p, C.c_long, C.c_void_p]
+        o._wf_ready = True
+    return o
+
+
+def oracle_wf_forward(nodes, query, p, bandwidth):
+    """-> rows (nnodes x bw cells), u0"""
+    o = _wf_lib()
+    bw = (bandwidth + 15) // 16 * 16
+    nodes = np.ascontiguousarray(nodes); query = np.ascontiguousarray(query, dtype=np.uint8)
+    rows = np.zeros((len(nodes), bw), WF_CELL)
+    u0 = np.zeros(len(nodes), np.int32)
+    par = wf_params(p, bandwidth)
+    o.orc_wf_forward(nodes.ctypes.data, len(nodes), query.ctypes.data, len(query), par.ctypes.data, rows.ctypes.data, u0.ctypes.data)
+    return rows, u0
+
+
+def wf_rows_to_blocks(rows, u0, block_of_node, nblocks, bandwidth, pw):
+    """absolute rows -> the reference's row blocks (partial nodes, block 0, are skipped)"""
+    o = _wf_lib()
+    bw = (bandwidth + 15) // 16 * 16
+    blk = block_bytes(bw, pw)
+    out = np.zeros(nblocks * blk, np.uint8)
+    rows = np.ascontiguousarray(rows)
+    for k in range(len(rows)):
+        if block_of_node[k]:
+            o.orc_wf_row_to_block(rows[k].ctypes.data, int(u0[k]), bw, pw, out.ctypes.data + int(block_of_node[k]) * blk)
+    return out
+
+
+def oracle_wf_best(nodes, cands, slen, p, bandwidth, rows):
+    o = _wf_lib()
+    res = np.zeros(1, RESULT_DTYPE)
+    par = wf_params(p, bandwidth)
+    cands = np.ascontiguousarray(cands)
+    o.orc_wf_best(nodes.ctypes.data, cands.ctypes.data, len(cands), slen, par.ctypes.data, rows.ctypes.data, res.ctypes.data)
+    return res[0]
+
+
+def oracle_wf_trace(nodes, edges, query, p, bandwidth, rows, u0, head, midx, xe):
+    o = _wf_lib()
+    ev = np.zeros(4 * (len(query) + len(nodes)) + 64, WF_EVENT)
+    fin = np.zeros(2, np.int32)
+    par = wf_params(p, bandwidth)
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    edges = np.ascontiguousarray(edges)
+    n = o.orc_wf_trace(nodes.ctypes.data, edges.ctypes.data, query.ctypes.data, len(query), par.ctypes.data, rows.ctypes.data, u0.ctypes.data,
+                       head, midx, xe, ev.ctypes.data, len(ev), fin.ctypes.data)
+    return n, ev[:max(n, 0)], fin
