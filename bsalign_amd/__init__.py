@@ -52,6 +52,18 @@ class SweepParams(C.Structure):
 
 SWEEP_PROG_DTYPE = np.dtype([("first_task", np.uint32), ("ntasks", np.uint32), ("first_block", np.uint32), ("reserved", np.uint32)])
 SWEEP_RESULT_DTYPE = np.dtype([("maxscr", np.int32), ("maxidx", np.int32), ("maxoff", np.int32), ("reserved", np.int32)])
+# the wavefront sweep's program (include/bsalign_hip.h: bsa_poa_node_t, bsa_poa_edge_t, bsa_poa_cand_t, bsa_poa_prog_t, ...)
+POA_CELL_DTYPE = np.dtype([("h", np.int32), ("e", np.int8), ("q", np.int8), ("tag", np.uint16)])
+POA_NODE_DTYPE = np.dtype([("rpos", np.uint32), ("gnode", np.uint32), ("first_in", np.uint32), ("n_in", np.uint16), ("base", np.uint8), ("flags", np.uint8),
+                           ("in0_src", np.uint32), ("in0_movx", np.uint32), ("in0_tk", np.uint32), ("in1_src", np.uint32), ("in1_movx", np.uint32), ("in1_tk", np.uint32),
+                           ("r0", np.uint32), ("r1", np.uint32)])
+POA_EDGE_DTYPE = np.dtype([("src", np.uint32), ("cov", np.uint32), ("src_rpos", np.uint32), ("reserved", np.uint32)])
+POA_CAND_DTYPE = np.dtype([("node", np.uint32), ("kind", np.uint32)])
+POA_EVENT_DTYPE = np.dtype([("node", np.uint32), ("x", np.int32), ("bt", np.uint32)])
+POA_PROG_DTYPE = np.dtype([("first_node", np.uint32), ("nnodes", np.uint32), ("first_edge", np.uint32), ("nedges", np.uint32), ("first_cand", np.uint32), ("ncands", np.uint32),
+                           ("slen", np.uint32), ("event_cap", np.uint32), ("query_off", np.uint64), ("first_event", np.uint64)])
+POA_RESULT_DTYPE = np.dtype([("maxscr", np.int32), ("maxidx", np.int32), ("maxoff", np.int32), ("status", np.int32), ("nevents", np.int32),
+                             ("fin_node", np.int32), ("fin_x", np.int32), ("reserved", np.int32)])
 ROW_OP_UPDATE, ROW_OP_MERGE, ROW_OP_INIT, ROW_OP_SCORE_TAIL, ROW_OP_SCORE_END = 0, 1, 2, 3, 4
 
 
@@ -137,6 +149,10 @@ def lib():
         L.bsa_rows_run.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(RowsParams)]
         L.bsa_sweep_run.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(SweepParams), vp]
         L.bsa_sweep_host.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.POINTER(SweepParams), vp, C.c_size_t, vp]
+        L.bsa_poa_graph_supported.argtypes = [C.POINTER(SweepParams), C.c_uint32]
+        L.bsa_poa_graph_host.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(SweepParams),
+                                         vp, vp, C.c_size_t, vp, vp]
+        L.bsa_poa_graph_run.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.POINTER(SweepParams), vp, vp, vp, vp]
         L.bsa_align_debug_rows.argtypes = [vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
         L.bsa_diagdp_batch.argtypes = [vp, u8p, C.c_size_t, vp, C.c_size_t, u8p, C.c_size_t]
         L.bsa_diagdp_last_ms.argtypes = [vp]
@@ -269,6 +285,25 @@ class Context:
                               rows.ctypes.data if want_rows else None, nblocks, res.ctypes.data)
         self._chk(rc)
         return rows, res
+
+    def poa_graph_host(self, nodes, edges, cands, progs, queries, par, events_cap, want_rows=False):
+        """host-pointer form of the wavefront sweep + device traceback (bsa_poa_graph_host): nodes POA_NODE_DTYPE, edges
+        POA_EDGE_DTYPE, cands POA_CAND_DTYPE, progs POA_PROG_DTYPE, queries one base per byte.
+        -> (results POA_RESULT_DTYPE, events POA_EVENT_DTYPE [events_cap], rows POA_CELL_DTYPE [nnodes, bw] or None, u0 or None)"""
+        L = lib()
+        nodes = np.ascontiguousarray(nodes, dtype=POA_NODE_DTYPE); edges = np.ascontiguousarray(edges, dtype=POA_EDGE_DTYPE)
+        cands = np.ascontiguousarray(cands, dtype=POA_CAND_DTYPE); progs = np.ascontiguousarray(progs, dtype=POA_PROG_DTYPE)
+        queries = np.ascontiguousarray(queries, dtype=np.uint8)
+        bw = (par.rows.bandwidth + 15) // 16 * 16
+        res = np.zeros(len(progs), dtype=POA_RESULT_DTYPE)
+        ev = np.zeros(max(events_cap, 1), dtype=POA_EVENT_DTYPE)
+        rows = np.zeros((len(nodes), bw), dtype=POA_CELL_DTYPE) if want_rows else None
+        u0 = np.zeros(len(nodes), dtype=np.int32) if want_rows else None
+        rc = L.bsa_poa_graph_host(self.h, nodes.ctypes.data, len(nodes), edges.ctypes.data, len(edges), cands.ctypes.data, len(cands),
+                                  progs.ctypes.data, len(progs), queries.ctypes.data, queries.size, C.byref(par), res.ctypes.data, ev.ctypes.data, events_cap,
+                                  rows.ctypes.data if want_rows else None, u0.ctypes.data if want_rows else None)
+        self._chk(rc)
+        return res, ev, rows, u0
 
     def diagdp_batch(self, planes, probs, matrix_bytes):
         """anti-diagonal u8 DP of the MSA refinement (bsa_diagdp_batch): planes = uint8 blob in the reference's layout,

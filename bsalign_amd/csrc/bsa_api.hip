@@ -37,6 +37,7 @@ struct bsa_ctx {
 	// of one pair otherwise spends more time in hipMalloc / hipFree than in its kernels
 	size_t budget_last = 0;          // last answer of ctx_ws_budget
 	void *keep[2] = {nullptr, nullptr}; size_t keep_bytes[2] = {0, 0}; bool keep_busy[2] = {false, false};
+	void *scratch[2] = {nullptr, nullptr}; size_t scratch_bytes[2] = {0, 0};      // grown on demand, kept (bsa_ctx_scratch_internal): the POA rows
 };
 
 static const size_t BSA_KEEP_MAX = (size_t)64 << 20;      // larger requests are plain allocations
@@ -92,6 +93,7 @@ extern "C" void bsa_ctx_destroy(bsa_ctx_t *c){
 	for(hipEvent_t e : c->tev) (void)hipEventDestroy(e);
 	if(c->ws) (void)hipFree(c->ws);
 	for(int k = 0; k < 2; k++) if(c->keep[k]) (void)hipFree(c->keep[k]);
+	for(int k = 0; k < 2; k++) if(c->scratch[k]) (void)hipFree(c->scratch[k]);
 	if(c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
 	if(c->own_stream) (void)hipStreamDestroy(c->own_stream);
 	delete c;
@@ -994,6 +996,20 @@ extern "C" int bsa_ctx_time_begin_internal(bsa_ctx_t *c, double cells, void **st
 extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *c, void *stop_event){
 	if(!c || !stop_event) return BSA_E_ARG;
 	HIPCHK(c, hipEventRecord((hipEvent_t)stop_event, c->stream));
+	return BSA_OK;
+}
+
+// a device buffer of at least `bytes` that stays the context's (stream-ordered users only: the previous user's kernels are on the same stream)
+extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *c, int slot, size_t bytes, void **out){
+	if(!c || !out || slot < 0 || slot > 1) return BSA_E_ARG;
+	(void)hipSetDevice(c->device);
+	if(c->scratch_bytes[slot] < bytes){
+		if(c->scratch[slot]){ HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->scratch[slot]); c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0; }
+		const size_t want = bytes + bytes / 4 + ((size_t)1 << 20);
+		if(hipMalloc(&c->scratch[slot], want) != hipSuccess){ c->scratch[slot] = nullptr; (void)hipGetLastError(); c->err = "scratch allocation failed"; return BSA_E_NOMEM; }
+		c->scratch_bytes[slot] = want;
+	}
+	*out = c->scratch[slot];
 	return BSA_OK;
 }
 

@@ -1,0 +1,618 @@
+// bsa_poa_wf.hip -- the POA's per-read seq->graph DP as an anti-diagonal wavefront, with the traceback on the device.
+//
+// Reference: align_rd_bspoacore bspoa.h:2515-2618 (dpalign_row_update_bspoa :2232-2261 = row_movx bsalign.h:2244 + row_cal
+// bsalign.h:2727/2885/3084, dpalign_row_merge_bspoa :2263-2272 = row_merge bsalign.h:2474) and alignment2graph_bspoa
+// bspoa.h:2274-2513.  C-ABI: bsa_poa_graph_run / bsa_poa_graph_host (include/bsalign_hip.h), programs built by
+// include/bsalign_poa_adapter.h from the reference's own graph.
+//
+// Why a wavefront: the band offset of every node is fixed before the sweep (prepare_rd_align_bspoa bspoa.h:2168-2174), so the cell
+// (node v, column x) depends on cells (u, x - 1) and (u, x) of v's predecessors and on (v, x - 1) -- nothing else.  One wave runs
+// one read.  Lane l owns node i (nodes in the order the reference completes them, i mod lanes = l), walks its row cell by cell
+// and trails each predecessor by movx + 1 cells; the rows of the nodes in flight are an LDS ring of 8-byte cells
+// {H, e | q << 8 | tag << 16}, the tag (node number) tells a reader whether the cell it needs has been written yet, so lanes never
+// wait for each other: a lane whose inputs are not there skips the step.  The nodes in flight are always 64 consecutive ones (a
+// lane takes its next node only when every node before the window is complete), which bounds the ring: a predecessor at most
+// NEAR nodes back is read from the ring, anything further from the drained rows in HBM.  Finished rows leave the ring in
+// batches as 4-byte cells {int16 H - H(0), e, q} + one int32 per node, coalesced -- the only HBM traffic of the forward pass and
+// exactly what the traceback reads.
+//
+// Arithmetic: absolute int32 scores.  The reference keeps int8 differences (u = H(p) - H(p-1), e = E - H, q = Q - H) and block
+// start scores; inside bsa_poa_graph_supported()'s guard none of its saturating operations clamps, so the two are the same
+// numbers (oracle/bsalign_oracle_wf.c is the scalar statement of this kernel, checked byte for byte against the lane-exact
+// restatement of the reference's rows and against the reference itself).  The rules that are not plain affine-gap DP are kept
+// literally: the seed of band cell 0 (bsalign.h:2899-2907, rh as bspoa.h:2242-2254 picks it), F and G restarting from
+// "predecessor's H - 63" at every running block (bsalign.h:2909-2931, 2639-2652), the synthetic cells behind a moved row's end
+// (bsalign.h:2347-2391), the dead row of a move by >= bandwidth (:2253-2259), S = -63 beyond the read end (:2157-2160).
+#include "bsa_common.h"
+#include <algorithm>
+#include <vector>
+#include <cstring>
+
+#define POA_NEAR   16      // predecessors at most this many nodes back are read from the LDS ring
+#define POA_DRAIN  16      // finished rows leave the ring in batches of this many
+#define POA_NEG    (2 * BSA_SCORE_MIN)
+
+struct PoaArgs {
+	const bsa_poa_node_t *nodes; const bsa_poa_edge_t *edges; const bsa_poa_cand_t *cands; const bsa_poa_prog_t *progs;
+	const uint8_t *queries;
+	uint32_t *rows; int32_t *u0;
+	bsa_poa_result_t *res; bsa_poa_event_t *events;
+	uint32_t bw, W, nl, R, qn_off, tile_off;
+	int32_t mode, M, X, refbonus, O, E, Q, P, T;
+	int32_t c0, d, head_u0, xp;
+};
+
+__device__ __forceinline__ uint32_t poa_tag(int node){ return (uint32_t)(node % 65535) + 1u; }
+__device__ __forceinline__ int sx8(uint32_t v){ return (int)(int8_t)(v & 0xFFu); }
+
+template<int PW>
+__device__ __forceinline__ int poa_init_h(const PoaArgs &a, int p){     // row_init (bsalign.h:2094-2140) as absolute scores
+	if((a.mode & 3) == BSA_MODE_OVERLAP) return 0;
+	if(PW == 2){
+		const int n1 = min(p, a.xp - 1);
+		return a.O + a.E + n1 * a.E + (p - n1) * a.P;
+	}
+	return a.O + a.E + p * a.E;
+}
+
+template<int PW>
+__global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
+	extern __shared__ __align__(16) uint8_t lds[];
+	uint2 *ring = (uint2*)lds;
+	uint32_t *qn = (uint32_t*)(lds + a.qn_off);
+	const bsa_poa_prog_t pg = a.progs[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int bw = (int)a.bw, W = (int)a.W, NL = (int)a.nl, R = (int)a.R;
+	const int nn = (int)pg.nnodes, slen = (int)pg.slen;
+	const bsa_poa_node_t *nodes = a.nodes + pg.first_node;
+	uint32_t *grows = a.rows + (size_t)pg.first_node * bw;
+	int32_t *gu0 = a.u0 + pg.first_node;
+	const uint64_t lmask = (NL == 64) ? ~0ull : ((1ull << NL) - 1ull);
+	const int mode = a.mode & 3;
+	const int E = a.E, OE = a.O + a.E, P = a.P, QP = a.Q + a.P;
+	if(nn == 0){ if(lane == 0){ bsa_poa_result_t r; r.maxscr = BSA_SCORE_MIN; r.maxidx = -1; r.maxoff = -1; r.status = BSA_POA_ST_NOCAND; r.nevents = 0; r.fin_node = -1; r.fin_x = -1; r.reserved = 0; a.res[blockIdx.x] = r; } return; }
+
+	// ring tags cleared, query as nibbles (code | differs-from-next << 2 | beyond-the-read << 3), head row in slot 0
+	for(int i = lane; i < R * bw; i += 64) ring[i] = make_uint2(0u, 0u);
+	{
+		const uint8_t *q = a.queries + pg.query_off;
+		const int nqw = (slen + bw + 16) / 8 + 1;
+		for(int w = lane; w < nqw; w += 64){
+			uint32_t v = 0;
+			for(int k = 0; k < 8; k++){
+				const int x = w * 8 + k; uint32_t nb;
+				if(x >= slen) nb = 8u;
+				else { const uint32_t c = q[x]; nb = c & 3u; if(x + 1 < slen && q[x + 1] != c) nb |= 4u; }
+				v |= nb << (4 * k);
+			}
+			qn[w] = v;
+		}
+	}
+	__syncthreads();
+	{
+		const uint32_t eq = ((PW >= 1) ? 0xC1u : 0u) | ((PW == 2) ? 0xC100u : 0u) | (poa_tag(0) << 16);      // e = q = -63
+		for(int p = lane; p < bw; p += 64) ring[p] = make_uint2((uint32_t)poa_init_h<PW>(a, p), eq);
+	}
+	__syncthreads();
+
+	// ---- forward pass ----
+	int m = -NL;                 // nodes below m are complete; the nodes in flight are m .. m + NL - 1
+	int dr = 0;                  // rows below dr are in HBM
+	int cur = lane - NL, p = 0;
+	bool fin = true;             // finished `cur`, waiting for the window to take the next node
+	int rposv = 0, Mv = 0, F = POA_NEG, G = POA_NEG, blk = 0;
+	uint32_t basev = 0, mytag = 0; int myrow = 0;
+	uint32_t qw = 0;
+	uint32_t fl0 = 0, fl1 = 0;   // input flags: 1 present, 2 merge, 4 same base, 8 far (HBM), 16 dead (moved by >= bandwidth)
+	int ad0 = 0, ad1 = 0, lim0 = 0, lim1 = 0, hp0 = 0, hp1 = 0, src0 = 0, src1 = 0, mv0 = 0, mv1 = 0, to0 = 0, to1 = 0;
+	uint32_t tg0 = 0, tg1 = 0; int fu0 = 0, fu1 = 0;       // far inputs: the predecessor's ubegs[0]
+
+	auto drain = [&](int upto){
+		// rows dr .. upto - 1 -> HBM as {int16 H - H(0), e, q}; four cells per lane and store
+		for(int r = dr; r < upto; r++){
+			const uint2 *src = ring + (r % R) * bw;
+			const int base = (int)src[0].x;
+			for(int c = lane * 4; c < bw; c += 256){
+				uint32_t o[4];
+#pragma unroll
+				for(int k = 0; k < 4; k++){ const uint2 en = src[c + k]; o[k] = (uint32_t)(((int)en.x - base) & 0xFFFF) | ((en.y & 0xFFFFu) << 16); }
+				*(uint4*)&grows[(size_t)r * bw + c] = make_uint4(o[0], o[1], o[2], o[3]);
+			}
+			if(lane == 0) gu0[r] = (r == 0) ? a.head_u0 : base;
+		}
+		dr = upto;
+	};
+
+	while(m < nn){
+		// (A) the window: lanes whose finished node heads the window take their next node
+		{
+			const uint64_t B = __ballot(fin) & lmask;
+			int r = m % NL; if(r < 0) r += NL;
+			uint64_t rot = B;
+			if(r) rot = ((B >> r) | (B << (NL - r))) & lmask;
+			const int t = (rot == lmask) ? NL : __builtin_ctzll(~rot);
+			int dd = lane - r; if(dd < 0) dd += NL;
+			if(lane < NL && fin && dd < t){
+				cur += NL; p = 0;
+				if(cur == 0){ fin = true; }                 // the head's row is there already
+				else if(cur >= nn){ fin = true; }           // past the end: a virtual node, complete at once
+				else {
+					const bsa_poa_node_t nd = nodes[cur];
+					fin = false;
+					rposv = (int)nd.rpos; basev = nd.base; Mv = a.M + ((nd.flags & 1) ? a.refbonus : 0);
+					F = POA_NEG; G = POA_NEG; blk = 0;
+					myrow = (cur % R) * bw; mytag = poa_tag(cur) << 16;
+					qw = qn[rposv >> 3];
+#define POA_SETUP(k, FL, AD, LIM, SRC, MV, TO, TG)                                                                   \
+					{                                                                                                      \
+						const bsa_poa_input_t in = nd.in[k];                                                               \
+						FL = 0;                                                                                            \
+						if(in.toff_kind & BSA_POA_IN_PRESENT){                                                             \
+							SRC = (int)in.src; MV = (int)in.movx; TO = (int)(in.toff_kind & BSA_POA_IN_TOFF);              \
+							FL = 1u | ((in.toff_kind & BSA_POA_IN_MERGE) ? 2u : 0u) | ((in.toff_kind & BSA_POA_IN_SAME) ? 4u : 0u); \
+							if(cur - SRC > POA_NEAR) FL |= 8u;                                                             \
+							if(MV >= bw) FL |= 16u;                                                                        \
+							LIM = bw - MV; AD = (SRC % R) * bw + MV; TG = poa_tag(SRC);                                    \
+						}                                                                                                  \
+					}
+					POA_SETUP(0, fl0, ad0, lim0, src0, mv0, to0, tg0)
+					POA_SETUP(1, fl1, ad1, lim1, src1, mv1, to1, tg1)
+#undef POA_SETUP
+				}
+			}
+			m += t;
+		}
+		// (B) finished rows leave the ring; a lane waiting for a far predecessor forces them out
+		{
+			const bool farwait = !fin && (((fl0 & 9u) == 9u && src0 >= dr) || ((fl1 & 9u) == 9u && src1 >= dr));
+			const int done = min(m, nn);
+			if(done - dr >= POA_DRAIN || (__ballot(farwait) != 0ull && done > dr)){
+				drain(done);
+				if(__ballot(farwait) != 0ull) __builtin_amdgcn_s_waitcnt(0);      // the stores have to land before they are read back
+			}
+		}
+		// (C) one cell for every lane whose inputs are there
+		if(!fin){
+			bool ready = true;
+			int h10 = 0, e10 = 0, q10 = 0, h11 = 0, e11 = 0, q11 = 0, hq0 = hp0, hq1 = hp1;
+#define POA_FETCH(FL, AD, LIM, SRC, MV, TG, FU, H1, E1, Q1, HQ)                                                        \
+			if(FL & 1u){                                                                                               \
+				if(FL & 16u){ H1 = BSA_SCORE_MIN; E1 = 0; Q1 = 0; HQ = BSA_SCORE_MIN; }                                \
+				else if(p < LIM){                                                                                      \
+					if(!(FL & 8u)){                                                                                    \
+						const uint2 en = ring[AD];                                                                     \
+						ready = ready && ((en.y >> 16) == TG);                                                         \
+						H1 = (int)en.x; E1 = sx8(en.y); Q1 = sx8(en.y >> 8);                                           \
+						if(p == 0 && MV > 0) HQ = (int)ring[AD - 1].x;                                                 \
+					} else if(SRC < dr){                                                                               \
+						if(p == 0) FU = *(const volatile int32_t*)&gu0[SRC];                                           \
+						const uint32_t cw = *(const volatile uint32_t*)&grows[(size_t)SRC * bw + p + MV];              \
+						H1 = FU + (int)(int16_t)(cw & 0xFFFFu); E1 = sx8(cw >> 16); Q1 = sx8(cw >> 24);                \
+						if(SRC == 0) H1 = poa_init_h<PW>(a, p + MV);                                                   \
+						if(p == 0 && MV > 0){                                                                          \
+							const uint32_t cp = *(const volatile uint32_t*)&grows[(size_t)SRC * bw + MV - 1];          \
+							HQ = (SRC == 0) ? poa_init_h<PW>(a, MV - 1) : FU + (int)(int16_t)(cp & 0xFFFFu);           \
+						}                                                                                              \
+					} else ready = false;                                                                              \
+				} else {                                                                                               \
+					const int ov = p - LIM;                                                                            \
+					H1 = HQ + (ov == 0 ? a.c0 : (ov < a.d ? E : P)); E1 = 0; Q1 = 0;                                   \
+				}                                                                                                      \
+			}
+			POA_FETCH(fl0, ad0, lim0, src0, mv0, tg0, fu0, h10, e10, q10, hq0)
+			POA_FETCH(fl1, ad1, lim1, src1, mv1, tg1, fu1, h11, e11, q11, hq1)
+#undef POA_FETCH
+			if(ready){
+				const int x = rposv + p;
+				const uint32_t nb = (qw >> ((x & 7) * 4)) & 0xFu;
+				const int Sb = ((nb & 3u) == basev) ? Mv : a.X;
+				const int hpc = (int)((nb >> 2) & 1u);
+				const bool beyond = (nb & 8u) != 0u;
+				int mm = POA_NEG, Ein = POA_NEG, Qin = POA_NEG, fl = POA_NEG, HX = POA_NEG, EX = POA_NEG, QX = POA_NEG;
+#define POA_INPUT(FL, SRC, MV, TO, H1, E1, Q1, HQ)                                                                     \
+				if(FL & 1u){                                                                                           \
+					if(FL & 2u){ HX = max(HX, H1); EX = max(EX, H1 + E1); QX = max(QX, H1 + Q1); }                    \
+					else {                                                                                             \
+						const int S = beyond ? BSA_EPI8_MIN : Sb + ((FL & 4u) ? 0 : hpc);                             \
+						int mc;                                                                                        \
+						if(p == 0){                                                                                    \
+							int ub0, rh, h0, t;                                                                        \
+							if(FL & 16u) ub0 = BSA_SCORE_MIN;                                                          \
+							else if(MV == 0) ub0 = (SRC == 0) ? a.head_u0 : H1;                                        \
+							else ub0 = HQ;                                                                             \
+							if(MV == 0){                                                                               \
+								if(rposv) rh = BSA_SCORE_MIN;                                                          \
+								else if(mode == BSA_MODE_OVERLAP || TO == 0) rh = 0;                                   \
+								else if(PW < 2) rh = a.O + E * TO;                                                     \
+								else rh = max(a.O + E * TO, a.Q + P * TO);                                             \
+							} else if(MV <= bw) rh = ub0;                                                              \
+							else rh = BSA_SCORE_MIN;                                                                   \
+							h0 = rh - ub0 + S;                                                                         \
+							t = (H1 - ub0) + (PW == 0 ? E : PW == 1 ? E1 : max(E1, Q1));                               \
+							if(h0 >= t) h0 = min(h0, BSA_EPI8_MAX); else h0 = BSA_EPI8_MIN;                            \
+							mc = ub0 + h0;                                                                             \
+							fl = max(fl, ub0 + BSA_EPI8_MIN);                                                          \
+						} else {                                                                                       \
+							mc = HQ + S;                                                                               \
+							if(blk == 0) fl = max(fl, HQ + BSA_EPI8_MIN);                                              \
+						}                                                                                              \
+						mm = max(mm, mc);                                                                              \
+						Ein = max(Ein, H1 + (PW == 0 ? E : E1));                                                       \
+						if(PW == 2) Qin = max(Qin, H1 + Q1);                                                           \
+					}                                                                                                  \
+				}
+				POA_INPUT(fl0, src0, mv0, to0, h10, e10, q10, hq0)
+				POA_INPUT(fl1, src1, mv1, to1, h11, e11, q11, hq1)
+#undef POA_INPUT
+				if(blk == 0){ F = max(F, fl); if(PW == 2) G = max(G, fl); }
+				int H = max(max(mm, Ein), max(F, HX));
+				if(PW == 2) H = max(max(H, Qin), G);
+				int e1 = 0, q1 = 0;
+				if(PW == 0) F = H + E;
+				else {
+					e1 = max(max(Ein + E, H + OE), EX) - H;
+					F = max(F + E, H + OE);
+					if(PW == 2){
+						q1 = max(max(Qin + P, H + QP), QX) - H;
+						G = max(G + P, H + QP);
+					}
+				}
+				ring[myrow + p] = make_uint2((uint32_t)H, ((uint32_t)e1 & 0xFFu) | (((uint32_t)q1 & 0xFFu) << 8) | mytag);
+				hp0 = h10; hp1 = h11;
+				ad0++; ad1++;
+				p++;
+				if(++blk == W) blk = 0;
+				if(((rposv + p) & 7) == 0) qw = qn[(rposv + p) >> 3];
+				if(p == bw) fin = true;
+			}
+		}
+	}
+	drain(nn);
+	__builtin_amdgcn_s_waitcnt(0);
+	__syncthreads();
+
+	// ---- the best end cell (bspoa.h:2549-2603): candidates in the reference's visiting order, strictly greater replaces ----
+	const bsa_poa_cand_t *cands = a.cands + pg.first_cand;
+	long long bkey = (long long)0x8000000000000000ull; int boff = -1;
+	auto cellH = [&](int node, int pp) -> int {
+		if(node == 0) return poa_init_h<PW>(a, pp);
+		const uint32_t cw = *(const volatile uint32_t*)&grows[(size_t)node * bw + pp];
+		return *(const volatile int32_t*)&gu0[node] + (int)(int16_t)(cw & 0xFFFFu);
+	};
+	for(int k = lane; k < (int)pg.ncands; k += 64){
+		const int node = (int)cands[k].node, rp = (int)nodes[node].rpos;
+		if(cands[k].kind == 1){
+			const int s = cellH(node, slen - 1 - rp) + a.T;
+			const long long key = ((long long)s << 32) | (long long)(0xFFFFFFFFu - (uint32_t)(2 * k));
+			if(key > bkey){ bkey = key; boff = slen - 1; }
+		} else {
+			const int mo = min(slen, rp + bw) - 1;
+			int s = cellH(node, mo - rp);
+			if(slen > mo + 1){ const int n = slen - mo - 1; s += (PW < 2) ? a.O + E * n : max(a.O + E * n, a.Q + P * n); }
+			s += a.T;
+			long long key = ((long long)s << 32) | (long long)(0xFFFFFFFFu - (uint32_t)(2 * k));
+			if(key > bkey){ bkey = key; boff = mo; }
+			if(mode == BSA_MODE_OVERLAP){
+				// row_max (bsalign.h:3213-3329): best cell of every running block, first one on ties; blocks in the order of the register reduction
+				int bs = 0, bp = 0;
+				for(int kk = 0; kk < 16; kk++){
+					const int j = (kk & 3) * 4 + (kk >> 2);
+					int mx = cellH(node, j * W), ai = 0;
+					for(int i = 1; i < W; i++){ const int v = cellH(node, j * W + i); if(v > mx){ mx = v; ai = i; } }
+					if(kk == 0 || mx > bs){ bs = mx; bp = j * W + ai; }
+				}
+				key = ((long long)bs << 32) | (long long)(0xFFFFFFFFu - (uint32_t)(2 * k + 1));
+				if(key > bkey){ bkey = key; boff = bp + rp; }
+			}
+		}
+	}
+	for(int o = 32; o > 0; o >>= 1){
+		const long long ok = __shfl_xor(bkey, o); const int oo = __shfl_xor(boff, o);
+		if(ok > bkey){ bkey = ok; boff = oo; }
+	}
+	bsa_poa_result_t rs;
+	rs.reserved = 0; rs.nevents = 0; rs.fin_node = -1; rs.fin_x = -1; rs.status = BSA_POA_ST_OK;
+	if(bkey == (long long)0x8000000000000000ull){
+		rs.maxscr = BSA_SCORE_MIN; rs.maxidx = -1; rs.maxoff = -1; rs.status = BSA_POA_ST_NOCAND;
+		if(lane == 0) a.res[blockIdx.x] = rs;
+		return;
+	}
+	rs.maxscr = (int)(bkey >> 32);
+	rs.maxidx = (int)cands[(0xFFFFFFFFu - (uint32_t)(bkey & 0xFFFFFFFFll)) >> 1].node;
+	rs.maxoff = boff;
+
+	// ---- traceback: lane 0 walks, the wave keeps a tile of 64 nodes (records, in-edges, rows) in LDS ahead of it ----
+	{
+		const bsa_poa_edge_t *gedges = a.edges + pg.first_edge;
+		bsa_poa_event_t *ev = a.events + pg.first_event;
+		const int ecap = (int)pg.event_cap;
+		uint32_t *t_rows = (uint32_t*)lds;                                  // 64 rows
+		int32_t *t_u0 = (int32_t*)(lds + (size_t)64 * bw * 4);
+		bsa_poa_node_t *t_nodes = (bsa_poa_node_t*)(lds + (size_t)64 * bw * 4 + 256);
+		bsa_poa_edge_t *t_edges = (bsa_poa_edge_t*)(lds + (size_t)64 * bw * 4 + 256 + 64 * sizeof(bsa_poa_node_t));
+		const int TE = 512;
+		int n = rs.maxidx, nidx = rs.maxidx, x = rs.maxoff, ne = 0, status = BSA_POA_ST_OK;
+		uint32_t bt = 0xFFFFFFFFu;
+		int Hs0 = 0, Hs1 = 0, Hs2 = 0;
+		bool done = false, first = true;
+		while(!done){
+			// tile = nodes [lo, hi], hi = the walker's node
+			const int hi = n, lo = max(0, hi - 63);
+			const int elo = (int)nodes[lo].first_in;
+			const int ecnt = min(TE, (int)nodes[hi].first_in + (int)nodes[hi].n_in - elo);
+			__syncthreads();
+			for(int i = lane; i < (hi - lo + 1) * (int)(sizeof(bsa_poa_node_t) / 16); i += 64) ((uint4*)t_nodes)[i] = ((const uint4*)(nodes + lo))[i];
+			for(int i = lane; i < ecnt; i += 64) ((uint4*)t_edges)[i] = ((const uint4*)(gedges + elo))[i];
+			for(int i = lane; i < (hi - lo + 1) * bw / 4; i += 64) ((uint4*)t_rows)[i] = ((const uint4*)(grows + (size_t)lo * bw))[i];
+			if(lane <= hi - lo) t_u0[lane] = gu0[lo + lane];
+			__syncthreads();
+			if(lane == 0){
+#define TNODE(i)   (((i) >= lo && (i) <= hi) ? t_nodes[(i) - lo] : nodes[i])
+#define TU0(i)     (((i) >= lo && (i) <= hi) ? t_u0[(i) - lo] : *(const volatile int32_t*)&gu0[i])
+#define TCELL(i, pp) (((i) >= lo && (i) <= hi) ? t_rows[((i) - lo) * bw + (pp)] : *(const volatile uint32_t*)&grows[(size_t)(i) * bw + (pp)])
+#define TH(i, pp)  (((i) == 0) ? poa_init_h<PW>(a, (pp)) : TU0(i) + (int)(int16_t)(TCELL(i, pp) & 0xFFFFu))
+#define TE8(i, pp) sx8(TCELL(i, pp) >> 16)
+#define TQ8(i, pp) sx8(TCELL(i, pp) >> 24)
+#define TUS(i, pp) ((pp) == 0 ? TH(i, 0) - TU0(i) : TH(i, pp) - TH(i, (pp) - 1))
+#define TEDGE(k)   (((k) >= elo && (k) < elo + ecnt) ? t_edges[(k) - elo] : gedges[k])
+#define EMIT(nn_, xx_, bb_) do{ if(ne >= ecap){ status = BSA_POA_ST_EVENTS; done = true; } else { ev[ne].node = (uint32_t)(nn_); ev[ne].x = (xx_); ev[ne].bt = (bb_); ne++; } }while(0)
+				if(first){
+					first = false;
+					const int pp = x - (int)TNODE(n).rpos;
+					if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
+					else Hs1 = TH(n, pp);
+				}
+				while(!done){
+					if(n == 0 || x < 0){ done = true; break; }
+					if(lo > 0 && n < lo + POA_NEAR + 1) break;          // the walker's predecessors are about to leave the tile: next tile
+					const bsa_poa_node_t nd = TNODE(n);
+					if(bt == 2u || bt == 4u){
+						EMIT(n, x, bt);
+						bool found = false;
+						for(int k = 0; k < (int)nd.n_in && !found; k++){
+							const bsa_poa_edge_t ed = TEDGE((int)nd.first_in + k);
+							const int w = (int)ed.src, wr = (int)ed.src_rpos;
+							if(x < wr || x >= wr + bw) continue;
+							Hs0 = TH(w, x - wr);
+							int qv;
+							if(bt == 2u) qv = PW ? TE8(w, x - wr) : a.O + E;
+							else qv = TQ8(w, x - wr);
+							if(Hs0 + qv != Hs1) continue;
+							n = w;
+							if(qv == ((bt == 2u) ? a.O + E : a.Q + P)){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
+							else { Hs1 -= (bt == 2u) ? E : P; Hs2++; }
+							found = true;
+						}
+						if(!found){ status = BSA_POA_ST_TRACE; done = true; }
+					} else if(bt == 1u){
+						EMIT(n, x, bt);
+						const int t = (PW == 2) ? max(a.O + E * Hs2, a.Q + P * Hs2) : a.O + E * Hs2;
+						x--;
+						if(Hs0 + t == Hs1){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
+						else if(x >= 0){
+							const int pp = x - (int)nd.rpos;
+							if(pp < 0){ status = BSA_POA_ST_TRACE; done = true; }
+							else { Hs0 -= TUS(n, pp); Hs2++; }
+						}
+					} else if(bt == 0u){
+						EMIT(n, x, bt);
+						x--;
+						n = nidx;
+						bt = 0xFFFFFFFFu;
+					} else {
+						uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
+						for(int k = 0; k < (int)nd.n_in; k++){
+							const bsa_poa_edge_t ed = TEDGE((int)nd.first_in + k);
+							const int w = (int)ed.src, wr = (int)ed.src_rpos;
+							const uint32_t cov = ed.cov;
+							int ft = 0, s, scr0, scr1, scr2;
+							if(x < wr || x > bw + wr) continue;
+							else if(x == bw + wr){ Hs0 = TH(w, x - wr - 1); ft |= (1 << 2) | (1 << 4); }
+							else if(x == wr){
+								Hs0 = TU0(w);
+								if(wr == 0 && (mode == BSA_MODE_OVERLAP || w == 0)) ft |= 1 << 15;
+								else ft |= 1;
+							} else Hs0 = TH(w, x - wr - 1);
+							{
+								const uint32_t nb = (qn[x >> 3] >> ((x & 7) * 4)) & 0xFu;
+								const bool same = TNODE(w).base == nd.base;
+								if(nb & 8u) s = BSA_EPI8_MIN;
+								else s = (((nb & 3u) == nd.base) ? a.M + ((nd.flags & 1) ? a.refbonus : 0) : a.X) + ((!same && (nb & 4u)) ? 1 : 0);
+							}
+							if(ft & (1 << 15)) s -= TU0(w);
+							const int pp = x - wr;
+							scr0 = (ft & 1) ? BSA_SCORE_MIN : s;
+							scr1 = (ft & (1 << 2)) ? BSA_SCORE_MIN : TUS(w, pp) + (PW ? TE8(w, pp) : E);
+							scr2 = (ft & (1 << 4)) ? BSA_SCORE_MIN : (PW == 2 ? TUS(w, pp) + TQ8(w, pp) : -BSA_SCORE_MIN);
+#define POA_PICK(i_, sc_) if(Hs0 + (sc_) == Hs1){ if(cov > btc || (cov == btc && (i_) == 0 && (bti & 0xFFu) != 0u)){ bti = (i_); btc = cov; bnode = w; bh = Hs0; } }
+							POA_PICK(0u, scr0) POA_PICK(1u, scr1) POA_PICK(2u, scr2)
+#undef POA_PICK
+						}
+						if(bti == 0xFFFFFFFFu){
+							const int pp = x - (int)nd.rpos;
+							if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
+							else { bt = 1u; Hs2 = 1; Hs0 = Hs1 - TUS(n, pp); }
+						} else if(bti == 0u){ bt = 0u; nidx = bnode; Hs1 = bh; Hs2 = 0; }
+						else if(bti == 1u){ bt = 2u; Hs2 = 1; }
+						else { bt = 4u; Hs2 = 1; }
+					}
+				}
+#undef TNODE
+#undef TU0
+#undef TCELL
+#undef TH
+#undef TE8
+#undef TQ8
+#undef TUS
+#undef TEDGE
+#undef EMIT
+			}
+			n = __shfl(n, 0); done = __shfl((int)done, 0) != 0;
+		}
+		if(lane == 0){
+			rs.status = status; rs.nevents = ne; rs.fin_node = n; rs.fin_x = x;
+			a.res[blockIdx.x] = rs;
+		}
+	}
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *ctx, hipStream_t *st);
+extern "C" int bsa_ctx_time_begin_internal(bsa_ctx_t *ctx, double cells, void **stop_event);
+extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *ctx, void *stop_event);
+extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *ctx, int slot, size_t bytes, void **out);
+
+static const size_t POA_LDS_MAX = 160u * 1024u - 1024u;
+static size_t poa_tile_bytes(uint32_t bw){ return (size_t)64 * bw * 4 + 256 + 64 * sizeof(bsa_poa_node_t) + 512 * sizeof(bsa_poa_edge_t); }
+static size_t poa_qn_bytes(uint32_t bw, uint32_t max_slen){ return (((size_t)max_slen + bw + 16) / 8 + 2) * 4; }
+static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max((size_t)(nl + POA_NEAR + POA_DRAIN) * bw * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
+
+extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen){
+	if(!par) return 0;
+	const bsa_rows_params_t *rp = &par->rows;
+	const uint32_t bw = (rp->bandwidth + 15u) / 16u * 16u;
+	if(bw < 16u || bw > 256u) return 0;
+	const int pw = bsa_get_piecewise(rp->gapo1, rp->gape1, rp->gapo2, rp->gape2, (int)bw);
+	// exact arithmetic is the reference's int8 arithmetic only while nothing saturates (cf. bsa_align8_x_supported): scores and
+	// gap costs small against the int8 range, the synthetic cell behind a moved row's end (bsalign.h:2357-2389) representable
+	const int m = rp->M + rp->refbonus + 1, n = -rp->X, ge = -rp->gape1, go = -rp->gapo1;
+	if(m < 0 || n < 0 || ge < 0 || go < 0 || rp->M < 0 || rp->refbonus < 0) return 0;
+	int g = go + ge;
+	if(pw == 2){
+		const int ge2 = -rp->gape2, go2 = -rp->gapo2;
+		if(ge2 < 0 || go2 < 0) return 0;
+		g = std::max(g, go2 + ge2);
+	}
+	if(m + 3 * g > 64 || n + m + g > 100) return 0;
+	if(std::min((int)rp->X, -g) - 1 - m - g < -100) return 0;
+	if((int)(bw / 16) * ge > 60) return 0;
+	for(uint32_t nl = 64; nl >= 8; nl >>= 1)
+		if(poa_front_bytes(bw, nl) + poa_qn_bytes(bw, max_slen) <= POA_LDS_MAX) return (int)nl;
+	return 0;
+}
+
+extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, size_t nnodes, const bsa_poa_edge_t *d_edges, const bsa_poa_cand_t *d_cands,
+		const bsa_poa_prog_t *d_progs, size_t nprogs, const uint8_t *d_queries, uint32_t max_slen, const bsa_sweep_params_t *par,
+		bsa_poa_result_t *d_results, bsa_poa_event_t *d_events, uint32_t *d_rows, int32_t *d_u0){
+	if(!ctx || !par || (nprogs && (!d_nodes || !d_progs || !d_queries || !d_results || !d_events))) return BSA_E_ARG;
+	if(nprogs == 0) return BSA_OK;
+	if(nprogs > 0x0FFFFFF0ull || (d_rows == nullptr) != (d_u0 == nullptr)) return BSA_E_ARG;
+	const int nl = bsa_poa_graph_supported(par, max_slen);
+	if(nl == 0) return BSA_E_UNSUPPORTED;
+	hipStream_t st;
+	int rc = bsa_ctx_get_stream_internal(ctx, &st);
+	if(rc != BSA_OK) return rc;
+	const bsa_rows_params_t *rp = &par->rows;
+	const uint32_t bw = (rp->bandwidth + 15u) / 16u * 16u;
+	const int pw = bsa_get_piecewise(rp->gapo1, rp->gape1, rp->gapo2, rp->gape2, (int)bw);
+	if(!d_rows){
+		void *ws = nullptr;
+		const size_t rb = ((size_t)nnodes * bw * 4 + 255) & ~(size_t)255;
+		rc = bsa_ctx_scratch_internal(ctx, 0, rb + (size_t)nnodes * 4 + 256, &ws);
+		if(rc != BSA_OK) return rc;
+		d_rows = (uint32_t*)ws; d_u0 = (int32_t*)((uint8_t*)ws + rb);
+	}
+	PoaArgs a;
+	a.nodes = d_nodes; a.edges = d_edges; a.cands = d_cands; a.progs = d_progs; a.queries = d_queries;
+	a.rows = d_rows; a.u0 = d_u0; a.res = d_results; a.events = d_events;
+	a.bw = bw; a.W = bw / 16; a.nl = (uint32_t)nl; a.R = (uint32_t)nl + POA_NEAR + POA_DRAIN;
+	a.qn_off = (uint32_t)poa_front_bytes(bw, (uint32_t)nl); a.tile_off = 0;
+	a.mode = rp->mode; a.M = rp->M; a.X = rp->X; a.refbonus = rp->refbonus;
+	a.O = rp->gapo1; a.E = rp->gape1; a.Q = rp->gapo2; a.P = rp->gape2; a.T = par->T;
+	{
+		// row_movx's synthetic cells (bsalign.h:2357-2389) and row_init's start (bsalign.h:2094-2126), as the POA passes the score range (bspoa.h:2226, 2240)
+		const int nt_max = a.M + a.refbonus + 1, nt_min = a.X;
+		const int goe = (pw == 2) ? a.Q + a.P : a.O + a.E;
+		a.c0 = std::min(nt_min, goe) - 1 - nt_max + goe;
+		a.d = (pw == 2) ? (a.O - a.Q) / (a.P - a.E) : (int)bw + 1;
+		a.xp = (pw == 2) ? (a.Q - a.O) / (a.E - a.P) : 1;
+		const int type = a.mode & 3;
+		a.head_u0 = (type == BSA_MODE_OVERLAP) ? 0 : nt_max - nt_min;
+	}
+	const size_t lds = (size_t)a.qn_off + poa_qn_bytes(bw, max_slen);
+	void *stop = nullptr;
+	rc = bsa_ctx_time_begin_internal(ctx, 0.0, &stop);
+	if(rc != BSA_OK) return rc;
+#define POA_LAUNCH(PWV) do {                                                                                                              \
+		if(hipFuncSetAttribute((const void*)k_poa_wf<PWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BSA_E_HIP; \
+		hipLaunchKernelGGL((k_poa_wf<PWV>), dim3((uint32_t)nprogs), dim3(64), lds, st, a); } while(0)
+	if(pw == 0) POA_LAUNCH(0); else if(pw == 1) POA_LAUNCH(1); else POA_LAUNCH(2);
+#undef POA_LAUNCH
+	if(hipGetLastError() != hipSuccess) return BSA_E_HIP;
+	return bsa_ctx_time_end_internal(ctx, stop);
+}
+
+namespace {
+struct PoaDevBuf {
+	void *p = nullptr;
+	~PoaDevBuf(){ if(p) (void)hipFree(p); }
+	hipError_t alloc(size_t n){ return hipMalloc(&p, n ? n : 16); }
+};
+}
+
+extern "C" int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, size_t nnodes, const bsa_poa_edge_t *edges, size_t nedges,
+		const bsa_poa_cand_t *cands, size_t ncands, const bsa_poa_prog_t *progs, size_t nprogs,
+		const uint8_t *queries, size_t query_bytes, const bsa_sweep_params_t *par,
+		bsa_poa_result_t *results, bsa_poa_event_t *events, size_t events_cap, bsa_poa_cell_t *rows_out, int32_t *u0_out){
+	if(!ctx || !par || !results || (nprogs && (!nodes || !progs || !queries || !events))) return BSA_E_ARG;
+	if(nprogs == 0) return BSA_OK;
+	uint32_t max_slen = 0;
+	for(size_t k = 0; k < nprogs; k++){
+		const bsa_poa_prog_t &pg = progs[k];
+		if((size_t)pg.first_node + pg.nnodes > nnodes || (size_t)pg.first_edge + pg.nedges > nedges || (size_t)pg.first_cand + pg.ncands > ncands) return BSA_E_ARG;
+		if(pg.query_off + pg.slen > query_bytes || pg.first_event + pg.event_cap > events_cap) return BSA_E_ARG;
+		max_slen = std::max(max_slen, pg.slen);
+		for(size_t i = 0; i < pg.nnodes; i++){
+			const bsa_poa_node_t &nd = nodes[pg.first_node + i];
+			for(int j = 0; j < 2; j++) if((nd.in[j].toff_kind & BSA_POA_IN_PRESENT) && nd.in[j].src >= i) return BSA_E_ARG;
+			if((size_t)nd.first_in + nd.n_in > pg.nedges) return BSA_E_ARG;
+			for(size_t e = 0; e < nd.n_in; e++) if(edges[pg.first_edge + nd.first_in + e].src >= i) return BSA_E_ARG;
+		}
+		for(size_t i = 0; i < pg.ncands; i++) if(cands[pg.first_cand + i].node >= pg.nnodes) return BSA_E_ARG;
+	}
+	if(bsa_poa_graph_supported(par, max_slen) == 0) return BSA_E_UNSUPPORTED;
+	hipStream_t st;
+	int rc = bsa_ctx_get_stream_internal(ctx, &st);
+	if(rc != BSA_OK) return rc;
+	const uint32_t bw = (par->rows.bandwidth + 15u) / 16u * 16u;
+	PoaDevBuf dn, de, dc, dp, dq, dr, dv, drows, du0;
+#define PCHK(x) do { if((x) != hipSuccess) return BSA_E_HIP; } while(0)
+	PCHK(dn.alloc(nnodes * sizeof(bsa_poa_node_t))); PCHK(de.alloc(nedges * sizeof(bsa_poa_edge_t))); PCHK(dc.alloc(ncands * sizeof(bsa_poa_cand_t)));
+	PCHK(dp.alloc(nprogs * sizeof(bsa_poa_prog_t))); PCHK(dq.alloc(query_bytes + 64)); PCHK(dr.alloc(nprogs * sizeof(bsa_poa_result_t)));
+	PCHK(dv.alloc(events_cap * sizeof(bsa_poa_event_t))); PCHK(drows.alloc(nnodes * bw * 4)); PCHK(du0.alloc(nnodes * 4));
+	PCHK(hipMemcpyAsync(dn.p, nodes, nnodes * sizeof(bsa_poa_node_t), hipMemcpyHostToDevice, st));
+	if(nedges) PCHK(hipMemcpyAsync(de.p, edges, nedges * sizeof(bsa_poa_edge_t), hipMemcpyHostToDevice, st));
+	if(ncands) PCHK(hipMemcpyAsync(dc.p, cands, ncands * sizeof(bsa_poa_cand_t), hipMemcpyHostToDevice, st));
+	PCHK(hipMemcpyAsync(dp.p, progs, nprogs * sizeof(bsa_poa_prog_t), hipMemcpyHostToDevice, st));
+	PCHK(hipMemcpyAsync(dq.p, queries, query_bytes, hipMemcpyHostToDevice, st));
+	rc = bsa_poa_graph_run(ctx, (const bsa_poa_node_t*)dn.p, nnodes, (const bsa_poa_edge_t*)de.p, (const bsa_poa_cand_t*)dc.p, (const bsa_poa_prog_t*)dp.p, nprogs,
+		(const uint8_t*)dq.p, max_slen, par, (bsa_poa_result_t*)dr.p, (bsa_poa_event_t*)dv.p, (uint32_t*)drows.p, (int32_t*)du0.p);
+	if(rc != BSA_OK) return rc;
+	PCHK(hipMemcpyAsync(results, dr.p, nprogs * sizeof(bsa_poa_result_t), hipMemcpyDeviceToHost, st));
+	PCHK(hipStreamSynchronize(st));
+	for(size_t k = 0; k < nprogs; k++){
+		const size_t ne = results[k].nevents > 0 ? (size_t)results[k].nevents : 0;
+		if(ne) PCHK(hipMemcpyAsync(events + progs[k].first_event, (const bsa_poa_event_t*)dv.p + progs[k].first_event, ne * sizeof(bsa_poa_event_t), hipMemcpyDeviceToHost, st));
+	}
+	if(rows_out && u0_out){
+		std::vector<uint32_t> cells(nnodes * bw);
+		PCHK(hipMemcpyAsync(cells.data(), drows.p, nnodes * bw * 4, hipMemcpyDeviceToHost, st));
+		PCHK(hipMemcpyAsync(u0_out, du0.p, nnodes * 4, hipMemcpyDeviceToHost, st));
+		PCHK(hipStreamSynchronize(st));
+		for(size_t k = 0; k < nprogs; k++){
+			for(size_t i = 0; i < progs[k].nnodes; i++){
+				const size_t nidx = progs[k].first_node + i;
+				// the head's cells are relative to its H(0), every other row's to its ubegs[0] (the same number there)
+				const int base = (i == 0) ? 0 : u0_out[nidx];
+				for(uint32_t p = 0; p < bw; p++){
+					const uint32_t cw = cells[nidx * bw + p];
+					bsa_poa_cell_t &o = rows_out[nidx * bw + p];
+					o.h = base + (int)(int16_t)(cw & 0xFFFFu); o.e = (int8_t)(cw >> 16); o.q = (int8_t)(cw >> 24); o.tag = 0;
+				}
+			}
+		}
+	}
+	PCHK(hipStreamSynchronize(st));
+#undef PCHK
+	return BSA_OK;
+}

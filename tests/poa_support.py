@@ -267,9 +267,9 @@ def tasks_to_graph(tasks):
             a = upd(tl[0]) if len(tl) > 0 else none
             b = upd(tl[1]) if len(tl) > 1 else none
         else:
-            recs.append((rpos[m], 0xFFFFFFFF, 0, 0, base[m], bonus[m]) + upd(tl[0]) + upd(tl[1]) + (0, 0)); blocks.append(0)
+            recs.append((rpos[m], 0xFFFFFFFF, first_edge, 0, base[m], bonus[m]) + upd(tl[0]) + upd(tl[1]) + (0, 0)); blocks.append(0)
             for t in tl[2:-1]:
-                recs.append((rpos[m], 0xFFFFFFFF, 0, 0, base[m], bonus[m]) + (len(recs) - 1, 0, IN_PRESENT | IN_MERGE) + upd(t) + (0, 0)); blocks.append(0)
+                recs.append((rpos[m], 0xFFFFFFFF, first_edge, 0, base[m], bonus[m]) + (len(recs) - 1, 0, IN_PRESENT | IN_MERGE) + upd(t) + (0, 0)); blocks.append(0)
             a = (len(recs) - 1, 0, IN_PRESENT | IN_MERGE)
             b = upd(tl[-1])
         loc[m] = len(recs)

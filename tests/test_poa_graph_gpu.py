@@ -1,0 +1,87 @@
+"""GPU parity of the wavefront sweep + device traceback (bsa_poa_graph_host; bsalign_amd/csrc/bsa_poa_wf.hip):
+* every row of every recorded program of the real end_bspoa (tests/golden/poa_sweep.npz), converted back into the reference's
+  row blocks, byte for byte against the lane-exact oracle (orc_sweep_run) and against the reference's own row hash;
+* the best end cell against the reference's;
+* the traceback steps against the scalar statement of the walk (orc_wf_trace) on the same rows."""
+import numpy as np
+import pytest
+
+import poa_support as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _sweep_params(p, bandwidth):
+    import bsalign_amd as B
+    sp = B.SweepParams()
+    sp.rows = B.RowsParams(p["alnmode"], bandwidth, p["M"], p["X"], p["refbonus"], p["O"], p["E"], p["Q"], p["P"])
+    sp.T = p["T"]
+    return sp
+
+
+def _prog(nodes, edges, cands, slen, first_event=0, base=(0, 0, 0), qoff=0):
+    cap = 4 * (slen + len(nodes)) + 64
+    pr = np.zeros(1, P.WF_PROG)
+    pr[0] = (base[0], len(nodes), base[1], len(edges), base[2], len(cands), slen, cap, qoff, first_event)
+    return pr, cap
+
+
+def _check_program(ctx, p, pg, want_trace=True):
+    bw, pw = pg["bandwidth"], pg["piecewise"]
+    nodes, edges, cands, blocks = P.tasks_to_graph(pg["tasks"])
+    pr, cap = _prog(nodes, edges, cands, pg["slen"])
+    res, ev, rows, u0 = ctx.poa_graph_host(nodes, edges, cands, pr, pg["query"], _sweep_params(p, bw), cap, want_rows=True)
+    orows, ou0 = P.oracle_wf_forward(nodes, pg["query"], p, bw)
+    bad = np.nonzero((rows.view(np.uint64)[:, :] != orows.view(np.uint64)[:, :]).any(axis=1))[0]
+    assert len(bad) == 0, ("first differing node", int(bad[0]), "of", len(nodes), "cell", int(np.nonzero(rows[bad[0]] != orows[bad[0]])[0][0]))
+    assert np.array_equal(u0, ou0)
+    mine = P.wf_rows_to_blocks(rows, u0, blocks, pg["nblocks"], bw, pw)
+    assert P.hash_node_blocks(mine, pg["nblocks"], bw, pw, pg["tasks"]) == pg["rows_hash"]
+    r = res[0]
+    gidx = int(nodes[int(r["maxidx"])]["gnode"]) if r["maxidx"] >= 0 else -1
+    assert (int(r["maxscr"]), gidx, int(r["maxoff"])) == (pg["maxscr"], pg["maxidx"], pg["maxoff"])
+    if want_trace:
+        n, oev, fin = P.oracle_wf_trace(nodes, edges, pg["query"], p, bw, orows, ou0, 0, int(r["maxidx"]), int(r["maxoff"]))
+        assert (r["status"] == 0) == (n >= 0), (int(r["status"]), n)
+        if n >= 0:
+            assert int(r["nevents"]) == n and np.array_equal(ev[:n], oev)
+            assert (int(r["fin_node"]), int(r["fin_x"])) == (int(fin[0]), int(fin[1]))
+
+
+def test_golden_programs_rows_best_cell_and_walk(ctx):
+    n = 0
+    for case in P.load_golden():
+        for pg in case["programs"]:
+            if pg["bandwidth"] > 256:
+                continue
+            _check_program(ctx, case["par"], pg)
+            n += 1
+    assert n >= 30
+
+
+def test_many_programs_in_one_launch(ctx):
+    """all programs of a case that share a bandwidth as ONE launch (many windows side by side), three copies of each"""
+    import bsalign_amd as B
+    for case in P.load_golden()[:3]:
+        p = case["par"]
+        by_bw = {}
+        for pg in case["programs"]:
+            if pg["bandwidth"] <= 256:
+                by_bw.setdefault(pg["bandwidth"], []).append(pg)
+        for bw, pgs in by_bw.items():
+            N, E, Cd, PR, Q, want = [], [], [], [], [], []
+            n0 = e0 = c0 = q0 = v0 = 0
+            for rep in range(3):
+                for pg in pgs:
+                    nodes, edges, cands, blocks = P.tasks_to_graph(pg["tasks"])
+                    cap = 4 * (pg["slen"] + len(nodes)) + 64
+                    pr = np.zeros(1, P.WF_PROG)
+                    pr[0] = (n0, len(nodes), e0, len(edges), c0, len(cands), pg["slen"], cap, q0, v0)
+                    N.append(nodes); E.append(edges); Cd.append(cands); PR.append(pr); Q.append(pg["query"]); want.append((pg, nodes))
+                    n0 += len(nodes); e0 += len(edges); c0 += len(cands); q0 += pg["slen"]; v0 += cap
+            res, ev, _, _ = ctx.poa_graph_host(np.concatenate(N), np.concatenate(E), np.concatenate(Cd), np.concatenate(PR), np.concatenate(Q),
+                                               _sweep_params(p, bw), v0)
+            for k, (pg, nodes) in enumerate(want):
+                r = res[k]
+                assert r["status"] == 0
+                assert (int(r["maxscr"]), int(nodes[int(r["maxidx"])]["gnode"]), int(r["maxoff"])) == (pg["maxscr"], pg["maxidx"], pg["maxoff"])
