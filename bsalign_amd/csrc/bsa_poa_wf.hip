@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	__syncthreads();
 
 	// ---- forward pass ----
+	const unsigned long long tick0 = wall_clock64();
 	int m = -NL;                 // nodes below m are complete; the nodes in flight are m .. m + NL - 1
 	int dr = 0;                  // rows below dr are in HBM
 	int cur = lane - NL, p = 0;
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		if(ok > bkey){ bkey = ok; boff = oo; }
 	}
 	bsa_poa_result_t rs;
-	rs.reserved = 0; rs.nevents = 0; rs.fin_node = -1; rs.fin_x = -1; rs.status = BSA_POA_ST_OK;
+	rs.reserved = (int)(wall_clock64() - tick0); rs.nevents = 0;       // forward pass + best end cell, in ticks of the 100 MHz counter rs.fin_node = -1; rs.fin_x = -1; rs.status = BSA_POA_ST_OK;
 	if(bkey == (long long)0x8000000000000000ull){
 		rs.maxscr = BSA_SCORE_MIN; rs.maxidx = -1; rs.maxoff = -1; rs.status = BSA_POA_ST_NOCAND;
 		if(lane == 0) a.res[blockIdx.x] = rs;
@@ -602,8 +603,8 @@ extern "C" int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, s
 		for(size_t k = 0; k < nprogs; k++){
 			for(size_t i = 0; i < progs[k].nnodes; i++){
 				const size_t nidx = progs[k].first_node + i;
-				// the head's cells are relative to its H(0), every other row's to its ubegs[0] (the same number there)
-				const int base = (i == 0) ? 0 : u0_out[nidx];
+				// the head's cells are relative to its H(0) (row_init: 0 in overlap mode, gapo1 + gape1 otherwise), every other row's to its ubegs[0] (the same number there)
+				const int base = (i == 0) ? (((par->rows.mode & 3) == BSA_MODE_OVERLAP) ? 0 : par->rows.gapo1 + par->rows.gape1) : u0_out[nidx];
 				for(uint32_t p = 0; p < bw; p++){
 					const uint32_t cw = cells[nidx * bw + p];
 					bsa_poa_cell_t &o = rows_out[nidx * bw + p];

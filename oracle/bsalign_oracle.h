@@ -131,6 +131,10 @@ typedef struct { uint32_t src, cov, src_rpos, reserved; } orc_wf_edge_t;
 typedef struct { uint32_t node, kind; } orc_wf_cand_t;                         /* kind 0: edge node -> tail, 1: node reaches the read end */
 typedef struct { uint32_t node; int32_t x; uint32_t bt; } orc_wf_event_t;
 typedef struct { int32_t mode; uint32_t bandwidth; int8_t M, X, refbonus, gapo1, gape1, gapo2, gape2, pad; int32_t T; } orc_wf_params_t;   /* == bsa_sweep_params_t */
+typedef struct { int32_t maxscr, maxidx, maxoff, status, nevents, fin_node, fin_x, reserved; } orc_wf_result_t;     /* == bsa_poa_result_t */
+int orc_wf_backend(void *user, const orc_wf_node_t *nodes, size_t nnodes, const orc_wf_edge_t *edges, size_t nedges,
+		const orc_wf_cand_t *cands, size_t ncands, const uint8_t *query, uint32_t slen,
+		const orc_wf_params_t *par, orc_wf_result_t *res, orc_wf_event_t *events, size_t events_cap);
 void orc_wf_init_row(const orc_wf_params_t *par, orc_wf_cell_t *row, int32_t *u0);
 void orc_wf_forward(const orc_wf_node_t *nodes, uint32_t nnodes, const uint8_t *query, uint32_t slen,
 		const orc_wf_params_t *par, orc_wf_cell_t *rows, int32_t *u0);

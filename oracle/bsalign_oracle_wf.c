@@ -324,3 +324,32 @@ long orc_wf_trace(const orc_wf_node_t *nodes, const orc_wf_edge_t *edges, const 
 #undef US
 #undef EMIT
 }
+
+/* the three steps above behind the signature of the binding's graph backend (bsa_poa_graph_backend_fn of
+ * include/bsalign_poa_adapter.h): what the device's bsa_poa_graph_host does, on the CPU, for the tests */
+int orc_wf_backend(void *user, const orc_wf_node_t *nodes, size_t nnodes, const orc_wf_edge_t *edges, size_t nedges,
+		const orc_wf_cand_t *cands, size_t ncands, const uint8_t *query, uint32_t slen,
+		const orc_wf_params_t *par, orc_wf_result_t *res, orc_wf_event_t *events, size_t events_cap){
+	const uint32_t bw = (par->bandwidth + NL - 1) / NL * NL;
+	orc_wf_cell_t *rows;
+	int32_t *u0, fin[2] = {-1, -1};
+	orc_sweep_result_t best;
+	long n;
+	(void)user; (void)nedges;
+	if(bw > 256) return -6;                 /* BSA_E_UNSUPPORTED: the device declines these as well (bsa_poa_graph_supported) */
+	rows = (orc_wf_cell_t*)malloc((size_t)nnodes * bw * sizeof(orc_wf_cell_t));
+	u0 = (int32_t*)malloc((size_t)nnodes * sizeof(int32_t));
+	orc_wf_forward(nodes, (uint32_t)nnodes, query, slen, par, rows, u0);
+	orc_wf_best(nodes, cands, (uint32_t)ncands, slen, par, rows, &best);
+	memset(res, 0, sizeof(*res));
+	res->maxscr = best.maxscr; res->maxidx = best.maxidx; res->maxoff = best.maxoff;
+	res->fin_node = -1; res->fin_x = -1;
+	if(best.maxidx < 0) res->status = 3;
+	else {
+		n = orc_wf_trace(nodes, edges, query, slen, par, rows, u0, 0, (uint32_t)best.maxidx, best.maxoff, events, (long)events_cap, fin);
+		if(n == -1) res->status = 1; else if(n == -2) res->status = 2;
+		else { res->nevents = (int32_t)n; res->fin_node = fin[0]; res->fin_x = fin[1]; }
+	}
+	free(rows); free(u0);
+	return 0;
+}

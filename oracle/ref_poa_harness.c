@@ -19,6 +19,14 @@
  *           ref_poa_set_batcher), which runs read r of all windows as one device launch.  No re-run of the reference's
  *           core here: the test compares every window's consensus / MSA with a mode-0 run of the same reads.
  *
+ *   mode 5  the GRAPH form of the binding in the shadow of the reference: bsa_poa_flatten_graph + a backend supplied by the test
+ *           (the oracle's orc_wf_backend on the CPU, bsa_poa_graph_host on the GPU) give the best end cell and the steps of the
+ *           traceback; then the reference's own align_rd_bspoacore and alignment2graph_bspoa run on the same graph state -- the
+ *           latter with the TEST-ONLY recording hook of oracle/bspoa_trace_record.diff (build _ref/libbsref_trace.so) -- and
+ *           best cell, every (node, x, bt) step and the end of the walk are compared; the reference's results are the ones kept.
+ *   mode 6  the graph form as the product runs it: flatten, backend, bsa_poa_apply_trace; nothing of the reference's sweep or
+ *           walk runs.  The test compares consensus / MSA with a mode-0 run.
+ *
  * Recorded per read: the seqalign_result_t of align_rd_bspoa, the program (tasks), the best end cell and a hash of
  * the reference's row blocks -- tests/golden/make_golden_poa.py turns these into the committed fixtures.
  */
@@ -78,6 +86,24 @@ __attribute__((visibility("hidden"))) int bsa_sweep_host(bsa_ctx_t *ctx, const b
 	return BSA_E_UNSUPPORTED;       /* no device library attached */
 }
 
+typedef int (*graph_host_fn)(bsa_ctx_t*, const bsa_poa_node_t*, size_t, const bsa_poa_edge_t*, size_t, const bsa_poa_cand_t*, size_t, const bsa_poa_prog_t*, size_t,
+		const uint8_t*, size_t, const bsa_sweep_params_t*, bsa_poa_result_t*, bsa_poa_event_t*, size_t, bsa_poa_cell_t*, int32_t*);
+static graph_host_fn g_graph_host = NULL;
+void ref_poa_set_graph_host(void *graph_host_addr, void *ctx){ g_graph_host = (graph_host_fn)graph_host_addr; g_device_ctx = ctx; }
+__attribute__((visibility("hidden"))) int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, size_t nnodes, const bsa_poa_edge_t *edges, size_t nedges,
+		const bsa_poa_cand_t *cands, size_t ncands, const bsa_poa_prog_t *progs, size_t nprogs, const uint8_t *queries, size_t query_bytes,
+		const bsa_sweep_params_t *par, bsa_poa_result_t *results, bsa_poa_event_t *events, size_t events_cap, bsa_poa_cell_t *rows_out, int32_t *u0_out){
+	if(g_graph_host) return g_graph_host(ctx, nodes, nnodes, edges, nedges, cands, ncands, progs, nprogs, queries, query_bytes, par, results, events, events_cap, rows_out, u0_out);
+	return BSA_E_UNSUPPORTED;
+}
+/* graph-form backend of modes 5 / 6: the oracle's orc_wf_backend (CPU tests), or NULL = the device through bsa_poa_graph_backend_hip */
+static bsa_poa_graph_backend_fn g_graph_backend = NULL;
+static void *g_graph_backend_user = NULL;
+void ref_poa_set_graph_backend(void *fn, void *user){ g_graph_backend = (bsa_poa_graph_backend_fn)fn; g_graph_backend_user = user; }
+/* the product's lock-step batcher, graph form (bsa_poa_batcher_submit_graph) */
+static bsa_poa_graph_backend_fn g_batch_submit_graph = NULL;
+void ref_poa_set_batcher_graph(void *submit_graph_addr){ g_batch_submit_graph = (bsa_poa_graph_backend_fn)submit_graph_addr; }
+
 /* the product's batcher (bsalign_hip.h: bsa_sweep_batcher_submit / _leave), attached by the GPU test */
 typedef void (*batch_leave_fn)(void *batcher);
 static bsa_poa_backend_fn g_batch_submit = NULL;
@@ -98,7 +124,11 @@ typedef struct {
 	uint64_t task_off;          /* into poa->tasks */
 	uint64_t query_off;         /* into poa->queries */
 	uint64_t rows_hash;         /* FNV-1a over the used bytes of every written node block of the reference's memp */
-	int mismatch;               /* mode 2: bit 0 best end cell differs, bit 1 some row block differs */
+	int mismatch;               /* mode 2: bit 0 best end cell differs, bit 1 some row block differs; mode 5: bit 2 a step of the walk differs, bit 3 its end */
+	/* graph form (modes 5 / 6, when recording): slices of poa->gnodes / gedges / gcands / gtrace */
+	uint64_t node_off, edge_off, cand_off, trace_off;
+	uint32_t nnodes, nedges, ncands, ntrace;
+	int32_t fin_gnode, fin_x, maxidx_local;
 } poa_read_rec_t;
 
 typedef struct {
@@ -108,6 +138,11 @@ typedef struct {
 	poa_read_rec_t *recs; size_t nrec, caprec;
 	bsa_row_task_t *tasks; size_t ntasks, captasks;
 	uint8_t *queries; size_t nq, capq;
+	bsa_poa_node_t *gnodes; size_t ngn, capgn;
+	bsa_poa_edge_t *gedges; size_t nge, capge;
+	bsa_poa_cand_t *gcands; size_t ngc, capgc;
+	bsa_poa_event_t *gtrace; size_t ngt, capgt;       /* the REFERENCE's steps (node = graph node index) */
+	bsa_poa_event_t *cur_trace; size_t ncur, capcur;  /* steps of the read being aligned, filled by the recording hook */
 	int mode, record_programs;
 	double core_seconds;        /* mode 1: wall time inside the reference's align_rd_bspoacore */
 	uint64_t core_updates;      /* mode 1: row updates (edges) those calls processed */
@@ -157,6 +192,7 @@ void ref_poa_destroy(void *vp){
 	free_bspoa(p->g);
 	bsa_poa_adapter_free(&p->ad);
 	free(p->recs); free(p->tasks); free(p->queries);
+	free(p->gnodes); free(p->gedges); free(p->gcands); free(p->gtrace); free(p->cur_trace);
 	free(p);
 }
 
@@ -170,7 +206,20 @@ static void record_read(ref_poa_t *p, seqalign_result_t rs, int mismatch, uint64
 	r->bandwidth = g->bandwidth; r->slen = g->slen; r->qb = g->qb; r->nblocks = (uint32_t)g->mmcnt; r->piecewise = (uint32_t)g->piecewise;
 	r->rows_hash = rows_hash; r->mismatch = mismatch;
 	r->task_off = p->ntasks; r->query_off = p->nq;
-	if(p->mode >= 1 && p->record_programs){      /* (mode 1: the program the adapter would submit, recorded beside the reference's own sweep) */
+	if(p->mode == 5 && p->record_programs){
+#define APPEND(dst, n, cap, src, cnt, type) do { if((n) + (cnt) > (cap)){ (cap) = ((n) + (cnt)) * 2 + 64; (dst) = (type*)realloc((dst), (cap) * sizeof(type)); } \
+		memcpy((dst) + (n), (src), (cnt) * sizeof(type)); (n) += (cnt); } while(0)
+		r->node_off = p->ngn; r->edge_off = p->nge; r->cand_off = p->ngc; r->trace_off = p->ngt;
+		r->nnodes = (uint32_t)p->ad.nnodes; r->nedges = (uint32_t)p->ad.nedges; r->ncands = (uint32_t)p->ad.ncands; r->ntrace = (uint32_t)p->ncur;
+		APPEND(p->gnodes, p->ngn, p->capgn, p->ad.nodes, p->ad.nnodes, bsa_poa_node_t);
+		APPEND(p->gedges, p->nge, p->capge, p->ad.edges, p->ad.nedges, bsa_poa_edge_t);
+		APPEND(p->gcands, p->ngc, p->capgc, p->ad.cands, p->ad.ncands, bsa_poa_cand_t);
+		APPEND(p->gtrace, p->ngt, p->capgt, p->cur_trace, p->ncur, bsa_poa_event_t);
+#undef APPEND
+		if(p->nq + g->slen > p->capq){ p->capq = (p->nq + g->slen) * 2; p->queries = (uint8_t*)realloc(p->queries, p->capq); }
+		memcpy(p->queries + p->nq, g->qseq->buffer + g->qb, g->slen);
+		p->nq += g->slen;
+	} else if(p->mode >= 1 && p->mode <= 4 && p->record_programs){      /* (mode 1: the program the adapter would submit, recorded beside the reference's own sweep) */
 		r->ntasks = (uint32_t)p->ad.ntasks;
 		if(p->ntasks + p->ad.ntasks > p->captasks){
 			p->captasks = (p->ntasks + p->ad.ntasks) * 2;
@@ -182,6 +231,21 @@ static void record_read(ref_poa_t *p, seqalign_result_t rs, int mismatch, uint64
 		memcpy(p->queries + p->nq, g->qseq->buffer + g->qb, g->slen);
 		p->nq += g->slen;
 	}
+}
+
+#ifdef REF_TRACE_RECORD
+static void harness_trace_hook(void *user, u4i node, int x, u4i bt){
+	ref_poa_t *p = (ref_poa_t*)user;
+	if(p->ncur == p->capcur){ p->capcur = p->capcur ? p->capcur * 2 : 4096; p->cur_trace = (bsa_poa_event_t*)realloc(p->cur_trace, p->capcur * sizeof(bsa_poa_event_t)); }
+	p->cur_trace[p->ncur].node = node; p->cur_trace[p->ncur].x = x; p->cur_trace[p->ncur].bt = bt; p->ncur ++;
+}
+#endif
+int ref_poa_can_record_trace(void){
+#ifdef REF_TRACE_RECORD
+	return 1;
+#else
+	return 0;
+#endif
 }
 
 /* orchestration of align_rd_bspoa (bspoa.h:2620-2667), realn == 0 entry only (the one end_bspoa uses) */
@@ -202,8 +266,60 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
 	sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
 	prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
-	if(p->mode == 4){
+	if(p->mode == 6 || p->mode == 7){
+		/* the product's path: graph form, the walk applied by the binding */
 		score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
+		if(p->ad.have_trace){
+			rs = bsa_poa_apply_trace(g, par, rid, 0, head, tail, &p->ad);
+			rs.qb += g->qb; rs.qe += g->qb; rs.score = score;
+			for(k=0;k<g->todels->size;k++){
+				chg_edge_bspoa(g, ref_bspoanodev(g->nodes, g->todels->buffer[k] >> 32), ref_bspoanodev(g->nodes, g->todels->buffer[k] & MAX_U4), -1, NULL);
+			}
+			clear_u8v(g->todels);
+			record_read(p, rs, 0, 0);
+			return rs;
+		}
+	} else if(p->mode == 5){
+		/* graph form in the shadow of the reference */
+		int a_scr = 0, a_idx = -1, a_off = -1, have;
+		p->ncur = 0;
+		score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
+		have = p->ad.have_trace;
+		if(have){ a_scr = g->maxscr; a_idx = g->maxidx; a_off = g->maxoff; }
+		for(k=0;k<g->sels->size;k++) ref_bspoanodev(g->nodes, g->sels->buffer[k])->vst = 0;
+		g->maxscr = SEQALIGN_SCORE_MIN; g->maxidx = -1; g->maxoff = -1;
+		score = align_rd_bspoacore(g, par, rid, head, tail);
+		if(have && (a_scr != g->maxscr || a_idx != g->maxidx || a_off != g->maxoff)) mismatch |= 1;
+		rows_hash = hash_node_blocks(g, tail);
+#ifdef REF_TRACE_RECORD
+		bspoa_trace_hook = harness_trace_hook; bspoa_trace_hook_user = p;
+#endif
+		rs = alignment2graph_bspoa(g, par, rid, 0, head, tail, g->maxidx, g->maxoff, NULL);
+#ifdef REF_TRACE_RECORD
+		bspoa_trace_hook = NULL;
+		if(have){
+			size_t i;
+			if((size_t)p->ad.res.nevents != p->ncur) mismatch |= 4;
+			else for(i = 0; i < p->ncur; i++){
+				const bsa_poa_event_t *m = p->ad.events + i, *r = p->cur_trace + i;
+				if(p->ad.nodes[m->node].gnode != r->node || m->x != r->x || m->bt != r->bt){ mismatch |= 4; break; }
+			}
+			/* the end of the walk is what alignment2graph_bspoa reports as rs.qb / rs.tb (bspoa.h:2307-2311) */
+			if(p->ad.res.fin_x != rs.qb - Int(g->qb) || ref_bspoanodev(g->nodes, p->ad.nodes[p->ad.res.fin_node].gnode)->cpos != rs.tb) mismatch |= 8;
+		}
+#endif
+		rs.qb += g->qb; rs.qe += g->qb; rs.score = score;
+		for(k=0;k<g->todels->size;k++){
+			chg_edge_bspoa(g, ref_bspoanodev(g->nodes, g->todels->buffer[k] >> 32), ref_bspoanodev(g->nodes, g->todels->buffer[k] & MAX_U4), -1, NULL);
+		}
+		clear_u8v(g->todels);
+		if(!have){ p->ad.nnodes = p->ad.nedges = p->ad.ncands = 0; p->ncur = 0; }
+		record_read(p, rs, mismatch, rows_hash);
+		if(p->nrec){ poa_read_rec_t *r = p->recs + p->nrec - 1; r->fin_gnode = have ? (int32_t)p->ad.nodes[p->ad.res.fin_node].gnode : -1; r->fin_x = have ? p->ad.res.fin_x : -1; r->maxidx_local = have ? p->ad.res.maxidx : -1; }
+		return rs;
+	}
+	if(p->mode == 4 || p->mode == 6 || p->mode == 7){
+		if(p->mode == 4) score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
 	} else if(p->mode >= 2){
 		int a_scr, a_idx, a_off;
 		const size_t used = (size_t)g->bandwidth * (g->piecewise + 1) + (WORDSIZE + 1) * sizeof(int);
@@ -306,12 +422,18 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 	int k, bad = 0;
 	size_t i;
 	p->mode = mode; p->record_programs = record_programs;
-	p->nrec = 0; p->ntasks = 0; p->nq = 0;
+	p->nrec = 0; p->ntasks = 0; p->nq = 0; p->ngn = p->nge = p->ngc = p->ngt = 0;
 	p->core_seconds = 0; p->core_updates = 0; p->core_merges = 0;
 	p->sweep = (orc_sweep_fn)sweep_fn;
 	bsa_poa_adapter_free(&p->ad);
 	if(mode == 3) bsa_poa_adapter_init(&p->ad, bsa_poa_backend_hip, g_device_ctx);
 	else if(mode == 4) bsa_poa_adapter_init(&p->ad, g_batch_submit, g_batcher);
+	else if(mode == 5 || mode == 6){
+		/* graph form; reads it declines (whole-read bands) take the rows form: the oracle's sweep on the CPU, the device's otherwise */
+		if(g_graph_backend) bsa_poa_adapter_init_graph(&p->ad, g_graph_backend, sweep_fn ? backend_oracle : bsa_poa_backend_hip, sweep_fn ? (void*)p : g_device_ctx);
+		else bsa_poa_adapter_init_graph(&p->ad, bsa_poa_graph_backend_hip, bsa_poa_backend_hip, g_device_ctx);
+		if(g_graph_backend && !sweep_fn) p->ad.user = g_graph_backend_user;
+	} else if(mode == 7) bsa_poa_adapter_init_graph(&p->ad, g_batch_submit_graph, g_batch_submit, g_batcher);
 	else bsa_poa_adapter_init(&p->ad, backend_oracle, p);
 	for(k = 0; k < nreads; k++) if(lens[k] > maxlen) maxlen = lens[k];
 	buf = (char*)malloc(maxlen + 1);
@@ -339,7 +461,7 @@ typedef struct {
 static void *many_thread(void *vp){
 	many_job_t *j = (many_job_t*)vp;
 	j->rc = ref_poa_run(j->handle, j->reads, j->offs, j->lens, j->nreads, j->mode, NULL, j->record);
-	if(j->mode == 4 && g_batch_leave) g_batch_leave(g_batcher);       /* this window submits nothing more */
+	if((j->mode == 4 || j->mode == 7) && g_batch_leave) g_batch_leave(g_batcher);       /* this window submits nothing more */
 	return NULL;
 }
 
@@ -358,13 +480,14 @@ int ref_poa_run_many(void **handles, int nwin, const uint8_t *reads, const uint6
 	many_job_t *jobs = (many_job_t*)calloc((size_t)nwin, sizeof(many_job_t));
 	pthread_t *th = (pthread_t*)calloc((size_t)nwin, sizeof(pthread_t));
 	int w, bad = 0;
-	if(mode == 4 && (!g_batch_submit || !g_batcher)){ free(jobs); free(th); return -1; }
+	if((mode == 4 || mode == 7) && (!g_batch_submit || !g_batcher)){ free(jobs); free(th); return -1; }
+	if(mode == 7 && !g_batch_submit_graph){ free(jobs); free(th); return -1; }
 	cal_permutation_bspoa(MAX_LOG_CACHE, 0);                             /* fill the reference's lazily built log table before any thread reads it (bspoa.h:3391-3401) */
 	for(w = 0; w < nwin; w++){
 		jobs[w].handle = handles[w]; jobs[w].reads = reads; jobs[w].offs = offs + first[w]; jobs[w].lens = lens + first[w];
 		jobs[w].nreads = count[w]; jobs[w].mode = mode; jobs[w].record = record;
 	}
-	if(mode == 4 || threads >= nwin){
+	if(mode == 4 || mode == 7 || threads >= nwin){
 		for(w = 0; w < nwin; w++) pthread_create(&th[w], NULL, many_thread, &jobs[w]);
 		for(w = 0; w < nwin; w++) pthread_join(th[w], NULL);
 	} else {
@@ -500,4 +623,27 @@ int ref_msa_load_binary(const uint8_t *in, uint64_t len, uint32_t *nrds, uint32_
 	free_string(md);
 	free_bspoa(g);
 	return rc;
+}
+
+/* ---- graph-form records (mode 5): per read the program the binding built and the steps the REFERENCE's walk took ---- */
+/* out: node_off, edge_off, cand_off, trace_off (u64 x 4), then nnodes, nedges, ncands, ntrace, fin_gnode, fin_x, maxidx_local as int64 */
+void ref_poa_graph_rec(void *vp, uint32_t k, int64_t *out){
+	const poa_read_rec_t *r = ((ref_poa_t*)vp)->recs + k;
+	out[0] = (int64_t)r->node_off; out[1] = (int64_t)r->edge_off; out[2] = (int64_t)r->cand_off; out[3] = (int64_t)r->trace_off;
+	out[4] = r->nnodes; out[5] = r->nedges; out[6] = r->ncands; out[7] = r->ntrace; out[8] = r->fin_gnode; out[9] = r->fin_x; out[10] = r->maxidx_local;
+}
+void ref_poa_graph_sizes(void *vp, uint64_t *out){
+	ref_poa_t *p = (ref_poa_t*)vp;
+	out[0] = p->ngn; out[1] = p->nge; out[2] = p->ngc; out[3] = p->ngt;
+}
+void ref_poa_graph_data(void *vp, void *nodes, void *edges, void *cands, void *trace){
+	ref_poa_t *p = (ref_poa_t*)vp;
+	if(nodes) memcpy(nodes, p->gnodes, p->ngn * sizeof(bsa_poa_node_t));
+	if(edges) memcpy(edges, p->gedges, p->nge * sizeof(bsa_poa_edge_t));
+	if(cands) memcpy(cands, p->gcands, p->ngc * sizeof(bsa_poa_cand_t));
+	if(trace) memcpy(trace, p->gtrace, p->ngt * sizeof(bsa_poa_event_t));
+}
+void ref_poa_form_counts(void *vp, uint64_t *graph_reads, uint64_t *rows_reads){
+	ref_poa_t *p = (ref_poa_t*)vp;
+	*graph_reads = p->ad.graph_reads; *rows_reads = p->ad.rows_reads;
 }

@@ -28,10 +28,7 @@ def par(**kw):
     return d
 
 
-def ref_poa():
-    r = S.ref()
-    if getattr(r, "_poa_ready", False):
-        return r
+def _poa_proto(r):
     r.ref_poa_create.restype = C.c_void_p
     r.ref_poa_create.argtypes = [C.c_int] * 16
     r.ref_poa_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -55,8 +52,93 @@ def ref_poa():
     r.ref_poa_programs.restype = None
     r.ref_poa_core_stats.argtypes = [C.c_void_p] * 4
     r.ref_poa_core_stats.restype = None
+    r.ref_poa_set_graph_backend.argtypes = [C.c_void_p, C.c_void_p]
+    r.ref_poa_set_graph_backend.restype = None
+    r.ref_poa_set_graph_host.argtypes = [C.c_void_p, C.c_void_p]
+    r.ref_poa_set_graph_host.restype = None
+    r.ref_poa_set_batcher_graph.argtypes = [C.c_void_p]
+    r.ref_poa_set_batcher_graph.restype = None
+    r.ref_poa_graph_rec.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    r.ref_poa_graph_rec.restype = None
+    r.ref_poa_graph_sizes.argtypes = [C.c_void_p, C.c_void_p]
+    r.ref_poa_graph_sizes.restype = None
+    r.ref_poa_graph_data.argtypes = [C.c_void_p] * 5
+    r.ref_poa_graph_data.restype = None
+    r.ref_poa_form_counts.argtypes = [C.c_void_p] * 3
+    r.ref_poa_form_counts.restype = None
     r._poa_ready = True
     return r
+
+
+def ref_poa():
+    r = S.ref()
+    return r if getattr(r, "_poa_ready", False) else _poa_proto(r)
+
+
+_TRACE = None
+
+
+def have_ref_trace():
+    return os.path.exists(os.path.join(S.ORACLE_DIR, "_ref", "libbsref_trace.so"))
+
+
+def ref_poa_trace():
+    """the same harness built against the reference WITH the test-only recording hook in alignment2graph_bspoa
+    (oracle/bspoa_trace_record.diff): the reference's own traceback steps"""
+    global _TRACE
+    if _TRACE is None:
+        _TRACE = _poa_proto(C.CDLL(os.path.join(S.ORACLE_DIR, "_ref", "libbsref_trace.so")))
+        assert _TRACE.ref_poa_can_record_trace() == 1
+    return _TRACE
+
+
+def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
+    """modes 5 / 6 of the harness (graph form of the binding).  backend "oracle": orc_wf_backend + orc_sweep_run on the CPU;
+    "device": whatever the GPU test attached with ref_poa_set_graph_host / ref_poa_set_device.
+    -> dict like run_ref_poa, plus per read (mode 5, record) nodes / edges / cands / trace / fin and the counts of reads per form"""
+    r, o = (lib or ref_poa()), S.oracle()
+    if backend == "oracle":
+        _wf_lib()
+        r.ref_poa_set_graph_backend(C.cast(o.orc_wf_backend, C.c_void_p), None)
+    else:
+        r.ref_poa_set_graph_backend(None, None)
+    h = r.ref_poa_create(*[int(p[k]) for k in PAR_ORDER])
+    lens = np.array([len(x) for x in reads], dtype=np.uint32)
+    offs = np.zeros(len(reads), dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)[:-1]
+    blob = np.concatenate(reads).astype(np.uint8)
+    bad = r.ref_poa_run(h, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads), mode,
+                        C.cast(o.orc_sweep_run, C.c_void_p) if backend == "oracle" else None, int(record))
+    n = r.ref_poa_cns_len(h)
+    cns, qlt, alt = (np.zeros(n, np.uint8) for _ in range(3))
+    r.ref_poa_cns(h, cns.ctypes.data, qlt.ctypes.data, alt.ctypes.data)
+    nc, nr = C.c_uint32(), C.c_uint32()
+    mh = r.ref_poa_msa_hash(h, C.byref(nc), C.byref(nr))
+    sizes = np.zeros(4, np.uint64)
+    r.ref_poa_graph_sizes(h, sizes.ctypes.data)
+    gn, ge, gc, gt = np.zeros(int(sizes[0]), WF_NODE), np.zeros(int(sizes[1]), WF_EDGE), np.zeros(int(sizes[2]), WF_CAND), np.zeros(int(sizes[3]), WF_EVENT)
+    r.ref_poa_graph_data(h, gn.ctypes.data, ge.ctypes.data, gc.ctypes.data, gt.ctypes.data)
+    queries = np.zeros(int(r.ref_poa_nquery_bytes(h)), dtype=np.uint8)
+    if len(queries):
+        dummy = np.zeros(max(int(r.ref_poa_ntasks(h)), 1), dtype=TASK_DTYPE)
+        r.ref_poa_programs(h, dummy.ctypes.data, queries.ctypes.data)
+    recs = []
+    for k in range(r.ref_poa_nrec(h)):
+        out = np.zeros(20, np.int32)
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        r.ref_poa_rec(h, k, out.ctypes.data, C.byref(a), C.byref(b), C.byref(c))
+        gr = np.zeros(11, np.int64)
+        r.ref_poa_graph_rec(h, k, gr.ctypes.data)
+        d = dict(rs=out[:10].copy(), maxscr=int(out[10]), maxidx=int(out[11]), maxoff=int(out[12]), bandwidth=int(out[13]), slen=int(out[14]),
+                 qb=int(out[15]), piecewise=int(out[18]), mismatch=int(out[19]), rows_hash=a.value, query_off=c.value)
+        if mode == 5 and record:
+            d.update(nodes=gn[gr[0]:gr[0] + gr[4]], edges=ge[gr[1]:gr[1] + gr[5]], cands=gc[gr[2]:gr[2] + gr[6]], trace=gt[gr[3]:gr[3] + gr[7]],
+                     fin_gnode=int(gr[8]), fin_x=int(gr[9]), maxidx_local=int(gr[10]), query=queries[c.value:c.value + int(out[14])])
+        recs.append(d)
+    g1, g2 = C.c_uint64(), C.c_uint64()
+    r.ref_poa_form_counts(h, C.byref(g1), C.byref(g2))
+    r.ref_poa_destroy(h)
+    return dict(bad=bad, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, graph_reads=g1.value, rows_reads=g2.value)
 
 
 def run_ref_poa(reads, mode, p, record=True):
