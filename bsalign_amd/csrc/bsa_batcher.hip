@@ -18,6 +18,8 @@
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *c, hipStream_t *st);
@@ -32,6 +34,16 @@ struct Sub {
 	int *rc;
 	const uint8_t **rows_src;      // where the submitter finds its row blocks (pinned staging) after the batch ran
 	size_t *rows_bytes;
+};
+struct SubG {                      // a program of the graph form (bsa_poa_batcher_submit_graph)
+	const bsa_poa_node_t *nodes; size_t nnodes;
+	const bsa_poa_edge_t *edges; size_t nedges;
+	const bsa_poa_cand_t *cands; size_t ncands;
+	const uint8_t *query; uint32_t slen;
+	bsa_sweep_params_t par;
+	bsa_poa_result_t *res; size_t cap;
+	int *rc;
+	const bsa_poa_event_t **ev_src;     // where the submitter finds its steps (pinned staging) after the batch ran
 };
 struct Pinned {
 	void *p = nullptr; size_t cap = 0;
@@ -68,6 +80,9 @@ struct Group {
 	uint32_t active = 0;
 	uint64_t gen = 0;                   // batches completed
 	std::vector<Sub> pend;
+	std::vector<SubG> pendg;
+	Pinned h_gin, h_gout;               // graph form: upload staging, download staging (results | events)
+	Dev d_gin, d_gout;
 	Pinned h_in, h_rows;                // upload staging (tasks | progs | qoff | qlen | queries), download staging (results | rows)
 	Dev d_in, d_rows, d_res;
 	// statistics
@@ -81,32 +96,133 @@ struct bsa_sweep_batcher {
 	std::vector<Group*> groups;
 	std::mutex dev;                       // one batch on the device at a time (a bsa_ctx_t is not shared between threads)
 	std::mutex am; uint32_t next = 0;     // group assignment, in order of first appearance
-	uint64_t key = 0;                     // identifies this batcher in the threads' assignment slots
+	std::unordered_map<std::thread::id, Group*> of;    // a thread keeps its group for the batcher's life, whatever other batchers it uses in between
 	~bsa_sweep_batcher(){ for(Group *g : groups) delete g; }
 };
-static std::atomic<uint64_t> g_batcher_keys{1};
 static Group *group_of_this_thread(bsa_sweep_batcher *b){
-	thread_local uint64_t t_key = 0; thread_local Group *t_grp = nullptr;
-	if(t_key != b->key){
-		std::lock_guard<std::mutex> lk(b->am);
-		t_grp = b->groups[b->next % b->groups.size()]; b->next++;
-		t_key = b->key;
-	}
-	return t_grp;
+	std::lock_guard<std::mutex> lk(b->am);
+	auto it = b->of.find(std::this_thread::get_id());
+	if(it != b->of.end()) return it->second;
+	Group *g = b->groups[b->next % b->groups.size()]; b->next++;
+	b->of.emplace(std::this_thread::get_id(), g);
+	return g;
+}
+// field by field: the structs carry padding a caller need not have initialised
+static bool same_params(const bsa_sweep_params_t &a, const bsa_sweep_params_t &b){
+	return a.rows.mode == b.rows.mode && a.rows.bandwidth == b.rows.bandwidth && a.rows.M == b.rows.M && a.rows.X == b.rows.X && a.rows.refbonus == b.rows.refbonus &&
+		a.rows.gapo1 == b.rows.gapo1 && a.rows.gape1 == b.rows.gape1 && a.rows.gapo2 == b.rows.gapo2 && a.rows.gape2 == b.rows.gape2 && a.T == b.T;
 }
 
 static size_t align16(size_t x){ return (x + 15) & ~(size_t)15; }
 
-// run everything in b->pend (caller holds the lock; every other participant is blocked)
+// the graph-form programs of a batch: one bsa_poa_graph_run per distinct parameter set; what comes back is 32 bytes per program
+// and its traceback steps -- no row block leaves the device
+static void run_batch_graph(Group *b){
+	std::vector<SubG> &P = b->pendg;
+	const size_t n = P.size();
+	if(n == 0) return;
+	std::vector<int> grp(n, -1);
+	std::vector<size_t> first;
+	for(size_t k = 0; k < n; k++){
+		for(size_t g = 0; g < first.size(); g++) if(same_params(P[first[g]].par, P[k].par)){ grp[k] = (int)g; break; }
+		if(grp[k] < 0){ grp[k] = (int)first.size(); first.push_back(k); }
+	}
+	hipStream_t st = nullptr;
+	const int rc0 = bsa_ctx_get_stream_internal(b->ctx, &st);
+	// the download staging holds every program's result and steps until its submitter has copied them: sized for the whole batch
+	size_t ev_total = 0;
+	std::vector<size_t> ev_off(n, 0);
+	for(size_t k = 0; k < n; k++){ ev_off[k] = ev_total; ev_total += P[k].cap; }
+	const size_t o_res = 0, o_ev = align16(n * sizeof(bsa_poa_result_t));
+	int rca = rc0;
+	if(rca == BSA_OK && (!b->h_gout.need(o_ev + ev_total * sizeof(bsa_poa_event_t) + 64) || !b->d_gout.need(o_ev + ev_total * sizeof(bsa_poa_event_t) + 64))) rca = BSA_E_NOMEM;
+	for(size_t g = 0; g < first.size(); g++){
+		int rc = rca;
+		std::vector<size_t> mem;
+		for(size_t k = 0; k < n; k++) if(grp[k] == (int)g) mem.push_back(k);
+		const size_t np = mem.size();
+		const bsa_sweep_params_t par = P[first[g]].par;
+		size_t nn = 0, ne = 0, nc = 0, qb = 0; uint32_t max_slen = 0;
+		for(size_t i = 0; i < np; i++){ const SubG &s = P[mem[i]]; nn += s.nnodes; ne += s.nedges; nc += s.ncands; qb += align16((size_t)s.slen + 16); max_slen = std::max(max_slen, s.slen); }
+		const size_t o_n = 0, o_e = align16(o_n + nn * sizeof(bsa_poa_node_t)), o_c = align16(o_e + ne * sizeof(bsa_poa_edge_t)),
+			o_p = align16(o_c + nc * sizeof(bsa_poa_cand_t)), o_q = align16(o_p + np * sizeof(bsa_poa_prog_t)), in_bytes = o_q + qb + 64;
+		if(rc == BSA_OK && (!b->h_gin.need(in_bytes) || !b->d_gin.need(in_bytes))) rc = BSA_E_NOMEM;
+		if(rc == BSA_OK){
+			uint8_t *h = (uint8_t*)b->h_gin.p;
+			bsa_poa_prog_t *hp = (bsa_poa_prog_t*)(h + o_p);
+			size_t n0 = 0, e0 = 0, c0 = 0, q0 = 0;
+			for(size_t i = 0; i < np; i++){
+				const SubG &s = P[mem[i]];
+				memcpy(h + o_n + n0 * sizeof(bsa_poa_node_t), s.nodes, s.nnodes * sizeof(bsa_poa_node_t));
+				if(s.nedges) memcpy(h + o_e + e0 * sizeof(bsa_poa_edge_t), s.edges, s.nedges * sizeof(bsa_poa_edge_t));
+				if(s.ncands) memcpy(h + o_c + c0 * sizeof(bsa_poa_cand_t), s.cands, s.ncands * sizeof(bsa_poa_cand_t));
+				memcpy(h + o_q + q0, s.query, s.slen);
+				bsa_poa_prog_t &pg = hp[i];
+				memset(&pg, 0, sizeof(pg));
+				pg.first_node = (uint32_t)n0; pg.nnodes = (uint32_t)s.nnodes; pg.first_edge = (uint32_t)e0; pg.nedges = (uint32_t)s.nedges;
+				pg.first_cand = (uint32_t)c0; pg.ncands = (uint32_t)s.ncands; pg.slen = s.slen; pg.event_cap = (uint32_t)s.cap;
+				pg.query_off = q0; pg.first_event = ev_off[mem[i]];
+				n0 += s.nnodes; e0 += s.nedges; c0 += s.ncands; q0 += align16((size_t)s.slen + 16);
+			}
+		}
+#define BCHK(x) do { if(rc == BSA_OK && (x) != hipSuccess){ rc = BSA_E_HIP; (void)hipGetLastError(); } } while(0)
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		std::vector<bsa_poa_result_t> hres(np);
+		std::unique_lock<std::mutex> devlk(b->parent->dev);
+		BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
+		BCHK(hipMemcpyAsync(b->d_gin.p, b->h_gin.p, in_bytes, hipMemcpyHostToDevice, st));
+		BCHK(hipEventRecord(e0, st));
+		uint8_t *dres = (uint8_t*)b->d_gout.p + o_res;
+		if(rc == BSA_OK){
+			const uint8_t *d = (const uint8_t*)b->d_gin.p;
+			// results of this parameter set's programs at the start of the result area, copied out before the next set overwrites them
+			rc = bsa_poa_graph_run(b->ctx, (const bsa_poa_node_t*)(d + o_n), nn, (const bsa_poa_edge_t*)(d + o_e), (const bsa_poa_cand_t*)(d + o_c),
+				(const bsa_poa_prog_t*)(d + o_p), np, d + o_q, max_slen, &par, (bsa_poa_result_t*)dres, (bsa_poa_event_t*)((uint8_t*)b->d_gout.p + o_ev), nullptr, nullptr);
+		}
+		BCHK(hipEventRecord(e1, st));
+		BCHK(hipMemcpyAsync(hres.data(), dres, np * sizeof(bsa_poa_result_t), hipMemcpyDeviceToHost, st));
+		BCHK(hipStreamSynchronize(st));
+		// the steps: one copy from the first to the last program of the set that has any
+		size_t lo = ~(size_t)0, hi = 0, down = np * sizeof(bsa_poa_result_t);
+		if(rc == BSA_OK) for(size_t i = 0; i < np; i++) if(hres[i].nevents > 0){ lo = std::min(lo, ev_off[mem[i]]); hi = std::max(hi, ev_off[mem[i]] + (size_t)hres[i].nevents); }
+		if(rc == BSA_OK && hi > lo){
+			BCHK(hipMemcpyAsync((uint8_t*)b->h_gout.p + o_ev + lo * sizeof(bsa_poa_event_t), (const uint8_t*)b->d_gout.p + o_ev + lo * sizeof(bsa_poa_event_t),
+				(hi - lo) * sizeof(bsa_poa_event_t), hipMemcpyDeviceToHost, st));
+			BCHK(hipStreamSynchronize(st));
+			down += (hi - lo) * sizeof(bsa_poa_event_t);
+		}
+		devlk.unlock();
+		if(rc == BSA_OK){ float ms = 0; if(hipEventElapsedTime(&ms, e0, e1) == hipSuccess) b->device_ms += ms; }
+		if(e0) (void)hipEventDestroy(e0);
+		if(e1) (void)hipEventDestroy(e1);
+#undef BCHK
+		for(size_t i = 0; i < np; i++){
+			const SubG &s = P[mem[i]];
+			*s.rc = rc;
+			if(rc == BSA_OK){ *s.res = hres[i]; *s.ev_src = (const bsa_poa_event_t*)((const uint8_t*)b->h_gout.p + o_ev) + ev_off[mem[i]]; }
+		}
+		b->launches++; b->programs += np; b->tasks += nn; b->bytes_up += in_bytes; b->bytes_down += down;
+	}
+	P.clear();
+}
+
+// run everything in b->pend / b->pendg (caller holds the lock; every other participant is blocked)
 static void run_batch(Group *b){
 	const auto w0 = std::chrono::steady_clock::now();
+	run_batch_graph(b);
 	std::vector<Sub> &P = b->pend;
 	const size_t n = P.size();
+	if(n == 0){
+		b->batches++;
+		b->wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+		b->gen++;
+		return;
+	}
 	// groups of equal parameters, in order of first appearance
 	std::vector<int> grp(n, -1);
 	std::vector<size_t> first;
 	for(size_t k = 0; k < n; k++){
-		for(size_t g = 0; g < first.size(); g++) if(memcmp(&P[first[g]].par, &P[k].par, sizeof(bsa_sweep_params_t)) == 0){ grp[k] = (int)g; break; }
+		for(size_t g = 0; g < first.size(); g++) if(same_params(P[first[g]].par, P[k].par)){ grp[k] = (int)g; break; }
 		if(grp[k] < 0){ grp[k] = (int)first.size(); first.push_back(k); }
 	}
 	hipStream_t st = nullptr;
@@ -211,7 +327,6 @@ extern "C" int bsa_sweep_batcher_create(bsa_ctx_t *ctx, uint32_t participants, b
 	uint32_t G = participants >= 32u ? 2u : 1u;
 	if(const char *e = getenv("BSA_POA_GROUPS")){ const int v = atoi(e); if(v >= 1 && v <= 64) G = (uint32_t)v; }
 	if(G > participants) G = participants;
-	b->key = g_batcher_keys.fetch_add(1);
 	for(uint32_t g = 0; g < G; g++){
 		Group *gr = new (std::nothrow) Group();
 		if(!gr){ delete b; return BSA_E_NOMEM; }
@@ -238,7 +353,7 @@ extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, s
 		const uint64_t my = b->gen;
 		Sub s{tasks, ntasks, query, slen, *par, rows_out, nblocks, res, &rc, &src, &nbytes};
 		b->pend.push_back(s);
-		if(b->pend.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
+		if(b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
 		else b->cv.wait(lk, [&]{ return b->gen > my; });
 	}
 	// the row blocks are copied out here, by every window's own thread (the staging is not reused before all of them
@@ -252,7 +367,31 @@ extern "C" void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *bb){
 	Group *b = group_of_this_thread(bb);
 	std::unique_lock<std::mutex> lk(b->m);
 	if(b->active) b->active--;
-	if(!b->pend.empty() && b->pend.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
+	if(b->pend.size() + b->pendg.size() > 0 && b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
+}
+
+// graph form of submit(): the signature of the binding's graph backend (include/bsalign_poa_adapter.h).  A parameter set the
+// wavefront kernel does not take is declined at once (BSA_E_UNSUPPORTED) -- the window then comes back through submit().
+extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *nodes, size_t nnodes, const bsa_poa_edge_t *edges, size_t nedges,
+		const bsa_poa_cand_t *cands, size_t ncands, const uint8_t *query, uint32_t slen, const bsa_sweep_params_t *par,
+		bsa_poa_result_t *res, bsa_poa_event_t *events, size_t events_cap){
+	bsa_sweep_batcher *bb = (bsa_sweep_batcher*)vb;
+	if(!bb || !nodes || !nnodes || !query || !par || !res || !events) return BSA_E_ARG;
+	if(bsa_poa_graph_supported(par, slen) == 0) return BSA_E_UNSUPPORTED;
+	Group *b = group_of_this_thread(bb);
+	int rc = BSA_E_HIP;
+	const bsa_poa_event_t *src = nullptr;
+	{
+		std::unique_lock<std::mutex> lk(b->m);
+		if(b->active == 0) return BSA_E_ARG;
+		const uint64_t my = b->gen;
+		SubG s{nodes, nnodes, edges, nedges, cands, ncands, query, slen, *par, res, events_cap, &rc, &src};
+		b->pendg.push_back(s);
+		if(b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
+		else b->cv.wait(lk, [&]{ return b->gen > my; });
+	}
+	if(rc == BSA_OK && src && res->nevents > 0) memcpy(events, src, (size_t)res->nevents * sizeof(bsa_poa_event_t));
+	return rc;
 }
 
 // out[0..7] = batches, launches, programs, tasks, bytes uploaded, bytes downloaded, device microseconds, wall microseconds inside the batches

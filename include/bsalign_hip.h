@@ -346,6 +346,12 @@ void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b);
 int  bsa_sweep_batcher_submit(void *batcher, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
                               const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *res);
 void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *b);
+/* the same rendezvous for the graph form (sweep + traceback on the device, nothing but the steps comes back): signature of
+ * bsa_poa_graph_backend_fn (include/bsalign_poa_adapter.h), `batcher` as user.  Declines with BSA_E_UNSUPPORTED, without
+ * waiting, what bsa_poa_graph_supported declines; the window then submits the read through bsa_sweep_batcher_submit. */
+int  bsa_poa_batcher_submit_graph(void *batcher, const bsa_poa_node_t *nodes, size_t nnodes, const bsa_poa_edge_t *edges, size_t nedges,
+                                  const bsa_poa_cand_t *cands, size_t ncands, const uint8_t *query, uint32_t slen, const bsa_sweep_params_t *par,
+                                  bsa_poa_result_t *res, bsa_poa_event_t *events, size_t events_cap);
 /* out[0..7] = batches, device launches, programs, tasks, bytes uploaded, bytes downloaded, device microseconds, microseconds inside batches */
 void bsa_sweep_batcher_stats(bsa_sweep_batcher_t *b, uint64_t out[8]);
 

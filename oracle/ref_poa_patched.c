@@ -22,7 +22,21 @@ void refp_attach(void *ctx, void *sweep_host, void *bcreate, void *bdestroy, voi
 	p_ctx = (bsa_ctx_t*)ctx; p_sweep_host = (fn_sweep_host)sweep_host; p_bcreate = (fn_bcreate)bcreate; p_bdestroy = (fn_bvoid)bdestroy;
 	p_bsubmit = (fn_bsubmit)bsubmit; p_bleave = (fn_bvoid)bleave;
 }
+typedef int (*fn_graph_host)(bsa_ctx_t*, const bsa_poa_node_t*, size_t, const bsa_poa_edge_t*, size_t, const bsa_poa_cand_t*, size_t, const bsa_poa_prog_t*, size_t,
+		const uint8_t*, size_t, const bsa_sweep_params_t*, bsa_poa_result_t*, bsa_poa_event_t*, size_t, bsa_poa_cell_t*, int32_t*);
+typedef int (*fn_bsubmit_graph)(void*, const bsa_poa_node_t*, size_t, const bsa_poa_edge_t*, size_t, const bsa_poa_cand_t*, size_t, const uint8_t*, uint32_t,
+		const bsa_sweep_params_t*, bsa_poa_result_t*, bsa_poa_event_t*, size_t);
+static fn_graph_host p_graph_host; static fn_bsubmit_graph p_bsubmit_graph;
+void refp_attach_graph(void *graph_host, void *bsubmit_graph){ p_graph_host = (fn_graph_host)graph_host; p_bsubmit_graph = (fn_bsubmit_graph)bsubmit_graph; }
 #define HID __attribute__((visibility("hidden")))
+HID int bsa_poa_graph_host(bsa_ctx_t *c, const bsa_poa_node_t *n, size_t nn, const bsa_poa_edge_t *e, size_t ne, const bsa_poa_cand_t *cd, size_t nc, const bsa_poa_prog_t *pg, size_t np,
+		const uint8_t *q, size_t qb, const bsa_sweep_params_t *par, bsa_poa_result_t *res, bsa_poa_event_t *ev, size_t cap, bsa_poa_cell_t *rows, int32_t *u0){
+	return p_graph_host ? p_graph_host(c, n, nn, e, ne, cd, nc, pg, np, q, qb, par, res, ev, cap, rows, u0) : BSA_E_UNSUPPORTED;
+}
+HID int bsa_poa_batcher_submit_graph(void *b, const bsa_poa_node_t *n, size_t nn, const bsa_poa_edge_t *e, size_t ne, const bsa_poa_cand_t *cd, size_t nc, const uint8_t *q, uint32_t sl,
+		const bsa_sweep_params_t *par, bsa_poa_result_t *res, bsa_poa_event_t *ev, size_t cap){
+	return p_bsubmit_graph ? p_bsubmit_graph(b, n, nn, e, ne, cd, nc, q, sl, par, res, ev, cap) : BSA_E_UNSUPPORTED;
+}
 HID int bsa_sweep_host(bsa_ctx_t *c, const bsa_row_task_t *t, size_t nt, const bsa_sweep_prog_t *p, size_t np, const uint8_t *q, const uint64_t *qo,
 		const uint32_t *ql, size_t nq, const bsa_sweep_params_t *par, uint8_t *rows, size_t nb, bsa_sweep_result_t *res){
 	return p_sweep_host ? p_sweep_host(c, t, nt, p, np, q, qo, ql, nq, par, rows, nb, res) : BSA_E_UNSUPPORTED;

@@ -422,3 +422,24 @@ def oracle_wf_trace(nodes, edges, query, p, bandwidth, rows, u0, head, midx, xe)
     n = o.orc_wf_trace(nodes.ctypes.data, edges.ctypes.data, query.ctypes.data, len(query), par.ctypes.data, rows.ctypes.data, u0.ctypes.data,
                        head, midx, xe, ev.ctypes.data, len(ev), fin.ctypes.data)
     return n, ev[:max(n, 0)], fin
+
+
+GOLDEN_GRAPH = os.path.join(HERE, "golden", "poa_graph.npz")
+
+
+def load_golden_graph():
+    """tests/golden/poa_graph.npz (make_golden_poa_graph.py): per case the parameters and, per read, the graph-form program with the
+    REFERENCE's best end cell and the steps of its own traceback.  -> list of dict(par, reads=[dict(...)])"""
+    g = np.load(GOLDEN_GRAPH)
+    cases = []
+    for c in range(int(g["ncases"][0])):
+        p = {k: int(v) for k, v in zip(PAR_ORDER, g["par_%d" % c])}
+        nodes, edges, cands, trace = (g["%s_%d" % (n, c)].view(t) for n, t in (("nodes", WF_NODE), ("edges", WF_EDGE), ("cands", WF_CAND), ("trace", WF_EVENT)))
+        query = g["query_%d" % c]
+        reads = []
+        for m in g["meta_%d" % c]:
+            bw, slen, maxscr, maxidx, maxoff, fin_g, fin_x, nn, ne, nc, nt, n0, e0, c0, t0, q0 = (int(x) for x in m)
+            reads.append(dict(bandwidth=bw, slen=slen, maxscr=maxscr, maxidx=maxidx, maxoff=maxoff, fin_gnode=fin_g, fin_x=fin_x, nodes=nodes[n0:n0 + nn],
+                              edges=edges[e0:e0 + ne], cands=cands[c0:c0 + nc], trace=trace[t0:t0 + nt], query=query[q0:q0 + slen]))
+        cases.append(dict(par=p, reads=reads))
+    return cases

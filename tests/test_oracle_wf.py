@@ -37,3 +37,22 @@ def test_recorded_programs_of_the_reference():
             _check(case, pg)
             n += 1
     assert n >= 30
+
+
+def test_fixture_of_the_references_own_walks():
+    """tests/golden/poa_graph.npz: programs as the binding builds them from the reference's graph (in-edges in erev order with
+    their coverage) and what the reference did: the scalar statement of the device kernel finds the same best end cell and takes
+    the same steps, one by one"""
+    steps = 0
+    for case in P.load_golden_graph():
+        p = case["par"]
+        for rd in case["reads"]:
+            rows, u0 = P.oracle_wf_forward(rd["nodes"], rd["query"], p, rd["bandwidth"])
+            best = P.oracle_wf_best(rd["nodes"], rd["cands"], rd["slen"], p, rd["bandwidth"], rows)
+            assert (int(best["maxscr"]), int(rd["nodes"][int(best["maxidx"])]["gnode"]), int(best["maxoff"])) == (rd["maxscr"], rd["maxidx"], rd["maxoff"])
+            n, ev, fin = P.oracle_wf_trace(rd["nodes"], rd["edges"], rd["query"], p, rd["bandwidth"], rows, u0, 0, int(best["maxidx"]), int(best["maxoff"]))
+            assert n == len(rd["trace"])
+            assert np.array_equal(rd["nodes"]["gnode"][ev["node"]], rd["trace"]["node"]) and np.array_equal(ev["x"], rd["trace"]["x"]) and np.array_equal(ev["bt"], rd["trace"]["bt"])
+            assert (int(rd["nodes"][int(fin[0])]["gnode"]), int(fin[1])) == (rd["fin_gnode"], rd["fin_x"])
+            steps += n
+    assert steps > 20000

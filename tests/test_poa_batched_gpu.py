@@ -28,6 +28,7 @@ class Batcher:
         r.ref_poa_set_batcher.argtypes = [C.c_void_p] * 3
         r.ref_poa_set_batcher.restype = None
         r.ref_poa_set_batcher(C.cast(self.L.bsa_sweep_batcher_submit, C.c_void_p), C.cast(self.L.bsa_sweep_batcher_leave, C.c_void_p), self.h)
+        r.ref_poa_set_batcher_graph(C.cast(self.L.bsa_poa_batcher_submit_graph, C.c_void_p))
 
     def stats(self):
         out = np.zeros(8, np.uint64)
@@ -36,6 +37,7 @@ class Batcher:
 
     def close(self):
         P.ref_poa().ref_poa_set_batcher(None, None, None)
+        P.ref_poa().ref_poa_set_batcher_graph(None)
         self.L.bsa_sweep_batcher_destroy(self.h)
 
 
@@ -53,14 +55,15 @@ def test_windows_of_different_sizes_in_lock_step(ctx, kw):
     rng = np.random.default_rng(5 + len(kw))
     windows = [P.synth_reads(900 + w, int(rng.integers(200, 700)), int(rng.integers(3, 9))) for w in range(12)]
     ref, _ = P.run_many(windows, 0, p, threads=4)
-    bt = Batcher(ctx, len(windows))
-    try:
-        dev, _ = P.run_many(windows, 4, p)
-        st = bt.stats()
-    finally:
-        bt.close()
-    _compare(ref, dev)
-    assert st["programs"] >= sum(len(w) - 1 for w in windows) and st["launches"] < st["programs"]       # programs were really run together
+    for mode in (4, 7):            # 4: row blocks come back, the reference's host traceback; 7: graph form, sweep and walk on the device
+        bt = Batcher(ctx, len(windows))
+        try:
+            dev, _ = P.run_many(windows, mode, p)
+            st = bt.stats()
+        finally:
+            bt.close()
+        _compare(ref, dev)
+        assert st["programs"] >= sum(len(w) - 1 for w in windows) and st["launches"] < st["programs"]       # programs were really run together
 
 
 def test_256_windows_of_c4_shaped_reads(ctx, capsys):
@@ -69,14 +72,15 @@ def test_256_windows_of_c4_shaped_reads(ctx, capsys):
     p = P.par()
     windows = [P.synth_reads(7000 + w, 1500, 12, eps=(0.1,)) for w in range(256)]
     ref, t_ref = P.run_many(windows, 0, p, threads=16)
-    bt = Batcher(ctx, len(windows))
-    try:
-        dev, t_dev = P.run_many(windows, 4, p)
-        st = bt.stats()
-    finally:
-        bt.close()
-    _compare(ref, dev)
-    with capsys.disabled():
-        print("\n[256 windows x 12 reads x 1.5 kbp] reference end_bspoa on 16 host threads %.2f s; lock-step with the sweeps on the device %.2f s "
-              "(%d batches, %d launches, %d programs, %.1f MB up, %.1f MB down, device %.2f s, inside batches %.2f s)"
-              % (t_ref, t_dev, st["batches"], st["launches"], st["programs"], st["bytes_up"] / 1e6, st["bytes_down"] / 1e6, st["device_us"] / 1e6, st["wall_us"] / 1e6))
+    for mode, what in ((7, "graph form: sweep and walk on the device"), (4, "rows form: row blocks back, host traceback")):
+        bt = Batcher(ctx, len(windows))
+        try:
+            dev, t_dev = P.run_many(windows, mode, p)
+            st = bt.stats()
+        finally:
+            bt.close()
+        _compare(ref, dev)
+        with capsys.disabled():
+            print("\n[256 windows x 12 reads x 1.5 kbp] reference end_bspoa on 16 host threads %.2f s; lock-step, %s %.2f s "
+                  "(%d batches, %d launches, %d programs, %.1f MB up, %.1f MB down, device %.2f s, inside batches %.2f s)"
+                  % (t_ref, what, t_dev, st["batches"], st["launches"], st["programs"], st["bytes_up"] / 1e6, st["bytes_down"] / 1e6, st["device_us"] / 1e6, st["wall_us"] / 1e6))

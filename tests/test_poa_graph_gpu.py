@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import poa_support as P
+import support as S
 
 pytestmark = pytest.mark.gpu
 
@@ -85,3 +86,76 @@ def test_many_programs_in_one_launch(ctx):
                 r = res[k]
                 assert r["status"] == 0
                 assert (int(r["maxscr"]), int(nodes[int(r["maxidx"])]["gnode"]), int(r["maxoff"])) == (pg["maxscr"], pg["maxidx"], pg["maxoff"])
+
+
+def test_fixture_of_the_references_own_walks(ctx):
+    """tests/golden/poa_graph.npz: the graph-form programs the binding built from the reference's graph, and the (node, x, bt) steps
+    the REFERENCE's alignment2graph_bspoa took (recorded through oracle/ref_poa_harness.c with the test-only hook): the device's
+    best end cell, every step of its walk and the walk's end are the reference's.  All reads of a case in one launch."""
+    steps = 0
+    for case in P.load_golden_graph():
+        p = case["par"]
+        by_bw = {}
+        for rd in case["reads"]:
+            by_bw.setdefault(rd["bandwidth"], []).append(rd)
+        for bw, rds in by_bw.items():
+            PR, n0, e0, c0, q0, v0 = [], 0, 0, 0, 0, 0
+            for rd in rds:
+                cap = 2 * (rd["slen"] + len(rd["nodes"])) + 64
+                pr = np.zeros(1, P.WF_PROG)
+                pr[0] = (n0, len(rd["nodes"]), e0, len(rd["edges"]), c0, len(rd["cands"]), rd["slen"], cap, q0, v0)
+                PR.append(pr)
+                n0 += len(rd["nodes"]); e0 += len(rd["edges"]); c0 += len(rd["cands"]); q0 += rd["slen"]; v0 += cap
+            res, ev, _, _ = ctx.poa_graph_host(np.concatenate([r["nodes"] for r in rds]), np.concatenate([r["edges"] for r in rds]),
+                                               np.concatenate([r["cands"] for r in rds]), np.concatenate(PR), np.concatenate([r["query"] for r in rds]),
+                                               _sweep_params(p, bw), v0)
+            for k, rd in enumerate(rds):
+                r, pr = res[k], PR[k][0]
+                assert r["status"] == 0
+                assert (int(r["maxscr"]), int(rd["nodes"][int(r["maxidx"])]["gnode"]), int(r["maxoff"])) == (rd["maxscr"], rd["maxidx"], rd["maxoff"])
+                mine = ev[int(pr["first_event"]):int(pr["first_event"]) + int(r["nevents"])]
+                assert len(mine) == len(rd["trace"])
+                assert np.array_equal(rd["nodes"]["gnode"][mine["node"]], rd["trace"]["node"]) and np.array_equal(mine["x"], rd["trace"]["x"]) and np.array_equal(mine["bt"], rd["trace"]["bt"])
+                assert (int(rd["nodes"][int(r["fin_node"])]["gnode"]), int(r["fin_x"])) == (rd["fin_gnode"], rd["fin_x"])
+                steps += len(mine)
+    assert steps > 20000
+
+
+def _attach(lib, ctx):
+    import ctypes as C
+    import bsalign_amd as B
+    b = B.lib()
+    lib.ref_poa_set_graph_host(C.cast(b.bsa_poa_graph_host, C.c_void_p), ctx.h)
+    lib.ref_poa_set_device.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ref_poa_set_device.restype = None
+    lib.ref_poa_set_device(C.cast(b.bsa_sweep_host, C.c_void_p), ctx.h)
+
+
+@pytest.mark.skipif(not P.have_ref_trace(), reason="oracle/_ref/libbsref_trace.so not built")
+@pytest.mark.parametrize("kw", [dict(), dict(alnmode=0, bandwidth=64), dict(alnmode=2, Q=0, P=0)])
+def test_device_in_the_shadow_of_the_reference(ctx, kw):
+    """harness mode 5 with the MI355X as backend: inside a real end_bspoa, read after read, the device's best end cell and every
+    step of its walk against what the reference's own align_rd_bspoacore + alignment2graph_bspoa do on the same graph"""
+    lib = P.ref_poa_trace()
+    _attach(lib, ctx)
+    p = P.par(**kw)
+    reads = P.synth_reads(520 + len(kw), 2500, 14, eps=(0.05, 0.12, 0.2))
+    r = P.run_ref_graph(reads, 5, p, record=True, lib=lib, backend="device")
+    assert r["bad"] == 0, [(i, rc["mismatch"]) for i, rc in enumerate(r["recs"]) if rc["mismatch"]]
+    assert r["graph_reads"] >= len(reads) - 3
+    assert sum(len(rc["trace"]) for rc in r["recs"] if "trace" in rc) > 10 * 2500
+
+
+@pytest.mark.skipif(not S.have_ref(), reason="oracle/_ref/libbsref.so not built")
+def test_end_bspoa_with_sweep_and_walk_on_the_device(ctx):
+    """harness mode 6: the product's path -- graph form on the device, the binding applies the steps -- gives the untouched
+    end_bspoa's consensus, qualities and MSA"""
+    lib = P.ref_poa()
+    _attach(lib, ctx)
+    for kw in (dict(), dict(bandwidth=64), dict(alnmode=0)):
+        p = P.par(**kw)
+        reads = P.synth_reads(620 + len(kw), 3000, 16, eps=(0.08, 0.12))
+        ref = P.run_ref_poa(reads, 0, p, record=False)
+        mine = P.run_ref_graph(reads, 6, p, record=False, lib=lib, backend="device")
+        assert mine["graph_reads"] >= len(reads) - 3
+        assert np.array_equal(mine["cns"], ref["cns"]) and np.array_equal(mine["qlt"], ref["qlt"]) and np.array_equal(mine["alt"], ref["alt"]) and mine["msa"] == ref["msa"]
