@@ -31,18 +31,25 @@
 #define POA_NEAR   16      // predecessors at most this many nodes back are read from the LDS ring
 #define POA_DRAIN  16      // finished rows leave the ring in batches of this many
 #define POA_NEG    (2 * BSA_SCORE_MIN)
+#define POA_NQ     256     // node records staged in LDS ahead of the window
 
 struct PoaArgs {
 	const bsa_poa_node_t *nodes; const bsa_poa_edge_t *edges; const bsa_poa_cand_t *cands; const bsa_poa_prog_t *progs;
 	const uint8_t *queries;
 	uint32_t *rows; int32_t *u0;
 	bsa_poa_result_t *res; bsa_poa_event_t *events;
-	uint32_t bw, W, nl, R, qn_off, tile_off;
+	uint32_t bw, W, nl, R, qn_off, nq_off;
 	int32_t mode, M, X, refbonus, O, E, Q, P, T;
 	int32_t c0, d, head_u0, xp;
 };
 
-__device__ __forceinline__ uint32_t poa_tag(int node){ return (uint32_t)(node % 65535) + 1u; }
+struct PoaNodeHead { uint32_t rpos, first_in, n_in, base, flags; };
+struct PoaTileNode {              // a bsa_poa_node_t as three uint4 in LDS
+	uint4 r0, r1, r2;
+	__device__ __forceinline__ uint32_t flags_word() const { return r0.w; }
+	__device__ __forceinline__ PoaNodeHead head() const { PoaNodeHead h; h.rpos = r0.x; h.first_in = r0.z; h.n_in = r0.w & 0xFFFFu; h.base = (r0.w >> 16) & 0xFFu; h.flags = r0.w >> 24; return h; }
+};
+__device__ __forceinline__ uint32_t poa_tag(int node){ return ((uint32_t)node & 0x7FFFu) + 1u; }     // never 0 (a cleared cell), distinct within any 32768 consecutive nodes
 __device__ __forceinline__ int sx8(uint32_t v){ return (int)(int8_t)(v & 0xFFu); }
 
 template<int PW>
@@ -60,6 +67,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	extern __shared__ __align__(16) uint8_t lds[];
 	uint2 *ring = (uint2*)lds;
 	uint32_t *qn = (uint32_t*)(lds + a.qn_off);
+	uint4 *nq = (uint4*)(lds + a.nq_off);           // node records of the next POA_NQ nodes, record i at slot i % POA_NQ (three uint4 each)
 	const bsa_poa_prog_t pg = a.progs[blockIdx.x];
 	const int lane = threadIdx.x;
 	const int bw = (int)a.bw, W = (int)a.W, NL = (int)a.nl, R = (int)a.R;
@@ -98,6 +106,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	// ---- forward pass ----
 	const unsigned long long tick0 = wall_clock64();
 	int m = -NL;                 // nodes below m are complete; the nodes in flight are m .. m + NL - 1
+	int mr = 0;                  // m mod NL
+	int myslot = lane - NL;      // cur mod R, kept incrementally (no divisions in the loop)
+	while(myslot < 0) myslot += R;
+	int drslot = 0;              // dr mod R
 	int dr = 0;                  // rows below dr are in HBM
 	int cur = lane - NL, p = 0;
 	bool fin = true;             // finished `cur`, waiting for the window to take the next node
@@ -107,11 +119,13 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	uint32_t fl0 = 0, fl1 = 0;   // input flags: 1 present, 2 merge, 4 same base, 8 far (HBM), 16 dead (moved by >= bandwidth)
 	int ad0 = 0, ad1 = 0, lim0 = 0, lim1 = 0, hp0 = 0, hp1 = 0, src0 = 0, src1 = 0, mv0 = 0, mv1 = 0, to0 = 0, to1 = 0;
 	uint32_t tg0 = 0, tg1 = 0; int fu0 = 0, fu1 = 0;       // far inputs: the predecessor's ubegs[0]
+	int rh00 = 0, rh01 = 0;                                // the diagonal score left of band cell 0 when the band did not move (bspoa.h:2242-2249)
 
 	auto drain = [&](int upto){
 		// rows dr .. upto - 1 -> HBM as {int16 H - H(0), e, q}; four cells per lane and store
 		for(int r = dr; r < upto; r++){
-			const uint2 *src = ring + (r % R) * bw;
+			const uint2 *src = ring + drslot * bw;
+			if(++drslot == R) drslot = 0;
 			const int base = (int)src[0].x;
 			for(int c = lane * 4; c < bw; c += 256){
 				uint32_t o[4];
@@ -124,44 +138,68 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		dr = upto;
 	};
 
+	int qfill = 0;               // node records below qfill are (or were) in the LDS queue
+	auto refill = [&](int upto){
+		// records [qfill, upto): 3 x 16 bytes each, coalesced
+		const uint4 *src = (const uint4*)nodes;
+		for(int i = qfill * 3 + lane; i < upto * 3; i += 64) nq[i % (POA_NQ * 3)] = src[i];
+		qfill = upto;
+	};
+	refill(min(nn, POA_NQ));
+	__syncthreads();
+	int iters = 0;
 	while(m < nn){
+		iters++;
+		if(qfill < nn && qfill < m + 2 * NL + 64){ refill(min(nn, qfill + 64)); __syncthreads(); }
 		// (A) the window: lanes whose finished node heads the window take their next node
 		{
 			const uint64_t B = __ballot(fin) & lmask;
-			int r = m % NL; if(r < 0) r += NL;
+			const int r = mr;
 			uint64_t rot = B;
 			if(r) rot = ((B >> r) | (B << (NL - r))) & lmask;
 			const int t = (rot == lmask) ? NL : __builtin_ctzll(~rot);
 			int dd = lane - r; if(dd < 0) dd += NL;
 			if(lane < NL && fin && dd < t){
 				cur += NL; p = 0;
+				myslot += NL; if(myslot >= R) myslot -= R;
 				if(cur == 0){ fin = true; }                 // the head's row is there already
 				else if(cur >= nn){ fin = true; }           // past the end: a virtual node, complete at once
 				else {
-					const bsa_poa_node_t nd = nodes[cur];
+					bsa_poa_node_t nd;
+					{
+						const uint4 *rec = nq + (cur % POA_NQ) * 3;
+						const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+						nd.rpos = r0.x; nd.gnode = r0.y; nd.first_in = r0.z; nd.n_in = (uint16_t)(r0.w & 0xFFFFu); nd.base = (uint8_t)((r0.w >> 16) & 0xFFu); nd.flags = (uint8_t)(r0.w >> 24);
+						nd.in[0].src = r1.x; nd.in[0].movx = r1.y; nd.in[0].toff_kind = r1.z; nd.in[1].src = r1.w; nd.in[1].movx = r2.x; nd.in[1].toff_kind = r2.y;
+					}
 					fin = false;
 					rposv = (int)nd.rpos; basev = nd.base; Mv = a.M + ((nd.flags & 1) ? a.refbonus : 0);
 					F = POA_NEG; G = POA_NEG; blk = 0;
-					myrow = (cur % R) * bw; mytag = poa_tag(cur) << 16;
+					myrow = myslot * bw; mytag = poa_tag(cur) << 16;
 					qw = qn[rposv >> 3];
-#define POA_SETUP(k, FL, AD, LIM, SRC, MV, TO, TG)                                                                   \
+#define POA_SETUP(k, FL, AD, LIM, SRC, MV, TO, TG, RH0)                                                              \
 					{                                                                                                      \
 						const bsa_poa_input_t in = nd.in[k];                                                               \
-						FL = 0;                                                                                            \
+						FL = 0; LIM = 0;                                                                                   \
 						if(in.toff_kind & BSA_POA_IN_PRESENT){                                                             \
 							SRC = (int)in.src; MV = (int)in.movx; TO = (int)(in.toff_kind & BSA_POA_IN_TOFF);              \
 							FL = 1u | ((in.toff_kind & BSA_POA_IN_MERGE) ? 2u : 0u) | ((in.toff_kind & BSA_POA_IN_SAME) ? 4u : 0u); \
 							if(cur - SRC > POA_NEAR) FL |= 8u;                                                             \
 							if(MV >= bw) FL |= 16u;                                                                        \
-							LIM = bw - MV; AD = (SRC % R) * bw + MV; TG = poa_tag(SRC);                                    \
+							LIM = bw - MV; TG = poa_tag(SRC);                                                              \
+							{ int sl = myslot - (cur - SRC); if(sl < 0) sl += R; AD = ((FL & 8u) ? 0 : sl * bw) + MV; }       \
+							if(rposv) RH0 = BSA_SCORE_MIN;                                                                 \
+							else if(mode == BSA_MODE_OVERLAP || TO == 0) RH0 = 0;                                          \
+							else if(PW < 2) RH0 = a.O + E * TO;                                                            \
+							else RH0 = max(a.O + E * TO, a.Q + P * TO);                                                    \
 						}                                                                                                  \
 					}
-					POA_SETUP(0, fl0, ad0, lim0, src0, mv0, to0, tg0)
-					POA_SETUP(1, fl1, ad1, lim1, src1, mv1, to1, tg1)
+					POA_SETUP(0, fl0, ad0, lim0, src0, mv0, to0, tg0, rh00)
+					POA_SETUP(1, fl1, ad1, lim1, src1, mv1, to1, tg1, rh01)
 #undef POA_SETUP
 				}
 			}
-			m += t;
+			m += t; mr += t; if(mr >= NL) mr -= NL;
 		}
 		// (B) finished rows leave the ring; a lane waiting for a far predecessor forces them out
 		{
@@ -172,99 +210,103 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				if(__ballot(farwait) != 0ull) __builtin_amdgcn_s_waitcnt(0);      // the stores have to land before they are read back
 			}
 		}
-		// (C) one cell for every lane whose inputs are there
+		// (C) one cell for every lane whose inputs are there.  Straight-line code: what a lane is (one or two inputs, update or merge, a
+		// moved row's synthetic tail, band cell 0) is decided by selects, not branches -- a branch costs a wave more than the few
+		// instructions it would skip.  Only predecessors read back from HBM (further than POA_NEAR nodes away: rare) take a branch.
 		if(!fin){
-			bool ready = true;
-			int h10 = 0, e10 = 0, q10 = 0, h11 = 0, e11 = 0, q11 = 0, hq0 = hp0, hq1 = hp1;
-#define POA_FETCH(FL, AD, LIM, SRC, MV, TG, FU, H1, E1, Q1, HQ)                                                        \
-			if(FL & 1u){                                                                                               \
-				if(FL & 16u){ H1 = BSA_SCORE_MIN; E1 = 0; Q1 = 0; HQ = BSA_SCORE_MIN; }                                \
-				else if(p < LIM){                                                                                      \
-					if(!(FL & 8u)){                                                                                    \
-						const uint2 en = ring[AD];                                                                     \
-						ready = ready && ((en.y >> 16) == TG);                                                         \
-						H1 = (int)en.x; E1 = sx8(en.y); Q1 = sx8(en.y >> 8);                                           \
-						if(p == 0 && MV > 0) HQ = (int)ring[AD - 1].x;                                                 \
-					} else if(SRC < dr){                                                                               \
-						if(p == 0) FU = *(const volatile int32_t*)&gu0[SRC];                                           \
-						const uint32_t cw = *(const volatile uint32_t*)&grows[(size_t)SRC * bw + p + MV];              \
-						H1 = FU + (int)(int16_t)(cw & 0xFFFFu); E1 = sx8(cw >> 16); Q1 = sx8(cw >> 24);                \
-						if(SRC == 0) H1 = poa_init_h<PW>(a, p + MV);                                                   \
-						if(p == 0 && MV > 0){                                                                          \
-							const uint32_t cp = *(const volatile uint32_t*)&grows[(size_t)SRC * bw + MV - 1];          \
-							HQ = (SRC == 0) ? poa_init_h<PW>(a, MV - 1) : FU + (int)(int16_t)(cp & 0xFFFFu);           \
-						}                                                                                              \
-					} else ready = false;                                                                              \
-				} else {                                                                                               \
-					const int ov = p - LIM;                                                                            \
-					H1 = HQ + (ov == 0 ? a.c0 : (ov < a.d ? E : P)); E1 = 0; Q1 = 0;                                   \
-				}                                                                                                      \
+			const bool is0 = (p == 0);
+			int h10, e10, q10, hq0, h11, e11, q11, hq1;
+			bool ok0, ok1;
+#define POA_FETCH(FL, AD, LIM, TG, HPK, H1, E1, Q1, HQ, OK)                                                              \
+			{                                                                                                        \
+				const bool real = (p < LIM) && !(FL & 8u);                                                           \
+				const int adc = real ? AD : 0;                                                                       \
+				const uint2 en = ring[adc];                                                                          \
+				const uint2 em = ring[adc - (adc > 0 ? 1 : 0)];                                                      \
+				const int ov = p - LIM;                                                                              \
+				const int inc = (ov == 0) ? a.c0 : ((ov < a.d) ? E : P);                                             \
+				OK = !real || ((en.y >> 16) == TG);                                                                  \
+				HQ = (FL & 16u) ? BSA_SCORE_MIN : (is0 ? (int)em.x : HPK);                                           \
+				H1 = real ? (int)en.x : ((FL & 16u) ? BSA_SCORE_MIN : HPK + inc);                                    \
+				E1 = real ? sx8(en.y) : 0; Q1 = real ? sx8(en.y >> 8) : 0;                                           \
 			}
-			POA_FETCH(fl0, ad0, lim0, src0, mv0, tg0, fu0, h10, e10, q10, hq0)
-			POA_FETCH(fl1, ad1, lim1, src1, mv1, tg1, fu1, h11, e11, q11, hq1)
+			POA_FETCH(fl0, ad0, lim0, tg0, hp0, h10, e10, q10, hq0, ok0)
+			POA_FETCH(fl1, ad1, lim1, tg1, hp1, h11, e11, q11, hq1, ok1)
 #undef POA_FETCH
-			if(ready){
+			if(__ballot(((fl0 | fl1) & 8u) != 0u) != 0ull){
+				// a predecessor further back than the ring holds: its finished row from HBM (drained first, see (B))
+#define POA_FAR(FL, LIM, SRC, MV, FU, H1, E1, Q1, HQ, OK)                                                                \
+				if((FL & 9u) == 9u && !(FL & 16u) && p < LIM){                                                       \
+					if(SRC < dr){                                                                                    \
+						if(is0) FU = *(const volatile int32_t*)&gu0[SRC];                                            \
+						const uint32_t cw = *(const volatile uint32_t*)&grows[(size_t)SRC * bw + p + MV];            \
+						H1 = (SRC == 0) ? poa_init_h<PW>(a, p + MV) : FU + (int)(int16_t)(cw & 0xFFFFu);             \
+						E1 = sx8(cw >> 16); Q1 = sx8(cw >> 24);                                                      \
+						if(is0 && MV > 0){                                                                           \
+							const uint32_t cp = *(const volatile uint32_t*)&grows[(size_t)SRC * bw + MV - 1];        \
+							HQ = (SRC == 0) ? poa_init_h<PW>(a, MV - 1) : FU + (int)(int16_t)(cp & 0xFFFFu);         \
+						}                                                                                            \
+						OK = true;                                                                                   \
+					} else OK = false;                                                                               \
+				}
+				POA_FAR(fl0, lim0, src0, mv0, fu0, h10, e10, q10, hq0, ok0)
+				POA_FAR(fl1, lim1, src1, mv1, fu1, h11, e11, q11, hq1, ok1)
+#undef POA_FAR
+			}
+			const bool ready = ok0 && ok1;
+			{
 				const int x = rposv + p;
 				const uint32_t nb = (qw >> ((x & 7) * 4)) & 0xFu;
-				const int Sb = ((nb & 3u) == basev) ? Mv : a.X;
-				const int hpc = (int)((nb >> 2) & 1u);
 				const bool beyond = (nb & 8u) != 0u;
+				const int Sb = beyond ? BSA_EPI8_MIN : (((nb & 3u) == basev) ? Mv : a.X);
+				const int hpc = beyond ? 0 : (int)((nb >> 2) & 1u);
+				const bool bs = is0 || (blk == 0);
 				int mm = POA_NEG, Ein = POA_NEG, Qin = POA_NEG, fl = POA_NEG, HX = POA_NEG, EX = POA_NEG, QX = POA_NEG;
-#define POA_INPUT(FL, SRC, MV, TO, H1, E1, Q1, HQ)                                                                     \
-				if(FL & 1u){                                                                                           \
-					if(FL & 2u){ HX = max(HX, H1); EX = max(EX, H1 + E1); QX = max(QX, H1 + Q1); }                    \
-					else {                                                                                             \
-						const int S = beyond ? BSA_EPI8_MIN : Sb + ((FL & 4u) ? 0 : hpc);                             \
-						int mc;                                                                                        \
-						if(p == 0){                                                                                    \
-							int ub0, rh, h0, t;                                                                        \
-							if(FL & 16u) ub0 = BSA_SCORE_MIN;                                                          \
-							else if(MV == 0) ub0 = (SRC == 0) ? a.head_u0 : H1;                                        \
-							else ub0 = HQ;                                                                             \
-							if(MV == 0){                                                                               \
-								if(rposv) rh = BSA_SCORE_MIN;                                                          \
-								else if(mode == BSA_MODE_OVERLAP || TO == 0) rh = 0;                                   \
-								else if(PW < 2) rh = a.O + E * TO;                                                     \
-								else rh = max(a.O + E * TO, a.Q + P * TO);                                             \
-							} else if(MV <= bw) rh = ub0;                                                              \
-							else rh = BSA_SCORE_MIN;                                                                   \
-							h0 = rh - ub0 + S;                                                                         \
-							t = (H1 - ub0) + (PW == 0 ? E : PW == 1 ? E1 : max(E1, Q1));                               \
-							if(h0 >= t) h0 = min(h0, BSA_EPI8_MAX); else h0 = BSA_EPI8_MIN;                            \
-							mc = ub0 + h0;                                                                             \
-							fl = max(fl, ub0 + BSA_EPI8_MIN);                                                          \
-						} else {                                                                                       \
-							mc = HQ + S;                                                                               \
-							if(blk == 0) fl = max(fl, HQ + BSA_EPI8_MIN);                                              \
-						}                                                                                              \
-						mm = max(mm, mc);                                                                              \
-						Ein = max(Ein, H1 + (PW == 0 ? E : E1));                                                       \
-						if(PW == 2) Qin = max(Qin, H1 + Q1);                                                           \
-					}                                                                                                  \
+#define POA_INPUT(FL, SRC, MV, RH0, H1, E1, Q1, HQ)                                                                      \
+				{                                                                                                    \
+					const bool upd = (FL & 3u) == 1u, mrg = (FL & 3u) == 3u;                                         \
+					const int S = Sb + ((FL & 4u) ? 0 : hpc);                                                        \
+					const int ub0 = (FL & 16u) ? BSA_SCORE_MIN : ((MV == 0) ? ((SRC == 0) ? a.head_u0 : H1) : HQ);   \
+					const int rh = (MV == 0) ? RH0 : ((MV <= bw) ? ub0 : BSA_SCORE_MIN);                             \
+					int h0 = rh - ub0 + S;                                                                           \
+					const int t = (H1 - ub0) + (PW == 0 ? E : PW == 1 ? E1 : max(E1, Q1));                           \
+					h0 = (h0 >= t) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;                                           \
+					const int b0 = is0 ? ub0 : HQ;                                                                   \
+					const int mc = b0 + (is0 ? h0 : S);                                                              \
+					mm = max(mm, upd ? mc : POA_NEG);                                                                \
+					fl = max(fl, (upd && bs) ? b0 + BSA_EPI8_MIN : POA_NEG);                                         \
+					Ein = max(Ein, upd ? H1 + (PW == 0 ? E : E1) : POA_NEG);                                         \
+					if(PW == 2) Qin = max(Qin, upd ? H1 + Q1 : POA_NEG);                                             \
+					HX = max(HX, mrg ? H1 : POA_NEG);                                                                \
+					if(PW >= 1) EX = max(EX, mrg ? H1 + E1 : POA_NEG);                                               \
+					if(PW == 2) QX = max(QX, mrg ? H1 + Q1 : POA_NEG);                                               \
 				}
-				POA_INPUT(fl0, src0, mv0, to0, h10, e10, q10, hq0)
-				POA_INPUT(fl1, src1, mv1, to1, h11, e11, q11, hq1)
+				POA_INPUT(fl0, src0, mv0, rh00, h10, e10, q10, hq0)
+				POA_INPUT(fl1, src1, mv1, rh01, h11, e11, q11, hq1)
 #undef POA_INPUT
-				if(blk == 0){ F = max(F, fl); if(PW == 2) G = max(G, fl); }
-				int H = max(max(mm, Ein), max(F, HX));
-				if(PW == 2) H = max(max(H, Qin), G);
-				int e1 = 0, q1 = 0;
-				if(PW == 0) F = H + E;
+				const int Fc = max(F, fl), Gc = max(G, fl);
+				int H = max(max(mm, Ein), max(Fc, HX));
+				if(PW == 2) H = max(max(H, Qin), Gc);
+				int e1 = 0, q1 = 0, Fn, Gn = Gc;
+				if(PW == 0) Fn = H + E;
 				else {
 					e1 = max(max(Ein + E, H + OE), EX) - H;
-					F = max(F + E, H + OE);
+					Fn = max(Fc + E, H + OE);
 					if(PW == 2){
 						q1 = max(max(Qin + P, H + QP), QX) - H;
-						G = max(G + P, H + QP);
+						Gn = max(Gc + P, H + QP);
 					}
 				}
-				ring[myrow + p] = make_uint2((uint32_t)H, ((uint32_t)e1 & 0xFFu) | (((uint32_t)q1 & 0xFFu) << 8) | mytag);
-				hp0 = h10; hp1 = h11;
-				ad0++; ad1++;
-				p++;
-				if(++blk == W) blk = 0;
-				if(((rposv + p) & 7) == 0) qw = qn[(rposv + p) >> 3];
-				if(p == bw) fin = true;
+				if(ready){
+					ring[myrow + p] = make_uint2((uint32_t)H, ((uint32_t)e1 & 0xFFu) | (((uint32_t)q1 & 0xFFu) << 8) | mytag);
+					F = Fn; G = Gn;
+					hp0 = h10; hp1 = h11;
+					ad0++; ad1++;
+					p++;
+					blk = (blk + 1 == W) ? 0 : blk + 1;
+					qw = qn[(rposv + p) >> 3];
+					fin = (p == bw);
+				}
 			}
 		}
 	}
@@ -312,7 +354,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		if(ok > bkey){ bkey = ok; boff = oo; }
 	}
 	bsa_poa_result_t rs;
-	rs.reserved = (int)(wall_clock64() - tick0); rs.nevents = 0;       // forward pass + best end cell, in ticks of the 100 MHz counter rs.fin_node = -1; rs.fin_x = -1; rs.status = BSA_POA_ST_OK;
+	rs.reserved = (int)(wall_clock64() - tick0); if(a.mode & 0x100) rs.reserved = iters; rs.nevents = 0;       // forward pass + best end cell, in ticks of the 100 MHz counter rs.fin_node = -1; rs.fin_x = -1; rs.status = BSA_POA_ST_OK;
 	if(bkey == (long long)0x8000000000000000ull){
 		rs.maxscr = BSA_SCORE_MIN; rs.maxidx = -1; rs.maxoff = -1; rs.status = BSA_POA_ST_NOCAND;
 		if(lane == 0) a.res[blockIdx.x] = rs;
@@ -329,7 +371,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		const int ecap = (int)pg.event_cap;
 		uint32_t *t_rows = (uint32_t*)lds;                                  // 64 rows
 		int32_t *t_u0 = (int32_t*)(lds + (size_t)64 * bw * 4);
-		bsa_poa_node_t *t_nodes = (bsa_poa_node_t*)(lds + (size_t)64 * bw * 4 + 256);
+		PoaTileNode *t_nodes = (PoaTileNode*)(lds + (size_t)64 * bw * 4 + 256);
 		bsa_poa_edge_t *t_edges = (bsa_poa_edge_t*)(lds + (size_t)64 * bw * 4 + 256 + 64 * sizeof(bsa_poa_node_t));
 		const int TE = 512;
 		int n = rs.maxidx, nidx = rs.maxidx, x = rs.maxoff, ne = 0, status = BSA_POA_ST_OK;
@@ -348,36 +390,37 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 			if(lane <= hi - lo) t_u0[lane] = gu0[lo + lane];
 			__syncthreads();
 			if(lane == 0){
-#define TNODE(i)   (((i) >= lo && (i) <= hi) ? t_nodes[(i) - lo] : nodes[i])
-#define TU0(i)     (((i) >= lo && (i) <= hi) ? t_u0[(i) - lo] : *(const volatile int32_t*)&gu0[i])
-#define TCELL(i, pp) (((i) >= lo && (i) <= hi) ? t_rows[((i) - lo) * bw + (pp)] : *(const volatile uint32_t*)&grows[(size_t)(i) * bw + (pp)])
-#define TH(i, pp)  (((i) == 0) ? poa_init_h<PW>(a, (pp)) : TU0(i) + (int)(int16_t)(TCELL(i, pp) & 0xFFFFu))
-#define TE8(i, pp) sx8(TCELL(i, pp) >> 16)
-#define TQ8(i, pp) sx8(TCELL(i, pp) >> 24)
-#define TUS(i, pp) ((pp) == 0 ? TH(i, 0) - TU0(i) : TH(i, pp) - TH(i, (pp) - 1))
-#define TEDGE(k)   (((k) >= elo && (k) < elo + ecnt) ? t_edges[(k) - elo] : gedges[k])
+				auto in_tile = [&](int i) -> bool { return i >= lo && i <= hi; };
+				auto U0 = [&](int i) -> int { if(in_tile(i)) return t_u0[i - lo]; return *(const volatile int32_t*)&gu0[i]; };
+				auto CELL = [&](int i, int pp) -> uint32_t { if(in_tile(i)) return t_rows[(i - lo) * bw + pp]; return *(const volatile uint32_t*)&grows[(size_t)i * bw + pp]; };
+				auto HH = [&](int i, int pp, uint32_t cw, int u0v) -> int { return (i == 0) ? poa_init_h<PW>(a, pp) : u0v + (int)(int16_t)(cw & 0xFFFFu); };
+				auto BASE = [&](int i) -> uint32_t { if(in_tile(i)) return (t_nodes[i - lo].flags_word() >> 16) & 0xFFu; return nodes[i].base; };
 #define EMIT(nn_, xx_, bb_) do{ if(ne >= ecap){ status = BSA_POA_ST_EVENTS; done = true; } else { ev[ne].node = (uint32_t)(nn_); ev[ne].x = (xx_); ev[ne].bt = (bb_); ne++; } }while(0)
 				if(first){
 					first = false;
-					const int pp = x - (int)TNODE(n).rpos;
+					const int pp = x - (int)nodes[n].rpos;
 					if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
-					else Hs1 = TH(n, pp);
+					else Hs1 = HH(n, pp, CELL(n, pp), U0(n));
 				}
 				while(!done){
 					if(n == 0 || x < 0){ done = true; break; }
 					if(lo > 0 && n < lo + POA_NEAR + 1) break;          // the walker's predecessors are about to leave the tile: next tile
-					const bsa_poa_node_t nd = TNODE(n);
+					// the walker's node: always inside the tile
+					const PoaNodeHead nd = t_nodes[n - lo].head();
+					const int nrpos = (int)nd.rpos, nin = (int)nd.n_in, nfirst = (int)nd.first_in;
 					if(bt == 2u || bt == 4u){
 						EMIT(n, x, bt);
 						bool found = false;
-						for(int k = 0; k < (int)nd.n_in && !found; k++){
-							const bsa_poa_edge_t ed = TEDGE((int)nd.first_in + k);
+						for(int k = 0; k < nin && !found; k++){
+							const int ek = nfirst + k;
+							bsa_poa_edge_t ed; if(ek >= elo && ek < elo + ecnt) ed = t_edges[ek - elo]; else ed = gedges[ek];
 							const int w = (int)ed.src, wr = (int)ed.src_rpos;
 							if(x < wr || x >= wr + bw) continue;
-							Hs0 = TH(w, x - wr);
+							const uint32_t cw = CELL(w, x - wr);
+							Hs0 = HH(w, x - wr, cw, U0(w));
 							int qv;
-							if(bt == 2u) qv = PW ? TE8(w, x - wr) : a.O + E;
-							else qv = TQ8(w, x - wr);
+							if(bt == 2u) qv = PW ? sx8(cw >> 16) : a.O + E;
+							else qv = sx8(cw >> 24);
 							if(Hs0 + qv != Hs1) continue;
 							n = w;
 							if(qv == ((bt == 2u) ? a.O + E : a.Q + P)){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
@@ -391,9 +434,15 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						x--;
 						if(Hs0 + t == Hs1){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
 						else if(x >= 0){
-							const int pp = x - (int)nd.rpos;
+							const int pp = x - nrpos;
 							if(pp < 0){ status = BSA_POA_ST_TRACE; done = true; }
-							else { Hs0 -= TUS(n, pp); Hs2++; }
+							else {
+								// us[pp] = H(pp) - H(pp - 1), us[0] = H(0) - ubegs[0]; Hs0 is H(pp) here
+								const int u0v = U0(n);
+								const int hm = (pp == 0) ? u0v : HH(n, pp - 1, CELL(n, pp - 1), u0v);
+								Hs0 -= HH(n, pp, CELL(n, pp), u0v) - hm;
+								Hs2++;
+							}
 						}
 					} else if(bt == 0u){
 						EMIT(n, x, bt);
@@ -402,50 +451,48 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						bt = 0xFFFFFFFFu;
 					} else {
 						uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
-						for(int k = 0; k < (int)nd.n_in; k++){
-							const bsa_poa_edge_t ed = TEDGE((int)nd.first_in + k);
+						const uint32_t nb = (qn[x >> 3] >> ((x & 7) * 4)) & 0xFu;
+						const int sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nd.base) ? a.M + ((nd.flags & 1) ? a.refbonus : 0) : a.X);
+						for(int k = 0; k < nin; k++){
+							const int ek = nfirst + k;
+							bsa_poa_edge_t ed; if(ek >= elo && ek < elo + ecnt) ed = t_edges[ek - elo]; else ed = gedges[ek];
 							const int w = (int)ed.src, wr = (int)ed.src_rpos;
 							const uint32_t cov = ed.cov;
-							int ft = 0, s, scr0, scr1, scr2;
 							if(x < wr || x > bw + wr) continue;
-							else if(x == bw + wr){ Hs0 = TH(w, x - wr - 1); ft |= (1 << 2) | (1 << 4); }
-							else if(x == wr){
-								Hs0 = TU0(w);
-								if(wr == 0 && (mode == BSA_MODE_OVERLAP || w == 0)) ft |= 1 << 15;
-								else ft |= 1;
-							} else Hs0 = TH(w, x - wr - 1);
-							{
-								const uint32_t nb = (qn[x >> 3] >> ((x & 7) * 4)) & 0xFu;
-								const bool same = TNODE(w).base == nd.base;
-								if(nb & 8u) s = BSA_EPI8_MIN;
-								else s = (((nb & 3u) == nd.base) ? a.M + ((nd.flags & 1) ? a.refbonus : 0) : a.X) + ((!same && (nb & 4u)) ? 1 : 0);
-							}
-							if(ft & (1 << 15)) s -= TU0(w);
-							const int pp = x - wr;
+							const int pp = x - wr, u0w = U0(w);
+							const uint32_t cm = (pp >= 1) ? CELL(w, pp - 1) : 0u;
+							const int hm = (pp >= 1) ? HH(w, pp - 1, cm, u0w) : u0w;            // H(pp - 1); at pp = 0 the block start ubegs[0]
+							int ft = 0, s, scr0, scr1 = BSA_SCORE_MIN, scr2 = BSA_SCORE_MIN;
+							if(pp == bw) ft |= (1 << 2) | (1 << 4);
+							else if(pp == 0){ if(wr == 0 && (mode == BSA_MODE_OVERLAP || w == 0)) ft |= 1 << 15; else ft |= 1; }
+							Hs0 = hm;
+							s = sbase;
+							if(!(nb & 8u) && (nb & 4u) && BASE(w) != nd.base) s += 1;
+							if(ft & (1 << 15)) s -= u0w;
 							scr0 = (ft & 1) ? BSA_SCORE_MIN : s;
-							scr1 = (ft & (1 << 2)) ? BSA_SCORE_MIN : TUS(w, pp) + (PW ? TE8(w, pp) : E);
-							scr2 = (ft & (1 << 4)) ? BSA_SCORE_MIN : (PW == 2 ? TUS(w, pp) + TQ8(w, pp) : -BSA_SCORE_MIN);
+							if(pp < bw){
+								const uint32_t cw = CELL(w, pp);
+								const int us = HH(w, pp, cw, u0w) - hm;
+								scr1 = us + (PW ? sx8(cw >> 16) : E);
+								scr2 = (PW == 2) ? us + sx8(cw >> 24) : -BSA_SCORE_MIN;
+							}
 #define POA_PICK(i_, sc_) if(Hs0 + (sc_) == Hs1){ if(cov > btc || (cov == btc && (i_) == 0 && (bti & 0xFFu) != 0u)){ bti = (i_); btc = cov; bnode = w; bh = Hs0; } }
 							POA_PICK(0u, scr0) POA_PICK(1u, scr1) POA_PICK(2u, scr2)
 #undef POA_PICK
 						}
 						if(bti == 0xFFFFFFFFu){
-							const int pp = x - (int)nd.rpos;
+							const int pp = x - nrpos;
 							if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
-							else { bt = 1u; Hs2 = 1; Hs0 = Hs1 - TUS(n, pp); }
+							else {
+								const int u0v = U0(n);
+								const int hm = (pp == 0) ? u0v : HH(n, pp - 1, CELL(n, pp - 1), u0v);
+								bt = 1u; Hs2 = 1; Hs0 = Hs1 - (HH(n, pp, CELL(n, pp), u0v) - hm);
+							}
 						} else if(bti == 0u){ bt = 0u; nidx = bnode; Hs1 = bh; Hs2 = 0; }
 						else if(bti == 1u){ bt = 2u; Hs2 = 1; }
 						else { bt = 4u; Hs2 = 1; }
 					}
 				}
-#undef TNODE
-#undef TU0
-#undef TCELL
-#undef TH
-#undef TE8
-#undef TQ8
-#undef TUS
-#undef TEDGE
 #undef EMIT
 			}
 			n = __shfl(n, 0); done = __shfl((int)done, 0) != 0;
@@ -465,7 +512,7 @@ extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *ctx, int slot, size_t bytes, 
 
 static const size_t POA_LDS_MAX = 160u * 1024u - 1024u;
 static size_t poa_tile_bytes(uint32_t bw){ return (size_t)64 * bw * 4 + 256 + 64 * sizeof(bsa_poa_node_t) + 512 * sizeof(bsa_poa_edge_t); }
-static size_t poa_qn_bytes(uint32_t bw, uint32_t max_slen){ return (((size_t)max_slen + bw + 16) / 8 + 2) * 4; }
+static size_t poa_qn_bytes(uint32_t bw, uint32_t max_slen){ return ((((size_t)max_slen + bw + 16) / 8 + 2) * 4 + 15) & ~(size_t)15; }
 static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max((size_t)(nl + POA_NEAR + POA_DRAIN) * bw * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
 
 extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen){
@@ -488,7 +535,7 @@ extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t m
 	if(std::min((int)rp->X, -g) - 1 - m - g < -100) return 0;
 	if((int)(bw / 16) * ge > 60) return 0;
 	for(uint32_t nl = 64; nl >= 8; nl >>= 1)
-		if(poa_front_bytes(bw, nl) + poa_qn_bytes(bw, max_slen) <= POA_LDS_MAX) return (int)nl;
+		if(poa_front_bytes(bw, nl) + poa_qn_bytes(bw, max_slen) + POA_NQ * sizeof(bsa_poa_node_t) <= POA_LDS_MAX) return (int)nl;
 	return 0;
 }
 
@@ -517,7 +564,8 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 	a.nodes = d_nodes; a.edges = d_edges; a.cands = d_cands; a.progs = d_progs; a.queries = d_queries;
 	a.rows = d_rows; a.u0 = d_u0; a.res = d_results; a.events = d_events;
 	a.bw = bw; a.W = bw / 16; a.nl = (uint32_t)nl; a.R = (uint32_t)nl + POA_NEAR + POA_DRAIN;
-	a.qn_off = (uint32_t)poa_front_bytes(bw, (uint32_t)nl); a.tile_off = 0;
+	a.qn_off = (uint32_t)poa_front_bytes(bw, (uint32_t)nl);
+	a.nq_off = a.qn_off + (uint32_t)poa_qn_bytes(bw, max_slen);
 	a.mode = rp->mode; a.M = rp->M; a.X = rp->X; a.refbonus = rp->refbonus;
 	a.O = rp->gapo1; a.E = rp->gape1; a.Q = rp->gapo2; a.P = rp->gape2; a.T = par->T;
 	{
@@ -530,7 +578,7 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 		const int type = a.mode & 3;
 		a.head_u0 = (type == BSA_MODE_OVERLAP) ? 0 : nt_max - nt_min;
 	}
-	const size_t lds = (size_t)a.qn_off + poa_qn_bytes(bw, max_slen);
+	const size_t lds = (size_t)a.nq_off + POA_NQ * sizeof(bsa_poa_node_t);
 	void *stop = nullptr;
 	rc = bsa_ctx_time_begin_internal(ctx, 0.0, &stop);
 	if(rc != BSA_OK) return rc;
