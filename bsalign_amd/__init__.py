@@ -152,7 +152,7 @@ def lib():
         L.bsa_poa_graph_supported.argtypes = [C.POINTER(SweepParams), C.c_uint32]
         L.bsa_poa_graph_host.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(SweepParams),
                                          vp, vp, C.c_size_t, vp, vp]
-        L.bsa_poa_graph_run.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.POINTER(SweepParams), vp, vp, vp, vp]
+        L.bsa_poa_graph_run.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.POINTER(SweepParams), vp, vp, vp, vp, vp, vp]
         L.bsa_align_debug_rows.argtypes = [vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
         L.bsa_diagdp_batch.argtypes = [vp, u8p, C.c_size_t, vp, C.c_size_t, u8p, C.c_size_t]
         L.bsa_diagdp_last_ms.argtypes = [vp]

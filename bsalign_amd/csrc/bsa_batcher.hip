@@ -43,7 +43,7 @@ struct SubG {                      // a program of the graph form (bsa_poa_batch
 	bsa_sweep_params_t par;
 	bsa_poa_result_t *res; size_t cap;
 	int *rc;
-	const bsa_poa_event_t **ev_src;     // where the submitter finds its steps (pinned staging) after the batch ran
+	const uint32_t **ev_src;            // where the submitter finds its step words (pinned staging) after the batch ran
 };
 struct Pinned {
 	void *p = nullptr; size_t cap = 0;
@@ -133,9 +133,11 @@ static void run_batch_graph(Group *b){
 	size_t ev_total = 0;
 	std::vector<size_t> ev_off(n, 0);
 	for(size_t k = 0; k < n; k++){ ev_off[k] = ev_total; ev_total += P[k].cap; }
-	const size_t o_res = 0, o_ev = align16(n * sizeof(bsa_poa_result_t));
+	// device: results | packed-steps counter | packed steps | per-program walk scratch; host staging: packed steps of every parameter set, one after the other
+	const size_t o_res = 0, o_cnt = align16(n * sizeof(bsa_poa_result_t)), o_pk = o_cnt + 16, o_ev = align16(o_pk + ev_total * 4);
 	int rca = rc0;
-	if(rca == BSA_OK && (!b->h_gout.need(o_ev + ev_total * sizeof(bsa_poa_event_t) + 64) || !b->d_gout.need(o_ev + ev_total * sizeof(bsa_poa_event_t) + 64))) rca = BSA_E_NOMEM;
+	if(rca == BSA_OK && (!b->h_gout.need(ev_total * 4 + 64) || !b->d_gout.need(o_ev + ev_total * 4 + 64))) rca = BSA_E_NOMEM;
+	size_t hused = 0;                   // words of the host staging in use
 	for(size_t g = 0; g < first.size(); g++){
 		int rc = rca;
 		std::vector<size_t> mem;
@@ -177,19 +179,21 @@ static void run_batch_graph(Group *b){
 			const uint8_t *d = (const uint8_t*)b->d_gin.p;
 			// results of this parameter set's programs at the start of the result area, copied out before the next set overwrites them
 			rc = bsa_poa_graph_run(b->ctx, (const bsa_poa_node_t*)(d + o_n), nn, (const bsa_poa_edge_t*)(d + o_e), (const bsa_poa_cand_t*)(d + o_c),
-				(const bsa_poa_prog_t*)(d + o_p), np, d + o_q, max_slen, &par, (bsa_poa_result_t*)dres, (bsa_poa_event_t*)((uint8_t*)b->d_gout.p + o_ev), nullptr, nullptr);
+				(const bsa_poa_prog_t*)(d + o_p), np, d + o_q, max_slen, &par, (bsa_poa_result_t*)dres, (uint32_t*)((uint8_t*)b->d_gout.p + o_ev),
+				(uint32_t*)((uint8_t*)b->d_gout.p + o_pk), (uint64_t*)((uint8_t*)b->d_gout.p + o_cnt), nullptr, nullptr);
 		}
 		BCHK(hipEventRecord(e1, st));
 		BCHK(hipMemcpyAsync(hres.data(), dres, np * sizeof(bsa_poa_result_t), hipMemcpyDeviceToHost, st));
 		BCHK(hipStreamSynchronize(st));
-		// the steps: one copy from the first to the last program of the set that has any
-		size_t lo = ~(size_t)0, hi = 0, down = np * sizeof(bsa_poa_result_t);
-		if(rc == BSA_OK) for(size_t i = 0; i < np; i++) if(hres[i].nevents > 0){ lo = std::min(lo, ev_off[mem[i]]); hi = std::max(hi, ev_off[mem[i]] + (size_t)hres[i].nevents); }
-		if(rc == BSA_OK && hi > lo){
-			BCHK(hipMemcpyAsync((uint8_t*)b->h_gout.p + o_ev + lo * sizeof(bsa_poa_event_t), (const uint8_t*)b->d_gout.p + o_ev + lo * sizeof(bsa_poa_event_t),
-				(hi - lo) * sizeof(bsa_poa_event_t), hipMemcpyDeviceToHost, st));
+		// the steps of the set's programs: one copy of the packed words
+		size_t total = 0, down = np * sizeof(bsa_poa_result_t);
+		if(rc == BSA_OK) for(size_t i = 0; i < np; i++) if(hres[i].nevents > 0) total = std::max(total, (size_t)(uint32_t)hres[i].reserved + (size_t)hres[i].nevents);
+		if(rc == BSA_OK && total > ev_total) rc = BSA_E_HIP;
+		const size_t hbase = hused;
+		if(rc == BSA_OK && total){
+			BCHK(hipMemcpyAsync((uint32_t*)b->h_gout.p + hbase, (const uint8_t*)b->d_gout.p + o_pk, total * 4, hipMemcpyDeviceToHost, st));
 			BCHK(hipStreamSynchronize(st));
-			down += (hi - lo) * sizeof(bsa_poa_event_t);
+			down += total * 4; hused += total;
 		}
 		devlk.unlock();
 		if(rc == BSA_OK){ float ms = 0; if(hipEventElapsedTime(&ms, e0, e1) == hipSuccess) b->device_ms += ms; }
@@ -199,7 +203,7 @@ static void run_batch_graph(Group *b){
 		for(size_t i = 0; i < np; i++){
 			const SubG &s = P[mem[i]];
 			*s.rc = rc;
-			if(rc == BSA_OK){ *s.res = hres[i]; *s.ev_src = (const bsa_poa_event_t*)((const uint8_t*)b->h_gout.p + o_ev) + ev_off[mem[i]]; }
+			if(rc == BSA_OK){ *s.res = hres[i]; *s.ev_src = (const uint32_t*)b->h_gout.p + hbase + (uint32_t)hres[i].reserved; }
 		}
 		b->launches++; b->programs += np; b->tasks += nn; b->bytes_up += in_bytes; b->bytes_down += down;
 	}
@@ -380,7 +384,7 @@ extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *node
 	if(bsa_poa_graph_supported(par, slen) == 0) return BSA_E_UNSUPPORTED;
 	Group *b = group_of_this_thread(bb);
 	int rc = BSA_E_HIP;
-	const bsa_poa_event_t *src = nullptr;
+	const uint32_t *src = nullptr;
 	{
 		std::unique_lock<std::mutex> lk(b->m);
 		if(b->active == 0) return BSA_E_ARG;
@@ -390,7 +394,11 @@ extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *node
 		if(b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
 		else b->cv.wait(lk, [&]{ return b->gen > my; });
 	}
-	if(rc == BSA_OK && src && res->nevents > 0) memcpy(events, src, (size_t)res->nevents * sizeof(bsa_poa_event_t));
+	if(rc == BSA_OK){
+		if((size_t)res->nevents > events_cap) return BSA_E_ARG;
+		if(src) bsa_poa_expand_steps(src, res, events);       // every window's own thread expands its steps
+		else res->reserved = 0;
+	}
 	return rc;
 }
 

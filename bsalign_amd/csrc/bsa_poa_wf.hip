@@ -37,8 +37,9 @@ struct PoaArgs {
 	const bsa_poa_node_t *nodes; const bsa_poa_edge_t *edges; const bsa_poa_cand_t *cands; const bsa_poa_prog_t *progs;
 	const uint8_t *queries;
 	uint32_t *rows; int32_t *u0;
-	bsa_poa_result_t *res; bsa_poa_event_t *events;
-	uint32_t bw, W, nl, R, qn_off, nq_off;
+	bsa_poa_result_t *res; uint32_t *steps;          // per program a scratch region of event_cap step words (node << 3 | bt)
+	uint32_t *packed; unsigned long long *packed_used;   // all programs' steps back to back, in the order the programs finish
+	uint32_t bw, W, nl, R, ri_off, qn_off, nq_off;
 	int32_t mode, M, X, refbonus, O, E, Q, P, T;
 	int32_t c0, d, head_u0, xp;
 };
@@ -65,7 +66,8 @@ __device__ __forceinline__ int poa_init_h(const PoaArgs &a, int p){     // row_i
 template<int PW>
 __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	extern __shared__ __align__(16) uint8_t lds[];
-	uint2 *ring = (uint2*)lds;
+	uint32_t *ring = (uint32_t*)lds;                // R rows of bw cells {int16 H - base, e, q}: exactly the cells the traceback reads from HBM
+	uint2 *rinfo = (uint2*)(lds + a.ri_off);        // per ring row: {base = H of its first cell, tag << 16 | cells written}
 	uint32_t *qn = (uint32_t*)(lds + a.qn_off);
 	uint4 *nq = (uint4*)(lds + a.nq_off);           // node records of the next POA_NQ nodes, record i at slot i % POA_NQ (three uint4 each)
 	const bsa_poa_prog_t pg = a.progs[blockIdx.x];
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	if(nn == 0){ if(lane == 0){ bsa_poa_result_t r; r.maxscr = BSA_SCORE_MIN; r.maxidx = -1; r.maxoff = -1; r.status = BSA_POA_ST_NOCAND; r.nevents = 0; r.fin_node = -1; r.fin_x = -1; r.reserved = 0; a.res[blockIdx.x] = r; } return; }
 
 	// ring tags cleared, query as nibbles (code | differs-from-next << 2 | beyond-the-read << 3), head row in slot 0
-	for(int i = lane; i < R * bw; i += 64) ring[i] = make_uint2(0u, 0u);
+	for(int i = lane; i < R; i += 64) rinfo[i] = make_uint2(0u, 0u);
 	{
 		const uint8_t *q = a.queries + pg.query_off;
 		const int nqw = (slen + bw + 16) / 8 + 1;
@@ -98,8 +100,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	}
 	__syncthreads();
 	{
-		const uint32_t eq = ((PW >= 1) ? 0xC1u : 0u) | ((PW == 2) ? 0xC100u : 0u) | (poa_tag(0) << 16);      // e = q = -63
-		for(int p = lane; p < bw; p += 64) ring[p] = make_uint2((uint32_t)poa_init_h<PW>(a, p), eq);
+		const uint32_t eq = ((PW >= 1) ? 0xC10000u : 0u) | ((PW == 2) ? 0xC1000000u : 0u);      // e = q = -63
+		const int h0 = poa_init_h<PW>(a, 0);
+		for(int p = lane; p < bw; p += 64) ring[p] = (uint32_t)((poa_init_h<PW>(a, p) - h0) & 0xFFFF) | eq;
+		if(lane == 0) rinfo[0] = make_uint2((uint32_t)h0, (poa_tag(0) << 16) | (uint32_t)bw);
 	}
 	__syncthreads();
 
@@ -114,7 +118,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	int cur = lane - NL, p = 0;
 	bool fin = true;             // finished `cur`, waiting for the window to take the next node
 	int rposv = 0, Mv = 0, F = POA_NEG, G = POA_NEG, blk = 0;
-	uint32_t basev = 0, mytag = 0; int myrow = 0;
+	uint32_t basev = 0, mytag = 0; int myrow = 0, mybase = 0;
 	uint32_t qw = 0;
 	uint32_t fl0 = 0, fl1 = 0;   // input flags: 1 present, 2 merge, 4 same base, 8 far (HBM), 16 dead (moved by >= bandwidth)
 	int ad0 = 0, ad1 = 0, lim0 = 0, lim1 = 0, hp0 = 0, hp1 = 0, src0 = 0, src1 = 0, mv0 = 0, mv1 = 0, to0 = 0, to1 = 0;
@@ -122,18 +126,12 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	int rh00 = 0, rh01 = 0;                                // the diagonal score left of band cell 0 when the band did not move (bspoa.h:2242-2249)
 
 	auto drain = [&](int upto){
-		// rows dr .. upto - 1 -> HBM as {int16 H - H(0), e, q}; four cells per lane and store
+		// rows dr .. upto - 1 -> HBM as they are; four cells per lane and store
 		for(int r = dr; r < upto; r++){
-			const uint2 *src = ring + drslot * bw;
+			const uint32_t *src = ring + drslot * bw;
+			for(int c = lane * 4; c < bw; c += 256) *(uint4*)&grows[(size_t)r * bw + c] = *(const uint4*)&src[c];
+			if(lane == 0) gu0[r] = (r == 0) ? a.head_u0 : (int)rinfo[drslot].x;
 			if(++drslot == R) drslot = 0;
-			const int base = (int)src[0].x;
-			for(int c = lane * 4; c < bw; c += 256){
-				uint32_t o[4];
-#pragma unroll
-				for(int k = 0; k < 4; k++){ const uint2 en = src[c + k]; o[k] = (uint32_t)(((int)en.x - base) & 0xFFFF) | ((en.y & 0xFFFFu) << 16); }
-				*(uint4*)&grows[(size_t)r * bw + c] = make_uint4(o[0], o[1], o[2], o[3]);
-			}
-			if(lane == 0) gu0[r] = (r == 0) ? a.head_u0 : base;
 		}
 		dr = upto;
 	};
@@ -187,7 +185,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							if(cur - SRC > POA_NEAR) FL |= 8u;                                                             \
 							if(MV >= bw) FL |= 16u;                                                                        \
 							LIM = bw - MV; TG = poa_tag(SRC);                                                              \
-							{ int sl = myslot - (cur - SRC); if(sl < 0) sl += R; AD = ((FL & 8u) ? 0 : sl * bw) + MV; }       \
+							{ int sl = myslot - (cur - SRC); if(sl < 0) sl += R; if(FL & 8u) sl = 0; AD = sl * bw + MV; TG = (TG << 16) | (uint32_t)sl; }   \
 							if(rposv) RH0 = BSA_SCORE_MIN;                                                                 \
 							else if(mode == BSA_MODE_OVERLAP || TO == 0) RH0 = 0;                                          \
 							else if(PW < 2) RH0 = a.O + E * TO;                                                            \
@@ -221,14 +219,16 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 			{                                                                                                        \
 				const bool real = (p < LIM) && !(FL & 8u);                                                           \
 				const int adc = real ? AD : 0;                                                                       \
-				const uint2 en = ring[adc];                                                                          \
-				const uint2 em = ring[adc - (adc > 0 ? 1 : 0)];                                                      \
+				const uint32_t cw = ring[adc];                                                                       \
+				const uint32_t cm = ring[adc - (adc > 0 ? 1 : 0)];                                                   \
+				const uint2 ri = rinfo[TG & 0xFFFFu];                                                                \
 				const int ov = p - LIM;                                                                              \
 				const int inc = (ov == 0) ? a.c0 : ((ov < a.d) ? E : P);                                             \
-				OK = !real || ((en.y >> 16) == TG);                                                                  \
-				HQ = (FL & 16u) ? BSA_SCORE_MIN : (is0 ? (int)em.x : HPK);                                           \
-				H1 = real ? (int)en.x : ((FL & 16u) ? BSA_SCORE_MIN : HPK + inc);                                    \
-				E1 = real ? sx8(en.y) : 0; Q1 = real ? sx8(en.y >> 8) : 0;                                           \
+				/* the cell is there when the row's owner has written past it (and the row is still this node's) */  \
+				OK = !real || (ri.y >> 16 == TG >> 16 && (int)(ri.y & 0xFFFFu) > adc - (int)(TG & 0xFFFFu) * bw);     \
+				HQ = (FL & 16u) ? BSA_SCORE_MIN : (is0 ? (int)ri.x + (int)(int16_t)(cm & 0xFFFFu) : HPK);            \
+				H1 = real ? (int)ri.x + (int)(int16_t)(cw & 0xFFFFu) : ((FL & 16u) ? BSA_SCORE_MIN : HPK + inc);     \
+				E1 = real ? sx8(cw >> 16) : 0; Q1 = real ? sx8(cw >> 24) : 0;                                        \
 			}
 			POA_FETCH(fl0, ad0, lim0, tg0, hp0, h10, e10, q10, hq0, ok0)
 			POA_FETCH(fl1, ad1, lim1, tg1, hp1, h11, e11, q11, hq1, ok1)
@@ -298,7 +298,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					}
 				}
 				if(ready){
-					ring[myrow + p] = make_uint2((uint32_t)H, ((uint32_t)e1 & 0xFFu) | (((uint32_t)q1 & 0xFFu) << 8) | mytag);
+					if(is0) mybase = H;
+					ring[myrow + p] = (uint32_t)((H - mybase) & 0xFFFF) | (((uint32_t)e1 & 0xFFu) << 16) | ((uint32_t)q1 << 24);
+					rinfo[myslot] = make_uint2((uint32_t)mybase, mytag | (uint32_t)(p + 1));
 					F = Fn; G = Gn;
 					hp0 = h10; hp1 = h11;
 					ad0++; ad1++;
@@ -364,10 +366,11 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	rs.maxidx = (int)cands[(0xFFFFFFFFu - (uint32_t)(bkey & 0xFFFFFFFFll)) >> 1].node;
 	rs.maxoff = boff;
 
+	if(a.mode & 0x200){ if(lane == 0) a.res[blockIdx.x] = rs; return; }      // (measurement: forward pass and best end cell only)
 	// ---- traceback: lane 0 walks, the wave keeps a tile of 64 nodes (records, in-edges, rows) in LDS ahead of it ----
 	{
 		const bsa_poa_edge_t *gedges = a.edges + pg.first_edge;
-		bsa_poa_event_t *ev = a.events + pg.first_event;
+		uint32_t *ev = a.steps + pg.first_event;
 		const int ecap = (int)pg.event_cap;
 		uint32_t *t_rows = (uint32_t*)lds;                                  // 64 rows
 		int32_t *t_u0 = (int32_t*)(lds + (size_t)64 * bw * 4);
@@ -381,21 +384,32 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		while(!done){
 			// tile = nodes [lo, hi], hi = the walker's node
 			const int hi = n, lo = max(0, hi - 63);
-			const int elo = (int)nodes[lo].first_in;
-			const int ecnt = min(TE, (int)nodes[hi].first_in + (int)nodes[hi].n_in - elo);
+			// eight 16-byte loads in flight per lane before the first is stored: a tile is 32 KB of rows and the loop would otherwise
+			// pay one memory latency per 1 KB
+			auto copy16 = [&](uint4 *dst, const uint4 *src, int n16){
+				for(int b0 = 0; b0 < n16; b0 += 512){
+					uint4 v[8];
+#pragma unroll
+					for(int k = 0; k < 8; k++){ const int i = b0 + k * 64 + lane; if(i < n16) v[k] = src[i]; }
+#pragma unroll
+					for(int k = 0; k < 8; k++){ const int i = b0 + k * 64 + lane; if(i < n16) dst[i] = v[k]; }
+				}
+			};
 			__syncthreads();
-			for(int i = lane; i < (hi - lo + 1) * (int)(sizeof(bsa_poa_node_t) / 16); i += 64) ((uint4*)t_nodes)[i] = ((const uint4*)(nodes + lo))[i];
-			for(int i = lane; i < ecnt; i += 64) ((uint4*)t_edges)[i] = ((const uint4*)(gedges + elo))[i];
-			for(int i = lane; i < (hi - lo + 1) * bw / 4; i += 64) ((uint4*)t_rows)[i] = ((const uint4*)(grows + (size_t)lo * bw))[i];
+			copy16((uint4*)t_nodes, (const uint4*)(nodes + lo), (hi - lo + 1) * (int)(sizeof(bsa_poa_node_t) / 16));
+			copy16((uint4*)t_rows, (const uint4*)(grows + (size_t)lo * bw), (hi - lo + 1) * bw / 4);
 			if(lane <= hi - lo) t_u0[lane] = gu0[lo + lane];
+			__syncthreads();
+			const int elo = (int)t_nodes[0].head().first_in;
+			const int ecnt = min(TE, (int)t_nodes[hi - lo].head().first_in + (int)t_nodes[hi - lo].head().n_in - elo);
+			copy16((uint4*)t_edges, (const uint4*)(gedges + elo), ecnt);
 			__syncthreads();
 			if(lane == 0){
 				auto in_tile = [&](int i) -> bool { return i >= lo && i <= hi; };
 				auto U0 = [&](int i) -> int { if(in_tile(i)) return t_u0[i - lo]; return *(const volatile int32_t*)&gu0[i]; };
 				auto CELL = [&](int i, int pp) -> uint32_t { if(in_tile(i)) return t_rows[(i - lo) * bw + pp]; return *(const volatile uint32_t*)&grows[(size_t)i * bw + pp]; };
 				auto HH = [&](int i, int pp, uint32_t cw, int u0v) -> int { return (i == 0) ? poa_init_h<PW>(a, pp) : u0v + (int)(int16_t)(cw & 0xFFFFu); };
-				auto BASE = [&](int i) -> uint32_t { if(in_tile(i)) return (t_nodes[i - lo].flags_word() >> 16) & 0xFFu; return nodes[i].base; };
-#define EMIT(nn_, xx_, bb_) do{ if(ne >= ecap){ status = BSA_POA_ST_EVENTS; done = true; } else { ev[ne].node = (uint32_t)(nn_); ev[ne].x = (xx_); ev[ne].bt = (bb_); ne++; } }while(0)
+#define EMIT(nn_, xx_, bb_) do{ if(ne >= ecap){ status = BSA_POA_ST_EVENTS; done = true; } else { ev[ne] = ((uint32_t)(nn_) << 3) | (bb_); ne++; } }while(0)
 				if(first){
 					first = false;
 					const int pp = x - (int)nodes[n].rpos;
@@ -459,22 +473,32 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							const int w = (int)ed.src, wr = (int)ed.src_rpos;
 							const uint32_t cov = ed.cov;
 							if(x < wr || x > bw + wr) continue;
-							const int pp = x - wr, u0w = U0(w);
-							const uint32_t cm = (pp >= 1) ? CELL(w, pp - 1) : 0u;
-							const int hm = (pp >= 1) ? HH(w, pp - 1, cm, u0w) : u0w;            // H(pp - 1); at pp = 0 the block start ubegs[0]
+							const int pp = x - wr;
+							int u0w, hm, hc = 0, ec = 0, qc = 0; uint32_t wbase;
+							if(w >= lo){
+								// (the common case: everything about the predecessor is in the tile)
+								const uint32_t *rw = t_rows + (w - lo) * bw;
+								const uint32_t cm = rw[pp >= 1 ? pp - 1 : 0], cw = rw[pp < bw ? pp : bw - 1];
+								u0w = t_u0[w - lo]; wbase = (t_nodes[w - lo].flags_word() >> 16) & 0xFFu;
+								hm = (pp >= 1) ? HH(w, pp - 1, cm, u0w) : u0w;
+								hc = HH(w, pp < bw ? pp : bw - 1, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24);
+							} else {
+								u0w = U0(w); wbase = nodes[w].base;
+								hm = (pp >= 1) ? HH(w, pp - 1, CELL(w, pp - 1), u0w) : u0w;          // H(pp - 1); at pp = 0 the block start ubegs[0]
+								if(pp < bw){ const uint32_t cw = CELL(w, pp); hc = HH(w, pp, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24); }
+							}
 							int ft = 0, s, scr0, scr1 = BSA_SCORE_MIN, scr2 = BSA_SCORE_MIN;
 							if(pp == bw) ft |= (1 << 2) | (1 << 4);
 							else if(pp == 0){ if(wr == 0 && (mode == BSA_MODE_OVERLAP || w == 0)) ft |= 1 << 15; else ft |= 1; }
 							Hs0 = hm;
 							s = sbase;
-							if(!(nb & 8u) && (nb & 4u) && BASE(w) != nd.base) s += 1;
+							if(!(nb & 8u) && (nb & 4u) && wbase != nd.base) s += 1;
 							if(ft & (1 << 15)) s -= u0w;
 							scr0 = (ft & 1) ? BSA_SCORE_MIN : s;
 							if(pp < bw){
-								const uint32_t cw = CELL(w, pp);
-								const int us = HH(w, pp, cw, u0w) - hm;
-								scr1 = us + (PW ? sx8(cw >> 16) : E);
-								scr2 = (PW == 2) ? us + sx8(cw >> 24) : -BSA_SCORE_MIN;
+								const int us = hc - hm;
+								scr1 = us + (PW ? ec : E);
+								scr2 = (PW == 2) ? us + qc : -BSA_SCORE_MIN;
 							}
 #define POA_PICK(i_, sc_) if(Hs0 + (sc_) == Hs1){ if(cov > btc || (cov == btc && (i_) == 0 && (bti & 0xFFu) != 0u)){ bti = (i_); btc = cov; bnode = w; bh = Hs0; } }
 							POA_PICK(0u, scr0) POA_PICK(1u, scr1) POA_PICK(2u, scr2)
@@ -488,7 +512,11 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 								const int hm = (pp == 0) ? u0v : HH(n, pp - 1, CELL(n, pp - 1), u0v);
 								bt = 1u; Hs2 = 1; Hs0 = Hs1 - (HH(n, pp, CELL(n, pp), u0v) - hm);
 							}
-						} else if(bti == 0u){ bt = 0u; nidx = bnode; Hs1 = bh; Hs2 = 0; }
+						} else if(bti == 0u){
+							// a match / mismatch column: the step itself (bspoa.h:2394-2410) taken at once
+							EMIT(n, x, 0u);
+							x--; n = bnode; nidx = bnode; Hs1 = bh; Hs2 = 0;
+						}
 						else if(bti == 1u){ bt = 2u; Hs2 = 1; }
 						else { bt = 4u; Hs2 = 1; }
 					}
@@ -497,8 +525,15 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 			}
 			n = __shfl(n, 0); done = __shfl((int)done, 0) != 0;
 		}
+		// the steps join the other programs' in one packed array (what the host downloads): reserve, then copy as a wave
+		ne = __shfl(ne, 0);
+		unsigned long long off = 0;
+		if(lane == 0 && ne > 0) off = atomicAdd(a.packed_used, (unsigned long long)ne);
+		off = __shfl(off, 0);
+		__builtin_amdgcn_s_waitcnt(0);
+		for(int i = lane; i < ne; i += 64) a.packed[off + i] = *(const volatile uint32_t*)&ev[i];
 		if(lane == 0){
-			rs.status = status; rs.nevents = ne; rs.fin_node = n; rs.fin_x = x;
+			rs.status = status; rs.nevents = ne; rs.fin_node = n; rs.fin_x = x; rs.reserved = (int)(uint32_t)off;
 			a.res[blockIdx.x] = rs;
 		}
 	}
@@ -513,7 +548,8 @@ extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *ctx, int slot, size_t bytes, 
 static const size_t POA_LDS_MAX = 160u * 1024u - 1024u;
 static size_t poa_tile_bytes(uint32_t bw){ return (size_t)64 * bw * 4 + 256 + 64 * sizeof(bsa_poa_node_t) + 512 * sizeof(bsa_poa_edge_t); }
 static size_t poa_qn_bytes(uint32_t bw, uint32_t max_slen){ return ((((size_t)max_slen + bw + 16) / 8 + 2) * 4 + 15) & ~(size_t)15; }
-static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max((size_t)(nl + POA_NEAR + POA_DRAIN) * bw * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
+static size_t poa_ring_bytes(uint32_t bw, uint32_t nl){ return (size_t)(nl + POA_NEAR + POA_DRAIN) * bw * 4; }
+static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max(poa_ring_bytes(bw, nl) + (size_t)(nl + POA_NEAR + POA_DRAIN) * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
 
 extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen){
 	if(!par) return 0;
@@ -541,8 +577,8 @@ extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t m
 
 extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, size_t nnodes, const bsa_poa_edge_t *d_edges, const bsa_poa_cand_t *d_cands,
 		const bsa_poa_prog_t *d_progs, size_t nprogs, const uint8_t *d_queries, uint32_t max_slen, const bsa_sweep_params_t *par,
-		bsa_poa_result_t *d_results, bsa_poa_event_t *d_events, uint32_t *d_rows, int32_t *d_u0){
-	if(!ctx || !par || (nprogs && (!d_nodes || !d_progs || !d_queries || !d_results || !d_events))) return BSA_E_ARG;
+		bsa_poa_result_t *d_results, uint32_t *d_steps, uint32_t *d_packed, uint64_t *d_packed_used, uint32_t *d_rows, int32_t *d_u0){
+	if(!ctx || !par || (nprogs && (!d_nodes || !d_progs || !d_queries || !d_results || !d_steps || !d_packed || !d_packed_used))) return BSA_E_ARG;
 	if(nprogs == 0) return BSA_OK;
 	if(nprogs > 0x0FFFFFF0ull || (d_rows == nullptr) != (d_u0 == nullptr)) return BSA_E_ARG;
 	const int nl = bsa_poa_graph_supported(par, max_slen);
@@ -562,8 +598,10 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 	}
 	PoaArgs a;
 	a.nodes = d_nodes; a.edges = d_edges; a.cands = d_cands; a.progs = d_progs; a.queries = d_queries;
-	a.rows = d_rows; a.u0 = d_u0; a.res = d_results; a.events = d_events;
+	a.rows = d_rows; a.u0 = d_u0; a.res = d_results; a.steps = d_steps; a.packed = d_packed; a.packed_used = (unsigned long long*)d_packed_used;
+	if(hipMemsetAsync(d_packed_used, 0, 8, st) != hipSuccess) return BSA_E_HIP;
 	a.bw = bw; a.W = bw / 16; a.nl = (uint32_t)nl; a.R = (uint32_t)nl + POA_NEAR + POA_DRAIN;
+	a.ri_off = (uint32_t)poa_ring_bytes(bw, (uint32_t)nl);
 	a.qn_off = (uint32_t)poa_front_bytes(bw, (uint32_t)nl);
 	a.nq_off = a.qn_off + (uint32_t)poa_qn_bytes(bw, max_slen);
 	a.mode = rp->mode; a.M = rp->M; a.X = rp->X; a.refbonus = rp->refbonus;
@@ -589,6 +627,16 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 #undef POA_LAUNCH
 	if(hipGetLastError() != hipSuccess) return BSA_E_HIP;
 	return bsa_ctx_time_end_internal(ctx, stop);
+}
+
+// step words (node << 3 | bt) -> (node, x, bt): x starts at the best end cell's column and moves left with every M and I step
+extern "C" void bsa_poa_expand_steps(const uint32_t *steps, bsa_poa_result_t *res, bsa_poa_event_t *events){
+	int x = res->maxoff;
+	for(int i = 0; i < res->nevents; i++){
+		events[i].node = steps[i] >> 3; events[i].bt = steps[i] & 7u; events[i].x = x;
+		if(events[i].bt <= 1u) x--;
+	}
+	res->reserved = 0;
 }
 
 namespace {
@@ -628,20 +676,26 @@ extern "C" int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, s
 #define PCHK(x) do { if((x) != hipSuccess) return BSA_E_HIP; } while(0)
 	PCHK(dn.alloc(nnodes * sizeof(bsa_poa_node_t))); PCHK(de.alloc(nedges * sizeof(bsa_poa_edge_t))); PCHK(dc.alloc(ncands * sizeof(bsa_poa_cand_t)));
 	PCHK(dp.alloc(nprogs * sizeof(bsa_poa_prog_t))); PCHK(dq.alloc(query_bytes + 64)); PCHK(dr.alloc(nprogs * sizeof(bsa_poa_result_t)));
-	PCHK(dv.alloc(events_cap * sizeof(bsa_poa_event_t))); PCHK(drows.alloc(nnodes * bw * 4)); PCHK(du0.alloc(nnodes * 4));
+	PoaDevBuf dpk;
+	PCHK(dv.alloc(events_cap * 4)); PCHK(dpk.alloc(events_cap * 4 + 16)); PCHK(drows.alloc(nnodes * bw * 4)); PCHK(du0.alloc(nnodes * 4));
 	PCHK(hipMemcpyAsync(dn.p, nodes, nnodes * sizeof(bsa_poa_node_t), hipMemcpyHostToDevice, st));
 	if(nedges) PCHK(hipMemcpyAsync(de.p, edges, nedges * sizeof(bsa_poa_edge_t), hipMemcpyHostToDevice, st));
 	if(ncands) PCHK(hipMemcpyAsync(dc.p, cands, ncands * sizeof(bsa_poa_cand_t), hipMemcpyHostToDevice, st));
 	PCHK(hipMemcpyAsync(dp.p, progs, nprogs * sizeof(bsa_poa_prog_t), hipMemcpyHostToDevice, st));
 	PCHK(hipMemcpyAsync(dq.p, queries, query_bytes, hipMemcpyHostToDevice, st));
 	rc = bsa_poa_graph_run(ctx, (const bsa_poa_node_t*)dn.p, nnodes, (const bsa_poa_edge_t*)de.p, (const bsa_poa_cand_t*)dc.p, (const bsa_poa_prog_t*)dp.p, nprogs,
-		(const uint8_t*)dq.p, max_slen, par, (bsa_poa_result_t*)dr.p, (bsa_poa_event_t*)dv.p, (uint32_t*)drows.p, (int32_t*)du0.p);
+		(const uint8_t*)dq.p, max_slen, par, (bsa_poa_result_t*)dr.p, (uint32_t*)dv.p, (uint32_t*)dpk.p + 4, (uint64_t*)dpk.p, (uint32_t*)drows.p, (int32_t*)du0.p);
 	if(rc != BSA_OK) return rc;
 	PCHK(hipMemcpyAsync(results, dr.p, nprogs * sizeof(bsa_poa_result_t), hipMemcpyDeviceToHost, st));
 	PCHK(hipStreamSynchronize(st));
-	for(size_t k = 0; k < nprogs; k++){
-		const size_t ne = results[k].nevents > 0 ? (size_t)results[k].nevents : 0;
-		if(ne) PCHK(hipMemcpyAsync(events + progs[k].first_event, (const bsa_poa_event_t*)dv.p + progs[k].first_event, ne * sizeof(bsa_poa_event_t), hipMemcpyDeviceToHost, st));
+	{
+		// the packed steps of all programs in one copy, expanded into (node, x, bt) here
+		size_t total = 0;
+		for(size_t k = 0; k < nprogs; k++) if(results[k].nevents > 0) total = std::max(total, (size_t)(uint32_t)results[k].reserved + (size_t)results[k].nevents);
+		std::vector<uint32_t> pk(total);
+		if(total) PCHK(hipMemcpyAsync(pk.data(), (const uint32_t*)dpk.p + 4, total * 4, hipMemcpyDeviceToHost, st));
+		PCHK(hipStreamSynchronize(st));
+		for(size_t k = 0; k < nprogs; k++) bsa_poa_expand_steps(pk.data() + (uint32_t)results[k].reserved, &results[k], events + progs[k].first_event);
 	}
 	if(rows_out && u0_out){
 		std::vector<uint32_t> cells(nnodes * bw);

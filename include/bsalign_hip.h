@@ -313,11 +313,16 @@ typedef struct { int32_t h; int8_t e, q; uint16_t tag; } bsa_poa_cell_t;      /*
 /* lanes a read of `max_slen` bases can use at this parameter set (a power of two up to 64), 0 = not supported: bandwidth above 256,
  * scores outside the exactness guard, or a read too long for the LDS.  Callers fall back to bsa_sweep_* then. */
 int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen);
-/* all pointers DEVICE memory, asynchronous on the context stream.  d_rows: (total nodes) x bw uint32 cells, d_u0: total nodes int32
- * (scratch the traceback reads; pass NULL for both to use the context's own buffer). */
+/* all pointers DEVICE memory, asynchronous on the context stream.  The steps of a walk leave the device as one word each,
+ * node << 3 | bt (x is implied: it starts at maxoff and moves left with every M and I step): d_steps is scratch, program k walks
+ * into d_steps[first_event .. + event_cap); when it is done its steps are appended to d_packed (capacity: the sum of all
+ * event_cap), result.reserved = where, *d_packed_used = words in use (zeroed by the call).  bsa_poa_expand_steps turns a
+ * program's words into bsa_poa_event_t on the host.  d_rows: (total nodes) x bw uint32 cells, d_u0: total nodes int32 (scratch
+ * the traceback reads; pass NULL for both to use the context's own buffer). */
 int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, size_t nnodes, const bsa_poa_edge_t *d_edges, const bsa_poa_cand_t *d_cands,
                       const bsa_poa_prog_t *d_progs, size_t nprogs, const uint8_t *d_queries, uint32_t max_slen, const bsa_sweep_params_t *par,
-                      bsa_poa_result_t *d_results, bsa_poa_event_t *d_events, uint32_t *d_rows, int32_t *d_u0);
+                      bsa_poa_result_t *d_results, uint32_t *d_steps, uint32_t *d_packed, uint64_t *d_packed_used, uint32_t *d_rows, int32_t *d_u0);
+void bsa_poa_expand_steps(const uint32_t *steps, bsa_poa_result_t *res, bsa_poa_event_t *events);
 /* HOST buffers in and out (uploads, runs, downloads, synchronises).  rows_out / u0_out (optional, tests): every node's row as
  * absolute cells, nnodes x bw, and its ubegs[0]. */
 int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, size_t nnodes, const bsa_poa_edge_t *edges, size_t nedges,
