@@ -97,8 +97,26 @@ struct bsa_sweep_batcher {
 	std::mutex dev;                       // one batch on the device at a time (a bsa_ctx_t is not shared between threads)
 	std::mutex am; uint32_t next = 0;     // group assignment, in order of first appearance
 	std::unordered_map<std::thread::id, Group*> of;    // a thread keeps its group for the batcher's life, whatever other batchers it uses in between
+	// host-side admission: one window thread per CPU the process may use is runnable at a time (bsa_sweep_batcher_enter); a thread
+	// waiting in submit() gives its slot to another window.  Hundreds of runnable threads on a CPU-quota'd container otherwise
+	// burn the quota in a fraction of each period and everybody is throttled for the rest of it.
+	std::mutex tm; std::condition_variable tcv; int tokens = 0; bool gated = false;
+	std::unordered_map<std::thread::id, bool> holds;
+	void acquire(){ std::unique_lock<std::mutex> lk(tm); tcv.wait(lk, [&]{ return tokens > 0; }); tokens--; holds[std::this_thread::get_id()] = true; }
+	void release(){ std::lock_guard<std::mutex> lk(tm); auto it = holds.find(std::this_thread::get_id()); if(it != holds.end() && it->second){ it->second = false; tokens++; tcv.notify_one(); } }
+	bool holding(){ std::lock_guard<std::mutex> lk(tm); auto it = holds.find(std::this_thread::get_id()); return it != holds.end() && it->second; }
 	~bsa_sweep_batcher(){ for(Group *g : groups) delete g; }
 };
+static int host_cpus(){
+	if(const char *e = getenv("BSA_POA_HOST_THREADS")){ const int v = atoi(e); if(v >= 1) return v; }
+	int n = (int)std::thread::hardware_concurrency();
+	if(FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")){          // cgroup v2 quota: "<quota> <period>" or "max <period>"
+		char q[32]; long per = 0;
+		if(fscanf(f, "%31s %ld", q, &per) == 2 && per > 0 && strcmp(q, "max") != 0){ const long v = (atol(q) + per - 1) / per; if(v >= 1 && (n <= 0 || v < n)) n = (int)v; }
+		fclose(f);
+	}
+	return n > 0 ? n : 16;
+}
 static Group *group_of_this_thread(bsa_sweep_batcher *b){
 	std::lock_guard<std::mutex> lk(b->am);
 	auto it = b->of.find(std::this_thread::get_id());
@@ -358,7 +376,12 @@ extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, s
 		Sub s{tasks, ntasks, query, slen, *par, rows_out, nblocks, res, &rc, &src, &nbytes};
 		b->pend.push_back(s);
 		if(b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
-		else b->cv.wait(lk, [&]{ return b->gen > my; });
+		else {
+			const bool had = bb->gated && bb->holding();
+			if(had) bb->release();
+			b->cv.wait(lk, [&]{ return b->gen > my; });
+			if(had){ lk.unlock(); bb->acquire(); }
+		}
 	}
 	// the row blocks are copied out here, by every window's own thread (the staging is not reused before all of them
 	// have come back with their next program)
@@ -366,8 +389,16 @@ extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, s
 	return rc;
 }
 
+// a window thread announces itself before it starts computing: it then runs only while it holds one of the host slots
+extern "C" void bsa_sweep_batcher_enter(bsa_sweep_batcher_t *bb){
+	if(!bb) return;
+	{ std::lock_guard<std::mutex> lk(bb->tm); if(!bb->gated){ bb->gated = true; bb->tokens = host_cpus(); } }
+	bb->acquire();
+}
+
 extern "C" void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *bb){
 	if(!bb) return;
+	if(bb->gated) bb->release();
 	Group *b = group_of_this_thread(bb);
 	std::unique_lock<std::mutex> lk(b->m);
 	if(b->active) b->active--;
@@ -392,7 +423,12 @@ extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *node
 		SubG s{nodes, nnodes, edges, nedges, cands, ncands, query, slen, *par, res, events_cap, &rc, &src};
 		b->pendg.push_back(s);
 		if(b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
-		else b->cv.wait(lk, [&]{ return b->gen > my; });
+		else {
+			const bool had = bb->gated && bb->holding();
+			if(had) bb->release();
+			b->cv.wait(lk, [&]{ return b->gen > my; });
+			if(had){ lk.unlock(); bb->acquire(); }
+		}
 	}
 	if(rc == BSA_OK){
 		if((size_t)res->nevents > events_cap) return BSA_E_ARG;

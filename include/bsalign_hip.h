@@ -351,6 +351,9 @@ void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b);
 int  bsa_sweep_batcher_submit(void *batcher, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
                               const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *res);
 void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *b);
+/* optional, first thing a window's thread does: from then on the thread computes only while it holds one of as many host slots
+ * as the process has CPUs (cgroup quota, or $BSA_POA_HOST_THREADS); waiting in submit() hands the slot to another window */
+void bsa_sweep_batcher_enter(bsa_sweep_batcher_t *b);
 /* the same rendezvous for the graph form (sweep + traceback on the device, nothing but the steps comes back): signature of
  * bsa_poa_graph_backend_fn (include/bsalign_poa_adapter.h), `batcher` as user.  Declines with BSA_E_UNSUPPORTED, without
  * waiting, what bsa_poa_graph_supported declines; the window then submits the read through bsa_sweep_batcher_submit. */

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <time.h>
 #include "bsalign_hip.h"
 
 /* executes one program; returns 0 or a BSA_E_* code.  rows_out receives nblocks row blocks. */
@@ -57,7 +58,10 @@ typedef struct {
 	bsa_poa_result_t res;
 	int have_trace;             /* the last bsa_poa_align_rd_core went through the graph form: bsa_poa_apply_trace has its steps */
 	unsigned long long graph_reads, rows_reads;     /* reads aligned through either form */
+	double seconds[3];          /* host time spent building programs, inside the backend (waiting for the device), applying walks */
 } bsa_poa_adapter_t;
+
+static inline double bsa_poa_now(void){ struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 static inline void bsa_poa_adapter_init(bsa_poa_adapter_t *ad, bsa_poa_backend_fn run, void *user){
 	memset(ad, 0, sizeof(*ad));
@@ -289,10 +293,13 @@ static inline int bsa_poa_align_rd_core(BSPOA *g, BSPOAPar *par, u2i rid, u4i nh
 	ad->have_trace = 0;
 	if(ad->run_graph && nhead != ntail && g->sels->size >= 2){
 		const size_t ecap = 2 * ((size_t)g->slen + g->sels->size) + 64;
+		double t0 = bsa_poa_now(), t1;
 		bsa_poa_flatten_graph(g, par, nhead, ntail, ad);
 		BSA_POA_GROW(ad->events, 0, ad->capevents, bsa_poa_event_t, ecap);
+		t1 = bsa_poa_now(); ad->seconds[0] += t1 - t0;
 		rc = ad->run_graph(ad->user, ad->nodes, ad->nnodes, ad->edges, ad->nedges, ad->cands, ad->ncands, g->qseq->buffer + g->qb, g->slen, &sp,
 			&ad->res, ad->events, ecap);
+		ad->seconds[1] += bsa_poa_now() - t1;
 		if(rc == 0){
 			if(ad->res.status != BSA_POA_ST_OK){
 				/* the walk left the stored rows: the reference reads outside its arena or does not terminate on this input */
@@ -345,6 +352,7 @@ static inline seqalign_result_t bsa_poa_apply_trace(BSPOA *g, BSPOAPar *par, u4i
 	bspoanode_t *gn, *rd;
 	const bsa_poa_event_t *ev;
 	int k, col;
+	const double t0 = bsa_poa_now();
 	UNUSED(par);
 	nhead = ref_bspoanodev(g->nodes, nhead)->header;
 	ntail = ref_bspoanodev(g->nodes, ntail)->header;
@@ -379,6 +387,7 @@ static inline seqalign_result_t bsa_poa_apply_trace(BSPOA *g, BSPOAPar *par, u4i
 		rd = get_rdnode_bspoa(g, rid, rbeg + k);
 		if(rd->cpos) col = rd->cpos; else rd->cpos = col;
 	}
+	ad->seconds[2] += bsa_poa_now() - t0;
 	return rs;
 }
 

@@ -35,6 +35,7 @@ static inline void bsa_poa_end_one(BSPOA *g, bsa_ctx_t *ctx);
 static void *bsa_poa_many_thread(void *vp){
 	bsa_poa_many_job_t *j = (bsa_poa_many_job_t*)vp;
 	bsa_poa_adapter_t ad;
+	bsa_sweep_batcher_enter(j->batcher);                 /* (runs while it holds one of the host slots) */
 	bsa_poa_adapter_init_graph(&ad, bsa_poa_batcher_submit_graph, bsa_sweep_batcher_submit, j->batcher);
 	j->g->devsweep = &ad;
 	end_bspoa(j->g);

@@ -458,8 +458,11 @@ typedef struct {
 	int nreads, mode, record, rc;
 } many_job_t;
 
+static batch_leave_fn g_batch_enter = NULL;
+void ref_poa_set_batcher_enter(void *enter_addr){ g_batch_enter = (batch_leave_fn)enter_addr; }
 static void *many_thread(void *vp){
 	many_job_t *j = (many_job_t*)vp;
+	if((j->mode == 4 || j->mode == 7) && g_batch_enter) g_batch_enter(g_batcher);
 	j->rc = ref_poa_run(j->handle, j->reads, j->offs, j->lens, j->nreads, j->mode, NULL, j->record);
 	if((j->mode == 4 || j->mode == 7) && g_batch_leave) g_batch_leave(g_batcher);       /* this window submits nothing more */
 	return NULL;
@@ -647,3 +650,4 @@ void ref_poa_form_counts(void *vp, uint64_t *graph_reads, uint64_t *rows_reads){
 	ref_poa_t *p = (ref_poa_t*)vp;
 	*graph_reads = p->ad.graph_reads; *rows_reads = p->ad.rows_reads;
 }
+void ref_poa_binding_seconds(void *vp, double *out){ ref_poa_t *p = (ref_poa_t*)vp; out[0] = p->ad.seconds[0]; out[1] = p->ad.seconds[1]; out[2] = p->ad.seconds[2]; }

@@ -44,6 +44,9 @@ HID int bsa_sweep_host(bsa_ctx_t *c, const bsa_row_task_t *t, size_t nt, const b
 HID int bsa_sweep_batcher_create(bsa_ctx_t *c, uint32_t n, bsa_sweep_batcher_t **out){ return p_bcreate ? p_bcreate(c, n, out) : BSA_E_UNSUPPORTED; }
 HID void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b){ if(p_bdestroy) p_bdestroy(b); }
 HID void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *b){ if(p_bleave) p_bleave(b); }
+static fn_bvoid p_benter;
+void refp_attach_enter(void *benter){ p_benter = (fn_bvoid)benter; }
+HID void bsa_sweep_batcher_enter(bsa_sweep_batcher_t *b){ if(p_benter) p_benter(b); }
 HID int bsa_sweep_batcher_submit(void *b, const bsa_row_task_t *t, size_t nt, const uint8_t *q, uint32_t sl, const bsa_sweep_params_t *par, uint8_t *rows, size_t nb, bsa_sweep_result_t *res){
 	return p_bsubmit ? p_bsubmit(b, t, nt, q, sl, par, rows, nb, res) : BSA_E_UNSUPPORTED;
 }

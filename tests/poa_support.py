@@ -137,8 +137,12 @@ def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
         recs.append(d)
     g1, g2 = C.c_uint64(), C.c_uint64()
     r.ref_poa_form_counts(h, C.byref(g1), C.byref(g2))
+    secs = np.zeros(3, np.float64)
+    r.ref_poa_binding_seconds.argtypes = [C.c_void_p, C.c_void_p]
+    r.ref_poa_binding_seconds.restype = None
+    r.ref_poa_binding_seconds(h, secs.ctypes.data)
     r.ref_poa_destroy(h)
-    return dict(bad=bad, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, graph_reads=g1.value, rows_reads=g2.value)
+    return dict(bad=bad, binding_seconds=secs, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, graph_reads=g1.value, rows_reads=g2.value)
 
 
 def run_ref_poa(reads, mode, p, record=True):

@@ -14,7 +14,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not S.have_ref(), reason="orac
 
 
 class Batcher:
-    def __init__(self, ctx, participants):
+    def __init__(self, ctx, participants, gate=True):
         import bsalign_amd as B
         self.L = B.lib()
         self.L.bsa_sweep_batcher_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -29,6 +29,9 @@ class Batcher:
         r.ref_poa_set_batcher.restype = None
         r.ref_poa_set_batcher(C.cast(self.L.bsa_sweep_batcher_submit, C.c_void_p), C.cast(self.L.bsa_sweep_batcher_leave, C.c_void_p), self.h)
         r.ref_poa_set_batcher_graph(C.cast(self.L.bsa_poa_batcher_submit_graph, C.c_void_p))
+        r.ref_poa_set_batcher_enter.argtypes = [C.c_void_p]
+        r.ref_poa_set_batcher_enter.restype = None
+        r.ref_poa_set_batcher_enter(C.cast(self.L.bsa_sweep_batcher_enter, C.c_void_p) if gate else None)
 
     def stats(self):
         out = np.zeros(8, np.uint64)

@@ -37,6 +37,8 @@ def _lib(ctx):
                   C.cast(b.bsa_sweep_batcher_submit, C.c_void_p), C.cast(b.bsa_sweep_batcher_leave, C.c_void_p))
     L.refp_attach_graph.argtypes = [C.c_void_p] * 2
     L.refp_attach_graph(C.cast(b.bsa_poa_graph_host, C.c_void_p), C.cast(b.bsa_poa_batcher_submit_graph, C.c_void_p))      # graph form: sweep + walk on the device
+    L.refp_attach_enter.argtypes = [C.c_void_p]
+    L.refp_attach_enter(C.cast(b.bsa_sweep_batcher_enter, C.c_void_p))
     return L
 
 
