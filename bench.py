@@ -280,11 +280,12 @@ def poa_cpu_baseline(args, bw):
 
 
 def main_poa_recorded(args):
-    """`--workload poa --poa-source recorded`: the sweep programs of REAL POA windows.  W windows of R synthetic reads each
-    are run through the reference's end_bspoa (oracle/_ref) once, outside the timed region, with the program of every
-    read recorded (exactly what include/bsalign_poa_adapter.h would submit); the timed region then runs all of them on
-    the device the way the lock-step batcher does -- read r of all windows as one launch per band width.  The best end
-    cell of every program is checked against what the reference's own sweep found.  Single GPU."""
+    """`--workload poa --poa-source recorded`: the sweeps of REAL POA windows.  W windows of R synthetic reads each are run through the
+    reference's end_bspoa (oracle/_ref) once, outside the timed region, and for every read the graph-form program the binding builds
+    (include/bsalign_poa_adapter.h: nodes, in-edges, candidates) is recorded; the timed region runs all of them on the device the
+    way the lock-step batcher does -- read r of all windows as one launch per band width: forward DP as a wavefront, best end cell,
+    traceback (bsa_poa_graph_run).  Every program's best end cell is checked against what the reference's own sweep found.
+    Single GPU."""
     import torch
     import bsalign_amd as B
     import support as S
@@ -294,119 +295,118 @@ def main_poa_recorded(args):
         return
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    nwin = args.pairs or 192
-    nreads, L = 16, (args.length or 3000)
+    nwin = args.pairs or 256
+    nreads, L = 12, (args.length or 1500)
     pp = P.par()
     windows = [P.synth_reads((SEED + 977 * w) & 0x7FFFFFFF, L, nreads, eps=(args.eps,)) for w in range(nwin)]
     ncores = len(physical_cores())
     q = cpu_quota()
     ncores = min(ncores, q) if q else ncores
-    # CPU side: the untouched end_bspoa of every window on the host's cores, and (recording run) the seconds inside the
-    # reference's own sweep
     _, t_ref = P.run_many(windows, 0, pp, threads=ncores)
-    rec, _ = P.run_many(windows, 1, pp, threads=ncores, record=True)
+    rec, _ = P.run_many(windows, 1, pp, threads=ncores, record=2)
     core_seconds = sum(w["core_seconds"] for w in rec)
     updates = sum(w["core_updates"] for w in rec)
     merges = sum(w["core_merges"] for w in rec)
     lib = B.lib()
     ctx = B.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    # groups: (read index, band width) -> programs of all windows
     groups = {}
     for w, d in enumerate(rec):
         for r, rc in enumerate(d["recs"]):
-            groups.setdefault((r, rc["bandwidth"]), []).append((w, r))
-    launches, cells, balg = [], 0.0, 0.0
-    keep = []
-    for (r, bw), members in sorted(groups.items()):
+            if rc["bandwidth"] <= 256 and len(rc["nodes"]) > 1:
+                groups.setdefault((r, rc["bandwidth"]), []).append(rc)
+    launches, cells, balg, nprog_total = [], 0.0, 0.0, 0
+    for (r, bw), rcs in sorted(groups.items()):
         sp = B.SweepParams()
         sp.rows = B.RowsParams(pp["alnmode"], bw, pp["M"], pp["X"], pp["refbonus"], pp["O"], pp["E"], pp["Q"], pp["P"])
         sp.T = pp["T"]
         blk = lib.bsa_rows_block_bytes(bw, pp["O"], pp["E"], pp["Q"], pp["P"])
-        tl, ql, progs, qoff, qlen, want = [], [], np.zeros(len(members), dtype=B.SWEEP_PROG_DTYPE), [], [], []
-        t0 = q0 = b0 = 0
-        for i, (w, rr) in enumerate(members):
-            rc = rec[w]["recs"][rr]
-            t = rec[w]["tasks"][rc["task_off"]:rc["task_off"] + rc["ntasks"]].copy()
-            t["query"] = i
-            tl.append(t)
-            ql.append(rec[w]["queries"][rc["query_off"]:rc["query_off"] + rc["slen"]])
-            progs[i] = (t0, rc["ntasks"], b0, 0)
-            qoff.append(q0); qlen.append(rc["slen"])
-            want.append((rc["maxscr"], rc["maxidx"], rc["maxoff"]))
-            t0 += rc["ntasks"]; q0 += (rc["slen"] + 127) & ~63; b0 += rc["nblocks"]
-            nu = int((t["op"] == 0).sum()); nm = int((t["op"] == 1).sum())       # BSA_ROW_OP_UPDATE, BSA_ROW_OP_MERGE
-            cells += float(nu) * bw
-            balg += (2.0 * nu + 3.0 * nm) * blk
+        progs = np.zeros(len(rcs), B.POA_PROG_DTYPE)
+        n0 = e0 = c0 = q0 = v0 = 0
+        for i, rc in enumerate(rcs):
+            cap = 2 * (rc["slen"] + len(rc["nodes"])) + 64
+            progs[i] = (n0, len(rc["nodes"]), e0, len(rc["edges"]), c0, len(rc["cands"]), rc["slen"], cap, q0, v0)
+            n0 += len(rc["nodes"]); e0 += len(rc["edges"]); c0 += len(rc["cands"]); q0 += (rc["slen"] + 31) & ~15; v0 += cap
+            nd = rc["nodes"]
+            for tk in (nd["in0_tk"], nd["in1_tk"]):
+                pres = (tk & 0x80000000) != 0
+                nu = int((pres & ((tk & 0x40000000) == 0)).sum()); nm = int((pres & ((tk & 0x40000000) != 0)).sum())
+                cells += float(nu) * bw; balg += (2.0 * nu + 3.0 * nm) * blk
         qb = np.zeros(q0 + 64, np.uint8)
-        for i, x in enumerate(ql):
-            qb[qoff[i]:qoff[i] + len(x)] = x
-        dv = dict(tasks=torch.from_numpy(np.concatenate(tl).view(np.uint8)).to(dev), progs=torch.from_numpy(progs.view(np.uint8)).to(dev),
-                  q=torch.from_numpy(qb).to(dev), qoff=torch.from_numpy(np.array(qoff, np.int64)).to(dev), qlen=torch.from_numpy(np.array(qlen, np.int32)).to(dev),
-                  res=torch.zeros(len(members) * 4, dtype=torch.int32, device=dev), rows=torch.zeros(b0 * blk, dtype=torch.uint8, device=dev))
-        keep.append(dv)
-        launches.append((sp, len(members), dv, want))
+        for i, rc in enumerate(rcs):
+            qb[int(progs[i]["query_off"]):int(progs[i]["query_off"]) + rc["slen"]] = rc["query"]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).copy()).to(dev)
+        dv = dict(nodes=t(np.concatenate([rc["nodes"] for rc in rcs])), edges=t(np.concatenate([rc["edges"] for rc in rcs])),
+                  cands=t(np.concatenate([rc["cands"] for rc in rcs])), progs=t(progs), q=t(qb),
+                  res=torch.zeros(len(rcs) * 8, dtype=torch.int32, device=dev), steps=torch.zeros(v0 + 16, dtype=torch.int32, device=dev),
+                  packed=torch.zeros(v0 + 16, dtype=torch.int32, device=dev), used=torch.zeros(2, dtype=torch.int64, device=dev))
+        launches.append((sp, len(rcs), n0, max(rc["slen"] for rc in rcs), dv, rcs))
+        nprog_total += len(rcs)
+
+    def launch(sp, n, nn, msl, dv):
+        rc = lib.bsa_poa_graph_run(ctx.h, dv["nodes"].data_ptr(), nn, dv["edges"].data_ptr(), dv["cands"].data_ptr(), dv["progs"].data_ptr(), n, dv["q"].data_ptr(),
+                                   msl, C.byref(sp), dv["res"].data_ptr(), dv["steps"].data_ptr(), dv["packed"].data_ptr(), dv["used"].data_ptr(), None, None)
+        assert rc == 0, "bsa_poa_graph_run failed: %d" % rc
 
     def step():
-        for sp, n, dv, _ in launches:
-            dv["rows"].zero_()
-            rc = lib.bsa_sweep_run(ctx.h, dv["rows"].data_ptr(), dv["tasks"].data_ptr(), dv["progs"].data_ptr(), n, dv["q"].data_ptr(),
-                                   dv["qoff"].data_ptr(), dv["qlen"].data_ptr(), C.byref(sp), dv["res"].data_ptr())
-            assert rc == 0, "bsa_sweep_run failed: %d" % rc
+        for sp, n, nn, msl, dv, _ in launches:
+            launch(sp, n, nn, msl, dv)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # kernel time: one launch at a time with the library's own HIP events
     kms_tot = 0.0
-    for sp, n, dv, _ in launches:
-        rc = lib.bsa_sweep_run(ctx.h, dv["rows"].data_ptr(), dv["tasks"].data_ptr(), dv["progs"].data_ptr(), n, dv["q"].data_ptr(),
-                               dv["qoff"].data_ptr(), dv["qlen"].data_ptr(), C.byref(sp), dv["res"].data_ptr())
-        kms, _, _ = ctx.last_kernel_ms()
-        kms_tot += kms
-    ident = True
-    for sp, n, dv, want in launches:
-        res = dv["res"].cpu().numpy().view(B.SWEEP_RESULT_DTYPE)
-        ident &= all((int(res[i]["maxscr"]), int(res[i]["maxidx"]), int(res[i]["maxoff"])) == want[i] for i in range(n))
-    # lock-step end to end: the reference's host code per window on host threads, every sweep through the batcher
+    for sp, n, nn, msl, dv, _ in launches:
+        launch(sp, n, nn, msl, dv)
+        kms_tot += ctx.last_kernel_ms()[0]
+    ident, steps_total = True, 0
+    for sp, n, nn, msl, dv, rcs in launches:
+        res = dv["res"].cpu().numpy().view(B.POA_RESULT_DTYPE)
+        for i, rc in enumerate(rcs):
+            gi = int(rc["nodes"][int(res[i]["maxidx"])]["gnode"]) if res[i]["maxidx"] >= 0 else -1
+            ident &= res[i]["status"] == 0 and (int(res[i]["maxscr"]), gi, int(res[i]["maxoff"])) == (rc["maxscr"], rc["maxidx"], rc["maxoff"])
+            steps_total += int(res[i]["nevents"])
+    # lock-step end to end: the reference's host code per window on host threads, every sweep + walk through the batcher
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     e2e = None
     try:
         from test_poa_batched_gpu import Batcher
         bt = Batcher(ctx, nwin)
         try:
-            devres, t_dev = P.run_many(windows, 4, pp)
+            devres, t_dev = P.run_many(windows, 7, pp)
             st = bt.stats()
         finally:
             bt.close()
-        same = all(np.array_equal(a["cns"], b["cns"]) and a["msa"] == b["msa"] for a, b in zip(rec, devres))
+        base, _ = P.run_many(windows, 0, pp, threads=ncores)
+        same = all(np.array_equal(a["cns"], b["cns"]) and a["msa"] == b["msa"] for a, b in zip(base, devres))
         e2e = {"windows_per_s": round(nwin / t_dev, 2), "seconds": round(t_dev, 3), "identical_to_reference": bool(same), "batches": st["batches"], "launches": st["launches"],
                "MB_up": round(st["bytes_up"] / 1e6, 1), "MB_down": round(st["bytes_down"] / 1e6, 1), "device_s": round(st["device_us"] / 1e6, 3),
-               "note": "host side = the reference's own C (oracle/_ref) on one thread per window; informational, not the measured value"}
+               "note": "host side = the reference's own C (oracle/_ref) on one thread per window, one runnable thread per CPU; informational, not the measured value"}
     except Exception as ex:          # the checker is optional here
         e2e = {"error": str(ex)}
     nl = len(launches)
     achieved = (balg / nl) / (kms_tot / nl / 1e3) / 1e9 if kms_tot > 0 else 0.0
     line = {
-        "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP sweep (align_rd_bspoacore) on recorded programs",
+        "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP (align_rd_bspoacore) + traceback (alignment2graph_bspoa) on recorded programs",
         "value": round(cells * args.steps / elapsed / 1e9, 3), "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8",
-        "data": "sweep programs recorded from the reference's end_bspoa (oracle/_ref, outside the timed region) on synthetic reads, seed %d" % SEED,
-        "config": {"workload": "poa-recorded: %d POA windows x %d reads x %d bp (eps %.2f), default POA parameters (overlap, bandwidth 128, 2-piece gaps); a step = every "
-                               "read's sweep of every window, read r of all windows per launch (%d launches, %.0f row updates + %.0f merges)" % (nwin, nreads, L, args.eps, nl, updates, merges),
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 (exact image of the reference's i8 differences)",
+        "data": "graph-form programs recorded from the reference's end_bspoa (oracle/_ref, outside the timed region) on synthetic reads, seed %d" % SEED,
+        "config": {"workload": "poa-recorded: %d POA windows x %d reads x %d bp (eps %.2f), default POA parameters (overlap, bandwidth 128, 2-piece gaps); a step = every read's "
+                               "sweep and traceback of every window, read r of all windows per launch (%d launches, %d programs, %.0f row updates + %.0f merges, %d traceback steps)"
+                               % (nwin, nreads, L, args.eps, nl, nprog_total, updates, merges, steps_total),
                    "windows": nwin, "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": "k_sweep", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1)},
-        "checks": {"best_end_cell_identical_all_programs": bool(ident), "programs": sum(n for _, n, _, _ in launches)},
-        "cpu_baseline": {"value": round(updates * 128 / core_seconds / 1e9 * 1.0, 4), "unit": "GCUPS", "cores": 1, "kind": "reference",
-                         "sample": "seconds inside the reference's align_rd_bspoacore for the same %d windows (sum over windows, each on one thread): %.2f s; "
-                                   "whole end_bspoa of all windows on %d host threads: %.2f s = %.1f windows/s" % (nwin, core_seconds, ncores, t_ref, nwin / t_ref),
+                     "kernel": "k_poa_wf", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
+                     "note": "latency-bound: one wave per read, a row trails its predecessor by movx + 1 cells (DESIGN section 4b)"},
+        "checks": {"best_end_cell_identical_all_programs": bool(ident), "programs": nprog_total},
+        "cpu_baseline": {"value": round(updates * 128 / (t_ref * 0 + core_seconds / ncores) / 1e9, 4) if core_seconds > 0 else None, "unit": "GCUPS", "cores": ncores, "kind": "reference",
+                         "sample": "the reference's align_rd_bspoacore inside end_bspoa of the same %d windows on %d host threads (one window per thread at a time): %.2f s summed over threads "
+                                   "= %.4f GCUPS per core; the whole end_bspoa of all windows: %.2f s = %.1f windows/s" % (nwin, ncores, core_seconds, updates * 128 / core_seconds / 1e9 if core_seconds > 0 else 0, t_ref, nwin / t_ref),
                          "end_bspoa_windows_per_s": round(nwin / t_ref, 2), "threads": ncores},
         "lockstep_end_to_end": e2e,
     }

@@ -206,7 +206,7 @@ static void record_read(ref_poa_t *p, seqalign_result_t rs, int mismatch, uint64
 	r->bandwidth = g->bandwidth; r->slen = g->slen; r->qb = g->qb; r->nblocks = (uint32_t)g->mmcnt; r->piecewise = (uint32_t)g->piecewise;
 	r->rows_hash = rows_hash; r->mismatch = mismatch;
 	r->task_off = p->ntasks; r->query_off = p->nq;
-	if(p->mode == 5 && p->record_programs){
+	if((p->mode == 5 && p->record_programs) || (p->mode == 1 && (p->record_programs & 2))){
 #define APPEND(dst, n, cap, src, cnt, type) do { if((n) + (cnt) > (cap)){ (cap) = ((n) + (cnt)) * 2 + 64; (dst) = (type*)realloc((dst), (cap) * sizeof(type)); } \
 		memcpy((dst) + (n), (src), (cnt) * sizeof(type)); (n) += (cnt); } while(0)
 		r->node_off = p->ngn; r->edge_off = p->nge; r->cand_off = p->ngc; r->trace_off = p->ngt;
@@ -354,6 +354,11 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 			else if(p->ad.tasks[i].op == BSA_ROW_OP_MERGE) p->core_merges ++;
 		}
 		for(k=0;k<g->sels->size;k++) ref_bspoanodev(g->nodes, g->sels->buffer[k])->vst = 0;
+		p->ad.nnodes = p->ad.nedges = p->ad.ncands = 0; p->ncur = 0;
+		if((p->record_programs & 2) && head != tail && g->sels->size >= 2){      /* the graph-form program the binding would build, recorded beside the reference's own sweep */
+			bsa_poa_flatten_graph(g, par, head, tail, &p->ad);
+			for(k=0;k<g->sels->size;k++) ref_bspoanodev(g->nodes, g->sels->buffer[k])->vst = 0;
+		}
 		clock_gettime(CLOCK_MONOTONIC, &t0);
 		score = align_rd_bspoacore(g, par, rid, head, tail);
 		clock_gettime(CLOCK_MONOTONIC, &t1);

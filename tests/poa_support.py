@@ -207,7 +207,29 @@ def run_many(windows, mode, p, threads=8, record=False):
         nc, nr = C.c_uint32(), C.c_uint32()
         mh = r.ref_poa_msa_hash(h, C.byref(nc), C.byref(nr))
         d = dict(cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value))
-        if record:
+        if record == 2:
+            # graph-form programs (bsa_poa_node_t ...) of this window, one per aligned read, with the reference's best end cell
+            sizes = np.zeros(4, np.uint64)
+            r.ref_poa_graph_sizes(h, sizes.ctypes.data)
+            gn, ge, gc = np.zeros(int(sizes[0]), WF_NODE), np.zeros(int(sizes[1]), WF_EDGE), np.zeros(int(sizes[2]), WF_CAND)
+            r.ref_poa_graph_data(h, gn.ctypes.data, ge.ctypes.data, gc.ctypes.data, None)
+            queries = np.zeros(int(r.ref_poa_nquery_bytes(h)), dtype=np.uint8)
+            if len(queries):
+                dummy = np.zeros(max(int(r.ref_poa_ntasks(h)), 1), dtype=TASK_DTYPE)
+                r.ref_poa_programs(h, dummy.ctypes.data, queries.ctypes.data)
+            recs = []
+            for k in range(r.ref_poa_nrec(h)):
+                o = np.zeros(20, np.int32)
+                a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+                r.ref_poa_rec(h, k, o.ctypes.data, C.byref(a), C.byref(b), C.byref(c))
+                gr = np.zeros(11, np.int64)
+                r.ref_poa_graph_rec(h, k, gr.ctypes.data)
+                recs.append(dict(maxscr=int(o[10]), maxidx=int(o[11]), maxoff=int(o[12]), bandwidth=int(o[13]), slen=int(o[14]), piecewise=int(o[18]),
+                                 nodes=gn[gr[0]:gr[0] + gr[4]], edges=ge[gr[1]:gr[1] + gr[5]], cands=gc[gr[2]:gr[2] + gr[6]], query=queries[c.value:c.value + int(o[14])]))
+            secs_c, nu, nm = C.c_double(), C.c_uint64(), C.c_uint64()
+            r.ref_poa_core_stats(h, C.byref(secs_c), C.byref(nu), C.byref(nm))
+            d.update(recs=recs, core_seconds=secs_c.value, core_updates=nu.value, core_merges=nm.value)
+        elif record:
             # the sweep programs of this window, one per aligned read (mode 1: recorded beside the reference's own sweep)
             recs = []
             for k in range(r.ref_poa_nrec(h)):

@@ -159,3 +159,24 @@ def test_end_bspoa_with_sweep_and_walk_on_the_device(ctx):
         mine = P.run_ref_graph(reads, 6, p, record=False, lib=lib, backend="device")
         assert mine["graph_reads"] >= len(reads) - 3
         assert np.array_equal(mine["cns"], ref["cns"]) and np.array_equal(mine["qlt"], ref["qlt"]) and np.array_equal(mine["alt"], ref["alt"]) and mine["msa"] == ref["msa"]
+
+
+@pytest.mark.skipif(not S.have_ref(), reason="oracle/_ref/libbsref.so not built")
+def test_c4_full_size_clean_wall_time(ctx, capsys):
+    """BASELINE config C4 as stated: one window of 64 ONT-like reads x 20 kbp, default POA parameters.  The product's path alone
+    (harness mode 6: no reference sweep or walk runs, nothing is re-checked read by read): the same consensus, qualities and MSA
+    as the untouched end_bspoa, and the two wall times."""
+    import time
+    lib = P.ref_poa()
+    _attach(lib, ctx)
+    p = P.par()
+    reads = P.synth_reads(20240611 & 0xFFFF, 20000, 64, eps=(0.1,))
+    t0 = time.time(); ref = P.run_ref_poa(reads, 0, p, record=False); t_ref = time.time() - t0
+    one = P.run_ref_poa(reads, 1, p, record=False)
+    t0 = time.time(); mine = P.run_ref_graph(reads, 6, p, record=False, lib=lib, backend="device"); t_dev = time.time() - t0
+    assert np.array_equal(mine["cns"], ref["cns"]) and np.array_equal(mine["qlt"], ref["qlt"]) and np.array_equal(mine["alt"], ref["alt"]) and mine["msa"] == ref["msa"]
+    b = mine["binding_seconds"]
+    with capsys.disabled():
+        print("\n[C4 full size, clean] end_bspoa 64 x 20 kbp: reference %.2f s (of which align_rd_bspoacore %.2f s for %d row updates + %d merges); with sweep and walk "
+              "on the device %.2f s (%d reads through the graph form: building programs %.2f s, device calls incl. transfers %.2f s, applying walks %.2f s)"
+              % (t_ref, one["core_seconds"], one["core_updates"], one["core_merges"], t_dev, mine["graph_reads"], b[0], b[1], b[2]))
