@@ -28,10 +28,10 @@
 #include <vector>
 #include <cstring>
 
-#define POA_NEAR   16      // predecessors at most this many nodes back are read from the LDS ring
-#define POA_DRAIN  16      // finished rows leave the ring in batches of this many
+#define POA_NEAR   12      // predecessors at most this many nodes back are read from the LDS ring
+#define POA_DRAIN  8       // finished rows leave the ring in batches of this many
 #define POA_NEG    (2 * BSA_SCORE_MIN)
-#define POA_NQ     256     // node records staged in LDS ahead of the window
+#define POA_NQ     192     // node records staged in LDS ahead of the window
 
 struct PoaArgs {
 	const bsa_poa_node_t *nodes; const bsa_poa_edge_t *edges; const bsa_poa_cand_t *cands; const bsa_poa_prog_t *progs;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	int iters = 0;
 	while(m < nn){
 		iters++;
-		if(qfill < nn && qfill < m + 2 * NL + 64){ refill(min(nn, qfill + 64)); __syncthreads(); }
+		if(qfill < nn && qfill < m + 2 * NL + 32){ refill(min(nn, qfill + 32)); __syncthreads(); }
 		// (A) the window: lanes whose finished node heads the window take their next node
 		{
 			const uint64_t B = __ballot(fin) & lmask;
