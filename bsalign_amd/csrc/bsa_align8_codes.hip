@@ -926,7 +926,11 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 				rs.qb -= sz; rs.ins += sz; rs.aln += sz;
 			}
 		} else {
-			// deletion run of piece d: up the column until a row whose Od bit of that piece is set (bsalign.h:3730-3760)
+			// deletion run of piece d: up the column until a row whose Od bit of that piece is set (bsalign.h:3730-3760).
+			// Not at query column 0: the D / D2 test there compares scores of two frames (the row is re-based at its first cell,
+			// bsalign.h:2632-2633), so it can fire where no deletion ends, and the reference's run-length scan, which works on real
+			// scores, then finds no opening and does not terminate -- the literal path reproduces (and flags) that
+			if(rs.qb == 0){ bad = true; break; }
 			const uint32_t osh = (d == 2) ? 24u : 16u;
 			int len = 1;
 			for(;;){
@@ -1148,6 +1152,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 				}
 				const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)info, k);
 				if(ik & 3u){                                                // not M and D or D2 set: a deletion of that piece opens
+					if(x == 0){ bad = true; walking = false; break; }         // (at query column 0 the flags cannot tell: k_align8_trace_codes2)
 					emit(2u, 1u); rs.del++; y--; dlen = (ik & 1u) ? 1 : 2; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
@@ -1235,6 +1240,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 				k0 = k;
 				if(x >= 0 && x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 			} else {
+				if(x == 0){ bad = true; walking = false; break; }             // (query column 0: k_align8_trace_codes2)
 				emit(2u, 1u); rs.del++;
 				y--; dlen = d; k0 = k + 1;
 			}

@@ -801,8 +801,12 @@ static int backcal_codes(const uint8_t *qseq, const uint8_t *tseq, const uint8_t
 				rs->qb -= sz; rs->ins += sz; rs->aln += sz;
 			}
 		} else {
-			/* deletion: walk up the column until the row whose stored e is a fresh opening */
+			/* deletion: walk up the column until the row whose stored e is a fresh opening.  Two pieces, query column 0: the D / D2
+			 * test there compares scores of two frames (the row is re-based at its first cell, bsalign.h:2632-2633) and can fire where
+			 * no deletion ends; the reference's run-length scan (bsalign.h:3730-3760) works on real scores, finds no opening then and
+			 * does not terminate: hand over to the literal traceback, which says so */
 			int len = 1;
+			if(pw == 2 && rs->qb == 0) return -1;
 			for(;;){
 				int r = rs->tb - len, pr;
 				if(r < -1) return -1;

@@ -197,6 +197,28 @@ def test_two_piece_gaps_take_the_compact_path(ctx, monkeypatch, wave):
         assert ctx.last_kernel_names()[1] == ("k_align8_trace_codes2_wave" if wave == "1" else "k_align8_trace_codes2")
 
 
+NONTERMINATING_2PIECE = (   # found by tools/stress_align8.py (seed 9202, batch 46): with two-piece gaps the reference's D test fires at query column 0
+    # where no deletion ends and its run-length scan walks off the matrix -- the literal oracle reports ORC_ERR_TRACE
+    [2, 1, 2, 2, 3, 0, 0, 2, 1, 2, 3, 3, 3, 1, 0, 0, 3, 0, 2, 1, 0, 2, 0, 3, 0, 2, 3, 0, 3, 2, 1, 1, 0, 2, 0, 0, 2, 0, 0, 2, 1, 2, 3, 0, 0, 0, 1, 2, 2, 1, 1, 3, 2, 0, 2, 0, 0,
+     2, 0, 1, 2, 2, 2, 2, 3, 0, 1, 0, 2, 2],
+    [1, 2, 1, 0, 0, 3, 0, 1, 1, 2, 3, 2, 3, 0, 0, 1, 0, 2, 0, 2, 1, 2, 3, 1, 0, 2, 2, 3, 0, 3, 2, 0, 1, 0, 0, 2, 0, 0, 2, 0, 0, 2, 1, 2, 3, 0, 2, 0, 0, 1, 1, 2, 2, 1, 3, 2, 1,
+     3, 3, 2, 3, 0, 2, 0])
+
+
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_two_piece_pair_on_which_the_reference_does_not_terminate_is_flagged(ctx, monkeypatch, wave):
+    """the code tracebacks returned a path with status 0 here.  The deletion the flags open at query column 0 is now
+    handed to the literal traceback, which -- like the reference -- finds no run length: BSA_ST_TRACE, no invented answer."""
+    import bsalign_amd as B
+    monkeypatch.setenv("BSA_ALIGN8_TRACE_WAVE", wave)
+    q, t = (np.array(x, np.uint8) for x in NONTERMINATING_2PIECE)
+    sc = (2, -6, -3, -2, -8, -1)
+    for bw in (0, 128):
+        assert S.oracle_align(q, t, S.MODE_GLOBAL, bw, *sc)[2] == S.ORC_ERR_TRACE
+        out, cigs, status = ctx.align_batch([(q, t)] * 3, B.make_params(S.MODE_GLOBAL, bw, *sc))
+        assert all(int(s) & B.ST_TRACE for s in status) and all(len(c) == 0 for c in cigs)
+
+
 def test_handover_to_literal_path_merges_results(ctx, monkeypatch):
     """bsa_align_batch re-runs pairs the compact traceback flags through the row-record kernels and splices their
     results and CIGARs back; the debug hook declares every 3rd pair undecided so that the merge is exercised"""
