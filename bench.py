@@ -24,6 +24,32 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 1024               # 256 CUs x 4 SIMDs
+ISSUE_NS = 1.8             # one VALU instruction of the kinds these kernels are made of (packed, three-operand, DPP) per SIMD, and one scalar
+                           # instruction of a SIMD's turn at the CU's scalar unit: 4 cycles (profiles/r02f_valu_rate_probe.txt)
+
+
+def issue_fractions(workload_key, kernel, cells_per_launch, kernel_ms):
+    """share of the VALU / scalar issue slots the kernel used: instructions per band cell from the committed PMC pass
+    (profiles/issue_counts.json, tools/issue_counts.sh) x the cells of THIS launch x the measured cost of an issue slot,
+    over 1024 SIMDs and the launch's duration measured in this run"""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "issue_counts.json")))
+    except Exception:
+        return None
+    ent = None
+    for k, v in tab.items():
+        wk, kn = k.split("|")
+        if wk == workload_key and kernel.startswith(kn.split("<")[0]):
+            ent = v
+    if ent is None or kernel_ms <= 0:
+        return None
+    ref_cells = float(ent["pairs"]) * ent["length"] * ent["bandwidth"]
+    scale = cells_per_launch / ref_cells
+    cap = SIMDS * kernel_ms * 1e6 / ISSUE_NS          # issue slots of the chip during the launch
+    return {"valu_frac": round(ent["valu_per_launch"] * scale / cap, 4), "salu_frac": round(ent["salu_per_launch"] * scale / cap, 4),
+            "valu_per_cell": round(ent["valu_per_launch"] / ref_cells, 4), "salu_per_cell": round(ent["salu_per_launch"] / ref_cells, 4),
+            "slot_ns": ISSUE_NS, "counts_from": ent["source"]}
 SEED = 20240611            # BASELINE.md section 3
 
 
@@ -686,6 +712,8 @@ def main():
                          "kernel": dname, "kernel_ms_avg": round(dms, 3), "launches_per_step": dlaunch,
                          "algorithmic_bytes_per_launch": round(balg / max(dlaunch, 1), 1),
                          "kernel_gcups": round(kcells / max(dlaunch, 1) / (dms / 1e3) / 1e9, 2) if dms > 0 else None,
+                         "issue": issue_fractions(args.workload + ("_2piece" if sc[4] or sc[5] else ""), dname, cells / max(dlaunch, 1), dms),
+                         "traffic_from": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/profile_round.sh)" if traffic else None,
                          "other_kernel": {"kernel": fwd_name if dom_trace else trace_name, "kernel_ms_avg": round(kms if dom_trace else tms, 3),
                                           "launches_per_step": klaunch if dom_trace else tlaunch}},
             "checks": {"pairs_flagged": nbad, "cigar_words": ncig, "oracle_identical_first8": ident},

@@ -938,8 +938,10 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	std::vector<uint32_t> scig(cigar ? scap : 0);
 	bsa_align_params_t lp = *par;
 	lp.mode |= BSA_MODE_ROWRECORDS;
+	const std::string keep_fwd = c->fwd_name, keep_trace = c->trace_name;         // the batch's kernels stay the ones reported, not the re-run's
 	rc = bsa_align_batch(c, seqs, seqs_bytes, sq.data(), sql.data(), stt.data(), stl.data(), m, &lp, sout.data(),
 		cigar ? scig.data() : nullptr, scap, (cigar && cigar_off) ? soff.data() : nullptr, sst.data());
+	c->fwd_name = keep_fwd; c->trace_name = keep_trace;
 	if(rc != BSA_OK) return rc;
 	for(size_t k = 0; k < m; k++){ out[idx[k]] = sout[k]; st[idx[k]] = sst[k]; }
 	if(cigar && cigar_off){
