@@ -1219,11 +1219,14 @@ extern "C" int bsa_diagdp_batch(bsa_ctx_t *c, const uint8_t *planes, size_t plan
 	hipError_t e;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	do {
-		if((e = hipMalloc((void**)&d_planes, planes_bytes)) != hipSuccess){ fail("hipMalloc", e); break; }
-		if((e = hipMalloc((void**)&d_matrix, matrix_bytes)) != hipSuccess){ fail("hipMalloc", e); break; }
-		if((e = hipMalloc((void**)&d_probs, n * sizeof(bsa_diagdp_prob_t))) != hipSuccess){ fail("hipMalloc", e); break; }
-		if((e = hipMalloc((void**)&d_T, tacc * sizeof(uint32_t))) != hipSuccess){ fail("hipMalloc", e); break; }
-		if((e = hipMalloc((void**)&d_toff, n * sizeof(uint64_t))) != hipSuccess){ fail("hipMalloc", e); break; }
+		// one buffer kept by the context between windows (an end_bspoa makes three calls per window, a polisher thousands of windows)
+		const size_t a256 = 255;
+		const size_t o_planes = 0, o_matrix = (o_planes + planes_bytes + a256) & ~a256, o_probs = (o_matrix + matrix_bytes + a256) & ~a256,
+			o_T = (o_probs + n * sizeof(bsa_diagdp_prob_t) + a256) & ~a256, o_toff = (o_T + tacc * sizeof(uint32_t) + a256) & ~a256, total = o_toff + n * sizeof(uint64_t) + 256;
+		void *ws = nullptr;
+		if((rc = bsa_ctx_scratch_internal(c, 1, total, &ws)) != BSA_OK) break;
+		d_planes = (uint8_t*)ws + o_planes; d_matrix = (uint8_t*)ws + o_matrix; d_probs = (bsa_diagdp_prob_t*)((uint8_t*)ws + o_probs);
+		d_T = (uint32_t*)((uint8_t*)ws + o_T); d_toff = (uint64_t*)((uint8_t*)ws + o_toff);
 		if((e = hipMemcpyAsync(d_planes, planes, planes_bytes, hipMemcpyHostToDevice, c->stream)) != hipSuccess){ fail("hipMemcpyAsync", e); break; }
 		if((e = hipMemcpyAsync(d_probs, probs, n * sizeof(bsa_diagdp_prob_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess){ fail("hipMemcpyAsync", e); break; }
 		if((e = hipMemcpyAsync(d_toff, toff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess){ fail("hipMemcpyAsync", e); break; }
@@ -1245,6 +1248,5 @@ extern "C" int bsa_diagdp_batch(bsa_ctx_t *c, const uint8_t *planes, size_t plan
 	} while(0);
 	if(ev0) (void)hipEventDestroy(ev0);
 	if(ev1) (void)hipEventDestroy(ev1);
-	(void)hipFree(d_planes); (void)hipFree(d_matrix); (void)hipFree(d_probs); (void)hipFree(d_T); (void)hipFree(d_toff);
 	return rc;
 }

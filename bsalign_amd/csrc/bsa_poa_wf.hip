@@ -8,17 +8,17 @@
 // Why a wavefront: the band offset of every node is fixed before the sweep (prepare_rd_align_bspoa bspoa.h:2168-2174), so the cell
 // (node v, column x) depends on cells (u, x - 1) and (u, x) of v's predecessors and on (v, x - 1) -- nothing else.  One wave runs
 // one read.  Lane l owns node i (nodes in the order the reference completes them, i mod lanes = l), walks its row cell by cell
-// and trails each predecessor by movx + 1 cells; the rows of the nodes in flight are an LDS ring of 8-byte cells
-// {H, e | q << 8 | tag << 16}, the tag (node number) tells a reader whether the cell it needs has been written yet, so lanes never
-// wait for each other: a lane whose inputs are not there skips the step.  The nodes in flight are always 64 consecutive ones (a
+// and trails each predecessor by movx + 1 cells; the rows of the nodes in flight are an LDS ring of 4-byte cells
+// {int16 H - H(first cell), e, q} with one word per row {node tag, cells written} that tells a reader whether the cell it needs is
+// there yet, so lanes never wait for each other: a lane whose inputs are not there skips the step.  The nodes in flight are always 64 consecutive ones (a
 // lane takes its next node only when every node before the window is complete), which bounds the ring: a predecessor at most
 // NEAR nodes back is read from the ring, anything further from the drained rows in HBM.  Finished rows leave the ring in
-// batches as 4-byte cells {int16 H - H(0), e, q} + one int32 per node, coalesced -- the only HBM traffic of the forward pass and
+// batches, as they are, + one int32 per node (H of the first cell), coalesced -- the only HBM traffic of the forward pass and
 // exactly what the traceback reads.
 //
 // Arithmetic: absolute int32 scores.  The reference keeps int8 differences (u = H(p) - H(p-1), e = E - H, q = Q - H) and block
 // start scores; inside bsa_poa_graph_supported()'s guard none of its saturating operations clamps, so the two are the same
-// numbers (oracle/bsalign_oracle_wf.c is the scalar statement of this kernel, checked byte for byte against the lane-exact
+// numbers (the test suite holds a scalar statement of this kernel, checked byte for byte against the lane-exact
 // restatement of the reference's rows and against the reference itself).  The rules that are not plain affine-gap DP are kept
 // literally: the seed of band cell 0 (bsalign.h:2899-2907, rh as bspoa.h:2242-2254 picks it), F and G restarting from
 // "predecessor's H - 63" at every running block (bsalign.h:2909-2931, 2639-2652), the synthetic cells behind a moved row's end

@@ -28,6 +28,8 @@ typedef struct {
 	bsa_diagdp_prob_t *probs;
 	uint8_t **ptrs;                  /* [2 * nseq]: the two planes of every read inside `matrix` (NULL: host fill) */
 	size_t cap;
+	size_t budget;                   /* bytes the matrices of one window may take on the host and on the device (0: BSA_POA_DIAGDP_BUDGET, 1 GiB);
+	                                    the reads that do not fit keep the host fill */
 	/* statistics */
 	uint64_t calls, reads, steps;
 } bsa_poa_diagdp_t;
@@ -46,22 +48,29 @@ static inline uint8_t** bsa_poa_diagdp_window(BSPOA *g, bsa_poa_diagdp_t *dd, u1
 	const u4i W = bandwidth / WORDSIZE, HW = bandwidth / 2;
 	const size_t PS = roundup_times(mlen + bandwidth, WORDSIZE);                       /* one plane */
 	const size_t MS = roundup_times((size_t)(2 * mlen + 1) * (bandwidth + 2), WORDSIZE);    /* one matrix plane */
-	size_t need_p, need_m, n = 0, slack;
+	size_t need_p, need_m, n = 0, slack, budget, nfit;
 	uint8_t stale[4 * WORDSIZE];
 	u4i rid, rdlen, b, i;
 	bspoanode_t *v;
 	if(!(W == 1 || W == 2 || W == 4) || nseq == 0 || mlen == 0) return NULL;
-	need_p = PS * 5 * ((size_t)nseq + 1);
-	need_m = MS * 2 * (size_t)nseq;
-	if(need_p > dd->planes_cap){ free(dd->planes); dd->planes = (uint8_t*)malloc(need_p); dd->planes_cap = need_p; }
-	if(need_m > dd->matrix_cap){ free(dd->matrix); dd->matrix = (uint8_t*)malloc(need_m); dd->matrix_cap = need_m; }
+	/* The reference fills one read's matrix at a time; here the matrices of all reads of the window exist at once, so a deep or long
+	 * window is cut at a byte budget: the first reads that fit go to the device, the others keep the host fill (ptrs stay NULL). */
+	budget = dd->budget;
+	if(budget == 0){ const char *e = getenv("BSA_POA_DIAGDP_BUDGET"); budget = e? (size_t)strtoull(e, NULL, 10) : 0; if(budget == 0) budget = (size_t)1 << 30; }
+	nfit = budget / (MS * 2);
+	if(nfit > nseq) nfit = nseq;
+	if(nfit == 0) return NULL;
+	need_p = PS * 5 * (nfit + 1);
+	need_m = MS * 2 * nfit;
+	if(need_p > dd->planes_cap){ free(dd->planes); dd->planes = (uint8_t*)malloc(need_p); dd->planes_cap = dd->planes? need_p : 0; }
+	if(need_m > dd->matrix_cap){ free(dd->matrix); dd->matrix = (uint8_t*)malloc(need_m); dd->matrix_cap = dd->matrix? need_m : 0; }
 	if(nseq > dd->cap){
 		free(dd->probs); free(dd->ptrs);
 		dd->probs = (bsa_diagdp_prob_t*)malloc(sizeof(bsa_diagdp_prob_t) * nseq);
 		dd->ptrs = (uint8_t**)malloc(sizeof(uint8_t*) * 2 * nseq);
-		dd->cap = nseq;
+		dd->cap = (dd->probs && dd->ptrs)? nseq : 0;
 	}
-	if(dd->planes == NULL || dd->matrix == NULL || dd->probs == NULL || dd->ptrs == NULL){ fprintf(stderr, " -- out of memory in %s -- %s:%d --\n", __FUNCTION__, __FILE__, __LINE__); abort(); }
+	if(dd->planes == NULL || dd->matrix == NULL || dd->probs == NULL || dd->ptrs == NULL) return NULL;        /* no memory for the batch form: the host fill, as without the patch */
 	memcpy(dd->planes, seq1 - HW, PS);
 	for(b=0;b<4;b++) memcpy(dd->planes + PS * (1 + b), mats1[b] - HW, PS);
 	/* The reference clears its four mats[0] planes with ONE memset of 4 * (mlen + bandwidth) bytes (bspoa.h:4349) although the
@@ -77,6 +86,11 @@ static inline uint8_t** bsa_poa_diagdp_window(BSPOA *g, bsa_poa_diagdp_t *dd, u1
 		dd->ptrs[2 * rid] = dd->ptrs[2 * rid + 1] = NULL;
 		rdlen = g->seqs->rdlens->buffer[rid];
 		if(rdlen == 0) continue;
+		if(rid >= nfit){
+			/* over the budget: host fill.  What survives in the tail of plane 3 from read to read (see above) is only carried for
+			 * the reads built here; the host fill of the others sees its own planes, exactly as without the patch. */
+			continue;
+		}
 		memset(rp, 4, PS);
 		memset(rp + PS, 0, 4 * PS);
 		memcpy(rp + PS * 5 - 4 * slack, stale, 4 * slack);
@@ -105,8 +119,9 @@ static inline uint8_t** bsa_poa_diagdp_window(BSPOA *g, bsa_poa_diagdp_t *dd, u1
 		n ++;
 	}
 	if(n && dd->run(dd->user, dd->planes, need_p, dd->probs, n, dd->matrix, need_m) != 0){
-		fprintf(stderr, " -- device DP failed in %s -- %s:%d --\n", __FUNCTION__, __FILE__, __LINE__);
-		abort();                                               /* the reference's error convention */
+		/* device out of memory or a failed call: nothing was filled -- every read takes the host fill */
+		for(rid=0;rid<nseq;rid++) dd->ptrs[2 * rid] = dd->ptrs[2 * rid + 1] = NULL;
+		return NULL;
 	}
 	dd->calls ++; dd->reads += n;
 	return dd->ptrs;
