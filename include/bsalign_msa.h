@@ -47,6 +47,22 @@ int bsa_msa_text(const uint8_t *cols, const uint32_t *idxs, uint32_t nseq, uint3
                  const char *label, uint32_t mbeg, uint32_t mend, uint32_t linewidth,
                  char *out, size_t cap, size_t *need);
 
+/* Consensus calling of a window's MSA: cns_bspoa (bspoa.h:3457-3733) with its alignment-event table
+ * (gen_cns_aln_event_table_bspoa, bspoa.h:142-204), sum_log_nums (:3413-3453) and the binomial / normal tail of the
+ * alternative-allele quality (:3391-3411), on the same plain arrays.  A column DP over five states (consensus base A, C, G, T or
+ * gap) whose transition score sums, over the reads, the log probability of the event each read shows (match, substitution,
+ * insertion / deletion opened or extended, homopolymer variants), followed by the traceback, the consensus quality (phred of the
+ * posterior of the chosen state) and the quality against the most frequent other allele.  Double precision in the reference's
+ * own order of operations: with the same libm the bytes are the reference's.
+ *   cols / idxs   as above, mrow = nall + 3; the three consensus bytes of every column are (over)written, as the reference does
+ *   nseq          reads that vote in the DP (the reference: min(g->nmsa, g->nrds));   nmax: reads counted for the alternative
+ *                 allele (g->nrds);   nall: read rows of a column (g->seqs->nseq)
+ *   cns/qlt/alt   receive the columns whose consensus is a base (room for mlen each), *clen their number; *score the DP's log
+ *                 probability (cns_bspoa's return value) */
+typedef struct { float psub, pins, pdel, piex, pdex, hins, hdel; } bsa_cns_params_t;     /* BSPOAPar, bspoa.h:70; defaults 0.10 0.10 0.15 0.15 0.20 0.20 0.40 */
+int bsa_msa_call_consensus(uint8_t *cols, const uint32_t *idxs, uint32_t nall, uint32_t nseq, uint32_t nmax, uint32_t mlen,
+                           const bsa_cns_params_t *par, uint8_t *cns, uint8_t *qlt, uint8_t *alt, uint32_t *clen, double *score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -656,3 +656,12 @@ void ref_poa_form_counts(void *vp, uint64_t *graph_reads, uint64_t *rows_reads){
 	*graph_reads = p->ad.graph_reads; *rows_reads = p->ad.rows_reads;
 }
 void ref_poa_binding_seconds(void *vp, double *out){ ref_poa_t *p = (ref_poa_t*)vp; out[0] = p->ad.seconds[0]; out[1] = p->ad.seconds[1]; out[2] = p->ad.seconds[2]; }
+
+/* ---- consensus calling (tests of bsa_msa_call_consensus in include/bsalign_msa.h): the REAL cns_bspoa (bspoa.h:3457-3733) re-run on the finished
+ * window's MSA; its inputs besides the columns */
+double ref_poa_cns_call(void *vp){ return cns_bspoa(((ref_poa_t*)vp)->g); }
+void ref_poa_cns_inputs(void *vp, uint32_t *nmsa, uint32_t *nrds, uint32_t *nall, float *par7){
+	BSPOA *g = ((ref_poa_t*)vp)->g;
+	*nmsa = g->nmsa; *nrds = g->nrds; *nall = (uint32_t)g->seqs->nseq;
+	par7[0] = g->par->psub; par7[1] = g->par->pins; par7[2] = g->par->pdel; par7[3] = g->par->piex; par7[4] = g->par->pdex; par7[5] = g->par->hins; par7[6] = g->par->hdel;
+}

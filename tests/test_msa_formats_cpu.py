@@ -79,3 +79,72 @@ def test_against_the_reference_live():
                 assert got == w.text("LBL", mb, me, lw), "text differs: case %d args %s" % (ci, (mb, me, lw))
         finally:
             w.close()
+
+
+import msa_support as MS  # noqa: E402
+import poa_support as P  # noqa: E402
+
+
+# ---- consensus calling (bsa_msa_call_consensus = cns_bspoa, bspoa.h:3457-3733) ----
+def _call_consensus(w, cols, nmsa, nrds, nall, par7):
+    import ctypes as C
+    M = MSA
+    L = M.lib()
+    L.bsa_msa_call_consensus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    cns, qlt, alt = (np.zeros(w.mlen + 1, np.uint8) for _ in range(3))
+    clen, score = C.c_uint32(), C.c_double()
+    rc = L.bsa_msa_call_consensus(cols.ctypes.data, w.idxs.ctypes.data, nall, min(nmsa, nrds), nrds, w.mlen, par7.ctypes.data,
+                                  cns.ctypes.data, qlt.ctypes.data, alt.ctypes.data, C.byref(clen), C.byref(score))
+    assert rc == 0
+    return cns[:clen.value], qlt[:clen.value], alt[:clen.value], score.value
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs oracle/_ref")
+@pytest.mark.parametrize("case", MS.CASES + [(15, 400, 70, (0.1,)), (16, 2500, 45, (0.08, 0.15))])
+def test_consensus_calling_is_the_references(case):
+    """the finished window's MSA through the product's consensus caller: consensus bases, both quality strings, the three consensus
+    bytes of EVERY column and the DP's log probability (an IEEE double, compared bit for bit) equal the real cns_bspoa's.  The two
+    deep windows (70 and 45 reads) take the normal-tail branch of the alternative-allele quality and seqcore < reads."""
+    import ctypes as C
+    seed, L, n, eps = case
+    w = MS.RefWindow(P.synth_reads(seed, L, n, eps=eps))
+    try:
+        r = w.r
+        r.ref_poa_cns_call.argtypes = [C.c_void_p]
+        r.ref_poa_cns_call.restype = C.c_double
+        r.ref_poa_cns_inputs.argtypes = [C.c_void_p] * 5
+        r.ref_poa_cns_inputs.restype = None
+        nmsa, nrds, nall = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        par7 = np.zeros(7, np.float32)
+        r.ref_poa_cns_inputs(w.h, C.byref(nmsa), C.byref(nrds), C.byref(nall), par7.ctypes.data)
+        want_score = r.ref_poa_cns_call(w.h)                    # the real function once more on the final MSA: same bytes, and its return value
+        mine = w.cols.copy()
+        mine.reshape(-1, w.mrow)[:, nall.value:] = 255           # nothing of the reference's answer left in the input
+        cns, qlt, alt, score = _call_consensus(w, mine, nmsa.value, nrds.value, nall.value, par7)
+        assert np.array_equal(cns, w.cns) and np.array_equal(qlt, w.qlt) and np.array_equal(alt, w.alt)
+        used = w.idxs.astype(np.int64)
+        a = mine.reshape(-1, w.mrow)[used]; b = w.cols.reshape(-1, w.mrow)[used]
+        assert np.array_equal(a, b)
+        assert np.float64(score).tobytes() == np.float64(want_score).tobytes()
+    finally:
+        w.close()
+
+
+def test_consensus_calling_fixture():
+    """tests/golden/cns.npz (make_golden_cns.py): MSAs of real windows and what the reference's cns_bspoa made of them"""
+    import ctypes as C
+    g = np.load(os.path.join(S.ROOT, "tests", "golden", "cns.npz"))
+    L = MSA.lib()
+    L.bsa_msa_call_consensus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for k in range(int(g["n"][0])):
+        want = g["cols_%d" % k]
+        nmsa, nrds, nall, mlen = (int(x) for x in g["dims_%d" % k])
+        mine = want.copy(); mine[:, nall:] = 255
+        cns, qlt, alt = (np.zeros(mlen + 1, np.uint8) for _ in range(3))
+        clen, score = C.c_uint32(), C.c_double()
+        par7 = np.ascontiguousarray(g["par_%d" % k], np.float32)
+        assert L.bsa_msa_call_consensus(mine.ctypes.data, None, nall, min(nmsa, nrds), nrds, mlen, par7.ctypes.data, cns.ctypes.data, qlt.ctypes.data, alt.ctypes.data,
+                                        C.byref(clen), C.byref(score)) == 0
+        assert np.array_equal(mine, want)
+        assert np.array_equal(cns[:clen.value], g["cns_%d" % k]) and np.array_equal(qlt[:clen.value], g["qlt_%d" % k]) and np.array_equal(alt[:clen.value], g["alt_%d" % k])
+        assert np.float64(score.value).tobytes() == g["score_%d" % k].tobytes()
