@@ -861,9 +861,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 	};
 	auto load_code = [&](int r, uint32_t y) -> uint2 { return *(const uint2*)((const uint32_t*)rows + bsa_code_off((uint32_t)r, y, CW)); };
 	bool bad = false;
-	rs.score = begs[tlen + 1];
-	if(rs.score == (int)0x80000000u) bad = true;               // band never reached the query end (bsalign.h:4034)
-	rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	const int type = a.mode & 3;
+	if(type == BSA_MODE_GLOBAL){
+		rs.score = begs[tlen + 1];
+		if(rs.score == (int)0x80000000u) bad = true;           // band never reached the query end (bsalign.h:4034)
+		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	} else codes_end_cell<W>(rows, RB, qlen, tlen, a.ref_bw, rs.score, rs.qe, rs.te);      // overlap / extend: the best end cell (bsalign.h:4023-4046)
 	if(rs.qe < begs[rs.te + 1] || rs.qe >= begs[rs.te + 1] + bw) bad = true;
 	rs.qb = rs.qe; rs.qe++;
 	rs.tb = rs.te; rs.te++;
@@ -950,12 +953,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 		}
 	}
 	if(!bad){
-		uint32_t op = 0, sz = 0;          // global: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
-		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
-		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
-		rs.aln += (int)sz;
-		cg = cig_add(cg, op, sz);
-		if(cg) cig_push(cg);
+		if(type == BSA_MODE_OVERLAP){ if(cg) cig_push(cg); }     // overlap: the alignment simply starts here (bsalign.h:3822-3826)
+		else {
+			uint32_t op = 0, sz = 0;      // global / extend: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
+			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+			else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+			rs.aln += (int)sz;
+			cg = cig_add(cg, op, sz);
+			if(cg) cig_push(cg);
+		}
 		rs.qb++; rs.tb++;
 	}
 	if(bad){
@@ -1034,9 +1040,17 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 		tok_flush(ntok); ntok = 0u;
 	};
 	bool bad = false;
-	rs.score = begs[tlen + 1];
-	if(rs.score == (int)0x80000000u) bad = true;                   // band never reached the query end (bsalign.h:4034)
-	rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	const int type = a.mode & 3;
+	if(type == BSA_MODE_GLOBAL){
+		rs.score = begs[tlen + 1];
+		if(rs.score == (int)0x80000000u) bad = true;               // band never reached the query end (bsalign.h:4034)
+		rs.qe = (int)qlen - 1; rs.te = (int)tlen - 1;
+	} else {
+		// overlap / extend: the best end cell (bsalign.h:4023-4046), worked out by one lane from the end record behind the code rows
+		int sc = 0, qe = 0, te = 0;
+		if(lane == 0) codes_end_cell<8>((const uint8_t*)codes, 64u * CW, qlen, tlen, a.ref_bw, sc, qe, te);
+		rs.score = __shfl(sc, 0); rs.qe = __shfl(qe, 0); rs.te = __shfl(te, 0);
+	}
 	{ const int lb = begs[rs.te + 1]; if(rs.qe < lb || rs.qe >= lb + bw) bad = true; }
 	int x = rs.qe, y = rs.te;
 	rs.qe++; rs.te++;
@@ -1253,10 +1267,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 	if(!bad && dlen && y < 0) bad = true;                            // a deletion run that reached row -1: the reference compares real scores there -- literal path
 	if(!bad){
 		rs.qb = x; rs.tb = y;
-		uint32_t op = 0, sz = 0;
-		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
-		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
-		if(sz) emit(op, sz);
+		if(type != BSA_MODE_OVERLAP){              // global / extend: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
+			uint32_t op = 0, sz = 0;
+			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+			else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+			if(sz) emit(op, sz);
+		}
 		cig_finish();
 		rs.qb++; rs.tb++;
 		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;

@@ -699,9 +699,9 @@ bool bsa_align8_x_supported(const Align8Args &a, int pw){
 	if(ge < 0 || go < 0 || m < 0 || n < 0 || (go == 0) != (pw == 0)) return false;
 	int g = go + ge;
 	if(pw == 2){
-		// two pieces: bandwidth 128 only; piece 2 opens dearer and extends cheaper (bsalign.h:2084-2092 guarantees it),
-		// the bound is taken with the dearer opening
-		if(W != 8 || (a.mode & 3) != BSA_MODE_GLOBAL) return false;
+		// two pieces: bandwidth 128 only (all three modes: the end record of overlap / extend is the one-piece kernels'); piece 2 opens
+		// dearer and extends cheaper (bsalign.h:2084-2092 guarantees it), the bound is taken with the dearer opening
+		if(W != 8) return false;
 		const int ge2 = -(int)(int8_t)a.gape2, go2 = -(int)(int8_t)a.gapo2;
 		if(ge2 < 0 || go2 <= go || ge2 >= ge) return false;
 		g = std::max(g, go2 + ge2);

@@ -176,7 +176,8 @@ def test_compact_path_band_and_ratio_corners(ctx, monkeypatch, wave):
 
 
 @pytest.mark.parametrize("wave", ["1", "0"])
-def test_two_piece_gaps_take_the_compact_path(ctx, monkeypatch, wave):
+@pytest.mark.parametrize("mode", [S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND])
+def test_two_piece_gaps_take_the_compact_path(ctx, monkeypatch, wave, mode):
     """2-piece gaps (POA default and others), global, bandwidth 128: 8-bit traceback codes written by k_align8_fwd_x2 and walked by
     k_align8_trace_codes2_wave (one walk per wave) or k_align8_trace_codes2 (one per lane) -- results identical to the oracle's
     literal backcal, corners included, and the plan really is compact"""
@@ -191,8 +192,15 @@ def test_two_piece_gaps_take_the_compact_path(ctx, monkeypatch, wave):
         Q = S.mutate(rng, T, float(rng.choice([0.0, 0.1, 0.4])))
         Q = Q[:Lq] if Lq <= len(Q) else np.concatenate([Q, rng.integers(0, 4, size=Lq - len(Q)).astype(np.uint8)])
         pairs.append((Q if len(Q) else np.array([2], np.uint8), T))
+    if mode != S.MODE_GLOBAL:                                # overlap-like inputs: the query is a suffix / prefix of what the target holds
+        for _ in range(60):
+            Lt = int(rng.choice([120, 400, 1200]))
+            T = rng.integers(0, 4, size=Lt).astype(np.uint8)
+            Q = S.mutate(rng, T, float(rng.choice([0.02, 0.1, 0.2])))
+            cut = int(len(Q) * float(rng.choice([0.3, 0.5])))
+            pairs.append((Q[cut:] if rng.random() < 0.5 else Q[:max(1, len(Q) - cut)], T))
     for sc in ((2, -6, -3, -2, -8, -1), (2, -4, -4, -2, -12, -1), (3, -5, -2, -3, -9, -1), (1, -3, -2, -2, -6, -1)):
-        _check(ctx, pairs, S.MODE_GLOBAL, 128, sc)
+        _check(ctx, pairs, mode, 128, sc)
         assert "k_align8_fwd_x2" in ctx.last_kernel_names()[0]
         assert ctx.last_kernel_names()[1] == ("k_align8_trace_codes2_wave" if wave == "1" else "k_align8_trace_codes2")
 
