@@ -679,7 +679,9 @@ def main():
             ident &= bool(np.array_equal(out[k], res)) and bool(np.array_equal(cig_host[int(off[k]):int(off[k + 1])], cig))
         # algorithmic bytes: 4-bit (8-bit path) / 2-bit (edit) traceback code per band cell +
         # sequences at 1 B/base + result struct + CIGAR words
-        per_cell = 0.5 if args.workload == "align8" else 0.25
+        # (two-piece gaps: 8 bits per cell, SURVEY.md 8(d) / bsalign.h:47-54)
+        two_piece = args.workload == "align8" and sc[4] < sc[2] and sc[5] > sc[3] and sc[4] + sc[5] < sc[2] + sc[3] and (sc[2] - sc[4]) // (sc[3] - sc[5]) < max(bw, 16)
+        per_cell = (1.0 if two_piece else 0.5) if args.workload == "align8" else 0.25
         balg = per_cell * cells + float(qlen.sum()) + float(tlen.sum()) + 40.0 * n + 4.0 * ncig
         # the roofline line is about the kernel that takes most of the step: the forward DP or the traceback, whichever
         # the library's own HIP events (on the streams the kernels run on) say is longer per step
