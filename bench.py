@@ -67,8 +67,8 @@ def parse():
     ap.add_argument("--scoring", default="2,-6,-3,-2,0,0", help="M,X,O,E,Q,P (reference CLI defaults, main.c:264)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs of the CPU baseline sample (0 = auto, -1 = skip)")
     ap.add_argument("--workspace-gb", type=float, default=0.0)
-    ap.add_argument("--poa-source", default="synthetic", choices=["synthetic", "recorded"], help="poa workload: synthetic sweep programs (poa_synth) or "
-                    "programs recorded from the reference's end_bspoa on synthetic reads (needs oracle/_ref)")
+    ap.add_argument("--poa-source", default="auto", choices=["auto", "synthetic", "recorded"], help="poa workload: graph programs recorded from the reference's end_bspoa on "
+                    "synthetic reads (needs oracle/_ref; the default when it is there) or synthetic row-task programs for the first form of the sweep (poa_synth)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, count them over the process group and print {n_gpus}: "
                     "the launcher's own test (gloo when there is no GPU)")
@@ -442,6 +442,9 @@ def main_poa_recorded(args):
 
 def main_poa(args):
     """C4-shaped workload: the per-read sweep (align_rd_bspoacore) of many POA windows side by side, one program per window"""
+    if args.poa_source == "auto":
+        import support as S
+        args.poa_source = "recorded" if (S.have_ref() and int(os.environ.get("WORLD_SIZE", "1")) == 1) else "synthetic"
     if args.poa_source == "recorded":
         return main_poa_recorded(args)
     import torch
