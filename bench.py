@@ -40,7 +40,8 @@ def issue_fractions(workload_key, kernel, cells_per_launch, kernel_ms):
     ent = None
     for k, v in tab.items():
         wk, kn = k.split("|")
-        if wk == workload_key and kernel.startswith(kn.split("<")[0]):
+        a, b = kn.split("<")[0], kernel.split()[0].split("<")[0]          # the library names a launch family ("k_align8_fwd_x"), the profiler an instance ("k_align8_fwd_x_mix")
+        if wk == workload_key and (a.startswith(b) or b.startswith(a)):
             ent = v
     if ent is None or kernel_ms <= 0:
         return None
