@@ -157,8 +157,22 @@ def lib():
         L.bsa_diagdp_batch.argtypes = [vp, u8p, C.c_size_t, vp, C.c_size_t, u8p, C.c_size_t]
         L.bsa_diagdp_last_ms.argtypes = [vp]
         L.bsa_diagdp_last_ms.restype = C.c_double
+        L.bsa_env_reload.restype = None
         _lib = L
+    _sync_env()
     return _lib
+
+
+_env_seen = None
+
+
+def _sync_env():
+    """the library reads its BSA_* knobs once; a test that flips one inside this process gets a fresh snapshot"""
+    global _env_seen
+    cur = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("BSA_")))
+    if cur != _env_seen:
+        _lib.bsa_env_reload()
+        _env_seen = cur
 
 
 def _np(a, dt):

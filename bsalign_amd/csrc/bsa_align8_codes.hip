@@ -1310,17 +1310,17 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 	if(a.count == 0) return hipSuccess;
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;
-		const char *we = getenv("BSA_ALIGN8_TRACE_WAVE");              // =0: the pair-per-lane walker
+		const char *we = bsa_env("BSA_ALIGN8_TRACE_WAVE");              // =0: the pair-per-lane walker
 		if(we && we[0] == '0'){ bsa_last_trace_kernel = "k_align8_trace_codes2"; hipLaunchKernelGGL(k_align8_trace_codes2, dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt); }
 		else { bsa_last_trace_kernel = "k_align8_trace_codes2_wave"; hipLaunchKernelGGL(k_align8_trace_codes2_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt); }
 		return hipGetLastError();
 	}
 	// BSA_ALIGN8_TRACE_SIMPLE=1: the plain kernel (kept as the reference point)
-	static const bool simple = [](){ const char *e = getenv("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
+	static const bool simple = [](){ const char *e = bsa_env("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
 	const uint32_t blocks = (a.count + 63u) / 64u;
 	bsa_last_trace_kernel = simple ? "k_align8_trace_codes_simple" : (a.bw == 256u) ? "k_align8_trace_codes_simple" : "k_align8_trace_codes_lds";
 	// one walk per wave (BSA_ALIGN8_TRACE_WAVE=0: the pair-per-lane kernels)
-	const char *we = getenv("BSA_ALIGN8_TRACE_WAVE");
+	const char *we = bsa_env("BSA_ALIGN8_TRACE_WAVE");
 	const bool wave = !simple && !(we && we[0] == '0');
 	if(wave) bsa_last_trace_kernel = "k_align8_trace_codes_wave";
 	switch(a.bw / 16){

@@ -715,11 +715,11 @@ bool bsa_align8_x_supported(const Align8Args &a, int pw){
 	return m + 3 * g + 2 * ge <= 100 && n + m + g + 2 * ge <= 110 && 63 + 2 * ge + n + m + 2 * g <= 125;
 }
 
-static bool x8_at_64(){ const char *e = getenv("BSA_ALIGN8_X_LANES"); return e && e[0] == '8'; }
+static bool x8_at_64(){ const char *e = bsa_env("BSA_ALIGN8_X_LANES"); return e && e[0] == '8'; }
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
 	const uint32_t b8 = (a.count + 31u) / 32u;
-	if(a.static_band && !getenv("BSA_ALIGN8_NO_STATIC")){
+	if(a.static_band && !bsa_env("BSA_ALIGN8_NO_STATIC")){
 		const uint32_t b4 = (a.count + 63u) / 64u;
 		if(pw == 2 && a.bw == 128u){ hipLaunchKernelGGL((k_align8_fwd_x_static<8, 8, 2>), dim3(b8), dim3(256), 0, st, a); return hipGetLastError(); }
 		if(pw == 1 && a.bw == 64u){ hipLaunchKernelGGL((k_align8_fwd_x_static<8, 4, 1>), dim3(b4), dim3(256), 0, st, a); return hipGetLastError(); }
@@ -761,13 +761,13 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 				if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
 				return v;
 			}();
-			const char *le = getenv("BSA_ALIGN8_X_LANES");
+			const char *le = bsa_env("BSA_ALIGN8_X_LANES");
 			const uint32_t round4 = (uint32_t)cus * 4u * 16u;
 			uint32_t n4 = a.count / round4 * round4;
 			if(a.count - n4 > round4 / 2u) n4 = a.count;
 			if(le && le[0] == '8') n4 = 0;
 			if(le && le[0] == '4') n4 = a.count;
-			if(const char *ne = getenv("BSA_ALIGN8_X_N8")){ const long v = atol(ne); if(v >= 0 && (uint32_t)v <= a.count) n4 = a.count - (uint32_t)v; }      // tuning: pairs that go eight lanes per pair
+			if(const char *ne = bsa_env("BSA_ALIGN8_X_N8")){ const long v = atol(ne); if(v >= 0 && (uint32_t)v <= a.count) n4 = a.count - (uint32_t)v; }      // tuning: pairs that go eight lanes per pair
 			if(n4 == a.count) hipLaunchKernelGGL((k_align8_fwd_x<16, 4>), dim3((n4 + 63u) / 64u), dim3(256), 0, st, a);
 			else if(n4 == 0) hipLaunchKernelGGL((k_align8_fwd_x<8, 8>), dim3(b8), dim3(256), 0, st, a);
 			else {

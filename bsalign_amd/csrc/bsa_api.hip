@@ -8,6 +8,8 @@
 // halves of the workspace alternating.
 #include "bsa_common.h"
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 #include <chrono>
@@ -62,6 +64,26 @@ static void ctx_buf_put(bsa_ctx *c, int slot, void *ptr, bool kept){
 	if(kept) c->keep_busy[slot] = false; else (void)hipFree(ptr);
 }
 
+// ---- environment snapshot ----
+extern char **environ;
+namespace { std::mutex g_env_m; std::unordered_map<std::string, std::string> g_env; bool g_env_ready = false; }
+extern "C" void bsa_env_reload(void){
+	std::lock_guard<std::mutex> lk(g_env_m);
+	g_env.clear();
+	for(char **e = environ; e && *e; e++){
+		if(strncmp(*e, "BSA_", 4) != 0) continue;
+		const char *eq = strchr(*e, '=');
+		if(eq) g_env.emplace(std::string(*e, (size_t)(eq - *e)), std::string(eq + 1));
+	}
+	g_env_ready = true;
+}
+const char *bsa_env(const char *name){
+	if(!g_env_ready) bsa_env_reload();
+	std::lock_guard<std::mutex> lk(g_env_m);
+	auto it = g_env.find(name);
+	return it == g_env.end() ? nullptr : it->second.c_str();
+}
+
 #define HIPCHK(ctx, call) do { hipError_t _e = (call); if(_e != hipSuccess){ (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e); return BSA_E_HIP; } } while(0)
 
 extern "C" void bsa_set_score_matrix(int8_t m[16], int8_t mat, int8_t mis){ // bsalign.h:323
@@ -75,6 +97,7 @@ extern "C" int bsa_ctx_create(int device, bsa_ctx_t **out){
 	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BSA_E_NODEVICE;
 	if(hipSetDevice(device) != hipSuccess) return BSA_E_NODEVICE;
 	bsa_ctx *c = new bsa_ctx();
+	(void)bsa_env("BSA_PIPELINE");          // (takes the snapshot of the BSA_* knobs if there is none yet)
 	c->device = device;
 	if(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess){ delete c; return BSA_E_NODEVICE; }
 	if(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess){ (void)hipStreamDestroy(c->own_stream); delete c; return BSA_E_NODEVICE; }
@@ -462,12 +485,12 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 	// per SIMD), so every resident traceback wave evicts a forward wave, and raising the traceback's wave priority
 	// changes nothing.  The mode stays opt-in (BSA_PIPELINE=1); BSA_CHUNK_PAIRS caps the pairs per chunk (tuning knob).
 	size_t cap;            // bytes per chunk
-	const char *pe = getenv("BSA_PIPELINE");
+	const char *pe = bsa_env("BSA_PIPELINE");
 	const bool want_pipe = pipe_default ? !(pe && pe[0] == '0') : (pe && pe[0] == '1');
 	size_t pipe_chunks = 4;
-	if(const char *ke = getenv("BSA_PIPE_CHUNKS")){ const long v = atol(ke); if(v > 0) pipe_chunks = (size_t)v; }
+	if(const char *ke = bsa_env("BSA_PIPE_CHUNKS")){ const long v = atol(ke); if(v > 0) pipe_chunks = (size_t)v; }
 	size_t cap_pairs = n ? n : 1;
-	if(const char *ce = getenv("BSA_CHUNK_PAIRS")){ const long v = atol(ce); if(v > 0) cap_pairs = (size_t)v; }
+	if(const char *ce = bsa_env("BSA_CHUNK_PAIRS")){ const long v = atol(ce); if(v > 0) cap_pairs = (size_t)v; }
 	bool all_resident = false;      // pipelined and everything fits: every chunk gets a region of its own
 	if(!want_pipe){ cap = std::max(std::min(total, budget), biggest); p->two_halves = false; }
 	else if(total + (total / std::max<size_t>(n, 1)) * 64 <= budget && pipe_chunks > 1 && n >= 4096){
@@ -684,8 +707,8 @@ extern "C" double bsa_align_plan_cells(const bsa_align_plan_t *p){ return p ? p-
 // Returns that width, or 0.  (See bsa_align_plan_create.)
 static uint32_t align8_widened_bw(const bsa_align_params_t *par, uint32_t cols){
 	const int type = par->mode & 3;
-	const char *we = getenv("BSA_ALIGN8_WIDEN");
-	const char *le = getenv("BSA_ALIGN8_LITERAL");
+	const char *we = bsa_env("BSA_ALIGN8_WIDEN");
+	const char *le = bsa_env("BSA_ALIGN8_LITERAL");
 	if((par->mode & BSA_MODE_ROWRECORDS) || (we && we[0] == '0') || (le && le[0] == '1') || cols == 0u || cols > 256u) return 0u;
 	// the gap model must not depend on the width (bsalign.h:2084-2092 compares a ratio of the penalties with it)
 	const int pwa = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 16);
@@ -744,7 +767,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	p->qpad = max_bw + 32;
 	{
 		// compact traceback where its preconditions hold (BSA_ALIGN8_LITERAL=1 keeps the row-record path)
-		const char *le = getenv("BSA_ALIGN8_LITERAL");
+		const char *le = bsa_env("BSA_ALIGN8_LITERAL");
 		Align8Args t;
 		memset(&t, 0, sizeof(t));
 		t.bw = bw; t.mode = par->mode; t.gapo1 = par->gapo1; t.gape1 = par->gape1; t.gapo2 = par->gapo2; t.gape2 = par->gape2;
@@ -824,7 +847,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	// saturating packed kernel: same code rows, the reference point of the tests)
 	bool fwd_x = false;
 	if(codes){
-		const char *fe = getenv("BSA_ALIGN8_FWD");
+		const char *fe = bsa_env("BSA_ALIGN8_FWD");
 		const bool force_pk = fe && fe[0] == 'p';
 		fwd_x = (pw == 2) || (!force_pk && bsa_align8_x_supported(a, pw));       // (two-piece gaps: the only forward kernel of the compact path)
 	}
@@ -925,7 +948,7 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	// ---- hand-over: pairs the compact traceback could not decide go through the literal kernels, so that a flag that
 	// survives means what it means for the reference (its own traceback does not terminate there)
 	std::vector<size_t> idx;
-	const char *dbg = getenv("BSA_DEBUG_HANDOVER");          // test hook: treat every N-th pair as undecided
+	const char *dbg = bsa_env("BSA_DEBUG_HANDOVER");          // test hook: treat every N-th pair as undecided
 	const long every = dbg ? atol(dbg) : 0;
 	for(size_t k = 0; k < n; k++) if((st[k] & BSA_ST_TRACE) || (every > 0 && k % (size_t)every == 0 && st[k] == 0)) idx.push_back(k);
 	if(idx.empty()) return BSA_OK;
@@ -1070,7 +1093,7 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 		bool moved[17] = {false};
 		size_t total = 0;
 		for(int w = 16; w >= 2; w--) if(cnt[w] && cnt[w] <= 8192 && total + cnt[w] <= 16384){ moved[w] = true; total += cnt[w]; }
-		if(getenv("BSA_EDIT_NO_MERGE")) for(int w = 0; w < 17; w++) moved[w] = false;
+		if(bsa_env("BSA_EDIT_NO_MERGE")) for(int w = 0; w < 17; w++) moved[w] = false;
 		for(size_t k = 0; k < n; k++){
 			cls[k] = bsa_edit_class(bwk[k]);
 			if(bwk[k] <= BSA_EDIT_REG_BW && moved[bwk[k] / 64u] && is_static(k) && qlen[k] && tlen[k]) cls[k] = bsa_edit_class(64u * 64u);
@@ -1109,7 +1132,7 @@ extern "C" int bsa_edit_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const ui
 	if(rc == BSA_OK) rc = dev_alloc(c, &p->d_sbeg, 3 * n);      // sbeg | smin | ry
 	p->extra = { p->d_qboff, p->d_qwords, p->d_qbits, p->d_sbeg };
 	if(rc != BSA_OK){ plan_free(p); return rc; }
-	if(getenv("BSA_BATCH_TIMING")){
+	if(bsa_env("BSA_BATCH_TIMING")){
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b){ return std::chrono::duration<double, std::milli>(b - a).count(); };
 		fprintf(stderr, "[bsa_edit_plan] %zu pairs: classes + order %.1f ms, layout + chunks %.1f ms, device metadata %.1f ms\n", n, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, std::chrono::steady_clock::now()));
 	}
@@ -1174,7 +1197,7 @@ extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_byt
 		if(qoff[k] + qlen[k] > seqs_bytes || toff[k] + tlen[k] > seqs_bytes){ c->err = "sequence offsets outside the blob"; return BSA_E_ARG; }
 	(void)hipSetDevice(c->device);
 	bsa_edit_plan_t *p = nullptr;
-	const bool timing = getenv("BSA_BATCH_TIMING") != nullptr;        // host-side phase times on stderr
+	const bool timing = bsa_env("BSA_BATCH_TIMING") != nullptr;        // host-side phase times on stderr
 	const auto t0 = std::chrono::steady_clock::now();
 	int rc = bsa_edit_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
 	if(rc != BSA_OK) return rc;

@@ -108,7 +108,7 @@ struct bsa_sweep_batcher {
 	~bsa_sweep_batcher(){ for(Group *g : groups) delete g; }
 };
 static int host_cpus(){
-	if(const char *e = getenv("BSA_POA_HOST_THREADS")){ const int v = atoi(e); if(v >= 1) return v; }
+	if(const char *e = bsa_env("BSA_POA_HOST_THREADS")){ const int v = atoi(e); if(v >= 1) return v; }
 	int n = (int)std::thread::hardware_concurrency();
 	if(FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")){          // cgroup v2 quota: "<quota> <period>" or "max <period>"
 		char q[32]; long per = 0;
@@ -347,7 +347,7 @@ extern "C" int bsa_sweep_batcher_create(bsa_ctx_t *ctx, uint32_t participants, b
 	bsa_sweep_batcher *b = new (std::nothrow) bsa_sweep_batcher();
 	if(!b) return BSA_E_NOMEM;
 	uint32_t G = participants >= 32u ? 2u : 1u;
-	if(const char *e = getenv("BSA_POA_GROUPS")){ const int v = atoi(e); if(v >= 1 && v <= 64) G = (uint32_t)v; }
+	if(const char *e = bsa_env("BSA_POA_GROUPS")){ const int v = atoi(e); if(v >= 1 && v <= 64) G = (uint32_t)v; }
 	if(G > participants) G = participants;
 	for(uint32_t g = 0; g < G; g++){
 		Group *gr = new (std::nothrow) Group();

@@ -5,6 +5,11 @@
 #include <stddef.h>
 #include "../../include/bsalign_hip.h"
 
+// Environment knobs (BSA_*): read ONCE, when the first context is created, into a snapshot; bsa_env() looks a knob up there (no
+// getenv on the launch path).  bsa_env_reload() takes a new snapshot (tests that flip a knob inside one process call it).
+const char *bsa_env(const char *name);
+extern "C" void bsa_env_reload(void);
+
 #define BSA_LANES      16                      // running blocks per band row == lanes of one DPP row
 #define BSA_EPI8_MIN   (-63)                   // bsalign.h:56
 #define BSA_EPI8_MAX   (63)                    // bsalign.h:57

@@ -1258,7 +1258,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 	// is its own serial chain (~600 instructions per row of 64-bit funnel shifts and block updates) whatever its lane
 	// count -- 16384 pairs x 100 kbp, ms per launch: 64 lanes 102, 32 -> 104, 16 -> 136, 8 -> 261, 4 -> 374
 	uint32_t lanes = 64;
-	if(const char *e = getenv("BSA_EDIT_FWD_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64) lanes = (uint32_t)v; }
+	if(const char *e = bsa_env("BSA_EDIT_FWD_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64) lanes = (uint32_t)v; }
 	const uint32_t fblocks = (a.count + lanes - 1) / lanes;
 #define EDIT_CASE(N) case N: if(track) hipLaunchKernelGGL((k_edit_fwd<N, true>), dim3(fblocks), dim3(64), 0, st, a, lanes); \
 		else hipLaunchKernelGGL((k_edit_fwd<N, false>), dim3(fblocks), dim3(64), 0, st, a, lanes); break;
@@ -1268,13 +1268,13 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 		const uint32_t nw = a.bw / 64u;
 		const uint32_t G = nw <= 2u ? 2u : nw <= 4u ? 4u : nw <= 8u ? 8u : 16u;
 		bool grp = a.bw != 0u && nw >= 2u && nw <= 16u && (uint64_t)a.count * G / 64u <= 4096u;
-		if(const char *e = getenv("BSA_EDIT_GRP")) grp = a.bw != 0u && nw >= 2u && nw <= 16u && e[0] == '1';
+		if(const char *e = bsa_env("BSA_EDIT_GRP")) grp = a.bw != 0u && nw >= 2u && nw <= 16u && e[0] == '1';
 		// 32-bit words, twice the lanes per pair (bands up to 512 columns): BSA_EDIT_GRP32=0/1 overrides
 		{
 			const uint32_t G32 = nw <= 1u ? 2u : nw <= 2u ? 4u : nw <= 4u ? 8u : 16u;
 			bool g32 = a.bw != 0u && nw >= 1u && nw <= 8u && (uint64_t)a.count * G32 / 64u <= 65536u;      // (faster than the other two kernels on every shape of tools/edit_shapes.sh)
-			if(const char *e = getenv("BSA_EDIT_GRP32")) g32 = a.bw != 0u && nw >= 1u && nw <= 8u && e[0] == '1';
-			if(getenv("BSA_EDIT_GRP")) g32 = false;
+			if(const char *e = bsa_env("BSA_EDIT_GRP32")) g32 = a.bw != 0u && nw >= 1u && nw <= 8u && e[0] == '1';
+			if(bsa_env("BSA_EDIT_GRP")) g32 = false;
 			if(g32){
 				bsa_last_fwd_kernel = "k_edit_fwd_grp32 (forward DP, 32-bit words, 2 NW lanes per pair)";
 				const uint32_t ppw = 64u / G32, gblocks = ((a.count + ppw - 1) / ppw + 3) / 4;
@@ -1312,7 +1312,7 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 			if(a.wide == 0u || ((a.mode & 3) == BSA_MODE_GLOBAL && a.bandwidth != 0u)){
 				uint32_t gl = 64;
 				while(gl > 2u && (a.count + gl / 2 - 1) / (gl / 2) <= 8192u) gl >>= 1;
-				if(const char *e = getenv("BSA_EDIT_GEN_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64) gl = (uint32_t)v; }
+				if(const char *e = bsa_env("BSA_EDIT_GEN_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64) gl = (uint32_t)v; }
 				hipLaunchKernelGGL(k_edit_fwd_gen, dim3((a.count + gl - 1) / gl), dim3(64), 0, st, a, gl);
 			}
 		} break;
@@ -1343,20 +1343,20 @@ hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t 
 		// wider than the LDS window -- 43 against 22; 262144 x 3 kbp 10.1 against 8.5)
 		const bool narrow = a.bw != 0u && a.bw <= 64u * EW_WW;
 		bool wave = a.count <= (narrow ? 8u : 2u) * (uint32_t)cus * 32u;
-		if(const char *e = getenv("BSA_EDIT_TRACE_WAVE")) wave = e[0] == '1';
-		if(getenv("BSA_EDIT_TRACE_LANES") || getenv("BSA_EDIT_TRACE_COOP")) wave = false;
+		if(const char *e = bsa_env("BSA_EDIT_TRACE_WAVE")) wave = e[0] == '1';
+		if(bsa_env("BSA_EDIT_TRACE_LANES") || bsa_env("BSA_EDIT_TRACE_COOP")) wave = false;
 		if(wave){
 			bsa_last_trace_kernel = "k_edit_trace_wave";
 			hipLaunchKernelGGL(k_edit_trace_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
 			return hipGetLastError();
 		}
 	}
-	const char *ce = getenv("BSA_EDIT_TRACE_COOP");
+	const char *ce = bsa_env("BSA_EDIT_TRACE_COOP");
 	const bool coop_ok = !(ce && ce[0] == '0');
 	uint32_t lanes = 2;
 	const uint32_t slots_c = (uint32_t)cus * (uint32_t)per_cu[1], slots_p = (uint32_t)cus * (uint32_t)per_cu[0];
 	while(lanes < 64u && (a.count + lanes - 1) / lanes > (lanes <= 8u && coop_ok ? slots_c : slots_p)) lanes <<= 1;
-	if(const char *e = getenv("BSA_EDIT_TRACE_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) lanes = (uint32_t)v; }
+	if(const char *e = bsa_env("BSA_EDIT_TRACE_LANES")){ const int v = atoi(e); if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) lanes = (uint32_t)v; }
 	const uint32_t blocks = (a.count + lanes - 1) / lanes;
 	bsa_last_trace_kernel = "k_edit_trace";
 	if(lanes <= 8u && lanes >= 2u && coop_ok) hipLaunchKernelGGL(k_edit_trace<true>, dim3(blocks), dim3(64), 0, st, a, out, cig_cnt, lanes);

@@ -4,6 +4,7 @@
  */
 #include "../../include/bsalign_compat.h"
 #include "../../include/bsalign_hip.h"
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -12,11 +13,20 @@
  * (error string, events, workspace) is not shared between threads (include/bsalign_hip.h) */
 static __thread bsa_ctx_t *g_ctx = NULL;
 static int g_device = 0;
+/* a thread's context (streams, events, workspace, kept device buffers) goes with the thread: the key's destructor runs at thread exit */
+static pthread_key_t g_ctx_key;
+static pthread_once_t g_ctx_once = PTHREAD_ONCE_INIT;
+static void ctx_at_thread_exit(void *p){ if(p) bsa_ctx_destroy((bsa_ctx_t*)p); }
+static void ctx_key_make(void){ (void)pthread_key_create(&g_ctx_key, ctx_at_thread_exit); }
 
 void bsalign_compat_set_device(int device){ g_device = device; }
 
 void bsalign_compat_shutdown(void){
-	if(g_ctx){ bsa_ctx_destroy(g_ctx); g_ctx = NULL; }
+	if(g_ctx){
+		(void)pthread_once(&g_ctx_once, ctx_key_make);
+		(void)pthread_setspecific(g_ctx_key, NULL);
+		bsa_ctx_destroy(g_ctx); g_ctx = NULL;
+	}
 }
 
 static void die(const char *what, const char *func){
@@ -29,6 +39,8 @@ static void die(const char *what, const char *func){
 static bsa_ctx_t *ctx(const char *func){
 	if(!g_ctx){
 		if(bsa_ctx_create(g_device, &g_ctx) != BSA_OK) die("no usable MI355X device (there is no CPU fallback)", func);
+		(void)pthread_once(&g_ctx_once, ctx_key_make);
+		(void)pthread_setspecific(g_ctx_key, g_ctx);
 	}
 	return g_ctx;
 }
