@@ -338,6 +338,26 @@ size_t bsa_shard_bytes(const uint32_t *qlen, const uint32_t *tlen, size_t first,
 int    bsa_shard_pack(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
                       size_t first, size_t count, uint8_t *out, size_t out_bytes, uint64_t *out_qoff, uint64_t *out_toff, unsigned threads);
 
+/* ---- the exchange itself, for a C host: RCCL point-to-point messages over xGMI (bsalign_amd/csrc/bsa_shard_rccl.hip) -----------
+ * One process per GPU.  Rank 0 calls bsa_shard_unique_id and ships the 128 bytes to the other ranks by whatever means the job has
+ * (launcher environment, a file, MPI); every rank then creates its communicator on its own context.  RCCL (librccl.so.1) is loaded
+ * at run time; with nranks == 1 nothing is loaded and both calls degenerate to copies.
+ *   scatter   the root holds the batch in HOST memory; every rank gets its contiguous range [*first, *first + *count) -- ranges
+ *             balanced by tlen x bandwidth --: the shard blob in DEVICE memory (*d_seqs, owned by the communicator, valid until the
+ *             next scatter) with the pairs' lengths and offsets inside it (host arrays of `cap` entries), ready for
+ *             bsa_align_plan_create / bsa_align_run.  Lengths travel as two broadcasts, the N - 1 shards as one ncclGroup of sends.
+ *   gather    every rank hands in its range's results (DEVICE), CIGAR words (DEVICE) and CIGAR offsets (HOST, count + 1); the root
+ *             receives all n records in input order, the CIGAR arena and its offsets (HOST).  Sizes travel as one ncclAllGather. */
+typedef struct bsa_shard_comm bsa_shard_comm_t;
+int  bsa_shard_unique_id(uint8_t id[128]);
+int  bsa_shard_comm_create(bsa_ctx_t *ctx, int rank, int nranks, const uint8_t id[128], bsa_shard_comm_t **out);
+void bsa_shard_comm_destroy(bsa_shard_comm_t *comm);
+int  bsa_shard_scatter(bsa_shard_comm_t *comm, int root, const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
+                       size_t n, uint32_t bandwidth, size_t *first, size_t *count, uint8_t **d_seqs, size_t *blob_bytes,
+                       uint32_t *local_qlen, uint32_t *local_tlen, uint64_t *local_qoff, uint64_t *local_toff, size_t cap);
+int  bsa_shard_gather(bsa_shard_comm_t *comm, int root, const bsa_result_t *d_out, const uint32_t *d_cigar, const uint64_t *cigar_off, size_t count,
+                      bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words, uint64_t *out_cigar_off, size_t n);
+
 /* ---- many windows in lock-step (bsalign_amd/csrc/bsa_batcher.hip) ----------------------------
  * One POA (end_bspoa, bspoa.h:4722-4776) is sequential in its reads, but windows are independent: a caller with many
  * of them runs each on a host thread of its own and lets every thread's sweep go through a batcher.  submit() has the
