@@ -696,6 +696,8 @@ struct bsa_align_plan : PlanBase {
 	uint32_t max_bw = 0;
 	uint32_t ref_bw = 0;                         // a whole-query band widened to bw: the reference's own bandwidth (1 = per pair), see bsa_align_plan_create
 	bool static_band = false;                    // no query is longer than the band: it never moves
+	bool sys = false;                            // whole-query bands above 256 columns, global mode: the systolic wavefront (bsa_align8_sys.hip)
+	uint32_t max_qlen = 0;
 	size_t stage_bytes = 0;                      // staged bytes of all pairs (which staging kernel)
 	uint32_t qpad = 0, tpad = 16;
 };
@@ -751,14 +753,36 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		const uint32_t kbw = full ? align8_widened_bw(par, max_bw) : 0u;
 		if(kbw){ bw = kbw; max_bw = kbw; widened = true; }
 	}
+	// Whole-query bands above 256 columns (the reference CLI's default on long reads): global mode, linear or affine gaps, scores inside
+	// the exact-arithmetic guard -> the systolic wavefront with its own code rows and traceback (bsa_align8_sys.hip) instead of the
+	// LDS-resident run-time-width kernel.  BSA_ALIGN8_SYS=0 keeps the old dispatch.
+	bool sys = false; uint32_t max_qlen = 0;
+	for(size_t k = 0; k < n; k++) max_qlen = std::max(max_qlen, qlen[k]);
+	if(!widened && type == BSA_MODE_GLOBAL && n > 0 && (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw > 256u && max_qlen <= 60000u && !(par->mode & BSA_MODE_ROWRECORDS)){
+		bool full = true;
+		if(bw != 0) for(size_t k = 0; k < n && full; k++) full = qlen[k] <= bw;
+		const char *se = bsa_env("BSA_ALIGN8_SYS"), *le = bsa_env("BSA_ALIGN8_LITERAL");
+		if(full && !(se && se[0] == '0') && !(le && le[0] == '1')){
+			Align8Args t;
+			memset(&t, 0, sizeof(t));
+			t.mode = type; t.gapo1 = par->gapo1; t.gape1 = par->gape1; t.gapo2 = par->gapo2; t.gape2 = par->gape2;
+			int smax = -127, smin = 127;
+			for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
+			t.smax = smax; t.smin = smin;
+			const int pwa = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 16), pwb = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)max_bw);
+			sys = pwa == pwb && bsa_align8_sys_supported(t, pwb);
+		}
+	}
 	bsa_align_plan *p = new bsa_align_plan();
 	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
-	p->ref_bw = widened ? (bw_req ? bw_req : 1u) : 0u;
+	p->sys = sys; p->max_qlen = max_qlen;
+	p->ref_bw = widened ? (bw_req ? bw_req : 1u) : sys ? bw_req : 0u;
 	p->static_band = bw != 0 && n > 0;
 	for(size_t k = 0; k < n && p->static_band; k++) p->static_band = qlen[k] <= bw;
 	p->generic = (bw == 0) || !bsa_align8_supported_bw(bw);
 	p->max_bw = max_bw;
 	p->pw = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)std::max(max_bw, 16u));
+	if(p->sys) p->generic = false;
 	if(p->generic && bsa_align8_gen_lds(max_bw, p->pw, bw == 0 ? 1u : 2u) > 160 * 1024){        // a whole-query band never moves: one row buffer
 		c->err = "bandwidth too large for the device's generic kernel (two band rows must fit 160 KB of LDS)";
 		delete p; return BSA_E_UNSUPPORTED;
@@ -774,7 +798,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		int smax = -127, smin = 127;
 		for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
 		t.smax = smax; t.smin = smin;
-		p->codes = !p->generic && !(le && le[0] == '1') && !(par->mode & BSA_MODE_ROWRECORDS) && bsa_align8_codes_supported(t, p->pw);
+		p->codes = !p->sys && !p->generic && !(le && le[0] == '1') && !(par->mode & BSA_MODE_ROWRECORDS) && bsa_align8_codes_supported(t, p->pw);
 		// the compact traceback packs band offsets into 26 bits of its ring entries
 		for(size_t k = 0; k < n && p->codes; k++) if(qlen[k] >= (1u << 26)) p->codes = false;
 	}
@@ -794,7 +818,8 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw_ref(k);
 	}
 	for(size_t pos = 0; pos < n; pos++)
-		need[pos] = p->codes ? bsa_code_slot_bytes(tlen[order[pos]], bw / 16u, p->pw) : bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
+		need[pos] = p->sys ? bsa_align8_sys_slot_bytes(qlen[order[pos]], tlen[order[pos]])
+			: p->codes ? bsa_code_slot_bytes(tlen[order[pos]], bw / 16u, p->pw) : bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
 	p->cells = cells;
 	p->stage_bytes = qacc + tacc;
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
@@ -842,7 +867,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	}
 	const int pw = p->pw;
 	uint32_t *cnt = p->d_cnt_pos;
-	const bool generic = p->generic, codes = p->codes; const uint32_t max_bw = p->max_bw;
+	const bool generic = p->generic, codes = p->codes, sys = p->sys; const uint32_t max_bw = p->max_bw;
 	// forward kernel of the compact path: the exact-arithmetic one wherever its guard holds (BSA_ALIGN8_FWD=pk keeps the
 	// saturating packed kernel: same code rows, the reference point of the tests)
 	bool fwd_x = false;
@@ -851,14 +876,15 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		const bool force_pk = fe && fe[0] == 'p';
 		fwd_x = (pw == 2) || (!force_pk && bsa_align8_x_supported(a, pw));       // (two-piece gaps: the only forward kernel of the compact path)
 	}
-	c->fwd_name = (fwd_x && pw == 2) ? "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)"
+	c->fwd_name = sys ? "k_align8_fwd_sys (whole-query band, systolic wavefront, 4-bit traceback codes)" : (fwd_x && pw == 2) ? "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)"
 		: fwd_x ? "k_align8_fwd_x (exact-arithmetic forward DP, 4-bit traceback codes)" : codes ? "k_align8_fwd_pk<.,.,true> (packed forward DP, 4-bit traceback codes)"
 		: generic ? "k_align8_fwd_gen (run-time bandwidth, row records)" : "k_align8_fwd_pk / k_align8_fwd (row records)";
-	c->trace_name = codes ? "" : "k_align8_backcal";
+	c->trace_name = sys ? "k_align8_trace_sys" : codes ? "" : "k_align8_backcal";
 	bsa_last_trace_kernel = nullptr;
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
-		if(codes && fwd_x) HIPCHK(c, bsa_launch_align8_fwd_x(b, pw, s));
+		if(sys) HIPCHK(c, bsa_launch_align8_fwd_sys(b, pw, p->max_qlen, s));
+		else if(codes && fwd_x) HIPCHK(c, bsa_launch_align8_fwd_x(b, pw, s));
 		else if(codes) HIPCHK(c, bsa_launch_align8_fwd_codes(b, pw, s));
 		else if(generic) HIPCHK(c, bsa_launch_align8_fwd_gen(b, pw, max_bw, s));
 		else HIPCHK(c, bsa_launch_align8_fwd(b, pw, s));
@@ -866,7 +892,8 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	};
 	auto trace = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
-		if(codes) HIPCHK(c, bsa_launch_align8_trace_codes(b, pw, d_out, cnt, s));
+		if(sys) HIPCHK(c, bsa_launch_align8_trace_sys(b, pw, d_out, cnt, p->d_slot_end, s));
+		else if(codes) HIPCHK(c, bsa_launch_align8_trace_codes(b, pw, d_out, cnt, s));
 		else HIPCHK(c, bsa_launch_align8_backcal(b, pw, d_out, cnt, s));
 		return BSA_OK;
 	};
@@ -939,7 +966,7 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	if(rc != BSA_OK) return rc;
 	std::vector<uint32_t> st_own;
 	uint32_t *st = status;
-	const bool codes = p->codes;
+	const bool codes = p->codes || p->sys;           // both read the traceback off codes and may hand a pair over
 	if(codes && !st){ st_own.resize(n); st = st_own.data(); }
 	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, st,
 		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_align_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });

@@ -344,6 +344,49 @@ def test_whole_query_bands_run_widened_on_the_compact_path(ctx, bw, monkeypatch)
     assert "k_align8_fwd_x" not in ctx.last_kernel_names()[0]
 
 
+@pytest.mark.parametrize("bw", [0, 1008, 3008])
+def test_whole_query_bands_above_256_columns_run_the_systolic_wavefront(ctx, bw, monkeypatch):
+    """global mode, a band that covers every query and is wider than the register kernels (the reference CLI's `-W 0` on long
+    reads): one wave per pair, a lane per target row, bit planes of traceback codes (bsa_align8_sys.hip) -- results equal the
+    reference's own band (the oracle runs the requested width) and the run-time-width kernel's (BSA_ALIGN8_SYS=0)"""
+    import bsalign_amd as B
+    rng = np.random.default_rng(9000 + bw)
+    top = bw if bw else 3000
+    lens = [l for l in (257, 258, 271, 272, 273, 300, 319, 320, 321, 500, 511, 512, 513, 700, 1000, 1008, 1500, 2047, 2048, 2049, 3000) if l <= top]
+    pairs = [(q[:top] if len(q) > top else q, t) for q, t in _mk_pairs(rng, 72, lens, eps_list=(0.0, 0.05, 0.2, 0.4), ratios=(1.0, 1.0, 0.5, 0.9, 1.1))]
+    pairs = [(q, t) for q, t in pairs if len(q) > 256 or bw]
+    pairs.append((pairs[0][0], pairs[0][1][:1]))            # a one-row target
+    pairs.append((pairs[1][0], pairs[1][1][:63]))
+    pairs.append((pairs[2][0], pairs[2][1][:64]))
+    pairs.append((pairs[3][0], pairs[3][1][:65]))
+    for scname in ("affine", "paper", "linear"):
+        _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS[scname])
+        names = ctx.last_kernel_names()
+        assert "k_align8_fwd_sys" in names[0] and "k_align8_trace_sys" in names[1], names
+    par = B.make_params(S.MODE_GLOBAL, bw, *SCORINGS["affine"])
+    out_s, cig_s, st_s = ctx.align_batch(pairs, par)
+    monkeypatch.setenv("BSA_ALIGN8_SYS", "0")
+    out_g, cig_g, st_g = ctx.align_batch(pairs, par)
+    assert "gen" in ctx.last_kernel_names()[0]
+    monkeypatch.delenv("BSA_ALIGN8_SYS")
+    assert np.array_equal(out_s, out_g) and np.array_equal(st_s, st_g) and all(np.array_equal(a, b) for a, b in zip(cig_s, cig_g))
+    # overlap / extend, two-piece gaps and scorings outside the guard keep the run-time-width kernel
+    _check(ctx, pairs[:16], S.MODE_OVERLAP, bw, SCORINGS["affine"])
+    assert "sys" not in ctx.last_kernel_names()[0]
+    _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, SCORINGS["twopiece"])
+    assert "sys" not in ctx.last_kernel_names()[0]
+    _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, (10, -30, -20, -10, 0, 0))
+    assert "sys" not in ctx.last_kernel_names()[0]
+
+
+def test_whole_query_bands_10k(ctx):
+    """`bsalign align -W 0` on the benchmark's 10 kbp pairs (bench.py --length 10000 --bw -1)"""
+    pairs = [S.synth_pair(k, 10000) for k in range(6)]
+    _check(ctx, pairs, S.MODE_GLOBAL, 0, SCORINGS["affine"])
+    assert "k_align8_fwd_sys" in ctx.last_kernel_names()[0]
+    _check(ctx, pairs[:3], S.MODE_GLOBAL, 0, SCORINGS["linear"])
+
+
 @pytest.mark.parametrize("bw", [0, 112])
 def test_mixed_whole_query_batch_runs_one_sub_batch_per_width_class(ctx, bw):
     """bandwidth 0 (or an odd one) over queries of very different lengths: the host-pointer entry sends every width class of the
