@@ -8,33 +8,39 @@
 // absolute scores with the reference's own boundary rules.  No striping is needed for that: one wave runs one pair, lane l owns
 // target row 64 b + l of the current block of 64 rows and walks the query; at step t it computes column x = t - l, so the row above
 // (lane l - 1) delivered H(x, y-1) and E(x, y-1) exactly one step earlier -- a DPP wave shift per value and step, no LDS, no
-// waiting.  The last row of a block is the boundary of the next one: it leaves through a 64-entry LDS ring, 64 columns per
-// coalesced store, and comes back 64 columns per coalesced load (lane 0 picks its column with v_readlane).
+// waiting.  The last row of a block is the boundary of the next one: it leaves through a 128-entry LDS ring, 64 columns per
+// coalesced store, and comes back 64 columns per coalesced load into a second ring (lane 0's shift-in is the ring entry of the step:
+// the LDS read is the `old` operand of the DPP move).
 // Kept literally (absolute-score form of the rules, cf. the POA wavefront bsa_poa_wf.hip):
 //   * row -1 (row_init, bsalign.h:2094-2140): H = gapo + gape (x + 1), e = -63; ubegs[0] = smax - smin with u[0] = gapo + gape + smin - smax
 //   * band cell 0 (bsalign.h:2899-2907) with rh = 0 on row 0 and gapo + gape y below (bsalign.h:3932-3946): h0 = rh - ubegs[0] + S, kept
 //     (clamped to 63) if >= u[0] + e[0], else -63; every later row has ubegs[0] = H(0, y-1), u[0] = 0 (the re-basing of :2632-2633)
-//   * F restarts from "H above - 63" at every running block of W = bw / 16 cells (bsalign.h:2909-2931 + the F-penetration :2639-2652)
+//   * F restarts from "H above - 63" at every running block of W = bw / 16 cells (bsalign.h:2909-2931 + the F-penetration :2639-2652):
+//     never binding inside the guard (see the kernel), so the striping of the reference's band does not enter
 // Traceback codes (the four facts backcal tests per cell): M (h == S-path; at column 0 against the UNclamped
 // rh + S), D (h == u + e; at column 0 in the frame mismatch of the re-based row: h - rh == u[0] + e[0]), R (h + gapo + gape >= f + gape:
 // an insertion reaching the next cell opens here), Od (the stored e is a fresh opening).  Row y, columns 32 k .. 32 k + 31: four
-// dwords {M, D, R, Od}, column c at bit 31 - (c & 31); rows are roundup(qlen, 32) / 2 bytes apart.
+// dwords {M, D, R, Od} of the wavefront steps t = x + (y & 63), 32 k <= t < 32 k + 32, step t at bit 31 - (t & 31); the 64 rows of a block
+// store their dwords of the same k side by side (one kilobyte per store instruction).
 #include "bsa_common.h"
+#include <type_traits>
 
 static __device__ __forceinline__ int sys_shr1(int fill, int x){                 // lane l <- lane l - 1 over the whole wave; lane 0 <- fill
-	int r = __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false);        // DPP wave_shr:1
-	asm("" : "+v"(r));
-	return r;
+	return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false);         // DPP wave_shr:1, bound_ctrl off: lane 0 keeps `fill`
 }
 
 struct SysHdr { int32_t score, reserved[3]; };
 
-static __host__ __device__ inline size_t bsa_sys_row_bytes(uint32_t qlen){ return ((size_t)qlen + 31) / 32 * 16; }
+// slot: header, the boundary row (qlen + 256 entries of {H * 32 | query code << 3, E * 32}), the code tiles, the CIGAR tail.
+// Code tiles: block b of 64 rows, word w = t >> 5 of the wavefront step t = x + (y & 63): 64 lanes x 16 bytes {M, D, R, Od}, step t at
+// bit 31 - (t & 31) -- every 32 steps the wave stores ONE contiguous kilobyte.
+static __host__ __device__ inline uint32_t bsa_sys_words(uint32_t qlen){ return (qlen + 63u + 31u) / 32u; }
 static __host__ __device__ inline size_t bsa_sys_bnd_off(){ return sizeof(SysHdr); }
-static __host__ __device__ inline size_t bsa_sys_codes_off(uint32_t qlen){ return (bsa_sys_bnd_off() + ((size_t)qlen + 64) * 8 + 63) & ~(size_t)63; }
+static __host__ __device__ inline size_t bsa_sys_codes_off(uint32_t qlen){ return (bsa_sys_bnd_off() + ((size_t)qlen + 256) * 8 + 1023) & ~(size_t)1023; }
+static __host__ __device__ inline size_t bsa_sys_codes_bytes(uint32_t qlen, uint32_t tlen){ return (size_t)((tlen + 63u) / 64u) * bsa_sys_words(qlen) * 1024u; }
 
 size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen){
-	return ((bsa_sys_codes_off(qlen) + (size_t)tlen * bsa_sys_row_bytes(qlen) + ((size_t)qlen + tlen + 16) * 4) + 255) & ~(size_t)255;
+	return ((bsa_sys_codes_off(qlen) + bsa_sys_codes_bytes(qlen, tlen) + ((size_t)qlen + tlen + 16) * 4) + 1023) & ~(size_t)1023;
 }
 
 bool bsa_align8_sys_supported(const Align8Args &a, int pw){
@@ -44,11 +50,16 @@ bool bsa_align8_sys_supported(const Align8Args &a, int pw){
 	return m + 3 * g <= 64 && n + m + g <= 100;
 }
 
+// Scores are carried times 32: the five low bits of the H register hold the query code of the column (code << 3), which travels down
+// the lanes with H in ONE wave shift and is the bit offset v_bfe_i32 takes the substitution score from (the matrix column of the
+// lane's target base, four bytes in a register).  Per step and lane (affine gaps): 2 DPP moves, 1 and, 1 bfe, 1 shift-add, 1 max3,
+// 3 adds, 2 max, 1 and-or, and two instructions per traceback fact (difference, v_alignbit of its sign into the lane's bit plane).
+// The F restart of the reference's running blocks (F = max(F, H above - 63)) is left out: inside the guard g <= 21, and the F that
+// reaches cell x is >= H(x - 1, y) + gapo + gape >= H(x - 1, y - 1) + 2 (gapo + gape) > H(x - 1, y - 1) - 63, so it never binds.
 template<int PW>
-__global__ void __launch_bounds__(64) k_align8_fwd_sys(const Align8Args a){
-	extern __shared__ __align__(16) uint8_t lds[];
-	int2 *oring = (int2*)lds;                        // the block's last row on its way out: 64 columns
-	uint8_t *qs = lds + 64 * sizeof(int2);           // the query
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_align8_fwd_sys(const Align8Args a){
+	__shared__ int2 inr[128 + 2];                    // the row above the block: columns t .. t + 127 of {H * 32 | q << 3, E * 32}; [128], [129] mirror [0], [1]
+	__shared__ int2 outr[128];                       // the block's last row on its way out: column c at (c + 63) & 127
 	const uint32_t ppos = a.first + blockIdx.x;
 	const uint32_t pair = a.order[ppos];
 	const int lane = threadIdx.x;
@@ -58,92 +69,129 @@ __global__ void __launch_bounds__(64) k_align8_fwd_sys(const Align8Args a){
 	if(a.status[pair] != 0u || qlen == 0 || tlen == 0){ if(lane == 0) hdr->score = (int)0x80000000u; return; }
 	int2 *bnd = (int2*)(slot + bsa_sys_bnd_off());
 	uint8_t *codes = slot + bsa_sys_codes_off((uint32_t)qlen);
-	const size_t rb = bsa_sys_row_bytes((uint32_t)qlen);
+	const int NW = (int)bsa_sys_words((uint32_t)qlen);
 	const uint8_t *qp = a.qst + a.qpoff[pair], *tp = a.tst + a.tpoff[pair];
-	for(int i = lane * 16; i < qlen; i += 64 * 16) *(uint4*)(qs + i) = *(const uint4*)(qp + i);      // (the staged query is padded)
-	__syncthreads();
-	const int GO = a.gapo1, GE = a.gape1, GOE = GO + GE;
-	const int Wc = a.ref_bw ? (int)(a.ref_bw / 16u) : ((qlen + 15) / 16 * 16) / 16;       // cells per running block of the reference's striping of its band
+	const int GO = a.gapo1, GE = a.gape1, GOE = GO + GE, GE5 = GE * 32, GOE5 = GOE * 32;
 	const int first_u = (int)(int8_t)(GOE + a.smin - a.smax), B0 = a.smax - a.smin;
-	const int nblk = (tlen + 63) / 64;
+	const int nblk = (tlen + 63) / 64, nsteps = qlen + 63, cmax = qlen + 192;
+	// row -1 (row_init): H = gapo + gape (x + 1), e = -63, with the query codes
+	for(int c = lane; c < cmax; c += 64){
+		const int h = GOE + GE * c, q = (c < qlen) ? ((int)qp[c] & 3) : 0;
+		bnd[c] = make_int2(h * 32 + q * 8, (h + BSA_EPI8_MIN) * 32);
+	}
 	for(int blk = 0; blk < nblk; blk++){
+		__builtin_amdgcn_s_waitcnt(0);                           // the boundary row is in memory before this block reads it
 		const int y = blk * 64 + lane;
-		const bool rowok = y < tlen;
-		const int tb = rowok ? (int)tp[y] & 3 : 0;
-		const uint32_t mr = (tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3];      // matrix[q * 4 + tb], q = 0..3, one byte each
+		const int tb = (y < tlen) ? (int)tp[y] & 3 : 0;
+		const int mr = (int)((tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3]);     // matrix[q * 4 + tb], q = 0..3, one byte each
 		const int rh = (y == 0) ? 0 : GO + GE * y;               // H left of column 0 (bsalign.h:3932-3946)
-		int Hout = 0, Eout = 0, Hd = 0, F = 0, wblk = 0;
-		uint32_t pM = 0, pD = 0, pR = 0, pO = 0;
-		uint8_t *myrow = codes + (size_t)(rowok ? y : 0) * rb;
-		// boundary chunk: columns [c0, c0 + 64) of the row above the block, one column per lane
-		int2 cur = make_int2(0, 0), nxt = make_int2(0, 0);
-		auto load_chunk = [&](int c0) -> int2 {
-			const int x = c0 + lane;
-			if(blk == 0){ const int h = GOE + GE * x; return make_int2(h, h + BSA_EPI8_MIN); }      // row -1: e = -63
-			return (x < qlen) ? bnd[x] : make_int2(0, 0);
-		};
-		cur = load_chunk(0);
-		const int nsteps = qlen + 63;
-		for(int t = 0; t < nsteps; t++){
-			if((t & 63) == 0) nxt = load_chunk(t + 64);
-			const int x = t - lane;
-			// from the row above: lane l - 1's cell of the previous step is this lane's column
-			int Hu = sys_shr1(0, Hout), Eu = sys_shr1(0, Eout);
-			{
-				const int bh = __builtin_amdgcn_readlane(cur.x, t & 63), be = __builtin_amdgcn_readlane(cur.y, t & 63);
-				if(lane == 0){ Hu = bh; Eu = be; }
+		int P = 0, E = 0, Hd = 0, F = 0;
+		uint32_t pM = 0, pD = 0, pR = 0, pO = 0;                 // NOT-facts, newest step in bit 0
+		uint4 *cp = (uint4*)codes + ((size_t)blk * NW * 64 + lane);
+		{ const int2 v0 = bnd[lane], v1 = bnd[64 + lane]; inr[lane] = v0; inr[64 + lane] = v1; if(lane < 2) inr[128 + lane] = v0; }
+		int2 nxt = bnd[128 + lane];
+		int drained = 0;
+		auto top = [&](int t){                                   // t % 64 == 0: ring maintenance, 64 columns per coalesced access
+			if(t >= 64){
+				const int ri = (t + 64 + lane) & 127;
+				inr[ri] = nxt;
+				if(ri < 2) inr[128 + ri] = nxt;
+				const int c = t + 128 + lane;
+				nxt = (c < cmax) ? bnd[c] : make_int2(0, 0);
 			}
-			if((t & 63) == 63) cur = nxt;
-			const bool on = x >= 0 && x < qlen;
-			const int qb = on ? (int)qs[x] : 4;
-			const int S = (int)(int8_t)((mr >> (8 * (qb & 3))) & 0xffu);
-			int diag = Hd + S, cmpM = diag, cmpD = Eu;
-			if(__any(x == 0)){
-				if(x == 0){
+			if(t >= 128 && blk + 1 < nblk){
+				const int c = t - 128 + lane;
+				bnd[c] = outr[(c + 63) & 127];
+				drained = t - 64;
+			}
+		};
+		auto flush = [&](int t){
+			const uint32_t sh = 31u - ((uint32_t)t & 31u);
+			*cp = (PW == 0) ? make_uint4(~(pM << sh), ~(pD << sh), 0xffffffffu, 0xffffffffu) : make_uint4(~(pM << sh), ~(pD << sh), ~(pR << sh), ~(pO << sh));
+			cp += 64;
+		};
+		auto step = [&](auto gen, const int t, const int2 b, int2 *ob){         // b: the ring entry of the step (all lanes read the same one; lane 0 uses it)
+			constexpr bool GEN = decltype(gen)::value;
+			const int Pi = sys_shr1(b.x, P);
+			const int Eu = (PW == 0) ? 0 : sys_shr1(b.y, E);
+			const int Hu = Pi & ~31;
+			const int S = __builtin_amdgcn_sbfe(mr, (unsigned)Pi, 8u);
+			const int Ein = (PW == 0) ? Hu + GE5 : Eu;
+			int diag = S * 32 + Hd, cmpM = diag, cmpD = Ein;
+			if constexpr(GEN){
+				if(t - lane == 0){
 					// band cell 0: the seed rule and the F restart; the M / D facts of column 0 in their own frames
-					const int ub0 = (y == 0) ? B0 : Hu;
+					const int Hui = Hu >> 5, Eui = Eu >> 5;
+					const int ub0 = (y == 0) ? B0 : Hui;
 					const int u0 = (y == 0) ? first_u : 0;
-					const int e0 = Eu - Hu;
+					const int e0 = Eui - Hui;
 					int h0 = rh - ub0 + S;
 					const int tt = u0 + (PW == 0 ? GE : e0);
 					h0 = (h0 >= tt) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;
-					diag = ub0 + h0;
-					cmpM = rh + S;
-					cmpD = rh + u0 + (PW == 0 ? GOE : e0);
-					F = ub0 + BSA_EPI8_MIN;
-					wblk = 0;
+					diag = (ub0 + h0) * 32;
+					cmpM = (rh + S) * 32;
+					cmpD = (rh + u0 + (PW == 0 ? GOE : e0)) * 32;
+					F = (ub0 + BSA_EPI8_MIN) * 32;
 				}
 			}
-			if(wblk == Wc){ F = max(F, Hd + BSA_EPI8_MIN); wblk = 0; }       // a new running block: F restarts from the sentinel
-			const int Ein = (PW == 0) ? Hu + GE : Eu;
 			const int H = max(max(diag, Ein), F);
-			const int t1 = H + GOE, tF = F + GE, tE = Ein + GE;
-			const uint32_t fM = (H == cmpM) ? 1u : 0u;
-			const uint32_t fD = (H == ((PW == 0 && x != 0) ? Hu + GOE : cmpD)) ? 1u : 0u;
-			const uint32_t fR = (PW == 0 || t1 >= tF) ? 1u : 0u;
-			const uint32_t fO = (PW == 0 || tE <= t1) ? 1u : 0u;
-			if(on){
-				pM = (pM << 1) | fM; pD = (pD << 1) | fD; pR = (pR << 1) | fR; pO = (pO << 1) | fO;
-				Hout = H; Eout = (PW == 0) ? H : max(tE, t1);
-				F = (PW == 0) ? H + GE : max(tF, t1);
-				Hd = Hu;
-				wblk++;
-				if((x & 31) == 31 || x == qlen - 1){
-					const int sh = 31 - (x & 31);
-					if(rowok) *(uint4*)(myrow + (size_t)(x >> 5) * 16) = make_uint4(pM << sh, pD << sh, pR << sh, pO << sh);
-					pM = pD = pR = pO = 0;
-				}
-				if(x == qlen - 1 && y == tlen - 1) hdr->score = H;
+			const int t1 = H + GOE5;
+			if constexpr(GEN){
+				pM = (pM << 1) | (H != cmpM ? 1u : 0u);
+				pD = (pD << 1) | (H != cmpD ? 1u : 0u);
+			} else {
+				pM = __builtin_amdgcn_alignbit(pM, (uint32_t)(diag - H), 31u);
+				pD = __builtin_amdgcn_alignbit(pD, (uint32_t)(Ein - H), 31u);
 			}
-			// the block's last row leaves: column x of lane 63 into the ring, a full ring to HBM
-			if(lane == 63 && on) oring[x & 63] = make_int2(Hout, Eout);
-			if(blk + 1 < nblk && t >= 63 && (((t - 63) & 63) == 63 || t == nsteps - 1)){
-				const int c0 = (t - 63) & ~63;
-				__builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): the ring entry just written
-				if(c0 + lane <= t - 63) bnd[c0 + lane] = oring[lane];
+			if(PW != 0){
+				const int tF = F + GE5, tE = Ein + GE5;
+				pR = __builtin_amdgcn_alignbit(pR, (uint32_t)(t1 - tF), 31u);        // R: t1 >= tF
+				pO = __builtin_amdgcn_alignbit(pO, (uint32_t)(t1 - tE), 31u);        // Od: tE <= t1
+				E = max(tE, t1);
+				F = max(tF, t1);
+			} else F = H + GE5;
+			P = (Pi & 31) | H;
+			Hd = Hu;
+			if constexpr(GEN){
+				const int x = t - lane;
+				if(lane == 63 && x >= 0 && x < qlen) *ob = make_int2(P, E);
+				if(x == qlen - 1 && y == tlen - 1) hdr->score = H >> 5;
+			} else {
+				if(lane == 63) *ob = make_int2(P, E);
 			}
+		};
+		int t = 0;
+		for(const int te = min(64, nsteps); t < te; t++){
+			if((t & 63) == 0) top(t);
+			step(std::true_type(), t, inr[t & 127], &outr[t & 127]);
+			if((t & 31) == 31 || t == nsteps - 1) flush(t);
 		}
-		__builtin_amdgcn_s_waitcnt(0);                           // the boundary row is in HBM before the next block reads it
+		// steady state: 0 < x < qlen - 1 on every lane
+		for(; t + 32 <= qlen - 1; t += 32){
+			if((t & 63) == 0) top(t);
+			int ro = t & 127;                                        // ring offset of the step, kept in a VGPR (a uniform address would be
+			asm volatile("" : "+v"(ro));                             // moved from an SGPR in front of every LDS instruction)
+			const int2 *ib = inr + ro; int2 *ob = outr + ro;
+			int2 b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
+#pragma unroll 1
+			for(int kk = 0; kk < 4; kk++, ib += 8, ob += 8){
+#pragma unroll
+				for(int k = 0; k < 8; k++){
+					const int2 b = b0;
+					b0 = b1;
+					b1 = ib[k + 2];
+					step(std::false_type(), t + kk * 8 + k, b, ob + k);
+				}
+			}
+			flush(t + 31);
+		}
+		for(; t < nsteps; t++){
+			if((t & 63) == 0) top(t);
+			step(std::true_type(), t, inr[t & 127], &outr[t & 127]);
+			if((t & 31) == 31 || t == nsteps - 1) flush(t);
+		}
+		if(blk + 1 < nblk)
+			for(int c0 = drained; c0 < qlen; c0 += 64){ const int c = c0 + lane; if(c < qlen) bnd[c] = outr[(c + 63) & 127]; }
 	}
 }
 
@@ -162,7 +210,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 	const uint8_t *slot = a.rows + a.slot_off[ppos];
 	const SysHdr *hdr = (const SysHdr*)slot;
 	const uint8_t *codes = slot + bsa_sys_codes_off((uint32_t)qlen);
-	const size_t rb = bsa_sys_row_bytes((uint32_t)qlen);
+	const int NW = (int)bsa_sys_words((uint32_t)qlen);
 	uint32_t *cig_end = (uint32_t*)(a.rows + slot_end[ppos]);
 	uint32_t ncig = 0;
 	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
@@ -171,8 +219,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 		if(cg) cig_push(cg);
 		return (sz << 4) | op;
 	};
-	auto plane = [&](int r, int x, int pl) -> uint32_t { return *(const uint32_t*)(codes + (size_t)r * rb + (size_t)(x >> 5) * 16 + pl * 4); };
-	auto bit = [&](int r, int x, int pl) -> bool { return (plane(r, x, pl) >> (31 - (x & 31))) & 1u; };
+	// the facts of cell (x, r): tile r >> 6, wavefront step t = x + (r & 63), word t >> 5, bit 31 - (t & 31)
+	auto word = [&](int r, int tw) -> const uint4* { return (const uint4*)codes + ((size_t)(r >> 6) * NW + tw) * 64 + (r & 63); };
+	auto bit = [&](int r, int x, int pl) -> bool {
+		const int t = x + (r & 63);
+		return (((const uint32_t*)word(r, t >> 5))[pl] >> (31 - (t & 31))) & 1u;
+	};
 	bool bad = false;
 	rs.score = hdr->score;
 	if(rs.score == (int)0x80000000u) bad = true;
@@ -183,8 +235,9 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 	uint32_t cg = 0;
 	while(!bad){
 		if(rs.qb < 0 || rs.tb < 0) break;
-		const uint4 cw = *(const uint4*)(codes + (size_t)rs.tb * rb + (size_t)(rs.qb >> 5) * 16);
-		const uint32_t sh = 31u - ((uint32_t)rs.qb & 31u);
+		const int lq = rs.tb & 63, tq = rs.qb + lq;
+		const uint4 cw = *word(rs.tb, tq >> 5);
+		const uint32_t sh = 31u - ((uint32_t)tq & 31u);
 		const bool fM = (cw.x >> sh) & 1u, fD = (cw.y >> sh) & 1u;
 		int bt;                                               // backcal_cell (bsalign.h:3679-3699): the order of the tests depends on prior_match
 		if(prior_match) bt = fM ? 0 : fD ? 2 : 1;
@@ -200,11 +253,11 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 				// the nearest cell to the left at which an insertion reaching its right neighbour opens (bsalign.h:3798-3814)
 				int sz = 0;
 				uint32_t w = cw.z & ~((2u << sh) - 1u);                                 // R bits of the cells left of qb in this word
-				int xw = rs.qb >> 5;
+				int tw = tq >> 5;
 				for(;;){
-					if(w){ const int c = xw * 32 + (31 - (int)__builtin_ctz(w)); sz = rs.qb - c; break; }
-					if(--xw < 0) break;
-					w = plane(rs.tb, xw * 32, 2);
+					if(w){ const int c = tw * 32 + (31 - (int)__builtin_ctz(w)) - lq; if(c >= 0) sz = rs.qb - c; break; }      // (steps left of column 0 hold no cell)
+					if(--tw < 0) break;
+					w = word(rs.tb, tw)->z;
 				}
 				if(sz == 0){ bad = true; break; }                                       // the reference's scan finds no length either
 				cg = cig_add(cg, 1, (uint32_t)sz);
@@ -244,14 +297,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 }
 
 hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_qlen, hipStream_t st){
+	(void)max_qlen;
 	if(a.count == 0) return hipSuccess;
-	const size_t lds = 64 * sizeof(int2) + (((size_t)max_qlen + 15) & ~(size_t)15) + 16;
-	if(lds > 64 * 1024){
-		if(hipFuncSetAttribute((const void*)k_align8_fwd_sys<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipErrorInvalidValue;
-		if(hipFuncSetAttribute((const void*)k_align8_fwd_sys<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipErrorInvalidValue;
-	}
-	if(pw == 0) hipLaunchKernelGGL(k_align8_fwd_sys<0>, dim3(a.count), dim3(64), lds, st, a);
-	else hipLaunchKernelGGL(k_align8_fwd_sys<1>, dim3(a.count), dim3(64), lds, st, a);
+	if(pw == 0) hipLaunchKernelGGL(k_align8_fwd_sys<0>, dim3(a.count), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL(k_align8_fwd_sys<1>, dim3(a.count), dim3(64), 0, st, a);
 	return hipGetLastError();
 }
 
