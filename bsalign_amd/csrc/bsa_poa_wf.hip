@@ -63,7 +63,277 @@ __device__ __forceinline__ int poa_init_h(const PoaArgs &a, int p){     // row_i
 	return a.O + a.E + p * a.E;
 }
 
-template<int PW>
+// ---- the forward pass, a row at a time (the default) ----------------------------------------------------------------------------
+// Nodes in the reference's completion order, ONE node per trip of the wave: lane l holds cells l, l + 64, ... of the node's row, the
+// node record is uniform (scalar registers: one or two inputs, update or merge, far or near are real branches that cost nothing),
+// predecessor rows come from an LDS ring of the last 64 rows (older ones from the rows already in HBM), and the two serial chains of a
+// row -- F and G, the horizontal gap states -- are max-plus prefix scans over the wave (DPP row shifts and broadcasts):
+//     H(p) = max(N(p), F(p), G(p)),   N = what the inputs offer (diagonal, E, Q, merged rows)
+//     F(p) = max(inj(p), max_{j<p} (max(inj(j), N(j) + gapo1) + (p - j) gape1)),   G the same with gapo2 / gape2
+// inj(p) = "H of the previous row - 63" at the start of every running block of the reference's striping (bsalign.h:2909-2931).  This is
+// the literal recurrence F(p) = max(F(p-1) + gape1, H(p-1) + gapo1 + gape1) with every path through an H that itself came from F or G
+// dropped: such a path is never better than staying in the chain it came from (gapo <= 0, and gapo1 + gape1 <= gape1 <= gape2,
+// bsa_poa_rows_supported), so the maxima -- the only thing stored -- are the same numbers.  Same rows in HBM as the wavefront below.
+// inclusive prefix maximum over the 64 lanes of two values at once: six DPP steps each (row shifts by 1, 2, 4, 8, then the row
+// broadcasts), the DPP operand folded into v_max_i32.  The two chains alternate, which leaves one wait state of the two a DPP read of
+// a just-written register needs to an s_nop (inline assembly is not seen by the compiler's hazard recogniser).
+static __device__ __forceinline__ void poa_scan_max2(int &f, int &g){
+	asm volatile(
+		"s_nop 1\n\t"
+		"v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+		"v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 0\n\t"
+		"v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+		"v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 0\n\t"
+		"v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+		"v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 0\n\t"
+		"v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+		"v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 0\n\t"
+		"v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+		"v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+		"s_nop 0\n\t"
+		"v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+		"v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+		"s_nop 1"
+		: "+v"(f), "+v"(g));
+}
+
+#ifdef POA_PROF
+// section timers of the row-at-a-time forward pass (make EXTRA=-DPOA_PROF): every mark waits for everything outstanding and adds the
+// shader clocks since the previous mark to the section that ends there
+#define POA_PROF_MARK(k_) { __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); prof_acc[k_] += t_ - prof_t; prof_t = t_; }
+#else
+#define POA_PROF_MARK(k_)
+#endif
+#define POA_ROWS_PAD 64       // ring rows are bw' + 64 cells apart (bw' = cells of a wave): a predecessor moved by <= 64 cells is read without clamping
+
+template<int PW, int CPL>
+static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const bsa_poa_prog_t &pg, uint8_t *lds, const int lane){
+	uint32_t *ring = (uint32_t*)lds;                    // R rows, RS cells apart, of bw cells {int16 H - base, e, q}
+	int32_t *rbase = (int32_t*)(lds + a.ri_off);        // H of the first cell of every ring row
+	uint8_t *qb = lds + a.nq_off;                       // the read as a profile: bit b = "base b matches", bit 4 = differs from the next base, bit 5 = beyond the end
+	const int bw = (int)a.bw, W = (int)a.W, RS = CPL * 64 + POA_ROWS_PAD, RM = (int)a.R - 1;
+	const int nn = (int)pg.nnodes, slen = (int)pg.slen;
+	const bsa_poa_node_t *nodes = a.nodes + pg.first_node;
+	uint32_t *grows = a.rows + (size_t)pg.first_node * bw;
+	int32_t *gu0 = a.u0 + pg.first_node;
+	const int mode = a.mode & 3;
+	const int E = a.E, O = a.O, OE = a.O + a.E, P = a.P, Q = a.Q, QP = a.Q + a.P;
+	const int NEG = POA_NEG;
+	const int p0 = CPL * lane;                          // the lane's cells: p0 .. p0 + CPL - 1
+	int pE[CPL], pP[CPL]; bool blk0[CPL], live[CPL];
+#pragma unroll
+	for(int j = 0; j < CPL; j++){ const int p = p0 + j; pE[j] = p * E; pP[j] = p * P; blk0[j] = (p % W) == 0; live[j] = p < bw; }
+	const int h0init = poa_init_h<PW>(a, 0);
+#ifdef POA_PROF
+	long long prof_acc[5] = {0, 0, 0, 0, 0}, prof_t = clock64();
+#endif
+	{
+		const uint8_t *q = a.queries + pg.query_off;
+		for(int x = lane; x < slen + CPL * 64 + 8; x += 64){
+			uint32_t v = 0x20u;
+			if(x < slen){ const uint32_t c = q[x] & 3u; v = 1u << c; if(x + 1 < slen && q[x + 1] != q[x]) v |= 0x10u; }
+			qb[x] = (uint8_t)v;
+		}
+	}
+	// the head: row_init, in ring row 0 already (the caller wrote it at the wavefront's stride bw; RS >= bw and row 0 starts at 0); its copy in HBM
+	for(int p = lane; p < bw; p += 64) grows[p] = ring[p];
+	if(lane == 0){ gu0[0] = a.head_u0; rbase[0] = h0init; }
+	__syncthreads();
+	for(int i0 = 0; i0 < nn; i0 += 64){
+		// 64 node records, one per lane; the fields of node i0 + k come out with v_readlane
+		uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+		if(i0 + lane < nn){ const uint4 *rec = (const uint4*)(nodes + i0 + lane); r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; }
+		// the records are waited for HERE: a wait inside the node loop would count the rows stored since (vmcnt is one in-order counter
+		// for loads and stores) and make every node wait for the previous node's stores to be acknowledged
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+		asm volatile("" : "+v"(r0.x), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w), "+v"(r2.x), "+v"(r2.y));
+		const int kend = min(64, nn - i0);
+		for(int k = (i0 == 0) ? 1 : 0; k < kend; k++){
+			const int i = i0 + k;
+			POA_PROF_MARK(0)
+			const int rpos = (int)__builtin_amdgcn_readlane((int)r0.x, k);
+			const uint32_t w3 = (uint32_t)__builtin_amdgcn_readlane((int)r0.w, k);
+			const uint32_t nbase = (w3 >> 16) & 0xFFu;
+			const int Mv = a.M + (((w3 >> 24) & 1u) ? a.refbonus : 0);
+			// phase 1: everything the node reads from LDS, requested at once (one round trip per node); an input further back than the
+			// ring (rare) is read from HBM into the same registers afterwards
+			int srcs[2], mvs[2], sbs[2], hls[2]; uint32_t kinds[2], cwv[2][CPL], cmv[2];
+			uint32_t qv[CPL];
+#pragma unroll
+			for(int j = 0; j < CPL; j++) qv[j] = qb[rpos + p0 + j];
+#pragma unroll
+			for(int kk = 0; kk < 2; kk++){
+				kinds[kk] = (uint32_t)__builtin_amdgcn_readlane((int)(kk == 0 ? r1.z : r2.y), k);
+				srcs[kk] = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.x : r1.w), k);
+				mvs[kk] = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.y : r2.x), k);
+				if(!(kinds[kk] & BSA_POA_IN_PRESENT)){ srcs[kk] = 0; mvs[kk] = 0; }
+				if(kinds[kk] & BSA_POA_IN_MERGE) mvs[kk] = 0;
+				const uint32_t *lrow = ring + (srcs[kk] & RM) * RS;
+				sbs[kk] = rbase[srcs[kk] & RM];
+				hls[kk] = (int)lrow[bw - 1];
+				const int bi = min(p0 + mvs[kk], RS - CPL);          // (a lane whose base is clamped holds synthetic cells only)
+#pragma unroll
+				for(int j = 0; j < CPL; j++) cwv[kk][j] = lrow[bi + j];
+				cmv[kk] = lrow[max(bi - 1, 0)];
+			}
+#pragma unroll
+			for(int kk = 0; kk < 2; kk++){
+				if((kinds[kk] & BSA_POA_IN_PRESENT) && (i - srcs[kk]) > RM){
+					// the rows stored so far have landed, and nothing stale is in this CU's vector cache
+					__builtin_amdgcn_s_waitcnt(0);
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+					const uint32_t *grow = grows + (size_t)srcs[kk] * bw;
+					sbs[kk] = (srcs[kk] == 0) ? h0init : gu0[srcs[kk]];
+					hls[kk] = (int)grow[bw - 1];
+#pragma unroll
+					for(int j = 0; j < CPL; j++) cwv[kk][j] = grow[min(p0 + j + mvs[kk], bw - 1)];
+					cmv[kk] = grow[min(max(p0 + mvs[kk] - 1, 0), bw - 1)];
+					__builtin_amdgcn_s_waitcnt(0x0F70);          // (waited for here, so that the common path never waits on the vector-memory counter)
+				}
+			}
+			POA_PROF_MARK(1)
+			// the substitution scores of the node's base along the lane's cells (bspoa.h:2199-2215; bsalign.h:2166-2221)
+			int Sb[CPL], hpc[CPL];
+#pragma unroll
+			for(int j = 0; j < CPL; j++){
+				Sb[j] = ((qv[j] >> nbase) & 1u) ? Mv : a.X;
+				hpc[j] = (int)((qv[j] >> 4) & 1u);
+			}
+			if(rpos + CPL * 64 > slen){
+#pragma unroll
+				for(int j = 0; j < CPL; j++) if(qv[j] & 0x20u) Sb[j] = BSA_EPI8_MIN;
+			}
+			int N[CPL], Ein[CPL], Qin[CPL], inj[CPL], HX[CPL], EX[CPL], QX[CPL];
+#pragma unroll
+			for(int j = 0; j < CPL; j++){ N[j] = NEG; Ein[j] = NEG; Qin[j] = NEG; inj[j] = NEG; HX[j] = NEG; EX[j] = NEG; QX[j] = NEG; }
+			bool has_merge = false;
+			// phase 2: what the inputs offer (uniform branches on the node record, selects per cell)
+#pragma unroll
+			for(int kk = 0; kk < 2; kk++){
+				const uint32_t kind = kinds[kk];
+				if(!(kind & BSA_POA_IN_PRESENT)) continue;
+				const int src = srcs[kk], mv = mvs[kk], sbase = sbs[kk];
+				if(kind & BSA_POA_IN_MERGE){
+					has_merge = true;
+#pragma unroll
+					for(int j = 0; j < CPL; j++){
+						const uint32_t cw = cwv[kk][j];
+						const int h = sbase + (int)(int16_t)(cw & 0xFFFFu);
+						HX[j] = max(HX[j], h); EX[j] = max(EX[j], h + sx8(cw >> 16)); QX[j] = max(QX[j], h + sx8(cw >> 24));
+					}
+					continue;
+				}
+				const int toff = (int)(kind & BSA_POA_IN_TOFF);
+				const bool same = (kind & BSA_POA_IN_SAME) != 0u;
+				const bool dead = mv >= bw;
+				int rh0;                                    // the diagonal score left of band cell 0 when the band did not move (bspoa.h:2242-2249)
+				if(rpos) rh0 = BSA_SCORE_MIN;
+				else if(mode == BSA_MODE_OVERLAP || toff == 0) rh0 = 0;
+				else if(PW < 2) rh0 = O + E * toff;
+				else rh0 = max(O + E * toff, Q + P * toff);
+				int h1[CPL], b0[CPL], ee[CPL], qq[CPL];
+#pragma unroll
+				for(int j = 0; j < CPL; j++){
+					const uint32_t cw = cwv[kk][j];
+					h1[j] = sbase + (int)(int16_t)(cw & 0xFFFFu);
+					ee[j] = sx8(cw >> 16); qq[j] = sx8(cw >> 24);
+					b0[j] = (j == 0) ? sbase + (int)(int16_t)(cmv[kk] & 0xFFFFu) : h1[j - 1];
+				}
+				if(mv > 0){
+					// synthetic cells behind the moved row's end (bsalign.h:2357-2389): c0, then gape1 up to distance d, then gape2
+					const int hlast = sbase + (int)(int16_t)((uint32_t)hls[kk] & 0xFFFFu) + a.c0;
+					auto synth = [&](int kx) -> int { return hlast + ((kx < a.d) ? kx * E : (a.d - 1) * E + (kx - a.d + 1) * P); };
+#pragma unroll
+					for(int j = 0; j < CPL; j++){
+						const int idx = p0 + j + mv;
+						if(idx >= bw){ h1[j] = synth(idx - bw); ee[j] = 0; qq[j] = 0; }
+						if(idx - 1 >= bw) b0[j] = synth(idx - 1 - bw);
+					}
+					if(dead){
+#pragma unroll
+						for(int j = 0; j < CPL; j++){ h1[j] = BSA_SCORE_MIN; b0[j] = BSA_SCORE_MIN; ee[j] = 0; qq[j] = 0; }
+					}
+				} else if(lane == 0) b0[0] = (src == 0) ? a.head_u0 : sbase;       // ubegs[0] of the predecessor
+#pragma unroll
+				for(int j = 0; j < CPL; j++){
+					const int S = Sb[j] + (same ? 0 : hpc[j]);
+					int mc = b0[j] + S;
+					if(j == 0){
+						// band cell 0: the seed rule (bsalign.h:2899-2907), rh as dpalign_row_update_bspoa picks it (bspoa.h:2242-2254)
+						const int rh = (mv == 0) ? rh0 : b0[0];
+						int h0 = rh - b0[0] + S;
+						const int tt = (h1[0] - b0[0]) + (PW == 0 ? E : PW == 1 ? ee[0] : max(ee[0], qq[0]));
+						h0 = (h0 >= tt) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;
+						if(lane == 0) mc = b0[0] + h0;
+					}
+					N[j] = max(N[j], mc);
+					inj[j] = max(inj[j], blk0[j] ? b0[j] + BSA_EPI8_MIN : NEG);
+					Ein[j] = max(Ein[j], h1[j] + (PW == 0 ? E : ee[j]));
+					if(PW == 2) Qin[j] = max(Qin[j], h1[j] + qq[j]);
+				}
+			}
+			POA_PROF_MARK(2)
+			// the chains: per lane the maximum of its cells' sources, one scan over the lanes, then cell by cell inside the lane
+			int Nc[CPL], af[CPL], ag[CPL];
+			int mf = NEG, mg = NEG;
+#pragma unroll
+			for(int j = 0; j < CPL; j++){
+				Nc[j] = max(N[j], Ein[j]);
+				if(has_merge) Nc[j] = max(Nc[j], HX[j]);
+				if(PW == 2) Nc[j] = max(Nc[j], Qin[j]);
+				if(CPL * 64 != bw && !live[j]){ Nc[j] = NEG; inj[j] = NEG; }
+				af[j] = max(inj[j], Nc[j] + O) - pE[j]; mf = max(mf, af[j]);
+				if(PW == 2){ ag[j] = max(inj[j], Nc[j] + Q) - pP[j]; mg = max(mg, ag[j]); }
+			}
+			poa_scan_max2(mf, mg);
+			int exf = __builtin_amdgcn_update_dpp(NEG, mf, 0x138, 0xf, 0xf, false);       // wave_shr:1: what the lanes before offer
+			int exg = (PW == 2) ? __builtin_amdgcn_update_dpp(NEG, mg, 0x138, 0xf, 0xf, false) : NEG;
+			int H[CPL];
+#pragma unroll
+			for(int j = 0; j < CPL; j++){
+				H[j] = max(Nc[j], max(exf + pE[j], inj[j]));
+				if(PW == 2) H[j] = max(H[j], exg + pP[j]);
+				exf = max(exf, af[j]);
+				if(PW == 2) exg = max(exg, ag[j]);
+			}
+			POA_PROF_MARK(3)
+			const int hb = __builtin_amdgcn_readlane(H[0], 0);
+			uint32_t cwo[CPL];
+#pragma unroll
+			for(int j = 0; j < CPL; j++){
+				int e1 = 0, q1 = 0;
+				if(PW >= 1){ e1 = max(Ein[j] + E, H[j] + OE); if(has_merge) e1 = max(e1, EX[j]); e1 -= H[j]; }
+				if(PW == 2){ q1 = max(Qin[j] + P, H[j] + QP); if(has_merge) q1 = max(q1, QX[j]); q1 -= H[j]; }
+				cwo[j] = (uint32_t)((H[j] - hb) & 0xFFFF) | (((uint32_t)e1 & 0xFFu) << 16) | ((uint32_t)q1 << 24);
+			}
+			{
+				uint32_t *lrow = ring + (i & RM) * RS + p0;
+				uint32_t *grow = grows + (size_t)i * bw + p0;
+				if(CPL * 64 == bw){
+					if(CPL == 2){ *(uint2*)lrow = make_uint2(cwo[0], cwo[1]); *(uint2*)grow = make_uint2(cwo[0], cwo[1]); }
+					else if(CPL == 4){ *(uint4*)lrow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); *(uint4*)grow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); }
+					else { lrow[0] = cwo[0]; grow[0] = cwo[0]; }
+				} else {
+#pragma unroll
+					for(int j = 0; j < CPL; j++) if(live[j]){ lrow[j] = cwo[j]; grow[j] = cwo[j]; }
+				}
+			}
+			if(lane == 0){ rbase[i & RM] = hb; gu0[i] = hb; }
+			POA_PROF_MARK(4)
+		}
+	}
+#ifdef POA_PROF
+	if(lane == 0 && blockIdx.x == 0) printf("poa_forward_rows profile: %d nodes; clocks per node: setup+issue %.0f, wait+far %.0f, inputs %.0f, chains %.0f, store %.0f\n", nn,
+		(double)prof_acc[1] / nn, (double)prof_acc[2] / nn, (double)prof_acc[3] / nn, (double)prof_acc[4] / nn, (double)prof_acc[0] / nn);
+#endif
+	return nn;
+}
+
+template<int PW, int ROWS>                  // ROWS: 0 = the wavefront forward pass, else the row-at-a-time one with ROWS cells per lane
 __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	extern __shared__ __align__(16) uint8_t lds[];
 	uint32_t *ring = (uint32_t*)lds;                // R rows of bw cells {int16 H - base, e, q}: exactly the cells the traceback reads from HBM
@@ -108,7 +378,11 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	__syncthreads();
 
 	// ---- forward pass ----
-	const unsigned long long tick0 = wall_clock64();
+	const unsigned long long tick0 = wall_clock64(), clk0 = clock64();
+	int iters = 0;
+	if constexpr(ROWS != 0){
+		iters = poa_forward_rows<PW, ROWS>(a, pg, lds, lane);
+	} else {
 	int m = -NL;                 // nodes below m are complete; the nodes in flight are m .. m + NL - 1
 	int mr = 0;                  // m mod NL
 	int myslot = lane - NL;      // cur mod R, kept incrementally (no divisions in the loop)
@@ -145,7 +419,6 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	};
 	refill(min(nn, POA_NQ));
 	__syncthreads();
-	int iters = 0;
 	while(m < nn){
 		iters++;
 		if(qfill < nn && qfill < m + 2 * NL + 32){ refill(min(nn, qfill + 32)); __syncthreads(); }
@@ -313,8 +586,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		}
 	}
 	drain(nn);
+	}
 	__builtin_amdgcn_s_waitcnt(0);
 	__syncthreads();
+	const int fwd_ticks = (int)(wall_clock64() - tick0), fwd_clk = (int)((clock64() - clk0) >> 6);
 
 	// ---- the best end cell (bspoa.h:2549-2603): candidates in the reference's visiting order, strictly greater replaces ----
 	const bsa_poa_cand_t *cands = a.cands + pg.first_cand;
@@ -356,7 +631,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		if(ok > bkey){ bkey = ok; boff = oo; }
 	}
 	bsa_poa_result_t rs;
-	rs.reserved = (int)(wall_clock64() - tick0); if(a.mode & 0x100) rs.reserved = iters; rs.nevents = 0;       // forward pass + best end cell, in ticks of the 100 MHz counter rs.fin_node = -1; rs.fin_x = -1; rs.status = BSA_POA_ST_OK;
+	rs.reserved = (int)(wall_clock64() - tick0);        // forward pass + best end cell, in ticks of the 100 MHz counter
+	if(a.mode & 0x100) rs.reserved = (ROWS != 0) ? fwd_ticks : iters;
+	rs.nevents = 0; rs.fin_node = -1; rs.fin_x = -1; rs.status = BSA_POA_ST_OK;
 	if(bkey == (long long)0x8000000000000000ull){
 		rs.maxscr = BSA_SCORE_MIN; rs.maxidx = -1; rs.maxoff = -1; rs.status = BSA_POA_ST_NOCAND;
 		if(lane == 0) a.res[blockIdx.x] = rs;
@@ -366,7 +643,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	rs.maxidx = (int)cands[(0xFFFFFFFFu - (uint32_t)(bkey & 0xFFFFFFFFll)) >> 1].node;
 	rs.maxoff = boff;
 
-	if(a.mode & 0x200){ if(lane == 0) a.res[blockIdx.x] = rs; return; }      // (measurement: forward pass and best end cell only)
+	if(a.mode & 0x200){ if(a.mode & 0x100){ rs.fin_node = fwd_ticks; rs.fin_x = fwd_clk; } if(lane == 0) a.res[blockIdx.x] = rs; return; }      // (measurement: forward pass and best end cell only)
 	// ---- traceback: lane 0 walks, the wave keeps a tile of 64 nodes (records, in-edges, rows) in LDS ahead of it ----
 	{
 		const bsa_poa_edge_t *gedges = a.edges + pg.first_edge;
@@ -551,6 +828,18 @@ static size_t poa_qn_bytes(uint32_t bw, uint32_t max_slen){ return ((((size_t)ma
 static size_t poa_ring_bytes(uint32_t bw, uint32_t nl){ return (size_t)(nl + POA_NEAR + POA_DRAIN) * bw * 4; }
 static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max(poa_ring_bytes(bw, nl) + (size_t)(nl + POA_NEAR + POA_DRAIN) * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
 
+static uint32_t poa_rows_cpl(uint32_t bw){ return bw <= 64 ? 1u : bw <= 128 ? 2u : 4u; }
+static const uint32_t POA_ROWS_R = 32;      // ring rows of the row-at-a-time forward pass (a power of two)
+static size_t poa_rows_ring_bytes(uint32_t bw){ return (size_t)POA_ROWS_R * (poa_rows_cpl(bw) * 64 + POA_ROWS_PAD) * 4; }
+static size_t poa_rows_front_bytes(uint32_t bw){ return (std::max(poa_rows_ring_bytes(bw) + POA_ROWS_R * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
+static size_t poa_rows_qb_bytes(uint32_t bw, uint32_t max_slen){ return ((size_t)max_slen + poa_rows_cpl(bw) * 64 + 8 + 15) & ~(size_t)15; }
+// the row-at-a-time forward pass (poa_forward_rows): its scans need gapo <= 0 and gapo1 + gape1 <= gape1 <= gape2 <= 0 (the guard of
+// bsa_poa_graph_supported has the signs), and 64 ring rows + the query in LDS
+static bool poa_rows_supported(const bsa_rows_params_t *rp, int pw, uint32_t bw, uint32_t max_slen){
+	if(pw == 2 && rp->gape1 > rp->gape2) return false;
+	return poa_rows_front_bytes(bw) + poa_qn_bytes(bw, max_slen) + poa_rows_qb_bytes(bw, max_slen) <= POA_LDS_MAX;
+}
+
 extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen){
 	if(!par) return 0;
 	const bsa_rows_params_t *rp = &par->rows;
@@ -600,9 +889,19 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 	a.nodes = d_nodes; a.edges = d_edges; a.cands = d_cands; a.progs = d_progs; a.queries = d_queries;
 	a.rows = d_rows; a.u0 = d_u0; a.res = d_results; a.steps = d_steps; a.packed = d_packed; a.packed_used = (unsigned long long*)d_packed_used;
 	if(hipMemsetAsync(d_packed_used, 0, 8, st) != hipSuccess) return BSA_E_HIP;
-	a.bw = bw; a.W = bw / 16; a.nl = (uint32_t)nl; a.R = (uint32_t)nl + POA_NEAR + POA_DRAIN;
-	a.ri_off = (uint32_t)poa_ring_bytes(bw, (uint32_t)nl);
-	a.qn_off = (uint32_t)poa_front_bytes(bw, (uint32_t)nl);
+	// forward pass: a row at a time wherever its preconditions hold (BSA_POA_FWD=wf keeps the wavefront)
+	bool rows_fwd = poa_rows_supported(rp, pw, bw, max_slen);
+	{ const char *fe = bsa_env("BSA_POA_FWD"); if(fe && fe[0] == 'w') rows_fwd = false; }
+	a.bw = bw; a.W = bw / 16; a.nl = (uint32_t)nl;
+	if(rows_fwd){
+		a.R = POA_ROWS_R;
+		a.ri_off = (uint32_t)poa_rows_ring_bytes(bw);
+		a.qn_off = (uint32_t)poa_rows_front_bytes(bw);
+	} else {
+		a.R = (uint32_t)nl + POA_NEAR + POA_DRAIN;
+		a.ri_off = (uint32_t)poa_ring_bytes(bw, (uint32_t)nl);
+		a.qn_off = (uint32_t)poa_front_bytes(bw, (uint32_t)nl);
+	}
 	a.nq_off = a.qn_off + (uint32_t)poa_qn_bytes(bw, max_slen);
 	a.mode = rp->mode; a.M = rp->M; a.X = rp->X; a.refbonus = rp->refbonus;
 	a.O = rp->gapo1; a.E = rp->gape1; a.Q = rp->gapo2; a.P = rp->gape2; a.T = par->T;
@@ -616,14 +915,19 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 		const int type = a.mode & 3;
 		a.head_u0 = (type == BSA_MODE_OVERLAP) ? 0 : nt_max - nt_min;
 	}
-	const size_t lds = (size_t)a.nq_off + POA_NQ * sizeof(bsa_poa_node_t);
+	const size_t lds = (size_t)a.nq_off + (rows_fwd ? poa_rows_qb_bytes(bw, max_slen) : POA_NQ * sizeof(bsa_poa_node_t));
 	void *stop = nullptr;
 	rc = bsa_ctx_time_begin_internal(ctx, 0.0, &stop);
 	if(rc != BSA_OK) return rc;
-#define POA_LAUNCH(PWV) do {                                                                                                              \
-		if(hipFuncSetAttribute((const void*)k_poa_wf<PWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BSA_E_HIP; \
-		hipLaunchKernelGGL((k_poa_wf<PWV>), dim3((uint32_t)nprogs), dim3(64), lds, st, a); } while(0)
-	if(pw == 0) POA_LAUNCH(0); else if(pw == 1) POA_LAUNCH(1); else POA_LAUNCH(2);
+#define POA_LAUNCH(PWV, RV) do {                                                                                                          \
+		if(hipFuncSetAttribute((const void*)k_poa_wf<PWV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BSA_E_HIP; \
+		hipLaunchKernelGGL((k_poa_wf<PWV, RV>), dim3((uint32_t)nprogs), dim3(64), lds, st, a); } while(0)
+#define POA_LAUNCH_R(RV) do { if(pw == 0) POA_LAUNCH(0, RV); else if(pw == 1) POA_LAUNCH(1, RV); else POA_LAUNCH(2, RV); } while(0)
+	if(!rows_fwd) POA_LAUNCH_R(0);
+	else if(bw <= 64) POA_LAUNCH_R(1);
+	else if(bw <= 128) POA_LAUNCH_R(2);
+	else POA_LAUNCH_R(4);
+#undef POA_LAUNCH_R
 #undef POA_LAUNCH
 	if(hipGetLastError() != hipSuccess) return BSA_E_HIP;
 	return bsa_ctx_time_end_internal(ctx, stop);
