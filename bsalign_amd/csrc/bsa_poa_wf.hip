@@ -681,12 +681,14 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 			const int ecnt = min(TE, (int)t_nodes[hi - lo].head().first_in + (int)t_nodes[hi - lo].head().n_in - elo);
 			copy16((uint4*)t_edges, (const uint4*)(gedges + elo), ecnt);
 			__syncthreads();
-			if(lane == 0){
+			{
+				// every lane runs the walk with the same state (no lane-0 region, no broadcasts); the lanes part only inside the step that
+				// looks at a node's in-edges, one edge per lane
 				auto in_tile = [&](int i) -> bool { return i >= lo && i <= hi; };
 				auto U0 = [&](int i) -> int { if(in_tile(i)) return t_u0[i - lo]; return *(const volatile int32_t*)&gu0[i]; };
 				auto CELL = [&](int i, int pp) -> uint32_t { if(in_tile(i)) return t_rows[(i - lo) * bw + pp]; return *(const volatile uint32_t*)&grows[(size_t)i * bw + pp]; };
 				auto HH = [&](int i, int pp, uint32_t cw, int u0v) -> int { return (i == 0) ? poa_init_h<PW>(a, pp) : u0v + (int)(int16_t)(cw & 0xFFFFu); };
-#define EMIT(nn_, xx_, bb_) do{ if(ne >= ecap){ status = BSA_POA_ST_EVENTS; done = true; } else { ev[ne] = ((uint32_t)(nn_) << 3) | (bb_); ne++; } }while(0)
+#define EMIT(nn_, xx_, bb_) do{ if(ne >= ecap){ status = BSA_POA_ST_EVENTS; done = true; } else { if(lane == 0) ev[ne] = ((uint32_t)(nn_) << 3) | (bb_); ne++; } }while(0)
 				if(first){
 					first = false;
 					const int pp = x - (int)nodes[n].rpos;
@@ -744,6 +746,72 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
 						const uint32_t nb = (qn[x >> 3] >> ((x & 7) * 4)) & 0xFu;
 						const int sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nd.base) ? a.M + ((nd.flags & 1) ? a.refbonus : 0) : a.X);
+						if(nin <= 64 && nfirst >= elo && nfirst + nin <= elo + ecnt){
+							// one in-edge per lane: what the loop below does edge after edge (bspoa.h:2360-2392), then its choice -- the reference
+							// keeps the candidate with the largest coverage, the first one on ties unless a later one is a match / mismatch move
+							// and the kept one is not; coverage 0 is only ever taken as a match / mismatch move
+							bool m0 = false, m1 = false, m2 = false, valid = false;
+							int w = 0, hm = 0; uint32_t cov = 0;
+							if(lane < nin){
+								const bsa_poa_edge_t ed = t_edges[nfirst - elo + lane];
+								w = (int)ed.src; cov = ed.cov;
+								const int wr = (int)ed.src_rpos;
+								if(!(x < wr || x > bw + wr)){
+									valid = true;
+									const int pp = x - wr;
+									int u0w, hc = 0, ec = 0, qc = 0; uint32_t wbase;
+									if(w >= lo){
+										const uint32_t *rw = t_rows + (w - lo) * bw;
+										const uint32_t cm = rw[pp >= 1 ? pp - 1 : 0], cw = rw[pp < bw ? pp : bw - 1];
+										u0w = t_u0[w - lo]; wbase = (t_nodes[w - lo].flags_word() >> 16) & 0xFFu;
+										hm = (pp >= 1) ? HH(w, pp - 1, cm, u0w) : u0w;
+										hc = HH(w, pp < bw ? pp : bw - 1, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24);
+									} else {
+										u0w = *(const volatile int32_t*)&gu0[w]; wbase = nodes[w].base;
+										hm = (pp >= 1) ? HH(w, pp - 1, *(const volatile uint32_t*)&grows[(size_t)w * bw + pp - 1], u0w) : u0w;
+										if(pp < bw){ const uint32_t cw = *(const volatile uint32_t*)&grows[(size_t)w * bw + pp]; hc = HH(w, pp, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24); }
+									}
+									int ft = 0, sc, scr0, scr1 = BSA_SCORE_MIN, scr2 = BSA_SCORE_MIN;
+									if(pp == bw) ft |= (1 << 2) | (1 << 4);
+									else if(pp == 0){ if(wr == 0 && (mode == BSA_MODE_OVERLAP || w == 0)) ft |= 1 << 15; else ft |= 1; }
+									sc = sbase;
+									if(!(nb & 8u) && (nb & 4u) && wbase != nd.base) sc += 1;
+									if(ft & (1 << 15)) sc -= u0w;
+									scr0 = (ft & 1) ? BSA_SCORE_MIN : sc;
+									if(pp < bw){
+										const int us = hc - hm;
+										scr1 = us + (PW ? ec : E);
+										scr2 = (PW == 2) ? us + qc : -BSA_SCORE_MIN;
+									}
+									m0 = hm + scr0 == Hs1; m1 = hm + scr1 == Hs1; m2 = hm + scr2 == Hs1;
+								}
+							}
+							const unsigned long long bval = __ballot(valid), bany = __ballot(m0 || m1 || m2);
+							if(bval) Hs0 = __builtin_amdgcn_readlane(hm, 63 - __builtin_clzll(bval));      // (what the loop leaves in Hs0: the last edge it looked at)
+							uint32_t C = 0;
+							for(unsigned long long r = bany; r; r &= r - 1) C = max(C, (uint32_t)__builtin_amdgcn_readlane((int)cov, __builtin_ctzll(r)));
+							const bool atc = (m0 || m1 || m2) && cov == C;
+							const unsigned long long b0c = __ballot(atc && m0), bc = __ballot(atc);
+							int win = -1; uint32_t wi = 0xFFFFFFFFu;
+							if(b0c){ win = __builtin_ctzll(b0c); wi = 0u; }
+							else if(bc && C > 0){ win = __builtin_ctzll(bc); wi = (__ballot(m1) >> win) & 1ull ? 1u : 2u; }
+							if(win < 0){
+								const int pp = x - nrpos;
+								if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
+								else {
+									const int u0v = U0(n);
+									const int hmn = (pp == 0) ? u0v : HH(n, pp - 1, CELL(n, pp - 1), u0v);
+									bt = 1u; Hs2 = 1; Hs0 = Hs1 - (HH(n, pp, CELL(n, pp), u0v) - hmn);
+								}
+							} else if(wi == 0u){
+								const int bnode = __builtin_amdgcn_readlane(w, win), bh = __builtin_amdgcn_readlane(hm, win);
+								EMIT(n, x, 0u);
+								x--; n = bnode; nidx = bnode; Hs1 = bh; Hs2 = 0;
+							}
+							else if(wi == 1u){ bt = 2u; Hs2 = 1; }
+							else { bt = 4u; Hs2 = 1; }
+							continue;
+						}
 						for(int k = 0; k < nin; k++){
 							const int ek = nfirst + k;
 							bsa_poa_edge_t ed; if(ek >= elo && ek < elo + ecnt) ed = t_edges[ek - elo]; else ed = gedges[ek];
