@@ -32,6 +32,9 @@
 #define POA_DRAIN  8       // finished rows leave the ring in batches of this many
 #define POA_NEG    (2 * BSA_SCORE_MIN)
 #define POA_NQ     192     // node records staged in LDS ahead of the window
+#define POA_TN     32      // traceback: nodes in the ring (a power of two >= POA_NEAR + 1 + 2 POA_TC)
+#define POA_TC     8       // ... nodes per refill
+#define POA_TE     256     // ... in-edges in the ring (a power of two)
 
 struct PoaArgs {
 	const bsa_poa_node_t *nodes; const bsa_poa_edge_t *edges; const bsa_poa_cand_t *cands; const bsa_poa_prog_t *progs;
@@ -108,7 +111,7 @@ static __device__ __forceinline__ void poa_scan_max2(int &f, int &g){
 #else
 #define POA_PROF_MARK(k_)
 #endif
-#define POA_ROWS_PAD 64       // ring rows are bw' + 64 cells apart (bw' = cells of a wave): a predecessor moved by <= 64 cells is read without clamping
+#define POA_ROWS_PAD 8        // ring rows are (cells of a wave) + 8 cells apart: a lane whose read would pass the end of a row holds synthetic cells only, its base is clamped
 
 template<int PW, int CPL>
 static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const bsa_poa_prog_t &pg, uint8_t *lds, const int lane){
@@ -649,44 +652,76 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		const bsa_poa_edge_t *gedges = a.edges + pg.first_edge;
 		uint32_t *ev = a.steps + pg.first_event;
 		const int ecap = (int)pg.event_cap;
-		uint32_t *t_rows = (uint32_t*)lds;                                  // 64 rows
-		int32_t *t_u0 = (int32_t*)(lds + (size_t)64 * bw * 4);
-		PoaTileNode *t_nodes = (PoaTileNode*)(lds + (size_t)64 * bw * 4 + 256);
-		bsa_poa_edge_t *t_edges = (bsa_poa_edge_t*)(lds + (size_t)64 * bw * 4 + 256 + 64 * sizeof(bsa_poa_node_t));
-		const int TE = 512;
+		// The walk's window of the graph: a RING of the last POA_TN nodes at and below the walker (rows, ubegs[0], records; node i at slot
+		// i mod POA_TN) and of POA_TE in-edges, refilled eight nodes / sixty-four edges at a time.  A refill is requested well before the
+		// walker needs it and kept in registers until it does, so its memory latency passes while the walk goes on.
+		uint32_t *t_rows = (uint32_t*)lds;
+		int32_t *t_u0 = (int32_t*)(lds + (size_t)POA_TN * bw * 4);
+		PoaTileNode *t_nodes = (PoaTileNode*)(lds + (size_t)POA_TN * bw * 4 + 256);
+		bsa_poa_edge_t *t_edges = (bsa_poa_edge_t*)(lds + (size_t)POA_TN * bw * 4 + 256 + POA_TN * sizeof(bsa_poa_node_t));
 		int n = rs.maxidx, nidx = rs.maxidx, x = rs.maxoff, ne = 0, status = BSA_POA_ST_OK;
 		uint32_t bt = 0xFFFFFFFFu;
 		int Hs0 = 0, Hs1 = 0, Hs2 = 0;
 		bool done = false, first = true;
-		while(!done){
-			// tile = nodes [lo, hi], hi = the walker's node
-			const int hi = n, lo = max(0, hi - 63);
-			// eight 16-byte loads in flight per lane before the first is stored: a tile is 32 KB of rows and the loop would otherwise
-			// pay one memory latency per 1 KB
-			auto copy16 = [&](uint4 *dst, const uint4 *src, int n16){
-				for(int b0 = 0; b0 < n16; b0 += 512){
-					uint4 v[8];
+		const int RQ = bw / 4;                              // 16-byte pieces of a row
+		const int NRQ = (POA_TC * RQ + 63) / 64;            // ... of a refill, per lane (<= 8: bandwidth <= 256)
+		int lo = max(0, n - (POA_TN - 1));                  // the ring holds nodes lo .. (the walker never goes up)
+		int elo, ehi;                                       // ... and edges elo .. ehi - 1
+		{
+			__syncthreads();
+			const int cnt = n - lo + 1;
+			for(int i = lane; i < cnt * 3; i += 64){ const int nd_ = lo + i / 3; ((uint4*)&t_nodes[nd_ & (POA_TN - 1)])[i % 3] = ((const uint4*)(nodes + nd_))[i % 3]; }
+			for(int b0 = 0; b0 < cnt * RQ; b0 += 512){
+				uint4 v[8];
 #pragma unroll
-					for(int k = 0; k < 8; k++){ const int i = b0 + k * 64 + lane; if(i < n16) v[k] = src[i]; }
+				for(int k = 0; k < 8; k++){ const int i = b0 + k * 64 + lane; if(i < cnt * RQ) v[k] = ((const uint4*)(grows + (size_t)lo * bw))[i]; }
 #pragma unroll
-					for(int k = 0; k < 8; k++){ const int i = b0 + k * 64 + lane; if(i < n16) dst[i] = v[k]; }
-				}
-			};
+				for(int k = 0; k < 8; k++){ const int i = b0 + k * 64 + lane; if(i < cnt * RQ){ const int nd_ = lo + i / RQ; ((uint4*)(t_rows + (nd_ & (POA_TN - 1)) * bw))[i % RQ] = v[k]; } }
+			}
+			if(lane < cnt) t_u0[(lo + lane) & (POA_TN - 1)] = gu0[lo + lane];
 			__syncthreads();
-			copy16((uint4*)t_nodes, (const uint4*)(nodes + lo), (hi - lo + 1) * (int)(sizeof(bsa_poa_node_t) / 16));
-			copy16((uint4*)t_rows, (const uint4*)(grows + (size_t)lo * bw), (hi - lo + 1) * bw / 4);
-			if(lane <= hi - lo) t_u0[lane] = gu0[lo + lane];
+			const PoaNodeHead hh = t_nodes[n & (POA_TN - 1)].head();
+			ehi = (int)hh.first_in + (int)hh.n_in;
+			elo = max(0, ehi - POA_TE);
+			for(int i = elo + lane; i < ehi; i += 64) ((uint4*)t_edges)[i & (POA_TE - 1)] = ((const uint4*)gedges)[i];
 			__syncthreads();
-			const int elo = (int)t_nodes[0].head().first_in;
-			const int ecnt = min(TE, (int)t_nodes[hi - lo].head().first_in + (int)t_nodes[hi - lo].head().n_in - elo);
-			copy16((uint4*)t_edges, (const uint4*)(gedges + elo), ecnt);
-			__syncthreads();
+		}
+		bool npend = false, epend = false;                   // a refill of nodes / edges is in flight (in the registers below)
+		int plo = 0, pelo = 0;
+		uint4 prow[8], pnode = make_uint4(0, 0, 0, 0), pedge = make_uint4(0, 0, 0, 0); int pu0 = 0;
+#pragma unroll
+		for(int k = 0; k < 8; k++) prow[k] = make_uint4(0, 0, 0, 0);
+		auto node_request = [&](){
+			plo = max(0, lo - POA_TC);
+			const int cnt = lo - plo;
+#pragma unroll
+			for(int k = 0; k < 8; k++){ const int i = k * 64 + lane; if(k < NRQ && i < cnt * RQ) prow[k] = ((const uint4*)(grows + (size_t)plo * bw))[i]; }
+			if(lane < cnt * 3) pnode = ((const uint4*)(nodes + plo))[lane];
+			if(lane < cnt) pu0 = gu0[plo + lane];
+			npend = true;
+		};
+		auto node_commit = [&](){
+			const int cnt = lo - plo;
+#pragma unroll
+			for(int k = 0; k < 8; k++){ const int i = k * 64 + lane; if(k < NRQ && i < cnt * RQ){ const int nd_ = plo + i / RQ; ((uint4*)(t_rows + (nd_ & (POA_TN - 1)) * bw))[i % RQ] = prow[k]; } }
+			if(lane < cnt * 3){ const int nd_ = plo + lane / 3; ((uint4*)&t_nodes[nd_ & (POA_TN - 1)])[lane % 3] = pnode; }
+			if(lane < cnt) t_u0[(plo + lane) & (POA_TN - 1)] = pu0;
+			lo = plo; npend = false;
+		};
+		auto edge_request = [&](){
+			pelo = max(0, elo - 64);
+			if(pelo + lane < elo) pedge = ((const uint4*)gedges)[pelo + lane];
+			epend = true;
+		};
+		auto edge_commit = [&](){
+			if(pelo + lane < elo) ((uint4*)t_edges)[(pelo + lane) & (POA_TE - 1)] = pedge;
+			elo = pelo; ehi = min(ehi, elo + POA_TE); epend = false;
+		};
+		{
 			{
-				// every lane runs the walk with the same state (no lane-0 region, no broadcasts); the lanes part only inside the step that
-				// looks at a node's in-edges, one edge per lane
-				auto in_tile = [&](int i) -> bool { return i >= lo && i <= hi; };
-				auto U0 = [&](int i) -> int { if(in_tile(i)) return t_u0[i - lo]; return *(const volatile int32_t*)&gu0[i]; };
-				auto CELL = [&](int i, int pp) -> uint32_t { if(in_tile(i)) return t_rows[(i - lo) * bw + pp]; return *(const volatile uint32_t*)&grows[(size_t)i * bw + pp]; };
+				auto in_tile = [&](int i) -> bool { return i >= lo; };
+				auto U0 = [&](int i) -> int { if(in_tile(i)) return t_u0[i & (POA_TN - 1)]; return *(const volatile int32_t*)&gu0[i]; };
+				auto CELL = [&](int i, int pp) -> uint32_t { if(in_tile(i)) return t_rows[(i & (POA_TN - 1)) * bw + pp]; return *(const volatile uint32_t*)&grows[(size_t)i * bw + pp]; };
 				auto HH = [&](int i, int pp, uint32_t cw, int u0v) -> int { return (i == 0) ? poa_init_h<PW>(a, pp) : u0v + (int)(int16_t)(cw & 0xFFFFu); };
 #define EMIT(nn_, xx_, bb_) do{ if(ne >= ecap){ status = BSA_POA_ST_EVENTS; done = true; } else { if(lane == 0) ev[ne] = ((uint32_t)(nn_) << 3) | (bb_); ne++; } }while(0)
 				if(first){
@@ -697,16 +732,20 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				}
 				while(!done){
 					if(n == 0 || x < 0){ done = true; break; }
-					if(lo > 0 && n < lo + POA_NEAR + 1) break;          // the walker's predecessors are about to leave the tile: next tile
-					// the walker's node: always inside the tile
-					const PoaNodeHead nd = t_nodes[n - lo].head();
+					// the ring: the walker's predecessors (at most POA_NEAR nodes back; further ones are read from HBM) have to be in it
+					while(lo > 0 && n < lo + POA_NEAR + 1){ if(!npend) node_request(); node_commit(); }
+					if(lo > 0 && !npend && n < lo + POA_NEAR + 1 + POA_TC) node_request();
+					// the walker's node: always inside the ring
+					const PoaNodeHead nd = t_nodes[n & (POA_TN - 1)].head();
 					const int nrpos = (int)nd.rpos, nin = (int)nd.n_in, nfirst = (int)nd.first_in;
+					while(elo > 0 && nfirst < elo){ if(!epend) edge_request(); edge_commit(); }
+					if(elo > 0 && !epend && nfirst < elo + 64) edge_request();
 					if(bt == 2u || bt == 4u){
 						EMIT(n, x, bt);
 						bool found = false;
 						for(int k = 0; k < nin && !found; k++){
 							const int ek = nfirst + k;
-							bsa_poa_edge_t ed; if(ek >= elo && ek < elo + ecnt) ed = t_edges[ek - elo]; else ed = gedges[ek];
+							bsa_poa_edge_t ed; if(ek >= elo && ek < ehi) ed = t_edges[ek & (POA_TE - 1)]; else ed = gedges[ek];
 							const int w = (int)ed.src, wr = (int)ed.src_rpos;
 							if(x < wr || x >= wr + bw) continue;
 							const uint32_t cw = CELL(w, x - wr);
@@ -746,14 +785,14 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
 						const uint32_t nb = (qn[x >> 3] >> ((x & 7) * 4)) & 0xFu;
 						const int sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nd.base) ? a.M + ((nd.flags & 1) ? a.refbonus : 0) : a.X);
-						if(nin <= 64 && nfirst >= elo && nfirst + nin <= elo + ecnt){
+						if(nin <= 64 && nfirst >= elo && nfirst + nin <= ehi){
 							// one in-edge per lane: what the loop below does edge after edge (bspoa.h:2360-2392), then its choice -- the reference
 							// keeps the candidate with the largest coverage, the first one on ties unless a later one is a match / mismatch move
 							// and the kept one is not; coverage 0 is only ever taken as a match / mismatch move
 							bool m0 = false, m1 = false, m2 = false, valid = false;
 							int w = 0, hm = 0; uint32_t cov = 0;
 							if(lane < nin){
-								const bsa_poa_edge_t ed = t_edges[nfirst - elo + lane];
+								const bsa_poa_edge_t ed = t_edges[(nfirst + lane) & (POA_TE - 1)];
 								w = (int)ed.src; cov = ed.cov;
 								const int wr = (int)ed.src_rpos;
 								if(!(x < wr || x > bw + wr)){
@@ -761,9 +800,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 									const int pp = x - wr;
 									int u0w, hc = 0, ec = 0, qc = 0; uint32_t wbase;
 									if(w >= lo){
-										const uint32_t *rw = t_rows + (w - lo) * bw;
+										const uint32_t *rw = t_rows + (w & (POA_TN - 1)) * bw;
 										const uint32_t cm = rw[pp >= 1 ? pp - 1 : 0], cw = rw[pp < bw ? pp : bw - 1];
-										u0w = t_u0[w - lo]; wbase = (t_nodes[w - lo].flags_word() >> 16) & 0xFFu;
+										u0w = t_u0[w & (POA_TN - 1)]; wbase = (t_nodes[w & (POA_TN - 1)].flags_word() >> 16) & 0xFFu;
 										hm = (pp >= 1) ? HH(w, pp - 1, cm, u0w) : u0w;
 										hc = HH(w, pp < bw ? pp : bw - 1, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24);
 									} else {
@@ -814,7 +853,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						}
 						for(int k = 0; k < nin; k++){
 							const int ek = nfirst + k;
-							bsa_poa_edge_t ed; if(ek >= elo && ek < elo + ecnt) ed = t_edges[ek - elo]; else ed = gedges[ek];
+							bsa_poa_edge_t ed; if(ek >= elo && ek < ehi) ed = t_edges[ek & (POA_TE - 1)]; else ed = gedges[ek];
 							const int w = (int)ed.src, wr = (int)ed.src_rpos;
 							const uint32_t cov = ed.cov;
 							if(x < wr || x > bw + wr) continue;
@@ -822,9 +861,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							int u0w, hm, hc = 0, ec = 0, qc = 0; uint32_t wbase;
 							if(w >= lo){
 								// (the common case: everything about the predecessor is in the tile)
-								const uint32_t *rw = t_rows + (w - lo) * bw;
+								const uint32_t *rw = t_rows + (w & (POA_TN - 1)) * bw;
 								const uint32_t cm = rw[pp >= 1 ? pp - 1 : 0], cw = rw[pp < bw ? pp : bw - 1];
-								u0w = t_u0[w - lo]; wbase = (t_nodes[w - lo].flags_word() >> 16) & 0xFFu;
+								u0w = t_u0[w & (POA_TN - 1)]; wbase = (t_nodes[w & (POA_TN - 1)].flags_word() >> 16) & 0xFFu;
 								hm = (pp >= 1) ? HH(w, pp - 1, cm, u0w) : u0w;
 								hc = HH(w, pp < bw ? pp : bw - 1, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24);
 							} else {
@@ -891,13 +930,13 @@ extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *ctx, void *stop_event);
 extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *ctx, int slot, size_t bytes, void **out);
 
 static const size_t POA_LDS_MAX = 160u * 1024u - 1024u;
-static size_t poa_tile_bytes(uint32_t bw){ return (size_t)64 * bw * 4 + 256 + 64 * sizeof(bsa_poa_node_t) + 512 * sizeof(bsa_poa_edge_t); }
+static size_t poa_tile_bytes(uint32_t bw){ return (size_t)POA_TN * bw * 4 + 256 + POA_TN * sizeof(bsa_poa_node_t) + POA_TE * sizeof(bsa_poa_edge_t); }
 static size_t poa_qn_bytes(uint32_t bw, uint32_t max_slen){ return ((((size_t)max_slen + bw + 16) / 8 + 2) * 4 + 15) & ~(size_t)15; }
 static size_t poa_ring_bytes(uint32_t bw, uint32_t nl){ return (size_t)(nl + POA_NEAR + POA_DRAIN) * bw * 4; }
 static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max(poa_ring_bytes(bw, nl) + (size_t)(nl + POA_NEAR + POA_DRAIN) * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
 
 static uint32_t poa_rows_cpl(uint32_t bw){ return bw <= 64 ? 1u : bw <= 128 ? 2u : 4u; }
-static const uint32_t POA_ROWS_R = 32;      // ring rows of the row-at-a-time forward pass (a power of two)
+static const uint32_t POA_ROWS_R = 16;      // ring rows of the row-at-a-time forward pass (a power of two; inputs further back are read from HBM)
 static size_t poa_rows_ring_bytes(uint32_t bw){ return (size_t)POA_ROWS_R * (poa_rows_cpl(bw) * 64 + POA_ROWS_PAD) * 4; }
 static size_t poa_rows_front_bytes(uint32_t bw){ return (std::max(poa_rows_ring_bytes(bw) + POA_ROWS_R * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
 static size_t poa_rows_qb_bytes(uint32_t bw, uint32_t max_slen){ return ((size_t)max_slen + poa_rows_cpl(bw) * 64 + 8 + 15) & ~(size_t)15; }
