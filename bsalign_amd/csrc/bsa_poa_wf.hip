@@ -32,9 +32,10 @@
 #define POA_DRAIN  8       // finished rows leave the ring in batches of this many
 #define POA_NEG    (2 * BSA_SCORE_MIN)
 #define POA_NQ     192     // node records staged in LDS ahead of the window
-#define POA_TN     32      // traceback: nodes in the ring (a power of two >= POA_NEAR + 1 + 2 POA_TC)
-#define POA_TC     8       // ... nodes per refill
-#define POA_TE     256     // ... in-edges in the ring (a power of two)
+#define POA_TN     16      // traceback: nodes in the ring (a power of two >= POA_TNEAR + 1 + 2 POA_TC)
+#define POA_TC     4       // ... nodes per refill
+#define POA_TNEAR  7       // ... predecessors at most this many nodes back are kept in the ring (0.3 % are further: read from HBM)
+#define POA_TE     128     // ... in-edges in the ring (a power of two)
 
 struct PoaArgs {
 	const bsa_poa_node_t *nodes; const bsa_poa_edge_t *edges; const bsa_poa_cand_t *cands; const bsa_poa_prog_t *progs;
@@ -653,7 +654,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		uint32_t *ev = a.steps + pg.first_event;
 		const int ecap = (int)pg.event_cap;
 		// The walk's window of the graph: a RING of the last POA_TN nodes at and below the walker (rows, ubegs[0], records; node i at slot
-		// i mod POA_TN) and of POA_TE in-edges, refilled eight nodes / sixty-four edges at a time.  A refill is requested well before the
+		// i mod POA_TN) and of POA_TE in-edges, refilled four nodes / sixty-four edges at a time.  A refill is requested well before the
 		// walker needs it and kept in registers until it does, so its memory latency passes while the walk goes on.
 		uint32_t *t_rows = (uint32_t*)lds;
 		int32_t *t_u0 = (int32_t*)(lds + (size_t)POA_TN * bw * 4);
@@ -732,9 +733,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				}
 				while(!done){
 					if(n == 0 || x < 0){ done = true; break; }
-					// the ring: the walker's predecessors (at most POA_NEAR nodes back; further ones are read from HBM) have to be in it
-					while(lo > 0 && n < lo + POA_NEAR + 1){ if(!npend) node_request(); node_commit(); }
-					if(lo > 0 && !npend && n < lo + POA_NEAR + 1 + POA_TC) node_request();
+					// the ring: the walker's predecessors (at most POA_TNEAR nodes back; further ones are read from HBM) have to be in it
+					while(lo > 0 && n < lo + POA_TNEAR + 1){ if(!npend) node_request(); node_commit(); }
+					if(lo > 0 && !npend && n < lo + POA_TNEAR + 1 + POA_TC) node_request();
 					// the walker's node: always inside the ring
 					const PoaNodeHead nd = t_nodes[n & (POA_TN - 1)].head();
 					const int nrpos = (int)nd.rpos, nin = (int)nd.n_in, nfirst = (int)nd.first_in;
