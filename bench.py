@@ -418,6 +418,11 @@ def main_poa_recorded(args):
         e2e = {"error": str(ex)}
     nl = len(launches)
     achieved = (balg / nl) / (kms_tot / nl / 1e3) / 1e9 if kms_tot > 0 else 0.0
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("poa-recorded_n%d_L%d_bw128" % (nwin, L), {}).get("bytes_per_launch")
+    except Exception:
+        traffic = None
     line = {
         "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP (align_rd_bspoacore) + traceback (alignment2graph_bspoa) on recorded programs",
         "value": round(cells * args.steps / elapsed / 1e9, 3), "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -426,10 +431,12 @@ def main_poa_recorded(args):
         "config": {"workload": "poa-recorded: %d POA windows x %d reads x %d bp (eps %.2f), default POA parameters (overlap, bandwidth 128, 2-piece gaps); a step = every read's "
                                "sweep and traceback of every window, read r of all windows per launch (%d launches, %d programs, %.0f row updates + %.0f merges, %d traceback steps)"
                                % (nwin, nreads, L, args.eps, nl, nprog_total, updates, merges, steps_total),
-                   "windows": nwin, "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": "k_poa_wf", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
-                     "note": "latency-bound: one wave per read, a row trails its predecessor by movx + 1 cells (DESIGN section 4b)"},
+                   "windows": nwin, "pairs_per_gpu": nwin, "bandwidth": 128, "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "kernel": "k_poa_wf<2, 2> (row-at-a-time forward pass + ring traceback)", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
+                     "traffic_from": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/profile_round3.sh)" if traffic else None,
+                     "note": "latency-bound, not HBM-bound: one wave per read, a graph node per trip (about 335 instructions, 4 clocks each for a lone wave: DESIGN section 4b); "
+                             "throughput grows with the windows in flight (14 KB of LDS per read: 11 reads per CU)"},
         "checks": {"best_end_cell_identical_all_programs": bool(ident), "programs": nprog_total},
         "cpu_baseline": {"value": round(updates * 128 / (t_ref * 0 + core_seconds / ncores) / 1e9, 4) if core_seconds > 0 else None, "unit": "GCUPS", "cores": ncores, "kind": "reference",
                          "sample": "the reference's align_rd_bspoacore inside end_bspoa of the same %d windows on %d host threads (one window per thread at a time): %.2f s summed over threads "
