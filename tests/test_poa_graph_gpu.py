@@ -49,7 +49,12 @@ def _check_program(ctx, p, pg, want_trace=True):
             assert (int(r["fin_node"]), int(r["fin_x"])) == (int(fin[0]), int(fin[1]))
 
 
-def test_golden_programs_rows_best_cell_and_walk(ctx):
+@pytest.mark.parametrize("fwd", ["rows", "wf"])
+def test_golden_programs_rows_best_cell_and_walk(ctx, fwd, monkeypatch):
+    """both forward passes of k_poa_wf -- a row at a time (the default) and the anti-diagonal wavefront (BSA_POA_FWD=wf) -- against the
+    scalar statement, the reference's row hashes, its best end cell and the walk"""
+    if fwd == "wf":
+        monkeypatch.setenv("BSA_POA_FWD", "wf")
     n = 0
     for case in P.load_golden():
         for pg in case["programs"]:
