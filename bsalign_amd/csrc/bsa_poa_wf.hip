@@ -143,8 +143,10 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 			qb[x] = (uint8_t)v;
 		}
 	}
+	const int synk = a.c0 + ((lane < a.d) ? lane * E : (a.d - 1) * E + (lane - a.d + 1) * P);      // synthetic cell `lane` behind a row's end, from the row's last H
 	// the head: row_init, in ring row 0 already (the caller wrote it at the wavefront's stride bw; RS >= bw and row 0 starts at 0); its copy in HBM
 	for(int p = lane; p < bw; p += 64) grows[p] = ring[p];
+	if(lane < POA_ROWS_PAD) ring[bw + lane] = (uint32_t)((poa_init_h<PW>(a, bw - 1) + synk - h0init) & 0xFFFF);
 	if(lane == 0){ gu0[0] = a.head_u0; rbase[0] = h0init; }
 	__syncthreads();
 	for(int i0 = 0; i0 < nn; i0 += 64){
@@ -184,9 +186,11 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 				for(int j = 0; j < CPL; j++) cwv[kk][j] = lrow[bi + j];
 				cmv[kk] = lrow[max(bi - 1, 0)];
 			}
+			bool fars[2] = {false, false};
 #pragma unroll
 			for(int kk = 0; kk < 2; kk++){
 				if((kinds[kk] & BSA_POA_IN_PRESENT) && (i - srcs[kk]) > RM){
+					fars[kk] = true;
 					// the rows stored so far have landed, and nothing stale is in this CU's vector cache
 					__builtin_amdgcn_s_waitcnt(0);
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -247,8 +251,10 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 					ee[j] = sx8(cw >> 16); qq[j] = sx8(cw >> 24);
 					b0[j] = (j == 0) ? sbase + (int)(int16_t)(cmv[kk] & 0xFFFFu) : h1[j - 1];
 				}
-				if(mv > 0){
-					// synthetic cells behind the moved row's end (bsalign.h:2357-2389): c0, then gape1 up to distance d, then gape2
+				if(mv > POA_ROWS_PAD || (fars[kk] && mv > 0)){
+					// synthetic cells behind the moved row's end (bsalign.h:2357-2389): c0, then gape1 up to distance d, then gape2.  (A row in
+					// the ring carries its first POA_ROWS_PAD synthetic cells behind its end, so a move by up to that many cells -- all but
+					// 0.04 % -- reads them like any other cell and only longer moves and rows read back from HBM come here.)
 					const int hlast = sbase + (int)(int16_t)((uint32_t)hls[kk] & 0xFFFFu) + a.c0;
 					auto synth = [&](int kx) -> int { return hlast + ((kx < a.d) ? kx * E : (a.d - 1) * E + (kx - a.d + 1) * P); };
 #pragma unroll
@@ -261,7 +267,7 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 #pragma unroll
 						for(int j = 0; j < CPL; j++){ h1[j] = BSA_SCORE_MIN; b0[j] = BSA_SCORE_MIN; ee[j] = 0; qq[j] = 0; }
 					}
-				} else if(lane == 0) b0[0] = (src == 0) ? a.head_u0 : sbase;       // ubegs[0] of the predecessor
+				} else if(mv == 0 && lane == 0) b0[0] = (src == 0) ? a.head_u0 : sbase;       // ubegs[0] of the predecessor
 #pragma unroll
 				for(int j = 0; j < CPL; j++){
 					const int S = Sb[j] + (same ? 0 : hpc[j]);
@@ -318,13 +324,18 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 				uint32_t *lrow = ring + (i & RM) * RS + p0;
 				uint32_t *grow = grows + (size_t)i * bw + p0;
 				if(CPL * 64 == bw){
-					if(CPL == 2){ *(uint2*)lrow = make_uint2(cwo[0], cwo[1]); *(uint2*)grow = make_uint2(cwo[0], cwo[1]); }
-					else if(CPL == 4){ *(uint4*)lrow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); *(uint4*)grow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); }
+					if constexpr(CPL == 2){ *(uint2*)lrow = make_uint2(cwo[0], cwo[1]); *(uint2*)grow = make_uint2(cwo[0], cwo[1]); }
+					else if constexpr(CPL == 4){ *(uint4*)lrow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); *(uint4*)grow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); }
 					else { lrow[0] = cwo[0]; grow[0] = cwo[0]; }
 				} else {
 #pragma unroll
 					for(int j = 0; j < CPL; j++) if(live[j]){ lrow[j] = cwo[j]; grow[j] = cwo[j]; }
 				}
+			}
+			{
+				// the row's first synthetic cells (e = q = 0) behind its end, ring only
+				const int hl = __builtin_amdgcn_readlane(H[(bw - 1) % CPL], (bw - 1) / CPL);
+				if(lane < POA_ROWS_PAD) ring[(i & RM) * RS + bw + lane] = (uint32_t)((hl + synk - hb) & 0xFFFF);
 			}
 			if(lane == 0){ rbase[i & RM] = hb; gu0[i] = hb; }
 			POA_PROF_MARK(4)
