@@ -117,9 +117,8 @@ static __device__ __forceinline__ void poa_scan_max2(int &f, int &g){
 template<int PW, int CPL>
 static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const bsa_poa_prog_t &pg, uint8_t *lds, const int lane){
 	uint32_t *ring = (uint32_t*)lds;                    // R rows, RS cells apart, of bw cells {int16 H - base, e, q}
-	int32_t *rbase = (int32_t*)(lds + a.ri_off);        // H of the first cell of every ring row
 	uint8_t *qb = lds + a.nq_off;                       // the read as a profile: bit b = "base b matches", bit 4 = differs from the next base, bit 5 = beyond the end
-	const int bw = (int)a.bw, W = (int)a.W, RS = CPL * 64 + POA_ROWS_PAD, RM = (int)a.R - 1;
+	const int bw = (int)a.bw, W = (int)a.W, RS = CPL * 64 + 2 * POA_ROWS_PAD, RM = (int)a.R - 1, BC = bw + POA_ROWS_PAD;      // BC: the cell of a ring row that holds its base
 	const int nn = (int)pg.nnodes, slen = (int)pg.slen;
 	const bsa_poa_node_t *nodes = a.nodes + pg.first_node;
 	uint32_t *grows = a.rows + (size_t)pg.first_node * bw;
@@ -147,7 +146,7 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 	// the head: row_init, in ring row 0 already (the caller wrote it at the wavefront's stride bw; RS >= bw and row 0 starts at 0); its copy in HBM
 	for(int p = lane; p < bw; p += 64) grows[p] = ring[p];
 	if(lane < POA_ROWS_PAD) ring[bw + lane] = (uint32_t)((poa_init_h<PW>(a, bw - 1) + synk - h0init) & 0xFFFF);
-	if(lane == 0){ gu0[0] = a.head_u0; rbase[0] = h0init; }
+	if(lane == 0){ gu0[0] = a.head_u0; ring[BC] = (uint32_t)h0init; }
 	__syncthreads();
 	for(int i0 = 0; i0 < nn; i0 += 64){
 		// 64 node records, one per lane; the fields of node i0 + k come out with v_readlane
@@ -156,7 +155,21 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 		// the records are waited for HERE: a wait inside the node loop would count the rows stored since (vmcnt is one in-order counter
 		// for loads and stores) and make every node wait for the previous node's stores to be acknowledged
 		__builtin_amdgcn_s_waitcnt(0x0F70);
-		asm volatile("" : "+v"(r0.x), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w), "+v"(r2.x), "+v"(r2.y));
+		// what a node's scalar code would work out of its record, worked out here by the lane that holds the record (1 / 64 of the cost):
+		// per input the byte offset of the predecessor's ring row | "predecessor is the head" << 15 | move << 16, the kind word with bit 28 =
+		// "further back than the ring", and the diagonal score left of band cell 0 when the band did not move (bspoa.h:2242-2249)
+		uint32_t dA[2], dK[2]; int dR[2];
+#pragma unroll
+		for(int kk = 0; kk < 2; kk++){
+			const uint32_t kind = (kk == 0) ? r1.z : r2.y, src = (kk == 0) ? r1.x : r1.w, mv = (kk == 0) ? r1.y : r2.x;
+			const bool present = (kind & BSA_POA_IN_PRESENT) != 0u, merge = (kind & BSA_POA_IN_MERGE) != 0u;
+			const uint32_t srcE = present ? src : 0u, mvE = (present && !merge) ? min(mv, 0xFFFFu) : 0u;
+			dA[kk] = ((srcE & (uint32_t)RM) * (uint32_t)RS * 4u) | ((present && src == 0u) ? 0x8000u : 0u) | (mvE << 16);
+			dK[kk] = (kind & ~0x10000000u) | ((present && (i0 + lane) - (int)src > RM) ? 0x10000000u : 0u);
+			const int toff = (int)(kind & 0x0FFFFFFFu);
+			dR[kk] = r0.x ? BSA_SCORE_MIN : (mode == BSA_MODE_OVERLAP || toff == 0) ? 0 : (PW < 2) ? O + E * toff : max(O + E * toff, Q + P * toff);
+		}
+		asm volatile("" : "+v"(r0.x), "+v"(r0.w), "+v"(dA[0]), "+v"(dA[1]), "+v"(dK[0]), "+v"(dK[1]), "+v"(dR[0]), "+v"(dR[1]), "+v"(r1.x), "+v"(r1.w));
 		const int kend = min(64, nn - i0);
 		for(int k = (i0 == 0) ? 1 : 0; k < kend; k++){
 			const int i = i0 + k;
@@ -167,36 +180,31 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 			const int Mv = a.M + (((w3 >> 24) & 1u) ? a.refbonus : 0);
 			// phase 1: everything the node reads from LDS, requested at once (one round trip per node); an input further back than the
 			// ring (rare) is read from HBM into the same registers afterwards
-			int srcs[2], mvs[2], sbs[2], hls[2]; uint32_t kinds[2], cwv[2][CPL], cmv[2];
+			int mvs[2], sbs[2]; uint32_t kinds[2], dAs[2], cwv[2][CPL], cmv[2];
 			uint32_t qv[CPL];
 #pragma unroll
 			for(int j = 0; j < CPL; j++) qv[j] = qb[rpos + p0 + j];
 #pragma unroll
 			for(int kk = 0; kk < 2; kk++){
-				kinds[kk] = (uint32_t)__builtin_amdgcn_readlane((int)(kk == 0 ? r1.z : r2.y), k);
-				srcs[kk] = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.x : r1.w), k);
-				mvs[kk] = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.y : r2.x), k);
-				if(!(kinds[kk] & BSA_POA_IN_PRESENT)){ srcs[kk] = 0; mvs[kk] = 0; }
-				if(kinds[kk] & BSA_POA_IN_MERGE) mvs[kk] = 0;
-				const uint32_t *lrow = ring + (srcs[kk] & RM) * RS;
-				sbs[kk] = rbase[srcs[kk] & RM];
-				hls[kk] = (int)lrow[bw - 1];
+				kinds[kk] = (uint32_t)__builtin_amdgcn_readlane((int)dK[kk], k);
+				dAs[kk] = (uint32_t)__builtin_amdgcn_readlane((int)dA[kk], k);
+				mvs[kk] = (int)(dAs[kk] >> 16);
+				const uint32_t *lrow = (const uint32_t*)((const uint8_t*)ring + (dAs[kk] & 0x7FFFu));
+				sbs[kk] = (int)lrow[BC];
 				const int bi = min(p0 + mvs[kk], RS - CPL);          // (a lane whose base is clamped holds synthetic cells only)
 #pragma unroll
 				for(int j = 0; j < CPL; j++) cwv[kk][j] = lrow[bi + j];
 				cmv[kk] = lrow[max(bi - 1, 0)];
 			}
-			bool fars[2] = {false, false};
 #pragma unroll
 			for(int kk = 0; kk < 2; kk++){
-				if((kinds[kk] & BSA_POA_IN_PRESENT) && (i - srcs[kk]) > RM){
-					fars[kk] = true;
-					// the rows stored so far have landed, and nothing stale is in this CU's vector cache
+				if(kinds[kk] & 0x10000000u){
+					// further back than the ring: the rows stored so far have landed, and nothing stale is in this CU's vector cache
+					const int src = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.x : r1.w), k);
 					__builtin_amdgcn_s_waitcnt(0);
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-					const uint32_t *grow = grows + (size_t)srcs[kk] * bw;
-					sbs[kk] = (srcs[kk] == 0) ? h0init : gu0[srcs[kk]];
-					hls[kk] = (int)grow[bw - 1];
+					const uint32_t *grow = grows + (size_t)src * bw;
+					sbs[kk] = (src == 0) ? h0init : gu0[src];
 #pragma unroll
 					for(int j = 0; j < CPL; j++) cwv[kk][j] = grow[min(p0 + j + mvs[kk], bw - 1)];
 					cmv[kk] = grow[min(max(p0 + mvs[kk] - 1, 0), bw - 1)];
@@ -224,7 +232,8 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 			for(int kk = 0; kk < 2; kk++){
 				const uint32_t kind = kinds[kk];
 				if(!(kind & BSA_POA_IN_PRESENT)) continue;
-				const int src = srcs[kk], mv = mvs[kk], sbase = sbs[kk];
+				const int mv = mvs[kk], sbase = sbs[kk];
+				const bool far = (kind & 0x10000000u) != 0u, src0 = (dAs[kk] & 0x8000u) != 0u;
 				if(kind & BSA_POA_IN_MERGE){
 					has_merge = true;
 #pragma unroll
@@ -235,14 +244,8 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 					}
 					continue;
 				}
-				const int toff = (int)(kind & BSA_POA_IN_TOFF);
 				const bool same = (kind & BSA_POA_IN_SAME) != 0u;
 				const bool dead = mv >= bw;
-				int rh0;                                    // the diagonal score left of band cell 0 when the band did not move (bspoa.h:2242-2249)
-				if(rpos) rh0 = BSA_SCORE_MIN;
-				else if(mode == BSA_MODE_OVERLAP || toff == 0) rh0 = 0;
-				else if(PW < 2) rh0 = O + E * toff;
-				else rh0 = max(O + E * toff, Q + P * toff);
 				int h1[CPL], b0[CPL], ee[CPL], qq[CPL];
 #pragma unroll
 				for(int j = 0; j < CPL; j++){
@@ -251,11 +254,14 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 					ee[j] = sx8(cw >> 16); qq[j] = sx8(cw >> 24);
 					b0[j] = (j == 0) ? sbase + (int)(int16_t)(cmv[kk] & 0xFFFFu) : h1[j - 1];
 				}
-				if(mv > POA_ROWS_PAD || (fars[kk] && mv > 0)){
+				if(mv > POA_ROWS_PAD || (far && mv > 0)){
 					// synthetic cells behind the moved row's end (bsalign.h:2357-2389): c0, then gape1 up to distance d, then gape2.  (A row in
 					// the ring carries its first POA_ROWS_PAD synthetic cells behind its end, so a move by up to that many cells -- all but
 					// 0.04 % -- reads them like any other cell and only longer moves and rows read back from HBM come here.)
-					const int hlast = sbase + (int)(int16_t)((uint32_t)hls[kk] & 0xFFFFu) + a.c0;
+					uint32_t hl_;
+					if(far){ const int src = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.x : r1.w), k); hl_ = grows[(size_t)src * bw + bw - 1]; __builtin_amdgcn_s_waitcnt(0x0F70); }
+					else hl_ = *(const uint32_t*)((const uint8_t*)ring + (dAs[kk] & 0x7FFFu) + (bw - 1) * 4);
+					const int hlast = sbase + (int)(int16_t)(hl_ & 0xFFFFu) + a.c0;
 					auto synth = [&](int kx) -> int { return hlast + ((kx < a.d) ? kx * E : (a.d - 1) * E + (kx - a.d + 1) * P); };
 #pragma unroll
 					for(int j = 0; j < CPL; j++){
@@ -267,14 +273,14 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 #pragma unroll
 						for(int j = 0; j < CPL; j++){ h1[j] = BSA_SCORE_MIN; b0[j] = BSA_SCORE_MIN; ee[j] = 0; qq[j] = 0; }
 					}
-				} else if(mv == 0 && lane == 0) b0[0] = (src == 0) ? a.head_u0 : sbase;       // ubegs[0] of the predecessor
+				} else if(mv == 0 && lane == 0) b0[0] = src0 ? a.head_u0 : sbase;       // ubegs[0] of the predecessor
 #pragma unroll
 				for(int j = 0; j < CPL; j++){
 					const int S = Sb[j] + (same ? 0 : hpc[j]);
 					int mc = b0[j] + S;
 					if(j == 0){
 						// band cell 0: the seed rule (bsalign.h:2899-2907), rh as dpalign_row_update_bspoa picks it (bspoa.h:2242-2254)
-						const int rh = (mv == 0) ? rh0 : b0[0];
+						const int rh = (mv == 0) ? __builtin_amdgcn_readlane(dR[kk], k) : b0[0];
 						int h0 = rh - b0[0] + S;
 						const int tt = (h1[0] - b0[0]) + (PW == 0 ? E : PW == 1 ? ee[0] : max(ee[0], qq[0]));
 						h0 = (h0 >= tt) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;
@@ -337,7 +343,7 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 				const int hl = __builtin_amdgcn_readlane(H[(bw - 1) % CPL], (bw - 1) / CPL);
 				if(lane < POA_ROWS_PAD) ring[(i & RM) * RS + bw + lane] = (uint32_t)((hl + synk - hb) & 0xFFFF);
 			}
-			if(lane == 0){ rbase[i & RM] = hb; gu0[i] = hb; }
+			if(lane == 0){ ring[(i & RM) * RS + BC] = (uint32_t)hb; gu0[i] = hb; }
 			POA_PROF_MARK(4)
 		}
 	}
@@ -949,7 +955,7 @@ static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max(poa_ri
 
 static uint32_t poa_rows_cpl(uint32_t bw){ return bw <= 64 ? 1u : bw <= 128 ? 2u : 4u; }
 static const uint32_t POA_ROWS_R = 16;      // ring rows of the row-at-a-time forward pass (a power of two; inputs further back are read from HBM)
-static size_t poa_rows_ring_bytes(uint32_t bw){ return (size_t)POA_ROWS_R * (poa_rows_cpl(bw) * 64 + POA_ROWS_PAD) * 4; }
+static size_t poa_rows_ring_bytes(uint32_t bw){ return (size_t)POA_ROWS_R * (poa_rows_cpl(bw) * 64 + 2 * POA_ROWS_PAD) * 4; }
 static size_t poa_rows_front_bytes(uint32_t bw){ return (std::max(poa_rows_ring_bytes(bw) + POA_ROWS_R * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
 static size_t poa_rows_qb_bytes(uint32_t bw, uint32_t max_slen){ return ((size_t)max_slen + poa_rows_cpl(bw) * 64 + 8 + 15) & ~(size_t)15; }
 // the row-at-a-time forward pass (poa_forward_rows): its scans need gapo <= 0 and gapo1 + gape1 <= gape1 <= gape2 <= 0 (the guard of
