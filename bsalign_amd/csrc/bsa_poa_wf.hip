@@ -322,9 +322,11 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 #pragma unroll
 			for(int j = 0; j < CPL; j++){
 				int e1 = 0, q1 = 0;
-				if(PW >= 1){ e1 = max(Ein[j] + E, H[j] + OE); if(has_merge) e1 = max(e1, EX[j]); e1 -= H[j]; }
-				if(PW == 2){ q1 = max(Qin[j] + P, H[j] + QP); if(has_merge) q1 = max(q1, QX[j]); q1 -= H[j]; }
-				cwo[j] = (uint32_t)((H[j] - hb) & 0xFFFF) | (((uint32_t)e1 & 0xFFu) << 16) | ((uint32_t)q1 << 24);
+				// e = max(E-path of the inputs + gape1, H + gapo1 + gape1, merged rows' E) - H, taken relative to H from the start
+				if(PW >= 1){ e1 = max(Ein[j] - H[j] + E, OE); if(has_merge) e1 = max(e1, EX[j] - H[j]); }
+				if(PW == 2){ q1 = max(Qin[j] - H[j] + P, QP); if(has_merge) q1 = max(q1, QX[j] - H[j]); }
+				// {int16 H - base, e, q}: the two low bytes of e and q side by side with one v_perm, then under the 16 bits of H
+				cwo[j] = (((uint32_t)(H[j] - hb)) & 0xFFFFu) | __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)e1, 0x04000c0cu);
 			}
 			{
 				uint32_t *lrow = ring + (i & RM) * RS + p0;
