@@ -750,17 +750,26 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
 					else Hs1 = HH(n, pp, CELL(n, pp), U0(n));
 				}
+#ifdef POA_PROF
+				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0;
+#define POA_TRK(k_) { __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq[k_] += t_ - tq_t; tq_t = t_; }
+#else
+#define POA_TRK(k_)
+#endif
 				while(!done){
+					POA_TRK(0)
 					if(n == 0 || x < 0){ done = true; break; }
 					// the ring: the walker's predecessors (at most POA_TNEAR nodes back; further ones are read from HBM) have to be in it
-					while(lo > 0 && n < lo + POA_TNEAR + 1){ if(!npend) node_request(); node_commit(); }
+					while(__builtin_expect(lo > 0 && n < lo + POA_TNEAR + 1, 0)){ if(!npend) node_request(); node_commit(); }
 					if(lo > 0 && !npend && n < lo + POA_TNEAR + 1 + POA_TC) node_request();
+					POA_TRK(1)
 					// the walker's node: always inside the ring
 					const PoaNodeHead nd = t_nodes[n & (POA_TN - 1)].head();
 					const int nrpos = (int)nd.rpos, nin = (int)nd.n_in, nfirst = (int)nd.first_in;
-					while(elo > 0 && nfirst < elo){ if(!epend) edge_request(); edge_commit(); }
+					while(__builtin_expect(elo > 0 && nfirst < elo, 0)){ if(!epend) edge_request(); edge_commit(); }
 					if(elo > 0 && !epend && nfirst < elo + 64) edge_request();
-					if(bt == 2u || bt == 4u){
+					POA_TRK(2)
+					if(__builtin_expect(bt == 2u || bt == 4u, 0)){
 						EMIT(n, x, bt);
 						bool found = false;
 						for(int k = 0; k < nin && !found; k++){
@@ -780,7 +789,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							found = true;
 						}
 						if(!found){ status = BSA_POA_ST_TRACE; done = true; }
-					} else if(bt == 1u){
+					} else if(__builtin_expect(bt == 1u, 0)){
 						EMIT(n, x, bt);
 						const int t = (PW == 2) ? max(a.O + E * Hs2, a.Q + P * Hs2) : a.O + E * Hs2;
 						x--;
@@ -796,7 +805,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 								Hs2++;
 							}
 						}
-					} else if(bt == 0u){
+					} else if(__builtin_expect(bt == 0u, 0)){
 						EMIT(n, x, bt);
 						x--;
 						n = nidx;
@@ -805,7 +814,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
 						const uint32_t nb = (qn[x >> 3] >> ((x & 7) * 4)) & 0xFu;
 						const int sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nd.base) ? a.M + ((nd.flags & 1) ? a.refbonus : 0) : a.X);
-						if(nin <= 64 && nfirst >= elo && nfirst + nin <= ehi){
+						if(__builtin_expect(nin <= 64 && nfirst >= elo && nfirst + nin <= ehi, 1)){
 							// one in-edge per lane: what the loop below does edge after edge (bspoa.h:2360-2392), then its choice -- the reference
 							// keeps the candidate with the largest coverage, the first one on ties unless a later one is a match / mismatch move
 							// and the kept one is not; coverage 0 is only ever taken as a match / mismatch move
@@ -845,6 +854,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 									m0 = hm + scr0 == Hs1; m1 = hm + scr1 == Hs1; m2 = hm + scr2 == Hs1;
 								}
 							}
+							POA_TRK(3)
 							const unsigned long long bval = __ballot(valid), bany = __ballot(m0 || m1 || m2);
 							if(bval) Hs0 = __builtin_amdgcn_readlane(hm, 63 - __builtin_clzll(bval));      // (what the loop leaves in Hs0: the last edge it looked at)
 							uint32_t C = 0;
@@ -869,6 +879,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							}
 							else if(wi == 1u){ bt = 2u; Hs2 = 1; }
 							else { bt = 4u; Hs2 = 1; }
+							POA_TRK(4)
+#ifdef POA_PROF
+							tq_n++;
+#endif
 							continue;
 						}
 						for(int k = 0; k < nin; k++){
@@ -925,6 +939,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						else { bt = 4u; Hs2 = 1; }
 					}
 				}
+#ifdef POA_PROF
+				if(lane == 0 && blockIdx.x == 0) printf("poa walk profile: %d cooperative steps; clocks per step: loop top %.0f, node ring %.0f, record + edge ring %.0f, edges evaluated %.0f, choice + move %.0f\n", tq_n,
+					(double)tq[0] / max(tq_n, 1), (double)tq[1] / max(tq_n, 1), (double)tq[2] / max(tq_n, 1), (double)tq[3] / max(tq_n, 1), (double)tq[4] / max(tq_n, 1));
+#endif
 #undef EMIT
 			}
 			n = __shfl(n, 0); done = __shfl((int)done, 0) != 0;
