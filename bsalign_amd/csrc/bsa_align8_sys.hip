@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 		if(rs.qb < 0 || rs.tb < 0) break;
 		const int lq = rs.tb & 63, tq = rs.qb + lq;
 		const uint4 cw = *word(rs.tb, tq >> 5);
+		const uint8_t qc = qseq[rs.qb], tc = tseq[rs.tb];     // (requested with the code word: one memory latency per step, not two)
 		const uint32_t sh = 31u - ((uint32_t)tq & 31u);
 		const bool fM = (cw.x >> sh) & 1u, fD = (cw.y >> sh) & 1u;
 		int bt;                                               // backcal_cell (bsalign.h:3679-3699): the order of the tests depends on prior_match
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 		else bt = fD ? 2 : fM ? 0 : 1;
 		prior_match = 1;
 		if(bt == 0){
-			if(qseq[rs.qb] == tseq[rs.tb]) rs.mat++; else rs.mis++;
+			if(qc == tc) rs.mat++; else rs.mis++;
 			rs.qb--; rs.tb--; rs.aln++;
 			cg = cig_add(cg, 0, 1);
 		} else if(bt == 1){

@@ -531,6 +531,9 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 	if(n > first) close((uint32_t)n);
 	p->half_bytes = (maxacc + 255) & ~(size_t)255;
 	if(p->chunks.size() < 2) p->two_halves = false;
+	// every chunk in a region of its own: the regions are all as large as the largest chunk, which with mixed lengths (chunks are cut by
+	// pair count over pairs sorted by length) can be several times the total -- then the chunks share one region, back to back
+	if(all_resident && p->half_bytes * p->chunks.size() > budget){ all_resident = false; p->two_halves = (2 * p->half_bytes <= budget); }
 	p->nbuf = !p->two_halves ? 1u : all_resident ? (uint32_t)p->chunks.size() : 2u;
 	return BSA_OK;
 }
