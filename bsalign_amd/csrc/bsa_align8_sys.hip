@@ -29,14 +29,15 @@ static __device__ __forceinline__ int sys_shr1(int fill, int x){                
 	return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false);         // DPP wave_shr:1, bound_ctrl off: lane 0 keeps `fill`
 }
 
-struct SysHdr { int32_t score, reserved[3]; };
+struct SysHdr { int32_t score, qe, te, reserved; };      // the alignment's end cell (global: the last cell)
 
 // slot: header, the boundary row (qlen + 256 entries of {H * 32 | query code << 3, E * 32}), the code tiles, the CIGAR tail.
 // Code tiles: block b of 64 rows, word w = t >> 5 of the wavefront step t = x + (y & 63): 64 lanes x 16 bytes {M, D, R, Od}, step t at
 // bit 31 - (t & 31) -- every 32 steps the wave stores ONE contiguous kilobyte.
 static __host__ __device__ inline uint32_t bsa_sys_words(uint32_t qlen){ return (qlen + 63u + 31u) / 32u; }
 static __host__ __device__ inline size_t bsa_sys_bnd_off(){ return sizeof(SysHdr); }
-static __host__ __device__ inline size_t bsa_sys_codes_off(uint32_t qlen){ return (bsa_sys_bnd_off() + ((size_t)qlen + 256) * 8 + 1023) & ~(size_t)1023; }
+static __host__ __device__ inline size_t bsa_sys_lasth_off(uint32_t qlen){ return bsa_sys_bnd_off() + ((size_t)qlen + 256) * 8; }      // H of the last target row (overlap / extend: row_max)
+static __host__ __device__ inline size_t bsa_sys_codes_off(uint32_t qlen){ return (bsa_sys_lasth_off(qlen) + ((size_t)qlen + 64) * 4 + 1023) & ~(size_t)1023; }
 static __host__ __device__ inline size_t bsa_sys_codes_bytes(uint32_t qlen, uint32_t tlen){ return (size_t)((tlen + 63u) / 64u) * bsa_sys_words(qlen) * 1024u; }
 
 size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen){
@@ -44,7 +45,7 @@ size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen){
 }
 
 bool bsa_align8_sys_supported(const Align8Args &a, int pw){
-	if(pw > 1 || (a.mode & 3) != BSA_MODE_GLOBAL) return false;
+	if(pw > 1) return false;
 	const int g = -((int)(int8_t)(a.gapo1 + a.gape1)), m = a.smax, n = -a.smin;
 	if(m < 0 || n < 0 || g < 0 || (int8_t)a.gape1 > 0 || (int8_t)a.gapo1 > 0 || ((int8_t)a.gapo1 == 0) != (pw == 0)) return false;
 	return m + 3 * g <= 64 && n + m + g <= 100;
@@ -72,11 +73,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 	const int NW = (int)bsa_sys_words((uint32_t)qlen);
 	const uint8_t *qp = a.qst + a.qpoff[pair], *tp = a.tst + a.tpoff[pair];
 	const int GO = a.gapo1, GE = a.gape1, GOE = GO + GE, GE5 = GE * 32, GOE5 = GOE * 32;
-	const int first_u = (int)(int8_t)(GOE + a.smin - a.smax), B0 = a.smax - a.smin;
+	const int type = a.mode & 3;
+	const bool ovl = type == BSA_MODE_OVERLAP, ends = type != BSA_MODE_GLOBAL;       // overlap: row -1 is all zero and H left of column 0 is 0 (row_init bsalign.h:2094-2140, :3932-3946); ends: the end cell is searched for
+	const int first_u = ovl ? 0 : (int)(int8_t)(GOE + a.smin - a.smax), B0 = ovl ? 0 : a.smax - a.smin;
+	int32_t *lastH = (int32_t*)(slot + bsa_sys_lasth_off((uint32_t)qlen));
+	long long bestc = (long long)0x8000000000000000ull;                              // best cell of the last query column: (score, first row) as one key
 	const int nblk = (tlen + 63) / 64, nsteps = qlen + 63, cmax = qlen + 192;
 	// row -1 (row_init): H = gapo + gape (x + 1), e = -63, with the query codes
 	for(int c = lane; c < cmax; c += 64){
-		const int h = GOE + GE * c, q = (c < qlen) ? ((int)qp[c] & 3) : 0;
+		const int h = ovl ? 0 : GOE + GE * c, q = (c < qlen) ? ((int)qp[c] & 3) : 0;
 		bnd[c] = make_int2(h * 32 + q * 8, (h + BSA_EPI8_MIN) * 32);
 	}
 	for(int blk = 0; blk < nblk; blk++){
@@ -84,7 +89,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 		const int y = blk * 64 + lane;
 		const int tb = (y < tlen) ? (int)tp[y] & 3 : 0;
 		const int mr = (int)((tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3]);     // matrix[q * 4 + tb], q = 0..3, one byte each
-		const int rh = (y == 0) ? 0 : GO + GE * y;               // H left of column 0 (bsalign.h:3932-3946)
+		const int rh = (y == 0 || ovl) ? 0 : GO + GE * y;        // H left of column 0 (bsalign.h:3932-3946)
+		const bool lastrow = ends && y == tlen - 1;
 		int P = 0, E = 0, Hd = 0, F = 0;
 		uint32_t pM = 0, pD = 0, pR = 0, pO = 0;                 // NOT-facts, newest step in bit 0
 		uint4 *cp = (uint4*)codes + ((size_t)blk * NW * 64 + lane);
@@ -110,8 +116,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 			*cp = (PW == 0) ? make_uint4(~(pM << sh), ~(pD << sh), 0xffffffffu, 0xffffffffu) : make_uint4(~(pM << sh), ~(pD << sh), ~(pR << sh), ~(pO << sh));
 			cp += 64;
 		};
-		auto step = [&](auto gen, const int t, const int2 b, int2 *ob){         // b: the ring entry of the step (all lanes read the same one; lane 0 uses it)
-			constexpr bool GEN = decltype(gen)::value;
+		auto step = [&](auto gen, auto last, const int t, const int2 b, int2 *ob){         // b: the ring entry of the step (all lanes read the same one; lane 0 uses it)
+			constexpr bool GEN = decltype(gen)::value, LAST = decltype(last)::value;     // LAST: the block holds the last target row and its H is wanted
 			const int Pi = sys_shr1(b.x, P);
 			const int Eu = (PW == 0) ? 0 : sys_shr1(b.y, E);
 			const int Hu = Pi & ~31;
@@ -155,43 +161,85 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 			if constexpr(GEN){
 				const int x = t - lane;
 				if(lane == 63 && x >= 0 && x < qlen) *ob = make_int2(P, E);
-				if(x == qlen - 1 && y == tlen - 1) hdr->score = H >> 5;
+				if(x == qlen - 1 && y < tlen){
+					if(!ends){ if(y == tlen - 1){ hdr->score = H >> 5; hdr->qe = qlen - 1; hdr->te = tlen - 1; } }
+					else {
+						// the last query column, row after row: strictly greater replaces (bsalign.h:4023-4032)
+						const long long key = ((long long)(H >> 5) << 32) | (long long)(0x7FFFFFFFu - (uint32_t)y);
+						if(key > bestc) bestc = key;
+					}
+				}
+				if(LAST && lastrow && x >= 0 && x < qlen) lastH[x] = H >> 5;
 			} else {
 				if(lane == 63) *ob = make_int2(P, E);
+				if(LAST && lastrow) lastH[t - lane] = H >> 5;
 			}
 		};
-		int t = 0;
-		for(const int te = min(64, nsteps); t < te; t++){
-			if((t & 63) == 0) top(t);
-			step(std::true_type(), t, inr[t & 127], &outr[t & 127]);
-			if((t & 31) == 31 || t == nsteps - 1) flush(t);
-		}
-		// steady state: 0 < x < qlen - 1 on every lane
-		for(; t + 32 <= qlen - 1; t += 32){
-			if((t & 63) == 0) top(t);
-			int ro = t & 127;                                        // ring offset of the step, kept in a VGPR (a uniform address would be
-			asm volatile("" : "+v"(ro));                             // moved from an SGPR in front of every LDS instruction)
-			const int2 *ib = inr + ro; int2 *ob = outr + ro;
-			int2 b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
-#pragma unroll 1
-			for(int kk = 0; kk < 4; kk++, ib += 8, ob += 8){
-#pragma unroll
-				for(int k = 0; k < 8; k++){
-					const int2 b = b0;
-					b0 = b1;
-					b1 = ib[k + 2];
-					step(std::false_type(), t + kk * 8 + k, b, ob + k);
-				}
+		auto sweep = [&](auto last){
+			int t = 0;
+			for(const int te = min(64, nsteps); t < te; t++){
+				if((t & 63) == 0) top(t);
+				step(std::true_type(), last, t, inr[t & 127], &outr[t & 127]);
+				if((t & 31) == 31 || t == nsteps - 1) flush(t);
 			}
-			flush(t + 31);
-		}
-		for(; t < nsteps; t++){
-			if((t & 63) == 0) top(t);
-			step(std::true_type(), t, inr[t & 127], &outr[t & 127]);
-			if((t & 31) == 31 || t == nsteps - 1) flush(t);
-		}
+			// steady state: 0 < x < qlen - 1 on every lane
+			for(; t + 32 <= qlen - 1; t += 32){
+				if((t & 63) == 0) top(t);
+				int ro = t & 127;                                        // ring offset of the step, kept in a VGPR (a uniform address would be
+				asm volatile("" : "+v"(ro));                             // moved from an SGPR in front of every LDS instruction)
+				const int2 *ib = inr + ro; int2 *ob = outr + ro;
+				int2 b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
+#pragma unroll 1
+				for(int kk = 0; kk < 4; kk++, ib += 8, ob += 8){
+#pragma unroll
+					for(int k = 0; k < 8; k++){
+						const int2 b = b0;
+						b0 = b1;
+						b1 = ib[k + 2];
+						step(std::false_type(), last, t + kk * 8 + k, b, ob + k);
+					}
+				}
+				flush(t + 31);
+			}
+			for(; t < nsteps; t++){
+				if((t & 63) == 0) top(t);
+				step(std::true_type(), last, t, inr[t & 127], &outr[t & 127]);
+				if((t & 31) == 31 || t == nsteps - 1) flush(t);
+			}
+		};
+		if(ends && blk + 1 == nblk) sweep(std::true_type()); else sweep(std::false_type());
 		if(blk + 1 < nblk)
 			for(int c0 = drained; c0 < qlen; c0 += 64){ const int c = c0 + lane; if(c < qlen) bnd[c] = outr[(c + 63) & 127]; }
+	}
+	if(ends){
+		// overlap / extend: the best cell of the last query column (first row on ties), replaced by row_max of the last target row if that
+		// is strictly greater (bsalign.h:4034-4048).  row_max (bsalign.h:3213-3329) in the reference's own striping: the best cell of every
+		// running block of W = band / 16 cells, the first one on ties, blocks compared in the order of its register reduction.  Band cells
+		// beyond the query end are never the maximum (each is smaller than its left neighbour), so the query's cells are all that matters.
+		for(int o = 32; o > 0; o >>= 1){ const long long ok = __shfl_xor(bestc, o); if(ok > bestc) bestc = ok; }
+		__builtin_amdgcn_s_waitcnt(0);
+		const int Wc = a.ref_bw ? (int)(a.ref_bw / 16u) : ((qlen + 15) / 16 * 16) / 16;
+		const int j = lane >> 2, sub = lane & 3, qw = (Wc + 3) / 4;
+		const int xb = j * Wc + sub * qw, xe = min(min(xb + qw, (j + 1) * Wc), qlen);
+		long long bk = (long long)0x8000000000000000ull;
+		for(int x = xb; x < xe; x++){
+			const long long key = ((long long)*(const volatile int32_t*)&lastH[x] << 32) | (long long)(0x7FFFFFFFu - (uint32_t)x);
+			if(key > bk) bk = key;
+		}
+		for(int o = 1; o <= 2; o <<= 1){ const long long ok = __shfl_xor(bk, o); if(ok > bk) bk = ok; }
+		int bs = 0, bp = 0; bool any = false;
+		for(int kk = 0; kk < 16; kk++){
+			const int jj = (kk & 3) * 4 + (kk >> 2);
+			const long long key = __shfl(bk, jj * 4);
+			if(key == (long long)0x8000000000000000ull) continue;                  // (a block beyond the query end)
+			const int mx = (int)(key >> 32), px = (int)(0x7FFFFFFFu - (uint32_t)(key & 0xFFFFFFFFll));
+			if(!any || mx > bs){ bs = mx; bp = px; any = true; }
+		}
+		if(lane == 0){
+			int sc = (int)(bestc >> 32), qe = qlen - 1, te = (int)(0x7FFFFFFFu - (uint32_t)(bestc & 0xFFFFFFFFll));
+			if(any && bs > sc){ sc = bs; qe = bp; te = tlen - 1; }
+			hdr->score = sc; hdr->qe = qe; hdr->te = te;
+		}
 	}
 }
 
@@ -205,7 +253,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 	bsa_result_t rs;
 	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
 	if(a.status[pair] != 0u){ out[pair] = rs; cig_cnt[ppos] = 0; return; }
-	const int qlen = (int)a.qlen[pair], tlen = (int)a.tlen[pair];
+	const int qlen = (int)a.qlen[pair];
 	const uint8_t *qseq = a.qst + a.qpoff[pair], *tseq = a.tst + a.tpoff[pair];
 	const uint8_t *slot = a.rows + a.slot_off[ppos];
 	const SysHdr *hdr = (const SysHdr*)slot;
@@ -228,7 +276,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 	bool bad = false;
 	rs.score = hdr->score;
 	if(rs.score == (int)0x80000000u) bad = true;
-	rs.qe = qlen - 1; rs.te = tlen - 1;
+	rs.qe = hdr->qe; rs.te = hdr->te;                     // (global: the last cell; overlap / extend: the end cell the forward pass found)
 	rs.qb = rs.qe; rs.qe++;
 	rs.tb = rs.te; rs.te++;
 	int prior_match = 0;
@@ -281,12 +329,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 		}
 	}
 	if(!bad){
-		uint32_t op = 0, sz = 0;          // global: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
-		if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
-		else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
-		rs.aln += (int)sz;
-		cg = cig_add(cg, op, sz);
-		if(cg) cig_push(cg);
+		if((a.mode & 3) == BSA_MODE_OVERLAP){ if(cg) cig_push(cg); }       // overlap: the alignment simply starts where the walk left the matrix
+		else {
+			uint32_t op = 0, sz = 0;          // global / extend: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
+			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
+			else if(rs.tb >= 0){ op = 2; sz = (uint32_t)rs.tb + 1u; rs.del += (int)sz; rs.tb = -1; }
+			rs.aln += (int)sz;
+			cg = cig_add(cg, op, sz);
+			if(cg) cig_push(cg);
+		}
 		rs.qb++; rs.tb++;
 	} else {
 		atomicOr(&a.status[pair], BSA_ST_TRACE);

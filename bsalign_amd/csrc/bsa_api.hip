@@ -756,12 +756,12 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		const uint32_t kbw = full ? align8_widened_bw(par, max_bw) : 0u;
 		if(kbw){ bw = kbw; max_bw = kbw; widened = true; }
 	}
-	// Whole-query bands above 256 columns (the reference CLI's default on long reads): global mode, linear or affine gaps, scores inside
+	// Whole-query bands above 256 columns (the reference CLI's default on long reads; `bsalign align` defaults to overlap mode): all three modes, linear or affine gaps, scores inside
 	// the exact-arithmetic guard -> the systolic wavefront with its own code rows and traceback (bsa_align8_sys.hip) instead of the
 	// LDS-resident run-time-width kernel.  BSA_ALIGN8_SYS=0 keeps the old dispatch.
 	bool sys = false; uint32_t max_qlen = 0;
 	for(size_t k = 0; k < n; k++) max_qlen = std::max(max_qlen, qlen[k]);
-	if(!widened && type == BSA_MODE_GLOBAL && n > 0 && (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw > 256u && max_qlen <= 60000u && !(par->mode & BSA_MODE_ROWRECORDS)){
+	if(!widened && n > 0 && (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw > 256u && max_qlen <= 60000u && !(par->mode & BSA_MODE_ROWRECORDS)){
 		bool full = true;
 		if(bw != 0) for(size_t k = 0; k < n && full; k++) full = qlen[k] <= bw;
 		const char *se = bsa_env("BSA_ALIGN8_SYS"), *le = bsa_env("BSA_ALIGN8_LITERAL");

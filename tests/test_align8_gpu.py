@@ -360,9 +360,10 @@ def test_whole_query_bands_above_256_columns_run_the_systolic_wavefront(ctx, bw,
     pairs.append((pairs[2][0], pairs[2][1][:64]))
     pairs.append((pairs[3][0], pairs[3][1][:65]))
     for scname in ("affine", "paper", "linear"):
-        _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS[scname])
-        names = ctx.last_kernel_names()
-        assert "k_align8_fwd_sys" in names[0] and "k_align8_trace_sys" in names[1], names
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):      # (`bsalign align` defaults to overlap: the end cell is searched for)
+            _check(ctx, pairs, mode, bw, SCORINGS[scname])
+            names = ctx.last_kernel_names()
+            assert "k_align8_fwd_sys" in names[0] and "k_align8_trace_sys" in names[1], names
     par = B.make_params(S.MODE_GLOBAL, bw, *SCORINGS["affine"])
     out_s, cig_s, st_s = ctx.align_batch(pairs, par)
     monkeypatch.setenv("BSA_ALIGN8_SYS", "0")
@@ -370,9 +371,7 @@ def test_whole_query_bands_above_256_columns_run_the_systolic_wavefront(ctx, bw,
     assert "gen" in ctx.last_kernel_names()[0]
     monkeypatch.delenv("BSA_ALIGN8_SYS")
     assert np.array_equal(out_s, out_g) and np.array_equal(st_s, st_g) and all(np.array_equal(a, b) for a, b in zip(cig_s, cig_g))
-    # overlap / extend, two-piece gaps and scorings outside the guard keep the run-time-width kernel
-    _check(ctx, pairs[:16], S.MODE_OVERLAP, bw, SCORINGS["affine"])
-    assert "sys" not in ctx.last_kernel_names()[0]
+    # two-piece gaps and scorings outside the guard keep the run-time-width kernel
     _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, SCORINGS["twopiece"])
     assert "sys" not in ctx.last_kernel_names()[0]
     _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, (10, -30, -20, -10, 0, 0))
@@ -385,6 +384,9 @@ def test_whole_query_bands_10k(ctx):
     _check(ctx, pairs, S.MODE_GLOBAL, 0, SCORINGS["affine"])
     assert "k_align8_fwd_sys" in ctx.last_kernel_names()[0]
     _check(ctx, pairs[:3], S.MODE_GLOBAL, 0, SCORINGS["linear"])
+    _check(ctx, pairs[:4], S.MODE_OVERLAP, 0, SCORINGS["paper"])          # example/run.sh "NoBand": align -M 2 -X 2 -O 4 -E 2, overlap
+    assert "k_align8_fwd_sys" in ctx.last_kernel_names()[0]
+    _check(ctx, pairs[:2], S.MODE_EXTEND, 0, SCORINGS["affine"])
 
 
 @pytest.mark.parametrize("bw", [0, 112])
