@@ -153,7 +153,7 @@ def _cpu_sample(args, L, bw, sc, mode, npairs, first_pair, kind):
     qoff = ((np.arange(npairs, dtype=np.uint64) + np.uint64(npairs)) * np.uint64(stride))
     cs = C.c_int64(0)
     if args.workload == "align8":
-        cells = float(L) * bw * npairs
+        cells = float(L) * bw * npairs if bw else float(L) * float(((qlen.astype(np.int64) + 15) // 16 * 16).sum())     # bandwidth 0 = the whole query (bsalign.h:3861)
         if kind == "reference":
             lib = S.ref()
             secs = lib.ref_align_batch_time(lib._ctx, S.ptr(seqs, S.u8p), S.ptr(qoff, S.u64p), S.ptr(qlen, S.u32p), S.ptr(toff, S.u64p),
