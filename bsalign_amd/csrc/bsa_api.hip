@@ -965,14 +965,22 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 		}
 	}
 	bsa_align_plan_t *p = nullptr;
+	const bool timing = bsa_env("BSA_API_TIMING") != nullptr;          // (stderr: where a host-pointer batch spends its wall time)
+	const auto tm0 = std::chrono::steady_clock::now();
 	int rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
 	if(rc != BSA_OK) return rc;
+	const auto tm1 = std::chrono::steady_clock::now();
 	std::vector<uint32_t> st_own;
 	uint32_t *st = status;
 	const bool codes = p->codes || p->sys;           // both read the traceback off codes and may hand a pair over
 	if(codes && !st){ st_own.resize(n); st = st_own.data(); }
 	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, st,
 		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_align_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });
+	if(timing){
+		const auto tm2 = std::chrono::steady_clock::now();
+		fprintf(stderr, "[bsa_align_batch] %zu pairs, mode %d, bandwidth %u: plan %.3f s (workspace %.1f GB, %zu chunks), staging + kernels + copies %.3f s, forward kernel %s\n", n, par->mode & 3, par->bandwidth,
+			std::chrono::duration<double>(tm1 - tm0).count(), (double)c->ws_bytes / 1e9, p->chunks.size(), std::chrono::duration<double>(tm2 - tm1).count(), c->fwd_name.c_str());
+	}
 	bsa_align_plan_destroy(p);
 	if(rc != BSA_OK || !codes) return rc;
 	// ---- hand-over: pairs the compact traceback could not decide go through the literal kernels, so that a flag that
@@ -983,6 +991,7 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	for(size_t k = 0; k < n; k++) if((st[k] & BSA_ST_TRACE) || (every > 0 && k % (size_t)every == 0 && st[k] == 0)) idx.push_back(k);
 	if(idx.empty()) return BSA_OK;
 	const size_t m = idx.size();
+	if(timing) fprintf(stderr, "[bsa_align_batch] %zu pairs handed over to the literal kernels\n", m);
 	std::vector<uint64_t> sq(m), stt(m), soff(m + 1);
 	std::vector<uint32_t> sql(m), stl(m), sst(m);
 	std::vector<bsa_result_t> sout(m);

@@ -32,3 +32,13 @@ t $HIP align -m global -W 128 $D/long.fa
 echo "== 2000 pairs x 10 kbp, edit, global, -W 256"
 t $HIP edit -m global -W 256 $D/long.fa
 [ -x $REF ] && t $REF edit -m global -W 256 $D/long.fa
+echo "== 2000 pairs x 10 kbp with no option at all (overlap, whole-query band: example/run.sh 'NoBand' without its scoring)"
+t $HIP align $D/long.fa
+[ -x $REF ] && t $REF align $D/long.fa
+echo "== example/run.sh: NoBand, Band64, Edit0"
+t $HIP align -M 2 -X 2 -O 4 -E 2 -Q 0 -P 0 $D/long.fa
+[ -x $REF ] && t $REF align -M 2 -X 2 -O 4 -E 2 -Q 0 -P 0 $D/long.fa
+t $HIP align -W 64 -M 2 -X 2 -O 4 -E 2 -Q 0 -P 0 -m overlap $D/long.fa
+[ -x $REF ] && t $REF align -W 64 -M 2 -X 2 -O 4 -E 2 -Q 0 -P 0 -m overlap $D/long.fa
+t $HIP edit -W 0 $D/long.fa
+[ -x $REF ] && t $REF edit -W 0 $D/long.fa
