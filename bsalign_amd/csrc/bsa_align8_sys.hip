@@ -57,17 +57,22 @@ bool bsa_align8_sys_supported(const Align8Args &a, int pw){
 // 3 adds, 2 max, 1 and-or, and two instructions per traceback fact (difference, v_alignbit of its sign into the lane's bit plane).
 // The F restart of the reference's running blocks (F = max(F, H above - 63)) is left out: inside the guard g <= 21, and the F that
 // reaches cell x is >= H(x - 1, y) + gapo + gape >= H(x - 1, y - 1) + 2 (gapo + gape) > H(x - 1, y - 1) - 63, so it never binds.
-template<int PW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_align8_fwd_sys(const Align8Args a){
-	__shared__ int2 inr[128 + 2];                    // the row above the block: columns t .. t + 127 of {H * 32 | q << 3, E * 32}; [128], [129] mirror [0], [1]
-	__shared__ int2 outr[128];                       // the block's last row on its way out: column c at (c + 63) & 127
+// One workgroup per pair, NWV waves (1 or 4): wave w owns rows 64 (NWV s + w) .. + 63 of super-block s and runs LAG = 192 steps behind
+// wave w - 1, whose last row reaches it through an LDS ring (column c at entry c mod 256, written one step late so that a 32-step body
+// never wraps); one barrier per 64 steps keeps writer and reader an epoch apart.  Wave 0's upper boundary and the last wave's lower one
+// go through HBM as before, 64 columns per access.  Four waves cut a pair's latency (and the memory a full chip needs) by four.
+#define SYS_LAG 192
+template<int PW, int NWV>
+__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4))) k_align8_fwd_sys(const Align8Args a){
+	__shared__ int2 rg[NWV + 1][256 + 2];            // rg[w]: the row above wave w's rows, rg[w + 1]: its own last row; {H * 32 | q << 3, E * 32} per column
+	__shared__ long long bestw[NWV];
 	const uint32_t ppos = a.first + blockIdx.x;
 	const uint32_t pair = a.order[ppos];
-	const int lane = threadIdx.x;
+	const int wv = (NWV == 1) ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const int qlen = (int)a.qlen[pair], tlen = (int)a.tlen[pair];
 	uint8_t *slot = a.rows + a.slot_off[ppos];
 	SysHdr *hdr = (SysHdr*)slot;
-	if(a.status[pair] != 0u || qlen == 0 || tlen == 0){ if(lane == 0) hdr->score = (int)0x80000000u; return; }
+	if(a.status[pair] != 0u || qlen == 0 || tlen == 0){ if(threadIdx.x == 0) hdr->score = (int)0x80000000u; return; }
 	int2 *bnd = (int2*)(slot + bsa_sys_bnd_off());
 	uint8_t *codes = slot + bsa_sys_codes_off((uint32_t)qlen);
 	const int NW = (int)bsa_sys_words((uint32_t)qlen);
@@ -78,36 +83,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 	const int first_u = ovl ? 0 : (int)(int8_t)(GOE + a.smin - a.smax), B0 = ovl ? 0 : a.smax - a.smin;
 	int32_t *lastH = (int32_t*)(slot + bsa_sys_lasth_off((uint32_t)qlen));
 	long long bestc = (long long)0x8000000000000000ull;                              // best cell of the last query column: (score, first row) as one key
-	const int nblk = (tlen + 63) / 64, nsteps = qlen + 63, cmax = qlen + 192;
+	const int nsb = (tlen + 64 * NWV - 1) / (64 * NWV), nsteps = qlen + 63, cmax = qlen + 192;
+	const int Ttot = nsteps + 1 + SYS_LAG * (NWV - 1);
 	// row -1 (row_init): H = gapo + gape (x + 1), e = -63, with the query codes
-	for(int c = lane; c < cmax; c += 64){
+	for(int c = (int)threadIdx.x; c < cmax; c += 64 * NWV){
 		const int h = ovl ? 0 : GOE + GE * c, q = (c < qlen) ? ((int)qp[c] & 3) : 0;
 		bnd[c] = make_int2(h * 32 + q * 8, (h + BSA_EPI8_MIN) * 32);
 	}
-	for(int blk = 0; blk < nblk; blk++){
-		__builtin_amdgcn_s_waitcnt(0);                           // the boundary row is in memory before this block reads it
+	for(int sb = 0; sb < nsb; sb++){
+		__builtin_amdgcn_s_waitcnt(0);                           // the boundary row is in memory before this super-block reads it
+		if(NWV > 1) __syncthreads();
+		const int blk = sb * NWV + wv;
+		const bool live = blk * 64 < tlen, lastsb = sb + 1 == nsb;
 		const int y = blk * 64 + lane;
 		const int tb = (y < tlen) ? (int)tp[y] & 3 : 0;
 		const int mr = (int)((tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3]);     // matrix[q * 4 + tb], q = 0..3, one byte each
 		const int rh = (y == 0 || ovl) ? 0 : GO + GE * y;        // H left of column 0 (bsalign.h:3932-3946)
 		const bool lastrow = ends && y == tlen - 1;
+		int2 *irng = rg[wv], *orng = rg[wv + 1];
 		int P = 0, E = 0, Hd = 0, F = 0;
 		uint32_t pM = 0, pD = 0, pR = 0, pO = 0;                 // NOT-facts, newest step in bit 0
 		uint4 *cp = (uint4*)codes + ((size_t)blk * NW * 64 + lane);
-		{ const int2 v0 = bnd[lane], v1 = bnd[64 + lane]; inr[lane] = v0; inr[64 + lane] = v1; if(lane < 2) inr[128 + lane] = v0; }
-		int2 nxt = bnd[128 + lane];
+		int2 nxt = make_int2(0, 0);
+		if(wv == 0){ irng[lane] = bnd[lane]; irng[64 + lane] = bnd[64 + lane]; nxt = bnd[128 + lane]; }
 		int drained = 0;
-		auto top = [&](int t){                                   // t % 64 == 0: ring maintenance, 64 columns per coalesced access
-			if(t >= 64){
-				const int ri = (t + 64 + lane) & 127;
-				inr[ri] = nxt;
-				if(ri < 2) inr[128 + ri] = nxt;
+		auto top = [&](int t){                                   // t % 64 == 0: ring maintenance against HBM, 64 columns per coalesced access
+			if(wv == 0 && t >= 64){
+				irng[(t + 64 + lane) & 255] = nxt;
 				const int c = t + 128 + lane;
 				nxt = (c < cmax) ? bnd[c] : make_int2(0, 0);
 			}
-			if(t >= 128 && blk + 1 < nblk){
+			if(wv == NWV - 1 && t >= 128 && !lastsb){         // (column c was written at step c + 64)
 				const int c = t - 128 + lane;
-				bnd[c] = outr[(c + 63) & 127];
+				bnd[c] = orng[c & 255];
 				drained = t - 64;
 			}
 		};
@@ -116,8 +124,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 			*cp = (PW == 0) ? make_uint4(~(pM << sh), ~(pD << sh), 0xffffffffu, 0xffffffffu) : make_uint4(~(pM << sh), ~(pD << sh), ~(pR << sh), ~(pO << sh));
 			cp += 64;
 		};
-		auto step = [&](auto gen, auto last, const int t, const int2 b, int2 *ob){         // b: the ring entry of the step (all lanes read the same one; lane 0 uses it)
+		auto step = [&](auto gen, auto last, const int t, const int2 b, int2 *ob){         // b: the ring entry of the step (all lanes read the same one; lane 0 uses it); ob: where column t - 64 of the last row goes
 			constexpr bool GEN = decltype(gen)::value, LAST = decltype(last)::value;     // LAST: the block holds the last target row and its H is wanted
+			if constexpr(GEN){
+				if(lane == 63 && t >= 64) *ob = make_int2(P, E);                         // the previous step's cell of the last row: column t - 64
+				if(t >= nsteps) return;
+			} else {
+				if(lane == 63) *ob = make_int2(P, E);
+			}
 			const int Pi = sys_shr1(b.x, P);
 			const int Eu = (PW == 0) ? 0 : sys_shr1(b.y, E);
 			const int Hu = Pi & ~31;
@@ -160,7 +174,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 			Hd = Hu;
 			if constexpr(GEN){
 				const int x = t - lane;
-				if(lane == 63 && x >= 0 && x < qlen) *ob = make_int2(P, E);
 				if(x == qlen - 1 && y < tlen){
 					if(!ends){ if(y == tlen - 1){ hdr->score = H >> 5; hdr->qe = qlen - 1; hdr->te = tlen - 1; } }
 					else {
@@ -171,45 +184,49 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 				}
 				if(LAST && lastrow && x >= 0 && x < qlen) lastH[x] = H >> 5;
 			} else {
-				if(lane == 63) *ob = make_int2(P, E);
 				if(LAST && lastrow) lastH[t - lane] = H >> 5;
 			}
 		};
-		auto sweep = [&](auto last){
-			int t = 0;
-			for(const int te = min(64, nsteps); t < te; t++){
-				if((t & 63) == 0) top(t);
-				step(std::true_type(), last, t, inr[t & 127], &outr[t & 127]);
-				if((t & 31) == 31 || t == nsteps - 1) flush(t);
-			}
-			// steady state: 0 < x < qlen - 1 on every lane
-			for(; t + 32 <= qlen - 1; t += 32){
-				if((t & 63) == 0) top(t);
-				int ro = t & 127;                                        // ring offset of the step, kept in a VGPR (a uniform address would be
-				asm volatile("" : "+v"(ro));                             // moved from an SGPR in front of every LDS instruction)
-				const int2 *ib = inr + ro; int2 *ob = outr + ro;
-				int2 b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
+		// 64 steps of this wave from its step t0 (a multiple of 64)
+		auto run64 = [&](auto last, const int t0){
+			if(t0 >= 64 && t0 + 64 <= qlen - 1){
+				// steady state: 0 < x < qlen - 1 on every lane
+				top(t0);
 #pragma unroll 1
-				for(int kk = 0; kk < 4; kk++, ib += 8, ob += 8){
+				for(int t = t0; t < t0 + 64; t += 32){
+					int ro = t & 255, wo = (t - 64) & 255;                   // ring offsets of the step, kept in VGPRs (a uniform address would be
+					asm volatile("" : "+v"(ro), "+v"(wo));                   // moved from an SGPR in front of every LDS instruction)
+					const int2 *ib = irng + ro; int2 *ob = orng + wo;
+					int2 b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
+#pragma unroll 1
+					for(int kk = 0; kk < 4; kk++, ib += 8, ob += 8){
 #pragma unroll
-					for(int k = 0; k < 8; k++){
-						const int2 b = b0;
-						b0 = b1;
-						b1 = ib[k + 2];
-						step(std::false_type(), last, t + kk * 8 + k, b, ob + k);
+						for(int k = 0; k < 8; k++){
+							const int2 b = b0;
+							b0 = b1;
+							b1 = ib[k + 2];
+							step(std::false_type(), last, t + kk * 8 + k, b, ob + k);
+						}
 					}
+					flush(t + 31);
 				}
-				flush(t + 31);
-			}
-			for(; t < nsteps; t++){
-				if((t & 63) == 0) top(t);
-				step(std::true_type(), last, t, inr[t & 127], &outr[t & 127]);
-				if((t & 31) == 31 || t == nsteps - 1) flush(t);
+			} else {
+				for(int t = t0; t < min(t0 + 64, nsteps + 1); t++){
+					if((t & 63) == 0) top(t);
+					step(std::true_type(), last, t, irng[t & 255], &orng[(t - 64) & 255]);
+					if(t < nsteps && ((t & 31) == 31 || t == nsteps - 1)) flush(t);
+				}
 			}
 		};
-		if(ends && blk + 1 == nblk) sweep(std::true_type()); else sweep(std::false_type());
-		if(blk + 1 < nblk)
-			for(int c0 = drained; c0 < qlen; c0 += 64){ const int c = c0 + lane; if(c < qlen) bnd[c] = outr[(c + 63) & 127]; }
+		for(int T = 0; T < Ttot; T += 64){
+			const int t0 = T - SYS_LAG * wv;
+			if(live && t0 >= 0 && t0 <= nsteps){
+				if(ends && lastsb) run64(std::true_type(), t0); else run64(std::false_type(), t0);
+			}
+			if(NWV > 1) __syncthreads();
+		}
+		if(wv == NWV - 1 && !lastsb)
+			for(int c0 = drained; c0 < qlen; c0 += 64){ const int c = c0 + lane; if(c < qlen) bnd[c] = orng[c & 255]; }
 	}
 	if(ends){
 		// overlap / extend: the best cell of the last query column (first row on ties), replaced by row_max of the last target row if that
@@ -218,6 +235,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 		// beyond the query end are never the maximum (each is smaller than its left neighbour), so the query's cells are all that matters.
 		for(int o = 32; o > 0; o >>= 1){ const long long ok = __shfl_xor(bestc, o); if(ok > bestc) bestc = ok; }
 		__builtin_amdgcn_s_waitcnt(0);
+		if(NWV > 1){
+			if(lane == 0) bestw[wv] = bestc;
+			__syncthreads();
+			if(wv != 0) return;
+#pragma unroll
+			for(int w = 1; w < NWV; w++) if(bestw[w] > bestc) bestc = bestw[w];
+		}
 		const int Wc = a.ref_bw ? (int)(a.ref_bw / 16u) : ((qlen + 15) / 16 * 16) / 16;
 		const int j = lane >> 2, sub = lane & 3, qw = (Wc + 3) / 4;
 		const int xb = j * Wc + sub * qw, xe = min(min(xb + qw, (j + 1) * Wc), qlen);
@@ -349,10 +373,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 }
 
 hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_qlen, hipStream_t st){
-	(void)max_qlen;
 	if(a.count == 0) return hipSuccess;
-	if(pw == 0) hipLaunchKernelGGL(k_align8_fwd_sys<0>, dim3(a.count), dim3(64), 0, st, a);
-	else hipLaunchKernelGGL(k_align8_fwd_sys<1>, dim3(a.count), dim3(64), 0, st, a);
+	// four waves per pair (BSA_ALIGN8_SYS_WAVES=1 / 2 / 4 / 8 overrides); a wave per pair for short queries, where the 576 steps the fourth
+	// wave lags by would not be small against the query
+	int nwv = (max_qlen >= 1024u) ? 4 : 1;
+	if(const char *e = bsa_env("BSA_ALIGN8_SYS_WAVES")){ const int v = atoi(e); if(v == 1 || v == 2 || v == 4 || v == 8) nwv = v; }
+#define SYS_LAUNCH(N_) do { if(pw == 0) hipLaunchKernelGGL((k_align8_fwd_sys<0, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); \
+		else hipLaunchKernelGGL((k_align8_fwd_sys<1, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); } while(0)
+	if(nwv == 8) SYS_LAUNCH(8); else if(nwv == 4) SYS_LAUNCH(4); else if(nwv == 2) SYS_LAUNCH(2); else SYS_LAUNCH(1);
+#undef SYS_LAUNCH
 	return hipGetLastError();
 }
 
