@@ -252,6 +252,10 @@ def cpu_baseline(args, L, bw, sc, mode):
     kind = "reference" if S.have_ref() else "port"
     if args.workload == "align8":
         npairs = args.cpu_pairs if args.cpu_pairs > 0 else (4000 if kind == "reference" else 1200)
+        if args.cpu_pairs <= 0:
+            # the sample is sized for bandwidth 128; wider bands (bandwidth 0 = the whole query) cost more per pair: keep it at 10 - 30 s
+            eff = bw if bw else (L + 15) // 16 * 16
+            npairs = max(16, int(npairs * min(1.0, 128.0 / eff)))
     else:
         npairs = args.cpu_pairs if args.cpu_pairs > 0 else (1500 if kind == "reference" else 60)
     what = ("the reference's SSE4.2 code (oracle/_ref)" if kind == "reference" else "own scalar C restatement (oracle/), not the reference")
