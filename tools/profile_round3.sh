@@ -25,6 +25,7 @@ run_stats poarec --workload poa --steps 2 --warmup 1
 run_pmc poarec FETCH_SIZE --workload poa --steps 1 --warmup 0
 run_pmc poarec WRITE_SIZE --workload poa --steps 1 --warmup 0
 run_stats poarec4096 --workload poa --pairs 4096 --steps 2 --warmup 1
+run_stats align8wq4096 --length 10000 --bw -1 --pairs 4096 --steps 2 --warmup 1
 run_stats edit --workload edit --steps 3 --warmup 1
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
 	timeout -s KILL 600 rocprofv3 --pmc $set --output-format csv -d $OUT -o align8wq_pmc_sq -- python bench.py $WQ --steps 1 --warmup 0 --cpu-pairs -1 > $OUT/align8wq_pmc_sq.log 2>&1 < /dev/null
@@ -32,7 +33,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
 done
 # the bench lines themselves (with the CPU baseline), outside the profiler
 timeout -s KILL 600 python bench.py --steps 3 --warmup 1 > $OUT/align8_bench_line.json 2> $OUT/align8_bench_line.err < /dev/null
-timeout -s KILL 600 python bench.py $WQ --steps 3 --warmup 1 > $OUT/align8wq_bench_line.json 2> $OUT/align8wq_bench_line.err < /dev/null
+timeout -s KILL 600 python bench.py $WQ --steps 3 --warmup 1 --cpu-pairs 40 > $OUT/align8wq_bench_line.json 2> $OUT/align8wq_bench_line.err < /dev/null
 timeout -s KILL 600 python bench.py --workload poa --steps 2 --warmup 1 > $OUT/poarec_bench_line.json 2> $OUT/poarec_bench_line.err < /dev/null
 timeout -s KILL 600 python bench.py --workload poa --pairs 4096 --steps 2 --warmup 1 > $OUT/poarec4096_bench_line.json 2> $OUT/poarec4096_bench_line.err < /dev/null
 timeout -s KILL 600 python bench.py --workload edit --steps 3 --warmup 1 > $OUT/edit_bench_line.json 2> $OUT/edit_bench_line.err < /dev/null

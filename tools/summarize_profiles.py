@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = {"align8": "k_align8_fwd", "edit": "k_edit_fwd", "poa": "k_sweep", "editfull": "k_edit_fwd_wide",
-            "align8wq": "k_align8_fwd_sys", "poarec": "k_poa_wf", "poarec4096": "k_poa_wf"}
+            "align8wq": "k_align8_fwd_sys", "align8wq4096": "k_align8_fwd_sys", "poarec": "k_poa_wf", "poarec4096": "k_poa_wf"}
 
 
 def pmc_sum(path, kernel_prefix):
