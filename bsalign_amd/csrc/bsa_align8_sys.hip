@@ -267,17 +267,25 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 	}
 }
 
-// ---- traceback: one pair per lane, backcal's decisions read off the codes (oracle: backcal_codes; bsalign.h:3704-3852) ----
-template<int PW>
+// ---- traceback: backcal's decisions read off the codes (oracle: backcal_codes; bsalign.h:3704-3852) ----
+// WAVE = true (the default): one pair per wave.  Every lane carries the walk's state; a code tile (64 rows x 32 wavefront steps, one
+// contiguous kilobyte) is fetched by the whole wave into one of four LDS slots and the tile to its left -- where a match / mismatch run
+// goes next -- is requested at the same time and waits in registers, so a step costs an LDS read, not a trip to HBM (the walk of a
+// 10 kbp pair: 20 k steps); the bases for the match / mismatch count come from 256-byte windows in LDS.  WAVE = false: a pair per lane.
+template<int PW, bool WAVE>
 __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt, const uint64_t *slot_end){
-	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	__shared__ uint4 tl[WAVE ? 4 : 1][64];
+	__shared__ uint32_t qwn[WAVE ? 64 : 1], twn[WAVE ? 64 : 1];
+	const int lane = threadIdx.x;
+	const bool wr = !WAVE || lane == 0;                   // who writes results
+	const uint32_t g = WAVE ? blockIdx.x : blockIdx.x * 64u + threadIdx.x;
 	if(g >= a.count) return;
 	const uint32_t ppos = a.first + g;
 	const uint32_t pair = a.order[ppos];
 	bsa_result_t rs;
 	rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
-	if(a.status[pair] != 0u){ out[pair] = rs; cig_cnt[ppos] = 0; return; }
-	const int qlen = (int)a.qlen[pair];
+	if(a.status[pair] != 0u){ if(wr){ out[pair] = rs; cig_cnt[ppos] = 0; } return; }
+	const int qlen = (int)a.qlen[pair], tlen_ = (int)a.tlen[pair];
 	const uint8_t *qseq = a.qst + a.qpoff[pair], *tseq = a.tst + a.tpoff[pair];
 	const uint8_t *slot = a.rows + a.slot_off[ppos];
 	const SysHdr *hdr = (const SysHdr*)slot;
@@ -285,17 +293,53 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 	const int NW = (int)bsa_sys_words((uint32_t)qlen);
 	uint32_t *cig_end = (uint32_t*)(a.rows + slot_end[ppos]);
 	uint32_t ncig = 0;
-	auto cig_push = [&](uint32_t w){ ncig++; *(cig_end - ncig) = w; };
+	auto cig_push = [&](uint32_t w){ ncig++; if(wr) *(cig_end - ncig) = w; };
 	auto cig_add = [&](uint32_t cg, uint32_t op, uint32_t sz) -> uint32_t {   // bsalign.h:409-417
 		if(op == (cg & 0xf)) return cg + (sz << 4);
 		if(cg) cig_push(cg);
 		return (sz << 4) | op;
 	};
 	// the facts of cell (x, r): tile r >> 6, wavefront step t = x + (r & 63), word t >> 5, bit 31 - (t & 31)
-	auto word = [&](int r, int tw) -> const uint4* { return (const uint4*)codes + ((size_t)(r >> 6) * NW + tw) * 64 + (r & 63); };
+	const uint4 *gt = (const uint4*)codes;
+	int tg0 = -1, tg1 = -1, tg2 = -1, tg3 = -1, pf_id = -1;          // the tiles in the LDS slots (slot = word index mod 4), the tile waiting in `pf`
+	uint4 pf = make_uint4(0, 0, 0, 0);
+	auto getw = [&](int r, int tw) -> uint4 {
+		const int id = (r >> 6) * NW + tw;
+		if constexpr(!WAVE) return gt[(size_t)id * 64 + (r & 63)];
+		else {
+			const int sl = tw & 3;
+			const int have = sl == 0 ? tg0 : sl == 1 ? tg1 : sl == 2 ? tg2 : tg3;
+			if(have != id){
+				if(pf_id == id) tl[sl][lane] = pf;
+				else tl[sl][lane] = gt[(size_t)id * 64 + lane];
+				if(sl == 0) tg0 = id; else if(sl == 1) tg1 = id; else if(sl == 2) tg2 = id; else tg3 = id;
+				const int sp = (tw - 1) & 3, hp = sp == 0 ? tg0 : sp == 1 ? tg1 : sp == 2 ? tg2 : tg3;
+				if(tw >= 1 && hp != id - 1){ pf = gt[(size_t)(id - 1) * 64 + lane]; pf_id = id - 1; }
+			}
+			return tl[sl][r & 63];
+		}
+	};
 	auto bit = [&](int r, int x, int pl) -> bool {
 		const int t = x + (r & 63);
-		return (((const uint32_t*)word(r, t >> 5))[pl] >> (31 - (t & 31))) & 1u;
+		const uint4 v = getw(r, t >> 5);
+		const uint32_t wd = pl == 0 ? v.x : pl == 1 ? v.y : pl == 2 ? v.z : v.w;
+		return (wd >> (31 - (t & 31))) & 1u;
+	};
+	// the two bases of a match / mismatch step
+	int qb0 = 1 << 30, tb0 = 1 << 30;                            // first base in the LDS windows (WAVE)
+	auto getq = [&](int x) -> uint32_t {
+		if constexpr(!WAVE) return qseq[x];
+		else {
+			if(x < qb0 || x >= qb0 + 256){ qb0 = max(0, x - 252) & ~3; qwn[lane] = (qb0 + 4 * lane < qlen) ? *(const uint32_t*)(qseq + qb0 + 4 * lane) : 0u; }      // (the staged sequences are padded past their ends)
+			return (qwn[(x - qb0) >> 2] >> (8 * ((x - qb0) & 3))) & 0xFFu;
+		}
+	};
+	auto gett = [&](int y) -> uint32_t {
+		if constexpr(!WAVE) return tseq[y];
+		else {
+			if(y < tb0 || y >= tb0 + 256){ tb0 = max(0, y - 252) & ~3; twn[lane] = (tb0 + 4 * lane < tlen_) ? *(const uint32_t*)(tseq + tb0 + 4 * lane) : 0u; }
+			return (twn[(y - tb0) >> 2] >> (8 * ((y - tb0) & 3))) & 0xFFu;
+		}
 	};
 	bool bad = false;
 	rs.score = hdr->score;
@@ -308,8 +352,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 	while(!bad){
 		if(rs.qb < 0 || rs.tb < 0) break;
 		const int lq = rs.tb & 63, tq = rs.qb + lq;
-		const uint4 cw = *word(rs.tb, tq >> 5);
-		const uint8_t qc = qseq[rs.qb], tc = tseq[rs.tb];     // (requested with the code word: one memory latency per step, not two)
+		const uint4 cw = getw(rs.tb, tq >> 5);
+		const uint32_t qc = getq(rs.qb), tc = gett(rs.tb);     // (pair per lane: requested with the code word, one memory latency per step, not two)
 		const uint32_t sh = 31u - ((uint32_t)tq & 31u);
 		const bool fM = (cw.x >> sh) & 1u, fD = (cw.y >> sh) & 1u;
 		int bt;                                               // backcal_cell (bsalign.h:3679-3699): the order of the tests depends on prior_match
@@ -330,7 +374,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 				for(;;){
 					if(w){ const int c = tw * 32 + (31 - (int)__builtin_ctz(w)) - lq; if(c >= 0) sz = rs.qb - c; break; }      // (steps left of column 0 hold no cell)
 					if(--tw < 0) break;
-					w = word(rs.tb, tw)->z;
+					w = getw(rs.tb, tw).z;
 				}
 				if(sz == 0){ bad = true; break; }                                       // the reference's scan finds no length either
 				cg = cig_add(cg, 1, (uint32_t)sz);
@@ -364,12 +408,11 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 		}
 		rs.qb++; rs.tb++;
 	} else {
-		atomicOr(&a.status[pair], BSA_ST_TRACE);
+		if(wr) atomicOr(&a.status[pair], BSA_ST_TRACE);
 		rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
 		ncig = 0;
 	}
-	out[pair] = rs;
-	cig_cnt[ppos] = ncig;
+	if(wr){ out[pair] = rs; cig_cnt[ppos] = ncig; }
 }
 
 hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_qlen, hipStream_t st){
@@ -387,8 +430,15 @@ hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_q
 
 hipError_t bsa_launch_align8_trace_sys(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, const uint64_t *slot_end, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
-	const dim3 grid((a.count + 63u) / 64u);
-	if(pw == 0) hipLaunchKernelGGL(k_align8_trace_sys<0>, grid, dim3(64), 0, st, a, out, cig_cnt, slot_end);
-	else hipLaunchKernelGGL(k_align8_trace_sys<1>, grid, dim3(64), 0, st, a, out, cig_cnt, slot_end);
+	bool wave = true;
+	if(const char *e = bsa_env("BSA_ALIGN8_SYS_TRACE")) wave = e[0] != 'l';            // "lane": a pair per lane
+	if(wave){
+		if(pw == 0) hipLaunchKernelGGL((k_align8_trace_sys<0, true>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt, slot_end);
+		else hipLaunchKernelGGL((k_align8_trace_sys<1, true>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt, slot_end);
+	} else {
+		const dim3 grid((a.count + 63u) / 64u);
+		if(pw == 0) hipLaunchKernelGGL((k_align8_trace_sys<0, false>), grid, dim3(64), 0, st, a, out, cig_cnt, slot_end);
+		else hipLaunchKernelGGL((k_align8_trace_sys<1, false>), grid, dim3(64), 0, st, a, out, cig_cnt, slot_end);
+	}
 	return hipGetLastError();
 }

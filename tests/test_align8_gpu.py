@@ -371,6 +371,18 @@ def test_whole_query_bands_above_256_columns_run_the_systolic_wavefront(ctx, bw,
     assert "gen" in ctx.last_kernel_names()[0]
     monkeypatch.delenv("BSA_ALIGN8_SYS")
     assert np.array_equal(out_s, out_g) and np.array_equal(st_s, st_g) and all(np.array_equal(a, b) for a, b in zip(cig_s, cig_g))
+    # the other shapes of the same kernels: one wave per pair in the forward pass, a pair per lane in the traceback
+    for knob, val in (("BSA_ALIGN8_SYS_WAVES", "1"), ("BSA_ALIGN8_SYS_WAVES", "4"), ("BSA_ALIGN8_SYS_TRACE", "lane")):
+        monkeypatch.setenv(knob, val)
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP):
+            out_v, cig_v, st_v = ctx.align_batch(pairs, B.make_params(mode, bw, *SCORINGS["affine"]))
+            out_r, cig_r, st_r = (out_s, cig_s, st_s) if mode == S.MODE_GLOBAL else (None, None, None)
+            if out_r is None:
+                monkeypatch.delenv(knob)
+                out_r, cig_r, st_r = ctx.align_batch(pairs, B.make_params(mode, bw, *SCORINGS["affine"]))
+                monkeypatch.setenv(knob, val)
+            assert np.array_equal(out_v, out_r) and np.array_equal(st_v, st_r) and all(np.array_equal(a, b) for a, b in zip(cig_v, cig_r)), (knob, val, mode)
+        monkeypatch.delenv(knob)
     # two-piece gaps and scorings outside the guard keep the run-time-width kernel
     _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, SCORINGS["twopiece"])
     assert "sys" not in ctx.last_kernel_names()[0]
