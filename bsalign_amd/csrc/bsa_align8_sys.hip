@@ -417,9 +417,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 
 hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_qlen, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
-	// four waves per pair (BSA_ALIGN8_SYS_WAVES=1 / 2 / 4 / 8 overrides); a wave per pair for short queries, where the 576 steps the fourth
-	// wave lags by would not be small against the query
-	int nwv = (max_qlen >= 1024u) ? 4 : 1;
+	// four waves per pair where a wave per pair would leave the chip short of waves (BSA_ALIGN8_SYS_WAVES=1 / 2 / 4 / 8 overrides); a wave per
+	// pair for short queries, where the 576 steps the fourth wave lags by would not be small against the query, and for large batches
+	// (2000 bp x 30000 pairs: 68 ms against 100; 10 kbp x 4096: 290 against 237)
+	int nwv = (max_qlen >= 1024u && a.count < 5120u) ? 4 : 1;          // (87 VGPRs: five waves per SIMD, 5120 on the chip -- a wave per pair fills it from there on)
 	if(const char *e = bsa_env("BSA_ALIGN8_SYS_WAVES")){ const int v = atoi(e); if(v == 1 || v == 2 || v == 4 || v == 8) nwv = v; }
 #define SYS_LAUNCH(N_) do { if(pw == 0) hipLaunchKernelGGL((k_align8_fwd_sys<0, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); \
 		else hipLaunchKernelGGL((k_align8_fwd_sys<1, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); } while(0)
@@ -430,8 +431,8 @@ hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_q
 
 hipError_t bsa_launch_align8_trace_sys(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, const uint64_t *slot_end, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
-	bool wave = true;
-	if(const char *e = bsa_env("BSA_ALIGN8_SYS_TRACE")) wave = e[0] != 'l';            // "lane": a pair per lane
+	bool wave = a.count < 16384u;            // a pair per wave while that leaves no SIMD idle, a pair per lane for large batches (1 kbp x 100 k pairs: 3.6 ms against 16.9)
+	if(const char *e = bsa_env("BSA_ALIGN8_SYS_TRACE")) wave = e[0] != 'l';            // "lane" / "wave"
 	if(wave){
 		if(pw == 0) hipLaunchKernelGGL((k_align8_trace_sys<0, true>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt, slot_end);
 		else hipLaunchKernelGGL((k_align8_trace_sys<1, true>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt, slot_end);
