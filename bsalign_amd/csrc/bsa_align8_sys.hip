@@ -124,22 +124,21 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 			*cp = (PW == 0) ? make_uint4(~(pM << sh), ~(pD << sh), 0xffffffffu, 0xffffffffu) : make_uint4(~(pM << sh), ~(pD << sh), ~(pR << sh), ~(pO << sh));
 			cp += 64;
 		};
+		// GEN: a step in which some lane is at column 0 or at / beyond the query's last column (the first 64 and the last 64 + steps of a
+		// block): the steady step plus, for the lane at column 0, the seed rule and its two facts, and the captures at the last column.
+		// Lanes left of column 0 or right of the last column compute on whatever arrives; nothing of theirs is kept.
 		auto step = [&](auto gen, auto last, const int t, const int2 b, int2 *ob){         // b: the ring entry of the step (all lanes read the same one; lane 0 uses it); ob: where column t - 64 of the last row goes
 			constexpr bool GEN = decltype(gen)::value, LAST = decltype(last)::value;     // LAST: the block holds the last target row and its H is wanted
-			if constexpr(GEN){
-				if(lane == 63 && t >= 64) *ob = make_int2(P, E);                         // the previous step's cell of the last row: column t - 64
-				if(t >= nsteps) return;
-			} else {
-				if(lane == 63) *ob = make_int2(P, E);
-			}
+			if(lane == 63 && (!GEN || t >= 64)) *ob = make_int2(P, E);                   // the previous step's cell of the last row: column t - 64
 			const int Pi = sys_shr1(b.x, P);
 			const int Eu = (PW == 0) ? 0 : sys_shr1(b.y, E);
 			const int Hu = Pi & ~31;
 			const int S = __builtin_amdgcn_sbfe(mr, (unsigned)Pi, 8u);
 			const int Ein = (PW == 0) ? Hu + GE5 : Eu;
-			int diag = S * 32 + Hd, cmpM = diag, cmpD = Ein;
+			int diag = S * 32 + Hd, cmpM = 0, cmpD = 0;
+			const bool col0 = GEN && t == lane;
 			if constexpr(GEN){
-				if(t - lane == 0){
+				if(col0){
 					// band cell 0: the seed rule and the F restart; the M / D facts of column 0 in their own frames
 					const int Hui = Hu >> 5, Eui = Eu >> 5;
 					const int ub0 = (y == 0) ? B0 : Hui;
@@ -156,12 +155,10 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 			}
 			const int H = max(max(diag, Ein), F);
 			const int t1 = H + GOE5;
+			pM = __builtin_amdgcn_alignbit(pM, (uint32_t)(diag - H), 31u);
+			pD = __builtin_amdgcn_alignbit(pD, (uint32_t)(Ein - H), 31u);
 			if constexpr(GEN){
-				pM = (pM << 1) | (H != cmpM ? 1u : 0u);
-				pD = (pD << 1) | (H != cmpD ? 1u : 0u);
-			} else {
-				pM = __builtin_amdgcn_alignbit(pM, (uint32_t)(diag - H), 31u);
-				pD = __builtin_amdgcn_alignbit(pD, (uint32_t)(Ein - H), 31u);
+				if(col0){ pM = (pM & ~1u) | (H != cmpM ? 1u : 0u); pD = (pD & ~1u) | (H != cmpD ? 1u : 0u); }
 			}
 			if(PW != 0){
 				const int tF = F + GE5, tE = Ein + GE5;
@@ -187,35 +184,31 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 				if(LAST && lastrow) lastH[t - lane] = H >> 5;
 			}
 		};
-		// 64 steps of this wave from its step t0 (a multiple of 64)
-		auto run64 = [&](auto last, const int t0){
-			if(t0 >= 64 && t0 + 64 <= qlen - 1){
-				// steady state: 0 < x < qlen - 1 on every lane
-				top(t0);
+		// 32 steps from step t (a multiple of 32)
+		auto body = [&](auto gen, auto last, const int t){
+			int ro = t & 255, wo = (t - 64) & 255;                   // ring offsets of the step, kept in VGPRs (a uniform address would be
+			asm volatile("" : "+v"(ro), "+v"(wo));                   // moved from an SGPR in front of every LDS instruction)
+			const int2 *ib = irng + ro; int2 *ob = orng + wo;
+			int2 b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
 #pragma unroll 1
-				for(int t = t0; t < t0 + 64; t += 32){
-					int ro = t & 255, wo = (t - 64) & 255;                   // ring offsets of the step, kept in VGPRs (a uniform address would be
-					asm volatile("" : "+v"(ro), "+v"(wo));                   // moved from an SGPR in front of every LDS instruction)
-					const int2 *ib = irng + ro; int2 *ob = orng + wo;
-					int2 b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
-#pragma unroll 1
-					for(int kk = 0; kk < 4; kk++, ib += 8, ob += 8){
+			for(int kk = 0; kk < 4; kk++, ib += 8, ob += 8){
 #pragma unroll
-						for(int k = 0; k < 8; k++){
-							const int2 b = b0;
-							b0 = b1;
-							b1 = ib[k + 2];
-							step(std::false_type(), last, t + kk * 8 + k, b, ob + k);
-						}
-					}
-					flush(t + 31);
+				for(int k = 0; k < 8; k++){
+					const int2 b = b0;
+					b0 = b1;
+					b1 = ib[k + 2];
+					step(gen, last, t + kk * 8 + k, b, ob + k);
 				}
-			} else {
-				for(int t = t0; t < min(t0 + 64, nsteps + 1); t++){
-					if((t & 63) == 0) top(t);
-					step(std::true_type(), last, t, irng[t & 255], &orng[(t - 64) & 255]);
-					if(t < nsteps && ((t & 31) == 31 || t == nsteps - 1)) flush(t);
-				}
+			}
+		};
+		// 64 steps of this wave from its step t0 (a multiple of 64).  The last body of a block runs to its end (the steps behind the last
+		// column change nothing that is kept; the one at nsteps hands the last row's last cell down); a word that holds a step is stored.
+		auto run64 = [&](auto last, const int t0){
+			for(int t = t0; t < t0 + 64 && t <= nsteps; t += 32){
+				if((t & 63) == 0) top(t);
+				if(t >= 64 && t + 32 <= qlen - 1) body(std::false_type(), last, t);       // steady state: 0 < x < qlen - 1 on every lane
+				else body(std::true_type(), last, t);
+				if(t < nsteps) flush(t + 31);
 			}
 		};
 		for(int T = 0; T < Ttot; T += 64){
