@@ -34,20 +34,28 @@ struct SysHdr { int32_t score, qe, te, reserved; };      // the alignment's end 
 // slot: header, the boundary row (qlen + 256 entries of {H * 32 | query code << 3, E * 32}), the code tiles, the CIGAR tail.
 // Code tiles: block b of 64 rows, word w = t >> 5 of the wavefront step t = x + (y & 63): 64 lanes x 16 bytes {M, D, R, Od}, step t at
 // bit 31 - (t & 31) -- every 32 steps the wave stores ONE contiguous kilobyte.
+// Two-piece gaps: boundary entries carry Q as well (16 bytes), and a cell has eight facts {A, D, D2, B | R1, R2, Od1, Od2} (section 3: the
+// 8-bit codes of the compact path) -- two kilobytes per tile, stored as two contiguous kilobytes.
 static __host__ __device__ inline uint32_t bsa_sys_words(uint32_t qlen){ return (qlen + 63u + 31u) / 32u; }
 static __host__ __device__ inline size_t bsa_sys_bnd_off(){ return sizeof(SysHdr); }
-static __host__ __device__ inline size_t bsa_sys_lasth_off(uint32_t qlen){ return bsa_sys_bnd_off() + ((size_t)qlen + 256) * 8; }      // H of the last target row (overlap / extend: row_max)
-static __host__ __device__ inline size_t bsa_sys_codes_off(uint32_t qlen){ return (bsa_sys_lasth_off(qlen) + ((size_t)qlen + 64) * 4 + 1023) & ~(size_t)1023; }
-static __host__ __device__ inline size_t bsa_sys_codes_bytes(uint32_t qlen, uint32_t tlen){ return (size_t)((tlen + 63u) / 64u) * bsa_sys_words(qlen) * 1024u; }
+static __host__ __device__ inline size_t bsa_sys_lasth_off(uint32_t qlen, int pw){ return bsa_sys_bnd_off() + ((size_t)qlen + 256) * (pw == 2 ? 16 : 8); }      // H of the last target row (overlap / extend: row_max)
+static __host__ __device__ inline size_t bsa_sys_codes_off(uint32_t qlen, int pw){ return (bsa_sys_lasth_off(qlen, pw) + ((size_t)qlen + 64) * 4 + 1023) & ~(size_t)1023; }
+static __host__ __device__ inline size_t bsa_sys_codes_bytes(uint32_t qlen, uint32_t tlen, int pw){ return (size_t)((tlen + 63u) / 64u) * bsa_sys_words(qlen) * (pw == 2 ? 2048u : 1024u); }
 
-size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen){
-	return ((bsa_sys_codes_off(qlen) + bsa_sys_codes_bytes(qlen, tlen) + ((size_t)qlen + tlen + 16) * 4) + 1023) & ~(size_t)1023;
+size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen, int pw){
+	return ((bsa_sys_codes_off(qlen, pw) + bsa_sys_codes_bytes(qlen, tlen, pw) + ((size_t)qlen + tlen + 16) * 4) + 1023) & ~(size_t)1023;
 }
 
 bool bsa_align8_sys_supported(const Align8Args &a, int pw){
-	if(pw > 1) return false;
-	const int g = -((int)(int8_t)(a.gapo1 + a.gape1)), m = a.smax, n = -a.smin;
+	int g = -((int)(int8_t)(a.gapo1 + a.gape1));
+	const int m = a.smax, n = -a.smin;
 	if(m < 0 || n < 0 || g < 0 || (int8_t)a.gape1 > 0 || (int8_t)a.gapo1 > 0 || ((int8_t)a.gapo1 == 0) != (pw == 0)) return false;
+	if(pw == 2){
+		// piece 2 opens dearer and extends cheaper (bsalign.h:2084-2092); the bound is taken with the dearer opening
+		const int ge = -(int)(int8_t)a.gape1, go = -(int)(int8_t)a.gapo1, ge2 = -(int)(int8_t)a.gape2, go2 = -(int)(int8_t)a.gapo2;
+		if(ge2 < 0 || go2 <= go || ge2 >= ge) return false;
+		g = max(g, go2 + ge2);
+	}
 	return m + 3 * g <= 64 && n + m + g <= 100;
 }
 
@@ -64,7 +72,9 @@ bool bsa_align8_sys_supported(const Align8Args &a, int pw){
 #define SYS_LAG 192
 template<int PW, int NWV>
 __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4))) k_align8_fwd_sys(const Align8Args a){
-	__shared__ int2 rg[NWV + 1][256 + 2];            // rg[w]: the row above wave w's rows, rg[w + 1]: its own last row; {H * 32 | q << 3, E * 32} per column
+	using Ent = typename std::conditional<PW == 2, int4, int2>::type;        // a boundary cell: {H * 32 | q << 3, E * 32 [, Q * 32, -]}
+	auto ent = [](int p_, int e_, int q_) -> Ent { if constexpr(PW == 2) return make_int4(p_, e_, q_, 0); else return make_int2(p_, e_); };
+	__shared__ Ent rg[NWV + 1][256 + 2];            // rg[w]: the row above wave w's rows, rg[w + 1]: its own last row; {H * 32 | q << 3, E * 32} per column
 	__shared__ long long bestw[NWV];
 	const uint32_t ppos = a.first + blockIdx.x;
 	const uint32_t pair = a.order[ppos];
@@ -73,22 +83,26 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 	uint8_t *slot = a.rows + a.slot_off[ppos];
 	SysHdr *hdr = (SysHdr*)slot;
 	if(a.status[pair] != 0u || qlen == 0 || tlen == 0){ if(threadIdx.x == 0) hdr->score = (int)0x80000000u; return; }
-	int2 *bnd = (int2*)(slot + bsa_sys_bnd_off());
-	uint8_t *codes = slot + bsa_sys_codes_off((uint32_t)qlen);
+	Ent *bnd = (Ent*)(slot + bsa_sys_bnd_off());
+	uint8_t *codes = slot + bsa_sys_codes_off((uint32_t)qlen, PW);
 	const int NW = (int)bsa_sys_words((uint32_t)qlen);
 	const uint8_t *qp = a.qst + a.qpoff[pair], *tp = a.tst + a.tpoff[pair];
 	const int GO = a.gapo1, GE = a.gape1, GOE = GO + GE, GE5 = GE * 32, GOE5 = GOE * 32;
+	const int GO2 = a.gapo2, GP = a.gape2, GQP = GO2 + GP, GP5 = GP * 32, GQP5 = GQP * 32;        // two-piece gaps: the second piece
+	const int xp = (PW == 2) ? (GO2 - GO) / (GE - GP) : 1;                                         // row_init: the first xp cells cost gape1, the rest gape2 (bsalign.h:2102-2112)
 	const int type = a.mode & 3;
 	const bool ovl = type == BSA_MODE_OVERLAP, ends = type != BSA_MODE_GLOBAL;       // overlap: row -1 is all zero and H left of column 0 is 0 (row_init bsalign.h:2094-2140, :3932-3946); ends: the end cell is searched for
 	const int first_u = ovl ? 0 : (int)(int8_t)(GOE + a.smin - a.smax), B0 = ovl ? 0 : a.smax - a.smin;
-	int32_t *lastH = (int32_t*)(slot + bsa_sys_lasth_off((uint32_t)qlen));
+	int32_t *lastH = (int32_t*)(slot + bsa_sys_lasth_off((uint32_t)qlen, PW));
 	long long bestc = (long long)0x8000000000000000ull;                              // best cell of the last query column: (score, first row) as one key
 	const int nsb = (tlen + 64 * NWV - 1) / (64 * NWV), nsteps = qlen + 63, cmax = qlen + 192;
 	const int Ttot = nsteps + 1 + SYS_LAG * (NWV - 1);
 	// row -1 (row_init): H = gapo + gape (x + 1), e = -63, with the query codes
 	for(int c = (int)threadIdx.x; c < cmax; c += 64 * NWV){
-		const int h = ovl ? 0 : GOE + GE * c, q = (c < qlen) ? ((int)qp[c] & 3) : 0;
-		bnd[c] = make_int2(h * 32 + q * 8, (h + BSA_EPI8_MIN) * 32);
+		int h = ovl ? 0 : GOE + GE * c;
+		if(PW == 2 && !ovl){ const int n1 = min(c, xp - 1); h = GOE + n1 * GE + (c - n1) * GP; }
+		const int q = (c < qlen) ? ((int)qp[c] & 3) : 0;
+		bnd[c] = ent(h * 32 + q * 8, (h + BSA_EPI8_MIN) * 32, (h + BSA_EPI8_MIN) * 32);
 	}
 	for(int sb = 0; sb < nsb; sb++){
 		__builtin_amdgcn_s_waitcnt(0);                           // the boundary row is in memory before this super-block reads it
@@ -98,20 +112,21 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 		const int y = blk * 64 + lane;
 		const int tb = (y < tlen) ? (int)tp[y] & 3 : 0;
 		const int mr = (int)((tb == 0) ? a.mrow[0] : (tb == 1) ? a.mrow[1] : (tb == 2) ? a.mrow[2] : a.mrow[3]);     // matrix[q * 4 + tb], q = 0..3, one byte each
-		const int rh = (y == 0 || ovl) ? 0 : GO + GE * y;        // H left of column 0 (bsalign.h:3932-3946)
+		const int rh = (y == 0 || ovl) ? 0 : (PW == 2) ? max(GO + GE * y, GO2 + GP * y) : GO + GE * y;        // H left of column 0 (bsalign.h:3932-3946)
 		const bool lastrow = ends && y == tlen - 1;
-		int2 *irng = rg[wv], *orng = rg[wv + 1];
-		int P = 0, E = 0, Hd = 0, F = 0;
-		uint32_t pM = 0, pD = 0, pR = 0, pO = 0;                 // NOT-facts, newest step in bit 0
-		uint4 *cp = (uint4*)codes + ((size_t)blk * NW * 64 + lane);
-		int2 nxt = make_int2(0, 0);
+		Ent *irng = rg[wv], *orng = rg[wv + 1];
+		int P = 0, E = 0, Q = 0, Hd = 0, F = 0, G = 0;
+		uint32_t pM = 0, pD = 0, pR = 0, pO = 0;                 // NOT-facts, newest step in bit 0 (two pieces: pM = A, pR / pO = R1 / Od1)
+		uint32_t pD2 = 0, pB = 0, pR2 = 0, pO2 = 0;             // two pieces: D2, B (as it is), R2, Od2
+		uint4 *cp = (uint4*)codes + ((size_t)blk * NW * (PW == 2 ? 128 : 64) + lane);
+		Ent nxt = ent(0, 0, 0);
 		if(wv == 0){ irng[lane] = bnd[lane]; irng[64 + lane] = bnd[64 + lane]; nxt = bnd[128 + lane]; }
 		int drained = 0;
 		auto top = [&](int t){                                   // t % 64 == 0: ring maintenance against HBM, 64 columns per coalesced access
 			if(wv == 0 && t >= 64){
 				irng[(t + 64 + lane) & 255] = nxt;
 				const int c = t + 128 + lane;
-				nxt = (c < cmax) ? bnd[c] : make_int2(0, 0);
+				nxt = (c < cmax) ? bnd[c] : ent(0, 0, 0);
 			}
 			if(wv == NWV - 1 && t >= 128 && !lastsb){         // (column c was written at step c + 64)
 				const int c = t - 128 + lane;
@@ -121,21 +136,29 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 		};
 		auto flush = [&](int t){
 			const uint32_t sh = 31u - ((uint32_t)t & 31u);
-			*cp = (PW == 0) ? make_uint4(~(pM << sh), ~(pD << sh), 0xffffffffu, 0xffffffffu) : make_uint4(~(pM << sh), ~(pD << sh), ~(pR << sh), ~(pO << sh));
-			cp += 64;
+			if constexpr(PW == 2){
+				cp[0] = make_uint4(~(pM << sh), ~(pD << sh), ~(pD2 << sh), pB << sh);
+				cp[64] = make_uint4(~(pR << sh), ~(pR2 << sh), ~(pO << sh), ~(pO2 << sh));
+				cp += 128;
+			} else {
+				*cp = (PW == 0) ? make_uint4(~(pM << sh), ~(pD << sh), 0xffffffffu, 0xffffffffu) : make_uint4(~(pM << sh), ~(pD << sh), ~(pR << sh), ~(pO << sh));
+				cp += 64;
+			}
 		};
 		// GEN: a step in which some lane is at column 0 or at / beyond the query's last column (the first 64 and the last 64 + steps of a
 		// block): the steady step plus, for the lane at column 0, the seed rule and its two facts, and the captures at the last column.
 		// Lanes left of column 0 or right of the last column compute on whatever arrives; nothing of theirs is kept.
-		auto step = [&](auto gen, auto last, const int t, const int2 b, int2 *ob){         // b: the ring entry of the step (all lanes read the same one; lane 0 uses it); ob: where column t - 64 of the last row goes
+		auto step = [&](auto gen, auto last, const int t, const Ent b, Ent *ob){         // b: the ring entry of the step (all lanes read the same one; lane 0 uses it); ob: where column t - 64 of the last row goes
 			constexpr bool GEN = decltype(gen)::value, LAST = decltype(last)::value;     // LAST: the block holds the last target row and its H is wanted
-			if(lane == 63 && (!GEN || t >= 64)) *ob = make_int2(P, E);                   // the previous step's cell of the last row: column t - 64
+			if(lane == 63 && (!GEN || t >= 64)) *ob = ent(P, E, Q);                   // the previous step's cell of the last row: column t - 64
 			const int Pi = sys_shr1(b.x, P);
 			const int Eu = (PW == 0) ? 0 : sys_shr1(b.y, E);
+			int Qu = 0;
+			if constexpr(PW == 2) Qu = sys_shr1(b.z, Q);
 			const int Hu = Pi & ~31;
 			const int S = __builtin_amdgcn_sbfe(mr, (unsigned)Pi, 8u);
 			const int Ein = (PW == 0) ? Hu + GE5 : Eu;
-			int diag = S * 32 + Hd, cmpM = 0, cmpD = 0;
+			int diag = S * 32 + Hd, cmpM = 0, cmpD = 0, cmpD2 = 0;
 			const bool col0 = GEN && t == lane;
 			if constexpr(GEN){
 				if(col0){
@@ -143,18 +166,42 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 					const int Hui = Hu >> 5, Eui = Eu >> 5;
 					const int ub0 = (y == 0) ? B0 : Hui;
 					const int u0 = (y == 0) ? first_u : 0;
-					const int e0 = Eui - Hui;
+					const int e0 = Eui - Hui, q0 = (Qu >> 5) - Hui;
 					int h0 = rh - ub0 + S;
-					const int tt = u0 + (PW == 0 ? GE : e0);
+					const int tt = u0 + (PW == 0 ? GE : PW == 1 ? e0 : max(e0, q0));
 					h0 = (h0 >= tt) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;
 					diag = (ub0 + h0) * 32;
 					cmpM = (rh + S) * 32;
 					cmpD = (rh + u0 + (PW == 0 ? GOE : e0)) * 32;
+					cmpD2 = (rh + u0 + q0) * 32;
 					F = (ub0 + BSA_EPI8_MIN) * 32;
+					G = F;
 				}
 			}
-			const int H = max(max(diag, Ein), F);
+			int H = max(max(diag, Ein), F);
+			if constexpr(PW == 2) H = max(max(H, Qu), G);
 			const int t1 = H + GOE5;
+			if constexpr(PW == 2){
+				// the eight facts of the two-piece codes (section 3): A = M or (neither D nor D2 and both insertion chains equal h), D, D2,
+				// B = not M and chain 1 equals h; R1 / R2: the chain reaching the next cell opens here; Od1 / Od2: the stored e / q is an opening
+				uint32_t nM = (uint32_t)(diag - H), nD = (uint32_t)(Ein - H), nD2 = (uint32_t)(Qu - H);
+				const uint32_t nI1 = (uint32_t)(F - H), nI2 = (uint32_t)(G - H);
+				if constexpr(GEN){
+					if(col0){ nM = (H != cmpM) ? 0x80000000u : 0u; nD = (H != cmpD) ? 0x80000000u : 0u; nD2 = (H != cmpD2) ? 0x80000000u : 0u; }
+				}
+				const uint32_t xx = (nD & nD2) & ~(nI1 | nI2);                      // (sign bit:) neither D nor D2, both chains
+				pM = __builtin_amdgcn_alignbit(pM, nM & ~xx, 31u);                  // not A
+				pD = __builtin_amdgcn_alignbit(pD, nD, 31u);
+				pD2 = __builtin_amdgcn_alignbit(pD2, nD2, 31u);
+				pB = __builtin_amdgcn_alignbit(pB, nM & ~nI1, 31u);                 // B
+				const int t2 = H + GQP5, tF = F + GE5, tE = Ein + GE5, tG = G + GP5, tQ = Qu + GP5;
+				pR = __builtin_amdgcn_alignbit(pR, (uint32_t)(t1 - tF), 31u);
+				pR2 = __builtin_amdgcn_alignbit(pR2, (uint32_t)(t2 - tG), 31u);
+				pO = __builtin_amdgcn_alignbit(pO, (uint32_t)(t1 - tE), 31u);
+				pO2 = __builtin_amdgcn_alignbit(pO2, (uint32_t)(t2 - tQ), 31u);
+				E = max(tE, t1); Q = max(tQ, t2);
+				F = max(tF, t1); G = max(tG, t2);
+			} else {
 			pM = __builtin_amdgcn_alignbit(pM, (uint32_t)(diag - H), 31u);
 			pD = __builtin_amdgcn_alignbit(pD, (uint32_t)(Ein - H), 31u);
 			if constexpr(GEN){
@@ -167,6 +214,7 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 				E = max(tE, t1);
 				F = max(tF, t1);
 			} else F = H + GE5;
+			}
 			P = (Pi & 31) | H;
 			Hd = Hu;
 			if constexpr(GEN){
@@ -188,13 +236,13 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 		auto body = [&](auto gen, auto last, const int t){
 			int ro = t & 255, wo = (t - 64) & 255;                   // ring offsets of the step, kept in VGPRs (a uniform address would be
 			asm volatile("" : "+v"(ro), "+v"(wo));                   // moved from an SGPR in front of every LDS instruction)
-			const int2 *ib = irng + ro; int2 *ob = orng + wo;
-			int2 b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
+			const Ent *ib = irng + ro; Ent *ob = orng + wo;
+			Ent b0 = ib[0], b1 = ib[1];                             // ring entries are read two steps ahead of their use
 #pragma unroll 1
 			for(int kk = 0; kk < 4; kk++, ib += 8, ob += 8){
 #pragma unroll
 				for(int k = 0; k < 8; k++){
-					const int2 b = b0;
+					const Ent b = b0;
 					b0 = b1;
 					b1 = ib[k + 2];
 					step(gen, last, t + kk * 8 + k, b, ob + k);
@@ -267,7 +315,8 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4
 // 10 kbp pair: 20 k steps); the bases for the match / mismatch count come from 256-byte windows in LDS.  WAVE = false: a pair per lane.
 template<int PW, bool WAVE>
 __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt, const uint64_t *slot_end){
-	__shared__ uint4 tl[WAVE ? 4 : 1][64];
+	constexpr int TU = (PW == 2) ? 128 : 64;              // 16-byte words of a code tile (two pieces: {A, D, D2, B} then {R1, R2, Od1, Od2})
+	__shared__ uint4 tl[WAVE ? 4 : 1][WAVE ? TU : 1];
 	__shared__ uint32_t qwn[WAVE ? 64 : 1], twn[WAVE ? 64 : 1];
 	const int lane = threadIdx.x;
 	const bool wr = !WAVE || lane == 0;                   // who writes results
@@ -282,7 +331,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 	const uint8_t *qseq = a.qst + a.qpoff[pair], *tseq = a.tst + a.tpoff[pair];
 	const uint8_t *slot = a.rows + a.slot_off[ppos];
 	const SysHdr *hdr = (const SysHdr*)slot;
-	const uint8_t *codes = slot + bsa_sys_codes_off((uint32_t)qlen);
+	const uint8_t *codes = slot + bsa_sys_codes_off((uint32_t)qlen, PW);
 	const int NW = (int)bsa_sys_words((uint32_t)qlen);
 	uint32_t *cig_end = (uint32_t*)(a.rows + slot_end[ppos]);
 	uint32_t ncig = 0;
@@ -295,27 +344,27 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 	// the facts of cell (x, r): tile r >> 6, wavefront step t = x + (r & 63), word t >> 5, bit 31 - (t & 31)
 	const uint4 *gt = (const uint4*)codes;
 	int tg0 = -1, tg1 = -1, tg2 = -1, tg3 = -1, pf_id = -1;          // the tiles in the LDS slots (slot = word index mod 4), the tile waiting in `pf`
-	uint4 pf = make_uint4(0, 0, 0, 0);
-	auto getw = [&](int r, int tw) -> uint4 {
+	uint4 pf = make_uint4(0, 0, 0, 0), pf2 = pf;
+	auto getw = [&](int r, int tw, int half = 0) -> uint4 {
 		const int id = (r >> 6) * NW + tw;
-		if constexpr(!WAVE) return gt[(size_t)id * 64 + (r & 63)];
+		if constexpr(!WAVE) return gt[(size_t)id * TU + half * 64 + (r & 63)];
 		else {
 			const int sl = tw & 3;
 			const int have = sl == 0 ? tg0 : sl == 1 ? tg1 : sl == 2 ? tg2 : tg3;
 			if(have != id){
-				if(pf_id == id) tl[sl][lane] = pf;
-				else tl[sl][lane] = gt[(size_t)id * 64 + lane];
+				if(pf_id == id){ tl[sl][lane] = pf; if(PW == 2) tl[sl][64 + lane] = pf2; }
+				else { tl[sl][lane] = gt[(size_t)id * TU + lane]; if(PW == 2) tl[sl][64 + lane] = gt[(size_t)id * TU + 64 + lane]; }
 				if(sl == 0) tg0 = id; else if(sl == 1) tg1 = id; else if(sl == 2) tg2 = id; else tg3 = id;
 				const int sp = (tw - 1) & 3, hp = sp == 0 ? tg0 : sp == 1 ? tg1 : sp == 2 ? tg2 : tg3;
-				if(tw >= 1 && hp != id - 1){ pf = gt[(size_t)(id - 1) * 64 + lane]; pf_id = id - 1; }
+				if(tw >= 1 && hp != id - 1){ pf = gt[(size_t)(id - 1) * TU + lane]; if(PW == 2) pf2 = gt[(size_t)(id - 1) * TU + 64 + lane]; pf_id = id - 1; }
 			}
-			return tl[sl][r & 63];
+			return tl[sl][(PW == 2 ? half * 64 : 0) + (r & 63)];
 		}
 	};
-	auto bit = [&](int r, int x, int pl) -> bool {
+	auto bit = [&](int r, int x, int pl) -> bool {              // plane pl of the cell's facts (two pieces: 0..3 first word, 4..7 second)
 		const int t = x + (r & 63);
-		const uint4 v = getw(r, t >> 5);
-		const uint32_t wd = pl == 0 ? v.x : pl == 1 ? v.y : pl == 2 ? v.z : v.w;
+		const uint4 v = getw(r, t >> 5, pl >> 2);
+		const uint32_t wd = (pl & 3) == 0 ? v.x : (pl & 3) == 1 ? v.y : (pl & 3) == 2 ? v.z : v.w;
 		return (wd >> (31 - (t & 31))) & 1u;
 	};
 	// the two bases of a match / mismatch step
@@ -348,10 +397,22 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 		const uint4 cw = getw(rs.tb, tq >> 5);
 		const uint32_t qc = getq(rs.qb), tc = gett(rs.tb);     // (pair per lane: requested with the code word, one memory latency per step, not two)
 		const uint32_t sh = 31u - ((uint32_t)tq & 31u);
-		const bool fM = (cw.x >> sh) & 1u, fD = (cw.y >> sh) & 1u;
-		int bt;                                               // backcal_cell (bsalign.h:3679-3699): the order of the tests depends on prior_match
-		if(prior_match) bt = fM ? 0 : fD ? 2 : 1;
-		else bt = fD ? 2 : fM ? 0 : 1;
+		int bt, dpl = 3, chains = 1;                          // dpl: the plane whose bit ends a deletion run; chains: which insertion chains equal h (two pieces)
+		if constexpr(PW == 2){
+			// backcal_cell with two pieces (bsalign.h:3679-3701) off the folded facts: D or D2 set: A is M; else (A, B) = (1, 0) M, (1, 1) both chains,
+			// (0, 1) chain 1 only, (0, 0) chain 2 only
+			const bool fA = (cw.x >> sh) & 1u, fD = (cw.y >> sh) & 1u, fD2 = (cw.z >> sh) & 1u, fB = (cw.w >> sh) & 1u;
+			const bool fM = (fD || fD2) ? fA : (fA && !fB);
+			const int d = fD ? 1 : fD2 ? 2 : 0;
+			if(prior_match) bt = fM ? 0 : d ? 2 : 1;
+			else bt = d ? 2 : fM ? 0 : 1;
+			dpl = (d == 2) ? 7 : 6;
+			chains = fA ? (fB ? 3 : 0) : (fB ? 1 : 2);
+		} else {
+			const bool fM = (cw.x >> sh) & 1u, fD = (cw.y >> sh) & 1u;
+			if(prior_match) bt = fM ? 0 : fD ? 2 : 1;             // backcal_cell (bsalign.h:3679-3699): the order of the tests depends on prior_match
+			else bt = fD ? 2 : fM ? 0 : 1;
+		}
 		prior_match = 1;
 		if(bt == 0){
 			if(qc == tc) rs.mat++; else rs.mis++;
@@ -362,12 +423,26 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 			else {
 				// the nearest cell to the left at which an insertion reaching its right neighbour opens (bsalign.h:3798-3814)
 				int sz = 0;
-				uint32_t w = cw.z & ~((2u << sh) - 1u);                                 // R bits of the cells left of qb in this word
+				const uint32_t lmask = ~((2u << sh) - 1u);                              // the cells left of qb in this word
+				auto rword = [&](int tw_) -> uint32_t {                                 // the R bits a scan may stop at
+					if constexpr(PW == 2){ const uint4 v = getw(rs.tb, tw_, 1); return ((chains & 1) ? v.x : 0u) | ((chains & 2) ? v.y : 0u); }
+					else return getw(rs.tb, tw_).z;
+				};
+				uint32_t w = rword(tq >> 5) & lmask;
 				int tw = tq >> 5;
 				for(;;){
 					if(w){ const int c = tw * 32 + (31 - (int)__builtin_ctz(w)) - lq; if(c >= 0) sz = rs.qb - c; break; }      // (steps left of column 0 hold no cell)
 					if(--tw < 0) break;
-					w = getw(rs.tb, tw).z;
+					w = rword(tw);
+				}
+				if constexpr(PW == 2){
+					if(sz){
+						// the reference tests H(x - sz) + max(cost1(sz), cost2(sz)) == H(x): the chain that is tight here must also be the one with the
+						// larger cost at this length (backcal_codes); else its scan finds no length
+						const bool h1 = (chains & 1) && bit(rs.tb, rs.qb - sz, 4), h2 = (chains & 2) && bit(rs.tb, rs.qb - sz, 5);
+						const int c1 = (int)a.gapo1 + sz * (int)a.gape1, c2 = (int)a.gapo2 + sz * (int)a.gape2;
+						if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))) sz = 0;
+					}
 				}
 				if(sz == 0){ bad = true; break; }                                       // the reference's scan finds no length either
 				cg = cig_add(cg, 1, (uint32_t)sz);
@@ -376,11 +451,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_sys(const Align8Args a, bsa
 		} else {
 			// deletion run: up the column until a row whose stored e is a fresh opening (bsalign.h:3730-3744)
 			int len = 1;
+			if(PW == 2 && rs.qb == 0){ bad = true; break; }          // (two pieces, column 0: the reference's own scan does not terminate there -- literal path)
 			for(;;){
 				const int r = rs.tb - len;
 				if(r < -1){ bad = true; break; }
 				if(r == -1){ if(PW != 0) bad = true; break; }       // linear gaps: an ordinary move; affine: the reference compares real scores there -- literal path
-				if(bit(r, rs.qb, 3)) break;
+				if(bit(r, rs.qb, dpl)) break;
 				len++;
 			}
 			if(bad) break;
@@ -416,7 +492,8 @@ hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_q
 	int nwv = (max_qlen >= 1024u && a.count < 5120u) ? 4 : 1;          // (87 VGPRs: five waves per SIMD, 5120 on the chip -- a wave per pair fills it from there on)
 	if(const char *e = bsa_env("BSA_ALIGN8_SYS_WAVES")){ const int v = atoi(e); if(v == 1 || v == 2 || v == 4 || v == 8) nwv = v; }
 #define SYS_LAUNCH(N_) do { if(pw == 0) hipLaunchKernelGGL((k_align8_fwd_sys<0, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); \
-		else hipLaunchKernelGGL((k_align8_fwd_sys<1, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); } while(0)
+		else if(pw == 1) hipLaunchKernelGGL((k_align8_fwd_sys<1, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); \
+		else hipLaunchKernelGGL((k_align8_fwd_sys<2, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); } while(0)
 	if(nwv == 8) SYS_LAUNCH(8); else if(nwv == 4) SYS_LAUNCH(4); else if(nwv == 2) SYS_LAUNCH(2); else SYS_LAUNCH(1);
 #undef SYS_LAUNCH
 	return hipGetLastError();
@@ -428,11 +505,13 @@ hipError_t bsa_launch_align8_trace_sys(const Align8Args &a, int pw, bsa_result_t
 	if(const char *e = bsa_env("BSA_ALIGN8_SYS_TRACE")) wave = e[0] != 'l';            // "lane" / "wave"
 	if(wave){
 		if(pw == 0) hipLaunchKernelGGL((k_align8_trace_sys<0, true>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt, slot_end);
-		else hipLaunchKernelGGL((k_align8_trace_sys<1, true>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt, slot_end);
+		else if(pw == 1) hipLaunchKernelGGL((k_align8_trace_sys<1, true>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt, slot_end);
+		else hipLaunchKernelGGL((k_align8_trace_sys<2, true>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt, slot_end);
 	} else {
 		const dim3 grid((a.count + 63u) / 64u);
 		if(pw == 0) hipLaunchKernelGGL((k_align8_trace_sys<0, false>), grid, dim3(64), 0, st, a, out, cig_cnt, slot_end);
-		else hipLaunchKernelGGL((k_align8_trace_sys<1, false>), grid, dim3(64), 0, st, a, out, cig_cnt, slot_end);
+		else if(pw == 1) hipLaunchKernelGGL((k_align8_trace_sys<1, false>), grid, dim3(64), 0, st, a, out, cig_cnt, slot_end);
+		else hipLaunchKernelGGL((k_align8_trace_sys<2, false>), grid, dim3(64), 0, st, a, out, cig_cnt, slot_end);
 	}
 	return hipGetLastError();
 }

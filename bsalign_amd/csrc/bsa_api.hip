@@ -821,7 +821,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		if(qlen[k] && tlen[k]) cells += (double)tlen[k] * (double)bw_ref(k);
 	}
 	for(size_t pos = 0; pos < n; pos++)
-		need[pos] = p->sys ? bsa_align8_sys_slot_bytes(qlen[order[pos]], tlen[order[pos]])
+		need[pos] = p->sys ? bsa_align8_sys_slot_bytes(qlen[order[pos]], tlen[order[pos]], p->pw)
 			: p->codes ? bsa_code_slot_bytes(tlen[order[pos]], bw / 16u, p->pw) : bsa_slot_bytes(tlen[order[pos]], bw_of(order[pos]) / 16u, p->pw);
 	p->cells = cells;
 	p->stage_bytes = qacc + tacc;

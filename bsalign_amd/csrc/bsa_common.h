@@ -211,7 +211,7 @@ extern thread_local const char *bsa_last_fwd_kernel, *bsa_last_trace_kernel;
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st);
 // whole-query bands above 256 columns, global mode: systolic wavefront + its own code layout and traceback (bsa_align8_sys.hip)
 bool bsa_align8_sys_supported(const Align8Args &a, int pw);
-size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen);
+size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen, int pw);
 hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_qlen, hipStream_t st);
 hipError_t bsa_launch_align8_trace_sys(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, const uint64_t *slot_end, hipStream_t st);
 hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);

@@ -383,9 +383,15 @@ def test_whole_query_bands_above_256_columns_run_the_systolic_wavefront(ctx, bw,
                 monkeypatch.setenv(knob, val)
             assert np.array_equal(out_v, out_r) and np.array_equal(st_v, st_r) and all(np.array_equal(a, b) for a, b in zip(cig_v, cig_r)), (knob, val, mode)
         monkeypatch.delenv(knob)
-    # two-piece gaps and scorings outside the guard keep the run-time-width kernel
-    _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, SCORINGS["twopiece"])
-    assert "sys" not in ctx.last_kernel_names()[0]
+    # two-piece gaps: eight facts per cell, the second gap chain and the second deletion state through the same kernels
+    for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+        _check(ctx, pairs, mode, bw, SCORINGS["twopiece"])
+        assert "k_align8_fwd_sys" in ctx.last_kernel_names()[0]
+    _check(ctx, pairs, S.MODE_GLOBAL, bw, (1, -3, -2, -2, -6, -1))
+    monkeypatch.setenv("BSA_ALIGN8_SYS_TRACE", "lane")
+    _check(ctx, pairs, S.MODE_OVERLAP, bw, SCORINGS["twopiece"])
+    monkeypatch.delenv("BSA_ALIGN8_SYS_TRACE")
+    # scorings outside the guard keep the run-time-width kernel
     _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, (10, -30, -20, -10, 0, 0))
     assert "sys" not in ctx.last_kernel_names()[0]
 
@@ -399,6 +405,8 @@ def test_whole_query_bands_10k(ctx):
     _check(ctx, pairs[:4], S.MODE_OVERLAP, 0, SCORINGS["paper"])          # example/run.sh "NoBand": align -M 2 -X 2 -O 4 -E 2, overlap
     assert "k_align8_fwd_sys" in ctx.last_kernel_names()[0]
     _check(ctx, pairs[:2], S.MODE_EXTEND, 0, SCORINGS["affine"])
+    _check(ctx, pairs[:3], S.MODE_OVERLAP, 0, SCORINGS["twopiece"])
+    assert "k_align8_fwd_sys" in ctx.last_kernel_names()[0]
 
 
 @pytest.mark.parametrize("bw", [0, 112])
