@@ -1,6 +1,6 @@
 // bsa_align8_sys.hip -- whole-query bands longer than 256 columns (the reference CLI's default `-W 0` on long reads, main.c:314-315;
 // the first command of example/run.sh): the 8-bit DP of banded_striped_epi8_seqalign_pairwise (bsalign.h:3854-4050) with the band
-// never moving, as a SYSTOLIC wavefront, and its traceback from 4-bit codes.
+// never moving, as a SYSTOLIC wavefront, and its traceback from 4-bit codes (two-piece gaps: 8-bit codes); all three modes.
 //
 // A band that covers the whole query never moves (bsalign.h:3338: qoff + bw >= qlen), every row has band offset 0, and inside the
 // exact-arithmetic guard of the compact path (bsa_align8_sys_supported = the score bounds of bsa_align8_codes_supported) none of
