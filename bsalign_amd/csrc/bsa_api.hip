@@ -761,7 +761,9 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	// LDS-resident run-time-width kernel.  BSA_ALIGN8_SYS=0 keeps the old dispatch.
 	bool sys = false; uint32_t max_qlen = 0;
 	for(size_t k = 0; k < n; k++) max_qlen = std::max(max_qlen, qlen[k]);
-	if(!widened && n > 0 && (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw > 256u && max_qlen <= 60000u && !(par->mode & BSA_MODE_ROWRECORDS)){
+	// (two-piece gaps: the register kernels stop at 128 columns, so the systolic kernel takes over from there)
+	const uint32_t sys_from = (bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)std::max(max_bw, 16u)) == 2) ? 128u : 256u;
+	if(!widened && n > 0 && (bw == 0 || !bsa_align8_supported_bw(bw)) && max_bw > sys_from && max_qlen <= 60000u && !(par->mode & BSA_MODE_ROWRECORDS)){
 		bool full = true;
 		if(bw != 0) for(size_t k = 0; k < n && full; k++) full = qlen[k] <= bw;
 		const char *se = bsa_env("BSA_ALIGN8_SYS"), *le = bsa_env("BSA_ALIGN8_LITERAL");
