@@ -396,6 +396,36 @@ def test_whole_query_bands_above_256_columns_run_the_systolic_wavefront(ctx, bw,
     assert "sys" not in ctx.last_kernel_names()[0]
 
 
+def test_whole_query_plan_with_mixed_lengths_on_device_pointers(ctx):
+    """the two-phase API does not sort pairs into width classes (the caller groups them): a plan over queries of 1 .. 3000 bases at
+    bandwidth 0 runs the systolic kernels for all of them, four waves per pair included -- same results as the oracle, pair by pair"""
+    import torch
+    import bsalign_amd as B
+    rng = np.random.default_rng(77)
+    pairs = _mk_pairs(rng, 96, [1, 2, 15, 63, 64, 65, 130, 300, 1000, 1100, 2500, 3000], eps_list=(0.0, 0.1, 0.3), ratios=(1.0, 0.5, 1.2))
+    seqs, qoff, qlen, toff, tlen = B.pack_pairs(pairs)
+    n = len(pairs)
+    for mode, sc in ((S.MODE_GLOBAL, SCORINGS["affine"]), (S.MODE_OVERLAP, SCORINGS["paper"]), (S.MODE_EXTEND, SCORINGS["twopiece"])):
+        par = B.make_params(mode, 0, *sc)
+        plan = B.AlignPlan(ctx, qoff, qlen, toff, tlen, par)
+        d_seqs = torch.from_numpy(seqs).cuda()
+        d_out = torch.zeros(n * 10, dtype=torch.int32, device="cuda")
+        d_cig = torch.empty(int(sum(len(q) + len(t) + 8 for q, t in pairs)), dtype=torch.int32, device="cuda")
+        d_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+        d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
+        plan.run(d_seqs, d_out, d_cig, d_off, d_st)
+        torch.cuda.synchronize()
+        assert "k_align8_fwd_sys" in ctx.last_kernel_names()[0]
+        out = d_out.cpu().numpy().reshape(n, 10); off = d_off.cpu().numpy(); st = d_st.cpu().numpy(); cig = d_cig.cpu().numpy().view(np.uint32)
+        for k, (q, t) in enumerate(pairs):
+            res, ocig, m = S.oracle_align(q, t, mode, 0, *sc)
+            if m == S.ORC_ERR_TRACE or (st[k] & B.ST_TRACE):
+                continue                      # (flagged pairs are the host entry's business: it hands them to the literal kernels)
+            assert st[k] == 0 and np.array_equal(out[k], res) and np.array_equal(cig[int(off[k]):int(off[k + 1])], ocig), (mode, k, len(q), len(t))
+        assert int((st != 0).sum()) <= 4
+        plan.close()
+
+
 def test_whole_query_bands_10k(ctx):
     """`bsalign align -W 0` on the benchmark's 10 kbp pairs (bench.py --length 10000 --bw -1)"""
     pairs = [S.synth_pair(k, 10000) for k in range(6)]
