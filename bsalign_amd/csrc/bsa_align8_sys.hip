@@ -71,7 +71,7 @@ bool bsa_align8_sys_supported(const Align8Args &a, int pw){
 // go through HBM as before, 64 columns per access.  Four waves cut a pair's latency (and the memory a full chip needs) by four.
 #define SYS_LAG 192
 template<int PW, int NWV>
-__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4))) k_align8_fwd_sys(const Align8Args a){
+__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(PW == 2 ? 2 : 4))) k_align8_fwd_sys(const Align8Args a){
 	using Ent = typename std::conditional<PW == 2, int4, int2>::type;        // a boundary cell: {H * 32 | q << 3, E * 32 [, Q * 32, -]}
 	auto ent = [](int p_, int e_, int q_) -> Ent { if constexpr(PW == 2) return make_int4(p_, e_, q_, 0); else return make_int2(p_, e_); };
 	__shared__ Ent rg[NWV + 1][256 + 2];            // rg[w]: the row above wave w's rows, rg[w + 1]: its own last row; {H * 32 | q << 3, E * 32} per column
