@@ -776,6 +776,13 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 			t.smax = smax; t.smin = smin;
 			const int pwa = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 16), pwb = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)max_bw);
 			sys = pwa == pwb && bsa_align8_sys_supported(t, pwb);
+			if(sys){
+				// the kernel carries scores times 32 in 32-bit registers: |H| <= (qlen + tlen) x the largest step
+				uint32_t max_tlen = 0;
+				for(size_t k = 0; k < n; k++) max_tlen = std::max(max_tlen, tlen[k]);
+				const long long step = std::max(std::max(-(long long)par->gapo1 - par->gape1, -(long long)par->gapo2 - par->gape2), std::max((long long)smax, -(long long)smin));
+				if(((long long)max_qlen + max_tlen) * std::max(step, 1ll) >= (1ll << 25)) sys = false;
+			}
 		}
 	}
 	bsa_align_plan *p = new bsa_align_plan();
