@@ -5,12 +5,12 @@
 // A band that covers the whole query never moves (bsalign.h:3338: qoff + bw >= qlen), every row has band offset 0, and inside the
 // exact-arithmetic guard of the compact path (bsa_align8_sys_supported = the score bounds of bsa_align8_codes_supported) none of
 // the reference's saturating int8 operations clamps: the stored differences are exact, i.e. the DP is the affine-gap recurrence on
-// absolute scores with the reference's own boundary rules.  No striping is needed for that: one wave runs one pair, lane l owns
-// target row 64 b + l of the current block of 64 rows and walks the query; at step t it computes column x = t - l, so the row above
-// (lane l - 1) delivered H(x, y-1) and E(x, y-1) exactly one step earlier -- a DPP wave shift per value and step, no LDS, no
-// waiting.  The last row of a block is the boundary of the next one: it leaves through a 128-entry LDS ring, 64 columns per
-// coalesced store, and comes back 64 columns per coalesced load into a second ring (lane 0's shift-in is the ring entry of the step:
-// the LDS read is the `old` operand of the DPP move).
+// absolute scores with the reference's own boundary rules.  No striping is needed for that: a wave owns 64 consecutive target rows, lane l
+// row 64 b + l, and walks the query; at step t it computes column x = t - l, so the row above (lane l - 1) delivered H(x, y-1) and
+// E(x, y-1) exactly one step earlier -- a DPP wave shift per value and step, no LDS, no waiting.  The last row of a wave's block is the
+// boundary of the rows below: it leaves through a 256-entry LDS ring -- to the next wave of the pair's workgroup (one or four waves per
+// pair, each 192 steps behind the one above, a barrier per 64 steps), or, below the last wave, to HBM and back, 64 columns per
+// coalesced access (lane 0's shift-in is the ring entry of the step: the LDS read is the `old` operand of the DPP move).
 // Kept literally (absolute-score form of the rules, cf. the POA wavefront bsa_poa_wf.hip):
 //   * row -1 (row_init, bsalign.h:2094-2140): H = gapo + gape (x + 1), e = -63; ubegs[0] = smax - smin with u[0] = gapo + gape + smin - smax
 //   * band cell 0 (bsalign.h:2899-2907) with rh = 0 on row 0 and gapo + gape y below (bsalign.h:3932-3946): h0 = rh - ubegs[0] + S, kept
@@ -21,7 +21,9 @@
 // rh + S), D (h == u + e; at column 0 in the frame mismatch of the re-based row: h - rh == u[0] + e[0]), R (h + gapo + gape >= f + gape:
 // an insertion reaching the next cell opens here), Od (the stored e is a fresh opening).  Row y, columns 32 k .. 32 k + 31: four
 // dwords {M, D, R, Od} of the wavefront steps t = x + (y & 63), 32 k <= t < 32 k + 32, step t at bit 31 - (t & 31); the 64 rows of a block
-// store their dwords of the same k side by side (one kilobyte per store instruction).
+// store their dwords of the same k side by side (one kilobyte per store instruction).  Overlap / extend mode: row -1 and the score left of
+// column 0 as row_init / the driver set them, the end cell searched for (last query column, then row_max of the last row in the reference's
+// striping).  Two-piece gaps: a second vertical state Q through the rings, a second horizontal chain G, eight facts per cell.
 #include "bsa_common.h"
 #include <type_traits>
 
