@@ -87,7 +87,7 @@ struct Group {
 	Dev d_in, d_rows, d_res;
 	// statistics
 	uint64_t batches = 0, launches = 0, programs = 0, tasks = 0, bytes_up = 0, bytes_down = 0;
-	double device_ms = 0, wall_ms = 0;
+	double device_ms = 0, wall_ms = 0, pack_ms = 0, devlock_ms = 0, wait_ms = 0;      // (BSA_BATCH_TIMING: packing, time under the device mutex, waiting for it)
 };
 // The windows are dealt into G groups (BSA_POA_GROUPS, default 2 from 32 windows on), each of which advances in lock-step on
 // its own; the device part of a batch runs under one mutex.  While one group's sweep is on the device (its host threads
@@ -167,6 +167,7 @@ static void run_batch_graph(Group *b){
 		const size_t o_n = 0, o_e = align16(o_n + nn * sizeof(bsa_poa_node_t)), o_c = align16(o_e + ne * sizeof(bsa_poa_edge_t)),
 			o_p = align16(o_c + nc * sizeof(bsa_poa_cand_t)), o_q = align16(o_p + np * sizeof(bsa_poa_prog_t)), in_bytes = o_q + qb + 64;
 		if(rc == BSA_OK && (!b->h_gin.need(in_bytes) || !b->d_gin.need(in_bytes))) rc = BSA_E_NOMEM;
+		const auto tp0 = std::chrono::steady_clock::now();
 		if(rc == BSA_OK){
 			uint8_t *h = (uint8_t*)b->h_gin.p;
 			bsa_poa_prog_t *hp = (bsa_poa_prog_t*)(h + o_p);
@@ -188,7 +189,9 @@ static void run_batch_graph(Group *b){
 #define BCHK(x) do { if(rc == BSA_OK && (x) != hipSuccess){ rc = BSA_E_HIP; (void)hipGetLastError(); } } while(0)
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		std::vector<bsa_poa_result_t> hres(np);
+		const auto tp1 = std::chrono::steady_clock::now();
 		std::unique_lock<std::mutex> devlk(b->parent->dev);
+		const auto tp2 = std::chrono::steady_clock::now();
 		BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
 		BCHK(hipMemcpyAsync(b->d_gin.p, b->h_gin.p, in_bytes, hipMemcpyHostToDevice, st));
 		BCHK(hipEventRecord(e0, st));
@@ -214,6 +217,11 @@ static void run_batch_graph(Group *b){
 			down += total * 4; hused += total;
 		}
 		devlk.unlock();
+		{
+			const auto tp3 = std::chrono::steady_clock::now();
+			b->pack_ms += std::chrono::duration<double, std::milli>(tp1 - tp0).count(); b->wait_ms += std::chrono::duration<double, std::milli>(tp2 - tp1).count();
+			b->devlock_ms += std::chrono::duration<double, std::milli>(tp3 - tp2).count();
+		}
 		if(rc == BSA_OK){ float ms = 0; if(hipEventElapsedTime(&ms, e0, e1) == hipSuccess) b->device_ms += ms; }
 		if(e0) (void)hipEventDestroy(e0);
 		if(e1) (void)hipEventDestroy(e1);
@@ -360,7 +368,16 @@ extern "C" int bsa_sweep_batcher_create(bsa_ctx_t *ctx, uint32_t participants, b
 	return BSA_OK;
 }
 
-extern "C" void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b){ delete b; }
+extern "C" void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b){
+	if(b && bsa_env("BSA_BATCH_TIMING")){
+		for(size_t g = 0; g < b->groups.size(); g++){
+			const Group *q = b->groups[g];
+			fprintf(stderr, "[bsa_sweep_batcher] group %zu: %llu batches, %llu launches: packing %.1f ms, waiting for the device %.1f ms, under the device mutex %.1f ms (kernels + upload %.1f ms), all inside batches %.1f ms\n",
+				g, (unsigned long long)q->batches, (unsigned long long)q->launches, q->pack_ms, q->wait_ms, q->devlock_ms, q->device_ms, q->wall_ms);
+		}
+	}
+	delete b;
+}
 
 extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
 		const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *res){
