@@ -119,8 +119,17 @@ static __device__ __forceinline__ void x_load_qcodes(const uint8_t *p, uint32_t 
 // and a cell has nine facts (bsa_common.h "COMPACT slot", 8 bits): M, D, D2, which chain equals h (I1, I2), R1, R2, Od1, Od2.
 // STATIC: every pair of the launch has a band that covers its whole query (Align8Args::static_band): the band never moves, so
 // the row is kept in place -- no speculative slide, no corrections of it, no band steering.
-template<int W, int L, int PW = 1, bool STATIC = false>
-static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint32_t first_pos, const uint32_t count, const uint32_t block){
+// Row segments (k_align8_fwd_xq): the rows [row0, row1) of the pairs (row0, row1 multiples of 8, so that no group of four code rows
+// and no group of L band offsets is open at a cut); `st` = the wave's state block (XS_WORDS(W, PW) x 64 dwords, dword r of lane l at
+// st[64 r + l]): loaded when row0 != 0, stored when a pair has rows left behind row1.  tid_base + threadIdx.x = the lane's index among
+// the launch's lanes (L consecutive ones share a pair).  The plain kernels pass row0 = 0, row1 = 0xFFFFFFF8, st = nullptr.
+#define XS_WORDS(W, PW) ((((PW) == 2) ? 3 : 2) * (W) + 11)
+// NWV: waves per workgroup.  The code dwords of a group of four rows wait in LDS (a lane's own sixteen dwords, no synchronisation) until
+// the group is complete and leaves as 16-byte pieces: kept in registers they were twelve of the 168 a wave may have at three per SIMD.
+// (Stored row by row as four-byte pieces the same launch takes 40 % longer.)
+template<int W, int L, int PW = 1, bool STATIC = false, int NWV = 4>
+static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint32_t first_pos, const uint32_t count, const uint32_t tid_base,
+		const uint32_t row0 = 0u, const uint32_t row1 = 0xFFFFFFF8u, uint32_t *st = nullptr){
 	constexpr int BW = 2 * L * W;
 	constexpr int WR = BW / 16, CR = 8 / L;
 	static_assert((L == 8 || L == 4) && W * L / 8 == WR && (CR == 1 || (CR == 2 && (W == 16 || W == 8))), "supported shapes");
@@ -133,7 +142,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	const int lt = threadIdx.x;
 	const int jl = lt & (L - 1);
 	const bool first = jl == 0, last = jl == L - 1;
-	const uint32_t g = (block * 256u + lt) / (uint32_t)L;
+	const uint32_t g = (tid_base + (uint32_t)lt) / (uint32_t)L;
 	const bool live = g < count;
 	const uint32_t ppos = first_pos + (live ? g : 0u);
 	const uint32_t pair = a.order[ppos];
@@ -177,8 +186,11 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	uint32_t PN;                  // packed int16: ubegs[b+1] - ubegs[0] - (b+1) W gape for b = jl (low) and jl + L (high)
 	uint32_t PM = 0;              // CR == 2: the same for the middle of the block (the end of its first reference block)
 	int HB;                       // ubegs[0]
+	uint32_t svU = 0, svNE = 0, svNQ = 0; // first cell of the row before the speculative slide (lane 0, low half: band position 0)
+	uint32_t rbeg = 0, mov = 0, i = row0;
+	int cand_sc = BSA_SCORE_MIN, cand_te = 0;       // overlap / extend: best end-of-query score this lane has seen, and its row
 	// ---- row -1 (bsalign.h:2094-2140)
-	{
+	if(row0 == 0u){
 		const int first_u = (int)(int8_t)(gapo1 + gape1 + a.smin - a.smax);
 		const int xp = (PW == 2) ? (gapo2 - gapo1) / (gape1 - gape2) : 0x7FFFFFFF;      // row -1 extends with piece 2 from here on (bsalign.h:2115-2125)
 		auto u_init = [&](int p) -> int { return (mode == BSA_MODE_OVERLAP) ? 0 : (p == 0) ? first_u : (p < xp) ? gape1 : gape2; };
@@ -201,9 +213,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			HB = a.smax - a.smin;
 		}
 	}
-	uint32_t svU = 0, svNE = 0, svNQ = 0; // first cell of the row before the speculative slide (lane 0, low half: band position 0)
 	// bring row -1 into the loop's form: slid by one cell, ubegs[0] not advanced
-	if constexpr (!STATIC){
+	if constexpr (!STATIC) if(row0 == 0u){
 		const uint32_t t0u = U[0], t0e = NE[0];
 #pragma unroll
 		for(int k = 0; k + 1 < W; k++){ U[k] = U[k + 1]; NE[k] = NE[k + 1]; }
@@ -219,16 +230,27 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		if constexpr (CR == 2) PM = x_add(x_add(PM, x_ashr8(U[W / 2 - 1])), GE16);
 		svU = t0u; svNE = t0e;
 	}
-
-	uint32_t rbeg = 0, mov = 0, i = 0;
-	uint32_t hist[3][ND];         // code dwords of the earlier rows of the current group of four
+	if(row0 != 0u){
+		// the state the previous segment left (plain loads behind the acquire of k_align8_fwd_xq)
+		const uint32_t *sp = st + (lt & 63);
+		int r = 0;
 #pragma unroll
-	for(int r = 0; r < 3; r++){ for(int q = 0; q < ND; q++) hist[r][q] = 0u; }
+		for(int k = 0; k < W; k++) U[k] = sp[64 * r++];
+#pragma unroll
+		for(int k = 0; k < W; k++) NE[k] = sp[64 * r++];
+		if constexpr (PW == 2){
+#pragma unroll
+			for(int k = 0; k < W; k++) NQ2[k] = sp[64 * r++];
+		}
+		PN = sp[64 * r++]; PM = sp[64 * r++]; HB = (int)sp[64 * r++]; svU = sp[64 * r++]; svNE = sp[64 * r++]; svNQ = sp[64 * r++];
+		rbeg = sp[64 * r++]; mov = sp[64 * r++]; cand_sc = (int)sp[64 * r++]; cand_te = (int)sp[64 * r++];
+	}
+	__shared__ uint32_t x_stage[NWV][16][64];       // [wave][4 q + row of the group (CWD == 1) | 4 row + dword (CWD == 2)][lane]
+	uint32_t *const stg = &x_stage[(NWV > 1) ? (lt >> 6) : 0][0][lt & 63];
 	int begq = 0;
-	int cand_sc = BSA_SCORE_MIN, cand_te = 0;       // overlap / extend: best end-of-query score this lane has seen, and its row
-	if(tlen != 0u && first) begs[0] = 0;
+	if(tlen != 0u && first && row0 == 0u) begs[0] = 0;
 	uint64_t twin = 0;
-	if(tlen) __builtin_memcpy(&twin, tp, 8);
+	if(row0 < tlen) __builtin_memcpy(&twin, tp + row0, 8);
 	// STATIC: the band never moves, so a lane's query codes are the same on every row -- loaded once
 	uint32_t sqlo[STATIC ? NQ : 1], sqhi[STATIC ? NQ : 1];
 	if constexpr (STATIC){
@@ -242,7 +264,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	const int rby_lane = (lt & (64 - L)) << 2;                   // byte address of lane 0 of this group for ds_bpermute
 	const uint32_t kd1 = last ? 0x01000000u : 0u;          // band cell bw - 1 after a slide by one: x == bw, no deletion there (bsalign.h:3672-3678)
 
-	while(__any(i < tlen)){
+	while(i < row1 && __any(i < tlen)){
 		const bool act = i < tlen;
 		if(!STATIC && mode == BSA_MODE_GLOBAL && (i & (uint32_t)(L - 1)) == 0u)
 			rby_tab = (int)((1.0 * (double)(i + (uint32_t)jl) / (double)tlen) * (double)qlen);      // bsalign.h:4009, row i + jl
@@ -523,9 +545,15 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				cur[2] = __builtin_amdgcn_perm(xd, xm, 0x07060302u); cur[3] = __builtin_amdgcn_perm(xo, xr, 0x07060302u);     // block jl + L
 			}
 			const uint32_t ri = i & 3u;                       // (uniform over the wave: all pairs are at row i)
-			if(ri == 0u){ for(int q = 0; q < ND; q++) hist[0][q] = cur[q]; }
-			else if(ri == 1u){ for(int q = 0; q < ND; q++) hist[1][q] = cur[q]; }
-			else if(ri == 2u){ for(int q = 0; q < ND; q++) hist[2][q] = cur[q]; }
+			if constexpr (CWD == 1){
+				uint32_t *const sr = stg + 64u * ri;
+#pragma unroll
+				for(int q = 0; q < ND; q++) sr[256 * q] = cur[q];
+			} else {
+				uint32_t *const sr = stg + 256u * ri;
+#pragma unroll
+				for(int q = 0; q < ND; q++) sr[64 * q] = cur[q];
+			}
 			if(act && (ri == 3u || i + 1u == tlen)){
 				uint32_t *gp = (uint32_t*)rowp + bsa_code_off(i & ~3u, 0u, CWD);       // block y of this group: gp[4 CWD y], rows then dwords
 				if constexpr (CWD == 1){
@@ -533,8 +561,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					for(int q = 0; q < ND; q++){
 						constexpr int RBH = (WR == 8) ? NACC : (WR == 4 && W == 8) ? 2 : 0;      // reference blocks (= code dwords) per half, where a half holds whole ones
 						const uint32_t blk = RBH ? (uint32_t)(RBH * (jl + L * (q / RBH)) + q % RBH) : (uint32_t)(jl + L * q);
-						uint4 t; t.x = hist[0][q]; t.y = hist[1][q]; t.z = hist[2][q]; t.w = cur[q];
-						if(ri == 0u) t.x = cur[q]; else if(ri == 1u) t.y = cur[q]; else if(ri == 2u) t.z = cur[q];
+						uint4 t; t.x = stg[256 * q]; t.y = stg[256 * q + 64]; t.z = stg[256 * q + 128]; t.w = stg[256 * q + 192];
 						*(uint4*)(gp + 4u * blk) = t;
 					}
 				} else {
@@ -542,11 +569,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					for(int hf = 0; hf < 2; hf++){
 						const uint32_t blk = (uint32_t)(jl + L * hf);
 						uint4 t0, t1;              // rows 0, 1 and rows 2, 3 of the block, two dwords each
-						t0.x = hist[0][2 * hf]; t0.y = hist[0][2 * hf + 1]; t0.z = hist[1][2 * hf]; t0.w = hist[1][2 * hf + 1];
-						t1.x = hist[2][2 * hf]; t1.y = hist[2][2 * hf + 1]; t1.z = cur[2 * hf]; t1.w = cur[2 * hf + 1];
-						if(ri == 0u){ t0.x = cur[2 * hf]; t0.y = cur[2 * hf + 1]; }
-						else if(ri == 1u){ t0.z = cur[2 * hf]; t0.w = cur[2 * hf + 1]; }
-						else if(ri == 2u){ t1.x = cur[2 * hf]; t1.y = cur[2 * hf + 1]; }
+						t0.x = stg[64 * (2 * hf)]; t0.y = stg[64 * (2 * hf + 1)]; t0.z = stg[256 + 64 * (2 * hf)]; t0.w = stg[256 + 64 * (2 * hf + 1)];
+						t1.x = stg[512 + 64 * (2 * hf)]; t1.y = stg[512 + 64 * (2 * hf + 1)]; t1.z = stg[768 + 64 * (2 * hf)]; t1.w = stg[768 + 64 * (2 * hf + 1)];
 						*(uint4*)(gp + 8u * blk) = t0; *(uint4*)(gp + 8u * blk + 4u) = t1;
 					}
 				}
@@ -661,25 +685,42 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		i++;
 		if((i & 7u) == 0u && i < tlen) __builtin_memcpy(&twin, tp + i, 8);
 	}
+	if(st != nullptr && row1 < tlen){
+		// write-through stores (sc1): the next segment usually runs on another CU, often on another XCD, and a release fence here
+		// would write back every dirty line of this XCD's L2 -- the half-filled lines of the code rows of 400 waves -- once per item
+		uint32_t *sp = st + (lt & 63);
+		int r = 0;
+		auto put = [&](uint32_t v){ __hip_atomic_store(sp + 64 * r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r++; };
+#pragma unroll
+		for(int k = 0; k < W; k++) put(U[k]);
+#pragma unroll
+		for(int k = 0; k < W; k++) put(NE[k]);
+		if constexpr (PW == 2){
+#pragma unroll
+			for(int k = 0; k < W; k++) put(NQ2[k]);
+		}
+		put(PN); put(PM); put((uint32_t)HB); put(svU); put(svNE); put(svNQ);
+		put(rbeg); put(mov); put((uint32_t)cand_sc); put((uint32_t)cand_te);
+	}
 }
 
 template<int W, int L>
 __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
-	x_forward<W, L>(a, a.first, a.count, blockIdx.x);
+	x_forward<W, L>(a, a.first, a.count, blockIdx.x * 256u);
 }
 // linear gaps (piecewise 0)
 template<int W, int L>
 __global__ void __launch_bounds__(256) k_align8_fwd_x0(const Align8Args a){
-	x_forward<W, L, 0>(a, a.first, a.count, blockIdx.x);
+	x_forward<W, L, 0>(a, a.first, a.count, blockIdx.x * 256u);
 }
 // two-piece gaps (bandwidth 128): 8 bits per band cell
 __global__ void __launch_bounds__(256) k_align8_fwd_x2(const Align8Args a){
-	x_forward<8, 8, 2>(a, a.first, a.count, blockIdx.x);
+	x_forward<8, 8, 2>(a, a.first, a.count, blockIdx.x * 256u);
 }
 // bands that cover their whole queries (Align8Args::static_band): the row stays in place, no steering
 template<int W, int L, int PW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_x_static(const Align8Args a){
-	x_forward<W, L, PW, true>(a, a.first, a.count, blockIdx.x);
+	x_forward<W, L, PW, true>(a, a.first, a.count, blockIdx.x * 256u);
 }
 
 // Bandwidth 128, a batch that is not a whole number of four-lane rounds: the first nb8 blocks take the last n8 pairs
@@ -687,8 +728,78 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
 // first and the dispatcher hands the long ones to whichever CU has room, so pairs of one length no longer finish in
 // lock-step rounds with a nearly empty last one.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_x_mix(const Align8Args a, const uint32_t nb8, const uint32_t n8){
-	if(blockIdx.x < nb8) x_forward<8, 8>(a, a.first + (a.count - n8), n8, blockIdx.x);
-	else x_forward<16, 4>(a, a.first, a.count - n8, blockIdx.x - nb8);
+	if(blockIdx.x < nb8) x_forward<8, 8>(a, a.first + (a.count - n8), n8, blockIdx.x * 256u);
+	else x_forward<16, 4>(a, a.first, a.count - n8, (blockIdx.x - nb8) * 256u);
+}
+
+// PERSISTENT form for batches of more than one generation of resident waves.  A pair's rows are serial and pairs of one length finish
+// together, so a launch of whole pairs ends with a generation that is mostly empty (100 000 pairs = 6250 waves of 16 pairs on 3072
+// wave slots: two full generations and 106 waves alone on the chip for a third).  Here the work item is a SEGMENT of rows of the 16
+// pairs of a wave: every wave of the launch takes ONE item (segment s of group g, all groups' segment s before any segment s + 1) off a
+// counter, takes the band state the previous segment left in memory (XS_WORDS dwords a lane: the two row planes, the block offsets,
+// the band position and its pending move), runs the rows and hands the state on.  The launch then ends within one segment of the
+// ideal.  ctl[0] = next item, ctl[16 + g] = segments of group g that are done (release / acquire at agent scope: the next segment
+// usually runs on another CU).  An item only ever waits for an item that was handed out before it, i.e. one that is running.
+struct XQArgs { uint32_t *ctl; uint32_t *state; uint32_t ngroups, nseg, seg_rows; };
+template<int W, int L, int PW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_xq(const Align8Args a, const XQArgs q){
+	// one item per wave (a block is a wave: the dispatcher refills a wave slot the moment it is free); the ticket, not the block
+	// index, names the item, so that an item's predecessor is always one that has started
+	uint32_t id = 0;
+	if(threadIdx.x == 0u) id = atomicAdd(q.ctl, 1u);
+	id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+	const uint32_t s = id / q.ngroups, g = id - s * q.ngroups;
+	uint32_t *done = q.ctl + 16u + g;
+	if(s != 0u){
+		if(threadIdx.x == 0u){ while(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s) __builtin_amdgcn_s_sleep(16); }
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
+	x_forward<W, L, PW, false, 1>(a, a.first, a.count, g * 64u, s * q.seg_rows, (s + 1u) * q.seg_rows, q.state + (size_t)g * (XS_WORDS(W, PW) * 64u));
+	if(s + 1u < q.nseg){
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the state's write-through stores have arrived
+		if(threadIdx.x == 0u) __hip_atomic_store(done, s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+static int x_cus(){
+	static const int cus = [](){
+		int dev = 0, v = 0;
+		if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+		return v;
+	}();
+	return cus;
+}
+// bytes of a.xq the persistent form needs for `count` pairs (0: the shape has no persistent form)
+size_t bsa_align8_xq_bytes(uint32_t bw, int pw, uint32_t count){
+	const uint32_t W = bw / 16u;
+	if(pw > 1 || !(W == 4u || W == 8u || W == 16u)) return 0;
+	const uint32_t L = (W == 16u) ? 8u : 4u, Wl = (W == 4u) ? 8u : 16u;          // lanes per pair, cells per lane and half
+	const size_t groups = ((size_t)count * L + 63u) / 64u;
+	return (16u + groups) * 4u + 256u + groups * (size_t)(XS_WORDS(Wl, pw) * 64u * 4u);
+}
+// true when the launch was made
+template<int W, int L, int PW>
+static bool x_launch_xq(const Align8Args &a, hipStream_t st, hipError_t &err){
+	const char *qe = bsa_env("BSA_ALIGN8_XQ");
+	if(!a.xq || (qe && qe[0] == '0')) return false;
+	const uint32_t groups = (uint32_t)(((size_t)a.count * L + 63u) / 64u);
+	const uint32_t workers = (uint32_t)x_cus() * 12u;          // three waves per SIMD
+	if(!(qe && qe[0] == '1') && groups <= workers) return false;       // one generation: whole pairs
+	const size_t ctl_bytes = ((16u + (size_t)groups) * 4u + 255u) & ~(size_t)255u;
+	if(ctl_bytes + (size_t)groups * (XS_WORDS(W, PW) * 64u * 4u) > a.xq_bytes) return false;
+	// segments: the last item of the launch should be a few percent of a wave slot's share
+	uint32_t nseg = (uint32_t)std::min<uint64_t>(64u, (48ull * workers + groups - 1u) / groups);
+	uint32_t seg_rows = ((a.max_tlen + nseg - 1u) / std::max(nseg, 1u) + 7u) & ~7u;
+	if(const char *se = bsa_env("BSA_ALIGN8_XQ_SEG")){ const long v = atol(se); if(v >= 8) seg_rows = ((uint32_t)v + 7u) & ~7u; }
+	seg_rows = std::max(seg_rows, 64u);
+	nseg = std::max(1u, (a.max_tlen + seg_rows - 1u) / seg_rows);
+	XQArgs q;
+	q.ctl = a.xq; q.state = (uint32_t*)((uint8_t*)a.xq + ctl_bytes); q.ngroups = groups; q.nseg = nseg; q.seg_rows = seg_rows;
+	err = hipMemsetAsync(a.xq, 0, ctl_bytes, st);
+	if(err != hipSuccess) return true;
+	hipLaunchKernelGGL((k_align8_fwd_xq<W, L, PW>), dim3(groups * nseg), dim3(64), 0, st, a, q);
+	err = hipGetLastError();
+	bsa_last_fwd_kernel = "k_align8_fwd_xq (exact-arithmetic forward DP in row segments, 4-bit traceback codes)";
+	return true;
 }
 
 // Exact arithmetic is the reference's arithmetic only while nothing saturates: the guard of the compact path
@@ -734,7 +845,11 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 		hipLaunchKernelGGL(k_align8_fwd_x2, dim3(b8), dim3(256), 0, st, a);
 		return hipGetLastError();
 	}
+	hipError_t qerr = hipSuccess;
 	if(pw == 0){
+		if(a.bw == 64u && !x8_at_64() && x_launch_xq<8, 4, 0>(a, st, qerr)) return qerr;
+		if(a.bw == 128u && x_launch_xq<16, 4, 0>(a, st, qerr)) return qerr;
+		if(a.bw == 256u && x_launch_xq<16, 8, 0>(a, st, qerr)) return qerr;
 		switch(a.bw / 16){
 			case 4:
 				if(x8_at_64()) hipLaunchKernelGGL((k_align8_fwd_x0<4, 8>), dim3(b8), dim3(256), 0, st, a);
@@ -746,6 +861,9 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 		}
 		return hipGetLastError();
 	}
+	if(a.bw == 64u && !x8_at_64() && x_launch_xq<8, 4, 1>(a, st, qerr)) return qerr;
+	if(a.bw == 128u && !bsa_env("BSA_ALIGN8_X_LANES") && !bsa_env("BSA_ALIGN8_X_N8") && x_launch_xq<16, 4, 1>(a, st, qerr)) return qerr;
+	if(a.bw == 256u && x_launch_xq<16, 8, 1>(a, st, qerr)) return qerr;
 	switch(a.bw / 16){
 		case 4:      // bandwidth 64: four lanes per pair (16 pairs per wave, eight cells per half); BSA_ALIGN8_X_LANES=8: eight lanes
 			if(x8_at_64()) hipLaunchKernelGGL((k_align8_fwd_x<4, 8>), dim3(b8), dim3(256), 0, st, a);

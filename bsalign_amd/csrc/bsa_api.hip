@@ -40,6 +40,7 @@ struct bsa_ctx {
 	size_t budget_last = 0;          // last answer of ctx_ws_budget
 	void *keep[2] = {nullptr, nullptr}; size_t keep_bytes[2] = {0, 0}; bool keep_busy[2] = {false, false};
 	void *scratch[2] = {nullptr, nullptr}; size_t scratch_bytes[2] = {0, 0};      // grown on demand, kept (bsa_ctx_scratch_internal): the POA rows
+	void *xq = nullptr; size_t xq_bytes = 0;          // control words + band states of the persistent 8-bit forward kernel (k_align8_fwd_xq), grown on demand
 };
 
 static const size_t BSA_KEEP_MAX = (size_t)64 << 20;      // larger requests are plain allocations
@@ -117,6 +118,7 @@ extern "C" void bsa_ctx_destroy(bsa_ctx_t *c){
 	if(c->ws) (void)hipFree(c->ws);
 	for(int k = 0; k < 2; k++) if(c->keep[k]) (void)hipFree(c->keep[k]);
 	for(int k = 0; k < 2; k++) if(c->scratch[k]) (void)hipFree(c->scratch[k]);
+	if(c->xq) (void)hipFree(c->xq);
 	if(c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
 	if(c->own_stream) (void)hipStreamDestroy(c->own_stream);
 	delete c;
@@ -393,7 +395,7 @@ __global__ void __launch_bounds__(256) k_cigar_final(const uint32_t *tmp, const 
 // plans: metadata + staging buffers shared by both paths, chunk pipeline
 // ------------------------------------------------------------------------------------------------
 struct Sub   { uint32_t first, count, bw; };               // a run of one launch class inside a chunk (forward launches)
-struct Chunk { uint32_t first, count, bw; size_t bytes; uint32_t sub0 = 0, nsub = 0; };      // bw = BSA_MIXED_BW when the chunk holds several classes
+struct Chunk { uint32_t first, count, bw; size_t bytes; uint32_t sub0 = 0, nsub = 0; uint32_t max_tlen = 0; };      // bw = BSA_MIXED_BW when the chunk holds several classes
 #define BSA_MIXED_BW 0xFFFFFFFFu
 
 struct PlanBase {
@@ -835,6 +837,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	p->cells = cells;
 	p->stage_bytes = qacc + tacc;
 	int rc = plan_chunks(p, order, need, bwv, slot, slot_end);
+	for(Chunk &ch : p->chunks) if(ch.count) ch.max_tlen = tlen[order[ch.first]];          // (ordered by target length, longest first)
 	if(rc == BSA_OK) rc = plan_common_alloc(p, qoff, qlen, toff, tlen, qpoff, tpoff, slot, slot_end, order, qacc, tacc);
 	if(rc != BSA_OK){ plan_free(p); return rc; }
 	*out = p;
@@ -892,9 +895,19 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		: fwd_x ? "k_align8_fwd_x (exact-arithmetic forward DP, 4-bit traceback codes)" : codes ? "k_align8_fwd_pk<.,.,true> (packed forward DP, 4-bit traceback codes)"
 		: generic ? "k_align8_fwd_gen (run-time bandwidth, row records)" : "k_align8_fwd_pk / k_align8_fwd (row records)";
 	c->trace_name = sys ? "k_align8_trace_sys" : codes ? "" : "k_align8_backcal";
-	bsa_last_trace_kernel = nullptr;
+	bsa_last_trace_kernel = nullptr; bsa_last_fwd_kernel = nullptr;
+	if(codes && fwd_x && !p->static_band){
+		// the persistent form of the forward kernel hands band states from one row segment to the next through this buffer
+		size_t need = 0;
+		for(const Chunk &ch : p->chunks) need = std::max(need, bsa_align8_xq_bytes(p->bw, pw, ch.count));
+		if(need > c->xq_bytes){
+			if(c->xq){ HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->aux_stream)); (void)hipFree(c->xq); c->xq = nullptr; c->xq_bytes = 0; }
+			if(hipMalloc(&c->xq, need) == hipSuccess) c->xq_bytes = need; else { c->xq = nullptr; (void)hipGetLastError(); }      // (without it the launcher takes the plain kernels)
+		}
+		a.xq = (uint32_t*)c->xq; a.xq_bytes = c->xq_bytes;
+	}
 	auto fwd = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
-		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
+		Align8Args b = a; b.first = ch.first; b.count = ch.count; b.rows = half; b.max_tlen = ch.max_tlen;
 		if(sys) HIPCHK(c, bsa_launch_align8_fwd_sys(b, pw, p->max_qlen, s));
 		else if(codes && fwd_x) HIPCHK(c, bsa_launch_align8_fwd_x(b, pw, s));
 		else if(codes) HIPCHK(c, bsa_launch_align8_fwd_codes(b, pw, s));
@@ -911,6 +924,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	};
 	const int rc8 = run_pipeline(p, want_cig, d_cigar, cigar_cap_words, d_cigar_off, fwd, trace);
 	if(codes && bsa_last_trace_kernel) c->trace_name = bsa_last_trace_kernel;
+	if(codes && fwd_x && bsa_last_fwd_kernel) c->fwd_name = bsa_last_fwd_kernel;
 	return rc8;
 }
 

@@ -34,6 +34,8 @@ struct Align8Args {
 	uint32_t rowb;              // bytes of one row group = 16 tiles (see the layout note below)
 	uint32_t static_band;       // every pair's band covers its whole query (qlen <= bw): the band never moves (k_align8_fwd_x_static)
 	uint32_t ref_bw;            // compact path, a whole-query band widened to `bw` (bsa_api.hip): the reference's own bandwidth (1 = per pair roundup(qlen, 16)); 0 = bw
+	uint32_t max_tlen;          // longest target of the launch (pairs are ordered by target length: that of position `first`)
+	uint32_t *xq; uint64_t xq_bytes;    // control words + band states of the persistent forward kernel (k_align8_fwd_xq), or null
 	int32_t  mode;
 	int32_t  gapo1, gape1, gapo2, gape2;
 	int32_t  smax, smin;        // max / min of the score matrix (bsalign.h:3868-3873)
@@ -209,6 +211,7 @@ hipError_t bsa_launch_diagdp(const uint8_t *d_planes, const bsa_diagdp_prob_t *d
 // the kernels the launchers picked last (this thread), for bsa_ctx_last_kernel_name
 extern thread_local const char *bsa_last_fwd_kernel, *bsa_last_trace_kernel;
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st);
+size_t bsa_align8_xq_bytes(uint32_t bw, int pw, uint32_t count);       // what Align8Args::xq must hold for a launch of `count` pairs (0: no persistent form)
 // whole-query bands above 256 columns, global mode: systolic wavefront + its own code layout and traceback (bsa_align8_sys.hip)
 bool bsa_align8_sys_supported(const Align8Args &a, int pw);
 size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen, int pw);

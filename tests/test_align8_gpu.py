@@ -89,6 +89,24 @@ def test_bandwidth_zero_is_full_query(ctx):
     _check(ctx, pairs, S.MODE_GLOBAL, 0, SCORINGS["twopiece"])
 
 
+@pytest.mark.parametrize("seg", ["64", "200"])
+@pytest.mark.parametrize("scname", ["affine", "linear", "paper"])
+def test_row_segments_of_the_persistent_forward_kernel(ctx, monkeypatch, seg, scname):
+    """k_align8_fwd_xq: a pair's rows in segments that hand the band state on through memory (forced here: BSA_ALIGN8_XQ=1
+    takes it for any batch, BSA_ALIGN8_XQ_SEG sets the rows per segment) -- lengths around the cuts, all three modes and widths"""
+    monkeypatch.setenv("BSA_ALIGN8_XQ", "1")
+    monkeypatch.setenv("BSA_ALIGN8_XQ_SEG", seg)
+    rng = np.random.default_rng(4100 + int(seg) + len(scname))
+    cut = int(seg)
+    lens = [1, 7, 8, 9, cut - 1, cut, cut + 1, 2 * cut - 1, 2 * cut, 2 * cut + 8, 3 * cut + 5, 1000, 1777]
+    pairs = _mk_pairs(rng, 120, lens)
+    for bw in (128, 64, 256):
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+            _check(ctx, pairs, mode, bw, SCORINGS[scname])
+            fwd, _ = ctx.last_kernel_names()
+            assert "k_align8_fwd_xq" in fwd, fwd
+
+
 def test_synthetic_10k_bw128(ctx):
     """the benchmark shape (C2): 10 kbp synthetic pairs, global, bw 128"""
     pairs = [S.synth_pair(k, 10000) for k in range(24)]
