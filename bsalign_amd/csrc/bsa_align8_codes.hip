@@ -360,9 +360,14 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_lds(const Align8Args 
 #define CWV_QWIN 512
 // W = 4, 8, 16 (bandwidth 64, 128, 256).  The window is always 32 cells: eight blocks of one code dword at W = 4 (two 16-byte
 // loads per lane), four at W = 8, two blocks of two dwords at W = 16; ND dwords per row in LDS, stride ND + 1.
-template<int W>
+// FMT 1 (W = 8): code format 1 of bsa_common.h -- M | R << 8 | eight two-bit fields << 16 (min(h - (u + e), -gapo): 0 = D, -gapo = Od).  The fields
+// of the window's 32 cells stay interleaved in two registers (bit-reversed, cell c of its half at bits 2c, 2c + 1: the field's high bit first) and
+// a step shifts the lane's field out of them; the one literal cell (query column 0 of a row whose band starts there) is answered from a per-tile copy.
+template<int W, int FMT = 0>
 __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
 	static_assert(W == 4 || W == 8 || W == 16, "bandwidth 64, 128, 256");
+	static_assert(FMT == 0 || W == 8, "code format 1: bandwidth 128");
+	const uint32_t NGO = (uint32_t)(-a.gapo1), NGOS = ((NGO & 1u) << 1) | (NGO >> 1);         // -gapo, and with its two bits swapped
 	constexpr int bw = 16 * W, ND = (W == 4) ? 8 : 4, STR = ND + 1;
 	constexpr uint32_t CW = (W == 16) ? 2u : 1u, RB = 64u * CW, FULL = (W == 16) ? 0xFFFFu : ((1u << W) - 1u);
 	constexpr int NB = 32 / W, B0MAX = 16 - NB;                        // blocks in the window, last window start
@@ -510,10 +515,21 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		if(T - 64 >= 0){ fetch_codes(T - 64, nxtB, x + (T - y) - 64, nxtC); fetch_begs(T - 128, nx2B); }
 		// the lane's row as four 32-bit planes in CELL order (bit c = window cell c = band cell 8 b0 + c): the bytes of a plane
 		// gathered last block first, then all 32 bits reversed (inside a block cell k is bit 7 - k)
-		uint32_t RM, RD, RR, RO;
+		uint32_t RM, RD = 0, RR, RO = 0;
+		uint32_t X0 = 0, X1 = 0, qc = 0xFFFFFFFFu, qinfo = 0;        // FMT 1
 		{
 			const uint32_t *mr = &tile[lane * STR];
-			if constexpr (W == 8){
+			if constexpr (W == 8 && FMT == 1){
+				const uint32_t d0 = mr[0], d1 = mr[1], d2 = mr[2], d3 = mr[3];
+				auto plane = [&](uint32_t j) -> uint32_t {
+					const uint32_t lo = __builtin_amdgcn_perm(d2, d3, 0x0c0c0000u | ((4u + j) << 8) | j);
+					const uint32_t hi = __builtin_amdgcn_perm(d0, d1, ((4u + j) << 24) | (j << 16) | 0x0c0cu);
+					return __builtin_bitreverse32(lo | hi);
+				};
+				RM = plane(0); RR = plane(1);
+				X0 = __builtin_bitreverse32(__builtin_amdgcn_perm(d0, d1, 0x07060302u));      // cells 0 .. 7 from d0's fields (low 16 bits), 8 .. 15 from d1's
+				X1 = __builtin_bitreverse32(__builtin_amdgcn_perm(d2, d3, 0x07060302u));
+			} else if constexpr (W == 8){
 				const uint32_t d0 = mr[0], d1 = mr[1], d2 = mr[2], d3 = mr[3];
 				auto plane = [&](uint32_t j) -> uint32_t {
 					const uint32_t lo = __builtin_amdgcn_perm(d2, d3, 0x0c0c0000u | ((4u + j) << 8) | j);
@@ -539,6 +555,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			}
 		}
 		const int cb = bc + W * b0;                                     // column of window cell 0
+		if constexpr (FMT == 1){
+			// the literal cell: window cell 0 when it is query column 0 of a row whose band starts there (bit 0: Od, bit 1: D after the reversal)
+			if(cb == 0 && bc == 0){ qc = 0u; qinfo = ((X0 >> 1) & 1u) | ((X0 & 1u) << 1); }
+		}
 		if(T - (int)lane < 0) RM = 0u;                                  // rows above the target: never a match (the walk ends before them)
 		// prior_match is dropped at the first column of the previous row's band (bsalign.h:3761-3764): that cell is taken out of
 		// the M plane and left to the literal step
@@ -554,7 +574,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const uint64_t mM = __ballot((int)(RM << (sh & 31u)) < 0) & __ballot(sh < 32u);
 			const uint64_t mNE = __ballot(qb != tbs);
 			const uint32_t c = (31u - sh) & 31u;
-			const uint32_t info = ((RD >> c) & 1u) | (((RO >> c) & 1u) << 1);      // D, Od of the lane's cell
+			uint32_t info;                                                          // D, Od of the lane's cell
+			if constexpr (FMT == 1){
+				const uint32_t raw = (((c & 16u) ? X1 : X0) >> ((c & 15u) * 2u)) & 3u;
+				info = (raw == 0u ? 1u : 0u) | (raw == NGOS ? 2u : 0u);
+				info = (c == qc) ? qinfo : info;
+			} else info = ((RD >> c) & 1u) | (((RO >> c) & 1u) << 1);
 			const uint64_t k0bit = 1ull << k0;
 			uint64_t stopm = ~(mM | (k0bit - 1ull));
 			if(dlen){
@@ -611,6 +636,13 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 				const uint32_t *rp = codes + bsa_code_off((uint32_t)y, blk, CW);
 				const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rp[0]);
 				Code cc;
+				if constexpr (FMT == 1){
+					// (d, o: only the bit of cell kk of block yb is ever looked at -- the walker's own cell)
+					cc.m = w0 & 0xFFu; cc.r = (w0 >> 8) & 0xFFu;
+					const uint32_t fld = (w0 >> (30u - 2u * kk)) & 3u;
+					if(pk == 0u && x == 0) { cc.d = (fld & 1u) ? bit : 0u; cc.o = (fld & 2u) ? bit : 0u; }      // the literal cell (bsa_common.h)
+					else { cc.d = (fld == 0u) ? bit : 0u; cc.o = (fld == NGO) ? bit : 0u; }
+				} else
 				if constexpr (W == 4){ cc.m = w0 & 0xFu; cc.d = (w0 >> 4) & 0xFu; cc.r = (w0 >> 8) & 0xFu; cc.o = (w0 >> 12) & 0xFu; }
 				else if constexpr (W == 8){ cc.m = w0 & 0xFFu; cc.d = (w0 >> 8) & 0xFFu; cc.r = (w0 >> 16) & 0xFFu; cc.o = w0 >> 24; }
 				else { const uint32_t w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rp[1]); cc.m = w0 & 0xFFFFu; cc.d = w0 >> 16; cc.r = w1 & 0xFFFFu; cc.o = w1 >> 16; }
@@ -1306,8 +1338,15 @@ static void launch_trace_lds(const Align8Args &a, bsa_result_t *out, uint32_t *c
 	}
 }
 
+// code format 1 (bsa_common.h) is read by the one-walk-per-wave kernel at bandwidth 128 only
+bool bsa_align8_trace_reads_do2(const Align8Args &a, int pw){
+	const char *se = bsa_env("BSA_ALIGN8_TRACE_SIMPLE"), *we = bsa_env("BSA_ALIGN8_TRACE_WAVE");
+	return pw == 1 && a.bw == 128u && !(se && se[0] == '1') && !(we && we[0] == '0');
+}
+
 hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
+	if(a.code_fmt == 1u && !bsa_align8_trace_reads_do2(a, pw)) return hipErrorInvalidValue;
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;
 		const char *we = bsa_env("BSA_ALIGN8_TRACE_WAVE");              // =0: the pair-per-lane walker
@@ -1331,6 +1370,7 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 			break;
 		case 8:
 			if(simple) hipLaunchKernelGGL((k_align8_trace_codes_simple<8>), dim3(blocks), dim3(64), 0, st, a, out, cig_cnt);
+			else if(wave && a.code_fmt == 1u) hipLaunchKernelGGL((k_align8_trace_codes_wave<8, 1>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
 			else if(wave) hipLaunchKernelGGL((k_align8_trace_codes_wave<8>), dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
 			else launch_trace_lds<8>(a, out, cig_cnt, st);
 			break;

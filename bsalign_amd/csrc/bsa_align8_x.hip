@@ -127,7 +127,10 @@ static __device__ __forceinline__ void x_load_qcodes(const uint8_t *p, uint32_t 
 // NWV: waves per workgroup.  The code dwords of a group of four rows wait in LDS (a lane's own sixteen dwords, no synchronisation) until
 // the group is complete and leaves as 16-byte pieces: kept in registers they were twelve of the 168 a wave may have at three per SIMD.
 // (Stored row by row as four-byte pieces the same launch takes 40 % longer.)
-template<int W, int L, int PW = 1, bool STATIC = false, int NWV = 4>
+// DO2 (one-piece gaps with 1 <= -gapo <= 3, bandwidth 128; Align8Args::code_fmt == 1): D and Od of a cell leave as ONE two-bit field,
+// the new e-difference min(h - ee, -gapo) itself (0: D, -gapo: Od) -- one multiply-add a cell where the two planes take four
+// instructions.  A reference block's dword is then M | R << 8 | field of cell c at bits 31 - 2c, 30 - 2c (bsa_common.h).
+template<int W, int L, int PW = 1, bool STATIC = false, int NWV = 4, bool DO2 = false>
 static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint32_t first_pos, const uint32_t count, const uint32_t tid_base,
 		const uint32_t row0 = 0u, const uint32_t row1 = 0xFFFFFFF8u, uint32_t *st = nullptr){
 	constexpr int BW = 2 * L * W;
@@ -137,6 +140,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
 	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
 	static_assert(PW == 0 || PW == 1 || (PW == 2 && W == 8 && L == 8), "two-piece gaps: bandwidth 128, eight lanes per pair");
+	static_assert(!DO2 || (PW == 1 && WR == 8), "two-bit D / Od fields: one-piece gaps, bandwidth 128");
+	constexpr int NDO = DO2 ? W / 4 : 1;                  // accumulators of the two-bit fields (four cells each, in the high byte of a half)
 	constexpr int CWD = (PW == 2) ? 2 : (WR >= 8) ? WR / 8 : 1;          // code dwords per reference block and row
 	constexpr int ND = (PW == 2) ? 4 : (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : (W == 8) ? 4 : 2;      // code dwords per lane and row
 	const int lt = threadIdx.x;
@@ -161,6 +166,10 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	const uint32_t ONE = 0x01000100u;
 	uint32_t TWO = 0x00020002u;
 	asm volatile("" : "+s"(TWO));                          // opaque multiplier of x_acc
+	// DO2: cell j of an accumulator's four goes to bits 15 - 2j, 14 - 2j of the half: multipliers 64, 16, 4 (and 1: an addition)
+	uint32_t KDO0 = 0x00400040u, KDO1 = 0x00100010u, KDO2 = 0x00040004u;
+	asm volatile("" : "+s"(KDO0), "+s"(KDO1), "+s"(KDO2));
+	const uint32_t DOSP = (GO == -1) ? 2u : 1u;            // a field value that is neither 0 (D) nor -gapo (Od)
 	const uint32_t MINF = x_q8(BSA_EPI8_MIN - 2 * GE);     // the -63 sentinel of f in the shifted frame
 	const uint32_t NGEQ = x_q8(-GE);                       // a cell with u = 0
 	const int gapo2 = a.gapo2, gape2 = a.gape2;
@@ -416,7 +425,9 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			}
 		}
 		// ---- pass 2 (bsalign.h:2932-2957), flags, new row written one slot to the left
-		uint32_t accM[NACC], accD[NACC], accR[NACC], accO[NACC];
+		uint32_t accM[NACC], accD[NACC], accR[NACC], accO[NACC], accDO[NDO];
+#pragma unroll
+		for(int n = 0; n < NDO; n++) accDO[n] = 0;
 		uint32_t accD2 = 0, accI1 = 0, accI2 = 0, accR2 = 0, accO2 = 0;          // PW == 2 (one accumulator: W == 8)
 #pragma unroll
 		for(int n = 0; n < NACC; n++){ accM[n] = 0; accD[n] = 0; accR[n] = 0; accO[n] = 0; }
@@ -445,9 +456,15 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			f = x_sub(fm, uk);
 			if constexpr (PW != 0) accR[k >> 3] = x_acc(accR[k >> 3], x_minu(x_sub(fm, mg[k]), ONE), TWO);
 			const uint32_t n = x_sub(h, ee[k]);
-			accD[k >> 3] = x_acc(accD[k >> 3], x_minu(n, ONE), TWO);
 			const uint32_t ne = (PW == 0) ? 0u : x_minu(n, NGOQ);
-			if constexpr (PW != 0) accO[k >> 3] = x_acc(accO[k >> 3], x_satsubu(ne, NGOQ1), TWO);
+			if constexpr (DO2){
+				const uint32_t kk = ((k & 3) == 0) ? KDO0 : ((k & 3) == 1) ? KDO1 : KDO2;
+				if((k & 3) == 3) accDO[k >> 2] = x_add(accDO[k >> 2], ne);
+				else accDO[k >> 2] = x_acc(ne, accDO[k >> 2], kk);                 // ne * K + acc
+			} else {
+				accD[k >> 3] = x_acc(accD[k >> 3], x_minu(n, ONE), TWO);
+				if constexpr (PW != 0) accO[k >> 3] = x_acc(accO[k >> 3], x_satsubu(ne, NGOQ1), TWO);
+			}
 			accM[k >> 3] = x_acc(accM[k >> 3], x_minu(x_sub(h, S[k]), ONE), TWO);
 			const uint32_t un = x_sub(h, v);
 			v = x_sub(h, uk);
@@ -474,6 +491,12 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				const uint32_t hl = hfirst & 0xffffu;
 				const uint32_t b0 = 1u << TOPBIT;
 				accM[0] = (accM[0] & ~b0) | ((hl == q0m) ? 0u : b0);
+				if constexpr (DO2){
+					// band position 0 of a row whose band starts at query column 0: D follows the quirk's comparison and need not agree with the
+					// field, so this one cell carries D and Od literally (bit 14: D, bit 15: Od); the traceback knows it by x == 0 == band offset
+					const uint32_t fld = (accDO[0] >> 14) & 3u;
+					accDO[0] = (accDO[0] & ~0xC000u) | ((hl == q0d) ? 0x4000u : 0u) | ((fld == (uint32_t)(-GO)) ? 0x8000u : 0u);
+				} else
 				accD[0] = (accD[0] & ~b0) | ((hl == q0d) ? 0u : b0);
 				if constexpr (PW == 2) accD2 = (accD2 & ~b0) | ((hl == q0d2) ? 0u : b0);
 			}
@@ -490,9 +513,22 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					// accumulator n holds cells 8n .. 8n + CN - 1, cell c at bit 8 + CN - 1 - (c - 8n)
 					const int cd = min(max(nd - 8 * n, 0), CN), cm = min(max(nm - 8 * n, 0), CN);
 					const uint32_t md = (((1u << (CN - cd)) - 1u) << 8) << (16 * hf), mm = (((1u << (CN - cm)) - 1u) << 8) << (16 * hf);
-					if(mov != 0u){ accD[n] |= md; accM[n] |= mm; if constexpr (PW == 2) accD2 |= md; }
+					if(mov != 0u){ if constexpr (!DO2) accD[n] |= md; accM[n] |= mm; if constexpr (PW == 2) accD2 |= md; }
+				}
+				if constexpr (DO2){
+					// "no deletion here" = a zero field becomes the spare value: cells nd .. W - 1 of the half
+#pragma unroll
+					for(int n = 0; n < NDO; n++){
+						const int c0 = min(max(nd - 4 * n, 0), 4);                    // the accumulator's cells c0 .. 3 (bits 15 - 2c, 14 - 2c)
+						const uint32_t cm = (0x5500u & ((1u << (16 - 2 * c0)) - 1u)) << (16 * hf);
+						const uint32_t z = ~(accDO[n] | (accDO[n] >> 1)) & cm;       // low bit of every zero field among them
+						if(mov != 0u) accDO[n] |= z * DOSP;
+					}
 				}
 			}
+		} else if constexpr (DO2){
+			const uint32_t t = accDO[NDO - 1];
+			if(mov == 1u && last && (t & 0x03000000u) == 0u) accDO[NDO - 1] = t | (DOSP << 24);
 		} else { accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u; if constexpr (PW == 2) accD2 |= (mov == 1u) ? kd1 : 0u; }
 		if constexpr (PW == 0){
 			// linear gaps: every gap is opened at length 1 (R and Od always set); accR is kept inverted, accO is not
@@ -516,6 +552,15 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				const uint32_t t4 = __builtin_amdgcn_perm(accO2, accO[0], 0x07030501u);
 				cur[0] = ~__builtin_amdgcn_perm(t2, t1, 0x05040100u); cur[1] = __builtin_amdgcn_perm(t4, t3, 0x05040100u) ^ 0x0000FFFFu;     // block jl
 				cur[2] = ~__builtin_amdgcn_perm(t2, t1, 0x07060302u); cur[3] = __builtin_amdgcn_perm(t4, t3, 0x07060302u) ^ 0x0000FFFFu;     // block jl + L
+			} else if constexpr (DO2){
+				// one dword per reference block: M | R << 8 | two-bit fields << 16 (cell c at bits 15 - 2c, 14 - 2c of those)
+#pragma unroll
+				for(int n = 0; n < NACC; n++){
+					const uint32_t t1 = __builtin_amdgcn_perm(accR[n], accM[n], 0x07030501u);               // {M.lo, R.lo, M.hi, R.hi}
+					const uint32_t t2 = __builtin_amdgcn_perm(accDO[2 * n], accDO[2 * n + 1], 0x07030501u);  // {cells 4-7 .lo, cells 0-3 .lo, 4-7 .hi, 0-3 .hi}
+					cur[n] = __builtin_amdgcn_perm(t2, t1, 0x05040100u) ^ 0x0000FFFFu;            // block NACC jl + n
+					cur[NACC + n] = __builtin_amdgcn_perm(t2, t1, 0x07060302u) ^ 0x0000FFFFu;     // block NACC (jl + L) + n
+				}
 			} else if constexpr (WR == 8){
 				// one dword per reference block: M | D << 8 | R << 16 | Od << 24, cell k at bit 7 - k
 #pragma unroll
@@ -704,9 +749,9 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	}
 }
 
-template<int W, int L>
+template<int W, int L, bool DO2 = false>
 __global__ void __launch_bounds__(256) k_align8_fwd_x(const Align8Args a){
-	x_forward<W, L>(a, a.first, a.count, blockIdx.x * 256u);
+	x_forward<W, L, 1, false, 4, DO2>(a, a.first, a.count, blockIdx.x * 256u);
 }
 // linear gaps (piecewise 0)
 template<int W, int L>
@@ -718,9 +763,9 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x2(const Align8Args a){
 	x_forward<8, 8, 2>(a, a.first, a.count, blockIdx.x * 256u);
 }
 // bands that cover their whole queries (Align8Args::static_band): the row stays in place, no steering
-template<int W, int L, int PW>
+template<int W, int L, int PW, bool DO2 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_x_static(const Align8Args a){
-	x_forward<W, L, PW, true>(a, a.first, a.count, blockIdx.x * 256u);
+	x_forward<W, L, PW, true, 4, DO2>(a, a.first, a.count, blockIdx.x * 256u);
 }
 
 // Bandwidth 128, a batch that is not a whole number of four-lane rounds: the first nb8 blocks take the last n8 pairs
@@ -741,7 +786,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
 // ideal.  ctl[0] = next item, ctl[16 + g] = segments of group g that are done (release / acquire at agent scope: the next segment
 // usually runs on another CU).  An item only ever waits for an item that was handed out before it, i.e. one that is running.
 struct XQArgs { uint32_t *ctl; uint32_t *state; uint32_t ngroups, nseg, seg_rows; };
-template<int W, int L, int PW>
+template<int W, int L, int PW, bool DO2 = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_xq(const Align8Args a, const XQArgs q){
 	// one item per wave (a block is a wave: the dispatcher refills a wave slot the moment it is free); the ticket, not the block
 	// index, names the item, so that an item's predecessor is always one that has started
@@ -754,7 +799,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 		if(threadIdx.x == 0u){ while(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s) __builtin_amdgcn_s_sleep(16); }
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	}
-	x_forward<W, L, PW, false, 1>(a, a.first, a.count, g * 64u, s * q.seg_rows, (s + 1u) * q.seg_rows, q.state + (size_t)g * (XS_WORDS(W, PW) * 64u));
+	x_forward<W, L, PW, false, 1, DO2>(a, a.first, a.count, g * 64u, s * q.seg_rows, (s + 1u) * q.seg_rows, q.state + (size_t)g * (XS_WORDS(W, PW) * 64u));
 	if(s + 1u < q.nseg){
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the state's write-through stores have arrived
 		if(threadIdx.x == 0u) __hip_atomic_store(done, s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -777,7 +822,7 @@ size_t bsa_align8_xq_bytes(uint32_t bw, int pw, uint32_t count){
 	return (16u + groups) * 4u + 256u + groups * (size_t)(XS_WORDS(Wl, pw) * 64u * 4u);
 }
 // true when the launch was made
-template<int W, int L, int PW>
+template<int W, int L, int PW, bool DO2 = false>
 static bool x_launch_xq(const Align8Args &a, hipStream_t st, hipError_t &err){
 	const char *qe = bsa_env("BSA_ALIGN8_XQ");
 	if(!a.xq || (qe && qe[0] == '0')) return false;
@@ -796,7 +841,7 @@ static bool x_launch_xq(const Align8Args &a, hipStream_t st, hipError_t &err){
 	q.ctl = a.xq; q.state = (uint32_t*)((uint8_t*)a.xq + ctl_bytes); q.ngroups = groups; q.nseg = nseg; q.seg_rows = seg_rows;
 	err = hipMemsetAsync(a.xq, 0, ctl_bytes, st);
 	if(err != hipSuccess) return true;
-	hipLaunchKernelGGL((k_align8_fwd_xq<W, L, PW>), dim3(groups * nseg), dim3(64), 0, st, a, q);
+	hipLaunchKernelGGL((k_align8_fwd_xq<W, L, PW, DO2>), dim3(groups * nseg), dim3(64), 0, st, a, q);
 	err = hipGetLastError();
 	bsa_last_fwd_kernel = "k_align8_fwd_xq (exact-arithmetic forward DP in row segments, 4-bit traceback codes)";
 	return true;
@@ -826,10 +871,33 @@ bool bsa_align8_x_supported(const Align8Args &a, int pw){
 	return m + 3 * g + 2 * ge <= 100 && n + m + g + 2 * ge <= 110 && 63 + 2 * ge + n + m + 2 * g <= 125;
 }
 
+// the code rows with two-bit D / Od fields (Align8Args::code_fmt 1): what the forward kernels need; the traceback side is asked in bsa_api.hip
+bool bsa_align8_do2_supported(const Align8Args &a, int pw){
+	const int go = -(int)(int8_t)a.gapo1;
+	const char *e = bsa_env("BSA_ALIGN8_DO2");
+	return pw == 1 && a.bw == 128u && go >= 1 && go <= 3 && !(e && e[0] == '0') && !bsa_env("BSA_ALIGN8_X_LANES") && !bsa_env("BSA_ALIGN8_X_N8") && bsa_align8_x_supported(a, pw);
+}
+
 static bool x8_at_64(){ const char *e = bsa_env("BSA_ALIGN8_X_LANES"); return e && e[0] == '8'; }
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
 	const uint32_t b8 = (a.count + 31u) / 32u;
+	if(a.code_fmt == 1u){
+		// two-bit D / Od fields (bsa_align8_do2_supported): bandwidth 128, one-piece gaps, four lanes per pair
+		if(pw != 1 || a.bw != 128u) return hipErrorInvalidValue;
+		hipError_t qe = hipSuccess;
+		if(a.static_band && !bsa_env("BSA_ALIGN8_NO_STATIC")){
+			hipLaunchKernelGGL((k_align8_fwd_x_static<16, 4, 1, true>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a);
+			bsa_last_fwd_kernel = "k_align8_fwd_x_static (exact-arithmetic forward DP, band in place, traceback codes with two-bit D/Od fields)";
+		} else if(x_launch_xq<16, 4, 1, true>(a, st, qe)){
+			bsa_last_fwd_kernel = "k_align8_fwd_xq (exact-arithmetic forward DP in row segments, traceback codes with two-bit D/Od fields)";
+			return qe;
+		} else {
+			hipLaunchKernelGGL((k_align8_fwd_x<16, 4, true>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a);
+			bsa_last_fwd_kernel = "k_align8_fwd_x (exact-arithmetic forward DP, traceback codes with two-bit D/Od fields)";
+		}
+		return hipGetLastError();
+	}
 	if(a.static_band && !bsa_env("BSA_ALIGN8_NO_STATIC")){
 		const uint32_t b4 = (a.count + 63u) / 64u;
 		if(pw == 2 && a.bw == 128u){ hipLaunchKernelGGL((k_align8_fwd_x_static<8, 8, 2>), dim3(b8), dim3(256), 0, st, a); return hipGetLastError(); }

@@ -891,6 +891,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		const bool force_pk = fe && fe[0] == 'p';
 		fwd_x = (pw == 2) || (!force_pk && bsa_align8_x_supported(a, pw));       // (two-piece gaps: the only forward kernel of the compact path)
 	}
+	if(codes && fwd_x && bsa_align8_do2_supported(a, pw) && bsa_align8_trace_reads_do2(a, pw)) a.code_fmt = 1u;      // two-bit D / Od fields (bsa_common.h)
 	c->fwd_name = sys ? "k_align8_fwd_sys (whole-query band, systolic wavefront, 4-bit traceback codes)" : (fwd_x && pw == 2) ? "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)"
 		: fwd_x ? "k_align8_fwd_x (exact-arithmetic forward DP, 4-bit traceback codes)" : codes ? "k_align8_fwd_pk<.,.,true> (packed forward DP, 4-bit traceback codes)"
 		: generic ? "k_align8_fwd_gen (run-time bandwidth, row records)" : "k_align8_fwd_pk / k_align8_fwd (row records)";

@@ -34,6 +34,7 @@ struct Align8Args {
 	uint32_t rowb;              // bytes of one row group = 16 tiles (see the layout note below)
 	uint32_t static_band;       // every pair's band covers its whole query (qlen <= bw): the band never moves (k_align8_fwd_x_static)
 	uint32_t ref_bw;            // compact path, a whole-query band widened to `bw` (bsa_api.hip): the reference's own bandwidth (1 = per pair roundup(qlen, 16)); 0 = bw
+	uint32_t code_fmt;          // compact slots, one-piece gaps at bandwidth 128: 0 = four flag planes a block, 1 = M, R and two-bit D / Od fields (below)
 	uint32_t max_tlen;          // longest target of the launch (pairs are ordered by target length: that of position `first`)
 	uint32_t *xq; uint64_t xq_bytes;    // control words + band states of the persistent forward kernel (k_align8_fwd_xq), or null
 	int32_t  mode;
@@ -73,6 +74,11 @@ static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t 
 // Code row = 16 blocks x CW dwords (CW = max(1, W / 8)), running block y of the row = dwords y*CW ...  The 4W bits of a
 // block are four planes of W bits, plane n at bit n*W: M, D, R (insert opens here for the next cell), Od (stored e is
 // a fresh opening); inside a plane cell k of the block is bit W-1-k.
+// Format 1 (Align8Args::code_fmt, W = 8, one-piece gaps with 1 <= -gapo <= 3; k_align8_fwd_x* with DO2, k_align8_trace_codes_wave<8>): the block's
+// dword is  M | R << 8 | F << 16,  F = eight two-bit fields, cell k at bits 15 - 2k, 14 - 2k: the cell's new e-difference min(h - (u + e), -gapo),
+// so 0 means D and -gapo means Od (they exclude each other); where the forward pass clears D (cells at / beyond the previous row's band end) a
+// zero field becomes a value that is neither.  One cell is literal: band position 0 of a row whose band offset is 0 (query column 0, where D
+// follows the comparison of bsalign.h:3763-3767 and may hold together with Od): bit 14 = D, bit 15 = Od.
 // Two-piece gaps (W = 8 only): two dwords per block, eight byte planes --
 //   dword 0: A | D << 8 | D2 << 16 | B << 24        dword 1: R1 | R2 << 8 | Od1 << 16 | Od2 << 24
 // D / D2: h == u + e / h == u + q.  A and B fold M and "which insertion chain equals h" (I1: h == f, I2: h == g), which are
@@ -206,6 +212,8 @@ hipError_t bsa_launch_align8_fwd_pk(const Align8Args &a, int pw, hipStream_t st)
 bool bsa_align8_codes_supported(const Align8Args &a, int pw);          // global mode, piecewise <= 1, small scores
 hipError_t bsa_launch_align8_fwd_codes(const Align8Args &a, int pw, hipStream_t st);
 bool bsa_align8_x_supported(const Align8Args &a, int pw);              // exact-arithmetic forward kernel of the compact path (bsa_align8_x.hip)
+bool bsa_align8_do2_supported(const Align8Args &a, int pw);            // ... able to write code format 1
+bool bsa_align8_trace_reads_do2(const Align8Args &a, int pw);          // the traceback kernel the launcher would pick reads code format 1
 hipError_t bsa_launch_diagdp(const uint8_t *d_planes, const bsa_diagdp_prob_t *d_probs, uint32_t *d_T, const uint64_t *d_toff, uint8_t *d_matrix,
 		uint32_t n, uint32_t W, uint32_t max_len, hipStream_t st);
 // the kernels the launchers picked last (this thread), for bsa_ctx_last_kernel_name

@@ -107,6 +107,31 @@ def test_row_segments_of_the_persistent_forward_kernel(ctx, monkeypatch, seg, sc
             assert "k_align8_fwd_xq" in fwd, fwd
 
 
+@pytest.mark.parametrize("xq", ["0", "1"])
+def test_code_rows_with_two_bit_fields(ctx, monkeypatch, xq):
+    """code format 1 (one-piece gaps with -gapo in 1 .. 3 at bandwidth 128): D and Od as one two-bit field per cell.  Gap openings 1, 2, 3,
+    tie-rich scorings, divergent short pairs (the literal cell at query column 0, cells beyond the previous band end after jumps), whole-query
+    bands in place -- and the planes format (BSA_ALIGN8_DO2=0) gives the same answers"""
+    monkeypatch.setenv("BSA_ALIGN8_XQ", xq)
+    monkeypatch.setenv("BSA_ALIGN8_XQ_SEG", "64")
+    rng = np.random.default_rng(977)
+    pairs = _mk_pairs(rng, 150, [1, 5, 17, 33, 64, 100, 129, 300, 1000, 2500], eps_list=(0.0, 0.05, 0.2, 0.4), ratios=(1.0, 1.0, 0.7, 1.4, 2.5))
+    for _ in range(40):                                                # band jumps: lengths far apart
+        Lt = int(rng.integers(20, 400))
+        pairs.append((rng.integers(0, 4, size=max(int(Lt * float(rng.choice([3.0, 0.3]))), 1)).astype(np.uint8), rng.integers(0, 4, size=Lt).astype(np.uint8)))
+    for sc in ((2, -6, -3, -2, 0, 0), (1, -1, -1, -1, 0, 0), (2, -3, -2, -1, 0, 0), (3, -4, -1, -2, 0, 0)):
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+            _check(ctx, pairs, mode, 128, sc)
+            fwd, trace = ctx.last_kernel_names()
+            assert "two-bit" in fwd and trace == "k_align8_trace_codes_wave", (fwd, trace)
+    short = [p for p in pairs if len(p[0]) <= 128]
+    _check(ctx, short, S.MODE_GLOBAL, 0, (2, -6, -3, -2, 0, 0))         # whole-query bands, widened to 128 columns, band in place
+    assert "k_align8_fwd_x_static" in ctx.last_kernel_names()[0] and "two-bit" in ctx.last_kernel_names()[0]
+    monkeypatch.setenv("BSA_ALIGN8_DO2", "0")
+    _check(ctx, pairs, S.MODE_GLOBAL, 128, (2, -6, -3, -2, 0, 0))
+    assert "two-bit" not in ctx.last_kernel_names()[0]
+
+
 def test_synthetic_10k_bw128(ctx):
     """the benchmark shape (C2): 10 kbp synthetic pairs, global, bw 128"""
     pairs = [S.synth_pair(k, 10000) for k in range(24)]
