@@ -816,8 +816,8 @@ static int x_cus(){
 // bytes of a.xq the persistent form needs for `count` pairs (0: the shape has no persistent form)
 size_t bsa_align8_xq_bytes(uint32_t bw, int pw, uint32_t count){
 	const uint32_t W = bw / 16u;
-	if(pw > 1 || !(W == 4u || W == 8u || W == 16u)) return 0;
-	const uint32_t L = (W == 16u) ? 8u : 4u, Wl = (W == 4u) ? 8u : 16u;          // lanes per pair, cells per lane and half
+	if(pw > 2 || (pw == 2 && W != 8u) || !(W == 4u || W == 8u || W == 16u)) return 0;
+	const uint32_t L = (W == 16u || pw == 2) ? 8u : 4u, Wl = (pw == 2) ? 8u : (W == 4u) ? 8u : 16u;          // lanes per pair, cells per lane and half
 	const size_t groups = ((size_t)count * L + 63u) / 64u;
 	return (16u + groups) * 4u + 256u + groups * (size_t)(XS_WORDS(Wl, pw) * 64u * 4u);
 }
@@ -910,6 +910,8 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	}
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;
+		hipError_t qe2 = hipSuccess;
+		if(x_launch_xq<8, 8, 2>(a, st, qe2)){ bsa_last_fwd_kernel = "k_align8_fwd_xq (exact-arithmetic forward DP in row segments, two-piece gaps, 8-bit traceback codes)"; return qe2; }
 		hipLaunchKernelGGL(k_align8_fwd_x2, dim3(b8), dim3(256), 0, st, a);
 		return hipGetLastError();
 	}

@@ -220,173 +220,3 @@ extern "C" int bsa_msa_text(const uint8_t *cols, const uint32_t *idxs, uint32_t 
 	*need = s.n;
 	return (out && s.n <= cap) ? BSA_OK : BSA_E_NOMEM;
 }
-
-
-// ---- consensus calling (cns_bspoa, bspoa.h:3457-3733) ---------------------------------------------------------------------
-namespace {
-const double CNS_MIN_LOG = -1000000000.0;      // BSPOA_MIN_LOGVAL, bspoa.h:86
-const int CNS_QLT_MAX = 90;                    // BSPOA_QLT_MAX
-
-// log-sum-exp of up to five values with the reference's shortcuts (bspoa.h:3413-3453): values 40 apart do not add up,
-// the running sum always holds the larger of the two operands before exp(difference) is taken
-double sum_logs(int cnt, const double *v){
-	if(cnt <= 0) return 0;
-	double sum = CNS_MIN_LOG;
-	for(int i = 0; i < cnt; i++){
-		double delta;
-		if(v[i] == CNS_MIN_LOG) continue;
-		if(v[i] > sum){
-			if(v[i] >= sum + 40){ sum = v[i]; continue; }
-			delta = sum - v[i];
-			sum = v[i];
-		} else {
-			if(sum >= v[i] + 40) continue;
-			delta = v[i] - sum;
-		}
-		delta = std::exp(delta);
-		delta = std::log(1 + delta);
-		sum += delta;
-	}
-	return sum;
-}
-
-// the event table: for (consensus state a, read symbol b, last consensus base c, last event d) the index of the event's
-// probability << 3 | the event (0 match / mismatch, 1 insertion, 2 deletion) -- bspoa.h:142-204
-void event_table(const bsa_cns_params_t &p, double logp[8], uint8_t table[625]){
-	double os[8];
-	os[0] = 1 - p.psub; os[1] = p.psub; os[2] = p.pins; os[3] = p.pdel; os[4] = p.piex; os[5] = p.pdex; os[6] = p.hins; os[7] = p.hdel;      // (1 - psub in single precision, as there)
-	for(int i = 0; i < 8; i++) logp[i] = std::log(os[i]);
-	for(uint32_t i = 0; i < 625; i++){
-		const uint32_t a = i % 5, b = (i % 25) / 5, c = (i % 125) / 25, d = i / 125;
-		uint8_t t;
-		if(a < 4 && b < 4) t = (uint8_t)((a == b ? 0 : 1) << 3);                                              // base over base
-		else if(a < 4){                                                                                       // consensus base, read gap: deletion
-			const int plain = (d == 2) ? 5 : 3;
-			t = (uint8_t)((((a == c && logp[7] > logp[plain]) ? 7 : plain) << 3) | 2);
-		} else if(b < 4){                                                                                     // consensus gap, read base: insertion
-			const int plain = (d == 1) ? 4 : 2;
-			t = (uint8_t)((((b == c && logp[6] > logp[plain]) ? 6 : plain) << 3) | 1);
-		} else t = (uint8_t)d;                                                                                // gap over gap keeps the last event
-		table[i] = t;
-	}
-}
-
-struct CnsCell { double sc[6]; uint8_t bt, lb; };
-}
-
-extern "C" int bsa_msa_call_consensus(uint8_t *cols, const uint32_t *idxs, uint32_t nall, uint32_t nseq, uint32_t nmax, uint32_t mlen,
-		const bsa_cns_params_t *par, uint8_t *cns, uint8_t *qlt, uint8_t *alt, uint32_t *clen, double *score){
-	if(!par || (mlen && !cols) || nseq > nall || nmax > nall) return BSA_E_ARG;
-	if(clen) *clen = 0;
-	if(score) *score = 0;
-	if(mlen == 0) return BSA_OK;
-	const uint32_t mrow = nall + 3;
-	double logp[8]; uint8_t table[625];
-	event_table(*par, logp, table);
-	const double log10v = std::log(10.0), min_freq = 0.1;
-	auto col = [&](uint32_t pos) -> uint8_t* { return cols + (size_t)(idxs ? idxs[pos] : pos) * mrow; };
-	// dps[state][pos + 1]; index 0 is the start column
-	std::vector<CnsCell> store((size_t)(mlen + 1) * 5);
-	CnsCell *dps[5];
-	for(int i = 0; i < 5; i++){
-		dps[i] = store.data() + (size_t)i * (mlen + 1);
-		for(int k = 0; k < 5; k++) dps[i][0].sc[k] = 0;
-		dps[i][0].sc[5] = (i == 4) ? 0 : CNS_MIN_LOG;
-		dps[i][0].bt = 4; dps[i][0].lb = 4;
-		dps[i]++;
-	}
-	// per state: the last event of every read (0 match, 1 insertion, 2 deletion) along the best path into that state; [5..9]: the column being computed
-	std::vector<uint8_t> bsbuf((size_t)nseq * 10, 0);
-	uint8_t *bs[10];
-	for(int i = 0; i < 10; i++) bs[i] = bsbuf.data() + (size_t)i * nseq;
-	for(uint32_t pos = 0; pos < mlen; pos++){
-		const uint8_t *qs = col(pos);
-		CnsCell *dp[5];
-		for(int a = 0; a < 5; a++){ dp[a] = dps[a] + pos; for(int k = 0; k < 6; k++) dp[a]->sc[k] = 0; }
-		uint32_t cnts[6] = {0, 0, 0, 0, 0, 0};
-		for(uint32_t r = 0; r < nseq; r++){ const uint32_t b = qs[r]; if(b > 4) continue; cnts[5]++; cnts[b]++; }
-		for(int i = 0; i < 5; i++) if(cnts[i] < (uint32_t)(min_freq * cnts[5])) cnts[i] = 0;
-		for(uint32_t a = 0; a <= 4; a++){
-			if(cnts[5] && cnts[a] == 0){                        // a state no read supports
-				for(int i = 0; i < 6; i++) dp[a]->sc[i] = CNS_MIN_LOG;
-				dp[a]->bt = 4; dp[a]->lb = 4;
-				for(uint32_t r = 0; r < nseq; r++) bs[a + 5][r] = 0;
-				continue;
-			}
-			double errs[10];
-			for(uint32_t e = 0; e <= 4; e++){
-				const CnsCell *lp = dps[e] + (long)pos - 1;
-				const uint32_t c = lp->lb;
-				if(cnts[5] && lp->sc[5] == CNS_MIN_LOG){ dp[a]->sc[e] = CNS_MIN_LOG; errs[e] = CNS_MIN_LOG; }
-				else {
-					for(uint32_t r = 0; r < nseq; r++){
-						const uint32_t b = qs[r];
-						if(b > 4) continue;
-						dp[a]->sc[e] += logp[table[a + b * 5 + c * 25 + (uint32_t)bs[e][r] * 125] >> 3];
-					}
-					errs[e] = dp[a]->sc[e] + lp->sc[5];
-				}
-				errs[e + 5] = errs[e];
-			}
-			dp[a]->sc[5] = sum_logs(5, errs + 5);
-			dp[a]->bt = 4;
-			for(uint32_t e = 0; e < 4; e++) if(errs[e] > errs[dp[a]->bt]) dp[a]->bt = (uint8_t)e;
-			const CnsCell *lp = dps[dp[a]->bt] + (long)pos - 1;
-			dp[a]->lb = (a < 4) ? (uint8_t)a : lp->lb;
-			for(uint32_t r = 0; r < nseq; r++){
-				const uint32_t b = qs[r];
-				bs[a + 5][r] = (b > 4) ? 4 : (uint8_t)(table[a + b * 5 + (uint32_t)lp->lb * 25 + (uint32_t)bs[dp[a]->bt][r] * 125] & 7);
-			}
-		}
-		for(int a = 0; a < 5; a++) memcpy(bs[a], bs[a + 5], nseq);
-	}
-	// traceback: the best final state, then the stored choices
-	uint32_t c = 4;
-	for(uint32_t a = 0; a < 4; a++) if(dps[a][mlen - 1].sc[5] > dps[c][mlen - 1].sc[5]) c = a;
-	if(score) *score = dps[c][mlen - 1].sc[5];
-	for(long pos = (long)mlen - 1; ; pos--){
-		col((uint32_t)pos)[nall] = (uint8_t)c;
-		c = dps[c][pos].bt;
-		if(pos == 0) break;
-	}
-	// qualities
-	std::vector<double> logfact;                               // log(k!) built by summation in k, the reference's cache (bspoa.h:3391-3401)
-	auto lfact = [&](uint32_t n) -> double { if(logfact.empty()) logfact.push_back(0.0); while(logfact.size() <= n) logfact.push_back(logfact.back() + std::log((double)(uint32_t)logfact.size())); return logfact[n]; };
-	uint32_t nc = 0;
-	for(uint32_t pos = 0; pos < mlen; pos++){
-		uint8_t *qs = col(pos);
-		const uint32_t cb = qs[nall];
-		double errs[5];
-		for(int a = 0; a < 5; a++) errs[a] = dps[a][pos].sc[5];
-		double erre = sum_logs(5, errs);
-		double errd = dps[cb][pos].sc[5];
-		erre = std::log(1 - std::exp(errd - erre));
-		erre = -(10 * (erre) / log10v);
-		qs[nall + 1] = (uint8_t)(int)(erre < (double)CNS_QLT_MAX ? erre : (double)CNS_QLT_MAX);
-		uint32_t cnts[6] = {0, 0, 0, 0, 0, 0};
-		for(uint32_t r = 0; r < nmax; r++){ const uint32_t b = qs[r]; if(b > 4) continue; cnts[5]++; cnts[b]++; }
-		uint32_t a = (cb + 1) % 5;
-		for(uint32_t e = 0; e <= 4; e++){ if(e == cb) continue; if(cnts[e] > cnts[a]) a = e; }
-		const double p = par->psub;
-		erre = 0;
-		if(cnts[5] > 50 && cnts[5] * p > 5 && cnts[5] * (1 - p) > 5){
-			erre = std::erfc(-((cnts[a] - cnts[5] * p) / std::sqrt(cnts[5] * p * (1 - p))) / 1.4142135623731) / 2;
-		} else {
-			for(uint32_t e = 0; e < cnts[a]; e++){
-				double perm = 1;                                 // cal_permutation_bspoa: 1 beyond its cache of 1000
-				if(cnts[5] <= 1000) perm = lfact(cnts[5]) - lfact(e) - lfact(cnts[5] - e);
-				erre += std::exp(std::log(p) * e + std::log(1 - p) * (cnts[5] - e) + perm);
-			}
-		}
-		errd = (erre == 0) ? 0 : -(10 * std::log(1 - erre) / log10v);
-		qs[nall + 2] = (uint8_t)(errd < (double)CNS_QLT_MAX ? errd : (double)CNS_QLT_MAX);
-		if(qs[nall] < 4){
-			if(cns) cns[nc] = qs[nall];
-			if(qlt) qlt[nc] = qs[nall + 1];
-			if(alt) alt[nc] = qs[nall + 2];
-			nc++;
-		}
-	}
-	if(clen) *clen = nc;
-	return BSA_OK;
-}
