@@ -29,28 +29,40 @@ ISSUE_NS = 1.8             # one VALU instruction of the kinds these kernels are
                            # instruction of a SIMD's turn at the CU's scalar unit: 4 cycles (profiles/r02f_valu_rate_probe.txt)
 
 
-def issue_fractions(workload_key, kernel, cells_per_launch, kernel_ms):
-    """share of the VALU / scalar issue slots the kernel used: instructions per band cell from the committed PMC pass
-    (profiles/issue_counts.json, tools/issue_counts.sh) x the cells of THIS launch x the measured cost of an issue slot,
-    over 1024 SIMDs and the launch's duration measured in this run"""
+def counters_for(config_workload, kernel):
+    """the committed PMC passes of EXACTLY this configuration (profiles/counters.json, keyed by the bench line's config.workload string --
+    pairs, length, mode, bandwidth, scoring -- and the profiler's kernel name; written by tools/summarize_round4.py from
+    tools/profile_round4.sh).  A shape that was not profiled has no entry: no traffic, no issue fractions are printed for it."""
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "issue_counts.json")))
+        tab = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
     except Exception:
         return None
-    ent = None
-    for k, v in tab.items():
-        wk, kn = k.split("|")
-        a, b = kn.split("<")[0], kernel.split()[0].split("<")[0]          # the library names a launch family ("k_align8_fwd_x"), the profiler an instance ("k_align8_fwd_x_mix")
-        if wk == workload_key and (a.startswith(b) or b.startswith(a)):
-            ent = v
-    if ent is None or kernel_ms <= 0:
+    ent = tab.get(config_workload)
+    if not ent:
         return None
-    ref_cells = float(ent["pairs"]) * ent["length"] * ent["bandwidth"]
-    scale = cells_per_launch / ref_cells
+    fam = kernel.split()[0].split("<")[0]          # the library names a launch family ("k_align8_fwd_xq"), the profiler an instance ("k_align8_fwd_xq<16, 4, 1, true>")
+    for kn, v in ent.items():
+        if kn.split("<")[0] == fam:
+            return dict(v, kernel_instance=kn)
+    return None
+
+
+def issue_fractions(ent, kernel_ms):
+    """share of the VALU / scalar issue slots the kernel used: instructions per launch from the PMC pass of this very configuration x the
+    measured cost of an issue slot, over 1024 SIMDs and the launch's duration measured in this run"""
+    if not ent or kernel_ms <= 0 or "valu_per_launch" not in ent:
+        return None
     cap = SIMDS * kernel_ms * 1e6 / ISSUE_NS          # issue slots of the chip during the launch
-    return {"valu_frac": round(ent["valu_per_launch"] * scale / cap, 4), "salu_frac": round(ent["salu_per_launch"] * scale / cap, 4),
-            "valu_per_cell": round(ent["valu_per_launch"] / ref_cells, 4), "salu_per_cell": round(ent["salu_per_launch"] / ref_cells, 4),
-            "slot_ns": ISSUE_NS, "counts_from": ent["source"]}
+    return {"valu_frac": round(ent["valu_per_launch"] / cap, 4), "salu_frac": round(ent["salu_per_launch"] / cap, 4),
+            "valu_per_launch": ent["valu_per_launch"], "salu_per_launch": ent["salu_per_launch"], "slot_ns": ISSUE_NS,
+            "kernel_instance": ent.get("kernel_instance"), "counts_from": ent.get("source")}
+
+
+def traffic_of(ent):
+    """HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled: gfx950 counts 64 of every 128 bytes of a wide read)"""
+    if not ent or "fetch_raw_bytes_per_launch" not in ent or "write_bytes_per_launch" not in ent:
+        return None
+    return 2.0 * ent["fetch_raw_bytes_per_launch"] + ent["write_bytes_per_launch"]
 SEED = 20240611            # BASELINE.md section 3
 
 
@@ -422,11 +434,9 @@ def main_poa_recorded(args):
         e2e = {"error": str(ex)}
     nl = len(launches)
     achieved = (balg / nl) / (kms_tot / nl / 1e3) / 1e9 if kms_tot > 0 else 0.0
-    traffic = None
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("poa-recorded_n%d_L%d_bw128" % (nwin, L), {}).get("bytes_per_launch")
-    except Exception:
-        traffic = None
+    shape = "poa-recorded|n%d|reads%d|L%d" % (nwin, nreads, L)
+    ent = counters_for(shape, "k_poa_wf")
+    traffic = traffic_of(ent)
     line = {
         "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP (align_rd_bspoacore) + traceback (alignment2graph_bspoa) on recorded programs",
         "value": round(cells * args.steps / elapsed / 1e9, 3), "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -435,10 +445,11 @@ def main_poa_recorded(args):
         "config": {"workload": "poa-recorded: %d POA windows x %d reads x %d bp (eps %.2f), default POA parameters (overlap, bandwidth 128, 2-piece gaps); a step = every read's "
                                "sweep and traceback of every window, read r of all windows per launch (%d launches, %d programs, %.0f row updates + %.0f merges, %d traceback steps)"
                                % (nwin, nreads, L, args.eps, nl, nprog_total, updates, merges, steps_total),
-                   "windows": nwin, "pairs_per_gpu": nwin, "bandwidth": 128, "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
+                   "shape": shape, "windows": nwin, "pairs_per_gpu": nwin, "bandwidth": 128, "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": "k_poa_wf<2, 2> (row-at-a-time forward pass + ring traceback)", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
-                     "traffic_from": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/profile_round3.sh)" if traffic else None,
+                     "issue": issue_fractions(ent, kms_tot / nl),
+                     "traffic_from": (ent or {}).get("source") if traffic else None,
                      "note": "latency-bound, not HBM-bound: one wave per read, a graph node per trip (about 335 instructions, 4 clocks each for a lone wave: DESIGN section 4b); "
                              "throughput grows with the windows in flight (14 KB of LDS per read: 11 reads per CU)"},
         "checks": {"best_end_cell_identical_all_programs": bool(ident), "programs": nprog_total},
@@ -560,13 +571,9 @@ def main_poa(args):
         # algorithmic bytes: one row block read + one written per row update; a merge reads two and writes one
         balg = (2.0 * updates + 3.0 * merges) * blk
         achieved = balg / (kms / 1e3) / 1e9 if kms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("poa_n%d_L%d_bw%d" % (nwin, npos, bw), {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        shape = "poa|n%d|pos%d|bw%d" % (nwin, npos, bw)
+        ent = counters_for(shape, "k_sweep")
+        traffic = traffic_of(ent)
         line = {
             "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP sweep (align_rd_bspoacore)",
             "value": round(cells * args.steps * world / elapsed / 1e9, 3), "unit": "GCUPS",
@@ -575,7 +582,7 @@ def main_poa(args):
             "data": "synthetic sweep programs (bsalign_amd/poa_synth.py: op mix of the reference's real programs), seed %d" % SEED,
             "config": {"workload": "poa: %d POA windows/GPU, one read-vs-graph sweep each over %d graph positions (%.0f row updates + %.0f merges per window), "
                                    "overlap mode, bandwidth %d, DEFAULT_BSPOA_PAR scoring (2-piece gaps)" % (nwin, npos, updates / nwin, merges / nwin, bw),
-                       "windows_per_gpu": nwin, "positions": npos, "bandwidth": bw,
+                       "shape": shape, "windows_per_gpu": nwin, "positions": npos, "bandwidth": bw,
                        "parallelism": "windows sharded across %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "kernel": "k_sweep", "kernel_ms_avg": round(kms, 3), "launches_per_step": klaunch,
@@ -703,15 +710,9 @@ def main():
         dom_trace = tms * tlaunch > kms * klaunch
         dms, dlaunch, dname = (tms, tlaunch, trace_name) if dom_trace else (kms, klaunch, fwd_name)
         achieved = (balg / max(dlaunch, 1)) / (dms / 1e3) / 1e9 if dms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "%s_n%d_L%d_bw%d" % (args.workload, n, L, bw)
-                traffic = tj.get(key, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        shape = "%s|n%d|L%d|%s|bw%d|%s" % (args.workload, n, L, args.mode, bw, args.scoring)
+        ent = counters_for(shape, dname)
+        traffic = traffic_of(ent)
         line = {
             "metric": "GCUPS (giga band-cell updates / s), %s" % ("8-bit banded striped global alignment" if args.workload == "align8" else "2-bit striped edit alignment"),
             "value": round(cells * args.steps * world / elapsed / 1e9, 3),
@@ -722,15 +723,15 @@ def main():
             "dtype": "i8" if args.workload == "align8" else "u64-bitplanes",
             "data": "synthetic (splitmix64 pairs, eps=%.2f, sub:ins:del=23:31:46, seed %d)" % (args.eps, SEED),
             "config": {"workload": "%s: %d pairs/GPU x %d bp, mode %s, bandwidth %d, scoring M,X,O,E,Q,P=%s" % (args.workload, n, L, args.mode, bw, args.scoring),
-                       "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world,
+                       "shape": shape, "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world,
                        "timed": "stage + forward + traceback + CIGAR compaction on device-resident inputs; plan creation (host planning, slot layout) and PCIe are outside the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": dname, "kernel_ms_avg": round(dms, 3), "launches_per_step": dlaunch,
                          "algorithmic_bytes_per_launch": round(balg / max(dlaunch, 1), 1),
                          "kernel_gcups": round(kcells / max(dlaunch, 1) / (dms / 1e3) / 1e9, 2) if dms > 0 else None,
-                         "issue": issue_fractions(args.workload + ("_2piece" if sc[4] or sc[5] else ""), dname, cells / max(dlaunch, 1), dms),
-                         "traffic_from": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/profile_round.sh)" if traffic else None,
+                         "issue": issue_fractions(ent, dms),
+                         "traffic_from": (ent or {}).get("source") if traffic else None,
                          "other_kernel": {"kernel": fwd_name if dom_trace else trace_name, "kernel_ms_avg": round(kms if dom_trace else tms, 3),
                                           "launches_per_step": klaunch if dom_trace else tlaunch}},
             "checks": {"pairs_flagged": nbad, "cigar_words": ncig, "oracle_identical_first8": ident},

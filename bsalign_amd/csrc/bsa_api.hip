@@ -1012,7 +1012,16 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	std::vector<size_t> idx;
 	const char *dbg = bsa_env("BSA_DEBUG_HANDOVER");          // test hook: treat every N-th pair as undecided
 	const long every = dbg ? atol(dbg) : 0;
-	for(size_t k = 0; k < n; k++) if((st[k] & BSA_ST_TRACE) || (every > 0 && k % (size_t)every == 0 && st[k] == 0)) idx.push_back(k);
+	// (only what the literal kernels can take: a pair whose band -- with bandwidth 0, its whole query -- does not fit the run-time-width
+	// kernel's LDS keeps its flag instead of failing the batch after all the work is done; the systolic kernel accepts longer queries)
+	auto literal_can_take = [&](size_t k) -> bool {
+		const uint32_t bw_req = (par->bandwidth + 15u) / 16u * 16u;
+		const uint32_t width = bw_req ? bw_req : std::max(16u, (qlen[k] + 15u) / 16u * 16u);
+		if(bsa_align8_supported_bw(width)) return true;
+		const int pwk = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)width);
+		return bsa_align8_gen_lds(width, pwk, bw_req ? 2u : 1u) <= 160 * 1024;
+	};
+	for(size_t k = 0; k < n; k++) if(((st[k] & BSA_ST_TRACE) || (every > 0 && k % (size_t)every == 0 && st[k] == 0)) && literal_can_take(k)) idx.push_back(k);
 	if(idx.empty()) return BSA_OK;
 	const size_t m = idx.size();
 	if(timing) fprintf(stderr, "[bsa_align_batch] %zu pairs handed over to the literal kernels\n", m);
@@ -1028,6 +1037,7 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	rc = bsa_align_batch(c, seqs, seqs_bytes, sq.data(), sql.data(), stt.data(), stl.data(), m, &lp, sout.data(),
 		cigar ? scig.data() : nullptr, scap, (cigar && cigar_off) ? soff.data() : nullptr, sst.data());
 	c->fwd_name = keep_fwd; c->trace_name = keep_trace;
+	if(rc == BSA_E_UNSUPPORTED) return BSA_OK;          // (the pairs keep BSA_ST_TRACE and their zeroed results)
 	if(rc != BSA_OK) return rc;
 	for(size_t k = 0; k < m; k++){ out[idx[k]] = sout[k]; st[idx[k]] = sst[k]; }
 	if(cigar && cigar_off){

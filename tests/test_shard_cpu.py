@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 import support as S
@@ -170,3 +171,139 @@ def test_scatter_of_100k_pairs_is_vectorised():
     for rank, secs, ok, bounds in got:
         assert ok and secs < 5.0, (rank, secs)
         assert bounds[0] == 0 and bounds[-1] == 100000 and 40000 < bounds[1] < 60000
+
+
+# ---- the C-level exchange (bsa_shard_scatter / bsa_shard_gather, bsalign_amd/csrc/bsa_shard_rccl.hip) at world size 2 and 3 --------------
+# The product wire is RCCL over xGMI with device buffers; BSA_SHARD_TRANSPORT=shm swaps in shared memory between processes and host
+# buffers (bsa_shard_shm.cpp) under the SAME exchange code, so its rank arithmetic -- ranges, blob offsets, grouped sends / receives, the
+# agreement on errors -- runs here, without a GPU.
+def _c_api():
+    import ctypes as C
+    import bsalign_amd as B
+    L = B.lib()
+    vp = C.c_void_p
+    L.bsa_shard_unique_id.argtypes = [vp]
+    L.bsa_shard_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.bsa_shard_comm_destroy.argtypes = [vp]
+    L.bsa_shard_comm_destroy.restype = None
+    L.bsa_shard_scatter.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(vp),
+                                    C.POINTER(C.c_size_t), vp, vp, vp, vp, C.c_size_t]
+    L.bsa_shard_gather.argtypes = [vp, C.c_int, vp, vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp, C.c_size_t]
+    return L
+
+
+def _c_batch(n=257, seed=5):
+    rng = np.random.default_rng(seed)
+    qlen = rng.integers(1, 400, size=n).astype(np.uint32)
+    tlen = rng.integers(1, 500, size=n).astype(np.uint32)
+    tlen[n // 2:] += 900                                    # uneven cells: the cut is not at n / 2
+    off = np.concatenate([[0], np.cumsum(qlen.astype(np.uint64) + tlen)[:-1]]).astype(np.uint64)
+    seqs = rng.integers(0, 4, size=int((qlen.astype(np.uint64) + tlen).sum())).astype(np.uint8)
+    return seqs, off, qlen, off + qlen, tlen
+
+
+def _fake_results(first, count, qlen, tlen):
+    """what a rank would hand to the gather: a result record and a few CIGAR words per pair, functions of the pair's global index"""
+    out = np.zeros((count, 10), np.int32)
+    words, offs = [], [0]
+    for i in range(count):
+        g = first + i
+        out[i] = [g, int(qlen[g]), int(tlen[g]), 0, 0, g % 7, 1, 2, 3, 4]
+        k = 1 + g % 5
+        words.extend([(g << 4) | j for j in range(k)])
+        offs.append(len(words))
+    return out, np.array(words, np.uint32), np.array(offs, np.uint64)
+
+
+def _worker_c_exchange(rank, world, idfile, q, scenario):
+    try:
+        import ctypes as C
+        import time
+        os.environ["BSA_SHARD_TRANSPORT"] = "shm"
+        L = _c_api()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            assert L.bsa_shard_unique_id(ident) == 0
+            with open(idfile + ".tmp", "wb") as f:
+                f.write(bytes(ident))
+            os.replace(idfile + ".tmp", idfile)
+        else:
+            for _ in range(6000):
+                if os.path.exists(idfile):
+                    break
+                time.sleep(0.01)
+            ident = (C.c_uint8 * 128).from_buffer_copy(open(idfile, "rb").read())
+        comm = C.c_void_p()
+        assert L.bsa_shard_comm_create(None, rank, world, ident, C.byref(comm)) == 0
+        seqs, qoff, qlen, toff, tlen = _c_batch()
+        n = len(qlen)
+        root = 1 if scenario == "root1" else 0
+        first, count, nbytes, blob = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_void_p()
+        cap = 3 if (scenario == "small_cap" and rank == 1) else n
+        lq, lt, lqo, lto = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        src = (seqs, qoff, qlen, toff, tlen) if rank == root else (None,) * 5
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        rc = L.bsa_shard_scatter(comm, root, ptr(src[0]), ptr(src[1]), ptr(src[2]), ptr(src[3]), ptr(src[4]), n if rank == root else 0, 128,
+                                 C.byref(first), C.byref(count), C.byref(blob), C.byref(nbytes), lq.ctypes.data, lt.ctypes.data, lqo.ctypes.data, lto.ctypes.data, cap)
+        if scenario == "small_cap":
+            q.put((rank, "scatter_rc", rc))                 # every rank must come back with the error of the rank that cannot take its shard
+            L.bsa_shard_comm_destroy(comm)
+            return
+        assert rc == 0, rc
+        f0, cn = first.value, count.value
+        # the shard blob: every pair's bytes at the offsets the scatter reported
+        raw = (C.c_uint8 * nbytes.value).from_address(blob.value)
+        got = np.frombuffer(raw, np.uint8)
+        ok = bool(np.array_equal(lq[:cn], qlen[f0:f0 + cn]) and np.array_equal(lt[:cn], tlen[f0:f0 + cn]))
+        for i in range(cn):
+            g = f0 + i
+            ok &= bool(np.array_equal(got[int(lqo[i]):int(lqo[i]) + int(qlen[g])], seqs[int(qoff[g]):int(qoff[g]) + int(qlen[g])]))
+            ok &= bool(np.array_equal(got[int(lto[i]):int(lto[i]) + int(tlen[g])], seqs[int(toff[g]):int(toff[g]) + int(tlen[g])]))
+        res, words, offs = _fake_results(f0, cn, qlen, tlen)
+        out = np.zeros((n, 10), np.int32); cig = np.zeros(8 * n, np.uint32); ooff = np.zeros(n + 1, np.uint64)
+        capw = 4 if (scenario == "small_arena" and rank == root) else cig.size
+        rc = L.bsa_shard_gather(comm, root, res.ctypes.data, words.ctypes.data, offs.ctypes.data, cn, out.ctypes.data, cig.ctypes.data, capw, ooff.ctypes.data, n)
+        if scenario == "small_arena":
+            q.put((rank, "gather_rc", rc))
+            L.bsa_shard_comm_destroy(comm)
+            return
+        assert rc == 0, rc
+        if rank == root:
+            wres, wwords, woffs = _fake_results(0, n, qlen, tlen)
+            ok &= bool(np.array_equal(out, wres) and np.array_equal(ooff, woffs) and np.array_equal(cig[:len(wwords)], wwords))
+        L.bsa_shard_comm_destroy(comm)
+        q.put((rank, "ok", (ok, f0, cn)))
+    except Exception as ex:          # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc() + str(ex)))
+
+
+def _run_c_exchange(world, scenario, tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    idfile = str(tmp_path / ("id_%s_%d" % (scenario, world)))
+    procs = [ctx.Process(target=_worker_c_exchange, args=(r, world, idfile, q, scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    return sorted(got)
+
+
+@pytest.mark.parametrize("world,scenario", [(2, "plain"), (2, "root1"), (3, "plain")])
+def test_c_level_exchange_over_shared_memory(world, scenario, tmp_path):
+    got = _run_c_exchange(world, scenario, tmp_path)
+    assert all(kind == "ok" and val[0] for _, kind, val in got), got
+    ranges = sorted((val[1], val[2]) for _, _, val in got)
+    assert ranges[0][0] == 0 and all(ranges[i][0] + ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)) and ranges[-1][0] + ranges[-1][1] == 257
+    assert all(c > 0 for _, c in ranges)                     # (balanced by cells: nobody is empty)
+
+
+def test_c_level_exchange_agrees_on_errors(tmp_path):
+    """a rank whose arrays cannot take its shard, a root whose arena is too small: EVERY rank returns the error, nobody is left waiting for a
+    message (the calls used to return on one side before the matching send / receive was posted)"""
+    got = _run_c_exchange(2, "small_cap", tmp_path)                     # BSA_E_NOMEM = -3, BSA_E_CIGAR_CAP = -5 (include/bsalign_hip.h)
+    assert [(k, v) for _, k, v in got] == [("scatter_rc", -3)] * 2, got
+    got = _run_c_exchange(2, "small_arena", tmp_path)
+    assert [(k, v) for _, k, v in got] == [("gather_rc", -5)] * 2, got
