@@ -845,7 +845,7 @@ bool bsa_align8_supported_bw(uint32_t bw){
 
 hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st){
 	// packed two-pairs-per-row kernel where its preconditions hold (BSA_ALIGN8_I32=1 forces the int32 kernel)
-	static const bool force_i32 = [](){ const char *e = bsa_env("BSA_ALIGN8_I32"); return e && e[0] == '1'; }();
+	const bool force_i32 = [](){ const char *e = bsa_env("BSA_ALIGN8_I32"); return e && e[0] == '1'; }();
 	if(!force_i32 && bsa_align8_pk_supported(a, pw)) return bsa_launch_align8_fwd_pk(a, pw, st);
 	switch(a.bw / 16){
 		case 1:  return launch_fwd_pw<1>(a, pw, st);
@@ -860,7 +860,7 @@ hipError_t bsa_launch_align8_fwd(const Align8Args &a, int pw, hipStream_t st){
 
 hipError_t bsa_launch_align8_backcal(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st){
 	// global mode, W <= 8: two-wave traceback (walker + prefetching helper); BSA_ALIGN8_TRACE1=1 forces the one-wave kernel
-	static const bool force_one = [](){ const char *e = bsa_env("BSA_ALIGN8_TRACE1"); return e && e[0] == '1'; }();
+	const bool force_one = [](){ const char *e = bsa_env("BSA_ALIGN8_TRACE1"); return e && e[0] == '1'; }();
 	if(!force_one && (a.mode & 3) == BSA_MODE_GLOBAL && a.bw / 16 <= 8 && a.count){
 		const uint32_t nb = (a.count + TRACE_LANES - 1) / TRACE_LANES;
 #define TRACE_CASE(WW) case WW: \

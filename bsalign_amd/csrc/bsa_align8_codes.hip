@@ -1355,7 +1355,7 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 		return hipGetLastError();
 	}
 	// BSA_ALIGN8_TRACE_SIMPLE=1: the plain kernel (kept as the reference point)
-	static const bool simple = [](){ const char *e = bsa_env("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
+	const bool simple = [](){ const char *e = bsa_env("BSA_ALIGN8_TRACE_SIMPLE"); return e && e[0] == '1'; }();
 	const uint32_t blocks = (a.count + 63u) / 64u;
 	bsa_last_trace_kernel = simple ? "k_align8_trace_codes_simple" : (a.bw == 256u) ? "k_align8_trace_codes_simple" : "k_align8_trace_codes_lds";
 	// one walk per wave (BSA_ALIGN8_TRACE_WAVE=0: the pair-per-lane kernels)

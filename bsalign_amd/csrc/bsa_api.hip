@@ -8,6 +8,8 @@
 // halves of the workspace alternating.
 #include "bsa_common.h"
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <string>
@@ -39,7 +41,7 @@ struct bsa_ctx {
 	// of one pair otherwise spends more time in hipMalloc / hipFree than in its kernels
 	size_t budget_last = 0;          // last answer of ctx_ws_budget
 	void *keep[2] = {nullptr, nullptr}; size_t keep_bytes[2] = {0, 0}; bool keep_busy[2] = {false, false};
-	void *scratch[2] = {nullptr, nullptr}; size_t scratch_bytes[2] = {0, 0};      // grown on demand, kept (bsa_ctx_scratch_internal): the POA rows
+	void *scratch[3] = {nullptr, nullptr, nullptr}; size_t scratch_bytes[3] = {0, 0, 0};      // grown on demand, kept (bsa_ctx_scratch_internal): the POA rows; 2: bsa_poa_graph_host's tables
 	void *xq = nullptr; size_t xq_bytes = 0;          // control words + band states of the persistent 8-bit forward kernel (k_align8_fwd_xq), grown on demand
 };
 
@@ -67,22 +69,30 @@ static void ctx_buf_put(bsa_ctx *c, int slot, void *ptr, bool kept){
 
 // ---- environment snapshot ----
 extern char **environ;
-namespace { std::mutex g_env_m; std::unordered_map<std::string, std::string> g_env; bool g_env_ready = false; }
+// Snapshots are immutable and never freed (a reload makes a new one and leaves the old ones to the pointers already handed out), the
+// current one is published through an atomic pointer: bsa_env() takes no lock and what it returns stays valid for the life of the process.
+namespace {
+typedef std::unordered_map<std::string, std::string> EnvMap;
+std::mutex g_env_m;
+std::atomic<const EnvMap*> g_env_cur{nullptr};
+std::vector<std::unique_ptr<EnvMap>> g_env_all;
+}
 extern "C" void bsa_env_reload(void){
-	std::lock_guard<std::mutex> lk(g_env_m);
-	g_env.clear();
+	std::unique_ptr<EnvMap> m(new EnvMap());
 	for(char **e = environ; e && *e; e++){
 		if(strncmp(*e, "BSA_", 4) != 0) continue;
 		const char *eq = strchr(*e, '=');
-		if(eq) g_env.emplace(std::string(*e, (size_t)(eq - *e)), std::string(eq + 1));
+		if(eq) m->emplace(std::string(*e, (size_t)(eq - *e)), std::string(eq + 1));
 	}
-	g_env_ready = true;
+	std::lock_guard<std::mutex> lk(g_env_m);
+	g_env_cur.store(m.get(), std::memory_order_release);
+	g_env_all.push_back(std::move(m));
 }
 const char *bsa_env(const char *name){
-	if(!g_env_ready) bsa_env_reload();
-	std::lock_guard<std::mutex> lk(g_env_m);
-	auto it = g_env.find(name);
-	return it == g_env.end() ? nullptr : it->second.c_str();
+	const EnvMap *m = g_env_cur.load(std::memory_order_acquire);
+	if(!m){ bsa_env_reload(); m = g_env_cur.load(std::memory_order_acquire); }
+	auto it = m->find(name);
+	return it == m->end() ? nullptr : it->second.c_str();
 }
 
 #define HIPCHK(ctx, call) do { hipError_t _e = (call); if(_e != hipSuccess){ (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e); return BSA_E_HIP; } } while(0)
@@ -117,7 +127,7 @@ extern "C" void bsa_ctx_destroy(bsa_ctx_t *c){
 	for(hipEvent_t e : c->tev) (void)hipEventDestroy(e);
 	if(c->ws) (void)hipFree(c->ws);
 	for(int k = 0; k < 2; k++) if(c->keep[k]) (void)hipFree(c->keep[k]);
-	for(int k = 0; k < 2; k++) if(c->scratch[k]) (void)hipFree(c->scratch[k]);
+	for(int k = 0; k < 3; k++) if(c->scratch[k]) (void)hipFree(c->scratch[k]);
 	if(c->xq) (void)hipFree(c->xq);
 	if(c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
 	if(c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1099,7 +1109,7 @@ extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *c, void *stop_event){
 
 // a device buffer of at least `bytes` that stays the context's (stream-ordered users only: the previous user's kernels are on the same stream)
 extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *c, int slot, size_t bytes, void **out){
-	if(!c || !out || slot < 0 || slot > 1) return BSA_E_ARG;
+	if(!c || !out || slot < 0 || slot > 2) return BSA_E_ARG;
 	(void)hipSetDevice(c->device);
 	if(c->scratch_bytes[slot] < bytes){
 		if(c->scratch[slot]){ HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->scratch[slot]); c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0; }

@@ -7,10 +7,15 @@
 // The batcher is the rendezvous for that: every window runs the reference's own host code on a host thread of its own
 // (node selection, band placement, traceback into the graph stay the reference's C); where that code would call
 // align_rd_bspoacore (bspoa.h:2515-2618) it calls bsa_sweep_batcher_submit() -- same arguments as the single-window
-// backend of include/bsalign_poa_adapter.h -- and blocks.  When every participating window is waiting, the last
-// arrival packs all programs into one task / query table, runs ONE bsa_sweep_run per distinct parameter set (band
-// width differs between the first read of a window and the later ones), copies results and row blocks back and wakes
-// everybody.  No window ever waits for a window that has finished: bsa_sweep_batcher_leave() takes a participant out.
+// backend of include/bsalign_poa_adapter.h -- and blocks until its program has run.
+// Round 4: no lock-step any more.  A DISPATCHER thread owns the device side: whenever it is free and programs are waiting it takes
+// all of them, packs them into one node / edge / candidate / query table, runs ONE launch per distinct parameter set (band width
+// differs between the first read of a window and the later ones), copies results and traceback steps back and wakes exactly those
+// submitters -- while the other windows' host code keeps the CPUs busy.  (Rounds 2-3 ran a batch only when EVERY live window was
+// waiting, packed by the last arrival with everybody blocked: host and device took turns, and 4096 windows spent 1.3 s in one
+// thread's memcpy.)  The batch size finds itself: what arrives during one launch is the next batch.  It never waits for more than
+// there can be: with every live window waiting, or no window computing, it goes at once.  BSA_POA_BATCH_MIN=all restores lock-step.
+// No window ever waits for a window that has finished: bsa_sweep_batcher_leave() takes a participant out.
 #include "bsa_common.h"
 #include <algorithm>
 #include <atomic>
@@ -34,6 +39,7 @@ struct Sub {
 	int *rc;
 	const uint8_t **rows_src;      // where the submitter finds its row blocks (pinned staging) after the batch ran
 	size_t *rows_bytes;
+	bool *done;
 };
 struct SubG {                      // a program of the graph form (bsa_poa_batcher_submit_graph)
 	const bsa_poa_node_t *nodes; size_t nnodes;
@@ -44,6 +50,8 @@ struct SubG {                      // a program of the graph form (bsa_poa_batch
 	bsa_poa_result_t *res; size_t cap;
 	int *rc;
 	const uint32_t **ev_src;            // where the submitter finds its step words (pinned staging) after the batch ran
+	int *outbuf;                        // ... and which download buffer that is (given back when the steps are expanded)
+	bool *done;
 };
 struct Pinned {
 	void *p = nullptr; size_t cap = 0;
@@ -72,31 +80,30 @@ struct Dev {
 }
 
 struct bsa_sweep_batcher;
-struct Group {
+#define BSA_BATCH_OUTBUFS 4
+// the device side: buffers and statistics; only the dispatcher thread touches it (but for `outstanding`, under the batcher's lock)
+struct Engine {
 	bsa_sweep_batcher *parent = nullptr;
 	bsa_ctx_t *ctx = nullptr;
-	std::mutex m;
-	std::condition_variable cv;
+	Pinned h_gin; Dev d_gin, d_gout;                // graph form: upload staging, device input / output
+	struct Out { Pinned mem; int outstanding = 0; } gout[BSA_BATCH_OUTBUFS];       // download staging of the steps: in use until every submitter of its batch has expanded its own
+	Pinned h_in, h_rows;                // rows form: upload staging (tasks | progs | qoff | qlen | queries), download staging (results | rows)
+	int rows_outstanding = 0;
+	Dev d_in, d_rows, d_res;
+	hipEvent_t fin = nullptr;           // blocking-sync event: the dispatcher sleeps while the device works, the CPUs belong to the windows
+	uint64_t batches = 0, launches = 0, programs = 0, tasks = 0, bytes_up = 0, bytes_down = 0;
+	double device_ms = 0, wall_ms = 0, pack_ms = 0, devlock_ms = 0;
+	~Engine(){ if(fin) (void)hipEventDestroy(fin); }
+};
+struct bsa_sweep_batcher {
+	Engine eng;
+	std::mutex m;                         // pending programs, `active`, completion flags, download buffers
+	std::condition_variable cv_work, cv_done;
 	uint32_t active = 0;
-	uint64_t gen = 0;                   // batches completed
 	std::vector<Sub> pend;
 	std::vector<SubG> pendg;
-	Pinned h_gin, h_gout;               // graph form: upload staging, download staging (results | events)
-	Dev d_gin, d_gout;
-	Pinned h_in, h_rows;                // upload staging (tasks | progs | qoff | qlen | queries), download staging (results | rows)
-	Dev d_in, d_rows, d_res;
-	// statistics
-	uint64_t batches = 0, launches = 0, programs = 0, tasks = 0, bytes_up = 0, bytes_down = 0;
-	double device_ms = 0, wall_ms = 0, pack_ms = 0, devlock_ms = 0, wait_ms = 0;      // (BSA_BATCH_TIMING: packing, time under the device mutex, waiting for it)
-};
-// The windows are dealt into G groups (BSA_POA_GROUPS, default 2 from 32 windows on), each of which advances in lock-step on
-// its own; the device part of a batch runs under one mutex.  While one group's sweep is on the device (its host threads
-// blocked) the other groups' host threads have the cores: with one group the host and the device simply take turns.
-struct bsa_sweep_batcher {
-	std::vector<Group*> groups;
-	std::mutex dev;                       // one batch on the device at a time (a bsa_ctx_t is not shared between threads)
-	std::mutex am; uint32_t next = 0;     // group assignment, in order of first appearance
-	std::unordered_map<std::thread::id, Group*> of;    // a thread keeps its group for the batcher's life, whatever other batchers it uses in between
+	bool stop = false, lockstep = false;
+	std::thread disp;
 	// host-side admission: one window thread per CPU the process may use is runnable at a time (bsa_sweep_batcher_enter); a thread
 	// waiting in submit() gives its slot to another window.  Hundreds of runnable threads on a CPU-quota'd container otherwise
 	// burn the quota in a fraction of each period and everybody is throttled for the rest of it.
@@ -105,7 +112,6 @@ struct bsa_sweep_batcher {
 	void acquire(){ std::unique_lock<std::mutex> lk(tm); tcv.wait(lk, [&]{ return tokens > 0; }); tokens--; holds[std::this_thread::get_id()] = true; }
 	void release(){ std::lock_guard<std::mutex> lk(tm); auto it = holds.find(std::this_thread::get_id()); if(it != holds.end() && it->second){ it->second = false; tokens++; tcv.notify_one(); } }
 	bool holding(){ std::lock_guard<std::mutex> lk(tm); auto it = holds.find(std::this_thread::get_id()); return it != holds.end() && it->second; }
-	~bsa_sweep_batcher(){ for(Group *g : groups) delete g; }
 };
 static int host_cpus(){
 	if(const char *e = bsa_env("BSA_POA_HOST_THREADS")){ const int v = atoi(e); if(v >= 1) return v; }
@@ -117,14 +123,6 @@ static int host_cpus(){
 	}
 	return n > 0 ? n : 16;
 }
-static Group *group_of_this_thread(bsa_sweep_batcher *b){
-	std::lock_guard<std::mutex> lk(b->am);
-	auto it = b->of.find(std::this_thread::get_id());
-	if(it != b->of.end()) return it->second;
-	Group *g = b->groups[b->next % b->groups.size()]; b->next++;
-	b->of.emplace(std::this_thread::get_id(), g);
-	return g;
-}
 // field by field: the structs carry padding a caller need not have initialised
 static bool same_params(const bsa_sweep_params_t &a, const bsa_sweep_params_t &b){
 	return a.rows.mode == b.rows.mode && a.rows.bandwidth == b.rows.bandwidth && a.rows.M == b.rows.M && a.rows.X == b.rows.X && a.rows.refbonus == b.rows.refbonus &&
@@ -133,10 +131,16 @@ static bool same_params(const bsa_sweep_params_t &a, const bsa_sweep_params_t &b
 
 static size_t align16(size_t x){ return (x + 15) & ~(size_t)15; }
 
+// wait for everything queued on the stream without spinning
+static hipError_t wait_stream(Engine *b, hipStream_t st){
+	if(!b->fin && hipEventCreateWithFlags(&b->fin, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess){ b->fin = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(st); }
+	hipError_t e = hipEventRecord(b->fin, st);
+	return e != hipSuccess ? e : hipEventSynchronize(b->fin);
+}
+
 // the graph-form programs of a batch: one bsa_poa_graph_run per distinct parameter set; what comes back is 32 bytes per program
-// and its traceback steps -- no row block leaves the device
-static void run_batch_graph(Group *b){
-	std::vector<SubG> &P = b->pendg;
+// and its traceback steps -- no row block leaves the device.  `ob`: the download buffer of this batch.
+static void run_batch_graph(Engine *b, std::vector<SubG> &P, int ob){
 	const size_t n = P.size();
 	if(n == 0) return;
 	std::vector<int> grp(n, -1);
@@ -147,14 +151,14 @@ static void run_batch_graph(Group *b){
 	}
 	hipStream_t st = nullptr;
 	const int rc0 = bsa_ctx_get_stream_internal(b->ctx, &st);
-	// the download staging holds every program's result and steps until its submitter has copied them: sized for the whole batch
+	Pinned &hout = b->gout[ob].mem;
 	size_t ev_total = 0;
 	std::vector<size_t> ev_off(n, 0);
 	for(size_t k = 0; k < n; k++){ ev_off[k] = ev_total; ev_total += P[k].cap; }
 	// device: results | packed-steps counter | packed steps | per-program walk scratch; host staging: packed steps of every parameter set, one after the other
 	const size_t o_res = 0, o_cnt = align16(n * sizeof(bsa_poa_result_t)), o_pk = o_cnt + 16, o_ev = align16(o_pk + ev_total * 4);
 	int rca = rc0;
-	if(rca == BSA_OK && (!b->h_gout.need(ev_total * 4 + 64) || !b->d_gout.need(o_ev + ev_total * 4 + 64))) rca = BSA_E_NOMEM;
+	if(rca == BSA_OK && (!hout.need(ev_total * 4 + 64) || !b->d_gout.need(o_ev + ev_total * 4 + 64))) rca = BSA_E_NOMEM;
 	size_t hused = 0;                   // words of the host staging in use
 	for(size_t g = 0; g < first.size(); g++){
 		int rc = rca;
@@ -190,8 +194,6 @@ static void run_batch_graph(Group *b){
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		std::vector<bsa_poa_result_t> hres(np);
 		const auto tp1 = std::chrono::steady_clock::now();
-		std::unique_lock<std::mutex> devlk(b->parent->dev);
-		const auto tp2 = std::chrono::steady_clock::now();
 		BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
 		BCHK(hipMemcpyAsync(b->d_gin.p, b->h_gin.p, in_bytes, hipMemcpyHostToDevice, st));
 		BCHK(hipEventRecord(e0, st));
@@ -205,22 +207,21 @@ static void run_batch_graph(Group *b){
 		}
 		BCHK(hipEventRecord(e1, st));
 		BCHK(hipMemcpyAsync(hres.data(), dres, np * sizeof(bsa_poa_result_t), hipMemcpyDeviceToHost, st));
-		BCHK(hipStreamSynchronize(st));
+		BCHK(wait_stream(b, st));
 		// the steps of the set's programs: one copy of the packed words
 		size_t total = 0, down = np * sizeof(bsa_poa_result_t);
 		if(rc == BSA_OK) for(size_t i = 0; i < np; i++) if(hres[i].nevents > 0) total = std::max(total, (size_t)(uint32_t)hres[i].reserved + (size_t)hres[i].nevents);
 		if(rc == BSA_OK && total > ev_total) rc = BSA_E_HIP;
 		const size_t hbase = hused;
 		if(rc == BSA_OK && total){
-			BCHK(hipMemcpyAsync((uint32_t*)b->h_gout.p + hbase, (const uint8_t*)b->d_gout.p + o_pk, total * 4, hipMemcpyDeviceToHost, st));
-			BCHK(hipStreamSynchronize(st));
+			BCHK(hipMemcpyAsync((uint32_t*)hout.p + hbase, (const uint8_t*)b->d_gout.p + o_pk, total * 4, hipMemcpyDeviceToHost, st));
+			BCHK(wait_stream(b, st));
 			down += total * 4; hused += total;
 		}
-		devlk.unlock();
 		{
 			const auto tp3 = std::chrono::steady_clock::now();
-			b->pack_ms += std::chrono::duration<double, std::milli>(tp1 - tp0).count(); b->wait_ms += std::chrono::duration<double, std::milli>(tp2 - tp1).count();
-			b->devlock_ms += std::chrono::duration<double, std::milli>(tp3 - tp2).count();
+			b->pack_ms += std::chrono::duration<double, std::milli>(tp1 - tp0).count();
+			b->devlock_ms += std::chrono::duration<double, std::milli>(tp3 - tp1).count();
 		}
 		if(rc == BSA_OK){ float ms = 0; if(hipEventElapsedTime(&ms, e0, e1) == hipSuccess) b->device_ms += ms; }
 		if(e0) (void)hipEventDestroy(e0);
@@ -228,26 +229,17 @@ static void run_batch_graph(Group *b){
 #undef BCHK
 		for(size_t i = 0; i < np; i++){
 			const SubG &s = P[mem[i]];
-			*s.rc = rc;
-			if(rc == BSA_OK){ *s.res = hres[i]; *s.ev_src = (const uint32_t*)b->h_gout.p + hbase + (uint32_t)hres[i].reserved; }
+			*s.rc = rc; *s.outbuf = ob;
+			if(rc == BSA_OK){ *s.res = hres[i]; *s.ev_src = (const uint32_t*)hout.p + hbase + (uint32_t)hres[i].reserved; }
 		}
 		b->launches++; b->programs += np; b->tasks += nn; b->bytes_up += in_bytes; b->bytes_down += down;
 	}
-	P.clear();
 }
 
-// run everything in b->pend / b->pendg (caller holds the lock; every other participant is blocked)
-static void run_batch(Group *b){
-	const auto w0 = std::chrono::steady_clock::now();
-	run_batch_graph(b);
-	std::vector<Sub> &P = b->pend;
+// the rows-form programs of a batch (what the graph form declines: a window's first read, scores outside its guard)
+static void run_batch_rows(Engine *b, std::vector<Sub> &P){
 	const size_t n = P.size();
-	if(n == 0){
-		b->batches++;
-		b->wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-		b->gen++;
-		return;
-	}
+	if(n == 0) return;
 	// groups of equal parameters, in order of first appearance
 	std::vector<int> grp(n, -1);
 	std::vector<size_t> first;
@@ -307,7 +299,6 @@ static void run_batch(Group *b){
 		}
 #define BCHK(x) do { if(rc == BSA_OK && (x) != hipSuccess){ rc = BSA_E_HIP; (void)hipGetLastError(); } } while(0)
 		hipEvent_t e0 = nullptr, e1 = nullptr;
-		std::unique_lock<std::mutex> devlk(b->parent->dev);
 		BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
 		BCHK(hipMemcpyAsync(b->d_in.p, b->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
 		BCHK(hipMemsetAsync(b->d_rows.p, 0, nblocks * blk, st));
@@ -327,8 +318,7 @@ static void run_batch(Group *b){
 			BCHK(hipMemcpyAsync((uint8_t*)b->h_rows.p + rows_off[mem[i]], (const uint8_t*)b->d_rows.p + blk0[i] * blk, s.nblocks * blk, hipMemcpyDeviceToHost, st));
 			down += s.nblocks * blk;
 		}
-		BCHK(hipStreamSynchronize(st));
-		devlk.unlock();
+		BCHK(wait_stream(b, st));
 		if(rc == BSA_OK){ float ms = 0; if(hipEventElapsedTime(&ms, e0, e1) == hipSuccess) b->device_ms += ms; }
 		if(e0) (void)hipEventDestroy(e0);
 		if(e1) (void)hipEventDestroy(e1);
@@ -344,65 +334,99 @@ static void run_batch(Group *b){
 		}
 		b->launches++; b->programs += np; b->tasks += ntasks; b->bytes_up += in_bytes; b->bytes_down += down + np * sizeof(bsa_sweep_result_t);
 	}
-	b->batches++;
-	b->wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-	P.clear();
-	b->gen++;
+}
+
+// The dispatcher: takes whatever is pending whenever the device side is free.
+static void dispatcher(bsa_sweep_batcher *bb){
+	Engine *e = &bb->eng;
+	std::unique_lock<std::mutex> lk(bb->m);
+	for(;;){
+		bb->cv_work.wait(lk, [&]{
+			const size_t np = bb->pend.size() + bb->pendg.size();
+			if(np == 0) return bb->stop;
+			return !bb->lockstep || np >= bb->active;
+		});
+		if(bb->pend.empty() && bb->pendg.empty()){ if(bb->stop) break; continue; }
+		std::vector<SubG> tg; std::vector<Sub> tr;
+		tg.swap(bb->pendg);
+		// rows-form programs wait for the previous rows batch's blocks to be collected (one download staging); graph batches need a free buffer
+		if(e->rows_outstanding == 0) tr.swap(bb->pend);
+		int ob = -1;
+		if(!tg.empty()){
+			for(;;){
+				for(int k = 0; k < BSA_BATCH_OUTBUFS; k++) if(e->gout[k].outstanding == 0){ ob = k; break; }
+				if(ob >= 0) break;
+				bb->cv_done.wait(lk);
+			}
+			e->gout[ob].outstanding = (int)tg.size();
+		}
+		if(tg.empty() && tr.empty()){ bb->cv_done.wait(lk); continue; }       // (only rows programs, and the staging is still being read)
+		e->rows_outstanding += (int)tr.size();
+		lk.unlock();
+		const auto w0 = std::chrono::steady_clock::now();
+		run_batch_graph(e, tg, ob);
+		run_batch_rows(e, tr);
+		e->batches++;
+		e->wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+		lk.lock();
+		for(SubG &s : tg) *s.done = true;
+		for(Sub &s : tr) *s.done = true;
+		bb->cv_done.notify_all();
+	}
 }
 
 extern "C" int bsa_sweep_batcher_create(bsa_ctx_t *ctx, uint32_t participants, bsa_sweep_batcher_t **out){
 	if(!ctx || !out || participants == 0) return BSA_E_ARG;
 	bsa_sweep_batcher *b = new (std::nothrow) bsa_sweep_batcher();
 	if(!b) return BSA_E_NOMEM;
-	uint32_t G = participants >= 32u ? 2u : 1u;
-	if(const char *e = bsa_env("BSA_POA_GROUPS")){ const int v = atoi(e); if(v >= 1 && v <= 64) G = (uint32_t)v; }
-	if(G > participants) G = participants;
-	for(uint32_t g = 0; g < G; g++){
-		Group *gr = new (std::nothrow) Group();
-		if(!gr){ delete b; return BSA_E_NOMEM; }
-		gr->parent = b; gr->ctx = ctx;
-		gr->active = participants / G + (g < participants % G ? 1u : 0u);     // threads are dealt round-robin in order of first appearance
-		b->groups.push_back(gr);
-	}
+	b->eng.parent = b; b->eng.ctx = ctx; b->active = participants;
+	if(const char *e = bsa_env("BSA_POA_BATCH_MIN")) b->lockstep = strcmp(e, "all") == 0;
+	b->disp = std::thread(dispatcher, b);
 	*out = b;
 	return BSA_OK;
 }
 
 extern "C" void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b){
-	if(b && bsa_env("BSA_BATCH_TIMING")){
-		for(size_t g = 0; g < b->groups.size(); g++){
-			const Group *q = b->groups[g];
-			fprintf(stderr, "[bsa_sweep_batcher] group %zu: %llu batches, %llu launches: packing %.1f ms, waiting for the device %.1f ms, under the device mutex %.1f ms (kernels + upload %.1f ms), all inside batches %.1f ms\n",
-				g, (unsigned long long)q->batches, (unsigned long long)q->launches, q->pack_ms, q->wait_ms, q->devlock_ms, q->device_ms, q->wall_ms);
-		}
+	if(!b) return;
+	{ std::lock_guard<std::mutex> lk(b->m); b->stop = true; }
+	b->cv_work.notify_all();
+	if(b->disp.joinable()) b->disp.join();
+	if(bsa_env("BSA_BATCH_TIMING")){
+		const Engine *q = &b->eng;
+		fprintf(stderr, "[bsa_sweep_batcher] %llu batches, %llu launches, %llu programs: packing %.1f ms, upload + kernels + download %.1f ms (kernels + upload %.1f ms), all inside batches %.1f ms\n",
+			(unsigned long long)q->batches, (unsigned long long)q->launches, (unsigned long long)q->programs, q->pack_ms, q->devlock_ms, q->device_ms, q->wall_ms);
 	}
 	delete b;
+}
+
+// blocks until the dispatcher has run the caller's program; meanwhile the caller's host slot is somebody else's
+template<class PushFn>
+static int submit_and_wait(bsa_sweep_batcher *bb, bool *done, PushFn push){
+	std::unique_lock<std::mutex> lk(bb->m);
+	if(bb->active == 0) return BSA_E_ARG;
+	push();
+	bb->cv_work.notify_one();
+	const bool had = bb->gated && bb->holding();
+	if(had) bb->release();
+	bb->cv_done.wait(lk, [&]{ return *done; });
+	lk.unlock();
+	if(had) bb->acquire();
+	return BSA_OK;
 }
 
 extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
 		const bsa_sweep_params_t *par, uint8_t *rows_out, size_t nblocks, bsa_sweep_result_t *res){
 	bsa_sweep_batcher *bb = (bsa_sweep_batcher*)vb;
 	if(!bb || !tasks || !query || !par || !res) return BSA_E_ARG;
-	Group *b = group_of_this_thread(bb);
 	int rc = BSA_E_HIP;
 	const uint8_t *src = nullptr; size_t nbytes = 0;
-	{
-		std::unique_lock<std::mutex> lk(b->m);
-		if(b->active == 0) return BSA_E_ARG;
-		const uint64_t my = b->gen;
-		Sub s{tasks, ntasks, query, slen, *par, rows_out, nblocks, res, &rc, &src, &nbytes};
-		b->pend.push_back(s);
-		if(b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
-		else {
-			const bool had = bb->gated && bb->holding();
-			if(had) bb->release();
-			b->cv.wait(lk, [&]{ return b->gen > my; });
-			if(had){ lk.unlock(); bb->acquire(); }
-		}
-	}
-	// the row blocks are copied out here, by every window's own thread (the staging is not reused before all of them
-	// have come back with their next program)
+	bool done = false;
+	const int sr = submit_and_wait(bb, &done, [&]{ bb->pend.push_back(Sub{tasks, ntasks, query, slen, *par, rows_out, nblocks, res, &rc, &src, &nbytes, &done}); });
+	if(sr != BSA_OK) return sr;
+	// the row blocks are copied out here, by every window's own thread; the staging is the next rows batch's once all have
 	if(rc == BSA_OK && rows_out && src) memcpy(rows_out, src, nbytes);
+	{ std::lock_guard<std::mutex> lk(bb->m); bb->eng.rows_outstanding--; }
+	bb->cv_work.notify_one(); bb->cv_done.notify_all();
 	return rc;
 }
 
@@ -416,10 +440,8 @@ extern "C" void bsa_sweep_batcher_enter(bsa_sweep_batcher_t *bb){
 extern "C" void bsa_sweep_batcher_leave(bsa_sweep_batcher_t *bb){
 	if(!bb) return;
 	if(bb->gated) bb->release();
-	Group *b = group_of_this_thread(bb);
-	std::unique_lock<std::mutex> lk(b->m);
-	if(b->active) b->active--;
-	if(b->pend.size() + b->pendg.size() > 0 && b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
+	{ std::lock_guard<std::mutex> lk(bb->m); if(bb->active) bb->active--; }
+	bb->cv_work.notify_one();            // (lock-step mode: the others may be complete now)
 }
 
 // graph form of submit(): the signature of the binding's graph backend (include/bsalign_poa_adapter.h).  A parameter set the
@@ -430,38 +452,26 @@ extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *node
 	bsa_sweep_batcher *bb = (bsa_sweep_batcher*)vb;
 	if(!bb || !nodes || !nnodes || !query || !par || !res || !events) return BSA_E_ARG;
 	if(bsa_poa_graph_supported(par, slen) == 0) return BSA_E_UNSUPPORTED;
-	Group *b = group_of_this_thread(bb);
-	int rc = BSA_E_HIP;
+	int rc = BSA_E_HIP, ob = -1;
 	const uint32_t *src = nullptr;
-	{
-		std::unique_lock<std::mutex> lk(b->m);
-		if(b->active == 0) return BSA_E_ARG;
-		const uint64_t my = b->gen;
-		SubG s{nodes, nnodes, edges, nedges, cands, ncands, query, slen, *par, res, events_cap, &rc, &src};
-		b->pendg.push_back(s);
-		if(b->pend.size() + b->pendg.size() >= b->active){ run_batch(b); b->cv.notify_all(); }
-		else {
-			const bool had = bb->gated && bb->holding();
-			if(had) bb->release();
-			b->cv.wait(lk, [&]{ return b->gen > my; });
-			if(had){ lk.unlock(); bb->acquire(); }
-		}
-	}
+	bool done = false;
+	const int sr = submit_and_wait(bb, &done, [&]{ bb->pendg.push_back(SubG{nodes, nnodes, edges, nedges, cands, ncands, query, slen, *par, res, events_cap, &rc, &src, &ob, &done}); });
+	if(sr != BSA_OK) return sr;
 	if(rc == BSA_OK){
-		if((size_t)res->nevents > events_cap) return BSA_E_ARG;
-		if(src) bsa_poa_expand_steps(src, res, events);       // every window's own thread expands its steps
+		if((size_t)res->nevents > events_cap) rc = BSA_E_ARG;
+		else if(src) bsa_poa_expand_steps(src, res, events);       // every window's own thread expands its steps
 		else res->reserved = 0;
 	}
+	if(ob >= 0){ std::lock_guard<std::mutex> lk(bb->m); bb->eng.gout[ob].outstanding--; }
+	bb->cv_done.notify_all();            // (the dispatcher may be waiting for a free download buffer)
 	return rc;
 }
 
 // out[0..7] = batches, launches, programs, tasks, bytes uploaded, bytes downloaded, device microseconds, wall microseconds inside the batches
 extern "C" void bsa_sweep_batcher_stats(bsa_sweep_batcher_t *bb, uint64_t out[8]){
 	if(!bb || !out) return;
-	for(int k = 0; k < 8; k++) out[k] = 0;
-	for(Group *b : bb->groups){
-		std::unique_lock<std::mutex> lk(b->m);
-		out[0] += b->batches; out[1] += b->launches; out[2] += b->programs; out[3] += b->tasks; out[4] += b->bytes_up; out[5] += b->bytes_down;
-		out[6] += (uint64_t)(b->device_ms * 1000.0); out[7] += (uint64_t)(b->wall_ms * 1000.0);
-	}
+	std::lock_guard<std::mutex> lk(bb->m);
+	const Engine *b = &bb->eng;
+	out[0] = b->batches; out[1] = b->launches; out[2] = b->programs; out[3] = b->tasks; out[4] = b->bytes_up; out[5] = b->bytes_down;
+	out[6] = (uint64_t)(b->device_ms * 1000.0); out[7] = (uint64_t)(b->wall_ms * 1000.0);
 }

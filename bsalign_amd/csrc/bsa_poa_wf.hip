@@ -1110,6 +1110,7 @@ extern "C" int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, s
 		max_slen = std::max(max_slen, pg.slen);
 		for(size_t i = 0; i < pg.nnodes; i++){
 			const bsa_poa_node_t &nd = nodes[pg.first_node + i];
+			if(nd.rpos > pg.slen) return BSA_E_ARG;                 // (the kernels index the read's profile by rpos)
 			for(int j = 0; j < 2; j++) if((nd.in[j].toff_kind & BSA_POA_IN_PRESENT) && nd.in[j].src >= i) return BSA_E_ARG;
 			if((size_t)nd.first_in + nd.n_in > pg.nedges) return BSA_E_ARG;
 			for(size_t e = 0; e < nd.n_in; e++) if(edges[pg.first_edge + nd.first_in + e].src >= i) return BSA_E_ARG;
@@ -1121,35 +1122,46 @@ extern "C" int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, s
 	int rc = bsa_ctx_get_stream_internal(ctx, &st);
 	if(rc != BSA_OK) return rc;
 	const uint32_t bw = (par->rows.bandwidth + 15u) / 16u * 16u;
-	PoaDevBuf dn, de, dc, dp, dq, dr, dv, drows, du0;
 #define PCHK(x) do { if((x) != hipSuccess) return BSA_E_HIP; } while(0)
-	PCHK(dn.alloc(nnodes * sizeof(bsa_poa_node_t))); PCHK(de.alloc(nedges * sizeof(bsa_poa_edge_t))); PCHK(dc.alloc(ncands * sizeof(bsa_poa_cand_t)));
-	PCHK(dp.alloc(nprogs * sizeof(bsa_poa_prog_t))); PCHK(dq.alloc(query_bytes + 64)); PCHK(dr.alloc(nprogs * sizeof(bsa_poa_result_t)));
-	PoaDevBuf dpk;
-	PCHK(dv.alloc(events_cap * 4)); PCHK(dpk.alloc(events_cap * 4 + 16)); PCHK(drows.alloc(nnodes * bw * 4)); PCHK(du0.alloc(nnodes * 4));
-	PCHK(hipMemcpyAsync(dn.p, nodes, nnodes * sizeof(bsa_poa_node_t), hipMemcpyHostToDevice, st));
-	if(nedges) PCHK(hipMemcpyAsync(de.p, edges, nedges * sizeof(bsa_poa_edge_t), hipMemcpyHostToDevice, st));
-	if(ncands) PCHK(hipMemcpyAsync(dc.p, cands, ncands * sizeof(bsa_poa_cand_t), hipMemcpyHostToDevice, st));
-	PCHK(hipMemcpyAsync(dp.p, progs, nprogs * sizeof(bsa_poa_prog_t), hipMemcpyHostToDevice, st));
-	PCHK(hipMemcpyAsync(dq.p, queries, query_bytes, hipMemcpyHostToDevice, st));
-	rc = bsa_poa_graph_run(ctx, (const bsa_poa_node_t*)dn.p, nnodes, (const bsa_poa_edge_t*)de.p, (const bsa_poa_cand_t*)dc.p, (const bsa_poa_prog_t*)dp.p, nprogs,
-		(const uint8_t*)dq.p, max_slen, par, (bsa_poa_result_t*)dr.p, (uint32_t*)dv.p, (uint32_t*)dpk.p + 4, (uint64_t*)dpk.p, (uint32_t*)drows.p, (int32_t*)du0.p);
+	// ONE device buffer that stays the context's (this is what a single window calls once per read: ten hipMalloc / hipFree pairs a call cost
+	// more than the kernel), ONE upload of the tables packed side by side, the rows only when the caller wants them
+	auto up = [](size_t b){ return (b + 255) & ~(size_t)255; };
+	const bool want_rows = rows_out && u0_out;
+	const size_t o_n = 0, o_e = o_n + up(nnodes * sizeof(bsa_poa_node_t)), o_c = o_e + up(nedges * sizeof(bsa_poa_edge_t)), o_p = o_c + up(ncands * sizeof(bsa_poa_cand_t)),
+		o_q = o_p + up(nprogs * sizeof(bsa_poa_prog_t)), in_bytes = o_q + up(query_bytes + 64);
+	const size_t o_r = in_bytes, o_v = o_r + up(nprogs * sizeof(bsa_poa_result_t)), o_pk = o_v + up(events_cap * 4), o_rows = o_pk + up(events_cap * 4 + 16),
+		o_u0 = o_rows + (want_rows ? up(nnodes * bw * 4) : 0), total_bytes = o_u0 + (want_rows ? up(nnodes * 4) : 0);
+	void *wsv = nullptr;
+	rc = bsa_ctx_scratch_internal(ctx, 2, total_bytes + 256, &wsv);
 	if(rc != BSA_OK) return rc;
-	PCHK(hipMemcpyAsync(results, dr.p, nprogs * sizeof(bsa_poa_result_t), hipMemcpyDeviceToHost, st));
+	uint8_t *ws = (uint8_t*)wsv;
+	static thread_local std::vector<uint8_t> stage;
+	if(stage.size() < in_bytes) stage.resize(in_bytes + in_bytes / 4);
+	memcpy(stage.data() + o_n, nodes, nnodes * sizeof(bsa_poa_node_t));
+	if(nedges) memcpy(stage.data() + o_e, edges, nedges * sizeof(bsa_poa_edge_t));
+	if(ncands) memcpy(stage.data() + o_c, cands, ncands * sizeof(bsa_poa_cand_t));
+	memcpy(stage.data() + o_p, progs, nprogs * sizeof(bsa_poa_prog_t));
+	memcpy(stage.data() + o_q, queries, query_bytes);
+	PCHK(hipMemcpyAsync(ws, stage.data(), in_bytes, hipMemcpyHostToDevice, st));
+	rc = bsa_poa_graph_run(ctx, (const bsa_poa_node_t*)(ws + o_n), nnodes, (const bsa_poa_edge_t*)(ws + o_e), (const bsa_poa_cand_t*)(ws + o_c), (const bsa_poa_prog_t*)(ws + o_p), nprogs,
+		ws + o_q, max_slen, par, (bsa_poa_result_t*)(ws + o_r), (uint32_t*)(ws + o_v), (uint32_t*)(ws + o_pk) + 4, (uint64_t*)(ws + o_pk),
+		want_rows ? (uint32_t*)(ws + o_rows) : nullptr, want_rows ? (int32_t*)(ws + o_u0) : nullptr);
+	if(rc != BSA_OK) return rc;
+	PCHK(hipMemcpyAsync(results, ws + o_r, nprogs * sizeof(bsa_poa_result_t), hipMemcpyDeviceToHost, st));
 	PCHK(hipStreamSynchronize(st));
 	{
 		// the packed steps of all programs in one copy, expanded into (node, x, bt) here
 		size_t total = 0;
 		for(size_t k = 0; k < nprogs; k++) if(results[k].nevents > 0) total = std::max(total, (size_t)(uint32_t)results[k].reserved + (size_t)results[k].nevents);
-		std::vector<uint32_t> pk(total);
-		if(total) PCHK(hipMemcpyAsync(pk.data(), (const uint32_t*)dpk.p + 4, total * 4, hipMemcpyDeviceToHost, st));
-		PCHK(hipStreamSynchronize(st));
+		static thread_local std::vector<uint32_t> pk;
+		if(pk.size() < total) pk.resize(total + total / 4);
+		if(total){ PCHK(hipMemcpyAsync(pk.data(), (const uint32_t*)(ws + o_pk) + 4, total * 4, hipMemcpyDeviceToHost, st)); PCHK(hipStreamSynchronize(st)); }
 		for(size_t k = 0; k < nprogs; k++) bsa_poa_expand_steps(pk.data() + (uint32_t)results[k].reserved, &results[k], events + progs[k].first_event);
 	}
-	if(rows_out && u0_out){
+	if(want_rows){
 		std::vector<uint32_t> cells(nnodes * bw);
-		PCHK(hipMemcpyAsync(cells.data(), drows.p, nnodes * bw * 4, hipMemcpyDeviceToHost, st));
-		PCHK(hipMemcpyAsync(u0_out, du0.p, nnodes * 4, hipMemcpyDeviceToHost, st));
+		PCHK(hipMemcpyAsync(cells.data(), ws + o_rows, nnodes * bw * 4, hipMemcpyDeviceToHost, st));
+		PCHK(hipMemcpyAsync(u0_out, ws + o_u0, nnodes * 4, hipMemcpyDeviceToHost, st));
 		PCHK(hipStreamSynchronize(st));
 		for(size_t k = 0; k < nprogs; k++){
 			for(size_t i = 0; i < progs[k].nnodes; i++){
@@ -1164,7 +1176,6 @@ extern "C" int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, s
 			}
 		}
 	}
-	PCHK(hipStreamSynchronize(st));
 #undef PCHK
 	return BSA_OK;
 }
