@@ -75,6 +75,12 @@ template<int L> static __device__ __forceinline__ uint32_t x_bcast_last(uint32_t
 }
 // block b receives the value of block b - 1 (low half: block l, high half: block l + L); block 0 receives fill_lo
 template<int L> static __device__ __forceinline__ uint32_t x_shift_down(uint32_t x, uint32_t fill_lo, bool first){
+	if constexpr (L == 4){
+		// a pair is one DPP quad: ONE rotation brings every lane its neighbour and lane 0 the last lane's value, ONE byte permute (the
+		// selector is a loop invariant of the lane) puts that value's low half above the fill in lane 0 and leaves the others as they are
+		const uint32_t r = XDPP(0, x, XQP(3, 0, 1, 2), 0xf);
+		return __builtin_amdgcn_perm(r, fill_lo, first ? 0x05040100u : 0x07060504u);
+	}
 	const uint32_t s = XDPP(0, x, XROW_SHR(1), 0xf);
 	const uint32_t w = XDPP(0, x, XROW_SHL(L - 1), 0xf);  // first lane <- last lane
 	const uint32_t fix = (w << 16) | (fill_lo & 0xffffu);
@@ -82,6 +88,10 @@ template<int L> static __device__ __forceinline__ uint32_t x_shift_down(uint32_t
 }
 // block b receives the value of block b + 1; block 2L - 1 receives fill (given in both halves)
 template<int L> static __device__ __forceinline__ uint32_t x_shift_up(uint32_t x, uint32_t fill, bool last){
+	if constexpr (L == 4){
+		const uint32_t r = XDPP(0, x, XQP(1, 2, 3, 0), 0xf);             // (lane 3 receives lane 0's value: its high half goes below the fill)
+		return __builtin_amdgcn_perm(fill, r, last ? 0x05040302u : 0x03020100u);
+	}
 	const uint32_t s = XDPP(0, x, XROW_SHL(1), 0xf);
 	const uint32_t w = XDPP(0, x, XROW_SHR(L - 1), 0xf);  // last lane <- first lane
 	const uint32_t fix = __builtin_amdgcn_alignbit(fill, w, 16);        // {fill.lo, w.hi}
@@ -718,8 +728,12 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		if constexpr (STATIC){ U[0] = tmpU0; NE[0] = tmpNE0; if constexpr (PW == 2) NQ2[0] = tmpNQ0; }
 		// ---- speculative slide by one cell: the first cell of every block becomes the last cell of the block before it
 		else {
-			const uint32_t nxt = XDPP(0, tmpU0, XROW_SHL(1), 0xf);          // (a DPP move must not sit in an arm of ?: -- only one arm runs)
-			const uint32_t inu = last ? __builtin_amdgcn_alignbit(NEWU0, bc0, 16) : nxt;
+			uint32_t inu;
+			if constexpr (L == 4) inu = x_shift_up<L>(tmpU0, NEWU0, last);
+			else {
+				const uint32_t nxt = XDPP(0, tmpU0, XROW_SHL(1), 0xf);          // (a DPP move must not sit in an arm of ?: -- only one arm runs)
+				inu = last ? __builtin_amdgcn_alignbit(NEWU0, bc0, 16) : nxt;
+			}
 			const uint32_t inne = x_shift_up<L>(tmpNE0, NEWNE, last);
 			U[W - 1] = inu; NE[W - 1] = inne;
 			if constexpr (PW == 2){ NQ2[W - 1] = x_shift_up<L>(tmpNQ0, NEWNE, last); svNQ = tmpNQ0; }

@@ -39,7 +39,7 @@ struct Sub {
 	int *rc;
 	const uint8_t **rows_src;      // where the submitter finds its row blocks (pinned staging) after the batch ran
 	size_t *rows_bytes;
-	bool *done;
+	bool *done; std::condition_variable *cv;      // the submitter's own: nobody else is woken when its program has run
 };
 struct SubG {                      // a program of the graph form (bsa_poa_batcher_submit_graph)
 	const bsa_poa_node_t *nodes; size_t nnodes;
@@ -51,7 +51,7 @@ struct SubG {                      // a program of the graph form (bsa_poa_batch
 	int *rc;
 	const uint32_t **ev_src;            // where the submitter finds its step words (pinned staging) after the batch ran
 	int *outbuf;                        // ... and which download buffer that is (given back when the steps are expanded)
-	bool *done;
+	bool *done; std::condition_variable *cv;
 };
 struct Pinned {
 	void *p = nullptr; size_t cap = 0;
@@ -98,7 +98,7 @@ struct Engine {
 struct bsa_sweep_batcher {
 	Engine eng;
 	std::mutex m;                         // pending programs, `active`, completion flags, download buffers
-	std::condition_variable cv_work, cv_done;
+	std::condition_variable cv_work, cv_buf;        // the dispatcher's: programs are pending / a download buffer has been given back
 	uint32_t active = 0;
 	std::vector<Sub> pend;
 	std::vector<SubG> pendg;
@@ -131,11 +131,17 @@ static bool same_params(const bsa_sweep_params_t &a, const bsa_sweep_params_t &b
 
 static size_t align16(size_t x){ return (x + 15) & ~(size_t)15; }
 
-// wait for everything queued on the stream without spinning
+// wait for everything queued on the stream without spinning: the CPUs belong to the windows (a blocking-sync event wakes up milliseconds
+// late in this runtime, hipStreamSynchronize spins: the event is polled between short sleeps)
 static hipError_t wait_stream(Engine *b, hipStream_t st){
-	if(!b->fin && hipEventCreateWithFlags(&b->fin, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess){ b->fin = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(st); }
+	if(!b->fin && hipEventCreateWithFlags(&b->fin, hipEventDisableTiming) != hipSuccess){ b->fin = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(st); }
 	hipError_t e = hipEventRecord(b->fin, st);
-	return e != hipSuccess ? e : hipEventSynchronize(b->fin);
+	if(e != hipSuccess) return e;
+	for(unsigned spin = 0; ; spin++){
+		e = hipEventQuery(b->fin);
+		if(e != hipErrorNotReady) return e;
+		if(spin < 20) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(40));
+	}
 }
 
 // the graph-form programs of a batch: one bsa_poa_graph_run per distinct parameter set; what comes back is 32 bytes per program
@@ -356,11 +362,11 @@ static void dispatcher(bsa_sweep_batcher *bb){
 			for(;;){
 				for(int k = 0; k < BSA_BATCH_OUTBUFS; k++) if(e->gout[k].outstanding == 0){ ob = k; break; }
 				if(ob >= 0) break;
-				bb->cv_done.wait(lk);
+				bb->cv_buf.wait(lk);
 			}
 			e->gout[ob].outstanding = (int)tg.size();
 		}
-		if(tg.empty() && tr.empty()){ bb->cv_done.wait(lk); continue; }       // (only rows programs, and the staging is still being read)
+		if(tg.empty() && tr.empty()){ bb->cv_buf.wait(lk); continue; }       // (only rows programs, and the staging is still being read)
 		e->rows_outstanding += (int)tr.size();
 		lk.unlock();
 		const auto w0 = std::chrono::steady_clock::now();
@@ -369,9 +375,8 @@ static void dispatcher(bsa_sweep_batcher *bb){
 		e->batches++;
 		e->wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
 		lk.lock();
-		for(SubG &s : tg) *s.done = true;
-		for(Sub &s : tr) *s.done = true;
-		bb->cv_done.notify_all();
+		for(SubG &s : tg){ *s.done = true; s.cv->notify_one(); }
+		for(Sub &s : tr){ *s.done = true; s.cv->notify_one(); }
 	}
 }
 
@@ -401,14 +406,14 @@ extern "C" void bsa_sweep_batcher_destroy(bsa_sweep_batcher_t *b){
 
 // blocks until the dispatcher has run the caller's program; meanwhile the caller's host slot is somebody else's
 template<class PushFn>
-static int submit_and_wait(bsa_sweep_batcher *bb, bool *done, PushFn push){
+static int submit_and_wait(bsa_sweep_batcher *bb, bool *done, std::condition_variable *cv, PushFn push){
 	std::unique_lock<std::mutex> lk(bb->m);
 	if(bb->active == 0) return BSA_E_ARG;
 	push();
 	bb->cv_work.notify_one();
 	const bool had = bb->gated && bb->holding();
 	if(had) bb->release();
-	bb->cv_done.wait(lk, [&]{ return *done; });
+	cv->wait(lk, [&]{ return *done; });
 	lk.unlock();
 	if(had) bb->acquire();
 	return BSA_OK;
@@ -420,13 +425,14 @@ extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, s
 	if(!bb || !tasks || !query || !par || !res) return BSA_E_ARG;
 	int rc = BSA_E_HIP;
 	const uint8_t *src = nullptr; size_t nbytes = 0;
-	bool done = false;
-	const int sr = submit_and_wait(bb, &done, [&]{ bb->pend.push_back(Sub{tasks, ntasks, query, slen, *par, rows_out, nblocks, res, &rc, &src, &nbytes, &done}); });
+	bool done = false; std::condition_variable cv;
+	const int sr = submit_and_wait(bb, &done, &cv, [&]{ bb->pend.push_back(Sub{tasks, ntasks, query, slen, *par, rows_out, nblocks, res, &rc, &src, &nbytes, &done, &cv}); });
 	if(sr != BSA_OK) return sr;
 	// the row blocks are copied out here, by every window's own thread; the staging is the next rows batch's once all have
 	if(rc == BSA_OK && rows_out && src) memcpy(rows_out, src, nbytes);
-	{ std::lock_guard<std::mutex> lk(bb->m); bb->eng.rows_outstanding--; }
-	bb->cv_work.notify_one(); bb->cv_done.notify_all();
+	bool last;
+	{ std::lock_guard<std::mutex> lk(bb->m); last = --bb->eng.rows_outstanding == 0; }
+	if(last){ bb->cv_buf.notify_one(); bb->cv_work.notify_one(); }
 	return rc;
 }
 
@@ -454,16 +460,19 @@ extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *node
 	if(bsa_poa_graph_supported(par, slen) == 0) return BSA_E_UNSUPPORTED;
 	int rc = BSA_E_HIP, ob = -1;
 	const uint32_t *src = nullptr;
-	bool done = false;
-	const int sr = submit_and_wait(bb, &done, [&]{ bb->pendg.push_back(SubG{nodes, nnodes, edges, nedges, cands, ncands, query, slen, *par, res, events_cap, &rc, &src, &ob, &done}); });
+	bool done = false; std::condition_variable cv;
+	const int sr = submit_and_wait(bb, &done, &cv, [&]{ bb->pendg.push_back(SubG{nodes, nnodes, edges, nedges, cands, ncands, query, slen, *par, res, events_cap, &rc, &src, &ob, &done, &cv}); });
 	if(sr != BSA_OK) return sr;
 	if(rc == BSA_OK){
 		if((size_t)res->nevents > events_cap) rc = BSA_E_ARG;
 		else if(src) bsa_poa_expand_steps(src, res, events);       // every window's own thread expands its steps
 		else res->reserved = 0;
 	}
-	if(ob >= 0){ std::lock_guard<std::mutex> lk(bb->m); bb->eng.gout[ob].outstanding--; }
-	bb->cv_done.notify_all();            // (the dispatcher may be waiting for a free download buffer)
+	if(ob >= 0){
+		bool last;
+		{ std::lock_guard<std::mutex> lk(bb->m); last = --bb->eng.gout[ob].outstanding == 0; }
+		if(last) bb->cv_buf.notify_one();            // (the dispatcher may be waiting for a free download buffer)
+	}
 	return rc;
 }
 
