@@ -195,9 +195,10 @@ def run_many(windows, mode, p, threads=8, record=False):
     count = np.array([len(w) for w in windows], dtype=np.int32)
     first = np.zeros(nwin, dtype=np.int32)
     first[1:] = np.cumsum(count)[:-1]
-    t0 = time.time()
+    t0 = time.time(); c0 = time.process_time()
     bad = r.ref_poa_run_many(hs, nwin, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, first.ctypes.data, count.ctypes.data, mode, threads, int(record))
     secs = time.time() - t0
+    run_many.last_cpu_seconds = time.process_time() - c0          # CPU time of the whole process over the run (all threads)
     assert bad == 0, "ref_poa_run_many: %d windows failed" % bad
     out = []
     for h in hs:

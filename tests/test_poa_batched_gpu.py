@@ -75,15 +75,17 @@ def test_256_windows_of_c4_shaped_reads(ctx, capsys):
     p = P.par()
     windows = [P.synth_reads(7000 + w, 1500, 12, eps=(0.1,)) for w in range(256)]
     ref, t_ref = P.run_many(windows, 0, p, threads=16)
+    c_ref = P.run_many.last_cpu_seconds
     for mode, what in ((7, "graph form: sweep and walk on the device"), (4, "rows form: row blocks back, host traceback")):
         bt = Batcher(ctx, len(windows))
         try:
             dev, t_dev = P.run_many(windows, mode, p)
+            c_dev = P.run_many.last_cpu_seconds
             st = bt.stats()
         finally:
             bt.close()
         _compare(ref, dev)
         with capsys.disabled():
-            print("\n[256 windows x 12 reads x 1.5 kbp] reference end_bspoa on 16 host threads %.2f s; lock-step, %s %.2f s "
-                  "(%d batches, %d launches, %d programs, %.1f MB up, %.1f MB down, device %.2f s, inside batches %.2f s)"
-                  % (t_ref, what, t_dev, st["batches"], st["launches"], st["programs"], st["bytes_up"] / 1e6, st["bytes_down"] / 1e6, st["device_us"] / 1e6, st["wall_us"] / 1e6))
+            print("\n[256 windows x 12 reads x 1.5 kbp] reference end_bspoa on 16 host threads %.2f s (%.1f CPU-seconds); through the batcher, %s %.2f s (%.1f CPU-seconds; "
+                  "%d batches, %d launches, %d programs, %.1f MB up, %.1f MB down, device %.2f s, inside batches %.2f s)"
+                  % (t_ref, c_ref, what, t_dev, c_dev, st["batches"], st["launches"], st["programs"], st["bytes_up"] / 1e6, st["bytes_down"] / 1e6, st["device_us"] / 1e6, st["wall_us"] / 1e6))
