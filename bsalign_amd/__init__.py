@@ -216,6 +216,9 @@ def pack_pairs(pairs):
     return seqs, qoff, qlen, toff, tlen
 
 
+DIAGDP_WALK_DTYPE = np.dtype([("nsteps", "<u4"), ("score", "<i4"), ("xi", "<i4"), ("yi", "<i4"), ("status", "<u4"), ("reserved", "<u4"), ("first_word", "<u8")])
+
+
 class Context:
     """one context per (thread, device) -- bsa_ctx_create / bsa_ctx_destroy"""
 
@@ -328,6 +331,26 @@ class Context:
         matrix = np.zeros(matrix_bytes, dtype=np.uint8)
         self._chk(L.bsa_diagdp_batch(self.h, planes.ctypes.data, planes.size, probs.ctypes.data, len(probs), matrix.ctypes.data, matrix.size))
         return matrix
+
+    def diagdp_walk_batch(self, planes, probs):
+        """the same DP followed by the traceback on the device (bsa_diagdp_walk_batch): no matrix comes back.
+        -> (walk records, list of uint8 step arrays: 0 diagonal, 1 x - 1, 2 y - 1)"""
+        L = lib()
+        planes = np.ascontiguousarray(planes, dtype=np.uint8)
+        probs = np.ascontiguousarray(probs, dtype=DIAGDP_PROB_DTYPE)
+        n = len(probs)
+        walks = np.zeros(n, dtype=DIAGDP_WALK_DTYPE)
+        cap = int(sum((2 * (int(p["mend"]) - int(p["mbeg"])) + 2 + 15) // 16 for p in probs)) + 1
+        words = np.zeros(cap, dtype=np.uint32)
+        L.bsa_diagdp_walk_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        self._chk(L.bsa_diagdp_walk_batch(self.h, planes.ctypes.data, planes.size, probs.ctypes.data, n, walks.ctypes.data, words.ctypes.data, cap))
+        steps = []
+        for k in range(n):
+            ns, fw = int(walks[k]["nsteps"]), int(walks[k]["first_word"])
+            w = words[fw:fw + (ns + 15) // 16]
+            st = ((w[:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3).astype(np.uint8).reshape(-1)[:ns]
+            steps.append(st)
+        return walks, steps
 
     def diagdp_last_ms(self):
         return float(lib().bsa_diagdp_last_ms(self.h))

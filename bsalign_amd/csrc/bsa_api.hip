@@ -1297,6 +1297,67 @@ extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_byt
 }
 
 // ---- anti-diagonal u8 DP of the MSA refinement (bsa_diagdp.hip), host pointers
+// fill + traceback, nothing but the steps comes back (include/bsalign_hip.h)
+extern "C" int bsa_diagdp_walk_batch(bsa_ctx_t *c, const uint8_t *planes, size_t planes_bytes, const bsa_diagdp_prob_t *probs_in, size_t n,
+		bsa_diagdp_walk_t *walks, uint32_t *steps, size_t steps_cap_words){
+	if(!c) return BSA_E_ARG;
+	if(n == 0) return BSA_OK;
+	if(!planes || !probs_in || !walks || !steps || n > 0x7fffffffu){ c->err = "bsa_diagdp_walk_batch: null argument"; return BSA_E_ARG; }
+	(void)hipSetDevice(c->device);
+	const uint32_t W = probs_in[0].W;
+	if(!(W == 1 || W == 2 || W == 4)){ c->err = "bsa_diagdp_walk_batch: W must be 1, 2 or 4"; return BSA_E_ARG; }
+	const uint64_t pad = 8ull * W, rowlen = 16ull * W + 2;
+	std::vector<bsa_diagdp_prob_t> probs(probs_in, probs_in + n);
+	std::vector<uint64_t> toff(n), woff(n);
+	uint64_t tacc = 0, macc = 0, wacc = 0; uint32_t max_len = 0;
+	for(size_t k = 0; k < n; k++){
+		bsa_diagdp_prob_t &p = probs[k];
+		if(p.W != W || p.mbeg > p.mend || p.mend > p.mlen){ c->err = "bsa_diagdp_walk_batch: bad problem"; return BSA_E_ARG; }
+		const uint64_t offs[10] = {p.seq0, p.seq1, p.mats0[0], p.mats0[1], p.mats0[2], p.mats0[3], p.mats1[0], p.mats1[1], p.mats1[2], p.mats1[3]};
+		for(uint64_t o : offs) if(o < pad || o + p.mlen + pad > planes_bytes){ c->err = "bsa_diagdp_walk_batch: plane outside the blob (8 W bytes of padding on both sides)"; return BSA_E_ARG; }
+		// the device's own layout of the difference planes: only the rows 2 mbeg .. 2 mend - 1 exist, row r at (r - 2 mbeg) * rowlen
+		const uint64_t rows = 2ull * (p.mend - p.mbeg) + 1, ms = (rows * rowlen + 15) & ~15ull;
+		p.out0 = macc - 2ull * p.mbeg * rowlen; p.out1 = macc + ms - 2ull * p.mbeg * rowlen;        // (row 0's address; wraps below the buffer, never dereferenced there)
+		macc += 2 * ms;
+		toff[k] = tacc; tacc += 2ull * (p.mlen + 16ull * W);
+		woff[k] = wacc; wacc += bsa_diagdp_walk_words(p.mbeg, p.mend);
+		max_len = std::max<uint32_t>(max_len, p.mlen + 16u * W);
+	}
+	if(wacc > steps_cap_words){ c->err = "bsa_diagdp_walk_batch: steps buffer too small"; return BSA_E_ARG; }
+	int rc = BSA_OK;
+	auto fail = [&](const char *what, hipError_t e){ c->err = std::string(what) + ": " + hipGetErrorString(e); rc = (e == hipErrorOutOfMemory) ? BSA_E_NOMEM : BSA_E_HIP; };
+	hipError_t e;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	do {
+		const size_t a256 = 255;
+		auto up = [&](size_t b){ return (b + a256) & ~a256; };
+		const size_t o_planes = 0, o_probs = up(planes_bytes), o_T = o_probs + up(n * sizeof(bsa_diagdp_prob_t)), o_toff = o_T + up(tacc * 4), o_woff = o_toff + up(n * 8),
+			o_walks = o_woff + up(n * 8), o_steps = o_walks + up(n * sizeof(bsa_diagdp_walk_t)), o_matrix = o_steps + up(wacc * 4 + 16) + 4096, total = o_matrix + macc + 4096;
+		void *ws = nullptr;
+		if((rc = bsa_ctx_scratch_internal(c, 1, total, &ws)) != BSA_OK) break;
+		uint8_t *b = (uint8_t*)ws;
+#define WCHK(x) if((e = (x)) != hipSuccess){ fail(#x, e); break; }
+		WCHK(hipMemcpyAsync(b + o_planes, planes, planes_bytes, hipMemcpyHostToDevice, c->stream));
+		WCHK(hipMemcpyAsync(b + o_probs, probs.data(), n * sizeof(bsa_diagdp_prob_t), hipMemcpyHostToDevice, c->stream));
+		WCHK(hipMemcpyAsync(b + o_toff, toff.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+		WCHK(hipMemcpyAsync(b + o_woff, woff.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+		(void)hipEventRecord(ev0, c->stream);
+		WCHK(bsa_launch_diagdp(b + o_planes, (const bsa_diagdp_prob_t*)(b + o_probs), (uint32_t*)(b + o_T), (const uint64_t*)(b + o_toff), b + o_matrix, (uint32_t)n, W, max_len, c->stream));
+		WCHK(bsa_launch_diagdp_walk(b + o_planes, (const bsa_diagdp_prob_t*)(b + o_probs), (const uint32_t*)(b + o_T), (const uint64_t*)(b + o_toff), b + o_matrix, (uint32_t)n,
+			(bsa_diagdp_walk_t*)(b + o_walks), (uint32_t*)(b + o_steps), (const uint64_t*)(b + o_woff), c->stream));
+		(void)hipEventRecord(ev1, c->stream);
+		WCHK(hipMemcpyAsync(walks, b + o_walks, n * sizeof(bsa_diagdp_walk_t), hipMemcpyDeviceToHost, c->stream));
+		WCHK(hipMemcpyAsync(steps, b + o_steps, wacc * 4, hipMemcpyDeviceToHost, c->stream));
+		WCHK(hipStreamSynchronize(c->stream));
+#undef WCHK
+		float ms = 0; if(hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) c->diagdp_ms = ms;
+	} while(0);
+	if(ev0) (void)hipEventDestroy(ev0);
+	if(ev1) (void)hipEventDestroy(ev1);
+	return rc;
+}
+
 extern "C" double bsa_diagdp_last_ms(bsa_ctx_t *c){ return c ? c->diagdp_ms : 0.0; }
 extern "C" int bsa_diagdp_batch(bsa_ctx_t *c, const uint8_t *planes, size_t planes_bytes, const bsa_diagdp_prob_t *probs, size_t n,
 		uint8_t *matrix, size_t matrix_bytes){

@@ -216,6 +216,8 @@ bool bsa_align8_do2_supported(const Align8Args &a, int pw);            // ... ab
 bool bsa_align8_trace_reads_do2(const Align8Args &a, int pw);          // the traceback kernel the launcher would pick reads code format 1
 hipError_t bsa_launch_diagdp(const uint8_t *d_planes, const bsa_diagdp_prob_t *d_probs, uint32_t *d_T, const uint64_t *d_toff, uint8_t *d_matrix,
 		uint32_t n, uint32_t W, uint32_t max_len, hipStream_t st);
+hipError_t bsa_launch_diagdp_walk(const uint8_t *d_planes, const bsa_diagdp_prob_t *d_probs, const uint32_t *d_T, const uint64_t *d_toff, const uint8_t *d_matrix,
+		uint32_t n, bsa_diagdp_walk_t *d_walks, uint32_t *d_steps, const uint64_t *d_word_off, hipStream_t st);
 // the kernels the launchers picked last (this thread), for bsa_ctx_last_kernel_name
 extern thread_local const char *bsa_last_fwd_kernel, *bsa_last_trace_kernel;
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st);

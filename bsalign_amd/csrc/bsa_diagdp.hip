@@ -118,6 +118,60 @@ __global__ void __launch_bounds__(64) k_diagdp_fill(const uint8_t *planes, const
 	}
 }
 
+// The traceback of remsa_pedit_rd_bspoacore (bspoa.h:3965-4040) on the device, so that the two difference planes -- 2.1 bytes a cell -- never
+// leave it: from (mend - 1, mend - 1) every step reads the cell's two rows, recomputes the column score and takes the reference's choice in
+// the reference's order (left when f alone explains the cell and it is not the band's first cell of an even row; up when e does; diagonal when
+// the column score does).  What goes back is two bits a step (0 diagonal, 1 x - 1, 2 y - 1), the score the reference returns (the sum over
+// the diagonal steps) and where the walk ended; the caller replays the steps to merge the nodes.  One lane per read: a walk is a chain of
+// dependent loads from rows the fill kernel has just written, all reads of all windows of the call side by side.
+__global__ void __launch_bounds__(64) k_diagdp_walk(const uint8_t *planes, const bsa_diagdp_prob_t *probs, const uint32_t *T, const uint64_t *toff,
+		const uint8_t *matrix, uint32_t n, bsa_diagdp_walk_t *walks, uint32_t *steps, const uint64_t *word_off){
+	const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+	if(k >= n) return;
+	const bsa_diagdp_prob_t pb = probs[k];
+	const int G = 16 * (int)pb.W, half = G / 2, rowlen = G + 2;
+	const int mlen = (int)pb.mlen, mbeg = (int)pb.mbeg, mend = (int)pb.mend;
+	const uint32_t len = pb.mlen + (uint32_t)G;
+	const uint32_t *t0 = T + toff[k] + half, *t1 = t0 + len;
+	const uint8_t *s0 = planes + pb.seq0, *s1 = planes + pb.seq1;
+	const uint8_t *o0 = matrix + pb.out0, *o1 = matrix + pb.out1;
+	uint32_t *out = steps + word_off[k];
+	auto count = [](uint32_t t, uint32_t b) -> uint32_t { return b < 4u ? (t >> (8u * b)) & 0xffu : 0u; };
+	int xi = mend - 1, yi = mend - 1, scr = 0;
+	uint32_t nst = 0, acc = 0, status = 0;
+	while(xi >= 0 && yi >= 0){
+		const int i = xi + yi;
+		if(i < mbeg + mbeg) break;
+		const int dir = i & 1;
+		const int xx = (xi - yi - dir) / 2 + half;
+		if(xx < 0 || xx >= G){ status = 1u; break; }
+		const uint32_t b0 = s0[xi], b1 = s1[mlen - 1 - yi];
+		const int h = (int)min(count(t0[xi], b1) + count(t1[mlen - 1 - yi], b0), 255u);
+		const uint8_t *r0 = o0 + (size_t)i * rowlen + 1, *r1 = o1 + (size_t)i * rowlen + 1;
+		const int e = dir ? r0[xx + 1] : r0[xx], f = dir ? r1[xx] : r1[xx - 1];
+		const int s = f + (int)o0[(size_t)(i + 1) * rowlen + 1 + xx];
+		uint32_t bt;
+		if(s == f && !(xx == 0 && dir == 0)){ bt = 1u; xi--; }
+		else if(s == e){ bt = 2u; yi--; }
+		else if(s == h){ bt = 0u; scr += s; xi--; yi--; }
+		else { status = 2u; break; }
+		acc |= bt << (2u * (nst & 15u));
+		nst++;
+		if((nst & 15u) == 0u){ out[(nst >> 4) - 1u] = acc; acc = 0; }
+	}
+	if(nst & 15u) out[nst >> 4] = acc;
+	bsa_diagdp_walk_t w;
+	w.nsteps = nst; w.score = scr; w.xi = xi; w.yi = yi; w.status = status; w.reserved = 0; w.first_word = word_off[k];
+	walks[k] = w;
+}
+
+hipError_t bsa_launch_diagdp_walk(const uint8_t *d_planes, const bsa_diagdp_prob_t *d_probs, const uint32_t *d_T, const uint64_t *d_toff, const uint8_t *d_matrix,
+		uint32_t n, bsa_diagdp_walk_t *d_walks, uint32_t *d_steps, const uint64_t *d_word_off, hipStream_t st){
+	if(n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_diagdp_walk, dim3((n + 63u) / 64u), dim3(64), 0, st, d_planes, d_probs, d_T, d_toff, d_matrix, n, d_walks, d_steps, d_word_off);
+	return hipGetLastError();
+}
+
 hipError_t bsa_launch_diagdp(const uint8_t *d_planes, const bsa_diagdp_prob_t *d_probs, uint32_t *d_T, const uint64_t *d_toff, uint8_t *d_matrix,
 		uint32_t n, uint32_t W, uint32_t max_len, hipStream_t st){
 	if(n == 0) return hipSuccess;

@@ -413,6 +413,16 @@ typedef struct {
 } bsa_diagdp_prob_t;
 int bsa_diagdp_batch(bsa_ctx_t *ctx, const uint8_t *planes, size_t planes_bytes, const bsa_diagdp_prob_t *probs, size_t n,
                      uint8_t *matrix, size_t matrix_bytes);
+/* The same fill FOLLOWED BY THE TRACEBACK of remsa_pedit_rd_bspoacore (bspoa.h:3965-4040) on the device: the difference planes stay there
+ * (2.1 bytes a cell: 12 GB for 64 windows of 64 reads x 22 k columns) and what comes back per problem is the walk from (mend - 1, mend - 1):
+ * two bits a step -- 0 diagonal (x - 1, y - 1), 1 x - 1, 2 y - 1 -- sixteen steps a word from bit 0 up, problem k's words at
+ * steps[first_word .. ], plus the score the reference returns (the sum over the diagonal steps) and where the walk stopped.  A caller
+ * replays the steps to do what the reference does at every diagonal step (merge_nodes_bspoa, bspoa.h:4011-4022).  probs[k].out0 / out1 are
+ * ignored (the planes are laid out by the library).  steps_cap_words >= sum over k of bsa_diagdp_walk_words(mbeg, mend). */
+typedef struct { uint32_t nsteps; int32_t score; int32_t xi, yi; uint32_t status, reserved; uint64_t first_word; } bsa_diagdp_walk_t;    /* status 0 ok, 1 left the band, 2 no source explains a cell (the reference aborts) */
+static inline uint64_t bsa_diagdp_walk_words(uint32_t mbeg, uint32_t mend){ return (2ull * (mend - mbeg) + 2 + 15) / 16; }
+int bsa_diagdp_walk_batch(bsa_ctx_t *ctx, const uint8_t *planes, size_t planes_bytes, const bsa_diagdp_prob_t *probs, size_t n,
+                          bsa_diagdp_walk_t *walks, uint32_t *steps, size_t steps_cap_words);
 /* device time of the last bsa_diagdp_batch (staging + fill kernels), ms */
 double bsa_diagdp_last_ms(bsa_ctx_t *ctx);
 

@@ -1287,3 +1287,37 @@ void orc_diagdp_fill(const uint8_t *seq0, const uint8_t *seq1, const uint8_t *co
 		if(x >= mend) break;
 	}
 }
+
+/* The traceback of remsa_pedit_rd_bspoacore (bspoa.h:3965-4040) over the planes orc_diagdp_fill left, without the graph work: from
+ * (mend - 1, mend - 1), per step the cell's two rows (maxmat_dp_diag_rowcal_prepare bspoa.h:3763-3787: row x + y and the one after it,
+ * band cell midx), the column score h, and the reference's choice in its order -- bt 1 (x - 1) when f alone explains the cell and it is not
+ * band cell 0 of an even row, bt 2 (y - 1) when e does, bt 0 (diagonal, score += s) when h does.  steps: one byte per step.
+ * Returns 0, 1 (left the band: the reference aborts) or 2 (nothing explains the cell: the reference aborts). */
+int orc_diagdp_walk(const uint8_t *seq0, const uint8_t *seq1, const uint8_t *const mats0[4], const uint8_t *const mats1[4],
+		int mlen, int mbeg, int mend, int W, const uint8_t *matrix0, const uint8_t *matrix1, uint8_t *steps, uint32_t *nsteps, int *score, int *xend, int *yend){
+	const int bw = W * 16, rowlen = bw + 2, half = bw / 2;
+	int xi = mend - 1, yi = mend - 1, scr = 0, status = 0;
+	uint32_t n = 0;
+	while(xi >= 0 && yi >= 0){
+		const int i = xi + yi;
+		if(i < mbeg + mbeg) break;
+		const int dir = i & 1;
+		const int xx = (xi - yi - dir) / 2 + half;
+		if(xx < 0 || xx >= bw){ status = 1; break; }
+		/* seqs[0][xx] = _seqs[0][xi], seqs[1][xx] = _seqs[1][mlen - 1 - yi] (prepare: xb = x - midx, yb = mlen - 1 - (y + midx)) */
+		const int b0 = seq0[xi], b1 = seq1[mlen - 1 - yi];
+		int h = (b1 < 4 ? mats0[b1][xi] : 0) + (b0 < 4 ? mats1[b0][mlen - 1 - yi] : 0);
+		if(h > 255) h = 255;
+		const uint8_t *r00 = matrix0 + (size_t)i * rowlen + 1, *r01 = matrix1 + (size_t)i * rowlen + 1, *r10 = matrix0 + (size_t)(i + 1) * rowlen + 1;
+		const int e = dir ? r00[xx + 1] : r00[xx], f = dir ? r01[xx] : r01[xx - 1];
+		const int s = f + r10[xx];
+		int bt;
+		if(s == f && !(xx == 0 && dir == 0)){ bt = 1; xi--; }
+		else if(s == e){ bt = 2; yi--; }
+		else if(s == h){ bt = 0; scr += s; xi--; yi--; }
+		else { status = 2; break; }
+		steps[n++] = (uint8_t)bt;
+	}
+	*nsteps = n; *score = scr; *xend = xi; *yend = yi;
+	return status;
+}

@@ -162,3 +162,5 @@ double   orc_edit_batch_time(const uint8_t *seqs, const uint64_t *qoff, const ui
  * (row = 16 W + 2 bytes, cell c at byte 1 + c) */
 void orc_diagdp_fill(const uint8_t *seq0, const uint8_t *seq1, const uint8_t *const mats0[4], const uint8_t *const mats1[4],
 		int mlen, int mbeg, int mend, int W, uint8_t *matrix0, uint8_t *matrix1);
+int orc_diagdp_walk(const uint8_t *seq0, const uint8_t *seq1, const uint8_t *const mats0[4], const uint8_t *const mats1[4],
+		int mlen, int mbeg, int mend, int W, const uint8_t *matrix0, const uint8_t *matrix1, uint8_t *steps, uint32_t *nsteps, int *score, int *xend, int *yend);

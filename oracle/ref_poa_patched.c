@@ -18,6 +18,9 @@ static bsa_ctx_t *p_ctx;
 typedef int (*fn_diagdp)(bsa_ctx_t*, const uint8_t*, size_t, const bsa_diagdp_prob_t*, size_t, uint8_t*, size_t);
 static fn_diagdp p_diagdp;
 void refp_attach_diagdp(void *diagdp){ p_diagdp = (fn_diagdp)diagdp; }
+typedef int (*fn_diagdp_walk)(bsa_ctx_t*, const uint8_t*, size_t, const bsa_diagdp_prob_t*, size_t, bsa_diagdp_walk_t*, uint32_t*, size_t);
+static fn_diagdp_walk p_diagdp_walk;
+void refp_attach_diagdp_walk(void *f){ p_diagdp_walk = (fn_diagdp_walk)f; }
 void refp_attach(void *ctx, void *sweep_host, void *bcreate, void *bdestroy, void *bsubmit, void *bleave){
 	p_ctx = (bsa_ctx_t*)ctx; p_sweep_host = (fn_sweep_host)sweep_host; p_bcreate = (fn_bcreate)bcreate; p_bdestroy = (fn_bvoid)bdestroy;
 	p_bsubmit = (fn_bsubmit)bsubmit; p_bleave = (fn_bvoid)bleave;
@@ -55,6 +58,10 @@ HID int bsa_diagdp_batch(bsa_ctx_t *c, const uint8_t *planes, size_t pb, const b
 	return p_diagdp ? p_diagdp(c, planes, pb, probs, n, m, mb) : BSA_E_UNSUPPORTED;
 }
 
+HID int bsa_diagdp_walk_batch(bsa_ctx_t *c, const uint8_t *planes, size_t pb, const bsa_diagdp_prob_t *probs, size_t n, bsa_diagdp_walk_t *w, uint32_t *steps, size_t cap){
+	return p_diagdp_walk ? p_diagdp_walk(c, planes, pb, probs, n, w, steps, cap) : BSA_E_UNSUPPORTED;
+}
+
 #include "bsalign.h"
 #include "bspoa.h"              /* the PATCHED copy (first on the include path) */
 HID size_t bsa_rows_block_bytes(uint32_t bandwidth, int8_t gapo1, int8_t gape1, int8_t gapo2, int8_t gape2){
@@ -87,7 +94,8 @@ void refp_push(void *vg, const uint8_t *reads, const uint64_t *offs, const uint3
 	free(buf);
 }
 /* how = 0: the reference's end_bspoa untouched; 1: bsa_poa_end_one on every window; 2: bsa_poa_end_many;
- * 3: end_bspoa with the MSA refinement's DP on the device (devdiag); 4: devdiag and the sweeps (bsa_poa_end_one) */
+ * 3: end_bspoa with the MSA refinement's DP on the device (devdiag); 4: devdiag and the sweeps (bsa_poa_end_one);
+ * 5: the refinement's DP AND its traceback on the device (only the steps come back); 6: that and the sweeps */
 static uint64_t g_dd_calls, g_dd_reads, g_dd_steps;
 int refp_end(void **gs, int n, int how){
 	int k;
@@ -95,8 +103,9 @@ int refp_end(void **gs, int n, int how){
 	for(k = 0; k < n; k++){
 		BSPOA *g = (BSPOA*)gs[k];
 		bsa_poa_diagdp_t dd;
-		if(how >= 3){ bsa_poa_diagdp_init(&dd, bsa_poa_diagdp_hip, p_ctx); g->devdiag = &dd; }
-		if(how == 1 || how == 4) bsa_poa_end_one(g, p_ctx); else end_bspoa(g);
+		if(how >= 5){ bsa_poa_diagdp_init_walk(&dd, bsa_poa_diagdp_walk_hip, p_ctx); g->devdiag = &dd; }
+		else if(how >= 3){ bsa_poa_diagdp_init(&dd, bsa_poa_diagdp_hip, p_ctx); g->devdiag = &dd; }
+		if(how == 1 || how == 4 || how == 6) bsa_poa_end_one(g, p_ctx); else end_bspoa(g);
 		if(how >= 3){ g->devdiag = NULL; g_dd_calls += dd.calls; g_dd_reads += dd.reads; g_dd_steps += dd.steps; bsa_poa_diagdp_free(&dd); }
 	}
 	return 0;

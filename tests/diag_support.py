@@ -108,6 +108,25 @@ def oracle_fill(planes, probs, matrix_bytes):
     return m
 
 
+def oracle_walk(planes, probs, matrix):
+    """orc_diagdp_walk over the planes a fill left -> list of (steps uint8 array, score, xi, yi, status)"""
+    orc = _libs()
+    orc.orc_diagdp_walk.restype = C.c_int
+    orc.orc_diagdp_walk.argtypes = [u8p, u8p, C.POINTER(u8p), C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p, u8p,
+                                    C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    base = planes.ctypes.data
+    out = []
+    for p in probs:
+        a0 = (u8p * 4)(*[base + o for o in p["mats0"]])
+        a1 = (u8p * 4)(*[base + o for o in p["mats1"]])
+        st = np.zeros(2 * (p["mend"] - p["mbeg"]) + 4, np.uint8)
+        n, sc, xe, ye = C.c_uint32(), C.c_int(), C.c_int(), C.c_int()
+        rc = orc.orc_diagdp_walk(base + p["seq0"], base + p["seq1"], a0, a1, p["mlen"], p["mbeg"], p["mend"], p["W"],
+                                 matrix.ctypes.data + p["out0"], matrix.ctypes.data + p["out1"], st.ctypes.data, C.byref(n), C.byref(sc), C.byref(xe), C.byref(ye))
+        out.append((st[:n.value].copy(), sc.value, xe.value, ye.value, rc))
+    return out
+
+
 def ref_fill(planes, probs, matrix_bytes):
     ref = S.ref()
     if not hasattr(ref, "_diag"):

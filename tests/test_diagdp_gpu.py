@@ -75,6 +75,60 @@ def test_c4_shaped_window(ctx):
           % (steps, ctx.diagdp_last_ms(), t_ref * 1e3, t_cpu * 1e3))
 
 
+@pytest.mark.parametrize("W", [1, 2, 4])
+def test_walk_on_the_device_equals_the_scalar_walk(ctx, W):
+    """bsa_diagdp_walk_batch: fill AND traceback on the device, only two bits a step come back -- every step, the score and the end of
+    the walk equal the scalar statement of remsa_pedit_rd_bspoacore's traceback run over the oracle's planes (several ragged windows in one call)"""
+    rng = np.random.default_rng(300 + W)
+    blobs, allp, off = [], [], 0
+    for w in range(5):
+        planes, probs = D.make_window(rng, int(rng.choice([40, 129, 333, 1000])), int(rng.integers(2, 12)), W, float(rng.choice([0.05, 0.2])), bool(w % 2))
+        for p in probs:
+            for f in ("seq0", "seq1"):
+                p[f] += off
+            p["mats0"] = [o + off for o in p["mats0"]]
+            p["mats1"] = [o + off for o in p["mats1"]]
+        blobs.append(planes)
+        allp += probs
+        off += planes.size
+    planes = np.concatenate(blobs)
+    nbytes = D.matrix_layout(allp)
+    want = D.oracle_walk(planes, allp, D.oracle_fill(planes, allp, nbytes))
+    walks, steps = ctx.diagdp_walk_batch(planes, D.to_struct(allp))
+    for k, (st, sc, xe, ye, rc) in enumerate(want):
+        assert rc == 0 and int(walks[k]["status"]) == 0, k
+        assert (int(walks[k]["score"]), int(walks[k]["xi"]), int(walks[k]["yi"])) == (sc, xe, ye), k
+        assert np.array_equal(steps[k], st), k
+
+
+def test_walk_of_64_windows_in_one_call(ctx):
+    """what the host-pointer fill cannot do: 64 windows x 24 reads x 4 k columns in ONE call -- the planes (0.85 GB) stay on the device, 3 MB of
+    steps come back; a sample of the reads against the scalar walk"""
+    import time
+    rng = np.random.default_rng(9)
+    planes, probs = D.make_window(rng, 4000, 24, 2, 0.12, False)
+    nbytes = D.matrix_layout(probs)
+    want = D.oracle_walk(planes, probs, D.oracle_fill(planes, probs, nbytes))
+    nwin = 64
+    big = np.tile(planes, nwin)
+    allp = []
+    for w in range(nwin):
+        for p in probs:
+            q = dict(p)
+            q["seq0"] += w * planes.size; q["seq1"] += w * planes.size
+            q["mats0"] = [o + w * planes.size for o in p["mats0"]]; q["mats1"] = [o + w * planes.size for o in p["mats1"]]
+            allp.append(q)
+    t0 = time.time()
+    walks, steps = ctx.diagdp_walk_batch(big, D.to_struct(allp))
+    dt = time.time() - t0
+    assert int((walks["status"] != 0).sum()) == 0
+    for w in (0, 17, 63):
+        for k, (st, sc, xe, ye, rc) in enumerate(want):
+            assert np.array_equal(steps[w * len(probs) + k], st) and int(walks[w * len(probs) + k]["score"]) == sc
+    print("\n[diag DP + walk, %d windows x %d reads x 4 k columns in one call] device kernels %.1f ms, the call %.2f s, %.1f MB of steps back (the planes: %.2f GB)"
+          % (nwin, len(probs), ctx.diagdp_last_ms(), dt, sum(len(s) for s in steps) / 4e6, nwin * nbytes / 1e9))
+
+
 def test_bad_arguments(ctx):
     import bsalign_amd as B
     planes, probs = D.make_window(np.random.default_rng(1), 100, 2, 1)

@@ -109,4 +109,13 @@ def test_refinement_dp_on_the_device_inside_end_bspoa(ctx):
     t0 = time.time(); a = _run(L, big, p, 0); t_ref = time.time() - t0
     t0 = time.time(); b = _run(L, big, p, 3); t_dev = time.time() - t0
     _same(a, b)
-    print("\n[C4 full size] end_bspoa 64 x 20 kbp: reference %.2f s, with the MSA refinement's DP on the device %.2f s" % (t_ref, t_dev))
+    # round 4: the traceback of the refinement on the device as well -- the planes stay there, two bits a step come back and the patched
+    # loop replays them (how = 5; 6: with the graph sweeps on the device too).  The same consensus and MSA is the proof that every step
+    # is the one the reference's own traceback takes: a different step merges different nodes.
+    L.refp_attach_diagdp_walk.argtypes = [C.c_void_p]
+    L.refp_attach_diagdp_walk(C.cast(B.lib().bsa_diagdp_walk_batch, C.c_void_p))
+    _same(ref, _run(L, windows, p, 5))
+    _same(ref, _run(L, windows[:3], p, 6))
+    t0 = time.time(); c = _run(L, big, p, 5); t_walk = time.time() - t0
+    _same(a, c)
+    print("\n[C4 full size] end_bspoa 64 x 20 kbp: reference %.2f s, with the MSA refinement's DP on the device %.2f s, DP and traceback on the device %.2f s" % (t_ref, t_dev, t_walk))
