@@ -858,9 +858,13 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_simple(const Align8Ar
 }
 
 // two-piece gaps (8 bits per cell, bsa_common.h; bandwidth 128): the plain walker with the nine facts of a cell
+// (W = 4, 8, 16: a reference block's eight planes of W bits -- A, D, D2, B, R1, R2, Od1, Od2 -- in W / 4 dwords, plane j at bit j W of them)
+template<int W>
 __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, bsa_result_t *out, uint32_t *cig_cnt){
-	constexpr int W = 8;
-	constexpr uint32_t CW = 2u, RB = 64u * CW;
+	static_assert(W == 4 || W == 8 || W == 16, "bandwidth 64, 128, 256");
+	constexpr uint32_t CW = (uint32_t)W / 4u, RB = 64u * CW, FULLW = (W == 16) ? 0xFFFFu : ((1u << W) - 1u);
+	struct Blk { uint32_t w[CW]; };
+	auto plane = [](const Blk &b, int j) -> uint32_t { return (b.w[(j * W) >> 5] >> ((j * W) & 31)) & FULLW; };
 	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
 	if(g >= a.count) return;
 	const uint32_t ppos = a.first + g;
@@ -891,7 +895,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 		if(idx < twb || idx >= twb + 8){ twb = max(idx - 7, 0); __builtin_memcpy(&twin, tseq + twb, 8); }
 		return (int)((twin >> (8 * (idx - twb))) & 0xffu);
 	};
-	auto load_code = [&](int r, uint32_t y) -> uint2 { return *(const uint2*)((const uint32_t*)rows + bsa_code_off((uint32_t)r, y, CW)); };
+	auto load_code = [&](int r, uint32_t y) -> Blk {
+		Blk b; const uint32_t *p = (const uint32_t*)rows + bsa_code_off((uint32_t)r, y, CW);
+#pragma unroll
+		for(uint32_t d = 0; d < CW; d++) b.w[d] = p[d];
+		return b;
+	};
 	bool bad = false;
 	const int type = a.mode & 3;
 	if(type == BSA_MODE_GLOBAL){
@@ -912,8 +921,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 		const int p = rs.qb - beg_c;
 		if(p < 0 || p >= bw){ bad = true; break; }
 		const uint32_t y = (uint32_t)p / W, k = (uint32_t)p % W, bit = 1u << (W - 1 - k);
-		const uint2 c = load_code(rs.tb, y);
-		const bool fA = (c.x & bit) != 0u, fD = ((c.x >> 8) & bit) != 0u, fD2 = ((c.x >> 16) & bit) != 0u, fB = ((c.x >> 24) & bit) != 0u;
+		const Blk c = load_code(rs.tb, y);
+		const bool fA = (plane(c, 0) & bit) != 0u, fD = (plane(c, 1) & bit) != 0u, fD2 = (plane(c, 2) & bit) != 0u, fB = (plane(c, 3) & bit) != 0u;
 		const bool fM = (fD || fD2) ? fA : (fA && !fB);
 		const int d = fD ? 1 : fD2 ? 2 : 0;                          // backcal_cell, bsalign.h:3679-3701
 		int bt;                                                       // 0 M, 1 I, 2 D
@@ -934,9 +943,9 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 				// the chains that equal h here (only reached with M = D = D2 = 0): the nearest cell to the left at which one of
 				// them was opened (bsalign.h:3798-3814: the smallest length whose cost -- the larger of the two pieces' -- closes the gap)
 				const bool ch1 = fB, ch2 = fA == fB;
-				auto rplane = [&](const uint2 &cc) -> uint32_t { return ((ch1 ? cc.y : 0u) | (ch2 ? (cc.y >> 8) : 0u)) & 0xFFu; };
+				auto rplane = [&](const Blk &cc) -> uint32_t { return (ch1 ? plane(cc, 4) : 0u) | (ch2 ? plane(cc, 5) : 0u); };
 				int sz = 0;
-				uint2 hc = c; uint32_t hb = 0;                            // block and bit of the cell the scan stops at
+				Blk hc = c; uint32_t hb = 0;                            // block and bit of the cell the scan stops at
 				const uint32_t cand = rplane(c) & ~((bit << 1) - 1u);
 				if(cand){ hb = cand & (0u - cand); sz = (int)(__builtin_ctz(cand) - (W - 1 - k)); }
 				else {
@@ -954,7 +963,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 					// larger cost at this length (always true between real DP cells; next to cells that entered the band with
 					// synthetic values it can fail, and the reference's scan then finds no length: literal path)
 					const int c1 = a.gapo1 + sz * a.gape1, c2 = a.gapo2 + sz * a.gape2;
-					const bool h1 = ch1 && (hc.y & hb) != 0u, h2 = ch2 && ((hc.y >> 8) & hb) != 0u;
+					const bool h1 = ch1 && (plane(hc, 4) & hb) != 0u, h2 = ch2 && (plane(hc, 5) & hb) != 0u;
 					if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))){ bad = true; break; }
 				}
 				cg = cig_add(cg, 1, (uint32_t)sz);
@@ -966,15 +975,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2(const Align8Args a, 
 			// bsalign.h:2632-2633), so it can fire where no deletion ends, and the reference's run-length scan, which works on real
 			// scores, then finds no opening and does not terminate -- the literal path reproduces (and flags) that
 			if(rs.qb == 0){ bad = true; break; }
-			const uint32_t osh = (d == 2) ? 24u : 16u;
+			const int opl = (d == 2) ? 7 : 6;
 			int len = 1;
 			for(;;){
 				const int r = rs.tb - len;
 				if(r == -1){ bad = true; break; }                        // row -1: the reference compares real scores there -- literal path
 				const int pr = rs.qb - begs[r + 1];
 				if(pr < 0 || pr >= bw){ bad = true; break; }
-				const uint2 c2 = load_code(r, (uint32_t)pr / W);
-				if((c2.y >> osh) & (1u << (W - 1 - (uint32_t)pr % W))) break;
+				const Blk c2 = load_code(r, (uint32_t)pr / W);
+				if(plane(c2, opl) & (1u << (W - 1 - (uint32_t)pr % W))) break;
 				len++;
 			}
 			if(bad) break;
@@ -1348,9 +1357,11 @@ hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result
 	if(a.count == 0) return hipSuccess;
 	if(a.code_fmt == 1u && !bsa_align8_trace_reads_do2(a, pw)) return hipErrorInvalidValue;
 	if(pw == 2){
+		if(a.bw == 64u){ bsa_last_trace_kernel = "k_align8_trace_codes2"; hipLaunchKernelGGL((k_align8_trace_codes2<4>), dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt); return hipGetLastError(); }
+		if(a.bw == 256u){ bsa_last_trace_kernel = "k_align8_trace_codes2"; hipLaunchKernelGGL((k_align8_trace_codes2<16>), dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt); return hipGetLastError(); }
 		if(a.bw != 128u) return hipErrorInvalidValue;
 		const char *we = bsa_env("BSA_ALIGN8_TRACE_WAVE");              // =0: the pair-per-lane walker
-		if(we && we[0] == '0'){ bsa_last_trace_kernel = "k_align8_trace_codes2"; hipLaunchKernelGGL(k_align8_trace_codes2, dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt); }
+		if(we && we[0] == '0'){ bsa_last_trace_kernel = "k_align8_trace_codes2"; hipLaunchKernelGGL((k_align8_trace_codes2<8>), dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out, cig_cnt); }
 		else { bsa_last_trace_kernel = "k_align8_trace_codes2_wave"; hipLaunchKernelGGL(k_align8_trace_codes2_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt); }
 		return hipGetLastError();
 	}

@@ -149,11 +149,11 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	constexpr int NQ = (W + 3) / 4;
 	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
 	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
-	static_assert(PW == 0 || PW == 1 || (PW == 2 && W == 8 && L == 8), "two-piece gaps: bandwidth 128, eight lanes per pair");
+	static_assert(PW == 0 || PW == 1 || (PW == 2 && ((W == 8 && (L == 8 || L == 4)) || (W == 16 && L == 8))), "two-piece gaps: bandwidth 128 (eight lanes per pair), 64 (four), 256 (eight, sixteen cells a half)");
 	static_assert(!DO2 || (PW == 1 && WR == 8), "two-bit D / Od fields: one-piece gaps, bandwidth 128");
 	constexpr int NDO = DO2 ? W / 4 : 1;                  // accumulators of the two-bit fields (four cells each, in the high byte of a half)
-	constexpr int CWD = (PW == 2) ? 2 : (WR >= 8) ? WR / 8 : 1;          // code dwords per reference block and row
-	constexpr int ND = (PW == 2) ? 4 : (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : (W == 8) ? 4 : 2;      // code dwords per lane and row
+	constexpr int CWD = (PW == 2) ? WR / 4 : (WR >= 8) ? WR / 8 : 1;          // code dwords per reference block and row (two-piece gaps: eight bits a cell)
+	constexpr int ND = (PW == 2) ? 2 * W / 4 : (WR == 8) ? 2 * NACC : (WR == 16) ? 4 : (W == 8) ? 4 : 2;      // code dwords per lane and row
 	const int lt = threadIdx.x;
 	const int jl = lt & (L - 1);
 	const bool first = jl == 0, last = jl == L - 1;
@@ -226,9 +226,10 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			HB = 0;
 		} else {
 			// sum of (u - gape1) over the cells in front of the block's end
-			auto pn_init = [&](int b) -> int { return (first_u - GE) + DP * max(0, (b + 1) * W - max(xp, 1)); };
+			auto pn_at = [&](int cells) -> int { return (first_u - GE) + DP * max(0, cells - max(xp, 1)); };
+			auto pn_init = [&](int b) -> int { return pn_at((b + 1) * W); };
 			PN = ((uint32_t)pn_init(jl) & 0xffffu) | ((uint32_t)pn_init(jl + L) << 16);
-			PM = PN;
+			PM = ((uint32_t)pn_at(jl * W + W / 2) & 0xffffu) | ((uint32_t)pn_at((jl + L) * W + W / 2) << 16);       // (the same number with one piece; with two, piece 2's cells in the block's second half do not count yet)
 			HB = a.smax - a.smin;
 		}
 	}
@@ -264,7 +265,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		PN = sp[64 * r++]; PM = sp[64 * r++]; HB = (int)sp[64 * r++]; svU = sp[64 * r++]; svNE = sp[64 * r++]; svNQ = sp[64 * r++];
 		rbeg = sp[64 * r++]; mov = sp[64 * r++]; cand_sc = (int)sp[64 * r++]; cand_te = (int)sp[64 * r++];
 	}
-	__shared__ uint32_t x_stage[NWV][16][64];       // [wave][4 q + row of the group (CWD == 1) | 4 row + dword (CWD == 2)][lane]
+	__shared__ uint32_t x_stage[NWV][4 * ND][64];       // [wave][4 q + row of the group (CWD == 1) | ND row + dword (CWD >= 2)][lane]
 	uint32_t *const stg = &x_stage[(NWV > 1) ? (lt >> 6) : 0][0][lt & 63];
 	int begq = 0;
 	if(tlen != 0u && first && row0 == 0u) begs[0] = 0;
@@ -438,7 +439,9 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		uint32_t accM[NACC], accD[NACC], accR[NACC], accO[NACC], accDO[NDO];
 #pragma unroll
 		for(int n = 0; n < NDO; n++) accDO[n] = 0;
-		uint32_t accD2 = 0, accI1 = 0, accI2 = 0, accR2 = 0, accO2 = 0;          // PW == 2 (one accumulator: W == 8)
+		uint32_t accD2[NACC], accI1[NACC], accI2[NACC], accR2[NACC], accO2[NACC];          // PW == 2
+#pragma unroll
+		for(int n = 0; n < NACC; n++){ accD2[n] = 0; accI1[n] = 0; accI2[n] = 0; accR2[n] = 0; accO2[n] = 0; }
 #pragma unroll
 		for(int n = 0; n < NACC; n++){ accM[n] = 0; accD[n] = 0; accR[n] = 0; accO[n] = 0; }
 		uint32_t tmpU0 = 0, tmpNE0 = 0, tmpNQ0 = 0, hfirst = 0;
@@ -451,15 +454,15 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			if constexpr (PW == 2){
 				const uint32_t t = x_add(h, GQQ);                  // max(m, f) + gapo2
 				h = x_max(h, g2);
-				accI1 = x_acc(accI1, x_minu(x_sub(h, f), ONE), TWO);
-				accI2 = x_acc(accI2, x_minu(x_sub(h, g2), ONE), TWO);
+				accI1[k >> 3] = x_acc(accI1[k >> 3], x_minu(x_sub(h, f), ONE), TWO);
+				accI2[k >> 3] = x_acc(accI2[k >> 3], x_minu(x_sub(h, g2), ONE), TWO);
 				const uint32_t gm = x_max(g2, t);
 				g2 = x_sub(gm, Ud[k]);
-				accR2 = x_acc(accR2, x_minu(x_sub(gm, t), ONE), TWO);
+				accR2[k >> 3] = x_acc(accR2[k >> 3], x_minu(x_sub(gm, t), ONE), TWO);
 				const uint32_t n2 = x_sub(h, qq[k]);
-				accD2 = x_acc(accD2, x_minu(n2, ONE), TWO);
+				accD2[k >> 3] = x_acc(accD2[k >> 3], x_minu(n2, ONE), TWO);
 				const uint32_t nqd = x_minu(n2, NGQQ);
-				accO2 = x_acc(accO2, x_satsubu(nqd, NGQQ1), TWO);
+				accO2[k >> 3] = x_acc(accO2[k >> 3], x_satsubu(nqd, NGQQ1), TWO);
 				nq = x_sub(nqd, DPQ);
 			}
 			const uint32_t fm = x_max(f, mg[k]);
@@ -508,7 +511,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					accDO[0] = (accDO[0] & ~0xC000u) | ((hl == q0d) ? 0x4000u : 0u) | ((fld == (uint32_t)(-GO)) ? 0x8000u : 0u);
 				} else
 				accD[0] = (accD[0] & ~b0) | ((hl == q0d) ? 0u : b0);
-				if constexpr (PW == 2) accD2 = (accD2 & ~b0) | ((hl == q0d2) ? 0u : b0);
+				if constexpr (PW == 2) accD2[0] = (accD2[0] & ~b0) | ((hl == q0d2) ? 0u : b0);
 			}
 		}
 		if(__any(act && mov > 1u)){          // (the general form covers mov == 1 of the other pairs of the wave)
@@ -523,7 +526,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					// accumulator n holds cells 8n .. 8n + CN - 1, cell c at bit 8 + CN - 1 - (c - 8n)
 					const int cd = min(max(nd - 8 * n, 0), CN), cm = min(max(nm - 8 * n, 0), CN);
 					const uint32_t md = (((1u << (CN - cd)) - 1u) << 8) << (16 * hf), mm = (((1u << (CN - cm)) - 1u) << 8) << (16 * hf);
-					if(mov != 0u){ if constexpr (!DO2) accD[n] |= md; accM[n] |= mm; if constexpr (PW == 2) accD2 |= md; }
+					if(mov != 0u){ if constexpr (!DO2) accD[n] |= md; accM[n] |= mm; if constexpr (PW == 2) accD2[n] |= md; }
 				}
 				if constexpr (DO2){
 					// "no deletion here" = a zero field becomes the spare value: cells nd .. W - 1 of the half
@@ -539,7 +542,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		} else if constexpr (DO2){
 			const uint32_t t = accDO[NDO - 1];
 			if(mov == 1u && last && (t & 0x03000000u) == 0u) accDO[NDO - 1] = t | (DOSP << 24);
-		} else { accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u; if constexpr (PW == 2) accD2 |= (mov == 1u) ? kd1 : 0u; }
+		} else { accD[NACC - 1] |= (mov == 1u) ? kd1 : 0u; if constexpr (PW == 2) accD2[NACC - 1] |= (mov == 1u) ? kd1 : 0u; }
 		if constexpr (PW == 0){
 			// linear gaps: every gap is opened at length 1 (R and Od always set); accR is kept inverted, accO is not
 #pragma unroll
@@ -550,18 +553,48 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		{
 			uint32_t cur[ND];
 			if constexpr (PW == 2){
-				// two dwords per reference block (bsa_common.h): A | D << 8 | D2 << 16 | B << 24 and R1 | R2 << 8 | Od1 << 16 | Od2 << 24.
+				// eight facts a cell (bsa_common.h): planes A, D, D2, B | R1, R2, Od1, Od2 of a reference block, W_R bits each.
 				// M, D, D2, I1, I2, R1, R2 were accumulated inverted; the decision facts fold into A = M or (no D, no D2, I1 and I2),
 				// B = not M and I1 (bit-wise on the planes, after the special cells were set above)
 				const uint32_t F8 = 0xFF00FF00u;
-				const uint32_t nA = accM[0] & (accI1 | accI2 | (~(accD[0] & accD2) & F8));
-				const uint32_t nB = (~accM[0] & F8) | accI1;
-				const uint32_t t1 = __builtin_amdgcn_perm(accD[0], nA, 0x07030501u);        // {A.lo, D.lo, A.hi, D.hi}
-				const uint32_t t2 = __builtin_amdgcn_perm(nB, accD2, 0x07030501u);          // {D2.lo, B.lo, D2.hi, B.hi}
-				const uint32_t t3 = __builtin_amdgcn_perm(accR2, accR[0], 0x07030501u);
-				const uint32_t t4 = __builtin_amdgcn_perm(accO2, accO[0], 0x07030501u);
-				cur[0] = ~__builtin_amdgcn_perm(t2, t1, 0x05040100u); cur[1] = __builtin_amdgcn_perm(t4, t3, 0x05040100u) ^ 0x0000FFFFu;     // block jl
-				cur[2] = ~__builtin_amdgcn_perm(t2, t1, 0x07060302u); cur[3] = __builtin_amdgcn_perm(t4, t3, 0x07060302u) ^ 0x0000FFFFu;     // block jl + L
+				uint32_t pl[8][NACC];                 // the eight planes as they are stored (not inverted), cells in bits 15 .. 8 of each half
+#pragma unroll
+				for(int n = 0; n < NACC; n++){
+					const uint32_t nA = accM[n] & (accI1[n] | accI2[n] | (~(accD[n] & accD2[n]) & F8));
+					const uint32_t nB = (~accM[n] & F8) | accI1[n];
+					pl[0][n] = ~nA & F8; pl[1][n] = ~accD[n] & F8; pl[2][n] = ~accD2[n] & F8; pl[3][n] = ~nB & F8;
+					pl[4][n] = ~accR[n] & F8; pl[5][n] = ~accR2[n] & F8; pl[6][n] = accO[n] & F8; pl[7][n] = accO2[n] & F8;
+				}
+				if constexpr (WR == 8){
+					// two dwords per reference block: A | D << 8 | D2 << 16 | B << 24 and R1 | R2 << 8 | Od1 << 16 | Od2 << 24
+					const uint32_t t1 = __builtin_amdgcn_perm(pl[1][0], pl[0][0], 0x07030501u);        // {A.lo, D.lo, A.hi, D.hi}
+					const uint32_t t2 = __builtin_amdgcn_perm(pl[3][0], pl[2][0], 0x07030501u);        // {D2.lo, B.lo, D2.hi, B.hi}
+					const uint32_t t3 = __builtin_amdgcn_perm(pl[5][0], pl[4][0], 0x07030501u);
+					const uint32_t t4 = __builtin_amdgcn_perm(pl[7][0], pl[6][0], 0x07030501u);
+					cur[0] = __builtin_amdgcn_perm(t2, t1, 0x05040100u); cur[1] = __builtin_amdgcn_perm(t4, t3, 0x05040100u);     // block jl
+					cur[2] = __builtin_amdgcn_perm(t2, t1, 0x07060302u); cur[3] = __builtin_amdgcn_perm(t4, t3, 0x07060302u);     // block jl + L
+				} else if constexpr (WR == 4){
+					// bandwidth 64: a half holds two reference blocks of four cells (bits 15 .. 12 and 11 .. 8); one dword a block, plane j at bits 4 j
+					uint32_t pa = 0, pb = 0;              // per half 16 bits: planes 0 .. 3 of block a / b; then planes 4 .. 7
+					uint32_t qa = 0, qb = 0;
+#pragma unroll
+					for(int j = 0; j < 4; j++){
+						pa |= ((pl[j][0] >> 12) & 0x000F000Fu) << (4 * j); pb |= ((pl[j][0] >> 8) & 0x000F000Fu) << (4 * j);
+						qa |= ((pl[4 + j][0] >> 12) & 0x000F000Fu) << (4 * j); qb |= ((pl[4 + j][0] >> 8) & 0x000F000Fu) << (4 * j);
+					}
+					cur[0] = (pa & 0xFFFFu) | (qa << 16); cur[1] = (pb & 0xFFFFu) | (qb << 16);                 // blocks 2 jl, 2 jl + 1
+					cur[2] = (pa >> 16) | (qa & 0xFFFF0000u); cur[3] = (pb >> 16) | (qb & 0xFFFF0000u);       // blocks 2 (jl + L), 2 (jl + L) + 1
+				} else {
+					// bandwidth 256: a half is one reference block of sixteen cells; four dwords a block, plane j in the halfword j of them
+					uint32_t x16[8];
+#pragma unroll
+					for(int j = 0; j < 8; j++) x16[j] = __builtin_amdgcn_perm(pl[j][0], pl[j][NACC - 1], 0x07030501u);      // {plane of the low block, plane of the high block}
+#pragma unroll
+					for(int d = 0; d < 4; d++){
+						cur[d] = __builtin_amdgcn_perm(x16[2 * d + 1], x16[2 * d], 0x05040100u);         // block jl
+						cur[4 + d] = __builtin_amdgcn_perm(x16[2 * d + 1], x16[2 * d], 0x07060302u);     // block jl + L
+					}
+				}
 			} else if constexpr (DO2){
 				// one dword per reference block: M | R << 8 | two-bit fields << 16 (cell c at bits 15 - 2c, 14 - 2c of those)
 #pragma unroll
@@ -605,7 +638,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 #pragma unroll
 				for(int q = 0; q < ND; q++) sr[256 * q] = cur[q];
 			} else {
-				uint32_t *const sr = stg + 256u * ri;
+				uint32_t *const sr = stg + (64u * ND) * ri;
 #pragma unroll
 				for(int q = 0; q < ND; q++) sr[64 * q] = cur[q];
 			}
@@ -620,13 +653,22 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 						*(uint4*)(gp + 4u * blk) = t;
 					}
 				} else {
+					// a block's four rows of CWD dwords are contiguous (row r at dword r CWD): 16-byte pieces of two rows (CWD == 2) or one (CWD == 4)
 #pragma unroll
 					for(int hf = 0; hf < 2; hf++){
 						const uint32_t blk = (uint32_t)(jl + L * hf);
-						uint4 t0, t1;              // rows 0, 1 and rows 2, 3 of the block, two dwords each
-						t0.x = stg[64 * (2 * hf)]; t0.y = stg[64 * (2 * hf + 1)]; t0.z = stg[256 + 64 * (2 * hf)]; t0.w = stg[256 + 64 * (2 * hf + 1)];
-						t1.x = stg[512 + 64 * (2 * hf)]; t1.y = stg[512 + 64 * (2 * hf + 1)]; t1.z = stg[768 + 64 * (2 * hf)]; t1.w = stg[768 + 64 * (2 * hf + 1)];
-						*(uint4*)(gp + 8u * blk) = t0; *(uint4*)(gp + 8u * blk + 4u) = t1;
+						uint32_t *bp = gp + (4u * CWD) * blk;
+#pragma unroll
+						for(int pc = 0; pc < CWD; pc++){           // piece pc: dwords 4 pc .. 4 pc + 3 of the block's 4 CWD
+							uint4 t;
+							uint32_t *tw = (uint32_t*)&t;
+#pragma unroll
+							for(int e = 0; e < 4; e++){
+								const int lin = 4 * pc + e, row = lin / CWD, d = lin % CWD;
+								tw[e] = stg[64 * (ND * row + CWD * hf + d)];
+							}
+							*(uint4*)(bp + 4 * pc) = t;
+						}
 					}
 				}
 			}
@@ -776,6 +818,11 @@ __global__ void __launch_bounds__(256) k_align8_fwd_x0(const Align8Args a){
 __global__ void __launch_bounds__(256) k_align8_fwd_x2(const Align8Args a){
 	x_forward<8, 8, 2>(a, a.first, a.count, blockIdx.x * 256u);
 }
+// ... at bandwidth 64 (four lanes per pair) and 256 (sixteen cells a half: 256 registers, two waves per SIMD)
+template<int W, int L>
+__global__ void __launch_bounds__(256) k_align8_fwd_x2w(const Align8Args a){
+	x_forward<W, L, 2>(a, a.first, a.count, blockIdx.x * 256u);
+}
 // bands that cover their whole queries (Align8Args::static_band): the row stays in place, no steering
 template<int W, int L, int PW, bool DO2 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_x_static(const Align8Args a){
@@ -830,8 +877,8 @@ static int x_cus(){
 // bytes of a.xq the persistent form needs for `count` pairs (0: the shape has no persistent form)
 size_t bsa_align8_xq_bytes(uint32_t bw, int pw, uint32_t count){
 	const uint32_t W = bw / 16u;
-	if(pw > 2 || (pw == 2 && W != 8u) || !(W == 4u || W == 8u || W == 16u)) return 0;
-	const uint32_t L = (W == 16u || pw == 2) ? 8u : 4u, Wl = (pw == 2) ? 8u : (W == 4u) ? 8u : 16u;          // lanes per pair, cells per lane and half
+	if(pw > 2 || !(W == 4u || W == 8u || W == 16u)) return 0;
+	const uint32_t L = (W == 16u || (pw == 2 && W == 8u)) ? 8u : 4u, Wl = (W == 4u || (pw == 2 && W == 8u)) ? 8u : 16u;          // lanes per pair, cells per lane and half
 	const size_t groups = ((size_t)count * L + 63u) / 64u;
 	return (16u + groups) * 4u + 256u + groups * (size_t)(XS_WORDS(Wl, pw) * 64u * 4u);
 }
@@ -869,9 +916,9 @@ bool bsa_align8_x_supported(const Align8Args &a, int pw){
 	if(ge < 0 || go < 0 || m < 0 || n < 0 || (go == 0) != (pw == 0)) return false;
 	int g = go + ge;
 	if(pw == 2){
-		// two pieces: bandwidth 128 only (all three modes: the end record of overlap / extend is the one-piece kernels'); piece 2 opens
+		// two pieces: bandwidth 64, 128, 256 (all three modes: the end record of overlap / extend is the one-piece kernels'); piece 2 opens
 		// dearer and extends cheaper (bsalign.h:2084-2092 guarantees it), the bound is taken with the dearer opening
-		if(W != 8) return false;
+		if(!(W == 4 || W == 8 || W == 16)) return false;
 		const int ge2 = -(int)(int8_t)a.gape2, go2 = -(int)(int8_t)a.gapo2;
 		if(ge2 < 0 || go2 <= go || ge2 >= ge) return false;
 		g = std::max(g, go2 + ge2);
@@ -921,6 +968,18 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 		if(pw == 0 && a.bw == 64u){ hipLaunchKernelGGL((k_align8_fwd_x_static<8, 4, 0>), dim3(b4), dim3(256), 0, st, a); return hipGetLastError(); }
 		if(pw == 0 && a.bw == 128u){ hipLaunchKernelGGL((k_align8_fwd_x_static<16, 4, 0>), dim3(b4), dim3(256), 0, st, a); return hipGetLastError(); }
 		if(pw == 0 && a.bw == 256u){ hipLaunchKernelGGL((k_align8_fwd_x_static<16, 8, 0>), dim3(b8), dim3(256), 0, st, a); return hipGetLastError(); }
+	}
+	if(pw == 2 && a.bw == 64u){
+		hipError_t qe2 = hipSuccess;
+		bsa_last_fwd_kernel = "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)";
+		if(x_launch_xq<8, 4, 2>(a, st, qe2)) return qe2;
+		hipLaunchKernelGGL((k_align8_fwd_x2w<8, 4>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a);
+		return hipGetLastError();
+	}
+	if(pw == 2 && a.bw == 256u){
+		bsa_last_fwd_kernel = "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)";
+		hipLaunchKernelGGL((k_align8_fwd_x2w<16, 8>), dim3(b8), dim3(256), 0, st, a);
+		return hipGetLastError();
 	}
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;

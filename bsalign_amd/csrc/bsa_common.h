@@ -90,8 +90,9 @@ static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t 
 //   dword offset of (row r, block y, dword d) = ((r / 4) * 64 + y * 4 + (r % 4)) * CW + d          (bsa_code_off)
 // Three neighbouring blocks of four rows are then 48 contiguous bytes (one or two 64-byte lines instead of four), and
 // the row count of a slot is rounded up to a multiple of four (bsa_code_rows).
-// (two-piece gaps: 8 bits per cell -- A, D, D2, B | R1, R2, Od1, Od2, one byte plane each at W = 8 -- twice the words)
-static inline __host__ __device__ uint32_t bsa_code_words(uint32_t W, int pw = 1){ return (W >= 8u ? W / 8u : 1u) * (pw == 2 ? 2u : 1u); }
+// (two-piece gaps: 8 bits per cell -- the planes A, D, D2, B, R1, R2, Od1, Od2 of W bits each, plane j at bit j W of the block's W / 4 dwords:
+// one dword at W = 4, the two dwords above at W = 8, four at W = 16)
+static inline __host__ __device__ uint32_t bsa_code_words(uint32_t W, int pw = 1){ return pw == 2 ? (W >= 4u ? W / 4u : 1u) : (W >= 8u ? W / 8u : 1u); }
 static inline __host__ __device__ uint32_t bsa_code_row_bytes(uint32_t W, int pw = 1){ return 64u * bsa_code_words(W, pw); }
 #define BSA_CODE_SPARE_ROWS 7u
 static inline __host__ __device__ size_t bsa_code_off(uint32_t r, uint32_t y, uint32_t CW){ return ((size_t)(r >> 2) * 64u + y * 4u + (r & 3u)) * CW; }

@@ -132,6 +132,26 @@ def test_code_rows_with_two_bit_fields(ctx, monkeypatch, xq):
     assert "two-bit" not in ctx.last_kernel_names()[0]
 
 
+@pytest.mark.parametrize("bw", [64, 256])
+def test_two_piece_gaps_at_bandwidth_64_and_256_take_the_compact_path(ctx, bw, monkeypatch):
+    """the two-piece code rows generalised from eight cells a reference block to four (one dword a block) and sixteen (four dwords):
+    k_align8_fwd_x2 + k_align8_trace_codes2 instead of row records, all three modes, also in row segments"""
+    rng = np.random.default_rng(640 + bw)
+    pairs = _mk_pairs(rng, 120, [1, 9, 17, 63, 64, 65, 130, 300, 1000, 2200], eps_list=(0.0, 0.05, 0.15, 0.3), ratios=(1.0, 1.0, 0.8, 1.3))
+    for _ in range(30):
+        Lt = int(rng.integers(20, 400))
+        pairs.append((rng.integers(0, 4, size=max(int(Lt * float(rng.choice([3.0, 0.4]))), 1)).astype(np.uint8), rng.integers(0, 4, size=Lt).astype(np.uint8)))
+    for sc in (SCORINGS["twopiece"], (1, -3, -2, -2, -6, -1)):
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+            _check(ctx, pairs, mode, bw, sc)
+            fwd, trace = ctx.last_kernel_names()
+            assert "k_align8_fwd_x2" in fwd and trace == "k_align8_trace_codes2", (fwd, trace)
+    if bw == 64:
+        monkeypatch.setenv("BSA_ALIGN8_XQ", "1")
+        monkeypatch.setenv("BSA_ALIGN8_XQ_SEG", "64")
+        _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS["twopiece"])
+
+
 def test_synthetic_10k_bw128(ctx):
     """the benchmark shape (C2): 10 kbp synthetic pairs, global, bw 128"""
     pairs = [S.synth_pair(k, 10000) for k in range(24)]
