@@ -149,7 +149,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	constexpr int NQ = (W + 3) / 4;
 	constexpr int NACC = (W + 7) / 8;                     // flag accumulators per plane (8 cells each)
 	constexpr int TOPBIT = 8 + ((W < 8) ? W : 8) - 1;     // accumulator bit of the first cell it holds
-	static_assert(PW == 0 || PW == 1 || (PW == 2 && ((W == 8 && (L == 8 || L == 4)) || (W == 16 && L == 8))), "two-piece gaps: bandwidth 128 (eight lanes per pair), 64 (four), 256 (eight, sixteen cells a half)");
+	static_assert(PW == 0 || PW == 1 || (PW == 2 && ((W == 8 && (L == 8 || L == 4)) || (W == 16 && (L == 8 || L == 4)))), "two-piece gaps: bandwidth 128 (eight lanes per pair), 64 (four), 256 (eight, sixteen cells a half)");
 	static_assert(!DO2 || (PW == 1 && WR == 8), "two-bit D / Od fields: one-piece gaps, bandwidth 128");
 	constexpr int NDO = DO2 ? W / 4 : 1;                  // accumulators of the two-bit fields (four cells each, in the high byte of a half)
 	constexpr int CWD = (PW == 2) ? WR / 4 : (WR >= 8) ? WR / 8 : 1;          // code dwords per reference block and row (two-piece gaps: eight bits a cell)
@@ -566,13 +566,16 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 					pl[4][n] = ~accR[n] & F8; pl[5][n] = ~accR2[n] & F8; pl[6][n] = accO[n] & F8; pl[7][n] = accO2[n] & F8;
 				}
 				if constexpr (WR == 8){
-					// two dwords per reference block: A | D << 8 | D2 << 16 | B << 24 and R1 | R2 << 8 | Od1 << 16 | Od2 << 24
-					const uint32_t t1 = __builtin_amdgcn_perm(pl[1][0], pl[0][0], 0x07030501u);        // {A.lo, D.lo, A.hi, D.hi}
-					const uint32_t t2 = __builtin_amdgcn_perm(pl[3][0], pl[2][0], 0x07030501u);        // {D2.lo, B.lo, D2.hi, B.hi}
-					const uint32_t t3 = __builtin_amdgcn_perm(pl[5][0], pl[4][0], 0x07030501u);
-					const uint32_t t4 = __builtin_amdgcn_perm(pl[7][0], pl[6][0], 0x07030501u);
-					cur[0] = __builtin_amdgcn_perm(t2, t1, 0x05040100u); cur[1] = __builtin_amdgcn_perm(t4, t3, 0x05040100u);     // block jl
-					cur[2] = __builtin_amdgcn_perm(t2, t1, 0x07060302u); cur[3] = __builtin_amdgcn_perm(t4, t3, 0x07060302u);     // block jl + L
+					// two dwords per reference block: A | D << 8 | D2 << 16 | B << 24 and R1 | R2 << 8 | Od1 << 16 | Od2 << 24; a half holds NACC blocks
+#pragma unroll
+					for(int n = 0; n < NACC; n++){
+						const uint32_t t1 = __builtin_amdgcn_perm(pl[1][n], pl[0][n], 0x07030501u);        // {A.lo, D.lo, A.hi, D.hi}
+						const uint32_t t2 = __builtin_amdgcn_perm(pl[3][n], pl[2][n], 0x07030501u);        // {D2.lo, B.lo, D2.hi, B.hi}
+						const uint32_t t3 = __builtin_amdgcn_perm(pl[5][n], pl[4][n], 0x07030501u);
+						const uint32_t t4 = __builtin_amdgcn_perm(pl[7][n], pl[6][n], 0x07030501u);
+						cur[2 * n] = __builtin_amdgcn_perm(t2, t1, 0x05040100u); cur[2 * n + 1] = __builtin_amdgcn_perm(t4, t3, 0x05040100u);                         // block NACC jl + n
+						cur[2 * (NACC + n)] = __builtin_amdgcn_perm(t2, t1, 0x07060302u); cur[2 * (NACC + n) + 1] = __builtin_amdgcn_perm(t4, t3, 0x07060302u);     // block NACC (jl + L) + n
+					}
 				} else if constexpr (WR == 4){
 					// bandwidth 64: a half holds two reference blocks of four cells (bits 15 .. 12 and 11 .. 8); one dword a block, plane j at bits 4 j
 					uint32_t pa = 0, pb = 0;              // per half 16 bits: planes 0 .. 3 of block a / b; then planes 4 .. 7
@@ -653,10 +656,13 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 						*(uint4*)(gp + 4u * blk) = t;
 					}
 				} else {
-					// a block's four rows of CWD dwords are contiguous (row r at dword r CWD): 16-byte pieces of two rows (CWD == 2) or one (CWD == 4)
+					// a block's four rows of CWD dwords are contiguous (row r at dword r CWD): 16-byte pieces of two rows (CWD == 2) or one (CWD == 4);
+					// a half holds RBH whole reference blocks, the lane's dwords of block (hf, n) are cur[CWD (RBH hf + n) ..]
+					constexpr int RBH = (WR == 8) ? NACC : 1;
 #pragma unroll
-					for(int hf = 0; hf < 2; hf++){
-						const uint32_t blk = (uint32_t)(jl + L * hf);
+					for(int hb = 0; hb < 2 * RBH; hb++){
+						const int hf = hb / RBH, n = hb % RBH;
+						const uint32_t blk = (uint32_t)(RBH * (jl + L * hf) + n);
 						uint32_t *bp = gp + (4u * CWD) * blk;
 #pragma unroll
 						for(int pc = 0; pc < CWD; pc++){           // piece pc: dwords 4 pc .. 4 pc + 3 of the block's 4 CWD
@@ -665,7 +671,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 #pragma unroll
 							for(int e = 0; e < 4; e++){
 								const int lin = 4 * pc + e, row = lin / CWD, d = lin % CWD;
-								tw[e] = stg[64 * (ND * row + CWD * hf + d)];
+								tw[e] = stg[64 * (ND * row + CWD * hb + d)];
 							}
 							*(uint4*)(bp + 4 * pc) = t;
 						}
@@ -847,8 +853,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
 // ideal.  ctl[0] = next item, ctl[16 + g] = segments of group g that are done (release / acquire at agent scope: the next segment
 // usually runs on another CU).  An item only ever waits for an item that was handed out before it, i.e. one that is running.
 struct XQArgs { uint32_t *ctl; uint32_t *state; uint32_t ngroups, nseg, seg_rows; };
-template<int W, int L, int PW, bool DO2 = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_xq(const Align8Args a, const XQArgs q){
+template<int W, int L, int PW, bool DO2 = false, int WPS = 3>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPS))) k_align8_fwd_xq(const Align8Args a, const XQArgs q){
 	// one item per wave (a block is a wave: the dispatcher refills a wave slot the moment it is free); the ticket, not the block
 	// index, names the item, so that an item's predecessor is always one that has started
 	uint32_t id = 0;
@@ -883,12 +889,12 @@ size_t bsa_align8_xq_bytes(uint32_t bw, int pw, uint32_t count){
 	return (16u + groups) * 4u + 256u + groups * (size_t)(XS_WORDS(Wl, pw) * 64u * 4u);
 }
 // true when the launch was made
-template<int W, int L, int PW, bool DO2 = false>
+template<int W, int L, int PW, bool DO2 = false, int WPS = 3>
 static bool x_launch_xq(const Align8Args &a, hipStream_t st, hipError_t &err){
 	const char *qe = bsa_env("BSA_ALIGN8_XQ");
 	if(!a.xq || (qe && qe[0] == '0')) return false;
 	const uint32_t groups = (uint32_t)(((size_t)a.count * L + 63u) / 64u);
-	const uint32_t workers = (uint32_t)x_cus() * 12u;          // three waves per SIMD
+	const uint32_t workers = (uint32_t)x_cus() * 4u * (uint32_t)WPS;          // waves per SIMD x SIMDs
 	if(!(qe && qe[0] == '1') && groups <= workers) return false;       // one generation: whole pairs
 	const size_t ctl_bytes = ((16u + (size_t)groups) * 4u + 255u) & ~(size_t)255u;
 	if(ctl_bytes + (size_t)groups * (XS_WORDS(W, PW) * 64u * 4u) > a.xq_bytes) return false;
@@ -902,7 +908,7 @@ static bool x_launch_xq(const Align8Args &a, hipStream_t st, hipError_t &err){
 	q.ctl = a.xq; q.state = (uint32_t*)((uint8_t*)a.xq + ctl_bytes); q.ngroups = groups; q.nseg = nseg; q.seg_rows = seg_rows;
 	err = hipMemsetAsync(a.xq, 0, ctl_bytes, st);
 	if(err != hipSuccess) return true;
-	hipLaunchKernelGGL((k_align8_fwd_xq<W, L, PW, DO2>), dim3(groups * nseg), dim3(64), 0, st, a, q);
+	hipLaunchKernelGGL((k_align8_fwd_xq<W, L, PW, DO2, WPS>), dim3(groups * nseg), dim3(64), 0, st, a, q);
 	err = hipGetLastError();
 	bsa_last_fwd_kernel = "k_align8_fwd_xq (exact-arithmetic forward DP in row segments, 4-bit traceback codes)";
 	return true;
@@ -984,6 +990,10 @@ hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st){
 	if(pw == 2){
 		if(a.bw != 128u) return hipErrorInvalidValue;
 		hipError_t qe2 = hipSuccess;
+		// row segments: four lanes per pair at two waves per SIMD (sixteen pairs a wave share the per-row work: 126 ms against 137 for the
+		// eight-lane shape at three waves, C2's shape); BSA_ALIGN8_X2_LANES=8 keeps the eight-lane shape
+		{ const char *le = bsa_env("BSA_ALIGN8_X2_LANES");
+		  if(!(le && le[0] == '8') && x_launch_xq<16, 4, 2, false, 2>(a, st, qe2)){ bsa_last_fwd_kernel = "k_align8_fwd_xq (exact-arithmetic forward DP in row segments, two-piece gaps, four lanes per pair, 8-bit traceback codes)"; return qe2; } }
 		if(x_launch_xq<8, 8, 2>(a, st, qe2)){ bsa_last_fwd_kernel = "k_align8_fwd_xq (exact-arithmetic forward DP in row segments, two-piece gaps, 8-bit traceback codes)"; return qe2; }
 		hipLaunchKernelGGL(k_align8_fwd_x2, dim3(b8), dim3(256), 0, st, a);
 		return hipGetLastError();

@@ -150,6 +150,13 @@ def test_two_piece_gaps_at_bandwidth_64_and_256_take_the_compact_path(ctx, bw, m
         monkeypatch.setenv("BSA_ALIGN8_XQ", "1")
         monkeypatch.setenv("BSA_ALIGN8_XQ_SEG", "64")
         _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS["twopiece"])
+        # bandwidth 128 in row segments: the four-lane shape (sixteen cells a half, two reference blocks), and the eight-lane one
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+            _check(ctx, pairs, mode, 128, SCORINGS["twopiece"])
+            assert "four lanes" in ctx.last_kernel_names()[0]
+        monkeypatch.setenv("BSA_ALIGN8_X2_LANES", "8")
+        _check(ctx, pairs, S.MODE_EXTEND, 128, SCORINGS["twopiece"])
+        assert "k_align8_fwd_xq" in ctx.last_kernel_names()[0] and "four lanes" not in ctx.last_kernel_names()[0]
 
 
 def test_synthetic_10k_bw128(ctx):
