@@ -25,8 +25,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SIMDS = 1024               # 256 CUs x 4 SIMDs
-ISSUE_NS = 1.8             # one VALU instruction of the kinds these kernels are made of (packed, three-operand, DPP) per SIMD, and one scalar
-                           # instruction of a SIMD's turn at the CU's scalar unit: 4 cycles (profiles/r02f_valu_rate_probe.txt)
+CLOCK_HZ = 2.4e9           # maximum shader clock (MI355X_MICROARCH.md); the chip clocks to its power budget below it, so cycle figures derived from
+                           # wall time are upper bounds of the cycles actually spent
 
 
 def counters_for(config_workload, kernel):
@@ -48,13 +48,19 @@ def counters_for(config_workload, kernel):
 
 
 def issue_fractions(ent, kernel_ms):
-    """share of the VALU / scalar issue slots the kernel used: instructions per launch from the PMC pass of this very configuration x the
-    measured cost of an issue slot, over 1024 SIMDs and the launch's duration measured in this run"""
+    """how densely the kernel issued: SIMD cycles (at the chip's 2.4 GHz maximum, MI355X_MICROARCH.md) per VALU / scalar instruction, from the
+    instruction counts of the PMC pass of this very configuration and the launch's duration measured in this run over 1024 SIMDs.  The packed,
+    three-operand and DPP instructions these kernels are made of occupy a SIMD for 4 cycles, plain two-operand 32-bit ones for 2
+    (profiles/r02f_valu_rate_probe.txt), and a SIMD's turn at the CU's scalar unit comes every 4: `valu_frac` = 4 / cycles per VALU instruction, capped
+    at 1 -- a stream with some 2-cycle instructions in it can issue faster than one per 4 cycles, which is then reported as full."""
     if not ent or kernel_ms <= 0 or "valu_per_launch" not in ent:
         return None
-    cap = SIMDS * kernel_ms * 1e6 / ISSUE_NS          # issue slots of the chip during the launch
-    return {"valu_frac": round(ent["valu_per_launch"] / cap, 4), "salu_frac": round(ent["salu_per_launch"] / cap, 4),
-            "valu_per_launch": ent["valu_per_launch"], "salu_per_launch": ent["salu_per_launch"], "slot_ns": ISSUE_NS,
+    cyc = SIMDS * kernel_ms * 1e-3 * CLOCK_HZ          # SIMD cycles of the chip during the launch
+    cpv = cyc / max(ent["valu_per_launch"], 1.0)
+    cps = cyc / max(ent["salu_per_launch"], 1.0)
+    return {"simd_cycles_per_valu": round(cpv, 3), "simd_cycles_per_salu": round(cps, 3),
+            "valu_frac": round(min(1.0, 4.0 / cpv), 4), "salu_frac": round(min(1.0, 4.0 / cps), 4),
+            "valu_per_launch": ent["valu_per_launch"], "salu_per_launch": ent["salu_per_launch"], "clock_hz": CLOCK_HZ,
             "kernel_instance": ent.get("kernel_instance"), "counts_from": ent.get("source")}
 
 
