@@ -201,6 +201,17 @@ def run_many(windows, mode, p, threads=8, record=False):
     run_many.last_cpu_seconds = time.process_time() - c0          # CPU time of the whole process over the run (all threads)
     assert bad == 0, "ref_poa_run_many: %d windows failed" % bad
     out = []
+    bs = np.zeros(3)
+    try:
+        r.ref_poa_binding_seconds.argtypes = [C.c_void_p, C.c_void_p]
+        r.ref_poa_binding_seconds.restype = None
+        for h in hs:
+            b3 = np.zeros(3)
+            r.ref_poa_binding_seconds(h, b3.ctypes.data)
+            bs += b3
+    except AttributeError:
+        pass
+    run_many.last_binding_seconds = bs          # summed over the windows: building programs, inside the backend (waiting), applying walks
     for h in hs:
         n = r.ref_poa_cns_len(h)
         cns, qlt, alt = (np.zeros(n, np.uint8) for _ in range(3))

@@ -81,11 +81,13 @@ def test_256_windows_of_c4_shaped_reads(ctx, capsys):
         try:
             dev, t_dev = P.run_many(windows, mode, p)
             c_dev = P.run_many.last_cpu_seconds
+            b_dev = P.run_many.last_binding_seconds
             st = bt.stats()
         finally:
             bt.close()
         _compare(ref, dev)
         with capsys.disabled():
             print("\n[256 windows x 12 reads x 1.5 kbp] reference end_bspoa on 16 host threads %.2f s (%.1f CPU-seconds); through the batcher, %s %.2f s (%.1f CPU-seconds; "
+                  "binding, summed over the windows: building programs %.2f s, waiting for the device %.2f s, applying walks %.2f s; "
                   "%d batches, %d launches, %d programs, %.1f MB up, %.1f MB down, device %.2f s, inside batches %.2f s)"
-                  % (t_ref, c_ref, what, t_dev, c_dev, st["batches"], st["launches"], st["programs"], st["bytes_up"] / 1e6, st["bytes_down"] / 1e6, st["device_us"] / 1e6, st["wall_us"] / 1e6))
+                  % (t_ref, c_ref, what, t_dev, c_dev, b_dev[0], b_dev[1], b_dev[2], st["batches"], st["launches"], st["programs"], st["bytes_up"] / 1e6, st["bytes_down"] / 1e6, st["device_us"] / 1e6, st["wall_us"] / 1e6))
