@@ -1064,8 +1064,12 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 	void *stop = nullptr;
 	rc = bsa_ctx_time_begin_internal(ctx, 0.0, &stop);
 	if(rc != BSA_OK) return rc;
+	// (the attribute is raised once per instantiation and size, and a failure closes the timing scope)
 #define POA_LAUNCH(PWV, RV) do {                                                                                                          \
-		if(hipFuncSetAttribute((const void*)k_poa_wf<PWV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BSA_E_HIP; \
+		static size_t lds_set = 0;                                                                                                        \
+		if(lds > lds_set){                                                                                                                \
+			if(hipFuncSetAttribute((const void*)k_poa_wf<PWV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess){ (void)bsa_ctx_time_end_internal(ctx, stop); return BSA_E_HIP; } \
+			lds_set = lds; }                                                                                                              \
 		hipLaunchKernelGGL((k_poa_wf<PWV, RV>), dim3((uint32_t)nprogs), dim3(64), lds, st, a); } while(0)
 #define POA_LAUNCH_R(RV) do { if(pw == 0) POA_LAUNCH(0, RV); else if(pw == 1) POA_LAUNCH(1, RV); else POA_LAUNCH(2, RV); } while(0)
 	if(!rows_fwd) POA_LAUNCH_R(0);
@@ -1074,7 +1078,7 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 	else POA_LAUNCH_R(4);
 #undef POA_LAUNCH_R
 #undef POA_LAUNCH
-	if(hipGetLastError() != hipSuccess) return BSA_E_HIP;
+	if(hipGetLastError() != hipSuccess){ (void)bsa_ctx_time_end_internal(ctx, stop); return BSA_E_HIP; }
 	return bsa_ctx_time_end_internal(ctx, stop);
 }
 

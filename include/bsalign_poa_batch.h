@@ -9,10 +9,10 @@
  *   bsa_poa_end_many(gs, n, ctx);                      instead of n calls of end_bspoa (bspoa.h:4722)
  *   gs[k]->cns / qlt / alt / msacols                   as before
  *
- * One POA is sequential in its reads, windows are independent: every window runs the reference's
- * own end_bspoa on a host thread of its own, and wherever that would sweep the graph (align_rd_bspoacore,
- * bspoa.h:2515-2618) the program goes to the batcher of libbsalign_hip (bsa_sweep_batcher_submit), which runs read r of
- * ALL windows as one device launch.  bsa_poa_end_one() is the single-window form (bsa_sweep_host behind it).
+ * One POA is sequential in its reads, windows are independent: a pool of host threads runs the reference's
+ * own end_bspoa window after window, and wherever that would sweep the graph (align_rd_bspoacore, bspoa.h:2515-2618) the program goes
+ * to the batcher of libbsalign_hip (bsa_poa_batcher_submit_graph / bsa_sweep_batcher_submit), whose dispatcher thread runs whatever
+ * programs are pending as one device launch.  bsa_poa_end_one() is the single-window form (bsa_poa_graph_host / bsa_sweep_host behind it).
  */
 #ifndef BSALIGN_POA_BATCH_H
 #define BSALIGN_POA_BATCH_H
@@ -24,61 +24,77 @@
 #ifndef BSA_POA_WAVE
 #define BSA_POA_WAVE 1024
 #endif
+#ifndef BSA_POA_POOL
+#define BSA_POA_POOL 256         /* window threads alive at once: the batcher runs whatever is pending, so a pool that takes the windows one after the other keeps the host's working set to this many graphs */
+#endif
 
 typedef struct {
-	BSPOA *g;
+	BSPOA **gs;
+	int n, t, nt;                                        /* this worker takes windows t, t + nt, ... */
 	bsa_sweep_batcher_t *batcher;
 } bsa_poa_many_job_t;
 
 static inline void bsa_poa_end_one(BSPOA *g, bsa_ctx_t *ctx);
 
+/* a worker: one window after the other.  The batcher runs whatever programs are pending whenever the device side is free (no lock-step since
+ * round 4), so the windows need not be alive together: BSA_POA_POOL workers keep that many graphs in the host's caches instead of all of them. */
 static void *bsa_poa_many_thread(void *vp){
 	bsa_poa_many_job_t *j = (bsa_poa_many_job_t*)vp;
 	bsa_poa_adapter_t ad;
-	bsa_sweep_batcher_enter(j->batcher);                 /* (runs while it holds one of the host slots) */
+	int k;
 	bsa_poa_adapter_init_graph(&ad, bsa_poa_batcher_submit_graph, bsa_sweep_batcher_submit, j->batcher);
-	j->g->devsweep = &ad;
-	end_bspoa(j->g);
-	j->g->devsweep = NULL;
-	bsa_sweep_batcher_leave(j->batcher);                 /* this window submits nothing more */
+	for(k=j->t;k<j->n;k+=j->nt){
+		bsa_sweep_batcher_enter(j->batcher);             /* (runs while it holds one of the host slots) */
+		j->gs[k]->devsweep = &ad;
+		end_bspoa(j->gs[k]);
+		j->gs[k]->devsweep = NULL;
+		bsa_sweep_batcher_leave(j->batcher);             /* gives the slot back; in lock-step mode: this participant submits nothing more */
+	}
 	bsa_poa_adapter_free(&ad);
 	return NULL;
 }
 
-/* end_bspoa for n windows in lock-step on the device.  Returns 0 or a BSA_E_* code (nothing was run then). */
+/* end_bspoa for n windows with their sweeps and walks on the device, batched.  Returns 0 or a BSA_E_* code (nothing was run then). */
 static inline int bsa_poa_end_many(BSPOA **gs, int n, bsa_ctx_t *ctx){
-	bsa_sweep_batcher_t *b;
+	bsa_sweep_batcher_t *b = NULL;
 	bsa_poa_many_job_t *jobs;
 	pthread_t *th;
 	char *up;
-	int k, rc, w0, wn, started;
+	const char *le = getenv("BSA_POA_BATCH_MIN");
+	int k, rc, nt, started = 0;
 	if(n <= 0) return BSA_OK;
-	jobs = (bsa_poa_many_job_t*)calloc((size_t)n, sizeof(bsa_poa_many_job_t));
-	th = (pthread_t*)calloc((size_t)n, sizeof(pthread_t));
-	up = (char*)calloc((size_t)n, 1);
+	if(le && strcmp(le, "all") == 0 && n > BSA_POA_WAVE){        /* lock-step: at most BSA_POA_WAVE windows (threads) at a time */
+		for(k=0;k<n;k+=BSA_POA_WAVE){ rc = bsa_poa_end_many(gs + k, (n - k < BSA_POA_WAVE)? n - k : BSA_POA_WAVE, ctx); if(rc != BSA_OK) return rc; }
+		return BSA_OK;
+	}
+	/* lock-step (BSA_POA_BATCH_MIN=all) needs every window alive: a thread each, as in rounds 2-3 */
+	nt = (le && strcmp(le, "all") == 0) ? ((n < BSA_POA_WAVE)? n : BSA_POA_WAVE) : ((n < BSA_POA_POOL)? n : BSA_POA_POOL);
+	jobs = (bsa_poa_many_job_t*)calloc((size_t)nt, sizeof(bsa_poa_many_job_t));
+	th = (pthread_t*)calloc((size_t)nt, sizeof(pthread_t));
+	up = (char*)calloc((size_t)nt, 1);
 	if(jobs == NULL || th == NULL || up == NULL){ free(jobs); free(th); free(up); return BSA_E_NOMEM; }
 	cal_permutation_bspoa(MAX_LOG_CACHE, 0);             /* the reference fills this table lazily (bspoa.h:3391-3401): do it before any thread reads it */
-	/* one host thread per window, at most BSA_POA_WAVE windows (threads) alive at once: a polisher hands over thousands */
-	rc = BSA_OK;
-	for(w0=0;w0<n && rc==BSA_OK;w0+=BSA_POA_WAVE){
-		wn = (n - w0 < BSA_POA_WAVE)? n - w0 : BSA_POA_WAVE;
-		b = NULL;
-		rc = bsa_sweep_batcher_create(ctx, (uint32_t)wn, &b);
-		if(rc != BSA_OK) break;
-		started = 0;
-		for(k=w0;k<w0+wn;k++){
-			jobs[k].g = gs[k]; jobs[k].batcher = b;
-			up[k] = (pthread_create(&th[k], NULL, bsa_poa_many_thread, &jobs[k]) == 0);
-			if(up[k]) started ++;
-			else bsa_sweep_batcher_leave(b);             /* nobody will submit for this window: the others must not wait for it */
-		}
-		for(k=w0;k<w0+wn;k++) if(up[k]) pthread_join(th[k], NULL);
-		bsa_sweep_batcher_destroy(b);
-		/* windows whose thread could not be started run here, one by one */
-		for(k=w0;k<w0+wn;k++) if(!up[k]) bsa_poa_end_one(gs[k], ctx);
+	rc = bsa_sweep_batcher_create(ctx, (uint32_t)n, &b);
+	if(rc != BSA_OK){ free(jobs); free(th); free(up); return rc; }
+	for(k=0;k<nt;k++){
+		jobs[k].gs = gs; jobs[k].n = n; jobs[k].t = k; jobs[k].nt = nt; jobs[k].batcher = b;
+		up[k] = (pthread_create(&th[k], NULL, bsa_poa_many_thread, &jobs[k]) == 0);
+		if(up[k]) started ++;
+	}
+	for(k=0;k<nt;k++) if(up[k]) pthread_join(th[k], NULL);
+	/* windows of a worker that could not be started run here, one by one (their participants leave the batcher first) */
+	for(k=0;k<nt;k++) if(!up[k]){
+		int w;
+		for(w=k;w<n;w+=nt){ bsa_sweep_batcher_leave(b); }
+	}
+	bsa_sweep_batcher_destroy(b);
+	for(k=0;k<nt;k++) if(!up[k]){
+		int w;
+		for(w=k;w<n;w+=nt) bsa_poa_end_one(gs[w], ctx);
 	}
 	free(jobs); free(th); free(up);
-	return rc;
+	(void)started;
+	return BSA_OK;
 }
 
 /* end_bspoa of one window with its sweeps on the device */

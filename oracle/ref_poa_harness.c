@@ -495,7 +495,15 @@ int ref_poa_run_many(void **handles, int nwin, const uint8_t *reads, const uint6
 		jobs[w].handle = handles[w]; jobs[w].reads = reads; jobs[w].offs = offs + first[w]; jobs[w].lens = lens + first[w];
 		jobs[w].nreads = count[w]; jobs[w].mode = mode; jobs[w].record = record;
 	}
-	if(mode == 4 || mode == 7 || threads >= nwin){
+	if(mode == 4 || mode == 7){
+		/* through the batcher: since it runs whatever is pending (round 4) the windows need not all be alive at once -- a pool of
+		 * BSA_POA_POOL threads (default 256) takes them one after the other, which keeps the working set to that many graphs.  With
+		 * BSA_POA_BATCH_MIN=all (lock-step) every window keeps a thread of its own. */
+		const char *pe = getenv("BSA_POA_POOL"), *le = getenv("BSA_POA_BATCH_MIN");
+		const int pool = (le && strcmp(le, "all") == 0) ? nwin : (pe && atoi(pe) > 0) ? atoi(pe) : 256;
+		threads = pool < nwin ? pool : nwin;
+	}
+	if(threads >= nwin){
 		for(w = 0; w < nwin; w++) pthread_create(&th[w], NULL, many_thread, &jobs[w]);
 		for(w = 0; w < nwin; w++) pthread_join(th[w], NULL);
 	} else {
