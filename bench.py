@@ -86,8 +86,9 @@ def parse():
     ap.add_argument("--scoring", default="2,-6,-3,-2,0,0", help="M,X,O,E,Q,P (reference CLI defaults, main.c:264)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs of the CPU baseline sample (0 = auto, -1 = skip)")
     ap.add_argument("--workspace-gb", type=float, default=0.0)
-    ap.add_argument("--poa-source", default="auto", choices=["auto", "synthetic", "recorded"], help="poa workload: graph programs recorded from the reference's end_bspoa on "
-                    "synthetic reads (needs oracle/_ref; the default when it is there) or synthetic row-task programs for the first form of the sweep (poa_synth)")
+    ap.add_argument("--poa-source", default="auto", choices=["auto", "synthetic", "recorded", "fixture"], help="poa workload: graph programs recorded from the reference's end_bspoa on "
+                    "synthetic reads (needs oracle/_ref; the default when it is there), the programs the reference recorded into tests/golden/poa_graph.npz tiled over the windows "
+                    "(fixture: the default without oracle/_ref), or synthetic row-task programs for the first form of the sweep (poa_synth)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, count them over the process group and print {n_gpus}: "
                     "the launcher's own test (gloo when there is no GPU)")
@@ -334,28 +335,39 @@ def main_poa_recorded(args):
     (include/bsalign_poa_adapter.h: nodes, in-edges, candidates) is recorded; the timed region runs all of them on the device the
     way the lock-step batcher does -- read r of all windows as one launch per band width: forward DP as a wavefront, best end cell,
     traceback (bsa_poa_graph_run).  Every program's best end cell is checked against what the reference's own sweep found.
+    `--poa-source fixture` runs the same launches on the programs committed in tests/golden/poa_graph.npz (case 0, the default
+    parameters; every window the same six reads) and needs no reference build: no cpu_baseline and no end-to-end leg then.
     Single GPU."""
     import torch
     import bsalign_amd as B
     import support as S
     import poa_support as P
-    if not S.have_ref():
-        print(json.dumps({"error": "oracle/_ref/libbsref.so absent: recorded POA programs need the reference build"}))
+    fixture = args.poa_source == "fixture"
+    if not fixture and not S.have_ref():
+        print(json.dumps({"error": "oracle/_ref/libbsref.so absent: recorded POA programs need the reference build (--poa-source fixture runs the committed ones)"}))
         return
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     nwin = args.pairs or 256
-    nreads, L = 12, (args.length or 1500)
-    pp = P.par()
-    windows = [P.synth_reads((SEED + 977 * w) & 0x7FFFFFFF, L, nreads, eps=(args.eps,)) for w in range(nwin)]
     ncores = len(physical_cores())
     q = cpu_quota()
     ncores = min(ncores, q) if q else ncores
-    _, t_ref = P.run_many(windows, 0, pp, threads=ncores)
-    rec, _ = P.run_many(windows, 1, pp, threads=ncores, record=2)
-    core_seconds = sum(w["core_seconds"] for w in rec)
-    updates = sum(w["core_updates"] for w in rec)
-    merges = sum(w["core_merges"] for w in rec)
+    if fixture:
+        # the programs the reference recorded into tests/golden/poa_graph.npz (case 0: default parameters), every window the same six reads
+        case = P.load_golden_graph()[0]
+        pp = case["par"]
+        nreads, L = len(case["reads"]), max(rc["slen"] for rc in case["reads"])
+        rec = [dict(recs=case["reads"]) for _ in range(nwin)]
+        windows, t_ref, core_seconds, updates, merges = None, None, 0.0, 0.0, 0.0
+    else:
+        nreads, L = 12, (args.length or 1500)
+        pp = P.par()
+        windows = [P.synth_reads((SEED + 977 * w) & 0x7FFFFFFF, L, nreads, eps=(args.eps,)) for w in range(nwin)]
+        _, t_ref = P.run_many(windows, 0, pp, threads=ncores)
+        rec, _ = P.run_many(windows, 1, pp, threads=ncores, record=2)
+        core_seconds = sum(w["core_seconds"] for w in rec)
+        updates = sum(w["core_updates"] for w in rec)
+        merges = sum(w["core_merges"] for w in rec)
     lib = B.lib()
     ctx = B.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -381,6 +393,8 @@ def main_poa_recorded(args):
                 pres = (tk & 0x80000000) != 0
                 nu = int((pres & ((tk & 0x40000000) == 0)).sum()); nm = int((pres & ((tk & 0x40000000) != 0)).sum())
                 cells += float(nu) * bw; balg += (2.0 * nu + 3.0 * nm) * blk
+                if fixture:
+                    updates += nu; merges += nm
         qb = np.zeros(q0 + 64, np.uint8)
         for i, rc in enumerate(rcs):
             qb[int(progs[i]["query_off"]):int(progs[i]["query_off"]) + rc["slen"]] = rc["query"]
@@ -424,6 +438,8 @@ def main_poa_recorded(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     e2e = None
     try:
+        if fixture:
+            raise RuntimeError("not run: the end-to-end leg drives the reference's own host code (oracle/_ref)")
         from test_poa_batched_gpu import Batcher
         bt = Batcher(ctx, nwin)
         try:
@@ -440,17 +456,26 @@ def main_poa_recorded(args):
         e2e = {"error": str(ex)}
     nl = len(launches)
     achieved = (balg / nl) / (kms_tot / nl / 1e3) / 1e9 if kms_tot > 0 else 0.0
-    shape = "poa-recorded|n%d|reads%d|L%d" % (nwin, nreads, L)
+    shape = "poa-%s|n%d|reads%d|L%d" % ("fixture" if fixture else "recorded", nwin, nreads, L)
     ent = counters_for(shape, "k_poa_wf")
     traffic = traffic_of(ent)
+    if fixture:
+        cpub = {"value": None, "unit": "GCUPS", "cores": 0, "kind": "reference", "sample": "not measured: oracle/_ref is absent and the fixture holds programs, not reads (the default "
+                "source, recorded, times the reference's align_rd_bspoacore on the same windows)"}
+    else:
+        cpub = {"value": round(updates * 128 / (t_ref * 0 + core_seconds / ncores) / 1e9, 4) if core_seconds > 0 else None, "unit": "GCUPS", "cores": ncores, "kind": "reference",
+                         "sample": "the reference's align_rd_bspoacore inside end_bspoa of the same %d windows on %d host threads (one window per thread at a time): %.2f s summed over threads "
+                                   "= %.4f GCUPS per core; the whole end_bspoa of all windows: %.2f s = %.1f windows/s" % (nwin, ncores, core_seconds, updates * 128 / core_seconds / 1e9 if core_seconds > 0 else 0, t_ref, nwin / t_ref),
+                         "end_bspoa_windows_per_s": round(nwin / t_ref, 2), "threads": ncores}
     line = {
         "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP (align_rd_bspoacore) + traceback (alignment2graph_bspoa) on recorded programs",
         "value": round(cells * args.steps / elapsed / 1e9, 3), "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 (exact image of the reference's i8 differences)",
-        "data": "graph-form programs recorded from the reference's end_bspoa (oracle/_ref, outside the timed region) on synthetic reads, seed %d" % SEED,
-        "config": {"workload": "poa-recorded: %d POA windows x %d reads x %d bp (eps %.2f), default POA parameters (overlap, bandwidth 128, 2-piece gaps); a step = every read's "
+        "data": ("graph-form programs the reference's end_bspoa recorded into tests/golden/poa_graph.npz (case 0), every window the same %d reads" % nreads) if fixture else
+                "graph-form programs recorded from the reference's end_bspoa (oracle/_ref, outside the timed region) on synthetic reads, seed %d" % SEED,
+        "config": {"workload": "poa-%s: %d POA windows x %d reads x %d bp (eps %.2f), default POA parameters (overlap, bandwidth 128, 2-piece gaps); a step = every read's "
                                "sweep and traceback of every window, read r of all windows per launch (%d launches, %d programs, %.0f row updates + %.0f merges, %d traceback steps)"
-                               % (nwin, nreads, L, args.eps, nl, nprog_total, updates, merges, steps_total),
+                               % ("fixture" if fixture else "recorded", nwin, nreads, L, args.eps, nl, nprog_total, updates, merges, steps_total),
                    "shape": shape, "windows": nwin, "pairs_per_gpu": nwin, "bandwidth": 128, "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": "k_poa_wf<2, 2> (row-at-a-time forward pass + ring traceback)", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
@@ -459,10 +484,7 @@ def main_poa_recorded(args):
                      "note": "latency-bound, not HBM-bound: one wave per read, a graph node per trip (about 335 instructions, 4 clocks each for a lone wave: DESIGN section 4b); "
                              "throughput grows with the windows in flight (14 KB of LDS per read: 11 reads per CU)"},
         "checks": {"best_end_cell_identical_all_programs": bool(ident), "programs": nprog_total},
-        "cpu_baseline": {"value": round(updates * 128 / (t_ref * 0 + core_seconds / ncores) / 1e9, 4) if core_seconds > 0 else None, "unit": "GCUPS", "cores": ncores, "kind": "reference",
-                         "sample": "the reference's align_rd_bspoacore inside end_bspoa of the same %d windows on %d host threads (one window per thread at a time): %.2f s summed over threads "
-                                   "= %.4f GCUPS per core; the whole end_bspoa of all windows: %.2f s = %.1f windows/s" % (nwin, ncores, core_seconds, updates * 128 / core_seconds / 1e9 if core_seconds > 0 else 0, t_ref, nwin / t_ref),
-                         "end_bspoa_windows_per_s": round(nwin / t_ref, 2), "threads": ncores},
+        "cpu_baseline": cpub,
         "lockstep_end_to_end": e2e,
     }
     print(json.dumps(line), flush=True)
@@ -473,8 +495,8 @@ def main_poa(args):
     """C4-shaped workload: the per-read sweep (align_rd_bspoacore) of many POA windows side by side, one program per window"""
     if args.poa_source == "auto":
         import support as S
-        args.poa_source = "recorded" if (S.have_ref() and int(os.environ.get("WORLD_SIZE", "1")) == 1) else "synthetic"
-    if args.poa_source == "recorded":
+        args.poa_source = "synthetic" if int(os.environ.get("WORLD_SIZE", "1")) != 1 else "recorded" if S.have_ref() else "fixture"
+    if args.poa_source in ("recorded", "fixture"):
         return main_poa_recorded(args)
     import torch
     import bsalign_amd as B

@@ -19,7 +19,8 @@ KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
     ["--workload", "edit", "--pairs", "1024", "--length", "5000", "--cpu-pairs", "10"],
     ["--workload", "edit", "--mode", "extend", "--bw", "-1", "--pairs", "512", "--length", "3000", "--cpu-pairs", "10"],
     ["--workload", "poa", "--pairs", "256", "--length", "800", "--cpu-pairs", "-1"],
-], ids=["align8", "edit", "edit-extend-full", "poa"])
+    ["--workload", "poa", "--poa-source", "fixture", "--pairs", "64", "--cpu-pairs", "-1"],
+], ids=["align8", "edit", "edit-extend-full", "poa", "poa-fixture"])
 def test_one_json_line_with_the_contract_keys(args):
     r = subprocess.run([sys.executable, os.path.join(S.ROOT, "bench.py"), "--steps", "2", "--warmup", "1"] + args,
                        capture_output=True, text=True, timeout=900, cwd=S.ROOT)
@@ -35,6 +36,8 @@ def test_one_json_line_with_the_contract_keys(args):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     if "checks" in j and "oracle_identical_first8" in j["checks"]:
         assert j["checks"]["oracle_identical_first8"] is True and j["checks"]["pairs_flagged"] == 0
+    if "fixture" in args:          # the committed programs: runs with oracle/_ref absent, every best end cell the reference's
+        assert j["checks"]["best_end_cell_identical_all_programs"] is True and j["checks"]["programs"] == 64 * 6 and j["cpu_baseline"]["value"] is None
     if args[-1] != "-1":
         cb = j["cpu_baseline"]
         # one pinned process per physical core the container may use, the one-core figure beside it (poa: one core)
