@@ -379,7 +379,7 @@ def main_poa_recorded(args):
     launches, cells, balg, nprog_total = [], 0.0, 0.0, 0
     for (r, bw), rcs in sorted(groups.items()):
         sp = B.SweepParams()
-        sp.rows = B.RowsParams(pp["alnmode"], bw, pp["M"], pp["X"], pp["refbonus"], pp["O"], pp["E"], pp["Q"], pp["P"])
+        sp.rows = B.RowsParams(pp["alnmode"] | (0x200 if os.environ.get("BSA_BENCH_POA_FWD_ONLY") else 0), bw, pp["M"], pp["X"], pp["refbonus"], pp["O"], pp["E"], pp["Q"], pp["P"])
         sp.T = pp["T"]
         blk = lib.bsa_rows_block_bytes(bw, pp["O"], pp["E"], pp["Q"], pp["P"])
         progs = np.zeros(len(rcs), B.POA_PROG_DTYPE)

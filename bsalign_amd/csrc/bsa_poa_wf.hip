@@ -756,6 +756,25 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 #else
 #define POA_TRK(k_)
 #endif
+				// The walk's state is uniform, and kept so for the compiler: every value that comes out of memory or out of one lane goes
+				// through v_readfirstlane / v_readlane, so that the loop's tests are scalar compares and branches and the lanes' work below has
+				// no divergent branch in it.
+#define POA_UNI(v_) __builtin_amdgcn_readfirstlane((int)(v_))
+				n = POA_UNI(n); nidx = n; x = POA_UNI(x); Hs1 = POA_UNI(Hs1); ne = 0; done = POA_UNI(done) != 0; status = POA_UNI(status);
+				lo = POA_UNI(lo); elo = POA_UNI(elo); ehi = POA_UNI(ehi);
+				bool hv = false; uint32_t h_rpos = 0, h_first = 0, h_w3 = 0;      // the walker's node record, when the step that chose the node brought it along
+				const int h0init = poa_init_h<PW>(a, 0);
+				const bool ovl = mode == BSA_MODE_OVERLAP;
+				auto start_insertion = [&](int nrpos_){
+					// no predecessor explains the cell: an insertion run along the node's own row (bspoa.h:2412-2440)
+					const int pp = x - nrpos_;
+					if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
+					else {
+						const int u0v = POA_UNI(U0(n));
+						const int hmn = (pp == 0) ? u0v : POA_UNI(HH(n, pp - 1, CELL(n, pp - 1), u0v));
+						bt = 1u; Hs2 = 1; Hs0 = Hs1 - (POA_UNI(HH(n, pp, CELL(n, pp), u0v)) - hmn);
+					}
+				};
 				while(!done){
 					POA_TRK(0)
 					if(n == 0 || x < 0){ done = true; break; }
@@ -764,153 +783,93 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					if(lo > 0 && !npend && n < lo + POA_TNEAR + 1 + POA_TC) node_request();
 					POA_TRK(1)
 					// the walker's node: always inside the ring
-					const PoaNodeHead nd = t_nodes[n & (POA_TN - 1)].head();
-					const int nrpos = (int)nd.rpos, nin = (int)nd.n_in, nfirst = (int)nd.first_in;
+					if(!hv){ const uint4 r0 = t_nodes[n & (POA_TN - 1)].r0; h_rpos = (uint32_t)POA_UNI(r0.x); h_first = (uint32_t)POA_UNI(r0.z); h_w3 = (uint32_t)POA_UNI(r0.w); }
+					hv = false;
+					const int nrpos = (int)h_rpos, nin = (int)(h_w3 & 0xFFFFu), nfirst = (int)h_first;
+					const uint32_t nbase = (h_w3 >> 16) & 0xFFu, nflags = h_w3 >> 24;
 					while(__builtin_expect(elo > 0 && nfirst < elo, 0)){ if(!epend) edge_request(); edge_commit(); }
 					if(elo > 0 && !epend && nfirst < elo + 64) edge_request();
 					POA_TRK(2)
-					if(__builtin_expect(bt == 2u || bt == 4u, 0)){
-						EMIT(n, x, bt);
-						bool found = false;
-						for(int k = 0; k < nin && !found; k++){
-							const int ek = nfirst + k;
-							bsa_poa_edge_t ed; if(ek >= elo && ek < ehi) ed = t_edges[ek & (POA_TE - 1)]; else ed = gedges[ek];
-							const int w = (int)ed.src, wr = (int)ed.src_rpos;
-							if(x < wr || x >= wr + bw) continue;
-							const uint32_t cw = CELL(w, x - wr);
-							Hs0 = HH(w, x - wr, cw, U0(w));
-							int qv;
-							if(bt == 2u) qv = PW ? sx8(cw >> 16) : a.O + E;
-							else qv = sx8(cw >> 24);
-							if(Hs0 + qv != Hs1) continue;
-							n = w;
-							if(qv == ((bt == 2u) ? a.O + E : a.Q + P)){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
-							else { Hs1 -= (bt == 2u) ? E : P; Hs2++; }
-							found = true;
-						}
-						if(!found){ status = BSA_POA_ST_TRACE; done = true; }
-					} else if(__builtin_expect(bt == 1u, 0)){
-						EMIT(n, x, bt);
-						const int t = (PW == 2) ? max(a.O + E * Hs2, a.Q + P * Hs2) : a.O + E * Hs2;
-						x--;
-						if(Hs0 + t == Hs1){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
-						else if(x >= 0){
-							const int pp = x - nrpos;
-							if(pp < 0){ status = BSA_POA_ST_TRACE; done = true; }
-							else {
-								// us[pp] = H(pp) - H(pp - 1), us[0] = H(0) - ubegs[0]; Hs0 is H(pp) here
-								const int u0v = U0(n);
-								const int hm = (pp == 0) ? u0v : HH(n, pp - 1, CELL(n, pp - 1), u0v);
-								Hs0 -= HH(n, pp, CELL(n, pp), u0v) - hm;
-								Hs2++;
-							}
-						}
-					} else if(__builtin_expect(bt == 0u, 0)){
-						EMIT(n, x, bt);
-						x--;
-						n = nidx;
-						bt = 0xFFFFFFFFu;
-					} else {
-						uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
-						const uint32_t nb = (qn[x >> 3] >> ((x & 7) * 4)) & 0xFu;
-						const int sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nd.base) ? a.M + ((nd.flags & 1) ? a.refbonus : 0) : a.X);
-						if(__builtin_expect(nin <= 64 && nfirst >= elo && nfirst + nin <= ehi, 1)){
-							// one in-edge per lane: what the loop below does edge after edge (bspoa.h:2360-2392), then its choice -- the reference
-							// keeps the candidate with the largest coverage, the first one on ties unless a later one is a match / mismatch move
-							// and the kept one is not; coverage 0 is only ever taken as a match / mismatch move
-							bool m0 = false, m1 = false, m2 = false, valid = false;
-							int w = 0, hm = 0; uint32_t cov = 0;
-							if(lane < nin){
-								const bsa_poa_edge_t ed = t_edges[(nfirst + lane) & (POA_TE - 1)];
-								w = (int)ed.src; cov = ed.cov;
-								const int wr = (int)ed.src_rpos;
-								if(!(x < wr || x > bw + wr)){
-									valid = true;
-									const int pp = x - wr;
-									int u0w, hc = 0, ec = 0, qc = 0; uint32_t wbase;
-									if(w >= lo){
-										const uint32_t *rw = t_rows + (w & (POA_TN - 1)) * bw;
-										const uint32_t cm = rw[pp >= 1 ? pp - 1 : 0], cw = rw[pp < bw ? pp : bw - 1];
-										u0w = t_u0[w & (POA_TN - 1)]; wbase = (t_nodes[w & (POA_TN - 1)].flags_word() >> 16) & 0xFFu;
-										hm = (pp >= 1) ? HH(w, pp - 1, cm, u0w) : u0w;
-										hc = HH(w, pp < bw ? pp : bw - 1, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24);
-									} else {
-										u0w = *(const volatile int32_t*)&gu0[w]; wbase = nodes[w].base;
-										hm = (pp >= 1) ? HH(w, pp - 1, *(const volatile uint32_t*)&grows[(size_t)w * bw + pp - 1], u0w) : u0w;
-										if(pp < bw){ const uint32_t cw = *(const volatile uint32_t*)&grows[(size_t)w * bw + pp]; hc = HH(w, pp, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24); }
-									}
-									int ft = 0, sc, scr0, scr1 = BSA_SCORE_MIN, scr2 = BSA_SCORE_MIN;
-									if(pp == bw) ft |= (1 << 2) | (1 << 4);
-									else if(pp == 0){ if(wr == 0 && (mode == BSA_MODE_OVERLAP || w == 0)) ft |= 1 << 15; else ft |= 1; }
-									sc = sbase;
-									if(!(nb & 8u) && (nb & 4u) && wbase != nd.base) sc += 1;
-									if(ft & (1 << 15)) sc -= u0w;
-									scr0 = (ft & 1) ? BSA_SCORE_MIN : sc;
-									if(pp < bw){
-										const int us = hc - hm;
-										scr1 = us + (PW ? ec : E);
-										scr2 = (PW == 2) ? us + qc : -BSA_SCORE_MIN;
-									}
-									m0 = hm + scr0 == Hs1; m1 = hm + scr1 == Hs1; m2 = hm + scr2 == Hs1;
-								}
-							}
-							POA_TRK(3)
-							const unsigned long long bval = __ballot(valid), bany = __ballot(m0 || m1 || m2);
-							if(bval) Hs0 = __builtin_amdgcn_readlane(hm, 63 - __builtin_clzll(bval));      // (what the loop leaves in Hs0: the last edge it looked at)
-							uint32_t C = 0;
-							for(unsigned long long r = bany; r; r &= r - 1) C = max(C, (uint32_t)__builtin_amdgcn_readlane((int)cov, __builtin_ctzll(r)));
-							const bool atc = (m0 || m1 || m2) && cov == C;
-							const unsigned long long b0c = __ballot(atc && m0), bc = __ballot(atc);
-							int win = -1; uint32_t wi = 0xFFFFFFFFu;
-							if(b0c){ win = __builtin_ctzll(b0c); wi = 0u; }
-							else if(bc && C > 0){ win = __builtin_ctzll(bc); wi = (__ballot(m1) >> win) & 1ull ? 1u : 2u; }
-							if(win < 0){
-								const int pp = x - nrpos;
-								if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
-								else {
-									const int u0v = U0(n);
-									const int hmn = (pp == 0) ? u0v : HH(n, pp - 1, CELL(n, pp - 1), u0v);
-									bt = 1u; Hs2 = 1; Hs0 = Hs1 - (HH(n, pp, CELL(n, pp), u0v) - hmn);
-								}
-							} else if(wi == 0u){
-								const int bnode = __builtin_amdgcn_readlane(w, win), bh = __builtin_amdgcn_readlane(hm, win);
-								EMIT(n, x, 0u);
-								x--; n = bnode; nidx = bnode; Hs1 = bh; Hs2 = 0;
-							}
-							else if(wi == 1u){ bt = 2u; Hs2 = 1; }
-							else { bt = 4u; Hs2 = 1; }
-							POA_TRK(4)
+					if(__builtin_expect(bt == 0xFFFFFFFFu, 1)){
+						bool coop = nin <= 64 && nfirst >= elo && nfirst + nin <= ehi;
+						uint32_t nb = 0; int sbase = 0;
+						if(coop){
+							// one in-edge per lane: what the loop further down does edge after edge (bspoa.h:2360-2392), then its choice -- the
+							// reference keeps the candidate with the largest coverage, the first one on ties unless a later one is a match /
+							// mismatch move and the kept one is not; coverage 0 is only ever taken as a match / mismatch move.  Two LDS round
+							// trips: the edge (and the read's base), then everything about the predecessor at once -- a lane without an edge
+							// reads what some edge slot and ring row hold and is masked afterwards.
+							const uint4 ed = ((const uint4*)t_edges)[(nfirst + lane) & (POA_TE - 1)];
+							const uint32_t qword = qn[x >> 3];
+							const int w = (int)ed.x, wr = (int)ed.z; const uint32_t cov = ed.y;
+							const int pp = x - wr;
+							const bool valid = lane < nin && pp >= 0 && pp <= bw;
+							const int ws = w & (POA_TN - 1);
+							const uint32_t *rw = t_rows + ws * bw;
+							const uint32_t cw = rw[min(max(pp, 0), bw - 1)], cm = rw[max(min(pp, bw) - 1, 0)];
+							const int u0w = t_u0[ws];
+							const uint4 r0w = t_nodes[ws].r0;
+							if(__builtin_expect(__ballot(valid && w < lo) != 0ull, 0)) coop = false;      // a predecessor below the ring (0.3 %): edge after edge
+							nb = (uint32_t)POA_UNI((qword >> ((x & 7) * 4)) & 0xFu);
+							sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nbase) ? a.M + ((nflags & 1u) ? a.refbonus : 0) : a.X);
+							if(coop){
+								const int rbase = (w == 0) ? h0init : u0w;                  // (the head's row is row_init; its ubegs[0] is not its first cell)
+								const int hm = (pp >= 1) ? rbase + (int)(int16_t)(cm & 0xFFFFu) : u0w;
+								const int hc = rbase + (int)(int16_t)(cw & 0xFFFFu);
+								const uint32_t wbase = (r0w.w >> 16) & 0xFFu;
+								const bool f15 = pp == 0 && wr == 0 && (ovl || w == 0);
+								int sc = sbase + (((nb & 12u) == 4u && wbase != nbase) ? 1 : 0);
+								if(f15) sc -= u0w;
+								const bool inb = valid && pp < bw;
+								const bool m0 = valid && (pp != 0 || f15) && hm + sc == Hs1;
+								const bool m1 = inb && hc + (PW ? sx8(cw >> 16) : E) == Hs1;
+								const bool m2 = (PW == 2) && inb && hc + sx8(cw >> 24) == Hs1;
+								POA_TRK(3)
+								const unsigned long long bany = __ballot(m0 || m1 || m2);
+								uint32_t C = 0;
+								for(unsigned long long r = bany; r; r &= r - 1) C = max(C, (uint32_t)__builtin_amdgcn_readlane((int)cov, __builtin_ctzll(r)));
+								const bool atc = (m0 || m1 || m2) && cov == C;
+								const unsigned long long b0c = __ballot(atc && m0), bc = __ballot(atc);
+								if(b0c){
+									// a match / mismatch column: the step itself (bspoa.h:2394-2410) taken at once, and the next node's record with it
+									const int win = __builtin_ctzll(b0c);
+									EMIT(n, x, 0u);
+									x--; n = __builtin_amdgcn_readlane(w, win); nidx = n; Hs1 = __builtin_amdgcn_readlane(hm, win); Hs2 = 0;
+									h_rpos = (uint32_t)__builtin_amdgcn_readlane((int)r0w.x, win); h_first = (uint32_t)__builtin_amdgcn_readlane((int)r0w.z, win);
+									h_w3 = (uint32_t)__builtin_amdgcn_readlane((int)r0w.w, win); hv = true;
+								} else if(bc && C > 0){
+									const int win = __builtin_ctzll(bc);
+									bt = ((__ballot(m1) >> win) & 1ull) ? 2u : 4u; Hs2 = 1;
+								} else start_insertion(nrpos);
+								POA_TRK(4)
 #ifdef POA_PROF
-							tq_n++;
+								tq_n++;
 #endif
-							continue;
+								continue;
+							}
+						} else {
+							nb = (uint32_t)POA_UNI((qn[x >> 3] >> ((x & 7) * 4)) & 0xFu);
+							sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nbase) ? a.M + ((nflags & 1u) ? a.refbonus : 0) : a.X);
 						}
+						uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
 						for(int k = 0; k < nin; k++){
 							const int ek = nfirst + k;
 							bsa_poa_edge_t ed; if(ek >= elo && ek < ehi) ed = t_edges[ek & (POA_TE - 1)]; else ed = gedges[ek];
-							const int w = (int)ed.src, wr = (int)ed.src_rpos;
-							const uint32_t cov = ed.cov;
+							const int w = POA_UNI(ed.src), wr = POA_UNI(ed.src_rpos);
+							const uint32_t cov = (uint32_t)POA_UNI(ed.cov);
 							if(x < wr || x > bw + wr) continue;
 							const int pp = x - wr;
-							int u0w, hm, hc = 0, ec = 0, qc = 0; uint32_t wbase;
-							if(w >= lo){
-								// (the common case: everything about the predecessor is in the tile)
-								const uint32_t *rw = t_rows + (w & (POA_TN - 1)) * bw;
-								const uint32_t cm = rw[pp >= 1 ? pp - 1 : 0], cw = rw[pp < bw ? pp : bw - 1];
-								u0w = t_u0[w & (POA_TN - 1)]; wbase = (t_nodes[w & (POA_TN - 1)].flags_word() >> 16) & 0xFFu;
-								hm = (pp >= 1) ? HH(w, pp - 1, cm, u0w) : u0w;
-								hc = HH(w, pp < bw ? pp : bw - 1, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24);
-							} else {
-								u0w = U0(w); wbase = nodes[w].base;
-								hm = (pp >= 1) ? HH(w, pp - 1, CELL(w, pp - 1), u0w) : u0w;          // H(pp - 1); at pp = 0 the block start ubegs[0]
-								if(pp < bw){ const uint32_t cw = CELL(w, pp); hc = HH(w, pp, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24); }
-							}
+							const int u0w = POA_UNI(U0(w));
+							const uint32_t wbase = (w >= lo) ? (uint32_t)POA_UNI((t_nodes[w & (POA_TN - 1)].flags_word() >> 16) & 0xFFu) : (uint32_t)POA_UNI(nodes[w].base);
+							const int hm = (pp >= 1) ? POA_UNI(HH(w, pp - 1, CELL(w, pp - 1), u0w)) : u0w;          // H(pp - 1); at pp = 0 the block start ubegs[0]
+							int hc = 0, ec = 0, qc = 0;
+							if(pp < bw){ const uint32_t cw = (uint32_t)POA_UNI(CELL(w, pp)); hc = HH(w, pp, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24); }
 							int ft = 0, s, scr0, scr1 = BSA_SCORE_MIN, scr2 = BSA_SCORE_MIN;
 							if(pp == bw) ft |= (1 << 2) | (1 << 4);
-							else if(pp == 0){ if(wr == 0 && (mode == BSA_MODE_OVERLAP || w == 0)) ft |= 1 << 15; else ft |= 1; }
+							else if(pp == 0){ if(wr == 0 && (ovl || w == 0)) ft |= 1 << 15; else ft |= 1; }
 							Hs0 = hm;
 							s = sbase;
-							if(!(nb & 8u) && (nb & 4u) && wbase != nd.base) s += 1;
+							if(!(nb & 8u) && (nb & 4u) && wbase != nbase) s += 1;
 							if(ft & (1 << 15)) s -= u0w;
 							scr0 = (ft & 1) ? BSA_SCORE_MIN : s;
 							if(pp < bw){
@@ -922,23 +881,58 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							POA_PICK(0u, scr0) POA_PICK(1u, scr1) POA_PICK(2u, scr2)
 #undef POA_PICK
 						}
-						if(bti == 0xFFFFFFFFu){
-							const int pp = x - nrpos;
-							if(pp < 0 || pp >= bw){ status = BSA_POA_ST_TRACE; done = true; }
-							else {
-								const int u0v = U0(n);
-								const int hm = (pp == 0) ? u0v : HH(n, pp - 1, CELL(n, pp - 1), u0v);
-								bt = 1u; Hs2 = 1; Hs0 = Hs1 - (HH(n, pp, CELL(n, pp), u0v) - hm);
-							}
-						} else if(bti == 0u){
-							// a match / mismatch column: the step itself (bspoa.h:2394-2410) taken at once
+						if(bti == 0xFFFFFFFFu) start_insertion(nrpos);
+						else if(bti == 0u){
 							EMIT(n, x, 0u);
 							x--; n = bnode; nidx = bnode; Hs1 = bh; Hs2 = 0;
 						}
 						else if(bti == 1u){ bt = 2u; Hs2 = 1; }
 						else { bt = 4u; Hs2 = 1; }
+					} else if(bt == 2u || bt == 4u){
+						// a deletion run: the first predecessor whose E (Q) continues it (bspoa.h:2325-2358)
+						EMIT(n, x, bt);
+						bool found = false;
+						for(int k = 0; k < nin && !found; k++){
+							const int ek = nfirst + k;
+							bsa_poa_edge_t ed; if(ek >= elo && ek < ehi) ed = t_edges[ek & (POA_TE - 1)]; else ed = gedges[ek];
+							const int w = POA_UNI(ed.src), wr = POA_UNI(ed.src_rpos);
+							if(x < wr || x >= wr + bw) continue;
+							const uint32_t cw = (uint32_t)POA_UNI(CELL(w, x - wr));
+							Hs0 = HH(w, x - wr, cw, POA_UNI(U0(w)));
+							int qv;
+							if(bt == 2u) qv = PW ? sx8(cw >> 16) : a.O + E;
+							else qv = sx8(cw >> 24);
+							if(Hs0 + qv != Hs1) continue;
+							n = w;
+							if(qv == ((bt == 2u) ? a.O + E : a.Q + P)){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
+							else { Hs1 -= (bt == 2u) ? E : P; Hs2++; }
+							found = true;
+						}
+						if(!found){ status = BSA_POA_ST_TRACE; done = true; }
+					} else if(bt == 1u){
+						EMIT(n, x, bt);
+						const int t = (PW == 2) ? max(a.O + E * Hs2, a.Q + P * Hs2) : a.O + E * Hs2;
+						x--;
+						if(Hs0 + t == Hs1){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
+						else if(x >= 0){
+							const int pp = x - nrpos;
+							if(pp < 0){ status = BSA_POA_ST_TRACE; done = true; }
+							else {
+								// us[pp] = H(pp) - H(pp - 1), us[0] = H(0) - ubegs[0]; Hs0 is H(pp) here
+								const int u0v = POA_UNI(U0(n));
+								const int hm = (pp == 0) ? u0v : POA_UNI(HH(n, pp - 1, CELL(n, pp - 1), u0v));
+								Hs0 -= POA_UNI(HH(n, pp, CELL(n, pp), u0v)) - hm;
+								Hs2++;
+							}
+						}
+					} else {
+						EMIT(n, x, bt);
+						x--;
+						n = nidx;
+						bt = 0xFFFFFFFFu;
 					}
 				}
+#undef POA_UNI
 #ifdef POA_PROF
 				if(lane == 0 && blockIdx.x == 0) printf("poa walk profile: %d cooperative steps; clocks per step: loop top %.0f, node ring %.0f, record + edge ring %.0f, edges evaluated %.0f, choice + move %.0f\n", tq_n,
 					(double)tq[0] / max(tq_n, 1), (double)tq[1] / max(tq_n, 1), (double)tq[2] / max(tq_n, 1), (double)tq[3] / max(tq_n, 1), (double)tq[4] / max(tq_n, 1));
