@@ -32,10 +32,14 @@
 #define POA_DRAIN  8       // finished rows leave the ring in batches of this many
 #define POA_NEG    (2 * BSA_SCORE_MIN)
 #define POA_NQ     192     // node records staged in LDS ahead of the window
-#define POA_TN     16      // traceback: nodes in the ring (a power of two >= POA_TNEAR + 1 + 2 POA_TC)
-#define POA_TC     4       // ... nodes per refill
+#define POA_TN     32      // traceback: nodes in the ring (a power of two >= POA_TNEAR + 1 + the nodes per refill: 16, or 8 above 128 columns)
+#define POA_TILE   16      // ... nodes of a tile of decisions (four columns each: one lane per (node, column))
+#ifndef POA_KEEP_QN
+#define POA_KEEP_QN 0
+#endif
+#define POA_TW     64      // ... cells of a row kept per node (a window around the walk's path; a power of two, a multiple of 4)
 #define POA_TNEAR  7       // ... predecessors at most this many nodes back are kept in the ring (0.3 % are further: read from HBM)
-#define POA_TE     128     // ... in-edges in the ring (a power of two)
+#define POA_TE     64      // ... in-edges in the ring (a power of two), refilled half a ring at a time
 
 struct PoaArgs {
 	const bsa_poa_node_t *nodes; const bsa_poa_edge_t *edges; const bsa_poa_cand_t *cands; const bsa_poa_prog_t *progs;
@@ -117,7 +121,7 @@ static __device__ __forceinline__ void poa_scan_max2(int &f, int &g){
 template<int PW, int CPL>
 static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const bsa_poa_prog_t &pg, uint8_t *lds, const int lane){
 	uint32_t *ring = (uint32_t*)lds;                    // R rows, RS cells apart, of bw cells {int16 H - base, e, q}
-	uint8_t *qb = lds + a.nq_off;                       // the read as a profile: bit b = "base b matches", bit 4 = differs from the next base, bit 5 = beyond the end
+	uint8_t *qb = lds + a.nq_off;                       // the read as a profile: bit b = "base b matches", bit 4 = differs from the next base, bit 5 = beyond the end, bits 6-7 = the base
 	const int bw = (int)a.bw, W = (int)a.W, RS = CPL * 64 + 2 * POA_ROWS_PAD, RM = (int)a.R - 1, BC = bw + POA_ROWS_PAD;      // BC: the cell of a ring row that holds its base
 	const int nn = (int)pg.nnodes, slen = (int)pg.slen;
 	const bsa_poa_node_t *nodes = a.nodes + pg.first_node;
@@ -138,7 +142,7 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 		const uint8_t *q = a.queries + pg.query_off;
 		for(int x = lane; x < slen + CPL * 64 + 8; x += 64){
 			uint32_t v = 0x20u;
-			if(x < slen){ const uint32_t c = q[x] & 3u; v = 1u << c; if(x + 1 < slen && q[x + 1] != q[x]) v |= 0x10u; }
+			if(x < slen){ const uint32_t c = q[x] & 3u; v = (1u << c) | (c << 6); if(x + 1 < slen && q[x + 1] != q[x]) v |= 0x10u; }      // (bits 6-7: the base itself, for the traceback)
 			qb[x] = (uint8_t)v;
 		}
 	}
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 
 	// ring tags cleared, query as nibbles (code | differs-from-next << 2 | beyond-the-read << 3), head row in slot 0
 	for(int i = lane; i < R; i += 64) rinfo[i] = make_uint2(0u, 0u);
-	{
+	if constexpr(ROWS == 0 || POA_KEEP_QN){
 		const uint8_t *q = a.queries + pg.query_off;
 		const int nqw = (slen + bw + 16) / 8 + 1;
 		for(int w = lane; w < nqw; w += 64){
@@ -672,64 +676,80 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		const bsa_poa_edge_t *gedges = a.edges + pg.first_edge;
 		uint32_t *ev = a.steps + pg.first_event;
 		const int ecap = (int)pg.event_cap;
-		// The walk's window of the graph: a RING of the last POA_TN nodes at and below the walker (rows, ubegs[0], records; node i at slot
-		// i mod POA_TN) and of POA_TE in-edges, refilled four nodes / sixty-four edges at a time.  A refill is requested well before the
-		// walker needs it and kept in registers until it does, so its memory latency passes while the walk goes on.
+		// The walk's window of the graph: a RING of the last POA_TN nodes at and below the walker (node i at slot i mod POA_TN: record,
+		// ubegs[0], and POA_TW cells of its row around the column the walk will pass it at -- cell p at position p mod POA_TW, the window's
+		// first cell beside it, so that a reader fetches cell and window start in one round trip and checks afterwards) and of POA_TE
+		// in-edges, refilled sixteen nodes / sixty-four edges at a time.  A refill is requested well before the walker needs it and kept
+		// in registers until it does, so its memory latency passes while the walk goes on.
 		uint32_t *t_rows = (uint32_t*)lds;
-		int32_t *t_u0 = (int32_t*)(lds + (size_t)POA_TN * bw * 4);
-		PoaTileNode *t_nodes = (PoaTileNode*)(lds + (size_t)POA_TN * bw * 4 + 256);
-		bsa_poa_edge_t *t_edges = (bsa_poa_edge_t*)(lds + (size_t)POA_TN * bw * 4 + 256 + POA_TN * sizeof(bsa_poa_node_t));
+		int32_t *t_u0 = (int32_t*)(lds + (size_t)POA_TN * POA_TW * 4);
+		int32_t *t_c0 = (int32_t*)(lds + (size_t)POA_TN * POA_TW * 4 + 128);
+		uint4 *t_r0 = (uint4*)(lds + (size_t)POA_TN * POA_TW * 4 + 256);           // the traceback's view of a node record: {rpos, gnode, first_in, n_in | base << 16 | flags << 24}
+		bsa_poa_edge_t *t_edges = (bsa_poa_edge_t*)(lds + (size_t)POA_TN * POA_TW * 4 + 256 + POA_TN * 16);
+		// the read's base at a column as code | differs-from-the-next << 2 | beyond-the-read << 3: nibbles for the wavefront, else out of the forward pass's profile
+		const uint8_t *qbw = lds + a.nq_off;
+		auto QCODE = [&](int xx) -> uint32_t {
+			if constexpr(ROWS == 0 || POA_KEEP_QN) return (qn[xx >> 3] >> ((xx & 7) * 4)) & 0xFu;
+			else { const uint32_t v = qbw[xx]; return (v >> 6) | ((v >> 2) & 12u); }
+		};
 		int n = rs.maxidx, nidx = rs.maxidx, x = rs.maxoff, ne = 0, status = BSA_POA_ST_OK;
 		uint32_t bt = 0xFFFFFFFFu;
 		int Hs0 = 0, Hs1 = 0, Hs2 = 0;
 		bool done = false, first = true;
-		const int RQ = bw / 4;                              // 16-byte pieces of a row
-		const int NRQ = (POA_TC * RQ + 63) / 64;            // ... of a refill, per lane (<= 8: bandwidth <= 256)
+		constexpr int RQ = POA_TW / 4;                      // 16-byte pieces of a ring row
+		constexpr int TC = 16;                              // nodes per refill
+		constexpr int NRQ = TC * RQ / 64;                   // 16-byte pieces of a refill, per lane
+		// the window of a node fetched while the walker's cell is pp: the walk drifts towards lower cells (the band moves on slower than
+		// the read), a refill is used some twenty to thirty nodes later
+		auto window_of = [&](int pp) -> int { return min(max((pp - (POA_TW - 20)) & ~3, 0), max(bw - POA_TW, 0)); };
 		int lo = max(0, n - (POA_TN - 1));                  // the ring holds nodes lo .. (the walker never goes up)
 		int elo, ehi;                                       // ... and edges elo .. ehi - 1
 		{
 			__syncthreads();
 			const int cnt = n - lo + 1;
-			for(int i = lane; i < cnt * 3; i += 64){ const int nd_ = lo + i / 3; ((uint4*)&t_nodes[nd_ & (POA_TN - 1)])[i % 3] = ((const uint4*)(nodes + nd_))[i % 3]; }
-			for(int b0 = 0; b0 < cnt * RQ; b0 += 512){
-				uint4 v[8];
-#pragma unroll
-				for(int k = 0; k < 8; k++){ const int i = b0 + k * 64 + lane; if(i < cnt * RQ) v[k] = ((const uint4*)(grows + (size_t)lo * bw))[i]; }
-#pragma unroll
-				for(int k = 0; k < 8; k++){ const int i = b0 + k * 64 + lane; if(i < cnt * RQ){ const int nd_ = lo + i / RQ; ((uint4*)(t_rows + (nd_ & (POA_TN - 1)) * bw))[i % RQ] = v[k]; } }
+			const int c0 = window_of(x - (int)nodes[n].rpos);
+			if(lane < cnt) t_r0[(lo + lane) & (POA_TN - 1)] = *(const uint4*)(nodes + lo + lane);
+			for(int i = lane; i < cnt * RQ; i += 64){
+				const int nd_ = lo + i / RQ, c = c0 + (i % RQ) * 4;
+				if(c < bw) *(uint4*)(t_rows + (nd_ & (POA_TN - 1)) * POA_TW + (c & (POA_TW - 1))) = *(const uint4*)(grows + (size_t)nd_ * bw + c);
 			}
-			if(lane < cnt) t_u0[(lo + lane) & (POA_TN - 1)] = gu0[lo + lane];
+			if(lane < cnt){ t_u0[(lo + lane) & (POA_TN - 1)] = gu0[lo + lane]; t_c0[(lo + lane) & (POA_TN - 1)] = c0; }
 			__syncthreads();
-			const PoaNodeHead hh = t_nodes[n & (POA_TN - 1)].head();
-			ehi = (int)hh.first_in + (int)hh.n_in;
+			const uint4 hh = t_r0[n & (POA_TN - 1)];
+			ehi = (int)hh.z + (int)(hh.w & 0xFFFFu);
 			elo = max(0, ehi - POA_TE);
 			for(int i = elo + lane; i < ehi; i += 64) ((uint4*)t_edges)[i & (POA_TE - 1)] = ((const uint4*)gedges)[i];
 			__syncthreads();
 		}
 		bool npend = false, epend = false;                   // a refill of nodes / edges is in flight (in the registers below)
-		int plo = 0, pelo = 0;
-		uint4 prow[8], pnode = make_uint4(0, 0, 0, 0), pedge = make_uint4(0, 0, 0, 0); int pu0 = 0;
+		int plo = 0, pelo = 0, pc0 = 0;
+		uint4 prow[NRQ], pnode = make_uint4(0, 0, 0, 0), pedge = make_uint4(0, 0, 0, 0); int pu0 = 0;
 #pragma unroll
-		for(int k = 0; k < 8; k++) prow[k] = make_uint4(0, 0, 0, 0);
-		auto node_request = [&](){
-			plo = max(0, lo - POA_TC);
+		for(int k = 0; k < NRQ; k++) prow[k] = make_uint4(0, 0, 0, 0);
+		auto node_request = [&](int pp){
+			plo = max(0, lo - TC); pc0 = window_of(pp);
 			const int cnt = lo - plo;
 #pragma unroll
-			for(int k = 0; k < 8; k++){ const int i = k * 64 + lane; if(k < NRQ && i < cnt * RQ) prow[k] = ((const uint4*)(grows + (size_t)plo * bw))[i]; }
-			if(lane < cnt * 3) pnode = ((const uint4*)(nodes + plo))[lane];
+			for(int k = 0; k < NRQ; k++){
+				const int i = k * 64 + lane, c = pc0 + (i % RQ) * 4;
+				if(i < cnt * RQ && c < bw) prow[k] = *(const uint4*)(grows + (size_t)(plo + i / RQ) * bw + c);
+			}
+			if(lane < cnt) pnode = *(const uint4*)(nodes + plo + lane);
 			if(lane < cnt) pu0 = gu0[plo + lane];
 			npend = true;
 		};
 		auto node_commit = [&](){
 			const int cnt = lo - plo;
 #pragma unroll
-			for(int k = 0; k < 8; k++){ const int i = k * 64 + lane; if(k < NRQ && i < cnt * RQ){ const int nd_ = plo + i / RQ; ((uint4*)(t_rows + (nd_ & (POA_TN - 1)) * bw))[i % RQ] = prow[k]; } }
-			if(lane < cnt * 3){ const int nd_ = plo + lane / 3; ((uint4*)&t_nodes[nd_ & (POA_TN - 1)])[lane % 3] = pnode; }
-			if(lane < cnt) t_u0[(plo + lane) & (POA_TN - 1)] = pu0;
+			for(int k = 0; k < NRQ; k++){
+				const int i = k * 64 + lane, c = pc0 + (i % RQ) * 4;
+				if(i < cnt * RQ && c < bw) *(uint4*)(t_rows + ((plo + i / RQ) & (POA_TN - 1)) * POA_TW + (c & (POA_TW - 1))) = prow[k];
+			}
+			if(lane < cnt){ t_r0[(plo + lane) & (POA_TN - 1)] = pnode; t_u0[(plo + lane) & (POA_TN - 1)] = pu0; t_c0[(plo + lane) & (POA_TN - 1)] = pc0; }
 			lo = plo; npend = false;
 		};
 		auto edge_request = [&](){
-			pelo = max(0, elo - 64);
+			pelo = max(0, elo - POA_TE / 2);
 			if(pelo + lane < elo) pedge = ((const uint4*)gedges)[pelo + lane];
 			epend = true;
 		};
@@ -741,7 +761,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 			{
 				auto in_tile = [&](int i) -> bool { return i >= lo; };
 				auto U0 = [&](int i) -> int { if(in_tile(i)) return t_u0[i & (POA_TN - 1)]; return *(const volatile int32_t*)&gu0[i]; };
-				auto CELL = [&](int i, int pp) -> uint32_t { if(in_tile(i)) return t_rows[(i & (POA_TN - 1)) * bw + pp]; return *(const volatile uint32_t*)&grows[(size_t)i * bw + pp]; };
+				auto CELL = [&](int i, int pp) -> uint32_t {
+					if(in_tile(i) && (unsigned)(pp - t_c0[i & (POA_TN - 1)]) < (unsigned)POA_TW) return t_rows[(i & (POA_TN - 1)) * POA_TW + (pp & (POA_TW - 1))];
+					return *(const volatile uint32_t*)&grows[(size_t)i * bw + pp];
+				};
 				auto HH = [&](int i, int pp, uint32_t cw, int u0v) -> int { return (i == 0) ? poa_init_h<PW>(a, pp) : u0v + (int)(int16_t)(cw & 0xFFFFu); };
 #define EMIT(nn_, xx_, bb_) do{ if(ne >= ecap){ status = BSA_POA_ST_EVENTS; done = true; } else { if(lane == 0) ev[ne] = ((uint32_t)(nn_) << 3) | (bb_); ne++; } }while(0)
 				if(first){
@@ -751,7 +774,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					else Hs1 = HH(n, pp, CELL(n, pp), U0(n));
 				}
 #ifdef POA_PROF
-				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0;
+				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[2] = {0, 0}, tq_l = clock64();
 #define POA_TRK(k_) { __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq[k_] += t_ - tq_t; tq_t = t_; }
 #else
 #define POA_TRK(k_)
@@ -762,7 +785,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 #define POA_UNI(v_) __builtin_amdgcn_readfirstlane((int)(v_))
 				n = POA_UNI(n); nidx = n; x = POA_UNI(x); Hs1 = POA_UNI(Hs1); ne = 0; done = POA_UNI(done) != 0; status = POA_UNI(status);
 				lo = POA_UNI(lo); elo = POA_UNI(elo); ehi = POA_UNI(ehi);
-				bool hv = false; uint32_t h_rpos = 0, h_first = 0, h_w3 = 0;      // the walker's node record, when the step that chose the node brought it along
+				int wpp = x - (int)nodes[n].rpos;                              // the walker's cell, as of the last node whose record was looked at
+				wpp = POA_UNI(wpp);
+				int h_n = -1; uint32_t h_rpos = 0, h_first = 0, h_w3 = 0;       // the record of node h_n (a step that chooses a node brings its record along)
 				const int h0init = poa_init_h<PW>(a, 0);
 				const bool ovl = mode == BSA_MODE_OVERLAP;
 				auto start_insertion = [&](int nrpos_){
@@ -775,21 +800,167 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						bt = 1u; Hs2 = 1; Hs0 = Hs1 - (POA_UNI(HH(n, pp, CELL(n, pp), u0v)) - hmn);
 					}
 				};
+				// THE TILE.  What the walk does at (node, column) in its plain state -- which predecessor explains the cell, as a match /
+				// mismatch, a deletion, or none (an insertion) -- depends on the rows alone, not on how the walk got there.  So the wave works
+				// it out for 64 places at once, the ones the walk is about to pass: lane 4 j + d holds the decision at node t_top - j, column
+				// t_x - j + d (a match / mismatch step goes down one node or more and left one column; d = the nodes skipped so far), each lane
+				// with the reference's own loop over its node's in-edges (bspoa.h:2360-2392, 2466-2476).  The walk then follows the lanes'
+				// decisions with v_readlane -- a dozen scalar instructions a step -- until it leaves the tile, meets a place a lane could not
+				// decide from the ring (7), or changes state; the states of a deletion / insertion run and everything odd take the steps
+				// further down, one at a time, as before.
+				int t_top = -1, t_x = 0;
+				uint32_t d_code = 7u; int d_w = 0, d_h = 0, d_H = 0, t_j[5] = {64, 64, 64, 64, 64};
 				while(!done){
 					POA_TRK(0)
+#ifdef POA_PROF
+					tq_l = clock64();
+#endif
 					if(n == 0 || x < 0){ done = true; break; }
-					// the ring: the walker's predecessors (at most POA_TNEAR nodes back; further ones are read from HBM) have to be in it
-					while(__builtin_expect(lo > 0 && n < lo + POA_TNEAR + 1, 0)){ if(!npend) node_request(); node_commit(); }
-					if(lo > 0 && !npend && n < lo + POA_TNEAR + 1 + POA_TC) node_request();
-					POA_TRK(1)
-					// the walker's node: always inside the ring
-					if(!hv){ const uint4 r0 = t_nodes[n & (POA_TN - 1)].r0; h_rpos = (uint32_t)POA_UNI(r0.x); h_first = (uint32_t)POA_UNI(r0.z); h_w3 = (uint32_t)POA_UNI(r0.w); }
-					hv = false;
+					bool build = false;
+#ifndef POA_NO_TILE
+					if(bt == 0xFFFFFFFFu){
+						// Follow the tile, all of its steps at once.  Every lane knows the lane its decision leads to (t_j[0]; 64 = out of the
+						// tile, itself = the walk stops here); t_j[k] is that map applied 2^k times.  Lane s composes the maps of s's bits
+						// and so stands on the place the walk reaches after s steps; the first s whose place is not a match / mismatch step
+						// is the number of steps taken, their words go out in one store, and the state after them is read off two lanes.
+						const int tj = t_top - n, td = x - t_x + tj;
+						if(t_top < 0 || (unsigned)tj >= (unsigned)POA_TILE || (unsigned)td >= 4u) build = true;
+						else {
+							const int id = tj * 4 + td;
+							bool slow = __builtin_amdgcn_readlane(d_H, id) != Hs1;          // (never, by construction; the step below would find out why)
+							if(!slow){
+								int pos = id;
+#pragma unroll
+								for(int k = 0; k < 5; k++){
+									const int nx = __builtin_amdgcn_ds_bpermute((pos & 63) << 2, t_j[k]);
+									if((lane >> k) & 1) pos = (pos >= 64) ? 64 : nx;
+								}
+								const uint32_t cat = (pos >= 64) ? 8u : (uint32_t)__builtin_amdgcn_ds_bpermute((pos & 63) << 2, (int)d_code);
+								const int L = __builtin_ctzll(__ballot(cat != 0u) | (1ull << 32));         // (a tile has sixteen nodes: at most sixteen steps)
+								const int Lc = min(L, ecap - ne);
+								if(lane < Lc) ev[ne + lane] = (uint32_t)(t_top - (pos >> 2)) << 3;
+								ne += Lc;
+#ifdef POA_PROF
+								tq_chase += Lc;
+#endif
+								if(Lc < L){ status = BSA_POA_ST_EVENTS; done = true; continue; }
+								if(L > 0){
+									const int last = __builtin_amdgcn_readlane(pos, L - 1);
+									n = __builtin_amdgcn_readlane(d_w, last); nidx = n; Hs1 = __builtin_amdgcn_readlane(d_h, last); x -= L; Hs2 = 0;
+								}
+								const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)cat, L);
+#ifdef POA_PROF
+								{ const long long t_ = clock64(); tq_c[0] += t_ - tq_l; tq_l = t_; }
+#endif
+								if(ce != 7u){
+									if(ce == 3u){ bt = 1u; Hs2 = 1; Hs0 = __builtin_amdgcn_readlane(d_h, __builtin_amdgcn_readlane(pos, L)); }
+									else if(ce != 8u){ bt = (ce == 1u) ? 2u : 4u; Hs2 = 1; }
+									continue;                                               // (out of the tile: the next trip builds one, or ends the walk)
+								}
+								if(n == 0 || x < 0) continue;
+							}
+						}
+					}
+#endif
+					// The ring: the walker's node and its predecessors (at most POA_TNEAR nodes back; further ones are read from HBM) have to be
+					// in it -- a step may have gone down further than that --; a new tile asks for the next nodes below it every time and takes
+					// them when their slots are free.  (ONE place requests: the registers a refill waits in are then written at one point of
+					// the loop and nothing has to move -- and wait for -- them.  The window of cells follows the walker's last known cell.)
+					{
+						const bool need = lo > 0 && n < lo + POA_TNEAR + 1;
+						if(npend && (need || (build && n < plo + POA_TN))) node_commit();
+						const bool need2 = lo > 0 && n < lo + POA_TNEAR + 1;
+						if(!npend && lo > 0 && (need2 || build || n < lo + POA_TNEAR + 1 + TC)) node_request(wpp);
+						if(need2) continue;
+					}
+					// the walker's node: inside the ring now
+					if(h_n != n){ const uint4 r0 = t_r0[n & (POA_TN - 1)]; h_rpos = (uint32_t)POA_UNI(r0.x); h_first = (uint32_t)POA_UNI(r0.z); h_w3 = (uint32_t)POA_UNI(r0.w); h_n = n; }
 					const int nrpos = (int)h_rpos, nin = (int)(h_w3 & 0xFFFFu), nfirst = (int)h_first;
 					const uint32_t nbase = (h_w3 >> 16) & 0xFFu, nflags = h_w3 >> 24;
-					while(__builtin_expect(elo > 0 && nfirst < elo, 0)){ if(!epend) edge_request(); edge_commit(); }
-					if(elo > 0 && !epend && nfirst < elo + 64) edge_request();
+					wpp = x - nrpos;
+					POA_TRK(1)
+					{
+						const int ef = build ? max(nfirst - 24, 0) : nfirst;       // (a tile looks at the in-edges of the nodes below the walker as well)
+						if(epend && elo > 0 && ef < elo) edge_commit();
+						const bool eneed = elo > 0 && ef < elo;
+						if(!epend && elo > 0 && ef < elo + POA_TE / 2) edge_request();
+						if(eneed) continue;
+					}
 					POA_TRK(2)
+					if(build){
+#ifdef POA_PROF
+							tq_build++;
+#endif
+							const int j = lane >> 2;
+							const int m = n - j, xm = x - j + (lane & 3), ms = m & (POA_TN - 1);
+							const uint4 r0m = t_r0[ms];
+							const int mfirst = (int)r0m.z, mnin = (int)(r0m.w & 0xFFFFu), ppm = xm - (int)r0m.x;
+							const uint32_t mbase = (r0m.w >> 16) & 0xFFu;
+							bool ok = m >= 1 && m >= lo && xm >= 0 && ppm >= 0 && ppm < bw && mfirst >= elo && mfirst + mnin <= ehi;
+							const int pc = min(max(ppm, 0), bw - 1), pcm = max(pc - 1, 0), xq = max(xm, 0);
+							const uint32_t cwm = t_rows[ms * POA_TW + (pc & (POA_TW - 1))], cmm = t_rows[ms * POA_TW + (pcm & (POA_TW - 1))];
+							const int u0m = t_u0[ms], c0m = t_c0[ms];
+							const uint32_t nbv = QCODE(xq);
+							uint4 ed = ((const uint4*)t_edges)[mfirst & (POA_TE - 1)];
+							ok = ok && (unsigned)(pc - c0m) < (unsigned)POA_TW && (unsigned)(pcm - c0m) < (unsigned)POA_TW;
+							const int Hm = u0m + (int)(int16_t)(cwm & 0xFFFFu);
+							const int hmn = (ppm >= 1) ? u0m + (int)(int16_t)(cmm & 0xFFFFu) : u0m;
+							const int sbv = (nbv & 8u) ? BSA_EPI8_MIN : (((nbv & 3u) == mbase) ? a.M + ((r0m.w >> 24) & 1u ? a.refbonus : 0) : a.X);
+							const bool hpv = (nbv & 12u) == 4u;
+							uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
+							for(int k = 0; __ballot(ok && k < mnin) != 0ull; k++){
+								const int w = (int)ed.x, wr = (int)ed.z; const uint32_t cov = ed.y;
+								ed = ((const uint4*)t_edges)[(mfirst + k + 1) & (POA_TE - 1)];         // (the next edge travels with this one's cells)
+								const int pp = xm - wr;
+								const bool valid = ok && k < mnin && pp >= 0 && pp <= bw;
+								const int ws = w & (POA_TN - 1);
+								const int p1 = min(max(pp, 0), bw - 1), p0 = max(min(pp, bw) - 1, 0);
+								const uint32_t cw = t_rows[ws * POA_TW + (p1 & (POA_TW - 1))], cm = t_rows[ws * POA_TW + (p0 & (POA_TW - 1))];
+								const int u0w = t_u0[ws]; int c0w = t_c0[ws];
+								const uint32_t wbase = (t_r0[ws].w >> 16) & 0xFFu;
+								asm volatile("" : "+v"(c0w));                                   // (read with the cells, not in a branch after them)
+								// a predecessor below the ring, or its cells outside the window kept of it
+								const bool bad = w < lo || (unsigned)(p1 - c0w) >= (unsigned)POA_TW || (unsigned)(p0 - c0w) >= (unsigned)POA_TW;
+								ok = ok && !(valid && bad);
+								const int rbase = (w == 0) ? h0init : u0w;
+								const int hm = (pp >= 1) ? rbase + (int)(int16_t)(cm & 0xFFFFu) : u0w;
+								const int hc = rbase + (int)(int16_t)(cw & 0xFFFFu);
+								const bool f15 = pp == 0 && wr == 0 && (ovl || w == 0);
+								int sc = sbv + ((hpv && wbase != mbase) ? 1 : 0);
+								if(f15) sc -= u0w;
+								const bool inb = valid && pp < bw;
+								const bool m0 = valid && (pp != 0 || f15) && hm + sc == Hm;
+								const bool m1 = inb && hc + (PW ? sx8(cw >> 16) : E) == Hm;
+								const bool m2 = (PW == 2) && inb && hc + sx8(cw >> 24) == Hm;
+								if(m0 && (cov > btc || (cov == btc && (bti & 0xFFu) != 0u))){ bti = 0u; btc = cov; bnode = w; bh = hm; }
+								if(m1 && cov > btc){ bti = 1u; btc = cov; bnode = w; bh = hm; }
+								if(m2 && cov > btc){ bti = 2u; btc = cov; bnode = w; bh = hm; }
+							}
+							d_code = !ok ? 7u : (bti == 0xFFFFFFFFu) ? 3u : bti;
+							d_w = bnode; d_h = (bti == 0xFFFFFFFFu) ? hmn : bh; d_H = Hm;
+							t_top = n; t_x = x;
+							{
+								// where the decision leads: a lane of this tile, out of it (64), or nowhere (the walk stops here: the lane itself)
+								int nid = lane;
+								if(d_code == 0u){
+									const int wj = n - bnode, dd = (xm - 1) - (x - wj);
+									nid = ((unsigned)wj < (unsigned)POA_TILE && (unsigned)dd < 4u) ? wj * 4 + dd : 64;
+								}
+								t_j[0] = nid;
+#pragma unroll
+								for(int k = 1; k < 5; k++){
+									const int nx = __builtin_amdgcn_ds_bpermute((t_j[k - 1] & 63) << 2, t_j[k - 1]);
+									t_j[k] = (t_j[k - 1] >= 64) ? 64 : nx;
+								}
+							}
+#ifdef POA_PROF
+							{ __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq_c[1] += t_ - tq_l; tq_l = t_; }
+#endif
+							continue;
+					}
+#ifdef POA_PROF
+					tq_slow++;
+#endif
 					if(__builtin_expect(bt == 0xFFFFFFFFu, 1)){
 						bool coop = nin <= 64 && nfirst >= elo && nfirst + nin <= ehi;
 						uint32_t nb = 0; int sbase = 0;
@@ -800,17 +971,18 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							// trips: the edge (and the read's base), then everything about the predecessor at once -- a lane without an edge
 							// reads what some edge slot and ring row hold and is masked afterwards.
 							const uint4 ed = ((const uint4*)t_edges)[(nfirst + lane) & (POA_TE - 1)];
-							const uint32_t qword = qn[x >> 3];
+							const uint32_t qword = QCODE(x);
 							const int w = (int)ed.x, wr = (int)ed.z; const uint32_t cov = ed.y;
 							const int pp = x - wr;
 							const bool valid = lane < nin && pp >= 0 && pp <= bw;
 							const int ws = w & (POA_TN - 1);
-							const uint32_t *rw = t_rows + ws * bw;
-							const uint32_t cw = rw[min(max(pp, 0), bw - 1)], cm = rw[max(min(pp, bw) - 1, 0)];
-							const int u0w = t_u0[ws];
-							const uint4 r0w = t_nodes[ws].r0;
-							if(__builtin_expect(__ballot(valid && w < lo) != 0ull, 0)) coop = false;      // a predecessor below the ring (0.3 %): edge after edge
-							nb = (uint32_t)POA_UNI((qword >> ((x & 7) * 4)) & 0xFu);
+							const int p1 = min(max(pp, 0), bw - 1), p0 = max(min(pp, bw) - 1, 0);
+							const uint32_t cw = t_rows[ws * POA_TW + (p1 & (POA_TW - 1))], cm = t_rows[ws * POA_TW + (p0 & (POA_TW - 1))];
+							const int u0w = t_u0[ws], c0w = t_c0[ws];
+							const uint4 r0w = t_r0[ws];
+							// a predecessor below the ring (0.3 %) or its cells outside the window kept of it: edge after edge
+							if(__builtin_expect(__ballot(valid && (w < lo || (unsigned)(p1 - c0w) >= (unsigned)POA_TW || (unsigned)(p0 - c0w) >= (unsigned)POA_TW)) != 0ull, 0)) coop = false;
+							nb = (uint32_t)POA_UNI(qword);
 							sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nbase) ? a.M + ((nflags & 1u) ? a.refbonus : 0) : a.X);
 							if(coop){
 								const int rbase = (w == 0) ? h0init : u0w;                  // (the head's row is row_init; its ubegs[0] is not its first cell)
@@ -836,7 +1008,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 									EMIT(n, x, 0u);
 									x--; n = __builtin_amdgcn_readlane(w, win); nidx = n; Hs1 = __builtin_amdgcn_readlane(hm, win); Hs2 = 0;
 									h_rpos = (uint32_t)__builtin_amdgcn_readlane((int)r0w.x, win); h_first = (uint32_t)__builtin_amdgcn_readlane((int)r0w.z, win);
-									h_w3 = (uint32_t)__builtin_amdgcn_readlane((int)r0w.w, win); hv = true;
+									h_w3 = (uint32_t)__builtin_amdgcn_readlane((int)r0w.w, win); h_n = n;
 								} else if(bc && C > 0){
 									const int win = __builtin_ctzll(bc);
 									bt = ((__ballot(m1) >> win) & 1ull) ? 2u : 4u; Hs2 = 1;
@@ -848,7 +1020,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 								continue;
 							}
 						} else {
-							nb = (uint32_t)POA_UNI((qn[x >> 3] >> ((x & 7) * 4)) & 0xFu);
+							nb = (uint32_t)POA_UNI(QCODE(x));
 							sbase = (nb & 8u) ? BSA_EPI8_MIN : (((nb & 3u) == nbase) ? a.M + ((nflags & 1u) ? a.refbonus : 0) : a.X);
 						}
 						uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
@@ -860,7 +1032,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							if(x < wr || x > bw + wr) continue;
 							const int pp = x - wr;
 							const int u0w = POA_UNI(U0(w));
-							const uint32_t wbase = (w >= lo) ? (uint32_t)POA_UNI((t_nodes[w & (POA_TN - 1)].flags_word() >> 16) & 0xFFu) : (uint32_t)POA_UNI(nodes[w].base);
+							const uint32_t wbase = (w >= lo) ? (uint32_t)POA_UNI((t_r0[w & (POA_TN - 1)].w >> 16) & 0xFFu) : (uint32_t)POA_UNI(nodes[w].base);
 							const int hm = (pp >= 1) ? POA_UNI(HH(w, pp - 1, CELL(w, pp - 1), u0w)) : u0w;          // H(pp - 1); at pp = 0 the block start ubegs[0]
 							int hc = 0, ec = 0, qc = 0;
 							if(pp < bw){ const uint32_t cw = (uint32_t)POA_UNI(CELL(w, pp)); hc = HH(w, pp, cw, u0w); ec = sx8(cw >> 16); qc = sx8(cw >> 24); }
@@ -934,6 +1106,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				}
 #undef POA_UNI
 #ifdef POA_PROF
+				if(lane == 0 && blockIdx.x == 0) printf("poa walk: %d steps from tiles (%lld clocks), %d tiles (%lld clocks), %d steps one at a time, %lld clocks in all\n", tq_chase, tq_c[0], tq_build, tq_c[1], tq_slow, (long long)(clock64() - tq_0));
 				if(lane == 0 && blockIdx.x == 0) printf("poa walk profile: %d cooperative steps; clocks per step: loop top %.0f, node ring %.0f, record + edge ring %.0f, edges evaluated %.0f, choice + move %.0f\n", tq_n,
 					(double)tq[0] / max(tq_n, 1), (double)tq[1] / max(tq_n, 1), (double)tq[2] / max(tq_n, 1), (double)tq[3] / max(tq_n, 1), (double)tq[4] / max(tq_n, 1));
 #endif
@@ -962,7 +1135,7 @@ extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *ctx, void *stop_event);
 extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *ctx, int slot, size_t bytes, void **out);
 
 static const size_t POA_LDS_MAX = 160u * 1024u - 1024u;
-static size_t poa_tile_bytes(uint32_t bw){ return (size_t)POA_TN * bw * 4 + 256 + POA_TN * sizeof(bsa_poa_node_t) + POA_TE * sizeof(bsa_poa_edge_t); }
+static size_t poa_tile_bytes(uint32_t bw){ (void)bw; return (size_t)POA_TN * POA_TW * 4 + 256 + POA_TN * 16 + POA_TE * sizeof(bsa_poa_edge_t); }
 static size_t poa_qn_bytes(uint32_t bw, uint32_t max_slen){ return ((((size_t)max_slen + bw + 16) / 8 + 2) * 4 + 15) & ~(size_t)15; }
 static size_t poa_ring_bytes(uint32_t bw, uint32_t nl){ return (size_t)(nl + POA_NEAR + POA_DRAIN) * bw * 4; }
 static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max(poa_ring_bytes(bw, nl) + (size_t)(nl + POA_NEAR + POA_DRAIN) * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
@@ -976,7 +1149,7 @@ static size_t poa_rows_qb_bytes(uint32_t bw, uint32_t max_slen){ return ((size_t
 // bsa_poa_graph_supported has the signs), and 64 ring rows + the query in LDS
 static bool poa_rows_supported(const bsa_rows_params_t *rp, int pw, uint32_t bw, uint32_t max_slen){
 	if(pw == 2 && rp->gape1 > rp->gape2) return false;
-	return poa_rows_front_bytes(bw) + poa_qn_bytes(bw, max_slen) + poa_rows_qb_bytes(bw, max_slen) <= POA_LDS_MAX;
+	return poa_rows_front_bytes(bw) + poa_rows_qb_bytes(bw, max_slen) <= POA_LDS_MAX;
 }
 
 extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen){
@@ -1041,7 +1214,7 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 		a.ri_off = (uint32_t)poa_ring_bytes(bw, (uint32_t)nl);
 		a.qn_off = (uint32_t)poa_front_bytes(bw, (uint32_t)nl);
 	}
-	a.nq_off = a.qn_off + (uint32_t)poa_qn_bytes(bw, max_slen);
+	a.nq_off = a.qn_off + ((rows_fwd && !POA_KEEP_QN) ? 0u : (uint32_t)poa_qn_bytes(bw, max_slen));     // (the row-at-a-time pass keeps the read as bytes only)
 	a.mode = rp->mode; a.M = rp->M; a.X = rp->X; a.refbonus = rp->refbonus;
 	a.O = rp->gapo1; a.E = rp->gape1; a.Q = rp->gapo2; a.P = rp->gape2; a.T = par->T;
 	{

@@ -303,7 +303,8 @@ static inline int bsa_poa_align_rd_core(BSPOA *g, BSPOAPar *par, u2i rid, u4i nh
 		if(rc == 0){
 			if(ad->res.status != BSA_POA_ST_OK){
 				/* the walk left the stored rows: the reference reads outside its arena or does not terminate on this input */
-				fprintf(stderr, " -- device traceback stopped (status %d) in %s -- %s:%d --\n", ad->res.status, __FUNCTION__, __FILE__, __LINE__); fflush(stderr);
+				fprintf(stderr, " -- device traceback stopped (status %d after %d steps at node %d, column %d; read of %u, %u nodes) in %s -- %s:%d --\n", ad->res.status, ad->res.nevents,
+					ad->res.fin_node, ad->res.fin_x, (unsigned)g->slen, (unsigned)ad->nnodes, __FUNCTION__, __FILE__, __LINE__); fflush(stderr);
 				abort();
 			}
 			g->maxscr = ad->res.maxscr;
