@@ -37,6 +37,7 @@
 #ifndef POA_KEEP_QN
 #define POA_KEEP_QN 0
 #endif
+#define POA_TWA    20      // ... of them above the walker's cell at the time the refill is asked for
 #define POA_TW     64      // ... cells of a row kept per node (a window around the walk's path; a power of two, a multiple of 4)
 #define POA_TNEAR  7       // ... predecessors at most this many nodes back are kept in the ring (0.3 % are further: read from HBM)
 #define POA_TE     64      // ... in-edges in the ring (a power of two), refilled half a ring at a time
@@ -191,6 +192,10 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 #pragma unroll
 			for(int kk = 0; kk < 2; kk++){
 				kinds[kk] = (uint32_t)__builtin_amdgcn_readlane((int)dK[kk], k);
+				dAs[kk] = 0; mvs[kk] = 0; sbs[kk] = 0; cmv[kk] = 0;
+#pragma unroll
+				for(int j = 0; j < CPL; j++) cwv[kk][j] = 0;
+				if(kk == 1 && !(kinds[1] & BSA_POA_IN_PRESENT)) continue;          // (most nodes have one input: nothing to fetch for the other)
 				dAs[kk] = (uint32_t)__builtin_amdgcn_readlane((int)dA[kk], k);
 				mvs[kk] = (int)(dAs[kk] >> 16);
 				const uint32_t *lrow = (const uint32_t*)((const uint8_t*)ring + (dAs[kk] & 0x7FFFu));
@@ -701,7 +706,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		constexpr int NRQ = TC * RQ / 64;                   // 16-byte pieces of a refill, per lane
 		// the window of a node fetched while the walker's cell is pp: the walk drifts towards lower cells (the band moves on slower than
 		// the read), a refill is used some twenty to thirty nodes later
-		auto window_of = [&](int pp) -> int { return min(max((pp - (POA_TW - 20)) & ~3, 0), max(bw - POA_TW, 0)); };
+		auto window_of = [&](int pp) -> int { return min(max((pp - (POA_TW - POA_TWA)) & ~3, 0), max(bw - POA_TW, 0)); };
 		int lo = max(0, n - (POA_TN - 1));                  // the ring holds nodes lo .. (the walker never goes up)
 		int elo, ehi;                                       // ... and edges elo .. ehi - 1
 		{
@@ -727,15 +732,17 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 #pragma unroll
 		for(int k = 0; k < NRQ; k++) prow[k] = make_uint4(0, 0, 0, 0);
 		auto node_request = [&](int pp){
+			// (every lane loads -- an index past the refill's end reads its last piece again --: a load under a condition would have to be
+			// merged into the register it waits in, and the merge waits for it)
 			plo = max(0, lo - TC); pc0 = window_of(pp);
 			const int cnt = lo - plo;
 #pragma unroll
 			for(int k = 0; k < NRQ; k++){
-				const int i = k * 64 + lane, c = pc0 + (i % RQ) * 4;
-				if(i < cnt * RQ && c < bw) prow[k] = *(const uint4*)(grows + (size_t)(plo + i / RQ) * bw + c);
+				const int i = min(k * 64 + lane, cnt * RQ - 1), c = min(pc0 + (i % RQ) * 4, bw - 4);
+				prow[k] = *(const uint4*)(grows + (size_t)(plo + i / RQ) * bw + c);
 			}
-			if(lane < cnt) pnode = *(const uint4*)(nodes + plo + lane);
-			if(lane < cnt) pu0 = gu0[plo + lane];
+			pnode = *(const uint4*)(nodes + plo + min(lane, cnt - 1));
+			pu0 = gu0[plo + min(lane, cnt - 1)];
 			npend = true;
 		};
 		auto node_commit = [&](){
@@ -750,7 +757,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		};
 		auto edge_request = [&](){
 			pelo = max(0, elo - POA_TE / 2);
-			if(pelo + lane < elo) pedge = ((const uint4*)gedges)[pelo + lane];
+			pedge = ((const uint4*)gedges)[min(pelo + lane, elo - 1)];
 			epend = true;
 		};
 		auto edge_commit = [&](){
@@ -774,7 +781,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					else Hs1 = HH(n, pp, CELL(n, pp), U0(n));
 				}
 #ifdef POA_PROF
-				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[2] = {0, 0}, tq_l = clock64();
+				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[6] = {0, 0, 0, 0, 0, 0}, tq_l = clock64(); int tq_cat = 5, tq_k[6] = {0, 0, 0, 0, 0, 0};
 #define POA_TRK(k_) { __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq[k_] += t_ - tq_t; tq_t = t_; }
 #else
 #define POA_TRK(k_)
@@ -813,7 +820,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				while(!done){
 					POA_TRK(0)
 #ifdef POA_PROF
-					tq_l = clock64();
+					{ __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq_c[tq_cat] += t_ - tq_l; tq_k[tq_cat]++; tq_l = t_; tq_cat = (bt == 0xFFFFFFFFu) ? 2 : (bt == 1u) ? 3 : 4; }
 #endif
 					if(n == 0 || x < 0){ done = true; break; }
 					bool build = false;
@@ -850,7 +857,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 								}
 								const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)cat, L);
 #ifdef POA_PROF
-								{ const long long t_ = clock64(); tq_c[0] += t_ - tq_l; tq_l = t_; }
+								tq_cat = 0;
 #endif
 								if(ce != 7u){
 									if(ce == 3u){ bt = 1u; Hs2 = 1; Hs0 = __builtin_amdgcn_readlane(d_h, __builtin_amdgcn_readlane(pos, L)); }
@@ -954,7 +961,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 								}
 							}
 #ifdef POA_PROF
-							{ __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq_c[1] += t_ - tq_l; tq_l = t_; }
+							tq_cat = 1;
 #endif
 							continue;
 					}
@@ -1064,6 +1071,30 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						// a deletion run: the first predecessor whose E (Q) continues it (bspoa.h:2325-2358)
 						EMIT(n, x, bt);
 						bool found = false;
+						if(nin <= 64 && nfirst >= elo && nfirst + nin <= ehi){
+							// one in-edge per lane, the first lane that continues the run
+							const uint4 ed = ((const uint4*)t_edges)[(nfirst + lane) & (POA_TE - 1)];
+							const int w = (int)ed.x, pp = x - (int)ed.z, ws = w & (POA_TN - 1);
+							const bool inb = lane < nin && pp >= 0 && pp < bw;
+							const int pq = min(max(pp, 0), bw - 1);
+							const uint32_t cw = t_rows[ws * POA_TW + (pq & (POA_TW - 1))];
+							const int u0w = t_u0[ws], c0w = t_c0[ws];
+							if(__ballot(inb && (w < lo || (unsigned)(pq - c0w) >= (unsigned)POA_TW)) == 0ull){
+								const int hw = ((w == 0) ? h0init : u0w) + (int)(int16_t)(cw & 0xFFFFu);
+								const int qv = (bt == 2u) ? (PW ? sx8(cw >> 16) : a.O + E) : sx8(cw >> 24);
+								const unsigned long long hit = __ballot(inb && hw + qv == Hs1);
+								if(hit){
+									const int win = __builtin_ctzll(hit);
+									const int qw = __builtin_amdgcn_readlane(qv, win);
+									Hs0 = __builtin_amdgcn_readlane(hw, win); n = __builtin_amdgcn_readlane(w, win);
+									if(qw == ((bt == 2u) ? a.O + E : a.Q + P)){ bt = 0xFFFFFFFFu; Hs1 = Hs0; Hs2 = 0; }
+									else { Hs1 -= (bt == 2u) ? E : P; Hs2++; }
+									continue;
+								}
+								status = BSA_POA_ST_TRACE; done = true;
+								continue;
+							}
+						}
 						for(int k = 0; k < nin && !found; k++){
 							const int ek = nfirst + k;
 							bsa_poa_edge_t ed; if(ek >= elo && ek < ehi) ed = t_edges[ek & (POA_TE - 1)]; else ed = gedges[ek];
@@ -1082,6 +1113,28 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						}
 						if(!found){ status = BSA_POA_ST_TRACE; done = true; }
 					} else if(bt == 1u){
+						{
+							// an insertion run along the node's own row, all of its lengths at once: lane l tries length Hs2 + l (bspoa.h:2412-2440)
+							const int ns = n & (POA_TN - 1), ppx = x - nrpos, c = ppx - 1 - lane;
+							const uint32_t cwc = t_rows[ns * POA_TW + (max(c, 0) & (POA_TW - 1))];
+							const int u0v = t_u0[ns], c0v = t_c0[ns];
+							const bool there = lane <= x && c >= -1;                          // (the walk gets as far as this length)
+							const bool inw = c < 0 || (unsigned)(c - c0v) < (unsigned)POA_TW;
+							const int V = (c >= 0) ? u0v + (int)(int16_t)(cwc & 0xFFFFu) : u0v;
+							const int D = Hs0 - __builtin_amdgcn_readlane(V, 0);              // (0: what the walk carries is H of the cell left of it)
+							const int Ln = Hs2 + lane;
+							const int t = (PW == 2) ? max(a.O + E * Ln, a.Q + P * Ln) : a.O + E * Ln;
+							const unsigned long long hit = __ballot(there && V + D + t == Hs1), bad = __ballot(!there || !inw);
+							if(ppx >= 0 && ppx <= bw && hit && !(bad & ((hit & (0ull - hit)) * 2ull - 1ull))){
+								const int f = __builtin_ctzll(hit);
+								const int Lc = min(f + 1, ecap - ne);
+								if(lane < Lc) ev[ne + lane] = ((uint32_t)n << 3) | 1u;
+								ne += Lc;
+								if(Lc < f + 1){ status = BSA_POA_ST_EVENTS; done = true; continue; }
+								x -= f + 1; bt = 0xFFFFFFFFu; Hs1 = __builtin_amdgcn_readlane(V, f) + D; Hs0 = Hs1; Hs2 = 0;
+								continue;
+							}
+						}
 						EMIT(n, x, bt);
 						const int t = (PW == 2) ? max(a.O + E * Hs2, a.Q + P * Hs2) : a.O + E * Hs2;
 						x--;
@@ -1106,7 +1159,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				}
 #undef POA_UNI
 #ifdef POA_PROF
-				if(lane == 0 && blockIdx.x == 0) printf("poa walk: %d steps from tiles (%lld clocks), %d tiles (%lld clocks), %d steps one at a time, %lld clocks in all\n", tq_chase, tq_c[0], tq_build, tq_c[1], tq_slow, (long long)(clock64() - tq_0));
+				if(lane == 0 && blockIdx.x == 0) printf("poa walk: %d steps in %d chases (%lld clocks), %d tiles (%lld), plain steps one at a time %d (%lld), insertion %d (%lld), deletion %d (%lld); %lld clocks in all\n", tq_chase, tq_k[0], tq_c[0], tq_k[1], tq_c[1], tq_k[2], tq_c[2], tq_k[3], tq_c[3], tq_k[4], tq_c[4], (long long)(clock64() - tq_0));
 				if(lane == 0 && blockIdx.x == 0) printf("poa walk profile: %d cooperative steps; clocks per step: loop top %.0f, node ring %.0f, record + edge ring %.0f, edges evaluated %.0f, choice + move %.0f\n", tq_n,
 					(double)tq[0] / max(tq_n, 1), (double)tq[1] / max(tq_n, 1), (double)tq[2] / max(tq_n, 1), (double)tq[3] / max(tq_n, 1), (double)tq[4] / max(tq_n, 1));
 #endif
