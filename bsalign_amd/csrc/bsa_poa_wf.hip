@@ -34,14 +34,13 @@
 #define POA_NQ     192     // node records staged in LDS ahead of the window
 #define POA_TN     32      // traceback: nodes in the ring (a power of two >= POA_TNEAR + 1 + the nodes per refill: 16, or 8 above 128 columns)
 #define POA_TILE   16      // ... nodes of a tile of decisions (four columns each: one lane per (node, column))
-#ifndef POA_KEEP_QN
-#define POA_KEEP_QN 0
-#endif
 #define POA_TWA    20      // ... of them above the walker's cell at the time the refill is asked for
+#define POA_QW     128     // ... columns of the read kept (a power of two)
 #define POA_TW     64      // ... cells of a row kept per node (a window around the walk's path; a power of two, a multiple of 4)
 #define POA_TNEAR  7       // ... predecessors at most this many nodes back are kept in the ring (0.3 % are further: read from HBM)
 #define POA_TE     64      // ... in-edges in the ring (a power of two), refilled half a ring at a time
 
+#define POA_TILE_BYTES (POA_TN * POA_TW * 4 + 256 + POA_TN * 16 + POA_TE * 16)      // the traceback's ring: rows, ubegs[0] + window starts, record heads, in-edges
 struct PoaArgs {
 	const bsa_poa_node_t *nodes; const bsa_poa_edge_t *edges; const bsa_poa_cand_t *cands; const bsa_poa_prog_t *progs;
 	const uint8_t *queries;
@@ -386,7 +385,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 
 	// ring tags cleared, query as nibbles (code | differs-from-next << 2 | beyond-the-read << 3), head row in slot 0
 	for(int i = lane; i < R; i += 64) rinfo[i] = make_uint2(0u, 0u);
-	if constexpr(ROWS == 0 || POA_KEEP_QN){
+	if constexpr(ROWS == 0){
 		const uint8_t *q = a.queries + pg.query_off;
 		const int nqw = (slen + bw + 16) / 8 + 1;
 		for(int w = lane; w < nqw; w += 64){
@@ -691,11 +690,22 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		int32_t *t_c0 = (int32_t*)(lds + (size_t)POA_TN * POA_TW * 4 + 128);
 		uint4 *t_r0 = (uint4*)(lds + (size_t)POA_TN * POA_TW * 4 + 256);           // the traceback's view of a node record: {rpos, gnode, first_in, n_in | base << 16 | flags << 24}
 		bsa_poa_edge_t *t_edges = (bsa_poa_edge_t*)(lds + (size_t)POA_TN * POA_TW * 4 + 256 + POA_TN * 16);
-		// the read's base at a column as code | differs-from-the-next << 2 | beyond-the-read << 3: nibbles for the wavefront, else out of the forward pass's profile
-		const uint8_t *qbw = lds + a.nq_off;
+		// the read's base at a column as code | differs-from-the-next << 2 | beyond-the-read << 3: the wavefront's nibbles of the whole read,
+		// else a window of POA_QW columns that slides down with the walker (column c at position c mod POA_QW; the forward pass's
+		// profile of the whole read lies where the ring is now)
+		uint8_t *t_q = lds + POA_TILE_BYTES;
+		int qlo = 0;
+		auto q_fill = [&](int c0_, int cnt_){
+			const uint8_t *q = a.queries + pg.query_off;
+			for(int c = c0_ + lane; c < c0_ + cnt_; c += 64){
+				uint32_t nb = 8u;
+				if(c < slen){ const uint32_t b = q[c]; nb = b & 3u; if(c + 1 < slen && q[c + 1] != b) nb |= 4u; }
+				t_q[c & (POA_QW - 1)] = (uint8_t)nb;
+			}
+		};
 		auto QCODE = [&](int xx) -> uint32_t {
-			if constexpr(ROWS == 0 || POA_KEEP_QN) return (qn[xx >> 3] >> ((xx & 7) * 4)) & 0xFu;
-			else { const uint32_t v = qbw[xx]; return (v >> 6) | ((v >> 2) & 12u); }
+			if constexpr(ROWS == 0) return (qn[xx >> 3] >> ((xx & 7) * 4)) & 0xFu;
+			else return t_q[xx & (POA_QW - 1)];
 		};
 		int n = rs.maxidx, nidx = rs.maxidx, x = rs.maxoff, ne = 0, status = BSA_POA_ST_OK;
 		uint32_t bt = 0xFFFFFFFFu;
@@ -711,6 +721,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		int elo, ehi;                                       // ... and edges elo .. ehi - 1
 		{
 			__syncthreads();
+			if constexpr(ROWS != 0){ qlo = max(0, x + 4 - POA_QW); q_fill(qlo, POA_QW); }
 			const int cnt = n - lo + 1;
 			const int c0 = window_of(x - (int)nodes[n].rpos);
 			if(lane < cnt) t_r0[(lo + lane) & (POA_TN - 1)] = *(const uint4*)(nodes + lo + lane);
@@ -823,6 +834,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					{ __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq_c[tq_cat] += t_ - tq_l; tq_k[tq_cat]++; tq_l = t_; tq_cat = (bt == 0xFFFFFFFFu) ? 2 : (bt == 1u) ? 3 : 4; }
 #endif
 					if(n == 0 || x < 0){ done = true; break; }
+					if constexpr(ROWS != 0){
+						// the read's window: the places looked at lie between x - POA_TILE and x + 3
+						if(__builtin_expect(qlo > 0 && x - POA_TILE - 4 < qlo, 0)){ const int nl_ = max(0, qlo - POA_QW / 2); q_fill(nl_, qlo - nl_); qlo = nl_; }
+					}
 					bool build = false;
 #ifndef POA_NO_TILE
 					if(bt == 0xFFFFFFFFu){
@@ -1188,21 +1203,21 @@ extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *ctx, void *stop_event);
 extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *ctx, int slot, size_t bytes, void **out);
 
 static const size_t POA_LDS_MAX = 160u * 1024u - 1024u;
-static size_t poa_tile_bytes(uint32_t bw){ (void)bw; return (size_t)POA_TN * POA_TW * 4 + 256 + POA_TN * 16 + POA_TE * sizeof(bsa_poa_edge_t); }
+static size_t poa_tile_bytes(uint32_t bw){ (void)bw; return (size_t)POA_TILE_BYTES; }
 static size_t poa_qn_bytes(uint32_t bw, uint32_t max_slen){ return ((((size_t)max_slen + bw + 16) / 8 + 2) * 4 + 15) & ~(size_t)15; }
 static size_t poa_ring_bytes(uint32_t bw, uint32_t nl){ return (size_t)(nl + POA_NEAR + POA_DRAIN) * bw * 4; }
 static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max(poa_ring_bytes(bw, nl) + (size_t)(nl + POA_NEAR + POA_DRAIN) * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
 
 static uint32_t poa_rows_cpl(uint32_t bw){ return bw <= 64 ? 1u : bw <= 128 ? 2u : 4u; }
-static const uint32_t POA_ROWS_R = 16;      // ring rows of the row-at-a-time forward pass (a power of two; inputs further back are read from HBM)
+static const uint32_t POA_ROWS_R = 8;       // ring rows of the row-at-a-time forward pass (a power of two; inputs further back are read from HBM)
 static size_t poa_rows_ring_bytes(uint32_t bw){ return (size_t)POA_ROWS_R * (poa_rows_cpl(bw) * 64 + 2 * POA_ROWS_PAD) * 4; }
-static size_t poa_rows_front_bytes(uint32_t bw){ return (std::max(poa_rows_ring_bytes(bw) + POA_ROWS_R * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
+static size_t poa_rows_front_bytes(uint32_t bw){ return (poa_rows_ring_bytes(bw) + POA_ROWS_R * 8 + 15) & ~(size_t)15; }       // (the forward pass's part; the traceback's ring + POA_QW bytes take its place afterwards)
 static size_t poa_rows_qb_bytes(uint32_t bw, uint32_t max_slen){ return ((size_t)max_slen + poa_rows_cpl(bw) * 64 + 8 + 15) & ~(size_t)15; }
 // the row-at-a-time forward pass (poa_forward_rows): its scans need gapo <= 0 and gapo1 + gape1 <= gape1 <= gape2 <= 0 (the guard of
 // bsa_poa_graph_supported has the signs), and 64 ring rows + the query in LDS
 static bool poa_rows_supported(const bsa_rows_params_t *rp, int pw, uint32_t bw, uint32_t max_slen){
 	if(pw == 2 && rp->gape1 > rp->gape2) return false;
-	return poa_rows_front_bytes(bw) + poa_rows_qb_bytes(bw, max_slen) <= POA_LDS_MAX;
+	return std::max(poa_rows_front_bytes(bw) + poa_rows_qb_bytes(bw, max_slen), poa_tile_bytes(bw) + POA_QW) <= POA_LDS_MAX;
 }
 
 extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen){
@@ -1267,7 +1282,7 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 		a.ri_off = (uint32_t)poa_ring_bytes(bw, (uint32_t)nl);
 		a.qn_off = (uint32_t)poa_front_bytes(bw, (uint32_t)nl);
 	}
-	a.nq_off = a.qn_off + ((rows_fwd && !POA_KEEP_QN) ? 0u : (uint32_t)poa_qn_bytes(bw, max_slen));     // (the row-at-a-time pass keeps the read as bytes only)
+	a.nq_off = a.qn_off + (rows_fwd ? 0u : (uint32_t)poa_qn_bytes(bw, max_slen));     // (the row-at-a-time pass keeps the read as bytes only)
 	a.mode = rp->mode; a.M = rp->M; a.X = rp->X; a.refbonus = rp->refbonus;
 	a.O = rp->gapo1; a.E = rp->gape1; a.Q = rp->gapo2; a.P = rp->gape2; a.T = par->T;
 	{
@@ -1280,7 +1295,7 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 		const int type = a.mode & 3;
 		a.head_u0 = (type == BSA_MODE_OVERLAP) ? 0 : nt_max - nt_min;
 	}
-	const size_t lds = (size_t)a.nq_off + (rows_fwd ? poa_rows_qb_bytes(bw, max_slen) : POA_NQ * sizeof(bsa_poa_node_t));
+	const size_t lds = rows_fwd ? std::max((size_t)a.nq_off + poa_rows_qb_bytes(bw, max_slen), poa_tile_bytes(bw) + POA_QW) : (size_t)a.nq_off + POA_NQ * sizeof(bsa_poa_node_t);
 	void *stop = nullptr;
 	rc = bsa_ctx_time_begin_internal(ctx, 0.0, &stop);
 	if(rc != BSA_OK) return rc;
