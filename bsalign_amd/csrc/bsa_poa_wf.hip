@@ -827,7 +827,42 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				// decide from the ring (7), or changes state; the states of a deletion / insertion run and everything odd take the steps
 				// further down, one at a time, as before.
 				int t_top = -1, t_x = 0;
-				uint32_t d_code = 7u; int d_w = 0, d_h = 0, d_H = 0, t_j[5] = {64, 64, 64, 64, 64};
+				uint32_t d_cat = 7u, d_word = 0; int d_w = 0, d_sx = 0, d_h = 0, d_H = 0, t_j[5] = {64, 64, 64, 64, 64};
+				// Follow the tile from lane `id`, all of its steps at once.  Every lane knows the lane its decision leads to (t_j[0]; 64 = out of
+				// the tile, itself = the walk changes state or cannot be decided here); t_j[k] is that map applied 2^k times.  Lane s composes the
+				// maps of s's bits and so stands on the place the walk reaches after s steps; the first s whose place does not go on is the
+				// number of steps taken, their words go out in one store, and the state after them is read off one or two lanes.  Steps that
+				// go on: match / mismatch, and deletions / insertions of length one (the runs the walk meets most).  -> false: the trip is over
+				auto chase = [&](int id) -> bool {
+					int pos = id;
+#pragma unroll
+					for(int k = 0; k < 5; k++){
+						const int nx = __builtin_amdgcn_ds_bpermute((pos & 63) << 2, t_j[k]);
+						if((lane >> k) & 1) pos = (pos >= 64) ? 64 : nx;
+					}
+					const uint32_t cat = (pos >= 64) ? 8u : (uint32_t)__builtin_amdgcn_ds_bpermute((pos & 63) << 2, (int)d_cat);
+					const uint32_t wd = (uint32_t)__builtin_amdgcn_ds_bpermute((pos & 63) << 2, (int)d_word);
+					const uint32_t stop = (uint32_t)__ballot(cat != 0u);
+					const int L = stop ? __builtin_ctz(stop) : 31;                              // (lanes 0 .. 31 stand for steps: a longer stay in the tile goes on next trip)
+					const int Lc = min(L, ecap - ne);
+					if(lane < Lc) ev[ne + lane] = wd;
+					ne += Lc;
+#ifdef POA_PROF
+					tq_chase += Lc; tq_cat = 0;
+#endif
+					if(Lc < L){ status = BSA_POA_ST_EVENTS; done = true; return false; }
+					const int pe = __builtin_amdgcn_readlane(pos, L);
+					const uint32_t ce = stop ? (uint32_t)__builtin_amdgcn_readlane((int)cat, L) : 9u;
+					if(L > 0){
+						if(pe < 64){ n = t_top - (pe >> 2); x = t_x - (pe >> 2) + (pe & 3); Hs1 = __builtin_amdgcn_readlane(d_H, pe); }
+						else { const int last = __builtin_amdgcn_readlane(pos, L - 1); n = __builtin_amdgcn_readlane(d_w, last); x = __builtin_amdgcn_readlane(d_sx, last); Hs1 = __builtin_amdgcn_readlane(d_h, last); }
+						nidx = n; Hs2 = 0;
+					}
+					if(ce == 7u) return !(n == 0 || x < 0);                                     // undecided here: the step below takes it
+					if(ce == 3u){ bt = 1u; Hs2 = 1; Hs0 = __builtin_amdgcn_readlane(d_h, pe); }
+					else if(ce == 1u || ce == 2u){ bt = (ce == 1u) ? 2u : 4u; Hs2 = 1; }
+					return false;                                                               // (out of the tile or paused: the next trip goes on)
+				};
 				while(!done){
 					POA_TRK(0)
 #ifdef POA_PROF
@@ -841,46 +876,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					bool build = false;
 #ifndef POA_NO_TILE
 					if(bt == 0xFFFFFFFFu){
-						// Follow the tile, all of its steps at once.  Every lane knows the lane its decision leads to (t_j[0]; 64 = out of the
-						// tile, itself = the walk stops here); t_j[k] is that map applied 2^k times.  Lane s composes the maps of s's bits
-						// and so stands on the place the walk reaches after s steps; the first s whose place is not a match / mismatch step
-						// is the number of steps taken, their words go out in one store, and the state after them is read off two lanes.
 						const int tj = t_top - n, td = x - t_x + tj;
 						if(t_top < 0 || (unsigned)tj >= (unsigned)POA_TILE || (unsigned)td >= 4u) build = true;
-						else {
-							const int id = tj * 4 + td;
-							bool slow = __builtin_amdgcn_readlane(d_H, id) != Hs1;          // (never, by construction; the step below would find out why)
-							if(!slow){
-								int pos = id;
-#pragma unroll
-								for(int k = 0; k < 5; k++){
-									const int nx = __builtin_amdgcn_ds_bpermute((pos & 63) << 2, t_j[k]);
-									if((lane >> k) & 1) pos = (pos >= 64) ? 64 : nx;
-								}
-								const uint32_t cat = (pos >= 64) ? 8u : (uint32_t)__builtin_amdgcn_ds_bpermute((pos & 63) << 2, (int)d_code);
-								const int L = __builtin_ctzll(__ballot(cat != 0u) | (1ull << 32));         // (a tile has sixteen nodes: at most sixteen steps)
-								const int Lc = min(L, ecap - ne);
-								if(lane < Lc) ev[ne + lane] = (uint32_t)(t_top - (pos >> 2)) << 3;
-								ne += Lc;
-#ifdef POA_PROF
-								tq_chase += Lc;
-#endif
-								if(Lc < L){ status = BSA_POA_ST_EVENTS; done = true; continue; }
-								if(L > 0){
-									const int last = __builtin_amdgcn_readlane(pos, L - 1);
-									n = __builtin_amdgcn_readlane(d_w, last); nidx = n; Hs1 = __builtin_amdgcn_readlane(d_h, last); x -= L; Hs2 = 0;
-								}
-								const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)cat, L);
-#ifdef POA_PROF
-								tq_cat = 0;
-#endif
-								if(ce != 7u){
-									if(ce == 3u){ bt = 1u; Hs2 = 1; Hs0 = __builtin_amdgcn_readlane(d_h, __builtin_amdgcn_readlane(pos, L)); }
-									else if(ce != 8u){ bt = (ce == 1u) ? 2u : 4u; Hs2 = 1; }
-									continue;                                               // (out of the tile: the next trip builds one, or ends the walk)
-								}
-								if(n == 0 || x < 0) continue;
-							}
+						else if(__builtin_amdgcn_readlane(d_H, tj * 4 + td) == Hs1){          // (always, by construction; if not, the step below finds out why)
+							if(!chase(tj * 4 + td)) continue;
 						}
 					}
 #endif
@@ -930,6 +929,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							const int sbv = (nbv & 8u) ? BSA_EPI8_MIN : (((nbv & 3u) == mbase) ? a.M + ((r0m.w >> 24) & 1u ? a.refbonus : 0) : a.X);
 							const bool hpv = (nbv & 12u) == 4u;
 							uint32_t btc = 0, bti = 0xFFFFFFFFu; int bnode = 0, bh = 0;
+							bool g1 = false, g2 = false, end1 = false, end2 = false; int w1 = 0, w2 = 0, h1 = 0, h2 = 0;       // the first in-edge a deletion run would take, and whether it ends there
 							for(int k = 0; __ballot(ok && k < mnin) != 0ull; k++){
 								const int w = (int)ed.x, wr = (int)ed.z; const uint32_t cov = ed.y;
 								ed = ((const uint4*)t_edges)[(mfirst + k + 1) & (POA_TE - 1)];         // (the next edge travels with this one's cells)
@@ -957,15 +957,23 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 								if(m0 && (cov > btc || (cov == btc && (bti & 0xFFu) != 0u))){ bti = 0u; btc = cov; bnode = w; bh = hm; }
 								if(m1 && cov > btc){ bti = 1u; btc = cov; bnode = w; bh = hm; }
 								if(m2 && cov > btc){ bti = 2u; btc = cov; bnode = w; bh = hm; }
+								if(m1 && !g1){ g1 = true; w1 = w; h1 = hc; end1 = (PW ? sx8(cw >> 16) : a.O + E) == a.O + E; }
+								if(m2 && !g2){ g2 = true; w2 = w; h2 = hc; end2 = sx8(cw >> 24) == a.Q + P; }
 							}
-							d_code = !ok ? 7u : (bti == 0xFFFFFFFFu) ? 3u : bti;
-							d_w = bnode; d_h = (bti == 0xFFFFFFFFu) ? hmn : bh; d_H = Hm;
-							t_top = n; t_x = x;
 							{
+								const uint32_t code = !ok ? 7u : (bti == 0xFFFFFFFFu) ? 3u : bti;
+								const int cost1 = (PW == 2) ? max(a.O + E, a.Q + P) : a.O + E;
+								bool on = code == 0u;
+								d_word = (uint32_t)m << 3; d_w = bnode; d_sx = xm - 1; d_h = bh; d_H = Hm;
+								if(code == 1u && g1 && end1){ on = true; d_word |= 2u; d_w = w1; d_sx = xm; d_h = h1; }          // a deletion of one node (bspoa.h:2325-2358)
+								else if(code == 2u && g2 && end2){ on = true; d_word |= 4u; d_w = w2; d_sx = xm; d_h = h2; }
+								else if(code == 3u){ d_h = hmn; if(hmn + cost1 == Hm){ on = true; d_word |= 1u; d_w = m; } }       // an insertion of one base (bspoa.h:2412-2440)
+								d_cat = on ? 0u : code;
+								t_top = n; t_x = x;
 								// where the decision leads: a lane of this tile, out of it (64), or nowhere (the walk stops here: the lane itself)
 								int nid = lane;
-								if(d_code == 0u){
-									const int wj = n - bnode, dd = (xm - 1) - (x - wj);
+								if(on){
+									const int wj = n - d_w, dd = d_sx - (x - wj);
 									nid = ((unsigned)wj < (unsigned)POA_TILE && (unsigned)dd < 4u) ? wj * 4 + dd : 64;
 								}
 								t_j[0] = nid;
@@ -978,6 +986,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 #ifdef POA_PROF
 							tq_cat = 1;
 #endif
+							if(__builtin_amdgcn_readlane(d_H, 0) == Hs1) (void)chase(0);       // (what is left undecided there: the next trip's step, with that node's record)
 							continue;
 					}
 #ifdef POA_PROF
