@@ -25,6 +25,7 @@
 // (bsalign.h:2347-2391), the dead row of a move by >= bandwidth (:2253-2259), S = -63 beyond the read end (:2157-2160).
 #include "bsa_common.h"
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include <cstring>
 
@@ -182,179 +183,195 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 			const uint32_t w3 = (uint32_t)__builtin_amdgcn_readlane((int)r0.w, k);
 			const uint32_t nbase = (w3 >> 16) & 0xFFu;
 			const int Mv = a.M + (((w3 >> 24) & 1u) ? a.refbonus : 0);
-			// phase 1: everything the node reads from LDS, requested at once (one round trip per node); an input further back than the
-			// ring (rare) is read from HBM into the same registers afterwards
-			int mvs[2], sbs[2]; uint32_t kinds[2], dAs[2], cwv[2][CPL], cmv[2];
-			uint32_t qv[CPL];
+			// The node's kind decides how much of the general row is needed.  Most nodes are PLAIN: one input, a row update (not a merge) of a
+			// row in the ring moved by at most the pad, the whole band inside the read -- for them the body below is compiled a second time
+			// with everything else cut out (no second input, no merged rows, no synthetic cells, no clamps), the same expressions otherwise.
+			uint32_t kinds[2];
+			kinds[0] = (uint32_t)__builtin_amdgcn_readlane((int)dK[0], k); kinds[1] = (uint32_t)__builtin_amdgcn_readlane((int)dK[1], k);
+			const uint32_t dA0 = (uint32_t)__builtin_amdgcn_readlane((int)dA[0], k);
+			const bool plain = (kinds[0] & (BSA_POA_IN_PRESENT | BSA_POA_IN_MERGE | 0x10000000u)) == BSA_POA_IN_PRESENT && !(kinds[1] & BSA_POA_IN_PRESENT)
+				&& (dA0 >> 16) <= (uint32_t)POA_ROWS_PAD && CPL * 64 == bw && rpos + CPL * 64 <= slen;
+			auto node_body = [&](auto plain_tag){
+				constexpr bool SIMPLE = decltype(plain_tag)::value;
+				// phase 1: everything the node reads from LDS, requested at once (one round trip per node); an input further back than the
+				// ring (rare) is read from HBM into the same registers afterwards
+				int mvs[2], sbs[2]; uint32_t dAs[2], cwv[2][CPL], cmv[2];
+				uint32_t qv[CPL];
 #pragma unroll
-			for(int j = 0; j < CPL; j++) qv[j] = qb[rpos + p0 + j];
+				for(int j = 0; j < CPL; j++) qv[j] = qb[rpos + p0 + j];
 #pragma unroll
-			for(int kk = 0; kk < 2; kk++){
-				kinds[kk] = (uint32_t)__builtin_amdgcn_readlane((int)dK[kk], k);
-				dAs[kk] = 0; mvs[kk] = 0; sbs[kk] = 0; cmv[kk] = 0;
+				for(int kk = 0; kk < 2; kk++){
+					dAs[kk] = 0; mvs[kk] = 0; sbs[kk] = 0; cmv[kk] = 0;
 #pragma unroll
-				for(int j = 0; j < CPL; j++) cwv[kk][j] = 0;
-				if(kk == 1 && !(kinds[1] & BSA_POA_IN_PRESENT)) continue;          // (most nodes have one input: nothing to fetch for the other)
-				dAs[kk] = (uint32_t)__builtin_amdgcn_readlane((int)dA[kk], k);
-				mvs[kk] = (int)(dAs[kk] >> 16);
-				const uint32_t *lrow = (const uint32_t*)((const uint8_t*)ring + (dAs[kk] & 0x7FFFu));
-				sbs[kk] = (int)lrow[BC];
-				const int bi = min(p0 + mvs[kk], RS - CPL);          // (a lane whose base is clamped holds synthetic cells only)
+					for(int j = 0; j < CPL; j++) cwv[kk][j] = 0;
+					if(kk == 1 && (SIMPLE || !(kinds[1] & BSA_POA_IN_PRESENT))) continue;          // (most nodes have one input: nothing to fetch for the other)
+					dAs[kk] = (kk == 0) ? dA0 : (uint32_t)__builtin_amdgcn_readlane((int)dA[kk], k);
+					mvs[kk] = (int)(dAs[kk] >> 16);
+					const uint32_t *lrow = (const uint32_t*)((const uint8_t*)ring + (dAs[kk] & 0x7FFFu));
+					sbs[kk] = (int)lrow[BC];
+					const int bi = SIMPLE ? p0 + mvs[kk] : min(p0 + mvs[kk], RS - CPL);          // (a lane whose base is clamped holds synthetic cells only; a move within the pad never gets there)
 #pragma unroll
-				for(int j = 0; j < CPL; j++) cwv[kk][j] = lrow[bi + j];
-				cmv[kk] = lrow[max(bi - 1, 0)];
-			}
-#pragma unroll
-			for(int kk = 0; kk < 2; kk++){
-				if(kinds[kk] & 0x10000000u){
-					// further back than the ring: the rows stored so far have landed, and nothing stale is in this CU's vector cache
-					const int src = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.x : r1.w), k);
-					__builtin_amdgcn_s_waitcnt(0);
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-					const uint32_t *grow = grows + (size_t)src * bw;
-					sbs[kk] = (src == 0) ? h0init : gu0[src];
-#pragma unroll
-					for(int j = 0; j < CPL; j++) cwv[kk][j] = grow[min(p0 + j + mvs[kk], bw - 1)];
-					cmv[kk] = grow[min(max(p0 + mvs[kk] - 1, 0), bw - 1)];
-					__builtin_amdgcn_s_waitcnt(0x0F70);          // (waited for here, so that the common path never waits on the vector-memory counter)
+					for(int j = 0; j < CPL; j++) cwv[kk][j] = lrow[bi + j];
+					cmv[kk] = lrow[max(bi - 1, 0)];
 				}
-			}
-			POA_PROF_MARK(1)
-			// the substitution scores of the node's base along the lane's cells (bspoa.h:2199-2215; bsalign.h:2166-2221)
-			int Sb[CPL], hpc[CPL];
 #pragma unroll
-			for(int j = 0; j < CPL; j++){
-				Sb[j] = ((qv[j] >> nbase) & 1u) ? Mv : a.X;
-				hpc[j] = (int)((qv[j] >> 4) & 1u);
-			}
-			if(rpos + CPL * 64 > slen){
+				for(int kk = 0; kk < (SIMPLE ? 0 : 2); kk++){
+					if(kinds[kk] & 0x10000000u){
+						// further back than the ring: the rows stored so far have landed, and nothing stale is in this CU's vector cache
+						const int src = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.x : r1.w), k);
+						__builtin_amdgcn_s_waitcnt(0);
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+						const uint32_t *grow = grows + (size_t)src * bw;
+						sbs[kk] = (src == 0) ? h0init : gu0[src];
 #pragma unroll
-				for(int j = 0; j < CPL; j++) if(qv[j] & 0x20u) Sb[j] = BSA_EPI8_MIN;
-			}
-			int N[CPL], Ein[CPL], Qin[CPL], inj[CPL], HX[CPL], EX[CPL], QX[CPL];
+						for(int j = 0; j < CPL; j++) cwv[kk][j] = grow[min(p0 + j + mvs[kk], bw - 1)];
+						cmv[kk] = grow[min(max(p0 + mvs[kk] - 1, 0), bw - 1)];
+						__builtin_amdgcn_s_waitcnt(0x0F70);          // (waited for here, so that the common path never waits on the vector-memory counter)
+					}
+				}
+				POA_PROF_MARK(1)
+				// the substitution scores of the node's base along the lane's cells (bspoa.h:2199-2215; bsalign.h:2166-2221)
+				int Sb[CPL], hpc[CPL];
 #pragma unroll
-			for(int j = 0; j < CPL; j++){ N[j] = NEG; Ein[j] = NEG; Qin[j] = NEG; inj[j] = NEG; HX[j] = NEG; EX[j] = NEG; QX[j] = NEG; }
-			bool has_merge = false;
-			// phase 2: what the inputs offer (uniform branches on the node record, selects per cell)
+				for(int j = 0; j < CPL; j++){
+					Sb[j] = ((qv[j] >> nbase) & 1u) ? Mv : a.X;
+					hpc[j] = (int)((qv[j] >> 4) & 1u);
+				}
+				if(!SIMPLE && rpos + CPL * 64 > slen){
 #pragma unroll
-			for(int kk = 0; kk < 2; kk++){
-				const uint32_t kind = kinds[kk];
-				if(!(kind & BSA_POA_IN_PRESENT)) continue;
-				const int mv = mvs[kk], sbase = sbs[kk];
-				const bool far = (kind & 0x10000000u) != 0u, src0 = (dAs[kk] & 0x8000u) != 0u;
-				if(kind & BSA_POA_IN_MERGE){
-					has_merge = true;
+					for(int j = 0; j < CPL; j++) if(qv[j] & 0x20u) Sb[j] = BSA_EPI8_MIN;
+				}
+				int N[CPL], Ein[CPL], Qin[CPL], inj[CPL], HX[CPL], EX[CPL], QX[CPL];
+#pragma unroll
+				for(int j = 0; j < CPL; j++){ N[j] = NEG; Ein[j] = NEG; Qin[j] = NEG; inj[j] = NEG; HX[j] = NEG; EX[j] = NEG; QX[j] = NEG; }
+				bool has_merge = false;
+				// phase 2: what the inputs offer (uniform branches on the node record, selects per cell)
+#pragma unroll
+				for(int kk = 0; kk < (SIMPLE ? 1 : 2); kk++){
+					const uint32_t kind = kinds[kk];
+					if(!SIMPLE && !(kind & BSA_POA_IN_PRESENT)) continue;
+					const int mv = mvs[kk], sbase = sbs[kk];
+					const bool far = !SIMPLE && (kind & 0x10000000u) != 0u, src0 = (dAs[kk] & 0x8000u) != 0u;
+					if(!SIMPLE && (kind & BSA_POA_IN_MERGE)){
+						has_merge = true;
+#pragma unroll
+						for(int j = 0; j < CPL; j++){
+							const uint32_t cw = cwv[kk][j];
+							const int h = sbase + (int)(int16_t)(cw & 0xFFFFu);
+							HX[j] = max(HX[j], h); EX[j] = max(EX[j], h + sx8(cw >> 16)); QX[j] = max(QX[j], h + sx8(cw >> 24));
+						}
+						continue;
+					}
+					const bool same = (kind & BSA_POA_IN_SAME) != 0u;
+					const bool dead = mv >= bw;
+					int h1[CPL], b0[CPL], ee[CPL], qq[CPL];
 #pragma unroll
 					for(int j = 0; j < CPL; j++){
 						const uint32_t cw = cwv[kk][j];
-						const int h = sbase + (int)(int16_t)(cw & 0xFFFFu);
-						HX[j] = max(HX[j], h); EX[j] = max(EX[j], h + sx8(cw >> 16)); QX[j] = max(QX[j], h + sx8(cw >> 24));
+						h1[j] = sbase + (int)(int16_t)(cw & 0xFFFFu);
+						ee[j] = sx8(cw >> 16); qq[j] = sx8(cw >> 24);
+						b0[j] = (j == 0) ? sbase + (int)(int16_t)(cmv[kk] & 0xFFFFu) : h1[j - 1];
 					}
-					continue;
-				}
-				const bool same = (kind & BSA_POA_IN_SAME) != 0u;
-				const bool dead = mv >= bw;
-				int h1[CPL], b0[CPL], ee[CPL], qq[CPL];
+					if(!SIMPLE && (mv > POA_ROWS_PAD || (far && mv > 0))){
+						// synthetic cells behind the moved row's end (bsalign.h:2357-2389): c0, then gape1 up to distance d, then gape2.  (A row in
+						// the ring carries its first POA_ROWS_PAD synthetic cells behind its end, so a move by up to that many cells -- all but
+						// 0.04 % -- reads them like any other cell and only longer moves and rows read back from HBM come here.)
+						uint32_t hl_;
+						if(far){ const int src = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.x : r1.w), k); hl_ = grows[(size_t)src * bw + bw - 1]; __builtin_amdgcn_s_waitcnt(0x0F70); }
+						else hl_ = *(const uint32_t*)((const uint8_t*)ring + (dAs[kk] & 0x7FFFu) + (bw - 1) * 4);
+						const int hlast = sbase + (int)(int16_t)(hl_ & 0xFFFFu) + a.c0;
+						auto synth = [&](int kx) -> int { return hlast + ((kx < a.d) ? kx * E : (a.d - 1) * E + (kx - a.d + 1) * P); };
 #pragma unroll
-				for(int j = 0; j < CPL; j++){
-					const uint32_t cw = cwv[kk][j];
-					h1[j] = sbase + (int)(int16_t)(cw & 0xFFFFu);
-					ee[j] = sx8(cw >> 16); qq[j] = sx8(cw >> 24);
-					b0[j] = (j == 0) ? sbase + (int)(int16_t)(cmv[kk] & 0xFFFFu) : h1[j - 1];
-				}
-				if(mv > POA_ROWS_PAD || (far && mv > 0)){
-					// synthetic cells behind the moved row's end (bsalign.h:2357-2389): c0, then gape1 up to distance d, then gape2.  (A row in
-					// the ring carries its first POA_ROWS_PAD synthetic cells behind its end, so a move by up to that many cells -- all but
-					// 0.04 % -- reads them like any other cell and only longer moves and rows read back from HBM come here.)
-					uint32_t hl_;
-					if(far){ const int src = __builtin_amdgcn_readlane((int)(kk == 0 ? r1.x : r1.w), k); hl_ = grows[(size_t)src * bw + bw - 1]; __builtin_amdgcn_s_waitcnt(0x0F70); }
-					else hl_ = *(const uint32_t*)((const uint8_t*)ring + (dAs[kk] & 0x7FFFu) + (bw - 1) * 4);
-					const int hlast = sbase + (int)(int16_t)(hl_ & 0xFFFFu) + a.c0;
-					auto synth = [&](int kx) -> int { return hlast + ((kx < a.d) ? kx * E : (a.d - 1) * E + (kx - a.d + 1) * P); };
+						for(int j = 0; j < CPL; j++){
+							const int idx = p0 + j + mv;
+							if(idx >= bw){ h1[j] = synth(idx - bw); ee[j] = 0; qq[j] = 0; }
+							if(idx - 1 >= bw) b0[j] = synth(idx - 1 - bw);
+						}
+						if(dead){
+#pragma unroll
+							for(int j = 0; j < CPL; j++){ h1[j] = BSA_SCORE_MIN; b0[j] = BSA_SCORE_MIN; ee[j] = 0; qq[j] = 0; }
+						}
+					} else if(mv == 0 && lane == 0) b0[0] = src0 ? a.head_u0 : sbase;       // ubegs[0] of the predecessor
 #pragma unroll
 					for(int j = 0; j < CPL; j++){
-						const int idx = p0 + j + mv;
-						if(idx >= bw){ h1[j] = synth(idx - bw); ee[j] = 0; qq[j] = 0; }
-						if(idx - 1 >= bw) b0[j] = synth(idx - 1 - bw);
+						const int S = Sb[j] + (same ? 0 : hpc[j]);
+						int mc = b0[j] + S;
+						if(j == 0){
+							// band cell 0: the seed rule (bsalign.h:2899-2907), rh as dpalign_row_update_bspoa picks it (bspoa.h:2242-2254)
+							const int rh = (mv == 0) ? __builtin_amdgcn_readlane(dR[kk], k) : b0[0];
+							int h0 = rh - b0[0] + S;
+							const int tt = (h1[0] - b0[0]) + (PW == 0 ? E : PW == 1 ? ee[0] : max(ee[0], qq[0]));
+							h0 = (h0 >= tt) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;
+							if(lane == 0) mc = b0[0] + h0;
+						}
+						if(SIMPLE){
+							N[j] = mc; inj[j] = blk0[j] ? b0[j] + BSA_EPI8_MIN : NEG; Ein[j] = h1[j] + (PW == 0 ? E : ee[j]);
+							if(PW == 2) Qin[j] = h1[j] + qq[j];
+						} else {
+							N[j] = max(N[j], mc);
+							inj[j] = max(inj[j], blk0[j] ? b0[j] + BSA_EPI8_MIN : NEG);
+							Ein[j] = max(Ein[j], h1[j] + (PW == 0 ? E : ee[j]));
+							if(PW == 2) Qin[j] = max(Qin[j], h1[j] + qq[j]);
+						}
 					}
-					if(dead){
-#pragma unroll
-						for(int j = 0; j < CPL; j++){ h1[j] = BSA_SCORE_MIN; b0[j] = BSA_SCORE_MIN; ee[j] = 0; qq[j] = 0; }
-					}
-				} else if(mv == 0 && lane == 0) b0[0] = src0 ? a.head_u0 : sbase;       // ubegs[0] of the predecessor
+				}
+				POA_PROF_MARK(2)
+				// the chains: per lane the maximum of its cells' sources, one scan over the lanes, then cell by cell inside the lane
+				int Nc[CPL], af[CPL], ag[CPL];
+				int mf = NEG, mg = NEG;
 #pragma unroll
 				for(int j = 0; j < CPL; j++){
-					const int S = Sb[j] + (same ? 0 : hpc[j]);
-					int mc = b0[j] + S;
-					if(j == 0){
-						// band cell 0: the seed rule (bsalign.h:2899-2907), rh as dpalign_row_update_bspoa picks it (bspoa.h:2242-2254)
-						const int rh = (mv == 0) ? __builtin_amdgcn_readlane(dR[kk], k) : b0[0];
-						int h0 = rh - b0[0] + S;
-						const int tt = (h1[0] - b0[0]) + (PW == 0 ? E : PW == 1 ? ee[0] : max(ee[0], qq[0]));
-						h0 = (h0 >= tt) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;
-						if(lane == 0) mc = b0[0] + h0;
+					Nc[j] = max(N[j], Ein[j]);
+					if(!SIMPLE && has_merge) Nc[j] = max(Nc[j], HX[j]);
+					if(PW == 2) Nc[j] = max(Nc[j], Qin[j]);
+					if(!SIMPLE && CPL * 64 != bw && !live[j]){ Nc[j] = NEG; inj[j] = NEG; }
+					af[j] = max(inj[j], Nc[j] + O) - pE[j]; mf = max(mf, af[j]);
+					if(PW == 2){ ag[j] = max(inj[j], Nc[j] + Q) - pP[j]; mg = max(mg, ag[j]); }
+				}
+				poa_scan_max2(mf, mg);
+				int exf = __builtin_amdgcn_update_dpp(NEG, mf, 0x138, 0xf, 0xf, false);       // wave_shr:1: what the lanes before offer
+				int exg = (PW == 2) ? __builtin_amdgcn_update_dpp(NEG, mg, 0x138, 0xf, 0xf, false) : NEG;
+				int H[CPL];
+#pragma unroll
+				for(int j = 0; j < CPL; j++){
+					H[j] = max(Nc[j], max(exf + pE[j], inj[j]));
+					if(PW == 2) H[j] = max(H[j], exg + pP[j]);
+					exf = max(exf, af[j]);
+					if(PW == 2) exg = max(exg, ag[j]);
+				}
+				POA_PROF_MARK(3)
+				const int hb = __builtin_amdgcn_readlane(H[0], 0);
+				uint32_t cwo[CPL];
+#pragma unroll
+				for(int j = 0; j < CPL; j++){
+					int e1 = 0, q1 = 0;
+					// e = max(E-path of the inputs + gape1, H + gapo1 + gape1, merged rows' E) - H, taken relative to H from the start
+					if(PW >= 1){ e1 = max(Ein[j] - H[j] + E, OE); if(!SIMPLE && has_merge) e1 = max(e1, EX[j] - H[j]); }
+					if(PW == 2){ q1 = max(Qin[j] - H[j] + P, QP); if(!SIMPLE && has_merge) q1 = max(q1, QX[j] - H[j]); }
+					// {int16 H - base, e, q}: the two low bytes of e and q side by side with one v_perm, then under the 16 bits of H
+					cwo[j] = (((uint32_t)(H[j] - hb)) & 0xFFFFu) | __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)e1, 0x04000c0cu);
+				}
+				{
+					uint32_t *lrow = ring + (i & RM) * RS + p0;
+					uint32_t *grow = grows + (size_t)i * bw + p0;
+					if(SIMPLE || CPL * 64 == bw){
+						if constexpr(CPL == 2){ *(uint2*)lrow = make_uint2(cwo[0], cwo[1]); *(uint2*)grow = make_uint2(cwo[0], cwo[1]); }
+						else if constexpr(CPL == 4){ *(uint4*)lrow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); *(uint4*)grow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); }
+						else { lrow[0] = cwo[0]; grow[0] = cwo[0]; }
+					} else {
+#pragma unroll
+						for(int j = 0; j < CPL; j++) if(live[j]){ lrow[j] = cwo[j]; grow[j] = cwo[j]; }
 					}
-					N[j] = max(N[j], mc);
-					inj[j] = max(inj[j], blk0[j] ? b0[j] + BSA_EPI8_MIN : NEG);
-					Ein[j] = max(Ein[j], h1[j] + (PW == 0 ? E : ee[j]));
-					if(PW == 2) Qin[j] = max(Qin[j], h1[j] + qq[j]);
 				}
-			}
-			POA_PROF_MARK(2)
-			// the chains: per lane the maximum of its cells' sources, one scan over the lanes, then cell by cell inside the lane
-			int Nc[CPL], af[CPL], ag[CPL];
-			int mf = NEG, mg = NEG;
-#pragma unroll
-			for(int j = 0; j < CPL; j++){
-				Nc[j] = max(N[j], Ein[j]);
-				if(has_merge) Nc[j] = max(Nc[j], HX[j]);
-				if(PW == 2) Nc[j] = max(Nc[j], Qin[j]);
-				if(CPL * 64 != bw && !live[j]){ Nc[j] = NEG; inj[j] = NEG; }
-				af[j] = max(inj[j], Nc[j] + O) - pE[j]; mf = max(mf, af[j]);
-				if(PW == 2){ ag[j] = max(inj[j], Nc[j] + Q) - pP[j]; mg = max(mg, ag[j]); }
-			}
-			poa_scan_max2(mf, mg);
-			int exf = __builtin_amdgcn_update_dpp(NEG, mf, 0x138, 0xf, 0xf, false);       // wave_shr:1: what the lanes before offer
-			int exg = (PW == 2) ? __builtin_amdgcn_update_dpp(NEG, mg, 0x138, 0xf, 0xf, false) : NEG;
-			int H[CPL];
-#pragma unroll
-			for(int j = 0; j < CPL; j++){
-				H[j] = max(Nc[j], max(exf + pE[j], inj[j]));
-				if(PW == 2) H[j] = max(H[j], exg + pP[j]);
-				exf = max(exf, af[j]);
-				if(PW == 2) exg = max(exg, ag[j]);
-			}
-			POA_PROF_MARK(3)
-			const int hb = __builtin_amdgcn_readlane(H[0], 0);
-			uint32_t cwo[CPL];
-#pragma unroll
-			for(int j = 0; j < CPL; j++){
-				int e1 = 0, q1 = 0;
-				// e = max(E-path of the inputs + gape1, H + gapo1 + gape1, merged rows' E) - H, taken relative to H from the start
-				if(PW >= 1){ e1 = max(Ein[j] - H[j] + E, OE); if(has_merge) e1 = max(e1, EX[j] - H[j]); }
-				if(PW == 2){ q1 = max(Qin[j] - H[j] + P, QP); if(has_merge) q1 = max(q1, QX[j] - H[j]); }
-				// {int16 H - base, e, q}: the two low bytes of e and q side by side with one v_perm, then under the 16 bits of H
-				cwo[j] = (((uint32_t)(H[j] - hb)) & 0xFFFFu) | __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)e1, 0x04000c0cu);
-			}
-			{
-				uint32_t *lrow = ring + (i & RM) * RS + p0;
-				uint32_t *grow = grows + (size_t)i * bw + p0;
-				if(CPL * 64 == bw){
-					if constexpr(CPL == 2){ *(uint2*)lrow = make_uint2(cwo[0], cwo[1]); *(uint2*)grow = make_uint2(cwo[0], cwo[1]); }
-					else if constexpr(CPL == 4){ *(uint4*)lrow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); *(uint4*)grow = make_uint4(cwo[0], cwo[1], cwo[2], cwo[3]); }
-					else { lrow[0] = cwo[0]; grow[0] = cwo[0]; }
-				} else {
-#pragma unroll
-					for(int j = 0; j < CPL; j++) if(live[j]){ lrow[j] = cwo[j]; grow[j] = cwo[j]; }
+				{
+					// the row's first synthetic cells (e = q = 0) behind its end, ring only
+					const int hl = __builtin_amdgcn_readlane(H[(bw - 1) % CPL], (bw - 1) / CPL);
+					if(lane < POA_ROWS_PAD) ring[(i & RM) * RS + bw + lane] = (uint32_t)((hl + synk - hb) & 0xFFFF);
 				}
-			}
-			{
-				// the row's first synthetic cells (e = q = 0) behind its end, ring only
-				const int hl = __builtin_amdgcn_readlane(H[(bw - 1) % CPL], (bw - 1) / CPL);
-				if(lane < POA_ROWS_PAD) ring[(i & RM) * RS + bw + lane] = (uint32_t)((hl + synk - hb) & 0xFFFF);
-			}
-			if(lane == 0){ ring[(i & RM) * RS + BC] = (uint32_t)hb; gu0[i] = hb; }
-			POA_PROF_MARK(4)
+				if(lane == 0){ ring[(i & RM) * RS + BC] = (uint32_t)hb; gu0[i] = hb; }
+				POA_PROF_MARK(4)
+			};
+			if(plain) node_body(std::true_type{}); else node_body(std::false_type{});
 		}
 	}
 #ifdef POA_PROF
