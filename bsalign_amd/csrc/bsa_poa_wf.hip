@@ -183,16 +183,22 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 			const uint32_t w3 = (uint32_t)__builtin_amdgcn_readlane((int)r0.w, k);
 			const uint32_t nbase = (w3 >> 16) & 0xFFu;
 			const int Mv = a.M + (((w3 >> 24) & 1u) ? a.refbonus : 0);
-			// The node's kind decides how much of the general row is needed.  Most nodes are PLAIN: one input, a row update (not a merge) of a
-			// row in the ring moved by at most the pad, the whole band inside the read -- for them the body below is compiled a second time
-			// with everything else cut out (no second input, no merged rows, no synthetic cells, no clamps), the same expressions otherwise.
+			// The node's kind decides how much of the general row is needed.  Most nodes are PLAIN: one or two inputs, each a row update (not
+			// a merge) of a row in the ring moved by at most the pad, the whole band inside the read -- for them the body below is compiled
+			// again (once for one input, once for two) with everything else cut out (no merged rows, no synthetic cells, no clamps, no
+			// input that may be absent), the same expressions otherwise.
 			uint32_t kinds[2];
 			kinds[0] = (uint32_t)__builtin_amdgcn_readlane((int)dK[0], k); kinds[1] = (uint32_t)__builtin_amdgcn_readlane((int)dK[1], k);
 			const uint32_t dA0 = (uint32_t)__builtin_amdgcn_readlane((int)dA[0], k);
-			const bool plain = (kinds[0] & (BSA_POA_IN_PRESENT | BSA_POA_IN_MERGE | 0x10000000u)) == BSA_POA_IN_PRESENT && !(kinds[1] & BSA_POA_IN_PRESENT)
-				&& (dA0 >> 16) <= (uint32_t)POA_ROWS_PAD && CPL * 64 == bw && rpos + CPL * 64 <= slen;
+			const uint32_t kmask = BSA_POA_IN_PRESENT | BSA_POA_IN_MERGE | 0x10000000u;
+			int plain = 0;
+			if((kinds[0] & kmask) == BSA_POA_IN_PRESENT && (dA0 >> 16) <= (uint32_t)POA_ROWS_PAD && CPL * 64 == bw && rpos + CPL * 64 <= slen){
+				if(!(kinds[1] & BSA_POA_IN_PRESENT)) plain = 1;
+				else if((kinds[1] & kmask) == BSA_POA_IN_PRESENT && ((uint32_t)__builtin_amdgcn_readlane((int)dA[1], k) >> 16) <= (uint32_t)POA_ROWS_PAD) plain = 2;
+			}
 			auto node_body = [&](auto plain_tag){
-				constexpr bool SIMPLE = decltype(plain_tag)::value;
+				constexpr int NINP = decltype(plain_tag)::value;
+				constexpr bool SIMPLE = NINP > 0;
 				// phase 1: everything the node reads from LDS, requested at once (one round trip per node); an input further back than the
 				// ring (rare) is read from HBM into the same registers afterwards
 				int mvs[2], sbs[2]; uint32_t dAs[2], cwv[2][CPL], cmv[2];
@@ -204,7 +210,7 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 					dAs[kk] = 0; mvs[kk] = 0; sbs[kk] = 0; cmv[kk] = 0;
 #pragma unroll
 					for(int j = 0; j < CPL; j++) cwv[kk][j] = 0;
-					if(kk == 1 && (SIMPLE || !(kinds[1] & BSA_POA_IN_PRESENT))) continue;          // (most nodes have one input: nothing to fetch for the other)
+					if(kk == 1 && (SIMPLE ? NINP < 2 : !(kinds[1] & BSA_POA_IN_PRESENT))) continue;          // (most nodes have one input: nothing to fetch for the other)
 					dAs[kk] = (kk == 0) ? dA0 : (uint32_t)__builtin_amdgcn_readlane((int)dA[kk], k);
 					mvs[kk] = (int)(dAs[kk] >> 16);
 					const uint32_t *lrow = (const uint32_t*)((const uint8_t*)ring + (dAs[kk] & 0x7FFFu));
@@ -247,7 +253,7 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 				bool has_merge = false;
 				// phase 2: what the inputs offer (uniform branches on the node record, selects per cell)
 #pragma unroll
-				for(int kk = 0; kk < (SIMPLE ? 1 : 2); kk++){
+				for(int kk = 0; kk < (SIMPLE ? NINP : 2); kk++){
 					const uint32_t kind = kinds[kk];
 					if(!SIMPLE && !(kind & BSA_POA_IN_PRESENT)) continue;
 					const int mv = mvs[kk], sbase = sbs[kk];
@@ -304,7 +310,7 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 							h0 = (h0 >= tt) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;
 							if(lane == 0) mc = b0[0] + h0;
 						}
-						if(SIMPLE){
+						if(SIMPLE && kk == 0){
 							N[j] = mc; inj[j] = blk0[j] ? b0[j] + BSA_EPI8_MIN : NEG; Ein[j] = h1[j] + (PW == 0 ? E : ee[j]);
 							if(PW == 2) Qin[j] = h1[j] + qq[j];
 						} else {
@@ -371,7 +377,7 @@ static __device__ __forceinline__ int poa_forward_rows(const PoaArgs &a, const b
 				if(lane == 0){ ring[(i & RM) * RS + BC] = (uint32_t)hb; gu0[i] = hb; }
 				POA_PROF_MARK(4)
 			};
-			if(plain) node_body(std::true_type{}); else node_body(std::false_type{});
+			if(plain == 1) node_body(std::integral_constant<int, 1>{}); else if(plain == 2) node_body(std::integral_constant<int, 2>{}); else node_body(std::integral_constant<int, 0>{});
 		}
 	}
 #ifdef POA_PROF
