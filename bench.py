@@ -440,6 +440,8 @@ def main_poa_recorded(args):
     try:
         if fixture:
             raise RuntimeError("not run: the end-to-end leg drives the reference's own host code (oracle/_ref)")
+        if args.cpu_pairs < 0:
+            raise RuntimeError("not run (--cpu-pairs -1: the timed launches only, as the profiler's counter passes want them)")
         from test_poa_batched_gpu import Batcher
         bt = Batcher(ctx, nwin)
         try:
