@@ -53,8 +53,13 @@ struct ShmTransport : BsaShardTransport {
 	// one pass over the posted operations; true when all are complete
 	bool progress(){
 		bool all = true;
+		// (a ring is one byte stream: an operation waits for the earlier ones on the same ring in the same direction, or a later one
+		// would slip its bytes in between when room -- or data -- turns up while the pass is under way)
+		std::vector<char> held(2 * (size_t)nranks, 0);
 		for(Op &o : ops){
 			if(o.done == o.bytes) continue;
+			char &hold = held[(o.is_send ? 0 : (size_t)nranks) + (size_t)o.peer];
+			if(hold){ all = false; continue; }
 			Ring *r = o.is_send ? ring(rank, o.peer) : ring(o.peer, rank);
 			uint64_t h = r->head.load(std::memory_order_acquire), t = r->tail.load(std::memory_order_acquire);
 			if(o.is_send){
@@ -72,7 +77,7 @@ struct ShmTransport : BsaShardTransport {
 				}
 				if(n){ r->tail.store(t + n, std::memory_order_release); o.done += n; }
 			}
-			if(o.done != o.bytes) all = false;
+			if(o.done != o.bytes){ all = false; hold = 1; }
 		}
 		return all;
 	}
