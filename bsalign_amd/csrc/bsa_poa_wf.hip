@@ -1241,15 +1241,19 @@ static size_t poa_ring_bytes(uint32_t bw, uint32_t nl){ return (size_t)(nl + POA
 static size_t poa_front_bytes(uint32_t bw, uint32_t nl){ return (std::max(poa_ring_bytes(bw, nl) + (size_t)(nl + POA_NEAR + POA_DRAIN) * 8, poa_tile_bytes(bw)) + 15) & ~(size_t)15; }
 
 static uint32_t poa_rows_cpl(uint32_t bw){ return bw <= 64 ? 1u : bw <= 128 ? 2u : 4u; }
-static const uint32_t POA_ROWS_R = 8;       // ring rows of the row-at-a-time forward pass (a power of two; inputs further back are read from HBM)
-static size_t poa_rows_ring_bytes(uint32_t bw){ return (size_t)POA_ROWS_R * (poa_rows_cpl(bw) * 64 + 2 * POA_ROWS_PAD) * 4; }
-static size_t poa_rows_front_bytes(uint32_t bw){ return (poa_rows_ring_bytes(bw) + POA_ROWS_R * 8 + 15) & ~(size_t)15; }       // (the forward pass's part; the traceback's ring + POA_QW bytes take its place afterwards)
+// Ring rows of the row-at-a-time forward pass (a power of two; inputs further back are read from HBM, after a wait for the stores and a
+// cache invalidate: microseconds).  8 rows keep a read's LDS at the traceback's 10 KB -- 16 reads per CU, what a launch of thousands of
+// windows wants; a launch that cannot fill the CUs anyway takes 16 rows: in the deep graph of a window with 64 reads 2 % of the inputs lie
+// more than 7 nodes back, none more than 15.
+static uint32_t poa_rows_r(size_t nprogs){ return nprogs > 2048 ? 8u : 16u; }
+static size_t poa_rows_ring_bytes(uint32_t bw, uint32_t R){ return (size_t)R * (poa_rows_cpl(bw) * 64 + 2 * POA_ROWS_PAD) * 4; }
+static size_t poa_rows_front_bytes(uint32_t bw, uint32_t R){ return (poa_rows_ring_bytes(bw, R) + R * 8 + 15) & ~(size_t)15; }       // (the forward pass's part; the traceback's ring + POA_QW bytes take its place afterwards)
 static size_t poa_rows_qb_bytes(uint32_t bw, uint32_t max_slen){ return ((size_t)max_slen + poa_rows_cpl(bw) * 64 + 8 + 15) & ~(size_t)15; }
 // the row-at-a-time forward pass (poa_forward_rows): its scans need gapo <= 0 and gapo1 + gape1 <= gape1 <= gape2 <= 0 (the guard of
 // bsa_poa_graph_supported has the signs), and 64 ring rows + the query in LDS
 static bool poa_rows_supported(const bsa_rows_params_t *rp, int pw, uint32_t bw, uint32_t max_slen){
 	if(pw == 2 && rp->gape1 > rp->gape2) return false;
-	return std::max(poa_rows_front_bytes(bw) + poa_rows_qb_bytes(bw, max_slen), poa_tile_bytes(bw) + POA_QW) <= POA_LDS_MAX;
+	return std::max(poa_rows_front_bytes(bw, 16) + poa_rows_qb_bytes(bw, max_slen), poa_tile_bytes(bw) + POA_QW) <= POA_LDS_MAX;
 }
 
 extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen){
@@ -1306,9 +1310,9 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 	{ const char *fe = bsa_env("BSA_POA_FWD"); if(fe && fe[0] == 'w') rows_fwd = false; }
 	a.bw = bw; a.W = bw / 16; a.nl = (uint32_t)nl;
 	if(rows_fwd){
-		a.R = POA_ROWS_R;
-		a.ri_off = (uint32_t)poa_rows_ring_bytes(bw);
-		a.qn_off = (uint32_t)poa_rows_front_bytes(bw);
+		a.R = poa_rows_r(nprogs);
+		a.ri_off = (uint32_t)poa_rows_ring_bytes(bw, a.R);
+		a.qn_off = (uint32_t)poa_rows_front_bytes(bw, a.R);
 	} else {
 		a.R = (uint32_t)nl + POA_NEAR + POA_DRAIN;
 		a.ri_off = (uint32_t)poa_ring_bytes(bw, (uint32_t)nl);

@@ -1,7 +1,9 @@
-import sys, os
-sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
+"""debugging aid (GPU box): the reads of BASELINE's C4 window through the reference's harness (oracle backend, mode 5: programs and the reference's own
+walk recorded), then every read's program on the device -- step-by-step comparison with the reference's walk, wall time and kernel time of the call."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
-import poa_support as P, support as S
+import poa_support as P
 import bsalign_amd as B
 from test_poa_graph_gpu import _sweep_params
 ctx = B.Context(0)
@@ -11,11 +13,17 @@ reads = P.synth_reads(20240611 & 0xFFFF, 20000, nreads, eps=(0.1,))
 r = P.run_ref_graph(reads, 5, p, record=True, lib=P.ref_poa_trace(), backend="oracle")
 print("bad", r["bad"], "graph reads", r["graph_reads"])
 for k, rd in enumerate(r["recs"]):
-    if "nodes" not in rd or len(rd["nodes"]) < 2 or rd["bandwidth"] > 256 or k < int(os.environ.get("DBG_FROM", "0")): continue
+    if "nodes" not in rd or len(rd["nodes"]) < 2 or rd["bandwidth"] > 256 or k < int(os.environ.get("DBG_FROM", "0")):
+        continue
     cap = 2 * (rd["slen"] + len(rd["nodes"])) + 64
     pr = np.zeros(1, P.WF_PROG)
     pr[0] = (0, len(rd["nodes"]), 0, len(rd["edges"]), 0, len(rd["cands"]), rd["slen"], cap, 0, 0)
-    res, ev, _, _ = ctx.poa_graph_host(rd["nodes"], rd["edges"], rd["cands"], pr, rd["query"], _sweep_params(p, rd["bandwidth"]), cap)
+    sp = _sweep_params(dict(p, alnmode=p["alnmode"] | (0x200 if os.environ.get("DBG_FWD_ONLY") else 0)), rd["bandwidth"])
+    ctx.poa_graph_host(rd["nodes"], rd["edges"], rd["cands"], pr, rd["query"], sp, cap)
+    t0 = time.perf_counter()
+    res, ev, _, _ = ctx.poa_graph_host(rd["nodes"], rd["edges"], rd["cands"], pr, rd["query"], sp, cap)
+    wall = time.perf_counter() - t0
+    kms = ctx.last_kernel_ms()[0]
     rr = res[0]
     mine = ev[:int(rr["nevents"])]
     tr = rd["trace"]
@@ -23,18 +31,12 @@ for k, rd in enumerate(r["recs"]):
     nmin = min(len(mine), len(tr))
     diff = np.nonzero((gn[:nmin] != tr["node"][:nmin]) | (mine["x"][:nmin] != tr["x"][:nmin]) | (mine["bt"][:nmin] != tr["bt"][:nmin]))[0]
     ok = rr["status"] == 0 and len(mine) == len(tr) and len(diff) == 0
-    print("read", k, "bw", rd["bandwidth"], "nodes", len(rd["nodes"]), "steps", len(tr), "status", int(rr["status"]), "mine", len(mine), "OK" if ok else "DIFF")
-    if not ok:
-        i = int(diff[0]) if len(diff) else nmin
-        g2l = {int(g): j for j, g in enumerate(rd["nodes"]["gnode"]) if g != 0xFFFFFFFF}
-        print("  first difference at step", i)
-        for j in range(max(0, i - 3), min(nmin, i + 3)):
-            ln = g2l[int(tr["node"][j])]
-            print("   step", j, "mine (node %d, x %d, bt %d)" % (mine["node"][j], mine["x"][j], mine["bt"][j]), "ref (node %d, x %d, bt %d)" % (ln, tr["x"][j], tr["bt"][j]),
-                  "rpos", int(rd["nodes"]["rpos"][ln]), "nin", int(rd["nodes"]["n_in"][ln]), "first_in", int(rd["nodes"]["first_in"][ln]))
-        ln = g2l[int(tr["node"][i])] if i < len(tr) else -1
-        if ln >= 0:
-            nd = rd["nodes"][ln]
-            for e in rd["edges"][int(nd["first_in"]):int(nd["first_in"]) + int(nd["n_in"])]:
-                print("    in-edge src", int(e["src"]), "cov", int(e["cov"]), "src_rpos", int(e["src_rpos"]), "delta node", ln - int(e["src"]))
-        break
+    print("read", k, "bw", rd["bandwidth"], "nodes", len(rd["nodes"]), "edges", len(rd["edges"]), "steps", len(tr), "status", int(rr["status"]), "OK" if ok else "DIFF at step %d" % (int(diff[0]) if len(diff) else nmin),
+          "call %.1f ms, kernel %.1f ms" % (wall * 1e3, kms))
+    if os.environ.get("DBG_DIST"):
+        nd = rd["nodes"]; idx = np.arange(len(nd))
+        for nm in ("in0", "in1"):
+            pres = (nd[nm + "_tk"] & 0x80000000) != 0
+            dist = (idx - nd[nm + "_src"].astype(np.int64))[pres]
+            print("   ", nm, "present", int(pres.sum()), "distance > 7: %.2f %%, > 15: %.2f %%, > 31: %.2f %%, max %d" % (100.0 * (dist > 7).mean(), 100.0 * (dist > 15).mean(), 100.0 * (dist > 31).mean(), int(dist.max())),
+                  "movx > 8: %.3f %%" % (100.0 * (nd[nm + "_movx"][pres] > 8).mean()))
