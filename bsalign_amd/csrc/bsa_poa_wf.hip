@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					else Hs1 = HH(n, pp, CELL(n, pp), U0(n));
 				}
 #ifdef POA_PROF
-				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[6] = {0, 0, 0, 0, 0, 0}, tq_l = clock64(); int tq_cat = 5, tq_k[6] = {0, 0, 0, 0, 0, 0};
+				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[6] = {0, 0, 0, 0, 0, 0}, tq_l = clock64(); int tq_cat = 5, tq_k[6] = {0, 0, 0, 0, 0, 0}, tq_end[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tq_endL[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
 #define POA_TRK(k_) { __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq[k_] += t_ - tq_t; tq_t = t_; }
 #else
 #define POA_TRK(k_)
@@ -851,6 +851,11 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				// further down, one at a time, as before.
 				int t_top = -1, t_x = 0;
 				uint32_t d_cat = 7u, d_word = 0; int d_w = 0, d_sx = 0, d_h = 0, d_H = 0, t_j[5] = {64, 64, 64, 64, 64};
+				// The four columns of a tile's node j start at t_base(j) = the skew the walk has shown so far: it loses columns against the
+				// nodes wherever it skips nodes (a graph of many reads: more than one node a step) or takes a deletion, and gains one with
+				// an insertion.  t_sig = that drift per node in 1/256 (of the tile), sig = the running estimate (halved into every tile's).
+				int t_sig = 0, sig = 0;
+				auto t_base = [&](int j) -> int { return max(((j * t_sig) >> 8) - 1, 0); };
 				// Follow the tile from lane `id`, all of its steps at once.  Every lane knows the lane its decision leads to (t_j[0]; 64 = out of
 				// the tile, itself = the walk changes state or cannot be decided here); t_j[k] is that map applied 2^k times.  Lane s composes the
 				// maps of s's bits and so stands on the place the walk reaches after s steps; the first s whose place does not go on is the
@@ -877,10 +882,16 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					const int pe = __builtin_amdgcn_readlane(pos, L);
 					const uint32_t ce = stop ? (uint32_t)__builtin_amdgcn_readlane((int)cat, L) : 9u;
 					if(L > 0){
-						if(pe < 64){ n = t_top - (pe >> 2); x = t_x - (pe >> 2) + (pe & 3); Hs1 = __builtin_amdgcn_readlane(d_H, pe); }
+						const int n_was = n, x_was = x;
+						if(pe < 64){ n = t_top - (pe >> 2); x = t_x - (pe >> 2) + (pe & 3) + t_base(pe >> 2); Hs1 = __builtin_amdgcn_readlane(d_H, pe); }
 						else { const int last = __builtin_amdgcn_readlane(pos, L - 1); n = __builtin_amdgcn_readlane(d_w, last); x = __builtin_amdgcn_readlane(d_sx, last); Hs1 = __builtin_amdgcn_readlane(d_h, last); }
 						nidx = n; Hs2 = 0;
+						// nodes gone down against columns gone left, in 1/256 per node
+						if(n_was - n >= 4) sig = (sig + min(max(((n_was - n) + (x - x_was)) * 256 / (n_was - n), 0), 224)) >> 1;
 					}
+#ifdef POA_PROF
+					{ int why = (int)ce; if(ce == 8u){ const int jj = t_top - n; why = (jj >= POA_TILE) ? 8 : (x - t_x + jj - t_base(jj) < 0) ? 10 : 11; } tq_end[why]++; tq_endL[why] += L; }
+#endif
 					if(ce == 7u) return !(n == 0 || x < 0);                                     // undecided here: the step below takes it
 					if(ce == 3u){ bt = 1u; Hs2 = 1; Hs0 = __builtin_amdgcn_readlane(d_h, pe); }
 					else if(ce == 1u || ce == 2u){ bt = (ce == 1u) ? 2u : 4u; Hs2 = 1; }
@@ -899,8 +910,8 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					bool build = false;
 #ifndef POA_NO_TILE
 					if(bt == 0xFFFFFFFFu){
-						const int tj = t_top - n, td = x - t_x + tj;
-						if(t_top < 0 || (unsigned)tj >= (unsigned)POA_TILE || (unsigned)td >= 4u) build = true;
+						const int tj = t_top - n, td = (t_top >= 0 && (unsigned)tj < (unsigned)POA_TILE) ? x - t_x + tj - t_base(tj) : -1;
+						if((unsigned)td >= 4u) build = true;
 						else if(__builtin_amdgcn_readlane(d_H, tj * 4 + td) == Hs1){          // (always, by construction; if not, the step below finds out why)
 							if(!chase(tj * 4 + td)) continue;
 						}
@@ -935,8 +946,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 #ifdef POA_PROF
 							tq_build++;
 #endif
+							t_sig = sig;
 							const int j = lane >> 2;
-							const int m = n - j, xm = x - j + (lane & 3), ms = m & (POA_TN - 1);
+							const int m = n - j, xm = x - j + (lane & 3) + t_base(j), ms = m & (POA_TN - 1);
 							const uint4 r0m = t_r0[ms];
 							const int mfirst = (int)r0m.z, mnin = (int)(r0m.w & 0xFFFFu), ppm = xm - (int)r0m.x;
 							const uint32_t mbase = (r0m.w >> 16) & 0xFFu;
@@ -996,8 +1008,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 								// where the decision leads: a lane of this tile, out of it (64), or nowhere (the walk stops here: the lane itself)
 								int nid = lane;
 								if(on){
-									const int wj = n - d_w, dd = d_sx - (x - wj);
-									nid = ((unsigned)wj < (unsigned)POA_TILE && (unsigned)dd < 4u) ? wj * 4 + dd : 64;
+									const int wj = n - d_w;
+									if((unsigned)wj < (unsigned)POA_TILE){ const int dd = d_sx - (x - wj) - t_base(wj); nid = ((unsigned)dd < 4u) ? wj * 4 + dd : 64; }
+									else nid = 64;
 								}
 								t_j[0] = nid;
 #pragma unroll
@@ -1207,6 +1220,8 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 #undef POA_UNI
 #ifdef POA_PROF
 				if(lane == 0 && blockIdx.x == 0) printf("poa walk: %d steps in %d chases (%lld clocks), %d tiles (%lld), plain steps one at a time %d (%lld), insertion %d (%lld), deletion %d (%lld); %lld clocks in all\n", tq_chase, tq_k[0], tq_c[0], tq_k[1], tq_c[1], tq_k[2], tq_c[2], tq_k[3], tq_c[3], tq_k[4], tq_c[4], (long long)(clock64() - tq_0));
+				if(lane == 0 && blockIdx.x == 0) printf("poa chases end at: deletion %d (%d steps before), q-deletion %d (%d), insertion %d (%d), undecided %d (%d), below the tile's nodes %d (%d), left of its columns %d (%d), right of them %d (%d), pause %d (%d); drift estimate %d/256\n",
+					tq_end[1], tq_endL[1], tq_end[2], tq_endL[2], tq_end[3], tq_endL[3], tq_end[7], tq_endL[7], tq_end[8], tq_endL[8], tq_end[10], tq_endL[10], tq_end[11], tq_endL[11], tq_end[9], tq_endL[9], sig);
 				if(lane == 0 && blockIdx.x == 0) printf("poa walk profile: %d cooperative steps; clocks per step: loop top %.0f, node ring %.0f, record + edge ring %.0f, edges evaluated %.0f, choice + move %.0f\n", tq_n,
 					(double)tq[0] / max(tq_n, 1), (double)tq[1] / max(tq_n, 1), (double)tq[2] / max(tq_n, 1), (double)tq[3] / max(tq_n, 1), (double)tq[4] / max(tq_n, 1));
 #endif
