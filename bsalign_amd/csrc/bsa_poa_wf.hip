@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					else Hs1 = HH(n, pp, CELL(n, pp), U0(n));
 				}
 #ifdef POA_PROF
-				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[6] = {0, 0, 0, 0, 0, 0}, tq_l = clock64(); int tq_cat = 5, tq_k[6] = {0, 0, 0, 0, 0, 0}, tq_end[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tq_endL[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[6] = {0, 0, 0, 0, 0, 0}, tq_l = clock64(); int d_why = 0, tq_why[10] = {0,0,0,0,0,0,0,0,0,0}; int tq_cat = 5, tq_k[6] = {0, 0, 0, 0, 0, 0}, tq_end[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tq_endL[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
 #define POA_TRK(k_) { __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq[k_] += t_ - tq_t; tq_t = t_; }
 #else
 #define POA_TRK(k_)
@@ -890,6 +890,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						if(n_was - n >= 4) sig = (sig + min(max(((n_was - n) + (x - x_was)) * 256 / (n_was - n), 0), 224)) >> 1;
 					}
 #ifdef POA_PROF
+					if(ce == 7u) tq_why[__builtin_amdgcn_readlane(d_why, pe) % 10]++;
 					{ int why = (int)ce; if(ce == 8u){ const int jj = t_top - n; why = (jj >= POA_TILE) ? 8 : (x - t_x + jj - t_base(jj) < 0) ? 10 : 11; } tq_end[why]++; tq_endL[why] += L; }
 #endif
 					if(ce == 7u) return !(n == 0 || x < 0);                                     // undecided here: the step below takes it
@@ -953,12 +954,18 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							const int mfirst = (int)r0m.z, mnin = (int)(r0m.w & 0xFFFFu), ppm = xm - (int)r0m.x;
 							const uint32_t mbase = (r0m.w >> 16) & 0xFFu;
 							bool ok = m >= 1 && m >= lo && xm >= 0 && ppm >= 0 && ppm < bw && mfirst >= elo && mfirst + mnin <= ehi;
+#ifdef POA_PROF
+							d_why = (m < 1) ? 1 : (m < lo) ? 2 : (xm < 0) ? 3 : (ppm < 0 || ppm >= bw) ? 4 : (mfirst < elo) ? 5 : (mfirst + mnin > ehi) ? 6 : 0;
+#endif
 							const int pc = min(max(ppm, 0), bw - 1), pcm = max(pc - 1, 0), xq = max(xm, 0);
 							const uint32_t cwm = t_rows[ms * POA_TW + (pc & (POA_TW - 1))], cmm = t_rows[ms * POA_TW + (pcm & (POA_TW - 1))];
 							const int u0m = t_u0[ms], c0m = t_c0[ms];
 							const uint32_t nbv = QCODE(xq);
 							uint4 ed = ((const uint4*)t_edges)[mfirst & (POA_TE - 1)];
 							ok = ok && (unsigned)(pc - c0m) < (unsigned)POA_TW && (unsigned)(pcm - c0m) < (unsigned)POA_TW;
+#ifdef POA_PROF
+							if(d_why == 0 && !ok) d_why = 7;
+#endif
 							const int Hm = u0m + (int)(int16_t)(cwm & 0xFFFFu);
 							const int hmn = (ppm >= 1) ? u0m + (int)(int16_t)(cmm & 0xFFFFu) : u0m;
 							const int sbv = (nbv & 8u) ? BSA_EPI8_MIN : (((nbv & 3u) == mbase) ? a.M + ((r0m.w >> 24) & 1u ? a.refbonus : 0) : a.X);
@@ -979,6 +986,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 								// a predecessor below the ring, or its cells outside the window kept of it
 								const bool bad = w < lo || (unsigned)(p1 - c0w) >= (unsigned)POA_TW || (unsigned)(p0 - c0w) >= (unsigned)POA_TW;
 								ok = ok && !(valid && bad);
+#ifdef POA_PROF
+								if(d_why == 0 && valid && bad) d_why = (w < lo) ? 8 : 9;
+#endif
 								const int rbase = (w == 0) ? h0init : u0w;
 								const int hm = (pp >= 1) ? rbase + (int)(int16_t)(cm & 0xFFFFu) : u0w;
 								const int hc = rbase + (int)(int16_t)(cw & 0xFFFFu);
@@ -1222,6 +1232,8 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				if(lane == 0 && blockIdx.x == 0) printf("poa walk: %d steps in %d chases (%lld clocks), %d tiles (%lld), plain steps one at a time %d (%lld), insertion %d (%lld), deletion %d (%lld); %lld clocks in all\n", tq_chase, tq_k[0], tq_c[0], tq_k[1], tq_c[1], tq_k[2], tq_c[2], tq_k[3], tq_c[3], tq_k[4], tq_c[4], (long long)(clock64() - tq_0));
 				if(lane == 0 && blockIdx.x == 0) printf("poa chases end at: deletion %d (%d steps before), q-deletion %d (%d), insertion %d (%d), undecided %d (%d), below the tile's nodes %d (%d), left of its columns %d (%d), right of them %d (%d), pause %d (%d); drift estimate %d/256\n",
 					tq_end[1], tq_endL[1], tq_end[2], tq_endL[2], tq_end[3], tq_endL[3], tq_end[7], tq_endL[7], tq_end[8], tq_endL[8], tq_end[10], tq_endL[10], tq_end[11], tq_endL[11], tq_end[9], tq_endL[9], sig);
+				if(lane == 0 && blockIdx.x == 0) printf("poa undecided places: node 0 %d, node below the ring %d, column < 0 %d, cell outside the band %d, in-edges below the edge ring %d, above it %d, own cells outside the window %d, predecessor below the ring %d, its cells outside the window %d, other %d\n",
+					tq_why[1], tq_why[2], tq_why[3], tq_why[4], tq_why[5], tq_why[6], tq_why[7], tq_why[8], tq_why[9], tq_why[0]);
 				if(lane == 0 && blockIdx.x == 0) printf("poa walk profile: %d cooperative steps; clocks per step: loop top %.0f, node ring %.0f, record + edge ring %.0f, edges evaluated %.0f, choice + move %.0f\n", tq_n,
 					(double)tq[0] / max(tq_n, 1), (double)tq[1] / max(tq_n, 1), (double)tq[2] / max(tq_n, 1), (double)tq[3] / max(tq_n, 1), (double)tq[4] / max(tq_n, 1));
 #endif
