@@ -35,7 +35,6 @@
 #define POA_NQ     192     // node records staged in LDS ahead of the window
 #define POA_TN     32      // traceback: nodes in the ring (a power of two >= POA_TNEAR + 1 + the nodes per refill: 16, or 8 above 128 columns)
 #define POA_TILE   16      // ... nodes of a tile of decisions (four columns each: one lane per (node, column))
-#define POA_TWA    20      // ... of them above the walker's cell at the time the refill is asked for
 #define POA_QW     128     // ... columns of the read kept (a power of two)
 #define POA_TW     64      // ... cells of a row kept per node (a window around the walk's path; a power of two, a multiple of 4)
 #define POA_TNEAR  7       // ... predecessors at most this many nodes back are kept in the ring (0.3 % are further: read from HBM)
@@ -737,22 +736,25 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		constexpr int RQ = POA_TW / 4;                      // 16-byte pieces of a ring row
 		constexpr int TC = 16;                              // nodes per refill
 		constexpr int NRQ = TC * RQ / 64;                   // 16-byte pieces of a refill, per lane
-		// the window of a node fetched while the walker's cell is pp: the walk drifts towards lower cells (the band moves on slower than
-		// the read), a refill is used some twenty to thirty nodes later
-		auto window_of = [&](int pp) -> int { return min(max((pp - (POA_TW - POA_TWA)) & ~3, 0), max(bw - POA_TW, 0)); };
+		// The window of a node: centred on the cell the walk is expected to pass it at.  The reference places a node's band around the read
+		// position it expects there, pinned to the read's two ends (bspoa.h:2168-2174), so the walker's cell runs along
+		// cell_of(x) = x - min(max(x - bw / 2, 0), slen - bw) -- down a cell a step near the ends, level in between -- plus whatever the
+		// walk has wandered off it so far; the column a node further down is passed at follows from the steps per node the walk has shown.
+		auto window_at = [&](int centre) -> int { return min(max((centre - POA_TW / 2) & ~3, 0), max(bw - POA_TW, 0)); };
+		auto cell_of = [&](int xx) -> int { return xx - min(max(xx - bw / 2, 0), max(slen - bw, 0)); };
 		int lo = max(0, n - (POA_TN - 1));                  // the ring holds nodes lo .. (the walker never goes up)
 		int elo, ehi;                                       // ... and edges elo .. ehi - 1
 		{
 			__syncthreads();
 			if constexpr(ROWS != 0){ qlo = max(0, x + 4 - POA_QW); q_fill(qlo, POA_QW); }
 			const int cnt = n - lo + 1;
-			const int c0 = window_of(x - (int)nodes[n].rpos);
+			const int off0 = x - (int)nodes[n].rpos - cell_of(x);          // (no history yet: a step a node)
 			if(lane < cnt) t_r0[(lo + lane) & (POA_TN - 1)] = *(const uint4*)(nodes + lo + lane);
 			for(int i = lane; i < cnt * RQ; i += 64){
-				const int nd_ = lo + i / RQ, c = c0 + (i % RQ) * 4;
+				const int nd_ = lo + i / RQ, c = window_at(cell_of(x - (n - nd_)) + off0) + (i % RQ) * 4;
 				if(c < bw) *(uint4*)(t_rows + (nd_ & (POA_TN - 1)) * POA_TW + (c & (POA_TW - 1))) = *(const uint4*)(grows + (size_t)nd_ * bw + c);
 			}
-			if(lane < cnt){ t_u0[(lo + lane) & (POA_TN - 1)] = gu0[lo + lane]; t_c0[(lo + lane) & (POA_TN - 1)] = c0; }
+			if(lane < cnt){ t_u0[(lo + lane) & (POA_TN - 1)] = gu0[lo + lane]; t_c0[(lo + lane) & (POA_TN - 1)] = window_at(cell_of(x - (n - lo - lane)) + off0); }
 			__syncthreads();
 			const uint4 hh = t_r0[n & (POA_TN - 1)];
 			ehi = (int)hh.z + (int)(hh.w & 0xFFFFu);
@@ -768,7 +770,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		auto node_request = [&](int pp){
 			// (every lane loads -- an index past the refill's end reads its last piece again --: a load under a condition would have to be
 			// merged into the register it waits in, and the merge waits for it)
-			plo = max(0, lo - TC); pc0 = window_of(pp);
+			plo = max(0, lo - TC); pc0 = window_at(pp);
 			const int cnt = lo - plo;
 #pragma unroll
 			for(int k = 0; k < NRQ; k++){
@@ -815,7 +817,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					else Hs1 = HH(n, pp, CELL(n, pp), U0(n));
 				}
 #ifdef POA_PROF
-				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[6] = {0, 0, 0, 0, 0, 0}, tq_l = clock64(); int d_why = 0, tq_why[10] = {0,0,0,0,0,0,0,0,0,0}; int tq_cat = 5, tq_k[6] = {0, 0, 0, 0, 0, 0}, tq_end[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tq_endL[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+				long long tq[6] = {0, 0, 0, 0, 0, 0}, tq_t = clock64(); int tq_n = 0, tq_chase = 0, tq_build = 0, tq_slow = 0; const long long tq_0 = clock64(); long long tq_c[6] = {0, 0, 0, 0, 0, 0}, tq_l = clock64(); int d_dbg = 0, d_why = 0, tq_why[10] = {0,0,0,0,0,0,0,0,0,0}; int tq_cat = 5, tq_k[6] = {0, 0, 0, 0, 0, 0}, tq_end[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tq_endL[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
 #define POA_TRK(k_) { __builtin_amdgcn_s_waitcnt(0xC07F); const long long t_ = clock64(); tq[k_] += t_ - tq_t; tq_t = t_; }
 #else
 #define POA_TRK(k_)
@@ -826,8 +828,8 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 #define POA_UNI(v_) __builtin_amdgcn_readfirstlane((int)(v_))
 				n = POA_UNI(n); nidx = n; x = POA_UNI(x); Hs1 = POA_UNI(Hs1); ne = 0; done = POA_UNI(done) != 0; status = POA_UNI(status);
 				lo = POA_UNI(lo); elo = POA_UNI(elo); ehi = POA_UNI(ehi);
-				int wpp = x - (int)nodes[n].rpos;                              // the walker's cell, as of the last node whose record was looked at
-				wpp = POA_UNI(wpp);
+				int wpp = x - (int)nodes[n].rpos, wpx = x;                     // the walker's cell, as of the last node whose record was looked at (then at column wpx)
+				wpp = POA_UNI(wpp); wpx = POA_UNI(wpx);
 				int h_n = -1; uint32_t h_rpos = 0, h_first = 0, h_w3 = 0;       // the record of node h_n (a step that chooses a node brings its record along)
 				const int h0init = poa_init_h<PW>(a, 0);
 				const bool ovl = mode == BSA_MODE_OVERLAP;
@@ -890,7 +892,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						if(n_was - n >= 4) sig = (sig + min(max(((n_was - n) + (x - x_was)) * 256 / (n_was - n), 0), 224)) >> 1;
 					}
 #ifdef POA_PROF
-					if(ce == 7u) tq_why[__builtin_amdgcn_readlane(d_why, pe) % 10]++;
+					if(ce == 7u){ tq_why[__builtin_amdgcn_readlane(d_why, pe) % 10]++; if(__builtin_amdgcn_readlane(d_why, pe) == 7 && lane == 0 && blockIdx.x == 0) printf("  window miss: window start %d, cell %d, node %d of tile at %d (column %d), lo %d, walker's cell %d, x %d, slen %d\n", __builtin_amdgcn_readlane(d_dbg, pe) >> 16, (int)(int16_t)(__builtin_amdgcn_readlane(d_dbg, pe) & 0xFFFF), t_top - (pe >> 2), t_top, t_x, lo, wpp, x, slen); }
 					{ int why = (int)ce; if(ce == 8u){ const int jj = t_top - n; why = (jj >= POA_TILE) ? 8 : (x - t_x + jj - t_base(jj) < 0) ? 10 : 11; } tq_end[why]++; tq_endL[why] += L; }
 #endif
 					if(ce == 7u) return !(n == 0 || x < 0);                                     // undecided here: the step below takes it
@@ -916,6 +918,9 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						else if(__builtin_amdgcn_readlane(d_H, tj * 4 + td) == Hs1){          // (always, by construction; if not, the step below finds out why)
 							if(!chase(tj * 4 + td)) continue;
 						}
+#ifdef POA_PROF
+						else { tq_why[0]++; if(lane == 0 && blockIdx.x == 0 && tq_why[0] < 6) printf("  H differs at lane %d of tile (%d, %d): walker (%d, %d) carries %d, lane has %d, code %d, why %d, window start %d cell %d, lo %d\n", tj * 4 + td, t_top, t_x, n, x, Hs1, __builtin_amdgcn_readlane(d_H, tj * 4 + td), __builtin_amdgcn_readlane((int)d_cat, tj * 4 + td), __builtin_amdgcn_readlane(d_why, tj * 4 + td), __builtin_amdgcn_readlane(d_dbg, tj * 4 + td) >> 16, (int)(int16_t)(__builtin_amdgcn_readlane(d_dbg, tj * 4 + td) & 0xFFFF), lo); }
+#endif
 					}
 #endif
 					// The ring: the walker's node and its predecessors (at most POA_TNEAR nodes back; further ones are read from HBM) have to be
@@ -926,14 +931,14 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 						const bool need = lo > 0 && n < lo + POA_TNEAR + 1;
 						if(npend && (need || (build && n < plo + POA_TN))) node_commit();
 						const bool need2 = lo > 0 && n < lo + POA_TNEAR + 1;
-						if(!npend && lo > 0 && (need2 || build || n < lo + POA_TNEAR + 1 + TC)) node_request(wpp);
+						if(!npend && lo > 0 && (need2 || build || n < lo + POA_TNEAR + 1 + TC)) node_request(cell_of(x - (((n - lo + TC / 2) * (256 - sig)) >> 8)) + wpp - cell_of(wpx));       // (the refill's nodes lie that far below the walker, on average)
 						if(need2) continue;
 					}
 					// the walker's node: inside the ring now
 					if(h_n != n){ const uint4 r0 = t_r0[n & (POA_TN - 1)]; h_rpos = (uint32_t)POA_UNI(r0.x); h_first = (uint32_t)POA_UNI(r0.z); h_w3 = (uint32_t)POA_UNI(r0.w); h_n = n; }
 					const int nrpos = (int)h_rpos, nin = (int)(h_w3 & 0xFFFFu), nfirst = (int)h_first;
 					const uint32_t nbase = (h_w3 >> 16) & 0xFFu, nflags = h_w3 >> 24;
-					wpp = x - nrpos;
+					wpp = x - nrpos; wpx = x;
 					POA_TRK(1)
 					{
 						const int ef = build ? max(nfirst - 24, 0) : nfirst;       // (a tile looks at the in-edges of the nodes below the walker as well)
@@ -965,6 +970,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 							ok = ok && (unsigned)(pc - c0m) < (unsigned)POA_TW && (unsigned)(pcm - c0m) < (unsigned)POA_TW;
 #ifdef POA_PROF
 							if(d_why == 0 && !ok) d_why = 7;
+							d_dbg = (c0m << 16) | (ppm & 0xFFFF);
 #endif
 							const int Hm = u0m + (int)(int16_t)(cwm & 0xFFFFu);
 							const int hmn = (ppm >= 1) ? u0m + (int)(int16_t)(cmm & 0xFFFFu) : u0m;
