@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 				// nodes wherever it skips nodes (a graph of many reads: more than one node a step) or takes a deletion, and gains one with
 				// an insertion.  t_sig = that drift per node in 1/256 (of the tile), sig = the running estimate (halved into every tile's).
 				int t_sig = 0, sig = 0;
-				auto t_base = [&](int j) -> int { return max(((j * t_sig) >> 8) - 1, 0); };
+				auto t_base = [&](int j) -> int { return j ? ((j * t_sig) >> 8) - 1 : 0; };       // (one column to the left of the expected one: an insertion on the way)
 				// Follow the tile from lane `id`, all of its steps at once.  Every lane knows the lane its decision leads to (t_j[0]; 64 = out of
 				// the tile, itself = the walk changes state or cannot be decided here); t_j[k] is that map applied 2^k times.  Lane s composes the
 				// maps of s's bits and so stands on the place the walk reaches after s steps; the first s whose place does not go on is the
