@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 	rs.maxoff = boff;
 
 	if(a.mode & 0x200){ if(a.mode & 0x100){ rs.fin_node = fwd_ticks; rs.fin_x = fwd_clk; } if(lane == 0) a.res[blockIdx.x] = rs; return; }      // (measurement: forward pass and best end cell only)
-	// ---- traceback: lane 0 walks, the wave keeps a tile of 64 nodes (records, in-edges, rows) in LDS ahead of it ----
+	// ---- traceback: the walk's state is uniform; the wave decides 64 places at a time (a tile) from a ring of nodes, row windows and in-edges in LDS ----
 	{
 		const bsa_poa_edge_t *gedges = a.edges + pg.first_edge;
 		uint32_t *ev = a.steps + pg.first_event;
@@ -1283,7 +1283,7 @@ static size_t poa_rows_ring_bytes(uint32_t bw, uint32_t R){ return (size_t)R * (
 static size_t poa_rows_front_bytes(uint32_t bw, uint32_t R){ return (poa_rows_ring_bytes(bw, R) + R * 8 + 15) & ~(size_t)15; }       // (the forward pass's part; the traceback's ring + POA_QW bytes take its place afterwards)
 static size_t poa_rows_qb_bytes(uint32_t bw, uint32_t max_slen){ return ((size_t)max_slen + poa_rows_cpl(bw) * 64 + 8 + 15) & ~(size_t)15; }
 // the row-at-a-time forward pass (poa_forward_rows): its scans need gapo <= 0 and gapo1 + gape1 <= gape1 <= gape2 <= 0 (the guard of
-// bsa_poa_graph_supported has the signs), and 64 ring rows + the query in LDS
+// bsa_poa_graph_supported has the signs), and its ring rows + the read's profile (or the traceback's ring) in LDS
 static bool poa_rows_supported(const bsa_rows_params_t *rp, int pw, uint32_t bw, uint32_t max_slen){
 	if(pw == 2 && rp->gape1 > rp->gape2) return false;
 	return std::max(poa_rows_front_bytes(bw, 16) + poa_rows_qb_bytes(bw, max_slen), poa_tile_bytes(bw) + POA_QW) <= POA_LDS_MAX;
