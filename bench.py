@@ -480,11 +480,11 @@ def main_poa_recorded(args):
                                % ("fixture" if fixture else "recorded", nwin, nreads, L, args.eps, nl, nprog_total, updates, merges, steps_total),
                    "shape": shape, "windows": nwin, "pairs_per_gpu": nwin, "bandwidth": 128, "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": "k_poa_wf<2, 2> (row-at-a-time forward pass + ring traceback)", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
+                     "kernel": "k_poa_wf<2, 2> (row-at-a-time forward pass, plain nodes in copies of their own + traceback in tiles)", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
                      "issue": issue_fractions(ent, kms_tot / nl),
                      "traffic_from": (ent or {}).get("source") if traffic else None,
-                     "note": "latency-bound, not HBM-bound: one wave per read, a graph node per trip (about 335 instructions, 4 clocks each for a lone wave: DESIGN section 4b); "
-                             "throughput grows with the windows in flight (14 KB of LDS per read: 11 reads per CU)"},
+                     "note": "not HBM-bound: one wave per read, a graph node per trip (about 180 instructions); a lone wave is bound by its own dependent latencies, thousands of "
+                             "windows in flight by VALU issue (DESIGN section 4b); 10 KB of LDS per read: 16 reads per CU"},
         "checks": {"best_end_cell_identical_all_programs": bool(ident), "programs": nprog_total},
         "cpu_baseline": cpub,
         "lockstep_end_to_end": e2e,
