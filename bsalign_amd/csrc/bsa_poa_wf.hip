@@ -885,8 +885,10 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 					const uint32_t ce = stop ? (uint32_t)__builtin_amdgcn_readlane((int)cat, L) : 9u;
 					if(L > 0){
 						const int n_was = n, x_was = x;
-						if(pe < 64){ n = t_top - (pe >> 2); x = t_x - (pe >> 2) + (pe & 3) + t_base(pe >> 2); Hs1 = __builtin_amdgcn_readlane(d_H, pe); }
-						else { const int last = __builtin_amdgcn_readlane(pos, L - 1); n = __builtin_amdgcn_readlane(d_w, last); x = __builtin_amdgcn_readlane(d_sx, last); Hs1 = __builtin_amdgcn_readlane(d_h, last); }
+						// (what the last step taken leads to -- not what the place it leads to holds: that lane may be one that could not be decided,
+						// its own cell outside the window kept of its row)
+						const int last = __builtin_amdgcn_readlane(pos, L - 1);
+						n = __builtin_amdgcn_readlane(d_w, last); x = __builtin_amdgcn_readlane(d_sx, last); Hs1 = __builtin_amdgcn_readlane(d_h, last);
 						nidx = n; Hs2 = 0;
 						// nodes gone down against columns gone left, in 1/256 per node
 						if(n_was - n >= 4) sig = (sig + min(max(((n_was - n) + (x - x_was)) * 256 / (n_was - n), 0), 224)) >> 1;
