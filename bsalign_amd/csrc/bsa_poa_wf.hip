@@ -28,6 +28,7 @@
 #include <type_traits>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 
 #define POA_NEAR   12      // predecessors at most this many nodes back are read from the LDS ring
 #define POA_DRAIN  8       // finished rows leave the ring in batches of this many
@@ -50,6 +51,7 @@ struct PoaArgs {
 	uint32_t bw, W, nl, R, ri_off, qn_off, nq_off;
 	int32_t mode, M, X, refbonus, O, E, Q, P, T;
 	int32_t c0, d, head_u0, xp;
+	int32_t win_shift;                                // test knob (BSA_POA_WIN_SHIFT): the traceback's row windows that many cells off their place, so that its fall-backs run
 };
 
 struct PoaNodeHead { uint32_t rpos, first_in, n_in, base, flags; };
@@ -740,7 +742,7 @@ __global__ void __launch_bounds__(64) k_poa_wf(const PoaArgs a){
 		// position it expects there, pinned to the read's two ends (bspoa.h:2168-2174), so the walker's cell runs along
 		// cell_of(x) = x - min(max(x - bw / 2, 0), slen - bw) -- down a cell a step near the ends, level in between -- plus whatever the
 		// walk has wandered off it so far; the column a node further down is passed at follows from the steps per node the walk has shown.
-		auto window_at = [&](int centre) -> int { return min(max((centre - POA_TW / 2) & ~3, 0), max(bw - POA_TW, 0)); };
+		auto window_at = [&](int centre) -> int { return min(max((centre + a.win_shift - POA_TW / 2) & ~3, 0), max(bw - POA_TW, 0)); };
 		auto cell_of = [&](int xx) -> int { return xx - min(max(xx - bw / 2, 0), max(slen - bw, 0)); };
 		int lo = max(0, n - (POA_TN - 1));                  // the ring holds nodes lo .. (the walker never goes up)
 		int elo, ehi;                                       // ... and edges elo .. ehi - 1
@@ -1365,6 +1367,7 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 		a.xp = (pw == 2) ? (a.Q - a.O) / (a.E - a.P) : 1;
 		const int type = a.mode & 3;
 		a.head_u0 = (type == BSA_MODE_OVERLAP) ? 0 : nt_max - nt_min;
+		{ const char *ws = bsa_env("BSA_POA_WIN_SHIFT"); a.win_shift = ws ? atoi(ws) : 0; }
 	}
 	const size_t lds = rows_fwd ? std::max((size_t)a.nq_off + poa_rows_qb_bytes(bw, max_slen), poa_tile_bytes(bw) + POA_QW) : (size_t)a.nq_off + POA_NQ * sizeof(bsa_poa_node_t);
 	void *stop = nullptr;

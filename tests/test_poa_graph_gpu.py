@@ -93,10 +93,15 @@ def test_many_programs_in_one_launch(ctx):
                 assert (int(r["maxscr"]), int(nodes[int(r["maxidx"])]["gnode"]), int(r["maxoff"])) == (pg["maxscr"], pg["maxidx"], pg["maxoff"])
 
 
-def test_fixture_of_the_references_own_walks(ctx):
+@pytest.mark.parametrize("shift", [0, 40, -40])
+def test_fixture_of_the_references_own_walks(ctx, shift, monkeypatch):
     """tests/golden/poa_graph.npz: the graph-form programs the binding built from the reference's graph, and the (node, x, bt) steps
     the REFERENCE's alignment2graph_bspoa took (recorded through oracle/ref_poa_harness.c with the test-only hook): the device's
-    best end cell, every step of its walk and the walk's end are the reference's.  All reads of a case in one launch."""
+    best end cell, every step of its walk and the walk's end are the reference's.  All reads of a case in one launch.
+    `shift`: the traceback's windows of the rows put that many cells off their place (BSA_POA_WIN_SHIFT), so that the places a tile
+    cannot decide, the steps taken one at a time and their reads from HBM carry the walk -- same steps."""
+    if shift:
+        monkeypatch.setenv("BSA_POA_WIN_SHIFT", str(shift))
     steps = 0
     for case in P.load_golden_graph():
         p = case["par"]
