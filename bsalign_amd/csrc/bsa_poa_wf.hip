@@ -1282,7 +1282,11 @@ static uint32_t poa_rows_cpl(uint32_t bw){ return bw <= 64 ? 1u : bw <= 128 ? 2u
 // cache invalidate: microseconds).  8 rows keep a read's LDS at the traceback's 10 KB -- 16 reads per CU, what a launch of thousands of
 // windows wants; a launch that cannot fill the CUs anyway takes 16 rows: in the deep graph of a window with 64 reads 2 % of the inputs lie
 // more than 7 nodes back, none more than 15.
-static uint32_t poa_rows_r(size_t nprogs){ return nprogs > 2048 ? 8u : 16u; }
+static uint32_t poa_rows_r(size_t nprogs){
+	const char *e = bsa_env("BSA_POA_FWD_RING");          // test knob: 2 / 4 / 8 / 16 ring rows (2: nearly every two-input node reads a row back from HBM)
+	if(e){ const int r = atoi(e); if(r == 2 || r == 4 || r == 8 || r == 16) return (uint32_t)r; }
+	return nprogs > 2048 ? 8u : 16u;
+}
 static size_t poa_rows_ring_bytes(uint32_t bw, uint32_t R){ return (size_t)R * (poa_rows_cpl(bw) * 64 + 2 * POA_ROWS_PAD) * 4; }
 static size_t poa_rows_front_bytes(uint32_t bw, uint32_t R){ return (poa_rows_ring_bytes(bw, R) + R * 8 + 15) & ~(size_t)15; }       // (the forward pass's part; the traceback's ring + POA_QW bytes take its place afterwards)
 static size_t poa_rows_qb_bytes(uint32_t bw, uint32_t max_slen){ return ((size_t)max_slen + poa_rows_cpl(bw) * 64 + 8 + 15) & ~(size_t)15; }

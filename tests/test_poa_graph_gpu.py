@@ -49,12 +49,15 @@ def _check_program(ctx, p, pg, want_trace=True):
             assert (int(r["fin_node"]), int(r["fin_x"])) == (int(fin[0]), int(fin[1]))
 
 
-@pytest.mark.parametrize("fwd", ["rows", "wf"])
+@pytest.mark.parametrize("fwd", ["rows", "wf", "rows-ring2", "rows-ring4"])
 def test_golden_programs_rows_best_cell_and_walk(ctx, fwd, monkeypatch):
     """both forward passes of k_poa_wf -- a row at a time (the default) and the anti-diagonal wavefront (BSA_POA_FWD=wf) -- against the
-    scalar statement, the reference's row hashes, its best end cell and the walk"""
+    scalar statement, the reference's row hashes, its best end cell and the walk.  `ring2` / `ring4`: the row-at-a-time pass with a ring of
+    two / four rows (BSA_POA_FWD_RING), so that inputs further back are read back from HBM -- the path a deep graph takes now and then"""
     if fwd == "wf":
         monkeypatch.setenv("BSA_POA_FWD", "wf")
+    if fwd.startswith("rows-ring"):
+        monkeypatch.setenv("BSA_POA_FWD_RING", fwd[len("rows-ring"):])
     n = 0
     for case in P.load_golden():
         for pg in case["programs"]:
