@@ -37,7 +37,7 @@
 #define POA_TN     32      // traceback: nodes in the ring (a power of two >= POA_TNEAR + 1 + the nodes per refill: 16, or 8 above 128 columns)
 #define POA_TILE   16      // ... nodes of a tile of decisions (four columns each: one lane per (node, column))
 #define POA_QW     128     // ... columns of the read kept (a power of two)
-#define POA_TW     64      // ... cells of a row kept per node (a window around the walk's path; a power of two, a multiple of 4)
+#define POA_TW     32      // ... cells of a row kept per node (a window around the walk's path; a power of two, a multiple of 4)
 #define POA_TNEAR  7       // ... predecessors at most this many nodes back are kept in the ring (0.3 % are further: read from HBM)
 #define POA_TE     64      // ... in-edges in the ring (a power of two), refilled half a ring at a time
 
