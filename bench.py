@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--poa-source", default="auto", choices=["auto", "synthetic", "recorded", "fixture"], help="poa workload: graph programs recorded from the reference's end_bspoa on "
                     "synthetic reads (needs oracle/_ref; the default when it is there), the programs the reference recorded into tests/golden/poa_graph.npz tiled over the windows "
                     "(fixture: the default without oracle/_ref), or synthetic row-task programs for the first form of the sweep (poa_synth)")
+    ap.add_argument("--poa-case", type=int, default=0, help="poa workload, fixture source: which case of tests/golden/poa_graph.npz (0: default parameters; 1, 2: global / extend; "
+                    "3: one-piece gaps; 4: linear gaps, bandwidth 32; 5: bandwidth 64; 6: bandwidth 256)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, count them over the process group and print {n_gpus}: "
                     "the launcher's own test (gloo when there is no GPU)")
@@ -354,7 +356,8 @@ def main_poa_recorded(args):
     ncores = min(ncores, q) if q else ncores
     if fixture:
         # the programs the reference recorded into tests/golden/poa_graph.npz (case 0: default parameters), every window the same six reads
-        case = P.load_golden_graph()[0]
+        cases = P.load_golden_graph()
+        case = cases[max(0, min(args.poa_case, len(cases) - 1))]
         pp = case["par"]
         nreads, L = len(case["reads"]), max(rc["slen"] for rc in case["reads"])
         rec = [dict(recs=case["reads"]) for _ in range(nwin)]
@@ -458,7 +461,9 @@ def main_poa_recorded(args):
         e2e = {"error": str(ex)}
     nl = len(launches)
     achieved = (balg / nl) / (kms_tot / nl / 1e3) / 1e9 if kms_tot > 0 else 0.0
-    shape = "poa-%s|n%d|reads%d|L%d" % ("fixture" if fixture else "recorded", nwin, nreads, L)
+    shape = "poa-%s|n%d|reads%d|L%d" % (("fixture%d" % args.poa_case if args.poa_case else "fixture") if fixture else "recorded", nwin, nreads, L)
+    pardesc = ("default POA parameters (overlap, bandwidth 128, 2-piece gaps)" if (not fixture or args.poa_case == 0) else
+               "mode %d, bandwidth %d, M %d X %d O %d E %d Q %d P %d" % (pp["alnmode"], pp["bandwidth"], pp["M"], pp["X"], pp["O"], pp["E"], pp["Q"], pp["P"]))
     ent = counters_for(shape, "k_poa_wf")
     traffic = traffic_of(ent)
     if fixture:
@@ -473,14 +478,15 @@ def main_poa_recorded(args):
         "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP (align_rd_bspoacore) + traceback (alignment2graph_bspoa) on recorded programs",
         "value": round(cells * args.steps / elapsed / 1e9, 3), "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 (exact image of the reference's i8 differences)",
-        "data": ("graph-form programs the reference's end_bspoa recorded into tests/golden/poa_graph.npz (case 0), every window the same %d reads" % nreads) if fixture else
+        "data": ("graph-form programs the reference's end_bspoa recorded into tests/golden/poa_graph.npz (case %d), every window the same %d reads" % (args.poa_case, nreads)) if fixture else
                 "graph-form programs recorded from the reference's end_bspoa (oracle/_ref, outside the timed region) on synthetic reads, seed %d" % SEED,
-        "config": {"workload": "poa-%s: %d POA windows x %d reads x %d bp (eps %.2f), default POA parameters (overlap, bandwidth 128, 2-piece gaps); a step = every read's "
-                               "sweep and traceback of every window, read r of all windows per launch (%d launches, %d programs, %.0f row updates + %.0f merges, %d traceback steps)"
-                               % ("fixture" if fixture else "recorded", nwin, nreads, L, args.eps, nl, nprog_total, updates, merges, steps_total),
-                   "shape": shape, "windows": nwin, "pairs_per_gpu": nwin, "bandwidth": 128, "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
+        "config": {"workload": ("poa-%s: %d POA windows x %d reads x %d bp (eps %.2f), " % ("fixture" if fixture else "recorded", nwin, nreads, L, args.eps)) + pardesc +
+                               ("; a step = every read's sweep and traceback of every window, read r of all windows per launch (%d launches, %d programs, %.0f row updates + %.0f merges, "
+                                "%d traceback steps)" % (nl, nprog_total, updates, merges, steps_total)),
+                   "shape": shape, "windows": nwin, "pairs_per_gpu": nwin, "bandwidth": int(pp["bandwidth"]), "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": "k_poa_wf<2, 2> (row-at-a-time forward pass, plain nodes in copies of their own + traceback in tiles)", "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
+                     "kernel": "k_poa_wf<%d, %d> (row-at-a-time forward pass, plain nodes in copies of their own + traceback in tiles)" % (
+                         2 if (pp["Q"] or pp["P"]) else 1 if pp["O"] else 0, 1 if int(pp["bandwidth"]) <= 64 else 2 if int(pp["bandwidth"]) <= 128 else 4), "kernel_ms_avg": round(kms_tot / nl, 3), "launches_per_step": nl, "algorithmic_bytes_per_launch": round(balg / nl, 1),
                      "issue": issue_fractions(ent, kms_tot / nl),
                      "traffic_from": (ent or {}).get("source") if traffic else None,
                      "note": "not HBM-bound: one wave per read, a graph node per trip (about 180 instructions); a lone wave is bound by its own dependent latencies, thousands of "
