@@ -92,8 +92,10 @@ def parse():
     ap.add_argument("--poa-case", type=int, default=0, help="poa workload, fixture source: which case of tests/golden/poa_graph.npz (0: default parameters; 1, 2: global / extend; "
                     "3: one-piece gaps; 4: linear gaps, bandwidth 32; 5: bandwidth 64; 6: bandwidth 256)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
-    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, count them over the process group and print {n_gpus}: "
-                    "the launcher's own test (gloo when there is no GPU)")
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, count them over the process group, run the shard exchange on a small synthetic "
+                    "batch and print {n_gpus, exchange}: the launcher's own test (gloo when there is no GPU)")
+    ap.add_argument("--no-secondary", action="store_true", help="default run only: do not measure the edit (C3) and POA (C4-shaped) workloads beside the headline one")
+    ap.add_argument("--no-exchange", action="store_true", help="skip the scatter / align / gather self-check of the shard exchange after the timed region")
     return ap.parse_args()
 
 
@@ -150,12 +152,95 @@ def init_ranks(args):
     return rank, seen, local, dist
 
 
+def exchange_selfcheck(dist, rank, world, dev, batch, bw, align=None, expect=None):
+    """The one exchange each way of SURVEY.md 8(e) on a real batch, timed: rank 0 scatters contiguous shards (bsalign_amd/shard.py: lengths as
+    broadcasts, shards packed by bsa_shard_pack, one grouped set of point-to-point messages), every rank produces its shard's records --
+    align(shard) -> (results [n, 10] int32, cigar words, offsets [n + 1] int64) on its GPU, or a deterministic stand-in derived from the shard's own
+    lengths when there is no GPU (launch check over gloo) --, rank 0 gathers them in pair order and compares with `expect` (its own results of the
+    whole batch).  -> dict for the JSON line (rank 0), None elsewhere.  With one rank the group calls degenerate to local copies."""
+    import torch
+    from bsalign_amd import shard
+    if dist is None:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        tdist.init_process_group("nccl" if dev.type == "cuda" else "gloo", rank=0, world_size=1, **({"device_id": dev} if dev.type == "cuda" else {}))
+        own = True
+        dist = tdist
+    else:
+        own = False
+    sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
+    sync(); dist.barrier(); sync()
+    t0 = time.perf_counter()
+    sh = shard.scatter_batch(batch if rank == 0 else None, bw, src=0, device=dev)
+    sync(); dist.barrier(); sync()
+    t1 = time.perf_counter()
+    n = len(sh["qlen"])
+    if align is not None:
+        res, cig, off = align(sh)
+    else:
+        # no GPU: records that only depend on the pair -- (global index, qlen, tlen, ...) and qlen % 7 + 1 words per pair
+        gi = np.arange(n, dtype=np.int64) + sh["first"]
+        r = np.zeros((n, 10), np.int32); r[:, 0] = gi; r[:, 1] = sh["qlen"]; r[:, 2] = sh["tlen"]
+        cnt = (sh["qlen"].astype(np.int64) % 7) + 1
+        offh = np.zeros(n + 1, np.int64); offh[1:] = np.cumsum(cnt)
+        words = (np.repeat(gi, cnt) * 16 + 1).astype(np.int32)
+        res, cig, off = torch.from_numpy(r).to(dev), torch.from_numpy(words).to(dev), torch.from_numpy(offh).to(dev)
+    sync(); dist.barrier(); sync()
+    t2 = time.perf_counter()
+    got = shard.gather_batch(res, cig, off, dst=0)
+    sync(); dist.barrier(); sync()
+    t3 = time.perf_counter()
+    out = None
+    if rank == 0:
+        gr, gw, go = got[0].cpu().numpy(), got[1].cpu().numpy().view(np.uint32), got[2].cpu().numpy()
+        if expect is not None:
+            er, ew, eo = expect
+            same = bool(np.array_equal(gr, er)) and bool(np.array_equal(go, eo)) and bool(np.array_equal(gw[: int(go[-1])], ew[: int(eo[-1])]))
+        else:
+            N = len(batch["qlen"])
+            cnt = (np.asarray(batch["qlen"]).astype(np.int64) % 7) + 1
+            eo = np.zeros(N + 1, np.int64); eo[1:] = np.cumsum(cnt)
+            same = gr.shape[0] == N and bool(np.array_equal(gr[:, 0], np.arange(N))) and bool(np.array_equal(gr[:, 1], np.asarray(batch["qlen"]).astype(np.int32))) \
+                and bool(np.array_equal(go, eo)) and bool(np.array_equal(gw, (np.repeat(np.arange(N, dtype=np.int64), cnt) * 16 + 1).astype(np.uint32)))
+        nbytes = int(np.asarray(batch["seqs"]).size)
+        out = {"pairs": int(len(batch["qlen"])), "ranks": world, "bounds": [int(b) for b in sh["bounds"]],
+               "scatter_ms": round((t1 - t0) * 1e3, 2), "align_ms": round((t2 - t1) * 1e3, 2), "gather_ms": round((t3 - t2) * 1e3, 2),
+               "round_trip_ms": round((t1 - t0 + t3 - t2) * 1e3, 2), "input_MB": round(nbytes / 1e6, 1), "result_MB": round((gr.nbytes + gw.nbytes) / 1e6, 1),
+               "backend": dist.get_backend(), "gathered_identical_to_rank0_whole_batch": same,
+               "what": "rank 0 scatters the batch (bsalign_amd/shard.py: bsa_shard_pack + grouped point-to-point sends), every rank %s, rank 0 gathers "
+                       "records + CIGAR words in pair order" % ("aligns its shard" if align is not None else "fills stand-in records (no GPU)")}
+    if own:
+        dist.destroy_process_group()
+    return out
+
+
 def launch_check(args):
     rank, world, local, dist = init_ranks(args)
     if dist is not None:
         dist.barrier()
+    import torch
+    have_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if have_gpu else torch.device("cpu")
+    ex = None
+    if dist is not None and not args.no_exchange:
+        # a small batch of synthetic pairs with ragged lengths through the exchange (stand-in records: no kernels run here)
+        batch = None
+        if rank == 0:
+            rng = np.random.default_rng(SEED)
+            N = 3000
+            tl = rng.integers(200, 1200, N).astype(np.uint32); ql = (tl.astype(np.int64) + rng.integers(-50, 50, N)).astype(np.uint32)
+            to = np.zeros(N, np.uint64); qo = np.zeros(N, np.uint64); acc = 0
+            for k in range(N):
+                to[k] = acc; acc += int(tl[k]); qo[k] = acc; acc += int(ql[k])
+            batch = dict(seqs=rng.integers(0, 4, acc).astype(np.uint8), qoff=qo, qlen=ql, toff=to, tlen=tl)
+        ex = exchange_selfcheck(dist, rank, world, dev, batch, 128)
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": dist.get_backend() if dist is not None else None}), flush=True)
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_counted": world, "backend": dist.get_backend() if dist is not None else None, "exchange": ex}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -382,7 +467,7 @@ def main_poa_recorded(args):
     launches, cells, balg, nprog_total = [], 0.0, 0.0, 0
     for (r, bw), rcs in sorted(groups.items()):
         sp = B.SweepParams()
-        sp.rows = B.RowsParams(pp["alnmode"] | (0x200 if os.environ.get("BSA_BENCH_POA_FWD_ONLY") else 0), bw, pp["M"], pp["X"], pp["refbonus"], pp["O"], pp["E"], pp["Q"], pp["P"])
+        sp.rows = B.RowsParams(pp["alnmode"], bw, pp["M"], pp["X"], pp["refbonus"], pp["O"], pp["E"], pp["Q"], pp["P"])
         sp.T = pp["T"]
         blk = lib.bsa_rows_block_bytes(bw, pp["O"], pp["E"], pp["Q"], pp["P"])
         progs = np.zeros(len(rcs), B.POA_PROG_DTYPE)
@@ -475,12 +560,14 @@ def main_poa_recorded(args):
                                    "= %.4f GCUPS per core; the whole end_bspoa of all windows: %.2f s = %.1f windows/s" % (nwin, ncores, core_seconds, updates * 128 / core_seconds / 1e9 if core_seconds > 0 else 0, t_ref, nwin / t_ref),
                          "end_bspoa_windows_per_s": round(nwin / t_ref, 2), "threads": ncores}
     line = {
-        "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP (align_rd_bspoacore) + traceback (alignment2graph_bspoa) on recorded programs",
+        "metric": "GCUPS (giga band-cell updates / s), POA seq->graph DP (align_rd_bspoacore) + traceback (alignment2graph_bspoa) on " +
+                  ("the committed fixture programs, tiled: every window the same reads" if fixture else "recorded programs"),
         "value": round(cells * args.steps / elapsed / 1e9, 3), "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 (exact image of the reference's i8 differences)",
         "data": ("graph-form programs the reference's end_bspoa recorded into tests/golden/poa_graph.npz (case %d), every window the same %d reads" % (args.poa_case, nreads)) if fixture else
                 "graph-form programs recorded from the reference's end_bspoa (oracle/_ref, outside the timed region) on synthetic reads, seed %d" % SEED,
-        "config": {"workload": ("poa-%s: %d POA windows x %d reads x %d bp (eps %.2f), " % ("fixture" if fixture else "recorded", nwin, nreads, L, args.eps)) + pardesc +
+        "config": {"workload": (("poa-fixture: %d POA windows (identical, tiled) x %d reads x %d bp, " % (nwin, nreads, L)) if fixture else
+                                ("poa-recorded: %d POA windows x %d reads x %d bp (eps %.2f), " % (nwin, nreads, L, args.eps))) + pardesc +
                                ("; a step = every read's sweep and traceback of every window, read r of all windows per launch (%d launches, %d programs, %.0f row updates + %.0f merges, "
                                 "%d traceback steps)" % (nl, nprog_total, updates, merges, steps_total)),
                    "shape": shape, "windows": nwin, "pairs_per_gpu": nwin, "bandwidth": int(pp["bandwidth"]), "reads": nreads, "length": L, "sweep_windows_per_s": round(nwin * args.steps / elapsed, 1)},
@@ -678,11 +765,14 @@ def main():
     toff = np.arange(n, dtype=np.uint64) * np.uint64(stride)
     qoff = (np.arange(n, dtype=np.uint64) + np.uint64(n)) * np.uint64(stride)
 
-    if args.workload == "align8":
-        par = B.make_params(mode, bw, *sc)
-        plan = B.AlignPlan(ctx, qoff, qlen, toff, tlen, par)
-    else:
-        plan = B.EditPlan(ctx, qoff, qlen, toff, tlen, mode, bw)
+    par = B.make_params(mode, bw, *sc) if args.workload == "align8" else None
+
+    def make_plan(qo, ql, to, tl):
+        return B.AlignPlan(ctx, qo, ql, to, tl, par) if args.workload == "align8" else B.EditPlan(ctx, qo, ql, to, tl, mode, bw)
+
+    tp0 = time.perf_counter()
+    plan = make_plan(qoff, qlen, toff, tlen)
+    plan_ms = (time.perf_counter() - tp0) * 1e3          # host planning of the batch (slot layout, chunking, kernel choice): outside the timed region, reported in config.plan_ms
     cells = plan.cells()
     cig_cap = int(n) * max(L // 4, 64)
     d_out = torch.zeros(n * 10, dtype=torch.int32, device=dev)
@@ -708,8 +798,15 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    per_rank = [round(cells * args.steps / elapsed / 1e9, 3)]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, mine)
+        allc = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allc, torch.tensor([float(cells)], dtype=torch.float64, device=dev))
+        per_rank = [round(float(c) * args.steps / float(t) / 1e9, 3) for c, t in zip(allc.cpu().tolist(), allt.cpu().tolist())]
+        tt = mine.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         barrier()
@@ -722,6 +819,46 @@ def main():
     status = d_st.cpu().numpy()
     ncig = int(off[n])
     nbad = int((status != 0).sum())
+
+    # ---- outside the timed region: what a caller with HOST buffers pays (PCIe-inclusive, never `value`), and the shard exchange on this very batch
+    pcie_ms = None
+    exchange = None
+    host = None
+    if not args.no_exchange and args.cpu_pairs >= 0:
+        plan.close()
+        plan = None
+        if rank == 0:
+            host = dict(seqs=d_seqs.cpu().numpy(), qoff=qoff, qlen=qlen, toff=toff, tlen=tlen)
+            cig_all = d_cig[:ncig].cpu().numpy().view(np.uint32)
+            # one host-pointer call of the whole batch: plan + upload + the same kernels + download
+            h_out = np.zeros((n, 10), np.int32); h_cig = np.zeros(cig_cap, np.uint32); h_off = np.zeros(n + 1, np.uint64); h_st = np.zeros(n, np.uint32)
+            fn = lib.bsa_align_batch if args.workload == "align8" else lib.bsa_edit_batch
+            hp = par if args.workload == "align8" else B.EditParams(mode, bw)
+            tq0 = time.perf_counter()
+            rcb = fn(ctx.h, host["seqs"].ctypes.data_as(C.POINTER(C.c_uint8)), host["seqs"].size, qoff.ctypes.data_as(C.POINTER(C.c_uint64)), qlen.ctypes.data_as(C.POINTER(C.c_uint32)),
+                     toff.ctypes.data_as(C.POINTER(C.c_uint64)), tlen.ctypes.data_as(C.POINTER(C.c_uint32)), n, C.byref(hp), h_out.ctypes.data_as(C.c_void_p),
+                     h_cig.ctypes.data_as(C.POINTER(C.c_uint32)), cig_cap, h_off.ctypes.data_as(C.POINTER(C.c_uint64)), h_st.ctypes.data_as(C.POINTER(C.c_uint32)))
+            pcie_ms = (time.perf_counter() - tq0) * 1e3 if rcb == 0 else None
+            pcie_same = rcb == 0 and bool(np.array_equal(h_out, out)) and bool(np.array_equal(h_off.astype(np.int64), off)) and bool(np.array_equal(h_cig[:ncig], cig_all))
+            del h_cig
+
+        def align_shard(sh):
+            m = len(sh["qlen"])
+            o = torch.zeros(max(m, 1) * 10, dtype=torch.int32, device=dev)
+            f = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+            stt = torch.zeros(max(m, 1), dtype=torch.int32, device=dev)
+            if m:
+                pl = make_plan(sh["qoff"], sh["qlen"], sh["toff"], sh["tlen"])
+                pl.run(sh["seqs"], o, d_cig, f, stt)
+                ctx.sync()
+                pl.close()
+            return o.view(-1, 10)[:m], d_cig, f
+
+        exchange = exchange_selfcheck(dist, rank, world, dev, host, bw if bw else 128, align=align_shard,
+                                      expect=(out, cig_all, off) if rank == 0 else None)
+        if rank == 0:
+            exchange["host_pointer_call_identical"] = pcie_same
+        host = None
 
     if rank == 0:
         import support as S
@@ -760,7 +897,12 @@ def main():
             "data": "synthetic (splitmix64 pairs, eps=%.2f, sub:ins:del=23:31:46, seed %d)" % (args.eps, SEED),
             "config": {"workload": "%s: %d pairs/GPU x %d bp, mode %s, bandwidth %d, scoring M,X,O,E,Q,P=%s" % (args.workload, n, L, args.mode, bw, args.scoring),
                        "shape": shape, "pairs_per_gpu": n, "length": L, "bandwidth": bw, "parallelism": "pairs sharded across %d GPU(s), no data-path collective" % world,
-                       "timed": "stage + forward + traceback + CIGAR compaction on device-resident inputs; plan creation (host planning, slot layout) and PCIe are outside the timed region"},
+                       "timed": "stage + forward + traceback + CIGAR compaction on device-resident inputs; plan creation (host planning, slot layout) and PCIe are outside the timed region",
+                       "plan_ms": round(plan_ms, 2),
+                       "pcie_inclusive_ms": round(pcie_ms, 2) if pcie_ms is not None else None,
+                       "pcie_inclusive_what": "ONE host-pointer call (bsa_%s_batch) of the same batch on rank 0: plan + pageable upload of the sequences + the same kernels + download of records and CIGAR words; "
+                                              "never `value`" % ("align" if args.workload == "align8" else "edit"),
+                       "per_rank_gcups": per_rank, "ranks_counted": world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": dname, "kernel_ms_avg": round(dms, 3), "launches_per_step": dlaunch,
@@ -772,13 +914,44 @@ def main():
                                           "launches_per_step": klaunch if dom_trace else tlaunch}},
             "checks": {"pairs_flagged": nbad, "cigar_words": ncig, "oracle_identical_first8": ident},
         }
+        if exchange is not None:
+            line["exchange"] = exchange
         if world == 1 and args.cpu_pairs >= 0:
             line["cpu_baseline"] = cpu_baseline(args, L, bw, sc, mode)
-        print(json.dumps(line), flush=True)
-    plan.close()
+    if plan is not None:
+        plan.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        default_run = (world == 1 and args.workload == "align8" and not args.pairs and not args.length and not args.bw and args.mode == "global"
+                       and args.scoring == "2,-6,-3,-2,0,0" and args.cpu_pairs >= 0 and not args.no_secondary and not os.environ.get("BSA_BENCH_NO_SECONDARY"))
+        if default_run:
+            # the other two configurations BASELINE.json names (C3, C4-shaped windows) in the same run, under the same clock: the device is free again here
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_lines(args)
+        print(json.dumps(line), flush=True)
+
+
+def secondary_lines(args):
+    """`bench.py` with no workload flags also measures the edit path (C3: 16384 x 100 kbp, bandwidth 256) and the POA's sweep + walk (256 windows x 12 reads x
+    1.5 kbp: programs recorded from the reference's end_bspoa where oracle/_ref exists, else the committed fixture programs) -- each as a run of this very script
+    with its own steps, roofline and cpu_baseline, its JSON line embedded under "secondary"."""
+    import subprocess
+    out = []
+    for extra in (["--workload", "edit", "--steps", "3", "--warmup", "1", "--no-exchange"],
+                  ["--workload", "poa", "--pairs", "256", "--steps", "5", "--warmup", "1"]):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra, capture_output=True, text=True, timeout=900)
+            ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
+            d = json.loads(ln[-1]) if ln else {"error": "no JSON line", "rc": r.returncode, "stderr_tail": r.stderr[-400:]}
+        except Exception as ex:
+            d = {"error": str(ex)}
+        d["argv"] = " ".join(extra)
+        d["wall_s"] = round(time.perf_counter() - t0, 1)
+        out.append(d)
+    return out
 
 
 if __name__ == "__main__":

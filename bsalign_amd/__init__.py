@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSA_LIB_PATH") or os.path.join(_HERE, "libbsalign_hip.so")      # BSA_LIB_PATH: development builds
 
 MODE_GLOBAL, MODE_OVERLAP, MODE_EXTEND = 0, 1, 2
-ST_BAD_BASE, ST_EMPTY, ST_TRACE = 1, 2, 4
+ST_BAD_BASE, ST_EMPTY, ST_TRACE, ST_DEVICE = 1, 2, 4, 8
 
 E_NAMES = {0: "OK", -1: "BSA_E_NODEVICE", -2: "BSA_E_ARG", -3: "BSA_E_NOMEM", -4: "BSA_E_HIP",
            -5: "BSA_E_CIGAR_CAP", -6: "BSA_E_UNSUPPORTED"}

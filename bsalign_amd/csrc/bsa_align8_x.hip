@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
 // the band position and its pending move), runs the rows and hands the state on.  The launch then ends within one segment of the
 // ideal.  ctl[0] = next item, ctl[16 + g] = segments of group g that are done (release / acquire at agent scope: the next segment
 // usually runs on another CU).  An item only ever waits for an item that was handed out before it, i.e. one that is running.
-struct XQArgs { uint32_t *ctl; uint32_t *state; uint32_t ngroups, nseg, seg_rows; };
+struct XQArgs { uint32_t *ctl; uint32_t *state; uint32_t ngroups, nseg, seg_rows, spin_cap; };          // ctl[0]: next ticket, ctl[1]: some wave gave up waiting, ctl[16 + g]: segments of group g done
 template<int W, int L, int PW, bool DO2 = false, int WPS = 3>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPS))) k_align8_fwd_xq(const Align8Args a, const XQArgs q){
 	// one item per wave (a block is a wave: the dispatcher refills a wave slot the moment it is free); the ticket, not the block
@@ -863,13 +863,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPS))) 
 	const uint32_t s = id / q.ngroups, g = id - s * q.ngroups;
 	uint32_t *done = q.ctl + 16u + g;
 	if(s != 0u){
-		if(threadIdx.x == 0u){ while(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s) __builtin_amdgcn_s_sleep(16); }
+		// BOUNDED wait (an item's predecessor was handed out earlier, i.e. is running: in a healthy launch this loop hardly ever turns).  Should the
+		// predecessor never arrive -- a fault in its wave, a future change of the ticket order -- the wave gives up after about two seconds
+		// (2^22 turns of s_sleep 16 = 1024 cycles), raises q.ctl[1] and flags its pairs BSA_ST_DEVICE instead of hanging the device: flagged pairs
+		// are skipped by every later segment and by the traceback (zeroed result), the plan's run returns BSA_E_HIP.
+		uint32_t gaveup = 0;
+		if(threadIdx.x == 0u){
+			uint32_t turns = 0;
+			while(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s){
+				__builtin_amdgcn_s_sleep(16);
+				if(++turns >= q.spin_cap || ((turns & 1023u) == 0u && __hip_atomic_load(q.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)){ gaveup = 1; break; }
+			}
+		}
+		gaveup = (uint32_t)__builtin_amdgcn_readfirstlane((int)gaveup);
+		if(gaveup){
+			const uint32_t pg = (g * 64u + threadIdx.x) / (uint32_t)L;
+			if((threadIdx.x & (uint32_t)(L - 1)) == 0u && pg < a.count) atomicOr(&a.status[a.order[a.first + pg]], BSA_ST_DEVICE);
+			if(threadIdx.x == 0u){
+				atomicOr(q.ctl + 1, 1u);
+				__hip_atomic_fetch_max(done, s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // successors go on (and skip the flagged pairs)
+			}
+			return;
+		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	}
 	x_forward<W, L, PW, false, 1, DO2>(a, a.first, a.count, g * 64u, s * q.seg_rows, (s + 1u) * q.seg_rows, q.state + (size_t)g * (XS_WORDS(W, PW) * 64u));
 	if(s + 1u < q.nseg){
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the state's write-through stores have arrived
-		if(threadIdx.x == 0u) __hip_atomic_store(done, s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if(threadIdx.x == 0u) __hip_atomic_fetch_max(done, s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (max: a successor that gave up may have written s + 2)
 	}
 }
 static int x_cus(){
@@ -906,6 +927,8 @@ static bool x_launch_xq(const Align8Args &a, hipStream_t st, hipError_t &err){
 	nseg = std::max(1u, (a.max_tlen + seg_rows - 1u) / seg_rows);
 	XQArgs q;
 	q.ctl = a.xq; q.state = (uint32_t*)((uint8_t*)a.xq + ctl_bytes); q.ngroups = groups; q.nseg = nseg; q.seg_rows = seg_rows;
+	q.spin_cap = 1u << 22;
+	if(const char *sc = bsa_env("BSA_ALIGN8_XQ_SPIN_CAP")){ const long v = atol(sc); if(v >= 1) q.spin_cap = (uint32_t)v; }          // (test hook: a cap of a few turns makes hand-over waits give up)
 	err = hipMemsetAsync(a.xq, 0, ctl_bytes, st);
 	if(err != hipSuccess) return true;
 	hipLaunchKernelGGL((k_align8_fwd_xq<W, L, PW, DO2, WPS>), dim3(groups * nseg), dim3(64), 0, st, a, q);

@@ -75,7 +75,6 @@ namespace {
 typedef std::unordered_map<std::string, std::string> EnvMap;
 std::mutex g_env_m;
 std::atomic<const EnvMap*> g_env_cur{nullptr};
-std::vector<std::unique_ptr<EnvMap>> g_env_all;
 }
 extern "C" void bsa_env_reload(void){
 	std::unique_ptr<EnvMap> m(new EnvMap());
@@ -85,8 +84,9 @@ extern "C" void bsa_env_reload(void){
 		if(eq) m->emplace(std::string(*e, (size_t)(eq - *e)), std::string(eq + 1));
 	}
 	std::lock_guard<std::mutex> lk(g_env_m);
-	g_env_cur.store(m.get(), std::memory_order_release);
-	g_env_all.push_back(std::move(m));
+	// deliberately leaked: no owner whose destructor runs at process exit, so a thread (the POA dispatcher) that reads the
+	// environment while the process is going down never sees freed memory
+	g_env_cur.store(m.release(), std::memory_order_release);
 }
 const char *bsa_env(const char *name){
 	const EnvMap *m = g_env_cur.load(std::memory_order_acquire);
@@ -1017,6 +1017,7 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	}
 	bsa_align_plan_destroy(p);
 	if(rc != BSA_OK || !codes) return rc;
+	for(size_t k = 0; k < n; k++) if(st[k] & BSA_ST_DEVICE){ c->err = "forward pass: a row-segment hand-over timed out (BSA_ST_DEVICE)"; return BSA_E_HIP; }
 	// ---- hand-over: pairs the compact traceback could not decide go through the literal kernels, so that a flag that
 	// survives means what it means for the reference (its own traceback does not terminate there)
 	std::vector<size_t> idx;
@@ -1031,8 +1032,19 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 		const int pwk = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)width);
 		return bsa_align8_gen_lds(width, pwk, bw_req ? 2u : 1u) <= 160 * 1024;
 	};
-	for(size_t k = 0; k < n; k++) if(((st[k] & BSA_ST_TRACE) || (every > 0 && k % (size_t)every == 0 && st[k] == 0)) && literal_can_take(k)) idx.push_back(k);
-	if(idx.empty()) return BSA_OK;
+	size_t left_flagged = 0;                           // undecided pairs the literal kernels cannot take: they keep BSA_ST_TRACE and a zeroed result
+	for(size_t k = 0; k < n; k++){
+		const bool want = (st[k] & BSA_ST_TRACE) || (every > 0 && k % (size_t)every == 0 && st[k] == 0);
+		if(!want) continue;
+		if(literal_can_take(k)) idx.push_back(k);
+		else if(st[k] & BSA_ST_TRACE) left_flagged ++;
+	}
+	// a caller that passed no status array cannot see a flag: undecided pairs are an error for it, never a silent zeroed result
+	auto finish = [&](size_t still_flagged) -> int {
+		if(status == nullptr && still_flagged){ c->err = "pairs left undecided (BSA_ST_TRACE) and no status array to report them in"; return BSA_E_UNSUPPORTED; }
+		return BSA_OK;
+	};
+	if(idx.empty()) return finish(left_flagged);
 	const size_t m = idx.size();
 	if(timing) fprintf(stderr, "[bsa_align_batch] %zu pairs handed over to the literal kernels\n", m);
 	std::vector<uint64_t> sq(m), stt(m), soff(m + 1);
@@ -1047,9 +1059,10 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	rc = bsa_align_batch(c, seqs, seqs_bytes, sq.data(), sql.data(), stt.data(), stl.data(), m, &lp, sout.data(),
 		cigar ? scig.data() : nullptr, scap, (cigar && cigar_off) ? soff.data() : nullptr, sst.data());
 	c->fwd_name = keep_fwd; c->trace_name = keep_trace;
-	if(rc == BSA_E_UNSUPPORTED) return BSA_OK;          // (the pairs keep BSA_ST_TRACE and their zeroed results)
+	// (literal_can_take filtered what the literal kernels decline, so BSA_E_UNSUPPORTED here is a real error of the re-run, not a pair
+	// to leave flagged: it is returned like any other)
 	if(rc != BSA_OK) return rc;
-	for(size_t k = 0; k < m; k++){ out[idx[k]] = sout[k]; st[idx[k]] = sst[k]; }
+	for(size_t k = 0; k < m; k++){ out[idx[k]] = sout[k]; st[idx[k]] = sst[k]; if(sst[k] & BSA_ST_TRACE) left_flagged ++; }
 	if(cigar && cigar_off){
 		// splice the re-run pairs' CIGARs into the arena (the compact pass left them empty or, in the debug hook, filled)
 		std::vector<uint32_t> merged;
@@ -1066,7 +1079,7 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 		if(merged.size() > cigar_cap_words){ c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
 		if(!merged.empty()) memcpy(cigar, merged.data(), merged.size() * 4);
 	}
-	return BSA_OK;
+	return finish(left_flagged);
 }
 
 // debug / test hook: copy the stored row records of `pair` to host.  Only meaningful right after a single-chunk run.

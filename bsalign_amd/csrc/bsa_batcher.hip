@@ -93,12 +93,13 @@ struct Engine {
 	hipEvent_t fin = nullptr;           // blocking-sync event: the dispatcher sleeps while the device works, the CPUs belong to the windows
 	uint64_t batches = 0, launches = 0, programs = 0, tasks = 0, bytes_up = 0, bytes_down = 0;
 	double device_ms = 0, wall_ms = 0, pack_ms = 0, devlock_ms = 0;
+	uint64_t pub[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // what bsa_sweep_batcher_stats reports: copied from the counters above under the batcher's mutex after every batch (the counters themselves are the dispatcher's own)
 	~Engine(){ if(fin) (void)hipEventDestroy(fin); }
 };
 struct bsa_sweep_batcher {
 	Engine eng;
 	std::mutex m;                         // pending programs, `active`, completion flags, download buffers
-	std::condition_variable cv_work, cv_buf;        // the dispatcher's: programs are pending / a download buffer has been given back
+	std::condition_variable cv_work;                // the dispatcher's one condition: programs are pending OR a download buffer has been given back (two variables let new graph programs wait behind a rows reader)
 	uint32_t active = 0;
 	std::vector<Sub> pend;
 	std::vector<SubG> pendg;
@@ -362,11 +363,11 @@ static void dispatcher(bsa_sweep_batcher *bb){
 			for(;;){
 				for(int k = 0; k < BSA_BATCH_OUTBUFS; k++) if(e->gout[k].outstanding == 0){ ob = k; break; }
 				if(ob >= 0) break;
-				bb->cv_buf.wait(lk);
+				bb->cv_work.wait(lk);
 			}
 			e->gout[ob].outstanding = (int)tg.size();
 		}
-		if(tg.empty() && tr.empty()){ bb->cv_buf.wait(lk); continue; }       // (only rows programs, and the staging is still being read)
+		if(tg.empty() && tr.empty()){ bb->cv_work.wait(lk); continue; }       // (only rows programs, and the staging is still being read)
 		e->rows_outstanding += (int)tr.size();
 		lk.unlock();
 		const auto w0 = std::chrono::steady_clock::now();
@@ -375,6 +376,8 @@ static void dispatcher(bsa_sweep_batcher *bb){
 		e->batches++;
 		e->wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
 		lk.lock();
+		e->pub[0] = e->batches; e->pub[1] = e->launches; e->pub[2] = e->programs; e->pub[3] = e->tasks; e->pub[4] = e->bytes_up; e->pub[5] = e->bytes_down;
+		e->pub[6] = (uint64_t)(e->device_ms * 1000.0); e->pub[7] = (uint64_t)(e->wall_ms * 1000.0);
 		for(SubG &s : tg){ *s.done = true; s.cv->notify_one(); }
 		for(Sub &s : tr){ *s.done = true; s.cv->notify_one(); }
 	}
@@ -432,7 +435,7 @@ extern "C" int bsa_sweep_batcher_submit(void *vb, const bsa_row_task_t *tasks, s
 	if(rc == BSA_OK && rows_out && src) memcpy(rows_out, src, nbytes);
 	bool last;
 	{ std::lock_guard<std::mutex> lk(bb->m); last = --bb->eng.rows_outstanding == 0; }
-	if(last){ bb->cv_buf.notify_one(); bb->cv_work.notify_one(); }
+	if(last) bb->cv_work.notify_one();
 	return rc;
 }
 
@@ -473,7 +476,7 @@ extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *node
 	if(ob >= 0){
 		bool last;
 		{ std::lock_guard<std::mutex> lk(bb->m); last = --bb->eng.gout[ob].outstanding == 0; }
-		if(last) bb->cv_buf.notify_one();            // (the dispatcher may be waiting for a free download buffer)
+		if(last) bb->cv_work.notify_one();            // (the dispatcher may be waiting for a free download buffer)
 	}
 	return rc;
 }
@@ -482,7 +485,5 @@ extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *node
 extern "C" void bsa_sweep_batcher_stats(bsa_sweep_batcher_t *bb, uint64_t out[8]){
 	if(!bb || !out) return;
 	std::lock_guard<std::mutex> lk(bb->m);
-	const Engine *b = &bb->eng;
-	out[0] = b->batches; out[1] = b->launches; out[2] = b->programs; out[3] = b->tasks; out[4] = b->bytes_up; out[5] = b->bytes_down;
-	out[6] = (uint64_t)(b->device_ms * 1000.0); out[7] = (uint64_t)(b->wall_ms * 1000.0);
+	for(int k = 0; k < 8; k++) out[k] = bb->eng.pub[k];
 }

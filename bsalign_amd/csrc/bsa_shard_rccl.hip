@@ -101,6 +101,7 @@ extern "C" int bsa_shard_unique_id(uint8_t id[128]){
 	return BSA_OK;
 }
 
+extern "C" void bsa_shard_comm_destroy(bsa_shard_comm_t *c);
 extern "C" int bsa_shard_comm_create(bsa_ctx_t *ctx, int rank, int nranks, const uint8_t id[128], bsa_shard_comm_t **out){
 	const bool shm = want_shm();
 	if((!ctx && !shm) || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id)) return BSA_E_ARG;
@@ -124,6 +125,8 @@ extern "C" int bsa_shard_comm_create(bsa_ctx_t *ctx, int rank, int nranks, const
 			c->wire = new RcclTransport(comm, st, nranks);
 		}
 	}
+	// the status words of agree(): allocated here so that agreeing on an error can never itself fail on one rank alone
+	if(nranks > 1 && !c->b_words.need(c->space, 8 * ((size_t)nranks + 1))){ bsa_shard_comm_destroy(c); return BSA_E_NOMEM; }
 	*out = c;
 	return BSA_OK;
 }
@@ -150,18 +153,24 @@ static void cut(const uint32_t *tlen, size_t n, uint32_t bw, int nranks, std::ve
 }
 
 #define TRY(x) do { const int _rc = (x); if(_rc != BSA_OK) return _rc; } while(0)
+// inside a group_begin / group_end section: remember the first error, post nothing more, but ALWAYS reach group_end (an RCCL group left
+// open keeps every peer blocked in its receive); GEND closes the group and returns what was collected
+#define GTRY(x) do { if(_grc == BSA_OK) _grc = (x); } while(0)
+#define GEND() do { const int _erc = c->wire->group_end(); if(_grc != BSA_OK) return _grc; if(_erc != BSA_OK) return _erc; } while(0)
 
 // every rank contributes a status word; all learn all of them.  Returns the first non-zero one in rank order (0: everybody can go on).
 static int agree(bsa_shard_comm *c, int mine, int *agreed){
 	*agreed = mine;
 	if(c->nranks == 1) return BSA_OK;
 	const size_t nr = (size_t)c->nranks;
-	if(!c->b_words.need(c->space, 8 * (nr + 1))) return BSA_E_NOMEM;          // (a failure HERE is not agreed: the buffer is 8 bytes a rank)
+	if(!c->b_words.p) return BSA_E_NOMEM;                  // (allocated by bsa_shard_comm_create, 8 bytes a rank: cannot fail here)
 	uint8_t *w = (uint8_t*)c->b_words.p;
-	const uint64_t v = (uint64_t)(uint32_t)mine;
+	uint64_t v = (uint64_t)(uint32_t)mine;
 	std::vector<uint64_t> all(nr);
-	TRY(c->space->to_space(w + 8 * nr, &v, 8));
+	// a rank whose own word cannot be staged still takes part in the collective -- the others must not hang in it -- and then reports
+	const int staged = c->space->to_space(w + 8 * nr, &v, 8);
 	TRY(c->wire->allgather(w + 8 * nr, w, 8));
+	if(staged != BSA_OK) return staged;
 	TRY(c->space->to_host(all.data(), w, 8 * nr));
 	TRY(c->space->sync());
 	*agreed = BSA_OK;
@@ -233,8 +242,9 @@ extern "C" int bsa_shard_scatter(bsa_shard_comm_t *c, int root, const uint8_t *s
 		TRY(sp->within(c->b_blob.p, (const uint8_t*)c->b_stage.p + soff[root], soff[root + 1] - soff[root]));
 		if(c->nranks > 1){
 			TRY(c->wire->group_begin());
-			for(int k = 0; k < c->nranks; k++) if(k != root && soff[k + 1] > soff[k]) TRY(c->wire->send((const uint8_t*)c->b_stage.p + soff[k], soff[k + 1] - soff[k], k));
-			TRY(c->wire->group_end());
+			int _grc = BSA_OK;
+			for(int k = 0; k < c->nranks; k++) if(k != root && soff[k + 1] > soff[k]) GTRY(c->wire->send((const uint8_t*)c->b_stage.p + soff[k], soff[k + 1] - soff[k], k));
+			GEND();
 		}
 		TRY(sp->sync());
 	} else if(acc){          // (acc == the root's soff[rank + 1] - soff[rank]: both sides derive it from the same lengths)
@@ -284,9 +294,10 @@ extern "C" int bsa_shard_gather(bsa_shard_comm_t *c, int root, const bsa_result_
 	if(count) TRY(sp->to_space(c->b_cnt.p, cnt.data(), 8 * count));
 	if(!isroot){
 		TRY(c->wire->group_begin());
-		if(count){ TRY(c->wire->send(d_out, count * sizeof(bsa_result_t), root)); TRY(c->wire->send(c->b_cnt.p, 8 * count, root)); }
-		if(nwords) TRY(c->wire->send(d_cigar, nwords * 4, root));
-		TRY(c->wire->group_end());
+		int _grc = BSA_OK;
+		if(count){ GTRY(c->wire->send(d_out, count * sizeof(bsa_result_t), root)); GTRY(c->wire->send(c->b_cnt.p, 8 * count, root)); }
+		if(nwords) GTRY(c->wire->send(d_cigar, nwords * 4, root));
+		GEND();
 		TRY(sp->sync());
 		return BSA_OK;
 	}
@@ -298,13 +309,14 @@ extern "C" int bsa_shard_gather(bsa_shard_comm_t *c, int root, const bsa_result_
 	}
 	if(c->nranks > 1){
 		TRY(c->wire->group_begin());
+		int _grc = BSA_OK;
 		for(int k = 0; k < c->nranks; k++){
 			if(k == root) continue;
 			const size_t ck = (size_t)sizes[3 * k], wk = (size_t)sizes[3 * k + 1];
-			if(ck){ TRY(c->wire->recv(dr + p0[k] * sizeof(bsa_result_t), ck * sizeof(bsa_result_t), k)); TRY(c->wire->recv(dc + 8 * p0[k], 8 * ck, k)); }
-			if(wk) TRY(c->wire->recv(dw + 4 * w0[k], wk * 4, k));
+			if(ck){ GTRY(c->wire->recv(dr + p0[k] * sizeof(bsa_result_t), ck * sizeof(bsa_result_t), k)); GTRY(c->wire->recv(dc + 8 * p0[k], 8 * ck, k)); }
+			if(wk) GTRY(c->wire->recv(dw + 4 * w0[k], wk * 4, k));
 		}
-		TRY(c->wire->group_end());
+		GEND();
 	}
 	std::vector<uint64_t> allcnt(tot);
 	TRY(sp->to_host(out, dr, tot * sizeof(bsa_result_t)));

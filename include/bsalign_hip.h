@@ -60,6 +60,9 @@ extern "C" {
                                     With device pointers (bsa_align_run) the compact path also sets it for a pair its flags
                                     cannot decide (none seen in testing): resubmit such pairs with BSA_MODE_ROWRECORDS.
                                     bsa_align_batch does that itself. */
+#define BSA_ST_DEVICE      8u   /* the device gave the pair up: a wave of the segmented forward pass waited for the previous segment's
+                                    state longer than its bound (about two seconds) -- a fault, never an input property.  Result zeroed;
+                                    bsa_align_batch returns BSA_E_HIP when any pair carries it. */
 
 /* == seqalign_result_t (bsalign.h:213-218): 10 x int32, [qb,qe) x [tb,te) half-open */
 typedef struct {
@@ -106,7 +109,9 @@ void        bsa_set_score_matrix(int8_t matrix[16], int8_t mat, int8_t mis);   /
  * Sequences: one base per byte, codes 0..3 (the reference's u1i* qseq/tseq), all pairs in one blob;
  * pair k uses seqs[qoff[k] .. qoff[k]+qlen[k]) and seqs[toff[k] .. toff[k]+tlen[k]).
  * Outputs: out[k]; CIGAR words of pair k at cigar[cigar_off[k] .. cigar_off[k+1]) (cigar_off has n+1
- * entries); status[k] (optional, may be NULL).
+ * entries); status[k] = 0 or BSA_ST_* flags.  status may be NULL, but it is the only place a pair that stays UNDECIDED
+ * can be reported (BSA_ST_TRACE: the reference's own traceback does not terminate on it, result zeroed): with status == NULL
+ * bsa_align_batch returns BSA_E_UNSUPPORTED if any such pair is left, instead of BSA_OK with silent zeroed records.
  *
  * bsa_align_batch      : every pointer is HOST memory (copies in, runs, copies out, synchronises).
  * bsa_align_plan_*     : two-phase form for resident data -- the plan takes the HOST metadata

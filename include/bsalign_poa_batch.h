@@ -80,20 +80,22 @@ static inline int bsa_poa_end_many(BSPOA **gs, int n, bsa_ctx_t *ctx){
 		jobs[k].gs = gs; jobs[k].n = n; jobs[k].t = k; jobs[k].nt = nt; jobs[k].batcher = b;
 		up[k] = (pthread_create(&th[k], NULL, bsa_poa_many_thread, &jobs[k]) == 0);
 		if(up[k]) started ++;
+		else {
+			/* a worker that could not be started: its windows leave the batcher NOW -- in lock-step mode the dispatcher waits for every
+			 * participant that has not left, and the started workers would block in submit for ever if this waited for their join */
+			int w;
+			for(w=k;w<n;w+=nt) bsa_sweep_batcher_leave(b);
+		}
 	}
 	for(k=0;k<nt;k++) if(up[k]) pthread_join(th[k], NULL);
-	/* windows of a worker that could not be started run here, one by one (their participants leave the batcher first) */
-	for(k=0;k<nt;k++) if(!up[k]){
-		int w;
-		for(w=k;w<n;w+=nt){ bsa_sweep_batcher_leave(b); }
-	}
 	bsa_sweep_batcher_destroy(b);
+	/* the windows of such a worker run here, one by one */
 	for(k=0;k<nt;k++) if(!up[k]){
 		int w;
 		for(w=k;w<n;w+=nt) bsa_poa_end_one(gs[w], ctx);
 	}
 	free(jobs); free(th); free(up);
-	(void)started;
+	(void)started;                                       /* every window was finished either way (with no worker at all: one by one, at the single-window rate) */
 	return BSA_OK;
 }
 

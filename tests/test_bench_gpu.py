@@ -38,8 +38,34 @@ def test_one_json_line_with_the_contract_keys(args):
         assert j["checks"]["oracle_identical_first8"] is True and j["checks"]["pairs_flagged"] == 0
     if "fixture" in args:          # the committed programs: runs with oracle/_ref absent, every best end cell the reference's
         assert j["checks"]["best_end_cell_identical_all_programs"] is True and j["checks"]["programs"] == 64 * 6 and j["cpu_baseline"]["value"] is None
+    if "--workload" not in args:
+        # the pairwise line says what sits outside the timed region and validates the shard exchange on its own batch
+        cfg, ex = j["config"], j["exchange"]
+        assert cfg["plan_ms"] > 0 and cfg["pcie_inclusive_ms"] > j["ms_per_step"] and cfg["per_rank_gcups"] == [j["value"]] and cfg["ranks_counted"] == 1
+        assert ex["pairs"] == 2048 and ex["ranks"] == 1 and ex["gathered_identical_to_rank0_whole_batch"] is True and ex["host_pointer_call_identical"] is True
+        assert ex["round_trip_ms"] > 0 and ex["backend"] == "nccl"
     if args[-1] != "-1":
         cb = j["cpu_baseline"]
         # one pinned process per physical core the container may use, the one-core figure beside it (poa: one core)
         assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
         assert cb["cores"] == 1 or (cb["one_core_alone"] > 0 and cb["per_core"] > 0)
+
+
+def test_default_run_carries_the_three_workloads():
+    """`python bench.py` (what the driver runs, here with fewer steps): the headline line with "secondary" = the edit (C3) and POA lines measured in the
+    same run, each with its own roofline and cpu_baseline; plan cost and the PCIe-inclusive time in config"""
+    r = subprocess.run([sys.executable, os.path.join(S.ROOT, "bench.py"), "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=1500, cwd=S.ROOT)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["config"]["pairs_per_gpu"] == 100000 and j["config"]["plan_ms"] > 0 and j["config"]["pcie_inclusive_ms"] > j["ms_per_step"]
+    assert j["exchange"]["gathered_identical_to_rank0_whole_batch"] is True and j["exchange"]["pairs"] == 100000
+    sec = j["secondary"]
+    assert len(sec) == 2 and all("error" not in d for d in sec), sec
+    ed, po = sec
+    assert ed["metric"].startswith("GCUPS") and "edit" in ed["config"]["workload"] and ed["value"] > 0 and ed["roofline"]["frac"] > 0 and ed["cpu_baseline"]["value"] > 0
+    assert ed["checks"]["oracle_identical_first8"] is True and ed["config"]["plan_ms"] > 0
+    assert "poa" in po["config"]["workload"] and po["value"] > 0 and po["roofline"]["frac"] > 0 and po["checks"]["best_end_cell_identical_all_programs"] is True
+    print("\n[bench.py default run] align8 %.0f GCUPS (%.1f ms/step, plan %.0f ms, PCIe-inclusive %.0f ms), edit %.0f GCUPS, poa %.1f GCUPS; secondaries took %.0f + %.0f s"
+          % (j["value"], j["ms_per_step"], j["config"]["plan_ms"], j["config"]["pcie_inclusive_ms"], ed["value"], po["value"], ed["wall_s"], po["wall_s"]))

@@ -99,6 +99,16 @@ KERNEL(k_bfe_u32,     I8("v_bfe_u32", "8, 8"),         "v_bfe_u32 %0, %0, 8, 8\n
 KERNEL(k_or3_b32,     I8("v_or3_b32", "%8, %9"),       "v_or3_b32 %0, %0, %1, %2\n")
 KERNEL(k_cvt_f32_f16, I8("v_cvt_f32_f16", ""),         "v_cvt_f32_f16 %0, %0\n")
 
+// round 5: gfx950's three-operand packed f16 max / min, and the three-input boolean op
+KERNEL(k_pk_maximum3_f16, I8("v_pk_maximum3_f16", "%8, %9"), "v_pk_maximum3_f16 %0, %0, %1, %2\n")
+KERNEL(k_pk_minimum3_f16, I8("v_pk_minimum3_f16", "%8, %9"), "v_pk_minimum3_f16 %0, %0, %1, %2\n")
+KERNEL(k_maximum3_f32,    I8("v_maximum3_f32", "%8, %9"),    "v_maximum3_f32 %0, %0, %1, %2\n")
+KERNEL(k_bitop3_b32,      I8("v_bitop3_b32", "%8, %9 bitop3:0x96"), "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n")
+KERNEL(k_pk_min_i16,      I8("v_pk_min_i16", "%8"),          "v_pk_min_i16 %0, %0, %1\n")
+KERNEL(k_pk_mad_i16,      I8("v_pk_mad_i16", "%9, %8"),      "v_pk_mad_i16 %0, %0, %2, %1\n")
+KERNEL(k_max3_i16,        I8("v_max3_i16", "%8, %9"),        "v_max3_i16 %0, %0, %1, %2\n")
+KERNEL(k_cndmask_sgpr,    I8("v_cndmask_b32", "%8, s[10:11]"), "v_cndmask_b32 %0, %0, %1, s[10:11]\n")
+
 // mixed streams: does a 2-cycle instruction between 4-cycle ones still cost 2?
 KERNEL(k_mix_pk_sub, \
 	"v_pk_max_i16 %0, %0, %8\n v_sub_u32 %1, %1, %9\n v_pk_max_i16 %2, %2, %8\n v_sub_u32 %3, %3, %9\n" \
@@ -143,6 +153,9 @@ int main(){
 		{"v_max_f32", k_max_f32, 8}, {"v_add_f32", k_add_f32, 8}, {"v_max_f16", k_max_f16, 8}, {"v_add_u16", k_add_u16, 8}, {"v_max_u16", k_max_u16, 8},
 		{"v_mul_u32_u24", k_mul_u32_u24, 8}, {"v_and_or_b32", k_and_or_b32, 8}, {"v_alignbit_b32", k_alignbit, 8}, {"v_bfe_u32", k_bfe_u32, 8},
 		{"v_or3_b32", k_or3_b32, 8}, {"v_cvt_f32_f16", k_cvt_f32_f16, 8},
+		{"v_pk_maximum3_f16", k_pk_maximum3_f16, 8}, {"v_pk_minimum3_f16", k_pk_minimum3_f16, 8}, {"v_maximum3_f32", k_maximum3_f32, 8},
+		{"v_bitop3_b32", k_bitop3_b32, 8}, {"v_pk_min_i16", k_pk_min_i16, 8}, {"v_pk_mad_i16", k_pk_mad_i16, 8}, {"v_max3_i16", k_max3_i16, 8},
+		{"v_cndmask_b32 (sgpr pair)", k_cndmask_sgpr, 8},
 		{"mix pk_max, sub_u32 alternating", k_mix_pk_sub, 8}, {"mix pk, pk, sub, sub", k_mix_pk_pk_sub_sub, 8},
 		{"chains: pk_max_u16 -> sub_u32 (x4)", k_mix_dep_chain, 8}, {"chains: pk_max_u16 -> pk_sub_i16 (x4)", k_mix_dep_chain_pk, 8},
 	};
