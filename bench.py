@@ -240,7 +240,7 @@ def launch_check(args):
             batch = dict(seqs=rng.integers(0, 4, acc).astype(np.uint8), qoff=qo, qlen=ql, toff=to, tlen=tl)
         ex = exchange_selfcheck(dist, rank, world, dev, batch, 128)
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_counted": world, "backend": dist.get_backend() if dist is not None else None, "exchange": ex}), flush=True)
+        emit({"launch_check": True, "n_gpus": world, "ranks_counted": world, "backend": dist.get_backend() if dist is not None else None, "exchange": ex})
     if dist is not None:
         dist.destroy_process_group()
 
@@ -431,7 +431,7 @@ def main_poa_recorded(args):
     import poa_support as P
     fixture = args.poa_source == "fixture"
     if not fixture and not S.have_ref():
-        print(json.dumps({"error": "oracle/_ref/libbsref.so absent: recorded POA programs need the reference build (--poa-source fixture runs the committed ones)"}))
+        emit({"error": "oracle/_ref/libbsref.so absent: recorded POA programs need the reference build (--poa-source fixture runs the committed ones)"})
         return
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -582,7 +582,7 @@ def main_poa_recorded(args):
         "cpu_baseline": cpub,
         "lockstep_end_to_end": e2e,
     }
-    print(json.dumps(line), flush=True)
+    emit(line)
     ctx.close()
 
 
@@ -714,7 +714,7 @@ def main_poa(args):
         }
         if world == 1 and args.cpu_pairs >= 0:
             line["cpu_baseline"] = poa_cpu_baseline(args, bw)
-        print(json.dumps(line), flush=True)
+        emit(line)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -725,11 +725,34 @@ def S_oracle_piecewise(pp, bw):
     return int(S.oracle().orc_get_piecewise(pp["O"], pp["E"], pp["Q"], pp["P"], bw))
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """ONE JSON line on stdout is the contract, and libraries talk there (RCCL prints a version banner on the first communicator): from here on fd 1 is
+    stderr, the JSON line goes out through emit() on the descriptor kept aside"""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    sys.stdout.flush()
+    data = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.buffer.write(data); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
     args = parse()
     if args.cpu_worker:
         return cpu_worker(args)
     ensure_ranks(args)
+    quiet_stdout()
     if args.launch_check:
         return launch_check(args)
     if args.workload == "poa":
@@ -930,7 +953,7 @@ def main():
             # the other two configurations BASELINE.json names (C3, C4-shaped windows) in the same run, under the same clock: the device is free again here
             torch.cuda.empty_cache()
             line["secondary"] = secondary_lines(args)
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 def secondary_lines(args):

@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <time.h>
 #include "bsalign_hip.h"
+#include "bsalign_poa.h"
 
 /* executes one program; returns 0 or a BSA_E_* code.  rows_out receives nblocks row blocks. */
 typedef int (*bsa_poa_backend_fn)(void *user, const bsa_row_task_t *tasks, size_t ntasks, const uint8_t *query, uint32_t slen,
@@ -59,6 +60,18 @@ typedef struct {
 	int have_trace;             /* the last bsa_poa_align_rd_core went through the graph form: bsa_poa_apply_trace has its steps */
 	unsigned long long graph_reads, rows_reads;     /* reads aligned through either form */
 	double seconds[3];          /* host time spent building programs, inside the backend (waiting for the device), applying walks */
+	/* the library's own POA graph (include/bsalign_poa.h): when use_pog is set, node selection, band placement, program building and the
+	 * graph surgery run inside libbsalign_hip on ITS graph; this side only keeps the reference's BSPOA in step for msa_bspoa / cns */
+	int use_pog;
+	bsa_pog_t *pog;
+	bsa_pog_params_t pog_par;
+	unsigned long long pog_ncall;   /* g->ncall the mirror was built for (a new beg_bspoa = a new window) */
+	void *pog_owner;                /* the BSPOA it mirrors */
+	int pog_stale;                  /* a read went through the reference's own path: re-import before the next one */
+	uint32_t *pog_gnodes; int32_t *pog_cpos; size_t cap_pog_gnodes, cap_pog_cpos;
+	uint8_t *pog_bases; size_t cap_pog_bases;
+	unsigned long long pog_reads, pog_imports, pog_declined;
+	double pog_seconds[4];          /* keeping the mirror (add / import), gathering inputs (guide alignment, cpos), inside the library, applying the steps to the reference's graph */
 } bsa_poa_adapter_t;
 
 static inline double bsa_poa_now(void){ struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
@@ -76,7 +89,16 @@ static inline void bsa_poa_adapter_init_graph(bsa_poa_adapter_t *ad, bsa_poa_gra
 
 static inline void bsa_poa_adapter_free(bsa_poa_adapter_t *ad){
 	free(ad->tasks); free(ad->nodes); free(ad->edges); free(ad->cands); free(ad->events); free(ad->visits); free(ad->voff); free(ad->loc);
+	free(ad->pog_gnodes); free(ad->pog_cpos); free(ad->pog_bases);
+	if(ad->pog) bsa_pog_destroy(ad->pog);
 	memset(ad, 0, sizeof(*ad));
+}
+
+/* the library's own graph for everything around the DP (default on; BSA_POA_POG=0 in the environment keeps the round-4 path: the reference's
+ * sel_nodes / prepare_rd_align + bsa_poa_flatten_graph + bsa_poa_apply_trace) */
+static inline void bsa_poa_adapter_use_pog(bsa_poa_adapter_t *ad, int on){
+	const char *e = getenv("BSA_POA_POG");
+	ad->use_pog = (e && e[0] == '0') ? 0 : on;
 }
 
 /* the GPU backend: one program through bsa_sweep_host */
@@ -390,6 +412,179 @@ static inline seqalign_result_t bsa_poa_apply_trace(BSPOA *g, BSPOAPar *par, u4i
 	}
 	ad->seconds[2] += bsa_poa_now() - t0;
 	return rs;
+}
+
+/* ---- the reference's graph as the flat snapshot of include/bsalign_poa.h (bsa_pog_import; the fixtures of tests/golden) ---- */
+typedef struct {
+	bsa_pog_snapshot_t snap;
+	bsa_pog_node_t *nodes; uint32_t *ndoff, *rdlen, *out_off, *out_to, *out_cov, *in_off, *in_from;
+} bsa_poa_graph_export_t;
+
+static inline void bsa_poa_graph_export_free(bsa_poa_graph_export_t *x){
+	free(x->nodes); free(x->ndoff); free(x->rdlen); free(x->out_off); free(x->out_to); free(x->out_cov); free(x->in_off); free(x->in_from);
+	memset(x, 0, sizeof(*x));
+}
+
+static inline void bsa_poa_graph_export(BSPOA *g, bsa_poa_graph_export_t *x){
+	const u4i n = (u4i)g->nodes->size, nr = (u4i)g->seqs->nseq;
+	u4i i, ei, ne = 0, k;
+	bspoaedge_t *e;
+	memset(x, 0, sizeof(*x));
+	x->nodes = (bsa_pog_node_t*)calloc((size_t)n + 1, sizeof(bsa_pog_node_t));
+	x->ndoff = (uint32_t*)calloc((size_t)nr + 1, 4); x->rdlen = (uint32_t*)calloc((size_t)nr + 1, 4);
+	x->out_off = (uint32_t*)calloc((size_t)n + 2, 4); x->in_off = (uint32_t*)calloc((size_t)n + 2, 4);
+	for(i=0;i<n;i++){
+		const bspoanode_t *u = ref_bspoanodev(g->nodes, i);
+		bsa_pog_node_t *d = x->nodes + i;
+		d->header = u->header; d->next = u->next; d->prev = u->prev; d->pos = u->pos; d->cpos = u->cpos; d->rid = u->rid; d->cov = u->cov; d->base = u->base;
+		d->flags = (uint8_t)((u->bless? BSA_POG_F_BLESS : 0) | (u->rdc? BSA_POG_F_RDC : 0) | (u->rdd? BSA_POG_F_RDD : 0) | (u->ref? BSA_POG_F_REF : 0));
+		for(ei=u->edge;ei;ei=e->next){ e = ref_bspoaedgev(g->edges, ei); ne ++; }
+	}
+	for(i=0;i<nr;i++){ x->ndoff[i] = g->ndoffs->buffer[i]; x->rdlen[i] = g->seqs->rdlens->buffer[i]; }
+	x->out_to = (uint32_t*)calloc((size_t)ne + 1, 4); x->out_cov = (uint32_t*)calloc((size_t)ne + 1, 4); x->in_from = (uint32_t*)calloc((size_t)ne + 1, 4);
+	for(i=0,k=0;i<n;i++){
+		x->out_off[i] = k;
+		for(ei=ref_bspoanodev(g->nodes, i)->edge;ei;ei=e->next){ e = ref_bspoaedgev(g->edges, ei); x->out_to[k] = e->node; x->out_cov[k] = e->cov; k ++; }
+	}
+	x->out_off[n] = k;
+	for(i=0,k=0;i<n;i++){
+		x->in_off[i] = k;
+		for(ei=ref_bspoanodev(g->nodes, i)->erev;ei;ei=e->next){ e = ref_bspoaedgev(g->edges, ei); x->in_from[k ++] = e->node; }
+	}
+	x->in_off[n] = k;
+	x->snap.nnodes = n; x->snap.nreads = nr; x->snap.head = g->HEAD; x->snap.tail = g->TAIL;
+	x->snap.nodes = x->nodes; x->snap.ndoff = x->ndoff; x->snap.rdlen = x->rdlen;
+	x->snap.out_off = x->out_off; x->snap.out_to = x->out_to; x->snap.out_cov = x->out_cov; x->snap.in_off = x->in_off; x->snap.in_from = x->in_from;
+}
+
+static inline void bsa_poa_pog_params(const BSPOAPar *par, bsa_pog_params_t *pp){
+	memset(pp, 0, sizeof(*pp));
+	pp->alnmode = seqalign_mode_type(par->alnmode); pp->bandwidth = par->bandwidth; pp->bwtrigger = par->bwtrigger; pp->nrec = par->nrec; pp->seqcore = (int32_t)par->seqcore;
+	pp->M = par->M; pp->X = par->X; pp->O = par->O; pp->E = par->E; pp->Q = par->Q; pp->P = par->P; pp->T = par->T; pp->refbonus = par->refbonus;
+}
+
+/* the mirror of this window: built read by read when the window's first read comes (bsa_pog_add_read = _add_read_bspoa_core, bspoa.h:916-951),
+ * re-imported whole after a read that went through the reference's own path */
+static inline int bsa_poa_pog_sync(BSPOA *g, BSPOAPar *par, bsa_poa_adapter_t *ad){
+	bsa_pog_params_t pp;
+	u4i r, i;
+	int rc;
+	bsa_poa_pog_params(par, &pp);
+	if(ad->pog && memcmp(&pp, &ad->pog_par, sizeof(pp))){ bsa_pog_destroy(ad->pog); ad->pog = NULL; }
+	if(ad->pog == NULL){
+		if((rc = bsa_pog_create(&pp, &ad->pog)) != BSA_OK) return rc;
+		ad->pog_par = pp; ad->pog_owner = NULL;
+	}
+	if(ad->pog_owner == (void*)g && ad->pog_ncall == g->ncall && !ad->pog_stale) return BSA_OK;
+	if(g->nrds == 1 && !ad->pog_stale){
+		/* a fresh window: every read was given its nodes (end_bspoa, bspoa.h:4746-4748), none is aligned yet */
+		bsa_pog_clear(ad->pog);
+		for(r=0;r<g->seqs->nseq;r++){
+			const u4i len = g->seqs->rdlens->buffer[r];
+			BSA_POA_GROW(ad->pog_bases, 0, ad->cap_pog_bases, uint8_t, len + 1);
+			for(i=0;i<len;i++) ad->pog_bases[i] = get_basebank(g->seqs->rdseqs, g->seqs->rdoffs->buffer[r] + i);
+			if((rc = bsa_pog_add_read(ad->pog, ad->pog_bases, len, NULL)) != BSA_OK) return rc;
+		}
+	} else {
+		bsa_poa_graph_export_t x;
+		bsa_poa_graph_export(g, &x);
+		rc = bsa_pog_import(ad->pog, &x.snap, NULL);
+		bsa_poa_graph_export_free(&x);
+		if(rc != BSA_OK) return rc;
+		ad->pog_imports ++;
+	}
+	ad->pog_owner = (void*)g; ad->pog_ncall = g->ncall; ad->pog_stale = 0;
+	return BSA_OK;
+}
+
+/* Drop-in for the body of align_rd_bspoa (bspoa.h:2632-2657) between `if(rlen == 0) return rs` and its return: selection, band placement, DP,
+ * walk and surgery through the library's own graph (bsa_pog_*), then the same steps applied to the reference's graph so that msa_bspoa / cns_bspoa
+ * go on from it.  Returns 1 with *out filled, or 0 when the read has to take the reference's own path (refmode, a shape the kernel declines):
+ * the caller goes on with sel_nodes_bspoa etc. and the mirror is re-imported before the next read. */
+static inline int bsa_poa_align_rd_pog(BSPOA *g, BSPOAPar *par, u2i rid, int rbeg, int rlen, bsa_poa_adapter_t *ad, seqalign_result_t *out){
+	bsa_pog_read_t rd;
+	bsa_pog_guide_t gd;
+	bsa_poa_result_t res;
+	bsa_result_t brs;
+	seqalign_result_t rs, krs;
+	const bsa_poa_event_t *ev;
+	const uint32_t *sel;
+	const uint64_t *aux; size_t naux, a;
+	bspoanode_t *gn, *rdn;
+	u4i k, nhead, ntail;
+	int rc, col, x;
+	double t0, t1;
+	if(!ad->use_pog || ad->run_graph == NULL || g->par->refmode) return 0;
+	t0 = bsa_poa_now();
+	if(bsa_poa_pog_sync(g, par, ad) != BSA_OK){ ad->pog_stale = 1; return 0; }
+	t1 = bsa_poa_now(); ad->pog_seconds[0] += t1 - t0; t0 = t1;
+	rc = bsa_pog_select(ad->pog, rid, (uint32_t)rbeg, (uint32_t)rlen, &rd, &sel);
+	if(rc != BSA_OK){ ad->pog_stale = 1; ad->pog_declined ++; return 0; }
+	if(rd.nhead == rd.ntail || rd.nsel < 2){ bsa_pog_abort(ad->pog); ad->pog_stale = 1; ad->pog_declined ++; return 0; }
+	/* the read, and its guide alignment against the running consensus when the band is placed by one (bspoa.h:2033-2038, 2086-2106) */
+	g->qlen = g->slen = (u4i)rlen; g->qb = 0; g->qe = g->qlen;
+	clear_and_encap_u1v(g->qseq, g->qlen);
+	bitseq_basebank(g->seqs->rdseqs, g->seqs->rdoffs->buffer[rid] + rbeg, g->qlen, g->qseq->buffer);
+	g->qseq->size = g->qlen;
+	memset(&gd, 0, sizeof(gd));
+	gd.reflen = (uint32_t)g->cns->size;
+	if(bsa_pog_needs_guide(ad->pog, gd.reflen)){
+		if(par->ksz) krs = kmer_striped_seqedit_pairwise(par->ksz, g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, g->memp, g->stack, 0);
+		else krs = striped_seqedit_pairwise(g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, par->alnmode, 0, g->memp, g->stack, 0);
+		gd.have = 1; gd.qb = krs.qb; gd.qe = krs.qe; gd.tb = krs.tb; gd.te = krs.te; gd.cigar = g->stack->buffer; gd.ncigar = (uint32_t)g->stack->size;
+	}
+	BSA_POA_GROW(ad->pog_cpos, 0, ad->cap_pog_cpos, int32_t, rd.nsel + 1);
+	for(k=0;k<rd.nsel;k++) ad->pog_cpos[k] = ref_bspoanodev(g->nodes, sel[k])->cpos;
+	t1 = bsa_poa_now(); ad->pog_seconds[1] += t1 - t0; t0 = t1;
+	rc = bsa_pog_place(ad->pog, &gd, ad->pog_cpos, &rd);
+	if(rc == BSA_OK) rc = bsa_pog_run(ad->pog, (bsa_pog_backend_fn)ad->run_graph, ad->user, &res, &ev);
+	if(rc != BSA_OK){
+		if(rc != BSA_E_UNSUPPORTED){
+			fprintf(stderr, " -- device sweep failed (code %d, bandwidth %u) in %s -- %s:%d --\n", rc, rd.bandwidth, __FUNCTION__, __FILE__, __LINE__); fflush(stderr);
+			abort();                                                              /* the reference's error convention */
+		}
+		bsa_pog_abort(ad->pog); ad->pog_stale = 1; ad->pog_declined ++;
+		return 0;
+	}
+	/* the auxiliary edges of this alignment, taken over before bsa_pog_apply takes them back */
+	bsa_pog_aux_edges(ad->pog, &aux, &naux);
+	clear_u8v(g->todels);
+	for(a=0;a<naux;a++) push_u8v(g->todels, aux[a]);
+	BSA_POA_GROW(ad->pog_gnodes, 0, ad->cap_pog_gnodes, uint32_t, (size_t)res.nevents + 1);
+	rc = bsa_pog_apply(ad->pog, &brs, ad->pog_gnodes);
+	if(rc != BSA_OK){ fprintf(stderr, " -- bsa_pog_apply failed (code %d) in %s -- %s:%d --\n", rc, __FUNCTION__, __FILE__, __LINE__); fflush(stderr); abort(); }
+	t1 = bsa_poa_now(); ad->pog_seconds[2] += t1 - t0; t0 = t1;
+	/* ---- the same on the reference's graph: auxiliary edges in, the walk's merges, the read chained, auxiliary edges out (the order of the
+	 * coverage-sorted edge lists depends on every one of these changes, bspoa.h:464-494) */
+	nhead = rd.nhead; ntail = rd.ntail;
+	g->bandwidth = rd.bandwidth; g->qb = rd.qb; g->qe = rd.qe; g->slen = rd.slen;
+	g->maxscr = res.maxscr; g->maxoff = res.maxoff;
+	for(a=0;a<g->todels->size;a++) chg_edge_bspoa(g, ref_bspoanodev(g->nodes, g->todels->buffer[a] >> 32), ref_bspoanodev(g->nodes, g->todels->buffer[a] & MAX_U4), 1, NULL);
+	for(x=0;x<Int(g->qlen);x++) get_rdnode_bspoa(g, rid, x)->cpos = 0;
+	col = 0;
+	for(x=0;x<res.nevents;x++){
+		if(ev[x].bt != SEQALIGN_BT_M) continue;
+		gn = ref_bspoanodev(g->nodes, ad->pog_gnodes[x]);
+		rdn = get_rdnode_bspoa(g, rid, rbeg + g->qb + ev[x].x);
+		rdn->cpos = gn->cpos;
+		if(ad->pog_gnodes[x] != nhead && ad->pog_gnodes[x] != ntail && rdn->base == gn->base) merge_nodes_bspoa(g, gn, rdn);
+	}
+	/* (the column the fill starts from: the best end cell's node, bspoa.h:2300-2301 -- its graph index is what the first step or, without steps, the end of the walk names) */
+	col = brs.te - 1;
+	connect_rdnode_bspoa(g, rid, rbeg + g->qlen);
+	for(x=Int(g->qlen)-1;x>=0;x--){
+		connect_rdnode_bspoa(g, rid, rbeg + x);
+		rdn = get_rdnode_bspoa(g, rid, rbeg + x);
+		if(rdn->cpos) col = rdn->cpos; else rdn->cpos = col;
+	}
+	for(a=0;a<g->todels->size;a++) chg_edge_bspoa(g, ref_bspoanodev(g->nodes, g->todels->buffer[a] >> 32), ref_bspoanodev(g->nodes, g->todels->buffer[a] & MAX_U4), -1, NULL);
+	clear_u8v(g->todels);
+	ZEROS(&rs);
+	rs.score = brs.score; rs.qb = brs.qb; rs.qe = brs.qe; rs.tb = brs.tb; rs.te = brs.te; rs.mat = brs.mat; rs.mis = brs.mis; rs.ins = brs.ins; rs.del = brs.del; rs.aln = brs.aln;
+	*out = rs;
+	ad->pog_reads ++; ad->graph_reads ++;
+	ad->pog_seconds[3] += bsa_poa_now() - t0;
+	return 1;
 }
 
 #endif

@@ -2,7 +2,9 @@
  * bsalign_poa_batch.h -- many POA windows at once, reference side.
  *
  * For a tree that has the reference's bspoa.h with patches/bspoa_device_sweep.diff applied (the patch adds one field,
- * BSPOA.devsweep, and makes align_rd_bspoa call include/bsalign_poa_adapter.h's bsa_poa_align_rd_core() when it is set).
+ * BSPOA.devsweep, and makes align_rd_bspoa go through include/bsalign_poa_adapter.h when it is set: bsa_poa_align_rd_pog() -- node
+ * selection, band placement, the DP, the walk and the graph surgery on libbsalign_hip's own POA graph, include/bsalign_poa.h -- and,
+ * for a read that declines, bsa_poa_align_rd_core() on the reference's own graph).
  * Include it after bspoa.h; link libbsalign_hip.so and pthread.
  *
  *   beg_bspoa(g); push_bspoa(g, seq, len); ...        for every window, as before (bspoa.h:1775, 961)
@@ -43,6 +45,7 @@ static void *bsa_poa_many_thread(void *vp){
 	bsa_poa_adapter_t ad;
 	int k;
 	bsa_poa_adapter_init_graph(&ad, bsa_poa_batcher_submit_graph, bsa_sweep_batcher_submit, j->batcher);
+	bsa_poa_adapter_use_pog(&ad, 1);                     /* node selection, band placement, program building and graph surgery on the library's own graph (bsalign_poa.h) */
 	for(k=j->t;k<j->n;k+=j->nt){
 		bsa_sweep_batcher_enter(j->batcher);             /* (runs while it holds one of the host slots) */
 		j->gs[k]->devsweep = &ad;
@@ -103,6 +106,7 @@ static inline int bsa_poa_end_many(BSPOA **gs, int n, bsa_ctx_t *ctx){
 static inline void bsa_poa_end_one(BSPOA *g, bsa_ctx_t *ctx){
 	bsa_poa_adapter_t ad;
 	bsa_poa_adapter_init_graph(&ad, bsa_poa_graph_backend_hip, bsa_poa_backend_hip, ctx);
+	bsa_poa_adapter_use_pog(&ad, 1);
 	g->devsweep = &ad;
 	end_bspoa(g);
 	g->devsweep = NULL;

@@ -26,6 +26,14 @@
  *           best cell, every (node, x, bt) step and the end of the walk are compared; the reference's results are the ones kept.
  *   mode 6  the graph form as the product runs it: flatten, backend, bsa_poa_apply_trace; nothing of the reference's sweep or
  *           walk runs.  The test compares consensus / MSA with a mode-0 run.
+ *   mode 8  the library's OWN graph (include/bsalign_poa.h, bsa_pog_*: container, node selection, band placement, program building,
+ *           surgery) in the shadow of the reference, step by step on every read: its selection list and in-degrees against sel_nodes_bspoa's,
+ *           its band width / read interval / every node's band offset / auxiliary edges against prepare_rd_align_bspoa's, its program byte
+ *           for byte against bsa_poa_flatten_graph on the reference's graph, its result against the binding's, and after the surgery the WHOLE
+ *           graph (rings, coverages, flags, every edge list in order) against the reference's.  The library's graph is never re-imported:
+ *           it is built once with bsa_pog_add_read and evolves by its own surgery.
+ *   mode 9  that path as a patched reference runs it (bsa_poa_align_rd_pog of include/bsalign_poa_adapter.h): nothing of sel_nodes /
+ *           prepare_rd_align / align_rd_bspoacore / alignment2graph runs.  The test compares consensus / MSA with a mode-0 run.
  *
  * Recorded per read: the seqalign_result_t of align_rd_bspoa, the program (tasks), the best end cell and a hash of
  * the reference's row blocks -- tests/golden/make_golden_poa.py turns these into the committed fixtures.
@@ -64,8 +72,11 @@ static inline seqalign_result_t harness_kmer_edit(u1i ksz, u1i *qseq, u4i qlen, 
 #define kmer_striped_seqedit_pairwise harness_kmer_edit
 #include "bspoa.h"
 #undef kmer_striped_seqedit_pairwise
+#include "pog_forward.h"
 #include "../include/bsalign_poa_adapter.h"
 #include <time.h>
+/* the product library's handle (ctypes CDLL._handle of libbsalign_hip.so): the bsa_pog_* entry points of modes 8 / 9 */
+int ref_poa_attach_product(void *dl_handle){ return pog_forward_attach(dl_handle); }
 
 /* the adapter's two link-time dependencies on libbsalign_hip.so, satisfied locally: this library must load without HIP.
  * bsa_sweep_host forwards to the real one when a GPU test has attached it (ref_poa_set_device). */
@@ -147,6 +158,7 @@ typedef struct {
 	double core_seconds;        /* mode 1: wall time inside the reference's align_rd_bspoacore */
 	uint64_t core_updates;      /* mode 1: row updates (edges) those calls processed */
 	uint64_t core_merges;
+	uint64_t pog_checked[6];    /* mode 8: selected nodes, placed nodes, program bytes, steps, graph nodes, graph edges compared */
 } ref_poa_t;
 
 static uint64_t fnv1a(uint64_t h, const void *p, size_t n){
@@ -248,6 +260,141 @@ int ref_poa_can_record_trace(void){
 #endif
 }
 
+/* mode 8: one read through the library's own graph AND through the reference, compared after every step.  mismatch bits: 16 selection, 32 placement,
+ * 64 program, 128 result, 256 graph after the surgery, 512 the library declined / failed */
+static int graphs_equal(BSPOA *g, bsa_pog_t *pog, uint64_t *nn, uint64_t *ne){
+	bsa_poa_graph_export_t x;
+	uint32_t n = 0, nr = 0, nedge = 0, hd = 0, tl = 0, i;
+	bsa_pog_node_t *nodes; uint32_t *ndoff, *rdlen, *oo, *ot, *oc, *io, *inf;
+	int ok = 1;
+	bsa_poa_graph_export(g, &x);
+	if(bsa_pog_export(pog, &n, &nr, &nedge, &hd, &tl, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL) != BSA_OK){ bsa_poa_graph_export_free(&x); return 0; }
+	if(n != x.snap.nnodes || nr != x.snap.nreads || hd != x.snap.head || tl != x.snap.tail || nedge != x.out_off[n]){ bsa_poa_graph_export_free(&x); return 0; }
+	nodes = (bsa_pog_node_t*)calloc((size_t)n + 1, sizeof(bsa_pog_node_t)); ndoff = (uint32_t*)calloc((size_t)nr + 1, 4); rdlen = (uint32_t*)calloc((size_t)nr + 1, 4);
+	oo = (uint32_t*)calloc((size_t)n + 2, 4); io = (uint32_t*)calloc((size_t)n + 2, 4);
+	ot = (uint32_t*)calloc((size_t)nedge + 1, 4); oc = (uint32_t*)calloc((size_t)nedge + 1, 4); inf = (uint32_t*)calloc((size_t)nedge + 1, 4);
+	bsa_pog_export(pog, NULL, NULL, NULL, NULL, NULL, nodes, ndoff, rdlen, oo, ot, oc, io, inf);
+	for(i = 0; i < n && ok; i++){
+		const bsa_pog_node_t *a = nodes + i, *b = x.nodes + i;
+		/* (cpos is compared where it is defined for both: the library holds the columns of the nodes it selected and of the reads it placed, the reference
+		 * recomputes every node's before each read) */
+		if(a->header != b->header || a->next != b->next || a->prev != b->prev || a->pos != b->pos || a->rid != b->rid || a->base != b->base || a->flags != b->flags) ok = 0;
+		if(a->header == i && a->cov != b->cov) ok = 0;
+	}
+	if(memcmp(ndoff, x.ndoff, (size_t)nr * 4) || memcmp(rdlen, x.rdlen, (size_t)nr * 4)) ok = 0;
+	if(memcmp(oo, x.out_off, ((size_t)n + 1) * 4) || memcmp(io, x.in_off, ((size_t)n + 1) * 4)) ok = 0;
+	if(ok && (memcmp(ot, x.out_to, (size_t)nedge * 4) || memcmp(oc, x.out_cov, (size_t)nedge * 4) || memcmp(inf, x.in_from, (size_t)nedge * 4))) ok = 0;
+	*nn += n; *ne += nedge;
+	free(nodes); free(ndoff); free(rdlen); free(oo); free(io); free(ot); free(oc); free(inf);
+	bsa_poa_graph_export_free(&x);
+	return ok;
+}
+
+static seqalign_result_t poa_align_read_shadow_pog(ref_poa_t *p, u2i rid){
+	BSPOA *g = p->g;
+	BSPOAPar *par = g->par;
+	seqalign_result_t rs, krs;
+	const int rlen = g->seqs->rdlens->buffer[rid];
+	bsa_pog_read_t rd;
+	bsa_pog_guide_t gd;
+	const uint32_t *sel = NULL;
+	uint32_t *kcig = NULL;
+	int32_t *cps = NULL;
+	const bsa_poa_node_t *pn; const bsa_poa_edge_t *pe; const bsa_poa_cand_t *pc; size_t npn = 0, npe = 0, npc = 0;
+	const uint8_t *pq = NULL;
+	const uint64_t *aux = NULL; size_t naux = 0;
+	bsa_sweep_params_t sp;
+	bsa_poa_result_t pres;
+	const bsa_poa_event_t *pev = NULL;
+	bsa_result_t brs;
+	u4i head, tail, k;
+	u2i rfirst;
+	int mismatch = 0, rc, score, lib_ok = 0;
+	ZEROS(&rs); ZEROS(&krs); memset(&gd, 0, sizeof(gd)); memset(&brs, 0, sizeof(brs)); memset(&pres, 0, sizeof(pres));
+	clear_u8v(g->todels);
+	/* ---- the library's selection, then the reference's */
+	if(bsa_poa_pog_sync(g, par, &p->ad) != BSA_OK) mismatch |= 512;
+	if(p->ad.pog_imports > p->ad.pog_declined) mismatch |= 512;            /* the mirror is only ever re-imported after a read the kernel declined (a whole-read band above 256 columns: a window's first read) */
+	rc = mismatch ? BSA_E_ARG : bsa_pog_select(p->ad.pog, rid, 0, (uint32_t)rlen, &rd, &sel);
+	if(rc != BSA_OK) mismatch |= 512;
+	head = get_rdnode_bspoa(g, rid, -1)->header;
+	tail = get_rdnode_bspoa(g, rid, rlen)->header;
+	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
+	sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
+	if(!(mismatch & 512)){
+		if(rd.nhead != head || rd.ntail != tail || rd.nsel != g->sels->size) mismatch |= 16;
+		else for(k = 0; k < g->sels->size; k++) if(sel[k] != g->sels->buffer[k]){ mismatch |= 16; break; }
+		p->pog_checked[0] += g->sels->size;
+	}
+	/* ---- the guide alignment (the same call prepare_rd_align_bspoa makes, bspoa.h:2087-2091), the library's placement, then the reference's */
+	if(!(mismatch & 512)){
+		clear_and_encap_u1v(g->qseq, (u4i)rlen);
+		bitseq_basebank(g->seqs->rdseqs, g->seqs->rdoffs->buffer[rid], (u4i)rlen, g->qseq->buffer);
+		g->qseq->size = (u4i)rlen;
+		gd.reflen = (uint32_t)g->cns->size;
+		if(bsa_pog_needs_guide(p->ad.pog, gd.reflen)){
+			if(par->ksz) krs = kmer_striped_seqedit_pairwise(par->ksz, g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, g->memp, g->stack, 0);
+			else krs = striped_seqedit_pairwise(g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, par->alnmode, 0, g->memp, g->stack, 0);
+			kcig = (uint32_t*)malloc((g->stack->size + 1) * sizeof(uint32_t));
+			memcpy(kcig, g->stack->buffer, g->stack->size * sizeof(uint32_t));
+			gd.have = 1; gd.qb = krs.qb; gd.qe = krs.qe; gd.tb = krs.tb; gd.te = krs.te; gd.cigar = kcig; gd.ncigar = (uint32_t)g->stack->size;
+		}
+		cps = (int32_t*)malloc(((size_t)rd.nsel + 1) * sizeof(int32_t));
+		for(k = 0; k < rd.nsel; k++) cps[k] = ref_bspoanodev(g->nodes, sel[k])->cpos;
+		rc = bsa_pog_place(p->ad.pog, &gd, cps, &rd);
+		if(rc != BSA_OK) mismatch |= 512;
+	}
+	prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
+	if(!(mismatch & 512)){
+		int32_t *rp = (int32_t*)malloc(((size_t)rd.nsel + 1) * sizeof(int32_t));
+		if(rd.bandwidth != g->bandwidth || rd.qlen != g->qlen || rd.slen != g->slen || rd.qb != g->qb || rd.qe != g->qe) mismatch |= 32;
+		bsa_pog_aux_edges(p->ad.pog, &aux, &naux);
+		if(naux != g->todels->size) mismatch |= 32;
+		else for(k = 0; k < naux; k++) if(aux[k] != g->todels->buffer[k]){ mismatch |= 32; break; }
+		/* band offsets and in-degrees come out with the program; compare it with the binding's own flattening of the reference's graph */
+		rc = bsa_pog_program(p->ad.pog, &pn, &npn, &pe, &npe, &pc, &npc, &pq, &sp);
+		if(rc != BSA_OK) mismatch |= 512;
+		else if(head != tail && g->sels->size >= 2){
+			bsa_poa_flatten_graph(g, par, head, tail, &p->ad);
+			for(k = 0; k < g->sels->size; k++) ref_bspoanodev(g->nodes, g->sels->buffer[k])->vst = 0;
+			if(npn != p->ad.nnodes || npe != p->ad.nedges || npc != p->ad.ncands) mismatch |= 64;
+			else if(memcmp(pn, p->ad.nodes, npn * sizeof(bsa_poa_node_t)) || memcmp(pe, p->ad.edges, npe * sizeof(bsa_poa_edge_t)) || memcmp(pc, p->ad.cands, npc * sizeof(bsa_poa_cand_t))) mismatch |= 64;
+			if(memcmp(pq, g->qseq->buffer + g->qb, g->slen)) mismatch |= 64;
+			if(sp.rows.bandwidth != g->bandwidth || sp.rows.mode != seqalign_mode_type(par->alnmode) || sp.T != par->T) mismatch |= 64;
+			p->pog_checked[1] += g->sels->size; p->pog_checked[2] += npn * sizeof(bsa_poa_node_t) + npe * sizeof(bsa_poa_edge_t) + npc * sizeof(bsa_poa_cand_t);
+		}
+		free(rp);
+	}
+	/* ---- the DP + walk: the library runs its program through the test's backend and applies the steps to ITS graph; the binding does the same
+	 * for the reference's graph (bsa_poa_align_rd_core + bsa_poa_apply_trace, the round-4 path, itself pinned against the reference's own walk) */
+	if(!(mismatch & 512) && p->ad.run_graph && head != tail && g->sels->size >= 2){
+		rc = bsa_pog_run(p->ad.pog, (bsa_pog_backend_fn)p->ad.run_graph, p->ad.user, &pres, &pev);
+		if(rc == BSA_OK && bsa_pog_apply(p->ad.pog, &brs, NULL) == BSA_OK) lib_ok = 1;
+		else { bsa_pog_abort(p->ad.pog); p->ad.pog_stale = 1; p->ad.pog_declined ++; }
+	} else if(!(mismatch & 512)){ bsa_pog_abort(p->ad.pog); p->ad.pog_stale = 1; p->ad.pog_declined ++; }
+	if(lib_ok) p->ad.pog_reads ++;
+	score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
+	if(p->ad.have_trace) rs = bsa_poa_apply_trace(g, par, rid, 0, head, tail, &p->ad);
+	else rs = alignment2graph_bspoa(g, par, rid, 0, head, tail, g->maxidx, g->maxoff, NULL);
+	rs.qb += g->qb; rs.qe += g->qb; rs.score = score;
+	for(k=0;k<g->todels->size;k++){
+		chg_edge_bspoa(g, ref_bspoanodev(g->nodes, g->todels->buffer[k] >> 32), ref_bspoanodev(g->nodes, g->todels->buffer[k] & MAX_U4), -1, NULL);
+	}
+	clear_u8v(g->todels);
+	if(lib_ok){
+		if(!p->ad.have_trace) mismatch |= 128;
+		else {
+			if(brs.score != rs.score || brs.qb != rs.qb || brs.qe != rs.qe || brs.tb != rs.tb || brs.te != rs.te || brs.mat != rs.mat || brs.mis != rs.mis || brs.ins != rs.ins || brs.del != rs.del) mismatch |= 128;
+			if(pres.maxscr != p->ad.res.maxscr || pres.maxidx != p->ad.res.maxidx || pres.maxoff != p->ad.res.maxoff || pres.nevents != p->ad.res.nevents) mismatch |= 128;
+			p->pog_checked[3] += (uint64_t)pres.nevents;
+		}
+		if(!graphs_equal(g, p->ad.pog, &p->pog_checked[4], &p->pog_checked[5])) mismatch |= 256;
+	} else if(p->ad.have_trace) mismatch |= 512;          /* the binding's graph form took the read, the library did not */
+	free(kcig); free(cps);
+	record_read(p, rs, mismatch, 0);
+	return rs;
+}
+
 /* orchestration of align_rd_bspoa (bspoa.h:2620-2667), realn == 0 entry only (the one end_bspoa uses) */
 static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 	BSPOA *g = p->g;
@@ -261,13 +408,18 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 	clear_u8v(g->todels);
 	ZEROS(&rs);
 	if(rlen == 0) return rs;
+	if(p->mode == 9 || p->mode == 10){
+		/* the product's path, as the patched align_rd_bspoa takes it */
+		if(bsa_poa_align_rd_pog(g, par, rid, 0, rlen, &p->ad, &rs)){ record_read(p, rs, 0, 0); return rs; }
+	}
+	if(p->mode == 8) return poa_align_read_shadow_pog(p, rid);
 	head = get_rdnode_bspoa(g, rid, -1)->header;
 	tail = get_rdnode_bspoa(g, rid, rlen)->header;
 	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
 	sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
 	prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
-	if(p->mode == 6 || p->mode == 7){
-		/* the product's path: graph form, the walk applied by the binding */
+	if(p->mode == 6 || p->mode == 7 || p->mode == 9 || p->mode == 10){
+		/* the product's path: graph form, the walk applied by the binding (modes 9 / 10: a read the library's own graph declined) */
 		score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
 		if(p->ad.have_trace){
 			rs = bsa_poa_apply_trace(g, par, rid, 0, head, tail, &p->ad);
@@ -318,7 +470,7 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 		if(p->nrec){ poa_read_rec_t *r = p->recs + p->nrec - 1; r->fin_gnode = have ? (int32_t)p->ad.nodes[p->ad.res.fin_node].gnode : -1; r->fin_x = have ? p->ad.res.fin_x : -1; r->maxidx_local = have ? p->ad.res.maxidx : -1; }
 		return rs;
 	}
-	if(p->mode == 4 || p->mode == 6 || p->mode == 7){
+	if(p->mode == 4 || p->mode == 6 || p->mode == 7 || p->mode == 9 || p->mode == 10){
 		if(p->mode == 4) score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
 	} else if(p->mode >= 2){
 		int a_scr, a_idx, a_off;
@@ -433,13 +585,15 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 	bsa_poa_adapter_free(&p->ad);
 	if(mode == 3) bsa_poa_adapter_init(&p->ad, bsa_poa_backend_hip, g_device_ctx);
 	else if(mode == 4) bsa_poa_adapter_init(&p->ad, g_batch_submit, g_batcher);
-	else if(mode == 5 || mode == 6){
+	else if(mode == 5 || mode == 6 || mode == 8 || mode == 9){
 		/* graph form; reads it declines (whole-read bands) take the rows form: the oracle's sweep on the CPU, the device's otherwise */
 		if(g_graph_backend) bsa_poa_adapter_init_graph(&p->ad, g_graph_backend, sweep_fn ? backend_oracle : bsa_poa_backend_hip, sweep_fn ? (void*)p : g_device_ctx);
 		else bsa_poa_adapter_init_graph(&p->ad, bsa_poa_graph_backend_hip, bsa_poa_backend_hip, g_device_ctx);
 		if(g_graph_backend && !sweep_fn) p->ad.user = g_graph_backend_user;
-	} else if(mode == 7) bsa_poa_adapter_init_graph(&p->ad, g_batch_submit_graph, g_batch_submit, g_batcher);
+	} else if(mode == 7 || mode == 10) bsa_poa_adapter_init_graph(&p->ad, g_batch_submit_graph, g_batch_submit, g_batcher);
 	else bsa_poa_adapter_init(&p->ad, backend_oracle, p);
+	p->ad.use_pog = (mode == 8 || mode == 9 || mode == 10);          /* (mode 10 = mode 7, many windows through the batcher, on the library's own graph) */
+	memset(p->pog_checked, 0, sizeof(p->pog_checked));
 	for(k = 0; k < nreads; k++) if(lens[k] > maxlen) maxlen = lens[k];
 	buf = (char*)malloc(maxlen + 1);
 	beg_bspoa(g);
@@ -467,9 +621,9 @@ static batch_leave_fn g_batch_enter = NULL;
 void ref_poa_set_batcher_enter(void *enter_addr){ g_batch_enter = (batch_leave_fn)enter_addr; }
 static void *many_thread(void *vp){
 	many_job_t *j = (many_job_t*)vp;
-	if((j->mode == 4 || j->mode == 7) && g_batch_enter) g_batch_enter(g_batcher);
+	if((j->mode == 4 || j->mode == 7 || j->mode == 10) && g_batch_enter) g_batch_enter(g_batcher);
 	j->rc = ref_poa_run(j->handle, j->reads, j->offs, j->lens, j->nreads, j->mode, NULL, j->record);
-	if((j->mode == 4 || j->mode == 7) && g_batch_leave) g_batch_leave(g_batcher);       /* this window submits nothing more */
+	if((j->mode == 4 || j->mode == 7 || j->mode == 10) && g_batch_leave) g_batch_leave(g_batcher);       /* this window submits nothing more */
 	return NULL;
 }
 
@@ -488,14 +642,14 @@ int ref_poa_run_many(void **handles, int nwin, const uint8_t *reads, const uint6
 	many_job_t *jobs = (many_job_t*)calloc((size_t)nwin, sizeof(many_job_t));
 	pthread_t *th = (pthread_t*)calloc((size_t)nwin, sizeof(pthread_t));
 	int w, bad = 0;
-	if((mode == 4 || mode == 7) && (!g_batch_submit || !g_batcher)){ free(jobs); free(th); return -1; }
-	if(mode == 7 && !g_batch_submit_graph){ free(jobs); free(th); return -1; }
+	if((mode == 4 || mode == 7 || mode == 10) && (!g_batch_submit || !g_batcher)){ free(jobs); free(th); return -1; }
+	if((mode == 7 || mode == 10) && !g_batch_submit_graph){ free(jobs); free(th); return -1; }
 	cal_permutation_bspoa(MAX_LOG_CACHE, 0);                             /* fill the reference's lazily built log table before any thread reads it (bspoa.h:3391-3401) */
 	for(w = 0; w < nwin; w++){
 		jobs[w].handle = handles[w]; jobs[w].reads = reads; jobs[w].offs = offs + first[w]; jobs[w].lens = lens + first[w];
 		jobs[w].nreads = count[w]; jobs[w].mode = mode; jobs[w].record = record;
 	}
-	if(mode == 4 || mode == 7){
+	if(mode == 4 || mode == 7 || mode == 10){
 		/* through the batcher: since it runs whatever is pending (round 4) the windows need not all be alive at once -- a pool of
 		 * BSA_POA_POOL threads (default 256) takes them one after the other, which keeps the working set to that many graphs.  With
 		 * BSA_POA_BATCH_MIN=all (lock-step) every window keeps a thread of its own. */
@@ -663,6 +817,20 @@ void ref_poa_form_counts(void *vp, uint64_t *graph_reads, uint64_t *rows_reads){
 	ref_poa_t *p = (ref_poa_t*)vp;
 	*graph_reads = p->ad.graph_reads; *rows_reads = p->ad.rows_reads;
 }
+/* modes 8 - 10: reads through the library's own graph / re-imports of it / reads it declined, and what mode 8 compared */
+void ref_poa_pog_counts(void *vp, uint64_t *out){
+	ref_poa_t *p = (ref_poa_t*)vp; int k;
+	out[0] = p->ad.pog_reads; out[1] = p->ad.pog_imports; out[2] = p->ad.pog_declined;
+	for(k = 0; k < 6; k++) out[3 + k] = p->pog_checked[k];
+}
+void ref_poa_pog_seconds(void *vp, double *out){
+	ref_poa_t *p = (ref_poa_t*)vp; int k;
+	for(k = 0; k < 4; k++) out[k] = p->ad.pog_seconds[k];
+	for(k = 0; k < 5; k++) out[4 + k] = 0;
+	if(p->ad.pog) bsa_pog_seconds(p->ad.pog, out + 4);
+}
+/* the graph as it stands (after ref_poa_run: the finished window's; the fixtures of tests/golden/make_golden_poa_pog.py record it BEFORE reads through
+ * ref_poa_snapshot_hook) */
 void ref_poa_binding_seconds(void *vp, double *out){ ref_poa_t *p = (ref_poa_t*)vp; out[0] = p->ad.seconds[0]; out[1] = p->ad.seconds[1]; out[2] = p->ad.seconds[2]; }
 
 /* ---- consensus calling (tests of bsa_msa_call_consensus in include/bsalign_msa.h): the REAL cns_bspoa (bspoa.h:3457-3733) re-run on the finished

@@ -62,6 +62,9 @@ HID int bsa_diagdp_walk_batch(bsa_ctx_t *c, const uint8_t *planes, size_t pb, co
 	return p_diagdp_walk ? p_diagdp_walk(c, planes, pb, probs, n, w, steps, cap) : BSA_E_UNSUPPORTED;
 }
 
+#include "pog_forward.h"        /* bsa_pog_*: forwarded into the real libbsalign_hip.so (refp_attach_product) */
+int refp_attach_product(void *dl_handle){ return pog_forward_attach(dl_handle); }
+
 #include "bsalign.h"
 #include "bspoa.h"              /* the PATCHED copy (first on the include path) */
 HID size_t bsa_rows_block_bytes(uint32_t bandwidth, int8_t gapo1, int8_t gape1, int8_t gapo2, int8_t gape2){

@@ -92,11 +92,29 @@ def ref_poa_trace():
     return _TRACE
 
 
+def attach_product(r):
+    """modes 8 - 10 of the harness call the bsa_pog_* entry points (include/bsalign_poa.h): hand it the handle of the REAL libbsalign_hip.so
+    (it loads without a GPU; the graph surface is host code), so that every call lands in the product's own code"""
+    import bsalign_amd as B
+    if getattr(r, "_product_attached", False):
+        return
+    r.ref_poa_attach_product.argtypes = [C.c_void_p]
+    r.ref_poa_attach_product.restype = C.c_int
+    assert r.ref_poa_attach_product(C.c_void_p(B.lib()._handle)) == 0, "libbsalign_hip.so lacks bsa_pog_* entry points"
+    r.ref_poa_pog_counts.argtypes = [C.c_void_p, C.c_void_p]
+    r.ref_poa_pog_counts.restype = None
+    r.ref_poa_pog_seconds.argtypes = [C.c_void_p, C.c_void_p]
+    r.ref_poa_pog_seconds.restype = None
+    r._product_attached = True
+
+
 def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
     """modes 5 / 6 of the harness (graph form of the binding).  backend "oracle": orc_wf_backend + orc_sweep_run on the CPU;
     "device": whatever the GPU test attached with ref_poa_set_graph_host / ref_poa_set_device.
     -> dict like run_ref_poa, plus per read (mode 5, record) nodes / edges / cands / trace / fin and the counts of reads per form"""
     r, o = (lib or ref_poa()), S.oracle()
+    if mode >= 8:
+        attach_product(r)
     if backend == "oracle":
         _wf_lib()
         r.ref_poa_set_graph_backend(C.cast(o.orc_wf_backend, C.c_void_p), None)
@@ -141,8 +159,15 @@ def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
     r.ref_poa_binding_seconds.argtypes = [C.c_void_p, C.c_void_p]
     r.ref_poa_binding_seconds.restype = None
     r.ref_poa_binding_seconds(h, secs.ctypes.data)
+    pog = None
+    if mode >= 8:
+        pc, ps = np.zeros(9, np.uint64), np.zeros(9, np.float64)
+        r.ref_poa_pog_counts(h, pc.ctypes.data)
+        r.ref_poa_pog_seconds(h, ps.ctypes.data)
+        pog = dict(reads=int(pc[0]), imports=int(pc[1]), declined=int(pc[2]), sel_nodes=int(pc[3]), placed_nodes=int(pc[4]), program_bytes=int(pc[5]),
+                   steps=int(pc[6]), graph_nodes=int(pc[7]), graph_edges=int(pc[8]), binding_seconds=ps[:4].copy(), library_seconds=ps[4:].copy())
     r.ref_poa_destroy(h)
-    return dict(bad=bad, binding_seconds=secs, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, graph_reads=g1.value, rows_reads=g2.value)
+    return dict(bad=bad, binding_seconds=secs, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, graph_reads=g1.value, rows_reads=g2.value, pog=pog)
 
 
 def run_ref_poa(reads, mode, p, record=True):

@@ -39,6 +39,10 @@ def _lib(ctx):
     L.refp_attach_graph(C.cast(b.bsa_poa_graph_host, C.c_void_p), C.cast(b.bsa_poa_batcher_submit_graph, C.c_void_p))      # graph form: sweep + walk on the device
     L.refp_attach_enter.argtypes = [C.c_void_p]
     L.refp_attach_enter(C.cast(b.bsa_sweep_batcher_enter, C.c_void_p))
+    # the library's own POA graph surface (include/bsalign_poa.h): bsa_poa_end_one / _end_many select, place, build programs and do the surgery on it
+    L.refp_attach_product.argtypes = [C.c_void_p]
+    L.refp_attach_product.restype = C.c_int
+    assert L.refp_attach_product(C.c_void_p(b._handle)) == 0
     return L
 
 
