@@ -159,7 +159,28 @@ typedef struct {
 	uint64_t core_updates;      /* mode 1: row updates (edges) those calls processed */
 	uint64_t core_merges;
 	uint64_t pog_checked[6];    /* mode 8: selected nodes, placed nodes, program bytes, steps, graph nodes, graph edges compared */
+	/* record_programs & 4 (mode 5): the flat graph BEFORE every aligned read with what the reference then decided (tests/golden/make_golden_poa_pog.py) */
+	uint8_t *snap; size_t nsnap, capsnap;
+	uint64_t *snapoff; size_t nsnaprec, capsnaprec;
 } ref_poa_t;
+
+/* one snapshot record: 20 x u64 header [nnodes, nreads, nedges, ncigar, nsel, naux, head, tail, guide.have, qb, qe, tb, te, reflen, bandwidth, slen, rd.qb, rd.qe, rid, rlen]
+ * then nodes (28 B each) | ndoff | rdlen | out_off (nnodes + 1) | out_to | out_cov | in_off (nnodes + 1) | in_from | cigar | sels (all u32) | aux (u64) */
+static void snap_put(ref_poa_t *p, const void *src, size_t bytes){
+	if(p->nsnap + bytes + 8 > p->capsnap){ p->capsnap = (p->nsnap + bytes) * 2 + 4096; p->snap = (uint8_t*)realloc(p->snap, p->capsnap); }
+	if(bytes) memcpy(p->snap + p->nsnap, src, bytes);
+	p->nsnap += (bytes + 7) & ~(size_t)7;
+}
+static void snap_record(ref_poa_t *p, const bsa_poa_graph_export_t *x, const uint64_t hdr[20], const uint32_t *cigar, const uint32_t *sels, const uint64_t *aux){
+	const size_t n = x->snap.nnodes, nr = x->snap.nreads, ne = x->out_off[n];
+	if(p->nsnaprec == p->capsnaprec){ p->capsnaprec = p->capsnaprec ? p->capsnaprec * 2 : 64; p->snapoff = (uint64_t*)realloc(p->snapoff, p->capsnaprec * sizeof(uint64_t)); }
+	p->snapoff[p->nsnaprec ++] = p->nsnap;
+	snap_put(p, hdr, 20 * sizeof(uint64_t));
+	snap_put(p, x->nodes, n * sizeof(bsa_pog_node_t)); snap_put(p, x->ndoff, nr * 4); snap_put(p, x->rdlen, nr * 4);
+	snap_put(p, x->out_off, (n + 1) * 4); snap_put(p, x->out_to, ne * 4); snap_put(p, x->out_cov, ne * 4);
+	snap_put(p, x->in_off, (n + 1) * 4); snap_put(p, x->in_from, ne * 4);
+	snap_put(p, cigar, (size_t)hdr[3] * 4); snap_put(p, sels, (size_t)hdr[4] * 4); snap_put(p, aux, (size_t)hdr[5] * 8);
+}
 
 static uint64_t fnv1a(uint64_t h, const void *p, size_t n){
 	const uint8_t *b = (const uint8_t*)p; size_t i;
@@ -204,7 +225,7 @@ void ref_poa_destroy(void *vp){
 	free_bspoa(p->g);
 	bsa_poa_adapter_free(&p->ad);
 	free(p->recs); free(p->tasks); free(p->queries);
-	free(p->gnodes); free(p->gedges); free(p->gcands); free(p->gtrace); free(p->cur_trace);
+	free(p->gnodes); free(p->gedges); free(p->gcands); free(p->gtrace); free(p->cur_trace); free(p->snap); free(p->snapoff);
 	free(p);
 }
 
@@ -218,7 +239,7 @@ static void record_read(ref_poa_t *p, seqalign_result_t rs, int mismatch, uint64
 	r->bandwidth = g->bandwidth; r->slen = g->slen; r->qb = g->qb; r->nblocks = (uint32_t)g->mmcnt; r->piecewise = (uint32_t)g->piecewise;
 	r->rows_hash = rows_hash; r->mismatch = mismatch;
 	r->task_off = p->ntasks; r->query_off = p->nq;
-	if((p->mode == 5 && p->record_programs) || (p->mode == 1 && (p->record_programs & 2))){
+	if((p->mode == 5 && (p->record_programs & 1)) || (p->mode == 1 && (p->record_programs & 2))){
 #define APPEND(dst, n, cap, src, cnt, type) do { if((n) + (cnt) > (cap)){ (cap) = ((n) + (cnt)) * 2 + 64; (dst) = (type*)realloc((dst), (cap) * sizeof(type)); } \
 		memcpy((dst) + (n), (src), (cnt) * sizeof(type)); (n) += (cnt); } while(0)
 		r->node_off = p->ngn; r->edge_off = p->nge; r->cand_off = p->ngc; r->trace_off = p->ngt;
@@ -416,8 +437,34 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 	head = get_rdnode_bspoa(g, rid, -1)->header;
 	tail = get_rdnode_bspoa(g, rid, rlen)->header;
 	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
-	sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
-	prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
+	{
+		bsa_poa_graph_export_t snapx; uint64_t shdr[20]; uint32_t *scig = NULL; int snapping = (p->mode == 5 && (p->record_programs & 4));
+		if(snapping){
+			seqalign_result_t krs;
+			memset(shdr, 0, sizeof(shdr)); ZEROS(&krs);
+			bsa_poa_graph_export(g, &snapx);
+			shdr[0] = snapx.snap.nnodes; shdr[1] = snapx.snap.nreads; shdr[2] = snapx.out_off[snapx.snap.nnodes]; shdr[6] = g->HEAD; shdr[7] = g->TAIL;
+			shdr[13] = g->cns->size; shdr[18] = rid; shdr[19] = (uint64_t)rlen;
+			/* the guide alignment prepare_rd_align_bspoa is about to make (bspoa.h:2086-2091): the same call, kept */
+			if(par->bwtrigger && head == g->HEAD && tail == g->TAIL && g->cns->size && Int(roundup_times(rlen, WORDSIZE)) > par->bandwidth){
+				clear_and_encap_u1v(g->qseq, (u4i)rlen);
+				bitseq_basebank(g->seqs->rdseqs, g->seqs->rdoffs->buffer[rid], (u4i)rlen, g->qseq->buffer);
+				g->qseq->size = (u4i)rlen;
+				if(par->ksz) krs = kmer_striped_seqedit_pairwise(par->ksz, g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, g->memp, g->stack, 0);
+				else krs = striped_seqedit_pairwise(g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, par->alnmode, 0, g->memp, g->stack, 0);
+				scig = (uint32_t*)malloc((g->stack->size + 1) * sizeof(uint32_t));
+				memcpy(scig, g->stack->buffer, g->stack->size * sizeof(uint32_t));
+				shdr[3] = g->stack->size; shdr[8] = 1; shdr[9] = (uint64_t)(int64_t)krs.qb; shdr[10] = (uint64_t)(int64_t)krs.qe; shdr[11] = (uint64_t)(int64_t)krs.tb; shdr[12] = (uint64_t)(int64_t)krs.te;
+			}
+		}
+		sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
+		prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
+		if(snapping){
+			shdr[4] = g->sels->size; shdr[5] = g->todels->size; shdr[14] = g->bandwidth; shdr[15] = g->slen; shdr[16] = g->qb; shdr[17] = g->qe;
+			snap_record(p, &snapx, shdr, scig, g->sels->buffer, g->todels->buffer);
+			bsa_poa_graph_export_free(&snapx); free(scig);
+		}
+	}
 	if(p->mode == 6 || p->mode == 7 || p->mode == 9 || p->mode == 10){
 		/* the product's path: graph form, the walk applied by the binding (modes 9 / 10: a read the library's own graph declined) */
 		score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
@@ -556,6 +603,15 @@ static void poa_finish(ref_poa_t *p){
 		poa_align_read(p, rid);
 		g->nrds ++;
 	}
+	if(p->mode == 5 && (p->record_programs & 4)){
+		/* the graph the last surgery left */
+		bsa_poa_graph_export_t x; uint64_t hdr[20];
+		memset(hdr, 0, sizeof(hdr));
+		bsa_poa_graph_export(g, &x);
+		hdr[0] = x.snap.nnodes; hdr[1] = x.snap.nreads; hdr[2] = x.out_off[x.snap.nnodes]; hdr[6] = g->HEAD; hdr[7] = g->TAIL; hdr[18] = (uint64_t)-1;
+		snap_record(p, &x, hdr, NULL, NULL, NULL);
+		bsa_poa_graph_export_free(&x);
+	}
 	for(round=0;round<g->par->realn;round++){
 		msa_bspoa(g);
 		cns_bspoa(g);
@@ -579,7 +635,7 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 	int k, bad = 0;
 	size_t i;
 	p->mode = mode; p->record_programs = record_programs;
-	p->nrec = 0; p->ntasks = 0; p->nq = 0; p->ngn = p->nge = p->ngc = p->ngt = 0;
+	p->nrec = 0; p->ntasks = 0; p->nq = 0; p->ngn = p->nge = p->ngc = p->ngt = 0; p->nsnap = 0; p->nsnaprec = 0;
 	p->core_seconds = 0; p->core_updates = 0; p->core_merges = 0;
 	p->sweep = (orc_sweep_fn)sweep_fn;
 	bsa_poa_adapter_free(&p->ad);
@@ -816,6 +872,14 @@ void ref_poa_graph_data(void *vp, void *nodes, void *edges, void *cands, void *t
 void ref_poa_form_counts(void *vp, uint64_t *graph_reads, uint64_t *rows_reads){
 	ref_poa_t *p = (ref_poa_t*)vp;
 	*graph_reads = p->ad.graph_reads; *rows_reads = p->ad.rows_reads;
+}
+/* record_programs & 4: the snapshot records (layout above snap_record) */
+uint64_t ref_poa_snap_count(void *vp){ return ((ref_poa_t*)vp)->nsnaprec; }
+uint64_t ref_poa_snap_bytes(void *vp){ return ((ref_poa_t*)vp)->nsnap; }
+void ref_poa_snap_data(void *vp, uint8_t *blob, uint64_t *offs){
+	ref_poa_t *p = (ref_poa_t*)vp;
+	if(blob) memcpy(blob, p->snap, p->nsnap);
+	if(offs) memcpy(offs, p->snapoff, p->nsnaprec * sizeof(uint64_t));
 }
 /* modes 8 - 10: reads through the library's own graph / re-imports of it / reads it declined, and what mode 8 compared */
 void ref_poa_pog_counts(void *vp, uint64_t *out){

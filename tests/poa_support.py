@@ -108,6 +108,31 @@ def attach_product(r):
     r._product_attached = True
 
 
+POG_NODE = np.dtype([("header", np.uint32), ("next", np.uint32), ("prev", np.uint32), ("pos", np.int32), ("cpos", np.int32),
+                     ("rid", np.uint16), ("cov", np.uint16), ("base", np.uint8), ("flags", np.uint8), ("reserved", np.uint16)])
+SNAP_HDR = ("nnodes", "nreads", "nedges", "ncigar", "nsel", "naux", "head", "tail", "have", "gqb", "gqe", "gtb", "gte", "reflen", "bandwidth", "slen", "qb", "qe", "rid", "rlen")
+
+
+def parse_snapshot(blob, o):
+    """one record of the harness's snapshot blob (oracle/ref_poa_harness.c: snap_record) -> dict"""
+    hdr = blob[o:o + 160].view(np.int64)
+    d = dict(zip(SNAP_HDR, (int(x) for x in hdr)))
+    o += 160
+
+    def take(n, dt):
+        nonlocal o
+        nb = n * np.dtype(dt).itemsize
+        a = blob[o:o + nb].view(dt).copy()
+        o += (nb + 7) & ~7
+        return a
+    n, nr, ne = d["nnodes"], d["nreads"], d["nedges"]
+    d["nodes"] = take(n, POG_NODE); d["ndoff"] = take(nr, np.uint32); d["rdlen"] = take(nr, np.uint32)
+    d["out_off"] = take(n + 1, np.uint32); d["out_to"] = take(ne, np.uint32); d["out_cov"] = take(ne, np.uint32)
+    d["in_off"] = take(n + 1, np.uint32); d["in_from"] = take(ne, np.uint32)
+    d["cigar"] = take(d["ncigar"], np.uint32); d["sels"] = take(d["nsel"], np.uint32); d["aux"] = take(d["naux"], np.uint64)
+    return d
+
+
 def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
     """modes 5 / 6 of the harness (graph form of the binding).  backend "oracle": orc_wf_backend + orc_sweep_run on the CPU;
     "device": whatever the GPU test attached with ref_poa_set_graph_host / ref_poa_set_device.
@@ -149,7 +174,7 @@ def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
         r.ref_poa_graph_rec(h, k, gr.ctypes.data)
         d = dict(rs=out[:10].copy(), maxscr=int(out[10]), maxidx=int(out[11]), maxoff=int(out[12]), bandwidth=int(out[13]), slen=int(out[14]),
                  qb=int(out[15]), piecewise=int(out[18]), mismatch=int(out[19]), rows_hash=a.value, query_off=c.value)
-        if mode == 5 and record:
+        if mode == 5 and (int(record) & 1):
             d.update(nodes=gn[gr[0]:gr[0] + gr[4]], edges=ge[gr[1]:gr[1] + gr[5]], cands=gc[gr[2]:gr[2] + gr[6]], trace=gt[gr[3]:gr[3] + gr[7]],
                      fin_gnode=int(gr[8]), fin_x=int(gr[9]), maxidx_local=int(gr[10]), query=queries[c.value:c.value + int(out[14])])
         recs.append(d)
@@ -159,6 +184,15 @@ def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
     r.ref_poa_binding_seconds.argtypes = [C.c_void_p, C.c_void_p]
     r.ref_poa_binding_seconds.restype = None
     r.ref_poa_binding_seconds(h, secs.ctypes.data)
+    snaps = None
+    if isinstance(record, int) and not isinstance(record, bool) and (record & 4):
+        r.ref_poa_snap_count.argtypes = [C.c_void_p]; r.ref_poa_snap_count.restype = C.c_uint64
+        r.ref_poa_snap_bytes.argtypes = [C.c_void_p]; r.ref_poa_snap_bytes.restype = C.c_uint64
+        r.ref_poa_snap_data.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; r.ref_poa_snap_data.restype = None
+        ns, nb = int(r.ref_poa_snap_count(h)), int(r.ref_poa_snap_bytes(h))
+        blob, so = np.zeros(nb, np.uint8), np.zeros(ns, np.uint64)
+        r.ref_poa_snap_data(h, blob.ctypes.data, so.ctypes.data)
+        snaps = [parse_snapshot(blob, int(o)) for o in so]
     pog = None
     if mode >= 8:
         pc, ps = np.zeros(9, np.uint64), np.zeros(9, np.float64)
@@ -167,7 +201,7 @@ def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
         pog = dict(reads=int(pc[0]), imports=int(pc[1]), declined=int(pc[2]), sel_nodes=int(pc[3]), placed_nodes=int(pc[4]), program_bytes=int(pc[5]),
                    steps=int(pc[6]), graph_nodes=int(pc[7]), graph_edges=int(pc[8]), binding_seconds=ps[:4].copy(), library_seconds=ps[4:].copy())
     r.ref_poa_destroy(h)
-    return dict(bad=bad, binding_seconds=secs, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, graph_reads=g1.value, rows_reads=g2.value, pog=pog)
+    return dict(bad=bad, binding_seconds=secs, cns=cns, qlt=qlt, alt=alt, msa=(mh, nc.value, nr.value), recs=recs, graph_reads=g1.value, rows_reads=g2.value, pog=pog, snaps=snaps)
 
 
 def run_ref_poa(reads, mode, p, record=True):

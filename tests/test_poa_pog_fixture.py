@@ -1,0 +1,55 @@
+"""The library's own POA graph surface (include/bsalign_poa.h) against tests/golden/poa_pog.npz WITHOUT any reference build (this test also runs where
+oracle/_ref is absent): every aligned read of five windows -- import the reference's flat graph once, then per read the selection list of sel_nodes_bspoa,
+the band placement and auxiliary edges of prepare_rd_align_bspoa, the program byte for byte, the reference's recorded walk replayed as the backend, the
+result of align_rd_bspoa, and after the library's own surgery the whole graph against the reference's graph before the next read."""
+import numpy as np
+import pytest
+
+import pog_fixture as F
+
+
+@pytest.mark.parametrize("c", range(5))
+def test_replay_of_the_references_windows(c):
+    case = F.load()[c]
+    st = F.replay_window(case, F.recorded_walk)
+    took = sum(1 for sn in case["snaps"][:-1] if sn["best"][5])          # reads the graph form took in the recording run: all but a window's first,
+    declined = len(case["snaps"]) - 1 - took                            # whose whole-read band the kernel declines above 256 columns (one re-import then)
+    assert declined <= 1 and st["reads"] == took and st["imports"] == 1 + declined
+    assert st["sel"] > 0 and st["prog_bytes"] > 0 and st["steps"] > 100 * st["reads"]
+
+
+def test_add_read_builds_the_graph_the_reference_starts_from():
+    """bsa_pog_add_read = _add_read_bspoa_core (bspoa.h:916-951): the reads pushed one by one give the first snapshot's structure"""
+    from bsalign_amd import poa as PG
+    case = F.load()[0]
+    sn = case["snaps"][0]
+    pog = PG.Pog(**case["par"])
+    try:
+        for r in range(len(sn["ndoff"])):
+            o, n = int(sn["ndoff"][r]), int(sn["rdlen"][r])
+            assert pog.add_read(sn["nodes"]["base"][o:o + n]) == r
+        assert F.same_structure(pog.export_graph(), sn) is None
+    finally:
+        pog.close()
+
+
+def test_misuse_is_refused():
+    from bsalign_amd import poa as PG
+    import bsalign_amd as B
+    pog = PG.Pog()
+    try:
+        with pytest.raises(B.BsaError):
+            pog.add_read(np.array([0, 1, 7], np.uint8))          # a base code above 3
+        pog.add_read(np.zeros(0, np.uint8)); pog.add_read(np.array([0, 1, 2, 3] * 10, np.uint8)); pog.add_read(np.array([0, 1, 2, 3] * 10, np.uint8))
+        with pytest.raises(B.BsaError):
+            pog.place(0)                                         # place before select
+        with pytest.raises(B.BsaError):
+            pog.select(9, 0, 4)                                  # no such read
+        rd, sel = pog.select(1, 0, 40)
+        assert rd.nsel == 2 and rd.qlen == 40
+        with pytest.raises(B.BsaError):
+            pog.select(2, 0, 40)                                 # a read is already being aligned
+        pog.abort()
+        assert len(pog.aux_edges()) == 0
+    finally:
+        pog.close()
