@@ -20,6 +20,7 @@
 #define BSALIGN_POA_BATCH_H
 
 #include <pthread.h>
+#include <unistd.h>
 #include "bsalign_hip.h"
 #include "bsalign_poa_adapter.h"
 
@@ -30,11 +31,52 @@
 #define BSA_POA_POOL 256         /* window threads alive at once: the batcher runs whatever is pending, so a pool that takes the windows one after the other keeps the host's working set to this many graphs */
 #endif
 
+/* WHEN the device is attached.  One POA is sequential in its reads and a lone wave of the device runs a read's DP several times slower than a host
+ * core; the device pays by running many windows at once.  Measured on the MI355X box (16 host threads, windows of 12 reads x
+ * 1.5 kbp, tests/test_poa_pog_gpu.py::test_where_many_windows_start_to_pay): 1 window 0.042 s on the device path against 0.024 s for the reference,
+ * 16: 0.074 / 0.030, 32: 0.086 / 0.067, 64: 0.117 / 0.123, 128: 0.183 / 0.241.  Below BSA_POA_MIN_WINDOWS windows in flight this binding therefore
+ * leaves BSPOA.devsweep NULL -- the reference's own end_bspoa on host threads, which is this header's caller's code, not a path of libbsalign_hip --
+ * and a single window (C4 as BASELINE states it: 2.8 s on the host, 3.9 s with every read's DP on a lone wave) is never slower than before the patch.
+ * $BSA_POA_MIN_WINDOWS overrides (1 = always the device). */
+#ifndef BSA_POA_MIN_WINDOWS
+#define BSA_POA_MIN_WINDOWS 64
+#endif
+static inline int bsa_poa_min_windows(void){
+	const char *e = getenv("BSA_POA_MIN_WINDOWS");
+	const int v = e ? atoi(e) : BSA_POA_MIN_WINDOWS;
+	return v < 1 ? 1 : v;
+}
+
 typedef struct {
 	BSPOA **gs;
 	int n, t, nt;                                        /* this worker takes windows t, t + nt, ... */
 	bsa_sweep_batcher_t *batcher;
 } bsa_poa_many_job_t;
+
+static void *bsa_poa_host_thread(void *vp){
+	bsa_poa_many_job_t *j = (bsa_poa_many_job_t*)vp;
+	int k;
+	for(k=j->t;k<j->n;k+=j->nt) end_bspoa(j->gs[k]);        /* the reference, untouched (devsweep NULL) */
+	return NULL;
+}
+
+/* too few windows for the device: the reference's end_bspoa on as many host threads as the process may run */
+static inline int bsa_poa_end_on_host(BSPOA **gs, int n){
+	long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+	int nt, k;
+	bsa_poa_many_job_t *jobs; pthread_t *th; char *up;
+	const char *ht = getenv("BSA_POA_HOST_THREADS");
+	if(ht && atoi(ht) > 0) ncpu = atoi(ht);
+	nt = (int)((ncpu < 1) ? 1 : (ncpu > n ? n : ncpu));
+	if(nt <= 1){ for(k=0;k<n;k++) end_bspoa(gs[k]); return BSA_OK; }
+	jobs = (bsa_poa_many_job_t*)calloc((size_t)nt, sizeof(bsa_poa_many_job_t)); th = (pthread_t*)calloc((size_t)nt, sizeof(pthread_t)); up = (char*)calloc((size_t)nt, 1);
+	if(jobs == NULL || th == NULL || up == NULL){ free(jobs); free(th); free(up); for(k=0;k<n;k++) end_bspoa(gs[k]); return BSA_OK; }
+	cal_permutation_bspoa(MAX_LOG_CACHE, 0);             /* (filled lazily by the reference, bspoa.h:3391-3401: before any thread reads it) */
+	for(k=0;k<nt;k++){ jobs[k].gs = gs; jobs[k].n = n; jobs[k].t = k; jobs[k].nt = nt; up[k] = (pthread_create(&th[k], NULL, bsa_poa_host_thread, &jobs[k]) == 0); }
+	for(k=0;k<nt;k++){ if(up[k]) pthread_join(th[k], NULL); else bsa_poa_host_thread(&jobs[k]); }
+	free(jobs); free(th); free(up);
+	return BSA_OK;
+}
 
 static inline void bsa_poa_end_one(BSPOA *g, bsa_ctx_t *ctx);
 
@@ -66,6 +108,7 @@ static inline int bsa_poa_end_many(BSPOA **gs, int n, bsa_ctx_t *ctx){
 	const char *le = getenv("BSA_POA_BATCH_MIN");
 	int k, rc, nt, started = 0;
 	if(n <= 0) return BSA_OK;
+	if(n < bsa_poa_min_windows()) return bsa_poa_end_on_host(gs, n);       /* too few windows in flight for the device to pay (see BSA_POA_MIN_WINDOWS above) */
 	if(le && strcmp(le, "all") == 0 && n > BSA_POA_WAVE){        /* lock-step: at most BSA_POA_WAVE windows (threads) at a time */
 		for(k=0;k<n;k+=BSA_POA_WAVE){ rc = bsa_poa_end_many(gs + k, (n - k < BSA_POA_WAVE)? n - k : BSA_POA_WAVE, ctx); if(rc != BSA_OK) return rc; }
 		return BSA_OK;
@@ -102,9 +145,10 @@ static inline int bsa_poa_end_many(BSPOA **gs, int n, bsa_ctx_t *ctx){
 	return BSA_OK;
 }
 
-/* end_bspoa of one window with its sweeps on the device */
+/* end_bspoa of one window: on the device only when a single window is what BSA_POA_MIN_WINDOWS allows (the default does not: one window is faster on the host) */
 static inline void bsa_poa_end_one(BSPOA *g, bsa_ctx_t *ctx){
 	bsa_poa_adapter_t ad;
+	if(1 < bsa_poa_min_windows()){ end_bspoa(g); return; }
 	bsa_poa_adapter_init_graph(&ad, bsa_poa_graph_backend_hip, bsa_poa_backend_hip, ctx);
 	bsa_poa_adapter_use_pog(&ad, 1);
 	g->devsweep = &ad;

@@ -31,7 +31,7 @@ def _declared_symbols():
 
 def test_library_exports_every_declared_symbol():
     import bsalign_amd as B
-    libs = {"bsalign_hip.h": C.CDLL(B.LIB_PATH), "bsalign_msa.h": C.CDLL(B.LIB_PATH)}
+    libs = {"bsalign_hip.h": C.CDLL(B.LIB_PATH), "bsalign_msa.h": C.CDLL(B.LIB_PATH), "bsalign_poa.h": C.CDLL(B.LIB_PATH)}
     compat = os.path.join(ROOT, "bsalign_amd", "libbsalign_compat.so")
     if os.path.exists(compat):
         libs["bsalign_compat.h"] = C.CDLL(compat)

@@ -75,7 +75,8 @@ def _same(a, b):
         assert all(np.array_equal(x[k], y[k]) for k in range(3)) and x[3] == y[3], w
 
 
-def test_patched_end_bspoa_one_window_and_many(ctx):
+def test_patched_end_bspoa_one_window_and_many(ctx, monkeypatch):
+    monkeypatch.setenv("BSA_POA_MIN_WINDOWS", "1")          # the device whatever the number of windows (the default attaches it from 64 windows in flight)
     L = _lib(ctx)
     p = P.par()
     rng = np.random.default_rng(3)
@@ -89,7 +90,29 @@ def test_patched_end_bspoa_one_window_and_many(ctx):
         assert np.array_equal(cns, d["cns"]) and np.array_equal(qlt, d["qlt"]) and np.array_equal(alt, d["alt"])
 
 
-def test_refinement_dp_on_the_device_inside_end_bspoa(ctx):
+def test_few_windows_stay_on_the_host_and_one_window_is_never_slower(ctx, capsys):
+    """the binding's policy (include/bsalign_poa_batch.h, BSA_POA_MIN_WINDOWS = 64, measured): below that many windows in flight bsa_poa_end_many / _end_one
+    leave the device unattached -- the reference's own end_bspoa on host threads.  Identical results, and BASELINE's C4 as stated (ONE window of 64 x 20 kbp)
+    through bsa_poa_end_one takes no longer than the untouched end_bspoa (it was 30 % slower with the device forced)"""
+    import time
+    L = _lib(ctx)
+    p = P.par()
+    rng = np.random.default_rng(4)
+    windows = [P.synth_reads(900 + w, int(rng.integers(300, 1200)), int(rng.integers(4, 12)), eps=(0.1,)) for w in range(12)]
+    ref = _run(L, windows, p, 0)
+    _same(ref, _run(L, windows, p, 2))
+    _same(ref, _run(L, windows[:2], p, 1))
+    big = [P.synth_reads(20240611 & 0xFFFF, 20000, 64, eps=(0.1,))]
+    t0 = time.time(); a = _run(L, big, p, 0); t_ref = time.time() - t0
+    t0 = time.time(); b = _run(L, big, p, 1); t_one = time.time() - t0
+    _same(a, b)
+    with capsys.disabled():
+        print("\n[C4 as stated, bsa_poa_end_one under the binding's default policy] reference end_bspoa %.2f s, bsa_poa_end_one %.2f s" % (t_ref, t_one))
+    assert t_one <= 1.15 * t_ref + 0.2
+
+
+def test_refinement_dp_on_the_device_inside_end_bspoa(ctx, monkeypatch):
+    monkeypatch.setenv("BSA_POA_MIN_WINDOWS", "1")
     """patches/bspoa_device_diagdp.diff + include/bsalign_poa_diagdp.h: end_bspoa with remsa_pedits filling the DP matrices of
     all reads of a window in one bsa_diagdp_batch call (how = 3), and with the graph sweeps on the device as well (how = 4):
     consensus, qualities, alternative bases and MSA of the untouched run"""

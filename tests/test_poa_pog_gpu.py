@@ -97,3 +97,39 @@ def test_c4_full_size_on_the_librarys_graph(ctx, capsys):
         print("\n[C4 full size, clean] end_bspoa 64 x 20 kbp: reference %.2f s; on the library's own graph %.2f s (%d reads, %d declined; binding: mirror %.2f s, guide alignment + "
               "columns %.2f s, inside the library %.2f s [select %.2f, place %.2f, program %.2f, device call %.2f, surgery %.2f], reference-side surgery %.2f s); round-4 binding %.2f s"
               % (t_ref, t_dev, g["reads"], g["declined"], bs[0], bs[1], bs[2], ls[0], ls[1], ls[2], ls[3], ls[4], bs[3], t_old))
+
+
+def test_replay_of_the_fixture_windows_on_the_device(ctx):
+    """tests/golden/poa_pog.npz without any reference build: the library's graph from the first snapshot, every read's selection / placement / program against
+    the reference's recorded decisions, the program run on the MI355X -- best end cell and every step of the walk against the reference's own recorded walk --,
+    the library's surgery, and the whole graph against the reference's before the next read"""
+    import pog_fixture as F
+    for case in F.load():
+        st = F.replay_window(case, lambda pog, sn: pog.run(ctx=ctx))
+        assert st["reads"] >= len(case["snaps"]) - 2 and st["steps"] > 100 * st["reads"]
+
+
+def test_where_many_windows_start_to_pay(ctx, capsys):
+    """how many windows have to be in flight before the device path beats the reference on the host's cores: n windows x 12 reads x 1.5 kbp through the
+    batcher on the library's graph against the reference's end_bspoa on min(n, 16) host threads (identical results); the table behind BSA_POA_MIN_WINDOWS of
+    include/bsalign_poa_batch.h"""
+    from test_poa_batched_gpu import Batcher, _compare
+    p = P.par()
+    P.attach_product(P.ref_poa())
+    allw = [P.synth_reads(7000 + w, 1500, 12, eps=(0.1,)) for w in range(128)]
+    rows = []
+    for n in (1, 2, 4, 8, 16, 32, 64, 128):
+        windows = allw[:n]
+        ref, t_ref = P.run_many(windows, 0, p, threads=min(n, 16))
+        best = 1e9
+        for _ in range(2):
+            bt = Batcher(ctx, n)
+            try:
+                dev, t_dev = P.run_many(windows, 10, p)
+            finally:
+                bt.close()
+            _compare(ref, dev)
+            best = min(best, t_dev)
+        rows.append((n, t_ref, best))
+    with capsys.disabled():
+        print("\n[windows in flight] " + "; ".join("%d: reference %.3f s, device path %.3f s" % r for r in rows))
