@@ -24,7 +24,7 @@ def _declared_symbols():
         # prototypes: identifier followed by '(' at declaration level, terminated by ';'
         for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text):
             name = m.group(1)
-            if name not in ("sizeof",):
+            if name not in ("sizeof", "int", "void"):          # (int / void: the return type of a function-pointer typedef)
                 names.add((fn, name))
     return names
 
