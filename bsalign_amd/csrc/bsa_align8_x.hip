@@ -140,9 +140,11 @@ static __device__ __forceinline__ void x_load_qcodes(const uint8_t *p, uint32_t 
 // DO2 (one-piece gaps with 1 <= -gapo <= 3, bandwidth 128; Align8Args::code_fmt == 1): D and Od of a cell leave as ONE two-bit field,
 // the new e-difference min(h - ee, -gapo) itself (0: D, -gapo: Od) -- one multiply-add a cell where the two planes take four
 // instructions.  A reference block's dword is then M | R << 8 | field of cell c at bits 31 - 2c, 30 - 2c (bsa_common.h).
-template<int W, int L, int PW = 1, bool STATIC = false, int NWV = 4, bool DO2 = false>
+// EXT: the two LDS areas come from the caller (k_align8_fwd_x_mix runs two shapes of this function in one launch and a block only ever one of
+// them: they share the areas instead of each instantiation carrying its own).
+template<int W, int L, int PW = 1, bool STATIC = false, int NWV = 4, bool DO2 = false, bool EXT = false>
 static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint32_t first_pos, const uint32_t count, const uint32_t tid_base,
-		const uint32_t row0 = 0u, const uint32_t row1 = 0xFFFFFFF8u, uint32_t *st = nullptr){
+		const uint32_t row0 = 0u, const uint32_t row1 = 0xFFFFFFF8u, uint32_t *st = nullptr, uint32_t *ext_stage = nullptr, uint32_t *ext_qwin = nullptr){
 	constexpr int BW = 2 * L * W;
 	constexpr int WR = BW / 16, CR = 8 / L;
 	static_assert((L == 8 || L == 4) && W * L / 8 == WR && (CR == 1 || (CR == 2 && (W == 16 || W == 8))), "supported shapes");
@@ -265,8 +267,25 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		PN = sp[64 * r++]; PM = sp[64 * r++]; HB = (int)sp[64 * r++]; svU = sp[64 * r++]; svNE = sp[64 * r++]; svNQ = sp[64 * r++];
 		rbeg = sp[64 * r++]; mov = sp[64 * r++]; cand_sc = (int)sp[64 * r++]; cand_te = (int)sp[64 * r++];
 	}
-	__shared__ uint32_t x_stage[NWV][4 * ND][64];       // [wave][4 q + row of the group (CWD == 1) | ND row + dword (CWD >= 2)][lane]
-	uint32_t *const stg = &x_stage[(NWV > 1) ? (lt >> 6) : 0][0][lt & 63];
+	__shared__ uint32_t x_stage[EXT ? 1 : NWV][EXT ? 1 : 4 * ND][64];       // [wave][4 q + row of the group (CWD == 1) | ND row + dword (CWD >= 2)][lane]
+	uint32_t *const stg = EXT ? ext_stage + (size_t)(lt >> 6) * (4 * ND * 64) + (lt & 63) : &x_stage[(!EXT && NWV > 1) ? (lt >> 6) : 0][0][lt & 63];
+	// QUERY WINDOW (round 5).  A lane needs the W query codes of each of its two blocks on every row, at a band offset that moves by about one base a
+	// row: loaded from memory row by row that is one full round trip the wave waits for per row -- and `vmcnt` also holds the row's wait back behind the
+	// code-row stores in flight (a second such round trip per row, added as an experiment, cost 5.4 ms of the 61: 9 %).  Instead the lane keeps, in LDS
+	// slots of its own (no synchronisation, like the staging above), KD dwords per block starting at the band offset of the last refill: a row reads
+	// NQ + 1 of them at the dword its offset has reached and shifts them into place (v_alignbyte), and only every 4 KD - W - 3 bases of band movement
+	// (about 45 rows) the window is loaded again.  The staged query is padded far enough behind its end (plan: bandwidth + 32 bytes).
+#ifdef XQ_NO_QWIN
+	constexpr bool QWIN = false;
+#else
+	constexpr bool QWIN = !STATIC && PW != 2 && W == 16;      // (measured: two-piece gaps at 251 registers lose 3 % with it, eight cells a half gain nothing)
+#endif
+	constexpr int KD = NQ + 12;                           // dwords per block in the window: 48 bytes of band movement between refills
+	constexpr uint32_t QOFFMAX = 4u * (uint32_t)(KD - NQ - 1) + 3u;      // the last offset at which dwords k .. k + NQ are all inside
+	static_assert(!QWIN || 4 * KD - W <= 96, "the window reads behind the band: the staged query's padding (bsa_api.hip: qpad = bandwidth + 32) must cover it");
+	__shared__ uint32_t x_qwin[(QWIN && !EXT) ? NWV : 1][(QWIN && !EXT) ? 2 * KD : 1][64];
+	uint32_t *const qwp = EXT ? ext_qwin + (size_t)(lt >> 6) * (2 * KD * 64) + (lt & 63) : &x_qwin[(QWIN && !EXT && NWV > 1) ? (lt >> 6) : 0][0][lt & 63];
+	uint32_t wbase = 0x40000000u;                          // band offset the window starts at (this value: no window yet)
 	int begq = 0;
 	if(tlen != 0u && first && row0 == 0u) begs[0] = 0;
 	uint64_t twin = 0;
@@ -368,6 +387,29 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			if constexpr (STATIC){
 #pragma unroll
 				for(int n = 0; n < NQ; n++){ qlo[n] = act ? sqlo[n] : 0x04040404u; qhi[n] = act ? sqhi[n] : 0x04040404u; }
+			} else if constexpr (QWIN){
+				uint32_t off = rbeg - wbase;
+				if(__any(act && off > QOFFMAX)){
+					// refill: KD dwords of each block from the band offset of this row
+					if(act && off > QOFFMAX){
+						const uint8_t *pl = qp + rbeg + jl * W, *ph = qp + rbeg + (jl + L) * W;
+						uint32_t bl[KD], bh[KD];
+						__builtin_memcpy(bl, pl, 4 * KD); __builtin_memcpy(bh, ph, 4 * KD);
+#pragma unroll
+						for(int m = 0; m < KD; m++){ qwp[64 * m] = bl[m]; qwp[64 * (KD + m)] = bh[m]; }
+						wbase = rbeg; off = 0u;
+					}
+				}
+				const uint32_t kq = act ? (off >> 2) : 0u;
+				const uint32_t *wl = qwp + 64u * kq;
+				uint32_t dl[NQ + 1], dh[NQ + 1];
+#pragma unroll
+				for(int n = 0; n <= NQ; n++){ dl[n] = wl[64 * n]; dh[n] = wl[64 * (KD + n)]; }
+#pragma unroll
+				for(int n = 0; n < NQ; n++){
+					const uint32_t vl = __builtin_amdgcn_alignbyte(dl[n + 1], dl[n], off), vh = __builtin_amdgcn_alignbyte(dh[n + 1], dh[n], off);
+					qlo[n] = vl; qhi[n] = vh;          // (a lane whose pair has no row left computes on whatever its window holds: nothing of it is stored)
+				}
 			} else if(act){ x_load_qcodes<W>(qp + rbeg + jl * W, qlo); x_load_qcodes<W>(qp + rbeg + (jl + L) * W, qhi); }
 			else {
 #pragma unroll
@@ -790,6 +832,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			svU = tmpU0; svNE = tmpNE0;
 		}
 		i++;
+		// (the next eight target bases.  The compiler waits for them at the top of the next row, with `s_waitcnt vmcnt(0)` on every row; forcing the wait
+		// into this branch instead -- once per eight rows, fully exposed -- was measured slower: 60.0 against 59.8 ms, two-piece gaps 129.8 against 127.1)
 		if((i & 7u) == 0u && i < tlen) __builtin_memcpy(&twin, tp + i, 8);
 	}
 	if(st != nullptr && row1 < tlen){
@@ -840,8 +884,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
 // first and the dispatcher hands the long ones to whichever CU has room, so pairs of one length no longer finish in
 // lock-step rounds with a nearly empty last one.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_align8_fwd_x_mix(const Align8Args a, const uint32_t nb8, const uint32_t n8){
-	if(blockIdx.x < nb8) x_forward<8, 8>(a, a.first + (a.count - n8), n8, blockIdx.x * 256u);
-	else x_forward<16, 4>(a, a.first, a.count - n8, (blockIdx.x - nb8) * 256u);
+	// one staging area and one query window for both shapes (four waves; <16, 4> is the larger: 16 code dwords and 2 x 16 window dwords a lane)
+	__shared__ uint32_t mix_stage[4 * 16 * 64], mix_qwin[4 * 32 * 64];
+	if(blockIdx.x < nb8) x_forward<8, 8, 1, false, 4, false, true>(a, a.first + (a.count - n8), n8, blockIdx.x * 256u, 0u, 0xFFFFFFF8u, nullptr, mix_stage, mix_qwin);
+	else x_forward<16, 4, 1, false, 4, false, true>(a, a.first, a.count - n8, (blockIdx.x - nb8) * 256u, 0u, 0xFFFFFFF8u, nullptr, mix_stage, mix_qwin);
 }
 
 // PERSISTENT form for batches of more than one generation of resident waves.  A pair's rows are serial and pairs of one length finish
