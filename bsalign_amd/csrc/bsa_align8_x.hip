@@ -299,6 +299,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	}
 	const int rbz = 2 * max((int)(tlen / max(qlen, 1u)), 1);          // bsalign.h:4008
 	const bool rush32 = (unsigned long long)(uint32_t)rbz * tlen + qlen + (uint32_t)BW + (uint32_t)rbz < 0xFFFFFFFFull;
+	// rbz * (rows left after this one), kept by subtraction: a 32-bit multiplication is a quarter-rate instruction and this one sat in every row
+	uint32_t rzl = rush32 ? (uint32_t)rbz * (tlen - min(row0, tlen) - 1u) : 0u;
 	int rby_tab = 0;
 	const int rby_lane = (lt & (64 - L)) << 2;                   // byte address of lane 0 of this group for ds_bpermute
 	const uint32_t kd1 = last ? 0x01000000u : 0u;          // band cell bw - 1 after a slide by one: x == bw, no deletion there (bsalign.h:3672-3678)
@@ -804,7 +806,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				const int rby = __builtin_amdgcn_ds_bpermute(rby_lane + (int)((i & (uint32_t)(L - 1)) << 2), rby_tab);
 				const uint32_t left = tlen - i - 1u;
 				bool rush;
-				if(rush32) rush = act && rbeg + (uint32_t)rbz * left + (uint32_t)BW <= qlen + (uint32_t)rbz - 1u;
+				if(rush32) rush = act && rbeg + rzl + (uint32_t)BW <= qlen + (uint32_t)rbz - 1u;
 				else {
 					const unsigned long long lhs = (unsigned long long)rbeg + (unsigned long long)(uint32_t)rbz * left + (unsigned long long)BW;
 					rush = act && lhs <= (unsigned long long)(uint32_t)(qlen + (uint32_t)rbz - 1u);
@@ -832,6 +834,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			svU = tmpU0; svNE = tmpNE0;
 		}
 		i++;
+		rzl -= (uint32_t)rbz;          // (meaningless once the pair has no row left: only read under `act`)
 		// (the next eight target bases.  The compiler waits for them at the top of the next row, with `s_waitcnt vmcnt(0)` on every row; forcing the wait
 		// into this branch instead -- once per eight rows, fully exposed -- was measured slower: 60.0 against 59.8 ms, two-piece gaps 129.8 against 127.1)
 		if((i & 7u) == 0u && i < tlen) __builtin_memcpy(&twin, tp + i, 8);
