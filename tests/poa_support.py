@@ -271,6 +271,14 @@ def run_many(windows, mode, p, threads=8, record=False):
     except AttributeError:
         pass
     run_many.last_binding_seconds = bs          # summed over the windows: building programs, inside the backend (waiting), applying walks
+    run_many.last_pog_seconds = None
+    if mode >= 8 and getattr(r, "_product_attached", False):
+        tot = np.zeros(9)
+        for h in hs:
+            one = np.zeros(9)
+            r.ref_poa_pog_seconds(h, one.ctypes.data)
+            tot += one
+        run_many.last_pog_seconds = tot         # binding: mirror, guide + columns, inside the library, reference-side surgery; library: select, place, program, run, apply
     for h in hs:
         n = r.ref_poa_cns_len(h)
         cns, qlt, alt = (np.zeros(n, np.uint8) for _ in range(3))
