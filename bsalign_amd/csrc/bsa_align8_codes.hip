@@ -436,8 +436,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	rs.score = __builtin_amdgcn_readfirstlane(rs.score); rs.qe = __builtin_amdgcn_readfirstlane(rs.qe); rs.te = __builtin_amdgcn_readfirstlane(rs.te);
 	{ const int lb = begs[rs.te + 1]; if(rs.qe < lb || rs.qe >= lb + bw) bad = true; }
 	int x = rs.qe, y = rs.te;
+	const int x_start = x, y_start = y;
 	rs.qe++; rs.te++;
 	int prior = 0, dlen = 0;
+	uint32_t vmis = 0;                                 // this lane's mismatch count (summed over the wave at the end)
 	// ---- tiles
 	struct TB { int bc, bp; uint32_t tb; };
 	struct TC { uint32_t v0, v1, v2, v3, v4, v5, v6, v7; int b0; };    // W = 8: rows 0..3 of one block; W = 4: of two blocks; W = 16: two rows x two dwords
@@ -572,7 +574,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const uint32_t sh = (uint32_t)(shK - xs);                     // 31 - c; c < 32 <=> sh < 32
 			const uint32_t qb = (uint32_t)s_q[xs - qKr];
 			const uint64_t mM = __ballot((int)(RM << (sh & 31u)) < 0) & __ballot(sh < 32u);
-			const uint64_t mNE = __ballot(qb != tbs);
+			const bool ne_l = qb != tbs;
+			const uint64_t mNE = __ballot(ne_l);
 			const uint32_t c = (31u - sh) & 31u;
 			uint32_t info;                                                          // D, Od of the lane's cell
 			if constexpr (FMT == 1){
@@ -591,9 +594,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
 			const int n = k - k0;
 			if(n > 0){
-				const uint64_t range = (~0ull >> ((64 - k) & 63)) & ~(k0bit - 1ull);      // lanes k0 .. k-1 (1 <= k <= 64)
-				const int mism = __popcll(mNE & range);
-				rs.mat += n - mism; rs.mis += mism;
+				// match / mismatch columns: the run's length goes to a scalar count, its mismatches to a count of the lane's own (lanes k0 .. k - 1 each add their
+				// base comparison: vector work on a unit the walk leaves idle, where mask, popcount and three additions were ten instructions of the scalar unit it is bound by)
+				rs.mat += n;
+				vmis += ((uint32_t)((int)lane - k0) < (uint32_t)n && ne_l) ? 1u : 0u;
 				emit(0u, (uint32_t)n);
 				x -= n; y -= n;
 			}
@@ -604,13 +608,13 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const uint32_t shk = (uint32_t)__builtin_amdgcn_readlane((int)sh, k);
 			if(shk < 32u && prior){
 				if(dlen){
-					emit(2u, 1u); rs.del++; y--; k0 = k + 1;
+					emit(2u, 1u); y--; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
 				const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)info, k);
 				if(ik & 1u){
-					emit(2u, 1u); rs.del++; y--; dlen = 1; k0 = k + 1;
+					emit(2u, 1u); y--; dlen = 1; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
@@ -620,7 +624,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 					if(cand){
 						const int sz = (int)ck - (31 - (int)__builtin_clz(cand));
 						emit(1u, (uint32_t)sz);
-						x -= sz; rs.ins += sz; k0 = k;
+						x -= sz; k0 = k;
 						if(x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 						continue;
 					}
@@ -651,7 +655,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const Code wck = code_at(yb);
 			if(dlen){
 				if(wck.o & bit) dlen = 0;
-				else { emit(2u, 1u); rs.del++; y--; k0 = k + 1; if(k0 > 63) break; continue; }
+				else { emit(2u, 1u); y--; k0 = k + 1; if(k0 > 63) break; continue; }
 			}
 			const bool pmatch = prior && !(x == bpk && x != 0);
 			const bool fm = (wck.m & bit) != 0u, fd = (wck.d & bit) != 0u;
@@ -660,11 +664,11 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			else bt = fd ? 2 : fm ? 0 : 1;
 			prior = 1;
 			if(bt == 0){
-				if((mNE >> k) & 1ull) rs.mis++; else rs.mat++;
+				rs.mat++; vmis += ((int)lane == k && ne_l) ? 1u : 0u;
 				emit(0u, 1u);
 				x--; y--; k0 = k + 1;
 			} else if(bt == 1){
-				if(x <= 0){ emit(1u, 1u); x--; rs.ins++; }
+				if(x <= 0){ emit(1u, 1u); x--; }
 				else {
 					int sz = 0;
 					const uint32_t cand = wck.r & ~((bit << 1) - 1u) & FULL;
@@ -679,12 +683,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 						if(sz == 0){ bad = true; walking = false; break; }  // the reference's scan finds no length either
 					}
 					emit(1u, (uint32_t)sz);
-					x -= sz; rs.ins += sz;
+					x -= sz;
 				}
 				k0 = k;
 				if(x >= 0 && x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 			} else {
-				emit(2u, 1u); rs.del++;
+				emit(2u, 1u);
 				y--; dlen = 1; k0 = k + 1;
 			}
 			if(k0 > 63) break;
@@ -696,6 +700,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	if(!bad && dlen && y < 0 && (!lin || x >= bw)) bad = true;        // a deletion run that reached row -1: see the general step of the LDS kernel
 	if(!bad){
 		rs.qb = x; rs.tb = y;
+		{
+			// rs.mat holds the match / mismatch columns of the walk: the gaps follow from its two ends, the mismatches from the lanes' counts
+			const int mcols = rs.mat;
+			uint32_t t = vmis;
+			t += (uint32_t)__shfl_xor((int)t, 32); t += (uint32_t)__shfl_xor((int)t, 16); t += (uint32_t)__shfl_xor((int)t, 8);
+			t += (uint32_t)__shfl_xor((int)t, 4); t += (uint32_t)__shfl_xor((int)t, 2); t += (uint32_t)__shfl_xor((int)t, 1);
+			rs.mis = __builtin_amdgcn_readfirstlane((int)t); rs.mat = mcols - rs.mis;
+			rs.ins = (x_start - x) - mcols; rs.del = (y_start - y) - mcols;
+		}
 		if(type != BSA_MODE_OVERLAP){
 			uint32_t op = 0, sz = 0;
 			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
@@ -1094,8 +1107,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 	}
 	{ const int lb = begs[rs.te + 1]; if(rs.qe < lb || rs.qe >= lb + bw) bad = true; }
 	int x = rs.qe, y = rs.te;
+	const int x_start = x, y_start = y;
 	rs.qe++; rs.te++;
 	int prior = 0, dlen = 0;                                        // dlen: the piece (1, 2) of an open deletion run
+	uint32_t vmis = 0;                                              // this lane's mismatch count (summed over the wave at the end)
 	struct TB { int bc, bp; uint32_t tb; };
 	struct TC { uint32_t v0, v1, v2, v3, v4, v5, v6, v7; int b0; };    // rows 0..3 of one block, two dwords each
 	auto fetch_begs = [&](int T, TB &t){
@@ -1176,7 +1191,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 			const uint32_t sh = (uint32_t)(shK - xs);
 			const uint32_t qb = (uint32_t)s_q[xs - qKr];
 			const uint64_t mM = __ballot((int)(RM << (sh & 31u)) < 0) & __ballot(sh < 32u);
-			const uint64_t mNE = __ballot(qb != tbs);
+			const bool ne_l = qb != tbs;
+			const uint64_t mNE = __ballot(ne_l);
 			const uint32_t c = (31u - sh) & 31u;
 			const uint32_t info = ((PD >> c) & 1u) | (((PD2 >> c) & 1u) << 1) | (((PO1 >> c) & 1u) << 2) | (((PO2 >> c) & 1u) << 3);
 			const uint64_t k0bit = 1ull << k0;
@@ -1190,9 +1206,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
 			const int n = k - k0;
 			if(n > 0){
-				const uint64_t range = (~0ull >> ((64 - k) & 63)) & ~(k0bit - 1ull);
-				const int mism = __popcll(mNE & range);
-				rs.mat += n - mism; rs.mis += mism;
+				// match / mismatch columns: the run's length goes to a scalar count, its mismatches to a count of the lane's own (lanes k0 .. k - 1 each add their
+				// base comparison: vector work on a unit the walk leaves idle, where mask, popcount and three additions were ten instructions of the scalar unit it is bound by)
+				rs.mat += n;
+				vmis += ((uint32_t)((int)lane - k0) < (uint32_t)n && ne_l) ? 1u : 0u;
 				emit(0u, (uint32_t)n);
 				x -= n; y -= n;
 			}
@@ -1201,14 +1218,14 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 			const uint32_t shk = (uint32_t)__builtin_amdgcn_readlane((int)sh, k);
 			if(shk < 32u && prior){
 				if(dlen){
-					emit(2u, 1u); rs.del++; y--; k0 = k + 1;
+					emit(2u, 1u); y--; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
 				const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)info, k);
 				if(ik & 3u){                                                // not M and D or D2 set: a deletion of that piece opens
 					if(x == 0){ bad = true; walking = false; break; }         // (at query column 0 the flags cannot tell: k_align8_trace_codes2)
-					emit(2u, 1u); rs.del++; y--; dlen = (ik & 1u) ? 1 : 2; k0 = k + 1;
+					emit(2u, 1u); y--; dlen = (ik & 1u) ? 1 : 2; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
@@ -1228,7 +1245,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 						const bool h1 = ch1 && ((r1k >> hp) & 1u), h2 = ch2 && ((r2k >> hp) & 1u);
 						if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))){ bad = true; walking = false; break; }
 						emit(1u, (uint32_t)sz);
-						x -= sz; rs.ins += sz; k0 = k;
+						x -= sz; k0 = k;
 						if(x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 						continue;
 					}
@@ -1251,7 +1268,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 			const uint2 cc = code_at(yb);
 			if(dlen){
 				if((cc.y >> (dlen == 2 ? 24 : 16)) & bit) dlen = 0;
-				else { emit(2u, 1u); rs.del++; y--; k0 = k + 1; if(k0 > 63) break; continue; }
+				else { emit(2u, 1u); y--; k0 = k + 1; if(k0 > 63) break; continue; }
 			}
 			const bool pmatch = prior && !(x == bpk && x != 0);
 			const bool fA = (cc.x & bit) != 0u, fD = ((cc.x >> 8) & bit) != 0u, fD2 = ((cc.x >> 16) & bit) != 0u, fB = ((cc.x >> 24) & bit) != 0u;
@@ -1262,11 +1279,11 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 			else bt = d ? 2 : fM ? 0 : 1;
 			prior = 1;
 			if(bt == 0){
-				if((mNE >> k) & 1ull) rs.mis++; else rs.mat++;
+				rs.mat++; vmis += ((int)lane == k && ne_l) ? 1u : 0u;
 				emit(0u, 1u);
 				x--; y--; k0 = k + 1;
 			} else if(bt == 1){
-				if(x <= 0){ emit(1u, 1u); x--; rs.ins++; }
+				if(x <= 0){ emit(1u, 1u); x--; }
 				else {
 					const bool ch1 = fB, ch2 = fA == fB;
 					auto rplane = [&](const uint2 &w) -> uint32_t { return ((ch1 ? w.y : 0u) | (ch2 ? (w.y >> 8) : 0u)) & 0xFFu; };
@@ -1290,13 +1307,13 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 						if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))){ bad = true; walking = false; break; }
 					}
 					emit(1u, (uint32_t)sz);
-					x -= sz; rs.ins += sz;
+					x -= sz;
 				}
 				k0 = k;
 				if(x >= 0 && x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 			} else {
 				if(x == 0){ bad = true; walking = false; break; }             // (query column 0: k_align8_trace_codes2)
-				emit(2u, 1u); rs.del++;
+				emit(2u, 1u);
 				y--; dlen = d; k0 = k + 1;
 			}
 			if(k0 > 63) break;
@@ -1308,6 +1325,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 	if(!bad && dlen && y < 0) bad = true;                            // a deletion run that reached row -1: the reference compares real scores there -- literal path
 	if(!bad){
 		rs.qb = x; rs.tb = y;
+		{
+			// rs.mat holds the match / mismatch columns of the walk: the gaps follow from its two ends, the mismatches from the lanes' counts
+			const int mcols = rs.mat;
+			uint32_t t = vmis;
+			t += (uint32_t)__shfl_xor((int)t, 32); t += (uint32_t)__shfl_xor((int)t, 16); t += (uint32_t)__shfl_xor((int)t, 8);
+			t += (uint32_t)__shfl_xor((int)t, 4); t += (uint32_t)__shfl_xor((int)t, 2); t += (uint32_t)__shfl_xor((int)t, 1);
+			rs.mis = __builtin_amdgcn_readfirstlane((int)t); rs.mat = mcols - rs.mis;
+			rs.ins = (x_start - x) - mcols; rs.del = (y_start - y) - mcols;
+		}
 		if(type != BSA_MODE_OVERLAP){              // global / extend: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
 			uint32_t op = 0, sz = 0;
 			if(rs.qb >= 0){ op = 1; sz = (uint32_t)rs.qb + 1u; rs.ins += (int)sz; rs.qb = -1; }
