@@ -396,34 +396,38 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	// tokens into words side by side: an M word when the run is not empty, then the gap's word, positions from two prefix popcounts
 	// (word m at cig_end - (m + 1)).  The word sequence is the reference's run-length merge (bsalign.h:409-417) of the same op stream.
 	uint32_t ncig = 0, tokN = 0, tokB = 0;            // words written; the lane's token: run length, len << 2 | op (op 0: none)
-	uint32_t ntok = 0, lastop = 0, carryM = 0;        // (uniform) tokens held, op of the last one, matches since the last event
+	// (uniform) tokens held; key = op of the last token << 28 | match / mismatch columns since it (a walk has fewer than 2^26 columns: bsa_api.hip
+	// sends longer queries to the literal kernels), so that "same op, nothing in between" is one compare
+	uint32_t ntok = 0, key = 0;
+	constexpr uint32_t KEYM = 0x0FFFFFFFu;
 	auto tok_flush = [&](uint32_t cnt){
 		const bool in = lane < cnt;
+		tokN &= KEYM;
 		const bool hasA = in && tokN != 0u, hasB = in && (tokB & 3u) != 0u;
 		const uint64_t mA = __ballot(hasA), mB = __ballot(hasB);
 		const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u))
 			+ __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
 		uint32_t *wp = cig_end - (ncig + below + 1u);
-		if(hasA){ *wp = tokN << 4; wp--; }
+		if(hasA){ *wp = tokN << 4; wp--; }                // (tokN: already without the key's op field)
 		if(hasB) *wp = ((tokB >> 2) << 4) | (tokB & 3u);
 		ncig += (uint32_t)(__popcll(mA) + __popcll(mB));
 	};
 	auto emit = [&](uint32_t op, uint32_t len){
-		if(op == 0u){ carryM += len; return; }
-		if(carryM == 0u && op == lastop){ if(lane + 1u == ntok) tokB += len << 2; return; }
+		if(op == 0u){ key += len; return; }
+		if(key == (op << 28)){ if(lane + 1u == ntok) tokB += len << 2; return; }
 		if(ntok == 64u){
 			tok_flush(63u);
 			tokN = (uint32_t)__builtin_amdgcn_readlane((int)tokN, 63); tokB = (uint32_t)__builtin_amdgcn_readlane((int)tokB, 63);
 			ntok = 1u;
 		}
-		if(lane == ntok){ tokN = carryM; tokB = (len << 2) | op; }
-		ntok++; lastop = op; carryM = 0u;
+		if(lane == ntok){ tokN = key; tokB = (len << 2) | op; }       // (the op field of the key is masked off when the token is written)
+		ntok++; key = op << 28;
 	};
 	auto cig_finish = [&](){                          // the matches behind the last event, then everything out
-		if(carryM){
+		if(key & KEYM){
 			if(ntok == 64u){ tok_flush(64u); ntok = 0u; }
-			if(lane == ntok){ tokN = carryM; tokB = 0u; }
-			ntok++; carryM = 0u; lastop = 0u;
+			if(lane == ntok){ tokN = key; tokB = 0u; }
+			ntok++; key = 0u;
 		}
 		tok_flush(ntok); ntok = 0u;
 	};
@@ -438,7 +442,10 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	int x = rs.qe, y = rs.te;
 	const int x_start = x, y_start = y;
 	rs.qe++; rs.te++;
-	int prior = 0, dlen = 0;
+	// prior: prior_match of the reference (0 only before the first step); dl31: bit 31 set while a deletion run is open.  Both are kept in the
+	// form the lanes' tests use them in, so that a step of the walk costs the scalar unit no selects
+	int prior = 0;
+	uint32_t dl31 = 0u, plim = 0u;                     // plim: 32 once prior_match holds (window cells c < plim take the fast paths)
 	uint32_t vmis = 0;                                 // this lane's mismatch count (summed over the wave at the end)
 	// ---- tiles
 	struct TB { int bc, bp; uint32_t tb; };
@@ -569,13 +576,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		const int shK = 31 + (int)lane + cb;                            // 31 - c = shK - xs for the lane's window cell c = xs - lane - cb
 		if(x + k0 - 63 < qw_lo && qw_lo > 0) q_refill(x);               // the query bases of all 64 cells are in the window
 		int qKr = (int)lane + qw_lo;                                    // index into s_q = xs - qKr
+		uint32_t RMe = prior ? RM : 0u;                                 // the M plane as the walk sees it: empty until prior_match holds
 		while(true){
 			const int xs = x + k0;
 			const uint32_t sh = (uint32_t)(shK - xs);                     // 31 - c; c < 32 <=> sh < 32
 			const uint32_t qb = (uint32_t)s_q[xs - qKr];
-			const uint64_t mM = __ballot((int)(RM << (sh & 31u)) < 0) & __ballot(sh < 32u);
-			const bool ne_l = qb != tbs;
-			const uint64_t mNE = __ballot(ne_l);
+			const uint32_t nei = qb != tbs ? 1u : 0u;
 			const uint32_t c = (31u - sh) & 31u;
 			uint32_t info;                                                          // D, Od of the lane's cell
 			if constexpr (FMT == 1){
@@ -583,38 +589,36 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 				info = (raw == 0u ? 1u : 0u) | (raw == NGOS ? 2u : 0u);
 				info = (c == qc) ? qinfo : info;
 			} else info = ((RD >> c) & 1u) | (((RO >> c) & 1u) << 1);
-			const uint64_t k0bit = 1ull << k0;
-			uint64_t stopm = ~(mM | (k0bit - 1ull));
-			if(dlen){
-				const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)info, k0), sh0 = (uint32_t)__builtin_amdgcn_readlane((int)sh, k0);
-				if(sh0 < 32u && (i0 & 2u)) dlen = 0;                         // the run ends at this cell, which is then an ordinary one
-				else stopm |= k0bit;
-			}
-			if(!prior) stopm |= k0bit;
+			// Where the run of matches from lane k0 ends: each lane's verdict in the sign bit of one word (the walk passes the cell: set), one ballot.
+			// Lanes below k0 are behind the walk; lane k0 under an open deletion run passes only where Od closes the run (bsalign.h:3789-3797).
+			uint32_t g = sh < 32u ? RMe << (sh & 31u) : 0u;
+			const uint32_t od = sh < 32u ? info << 30 : 0u;
+			const uint32_t gk = g & (od | ~dl31);
+			g = (int)lane == k0 ? gk : g;
+			g = (int)lane < k0 ? 0x80000000u : g;
+			const uint64_t stopm = __ballot((int)g >= 0);
+			dl31 &= ~(uint32_t)__builtin_amdgcn_readlane((int)od, k0);      // the run ends at this cell, which is then an ordinary one
 			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
 			const int n = k - k0;
-			if(n > 0){
-				// match / mismatch columns: the run's length goes to a scalar count, its mismatches to a count of the lane's own (lanes k0 .. k - 1 each add their
-				// base comparison: vector work on a unit the walk leaves idle, where mask, popcount and three additions were ten instructions of the scalar unit it is bound by)
-				rs.mat += n;
-				vmis += ((uint32_t)((int)lane - k0) < (uint32_t)n && ne_l) ? 1u : 0u;
-				emit(0u, (uint32_t)n);
-				x -= n; y -= n;
-			}
+			// n match / mismatch columns (possibly none): the count goes to the token key, the mismatches to the lanes' own counts (vector work on a
+			// unit the walk leaves idle; masks, popcounts and additions of the scalar unit were a sixth of its instructions)
+			vmis += (uint32_t)((int)lane - k0) < (uint32_t)n ? nei : 0u;
+			key += (uint32_t)n;
+			x -= n; y -= n;
 			if(k == 64) break;
 			if(x < 0 || y < 0){ walking = false; break; }
 			// ---- the cell at lane k.  The common cases first: an open deletion run goes on, a deletion opens (not M and D set, in
 			// both tie orders), an insertion whose opening cell lies inside the window
 			const uint32_t shk = (uint32_t)__builtin_amdgcn_readlane((int)sh, k);
-			if(shk < 32u && prior){
-				if(dlen){
+			if(shk < plim){
+				if(dl31){
 					emit(2u, 1u); y--; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
 				const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)info, k);
 				if(ik & 1u){
-					emit(2u, 1u); y--; dlen = 1; k0 = k + 1;
+					emit(2u, 1u); y--; dl31 = 0x80000000u; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
@@ -624,7 +628,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 					if(cand){
 						const int sz = (int)ck - (31 - (int)__builtin_clz(cand));
 						emit(1u, (uint32_t)sz);
-						x -= sz; k0 = k;
+						x -= sz; rs.ins += sz; k0 = k;
 						if(x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 						continue;
 					}
@@ -653,8 +657,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 				return cc;
 			};
 			const Code wck = code_at(yb);
-			if(dlen){
-				if(wck.o & bit) dlen = 0;
+			if(dl31){
+				if(wck.o & bit) dl31 = 0u;
 				else { emit(2u, 1u); y--; k0 = k + 1; if(k0 > 63) break; continue; }
 			}
 			const bool pmatch = prior && !(x == bpk && x != 0);
@@ -662,13 +666,13 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			int bt;
 			if(pmatch) bt = fm ? 0 : fd ? 2 : 1;
 			else bt = fd ? 2 : fm ? 0 : 1;
-			prior = 1;
+			prior = 1; plim = 32u; RMe = RM;
 			if(bt == 0){
-				rs.mat++; vmis += ((int)lane == k && ne_l) ? 1u : 0u;
+				vmis += (int)lane == k ? nei : 0u;
 				emit(0u, 1u);
 				x--; y--; k0 = k + 1;
 			} else if(bt == 1){
-				if(x <= 0){ emit(1u, 1u); x--; }
+				if(x <= 0){ emit(1u, 1u); x--; rs.ins++; }
 				else {
 					int sz = 0;
 					const uint32_t cand = wck.r & ~((bit << 1) - 1u) & FULL;
@@ -683,13 +687,13 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 						if(sz == 0){ bad = true; walking = false; break; }  // the reference's scan finds no length either
 					}
 					emit(1u, (uint32_t)sz);
-					x -= sz;
+					x -= sz; rs.ins += sz;
 				}
 				k0 = k;
 				if(x >= 0 && x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 			} else {
 				emit(2u, 1u);
-				y--; dlen = 1; k0 = k + 1;
+				y--; dl31 = 0x80000000u; k0 = k + 1;
 			}
 			if(k0 > 63) break;
 		}
@@ -697,17 +701,17 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		T -= 64;
 		curB = nxtB; curC = nxtC; nxtB = nx2B;
 	}
-	if(!bad && dlen && y < 0 && (!lin || x >= bw)) bad = true;        // a deletion run that reached row -1: see the general step of the LDS kernel
+	if(!bad && dl31 && y < 0 && (!lin || x >= bw)) bad = true;        // a deletion run that reached row -1: see the general step of the LDS kernel
 	if(!bad){
 		rs.qb = x; rs.tb = y;
 		{
-			// rs.mat holds the match / mismatch columns of the walk: the gaps follow from its two ends, the mismatches from the lanes' counts
-			const int mcols = rs.mat;
+			// rs.ins holds the inserted columns of the walk: the other totals follow from its two ends, the mismatches from the lanes' counts
+			const int mcols = (x_start - x) - rs.ins;
 			uint32_t t = vmis;
 			t += (uint32_t)__shfl_xor((int)t, 32); t += (uint32_t)__shfl_xor((int)t, 16); t += (uint32_t)__shfl_xor((int)t, 8);
 			t += (uint32_t)__shfl_xor((int)t, 4); t += (uint32_t)__shfl_xor((int)t, 2); t += (uint32_t)__shfl_xor((int)t, 1);
 			rs.mis = __builtin_amdgcn_readfirstlane((int)t); rs.mat = mcols - rs.mis;
-			rs.ins = (x_start - x) - mcols; rs.del = (y_start - y) - mcols;
+			rs.del = (y_start - y) - mcols;
 		}
 		if(type != BSA_MODE_OVERLAP){
 			uint32_t op = 0, sz = 0;
