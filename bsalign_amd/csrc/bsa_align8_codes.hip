@@ -1066,9 +1066,12 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 	// tokens into words side by side: an M word when the run is not empty, then the gap's word, positions from two prefix popcounts
 	// (word m at cig_end - (m + 1)).  The word sequence is the reference's run-length merge (bsalign.h:409-417) of the same op stream.
 	uint32_t ncig = 0, tokN = 0, tokB = 0;            // words written; the lane's token: run length, len << 2 | op (op 0: none)
-	uint32_t ntok = 0, lastop = 0, carryM = 0;        // (uniform) tokens held, op of the last one, matches since the last event
+	// (uniform) tokens held; key = op of the last token << 28 | match / mismatch columns since it (k_align8_trace_codes_wave)
+	uint32_t ntok = 0, key = 0;
+	constexpr uint32_t KEYM = 0x0FFFFFFFu;
 	auto tok_flush = [&](uint32_t cnt){
 		const bool in = lane < cnt;
+		tokN &= KEYM;
 		const bool hasA = in && tokN != 0u, hasB = in && (tokB & 3u) != 0u;
 		const uint64_t mA = __ballot(hasA), mB = __ballot(hasB);
 		const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u))
@@ -1079,21 +1082,21 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 		ncig += (uint32_t)(__popcll(mA) + __popcll(mB));
 	};
 	auto emit = [&](uint32_t op, uint32_t len){
-		if(op == 0u){ carryM += len; return; }
-		if(carryM == 0u && op == lastop){ if(lane + 1u == ntok) tokB += len << 2; return; }
+		if(op == 0u){ key += len; return; }
+		if(key == (op << 28)){ if(lane + 1u == ntok) tokB += len << 2; return; }
 		if(ntok == 64u){
 			tok_flush(63u);
 			tokN = (uint32_t)__builtin_amdgcn_readlane((int)tokN, 63); tokB = (uint32_t)__builtin_amdgcn_readlane((int)tokB, 63);
 			ntok = 1u;
 		}
-		if(lane == ntok){ tokN = carryM; tokB = (len << 2) | op; }
-		ntok++; lastop = op; carryM = 0u;
+		if(lane == ntok){ tokN = key; tokB = (len << 2) | op; }       // (the op field of the key is masked off when the token is written)
+		ntok++; key = op << 28;
 	};
 	auto cig_finish = [&](){                          // the matches behind the last event, then everything out
-		if(carryM){
+		if(key & KEYM){
 			if(ntok == 64u){ tok_flush(64u); ntok = 0u; }
-			if(lane == ntok){ tokN = carryM; tokB = 0u; }
-			ntok++; carryM = 0u; lastop = 0u;
+			if(lane == ntok){ tokN = key; tokB = 0u; }
+			ntok++; key = 0u;
 		}
 		tok_flush(ntok); ntok = 0u;
 	};
@@ -1113,7 +1116,11 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 	int x = rs.qe, y = rs.te;
 	const int x_start = x, y_start = y;
 	rs.qe++; rs.te++;
-	int prior = 0, dlen = 0;                                        // dlen: the piece (1, 2) of an open deletion run
+	// prior: prior_match of the reference (0 only before the first step).  An open deletion run is held as the Od bit of its piece in the lanes' od
+	// word (piece 1: bit 31, piece 2: bit 30; 0: no run) next to its complement in the sign bit (ndl), the forms the lanes' tests use (k_align8_trace_codes_wave)
+	int prior = 0;
+	constexpr uint32_t DL1 = 0x80000000u, DL2 = 0x40000000u;
+	uint32_t dl = 0u, ndl = 0x80000000u, plim = 0u;                 // plim: 32 once prior_match holds
 	uint32_t vmis = 0;                                              // this lane's mismatch count (summed over the wave at the end)
 	struct TB { int bc, bp; uint32_t tb; };
 	struct TC { uint32_t v0, v1, v2, v3, v4, v5, v6, v7; int b0; };    // rows 0..3 of one block, two dwords each
@@ -1190,38 +1197,35 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 		const int shK = 31 + (int)lane + cb;
 		if(x + k0 - 63 < qw_lo && qw_lo > 0) q_refill(x);
 		int qKr = (int)lane + qw_lo;
+		uint32_t RMe = prior ? RM : 0u;                                 // the M plane as the walk sees it: empty until prior_match holds
 		while(true){
 			const int xs = x + k0;
 			const uint32_t sh = (uint32_t)(shK - xs);
 			const uint32_t qb = (uint32_t)s_q[xs - qKr];
-			const uint64_t mM = __ballot((int)(RM << (sh & 31u)) < 0) & __ballot(sh < 32u);
-			const bool ne_l = qb != tbs;
-			const uint64_t mNE = __ballot(ne_l);
+			const uint32_t nei = qb != tbs ? 1u : 0u;
 			const uint32_t c = (31u - sh) & 31u;
-			const uint32_t info = ((PD >> c) & 1u) | (((PD2 >> c) & 1u) << 1) | (((PO1 >> c) & 1u) << 2) | (((PO2 >> c) & 1u) << 3);
-			const uint64_t k0bit = 1ull << k0;
-			uint64_t stopm = ~(mM | (k0bit - 1ull));
-			if(dlen){
-				const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)info, k0), sh0 = (uint32_t)__builtin_amdgcn_readlane((int)sh, k0);
-				if(sh0 < 32u && ((i0 >> (1 + dlen)) & 1u)) dlen = 0;          // Od of the run's piece: the run ends at this cell
-				else stopm |= k0bit;
-			}
-			if(!prior) stopm |= k0bit;
+			const uint32_t info = ((PD >> c) & 1u) | (((PD2 >> c) & 1u) << 1);            // D, D2 of the lane's cell
+			// the lanes' verdicts in the sign bit of one word, one ballot (k_align8_trace_codes_wave); lane k0 under an open run passes only where
+			// the Od of the run's piece closes it
+			uint32_t g = sh < 32u ? RMe << (sh & 31u) : 0u;
+			const uint32_t od = sh < 32u ? ((PO1 << (sh & 31u)) & DL1) | (((PO2 << (sh & 31u)) >> 1) & DL2) : 0u;
+			const uint32_t odr = od & dl;
+			const uint32_t gk = g & (odr | (odr << 1) | ndl);
+			g = (int)lane == k0 ? gk : g;
+			g = (int)lane < k0 ? 0x80000000u : g;
+			const uint64_t stopm = __ballot((int)g >= 0);
+			if((uint32_t)__builtin_amdgcn_readlane((int)od, k0) & dl){ dl = 0u; ndl = 0x80000000u; }      // Od of the run's piece: the run ends at this cell
 			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
 			const int n = k - k0;
-			if(n > 0){
-				// match / mismatch columns: the run's length goes to a scalar count, its mismatches to a count of the lane's own (lanes k0 .. k - 1 each add their
-				// base comparison: vector work on a unit the walk leaves idle, where mask, popcount and three additions were ten instructions of the scalar unit it is bound by)
-				rs.mat += n;
-				vmis += ((uint32_t)((int)lane - k0) < (uint32_t)n && ne_l) ? 1u : 0u;
-				emit(0u, (uint32_t)n);
-				x -= n; y -= n;
-			}
+			// n match / mismatch columns (possibly none): the count goes to the token key, the mismatches to the lanes' own counts
+			vmis += (uint32_t)((int)lane - k0) < (uint32_t)n ? nei : 0u;
+			key += (uint32_t)n;
+			x -= n; y -= n;
 			if(k == 64) break;
 			if(x < 0 || y < 0){ walking = false; break; }
 			const uint32_t shk = (uint32_t)__builtin_amdgcn_readlane((int)sh, k);
-			if(shk < 32u && prior){
-				if(dlen){
+			if(shk < plim){
+				if(dl){
 					emit(2u, 1u); y--; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
@@ -1229,7 +1233,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 				const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)info, k);
 				if(ik & 3u){                                                // not M and D or D2 set: a deletion of that piece opens
 					if(x == 0){ bad = true; walking = false; break; }         // (at query column 0 the flags cannot tell: k_align8_trace_codes2)
-					emit(2u, 1u); y--; dlen = (ik & 1u) ? 1 : 2; k0 = k + 1;
+					emit(2u, 1u); y--; dl = (ik & 1u) ? DL1 : DL2; ndl = 0u; k0 = k + 1;
 					if(k0 > 63) break;
 					continue;
 				}
@@ -1249,7 +1253,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 						const bool h1 = ch1 && ((r1k >> hp) & 1u), h2 = ch2 && ((r2k >> hp) & 1u);
 						if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))){ bad = true; walking = false; break; }
 						emit(1u, (uint32_t)sz);
-						x -= sz; k0 = k;
+						x -= sz; rs.ins += sz; k0 = k;
 						if(x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 						continue;
 					}
@@ -1270,8 +1274,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 				return r;
 			};
 			const uint2 cc = code_at(yb);
-			if(dlen){
-				if((cc.y >> (dlen == 2 ? 24 : 16)) & bit) dlen = 0;
+			if(dl){
+				if((cc.y >> (dl == DL2 ? 24 : 16)) & bit){ dl = 0u; ndl = 0x80000000u; }
 				else { emit(2u, 1u); y--; k0 = k + 1; if(k0 > 63) break; continue; }
 			}
 			const bool pmatch = prior && !(x == bpk && x != 0);
@@ -1281,13 +1285,13 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 			int bt;
 			if(pmatch) bt = fM ? 0 : d ? 2 : 1;
 			else bt = d ? 2 : fM ? 0 : 1;
-			prior = 1;
+			prior = 1; plim = 32u; RMe = RM;
 			if(bt == 0){
-				rs.mat++; vmis += ((int)lane == k && ne_l) ? 1u : 0u;
+				vmis += (int)lane == k ? nei : 0u;
 				emit(0u, 1u);
 				x--; y--; k0 = k + 1;
 			} else if(bt == 1){
-				if(x <= 0){ emit(1u, 1u); x--; }
+				if(x <= 0){ emit(1u, 1u); x--; rs.ins++; }
 				else {
 					const bool ch1 = fB, ch2 = fA == fB;
 					auto rplane = [&](const uint2 &w) -> uint32_t { return ((ch1 ? w.y : 0u) | (ch2 ? (w.y >> 8) : 0u)) & 0xFFu; };
@@ -1311,14 +1315,14 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 						if(!((h1 && c1 >= c2) || (h2 && c2 >= c1))){ bad = true; walking = false; break; }
 					}
 					emit(1u, (uint32_t)sz);
-					x -= sz;
+					x -= sz; rs.ins += sz;
 				}
 				k0 = k;
 				if(x >= 0 && x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qKr = (int)lane + qw_lo; }
 			} else {
 				if(x == 0){ bad = true; walking = false; break; }             // (query column 0: k_align8_trace_codes2)
 				emit(2u, 1u);
-				y--; dlen = d; k0 = k + 1;
+				y--; dl = d == 1 ? DL1 : DL2; ndl = 0u; k0 = k + 1;
 			}
 			if(k0 > 63) break;
 		}
@@ -1326,17 +1330,17 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 		T -= 64;
 		curB = nxtB; curC = nxtC; nxtB = nx2B;
 	}
-	if(!bad && dlen && y < 0) bad = true;                            // a deletion run that reached row -1: the reference compares real scores there -- literal path
+	if(!bad && dl && y < 0) bad = true;                            // a deletion run that reached row -1: the reference compares real scores there -- literal path
 	if(!bad){
 		rs.qb = x; rs.tb = y;
 		{
-			// rs.mat holds the match / mismatch columns of the walk: the gaps follow from its two ends, the mismatches from the lanes' counts
-			const int mcols = rs.mat;
+			// rs.ins holds the inserted columns of the walk: the other totals follow from its two ends, the mismatches from the lanes' counts
+			const int mcols = (x_start - x) - rs.ins;
 			uint32_t t = vmis;
 			t += (uint32_t)__shfl_xor((int)t, 32); t += (uint32_t)__shfl_xor((int)t, 16); t += (uint32_t)__shfl_xor((int)t, 8);
 			t += (uint32_t)__shfl_xor((int)t, 4); t += (uint32_t)__shfl_xor((int)t, 2); t += (uint32_t)__shfl_xor((int)t, 1);
 			rs.mis = __builtin_amdgcn_readfirstlane((int)t); rs.mat = mcols - rs.mis;
-			rs.ins = (x_start - x) - mcols; rs.del = (y_start - y) - mcols;
+			rs.del = (y_start - y) - mcols;
 		}
 		if(type != BSA_MODE_OVERLAP){              // global / extend: what is left at the top becomes a leading I / D (bsalign.h:3827-3842)
 			uint32_t op = 0, sz = 0;

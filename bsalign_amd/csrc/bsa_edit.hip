@@ -968,9 +968,13 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	// the lanes turn them into words side by side (an M word when the run is not empty, then the gap's word; positions from two
 	// prefix popcounts; word m at cig_end - (m + 1)).  The same scheme as k_align8_trace_codes_wave (bsa_align8_codes.hip).
 	uint32_t ncig = 0, tokN = 0, tokB = 0;            // words written; the lane's token: run length, len << 2 | op (op 0: none)
-	uint32_t ntok = 0, lastop = 0, carryM = 0;        // (uniform) tokens held, op of the last one, matches since the last event
+	// (uniform) tokens held; key = op of the last token << 28 | match / mismatch columns since it (a walk has fewer than 2^28 columns: the
+	// plan sends longer pairs to k_edit_trace), so that "same op, nothing in between" is one compare
+	uint32_t ntok = 0, key = 0;
+	constexpr uint32_t KEYM = 0x0FFFFFFFu;
 	auto tok_flush = [&](uint32_t cnt){
 		const bool in = lane < cnt;
+		tokN &= KEYM;
 		const bool hasA = in && tokN != 0u, hasB = in && (tokB & 3u) != 0u;
 		const u64 mA = __ballot(hasA), mB = __ballot(hasB);
 		const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u))
@@ -981,25 +985,26 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		ncig += (uint32_t)(__popcll(mA) + __popcll(mB));
 	};
 	auto emit = [&](uint32_t op, uint32_t len){
-		if(op == 0u){ carryM += len; return; }
-		if(carryM == 0u && op == lastop){ if(lane + 1u == ntok) tokB += len << 2; return; }
+		if(op == 0u){ key += len; return; }
+		if(key == (op << 28)){ if(lane + 1u == ntok) tokB += len << 2; return; }
 		if(ntok == 64u){
 			tok_flush(63u);
 			tokN = (uint32_t)__builtin_amdgcn_readlane((int)tokN, 63); tokB = (uint32_t)__builtin_amdgcn_readlane((int)tokB, 63);
 			ntok = 1u;
 		}
-		if(lane == ntok){ tokN = carryM; tokB = (len << 2) | op; }
-		ntok++; lastop = op; carryM = 0u;
+		if(lane == ntok){ tokN = key; tokB = (len << 2) | op; }       // (the op field of the key is masked off when the token is written)
+		ntok++; key = op << 28;
 	};
 	auto cig_finish = [&](){
-		if(carryM){
+		if(key & KEYM){
 			if(ntok == 64u){ tok_flush(64u); ntok = 0u; }
-			if(lane == ntok){ tokN = carryM; tokB = 0u; }
-			ntok++; carryM = 0u; lastop = 0u;
+			if(lane == ntok){ tokN = key; tokB = 0u; }
+			ntok++; key = 0u;
 		}
 		tok_flush(ntok); ntok = 0u;
 	};
 	int x = rx, y = ry;
+	uint32_t vmis = 0;                               // this lane's mismatch count (summed over the wave at the end)
 	const bool bad = (rx >= (int)qlen);
 	rs.qe = x + 1; rs.te = y + 1;
 	const bool dbl_ok = (u64)tlen * (u64)qlen < (1ull << 52);
@@ -1076,7 +1081,9 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		s_beg[lane] = pf.beg; s_ws[lane] = pf.ws;
 		const uint32_t beg = pf.beg, ws = pf.ws, tb = pf.tb;
 		const int r_own = R_hi - (int)lane;
-		const u64 tilem = __ballot(lane <= 62u && r_own >= 1);       // lanes whose cell lies inside the target (y - d >= 0) with both rows in the tile
+		// lanes whose cell lies inside the target (y - d >= 0) with both rows in the tile: the others stop the walk (lane 63 always does).  Kept in
+		// the two forms the lanes' tests use: the sign bit of the stop word, bit 2 of the event word
+		const uint32_t TL = (lane <= 62u && r_own >= 1) ? 0u : 0x80000000u, TE = TL ? 0u : 4u;
 		__syncthreads();
 		const uint32_t begn = s_beg[(lane + 1u) & 63u], wsn = s_ws[(lane + 1u) & 63u];
 		// the next tile starts 63 rows further up: its rows travel while this one is walked
@@ -1132,27 +1139,28 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 			const int xs = x + k0;
 			const uint32_t sh = (uint32_t)(shK - xs);
 			const uint32_t qb = (uint32_t)s_q[xs - qK];
-			const u64 mNE = __ballot(qb != tb);
-			const u64 mS = __ballot((int)(SM << (sh & 31u)) < 0) | ~__ballot(sh < 32u);
 			const uint32_t c = (31u - sh) & 31u;
-			const uint32_t cls = ((IM >> c) & 1u) | (((VM >> c) & 1u) << 1);      // bit 0: insertion, bit 1: looked up here
-			const u64 below = (1ull << k0) - 1ull;                  // k0 <= 63
-			u64 stopm = ((mNE & mS) | ~tilem) & ~below;             // lane 63 always stops
-			if(xs < 63) stopm |= ~0ull << (xs + 1);                  // columns left of the query
+			// Where the diagonal run from lane k0 ends: each lane's verdict in the sign bit of one word, one ballot.  A cell stops the run when its bases
+			// differ and the masks say gap or cannot tell (outside the 32 columns: the literal step), when it is not the tile's, or left of the query;
+			// lanes below k0 are behind the walk.  (All of it vector work: the walk is bound by the CU's one scalar unit.)
+			uint32_t st = sh < 32u ? SM << (sh & 31u) : 0x80000000u;
+			const uint32_t nei = qb != tb ? 1u : 0u;
+			st = nei ? st : 0u;
+			st |= TL | (uint32_t)(xs - (int)lane);                   // (the sign of xs - lane: columns left of the query)
+			st = (int)lane < k0 ? 0u : st;
+			const u64 stopm = __ballot((int)st < 0);                // lane 63 always stops
+			// what the cell is if the walk stops on it: bit 0 insertion, bit 1 decided by the masks, bit 2 the tile's own
+			const uint32_t ev = (sh < 32u ? ((IM >> c) & 1u) | (((VM >> c) & 1u) << 1) : 0u) | TE;
 			const int k = __builtin_ctzll(stopm);
 			const int n = k - k0;
-			if(n > 0){
-				const u64 range = ((1ull << k) - 1ull) & ~below;
-				const int mism = __popcll(mNE & range);
-				rs.mat += n - mism; rs.mis += mism;
-				emit(0u, (uint32_t)n);
-				x -= n; y -= n;
-			}
-			if(!((tilem >> k) & 1ull) || x < 0) break;               // end of the tile / of the walk
-			const uint32_t shk = (uint32_t)__builtin_amdgcn_readlane((int)sh, k);
-			const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cls, k);
+			// n match / mismatch columns (possibly none): the count goes to the token key, the mismatches to the lanes' own counts
+			vmis += (uint32_t)((int)lane - k0) < (uint32_t)n ? nei : 0u;
+			key += (uint32_t)n;
+			x -= n; y -= n;
+			const uint32_t ek = (uint32_t)__builtin_amdgcn_readlane((int)ev, k);
+			if(!(ek & 4u) || x < 0) break;                           // end of the tile / of the walk
 			bool isI, isD;
-			if(shk < 32u && (ck & 2u)){ isI = ck & 1u; isD = !isI; }   // (a stop inside VM is I or D)
+			if(ek & 2u){ isI = ek & 1u; isD = !isI; }                  // (a stop inside VM is I or D)
 			else {
 				// literally (bsalign.h:986-1010), the lookups as plain loads: outside the band or the windows
 				const long pb1 = (long)x - (long)__builtin_amdgcn_readlane((int)beg, k), pb0 = (long)x - (long)__builtin_amdgcn_readlane((int)begn, k);
@@ -1164,13 +1172,21 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 				rs.ins++; emit(1u, 1u); x--; k0 = k;
 				if(x + k0 - 63 < qw_lo && qw_lo > 0){ q_refill(x); qK = (int)lane + qw_lo; }
 			}
-			else if(isD){ rs.del++; emit(2u, 1u); y--; k0 = k + 1; }
-			else { rs.mis++; emit(0u, 1u); x--; y--; k0 = k + 1; }    // a mismatch the masks could not decide
+			else if(isD){ emit(2u, 1u); y--; k0 = k + 1; }
+			else { vmis += (int)lane == k ? 1u : 0u; emit(0u, 1u); x--; y--; k0 = k + 1; }    // a mismatch the masks could not decide
 			if(k0 > 62) break;
 		}
 	}
 	if(!bad){
 		rs.qb = x + 1; rs.tb = y + 1;
+		{
+			// rs.ins holds the inserted columns of the walk: the other totals follow from its two ends, the mismatches from the lanes' counts
+			const int mcols = (rx - x) - rs.ins;
+			uint32_t t = vmis;
+			for(int o = 32; o; o >>= 1) t += (uint32_t)__shfl_xor((int)t, o);
+			rs.mis = __builtin_amdgcn_readfirstlane((int)t); rs.mat = mcols - rs.mis;
+			rs.del = (ry - y) - mcols;
+		}
 		if(rs.qb){ emit(1u, (uint32_t)rs.qb); rs.ins += rs.qb; rs.qb = 0; }
 		if((type == BSA_MODE_GLOBAL || type == BSA_MODE_EXTEND) && rs.tb){ emit(2u, (uint32_t)rs.tb); rs.del += rs.tb; rs.tb = 0; }
 		rs.aln = rs.mat + rs.mis + rs.ins + rs.del;
