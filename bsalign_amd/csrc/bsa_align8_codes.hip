@@ -396,8 +396,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 	// tokens into words side by side: an M word when the run is not empty, then the gap's word, positions from two prefix popcounts
 	// (word m at cig_end - (m + 1)).  The word sequence is the reference's run-length merge (bsalign.h:409-417) of the same op stream.
 	uint32_t ncig = 0, tokN = 0, tokB = 0;            // words written; the lane's token: run length, len << 2 | op (op 0: none)
-	// (uniform) tokens held; key = op of the last token << 28 | match / mismatch columns since it (a walk has fewer than 2^26 columns: bsa_api.hip
-	// sends longer queries to the literal kernels), so that "same op, nothing in between" is one compare
+	// (uniform) tokens held; key = op of the last token << 28 | match / mismatch columns since it, so that "same op, nothing in between" is one
+	// compare (a walk over codes has fewer than 2^26 columns: bsa_api.hip sends longer queries to the literal kernels)
 	uint32_t ntok = 0, key = 0;
 	constexpr uint32_t KEYM = 0x0FFFFFFFu;
 	auto tok_flush = [&](uint32_t cnt){
@@ -525,7 +525,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		// the lane's row as four 32-bit planes in CELL order (bit c = window cell c = band cell 8 b0 + c): the bytes of a plane
 		// gathered last block first, then all 32 bits reversed (inside a block cell k is bit 7 - k)
 		uint32_t RM, RD = 0, RR, RO = 0;
-		uint32_t X0 = 0, X1 = 0, qc = 0xFFFFFFFFu, qinfo = 0;        // FMT 1
+		uint32_t X0 = 0, X1 = 0;                                     // FMT 1
+		uint64_t E = 0;                                              // FMT 1: D, Od of the window's 32 cells, two bits a cell
 		{
 			const uint32_t *mr = &tile[lane * STR];
 			if constexpr (W == 8 && FMT == 1){
@@ -565,8 +566,15 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 		}
 		const int cb = bc + W * b0;                                     // column of window cell 0
 		if constexpr (FMT == 1){
+			// The two-bit fields decoded once per tile, all 32 cells at a time (bit 2 c: D, the field is 0; bit 2 c + 1: Od, the field is -gapo), where a
+			// step of the walk used to decode its own cell -- a quarter of the vector instructions of a step, and the walk is bound by them now
+			auto fields = [&](uint32_t X) -> uint32_t {
+				const uint32_t z = ~(X | (X >> 1)) & 0x55555555u, y = X ^ (NGOS * 0x55555555u);
+				return z | ((~(y | (y >> 1)) & 0x55555555u) << 1);
+			};
+			E = (uint64_t)fields(X0) | ((uint64_t)fields(X1) << 32);
 			// the literal cell: window cell 0 when it is query column 0 of a row whose band starts there (bit 0: Od, bit 1: D after the reversal)
-			if(cb == 0 && bc == 0){ qc = 0u; qinfo = ((X0 >> 1) & 1u) | ((X0 & 1u) << 1); }
+			if(cb == 0 && bc == 0) E = (E & ~3ull) | (uint64_t)(((X0 >> 1) & 1u) | ((X0 & 1u) << 1));
 		}
 		if(T - (int)lane < 0) RM = 0u;                                  // rows above the target: never a match (the walk ends before them)
 		// prior_match is dropped at the first column of the previous row's band (bsalign.h:3761-3764): that cell is taken out of
@@ -584,11 +592,8 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const uint32_t nei = qb != tbs ? 1u : 0u;
 			const uint32_t c = (31u - sh) & 31u;
 			uint32_t info;                                                          // D, Od of the lane's cell
-			if constexpr (FMT == 1){
-				const uint32_t raw = (((c & 16u) ? X1 : X0) >> ((c & 15u) * 2u)) & 3u;
-				info = (raw == 0u ? 1u : 0u) | (raw == NGOS ? 2u : 0u);
-				info = (c == qc) ? qinfo : info;
-			} else info = ((RD >> c) & 1u) | (((RO >> c) & 1u) << 1);
+			if constexpr (FMT == 1) info = (uint32_t)(E >> (2u * c)) & 3u;
+			else info = ((RD >> c) & 1u) | (((RO >> c) & 1u) << 1);
 			// Where the run of matches from lane k0 ends: each lane's verdict in the sign bit of one word (the walk passes the cell: set), one ballot.
 			// Lanes below k0 are behind the walk; lane k0 under an open deletion run passes only where Od closes the run (bsalign.h:3789-3797).
 			uint32_t g = sh < 32u ? RMe << (sh & 31u) : 0u;

@@ -968,8 +968,8 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	// the lanes turn them into words side by side (an M word when the run is not empty, then the gap's word; positions from two
 	// prefix popcounts; word m at cig_end - (m + 1)).  The same scheme as k_align8_trace_codes_wave (bsa_align8_codes.hip).
 	uint32_t ncig = 0, tokN = 0, tokB = 0;            // words written; the lane's token: run length, len << 2 | op (op 0: none)
-	// (uniform) tokens held; key = op of the last token << 28 | match / mismatch columns since it (a walk has fewer than 2^28 columns: the
-	// plan sends longer pairs to k_edit_trace), so that "same op, nothing in between" is one compare
+	// (uniform) tokens held; key = op of the last token << 28 | match / mismatch columns since it, so that "same op, nothing in between" is one
+	// compare (28 bits: the length field of a CIGAR word, length << 4 | op in 32 bits -- a longer run has no word in the reference's format either)
 	uint32_t ntok = 0, key = 0;
 	constexpr uint32_t KEYM = 0x0FFFFFFFu;
 	auto tok_flush = [&](uint32_t cnt){
@@ -1012,18 +1012,31 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	int qw_lo = 0, qw_hi = -1;                       // query bases [qw_lo, qw_hi] are in s_q
 	// a tile's rows for lane i: row R_hi - i, window start ws (in words), band offset beg, target base of the row
 	struct TileRegs { u64 w[2][EW_WW]; uint32_t beg, ws, tb; };
-	auto tile_fetch = [&](int R_hi, int xs, TileRegs &t){
+	// The band offset of row r is (r - 1) qlen / tlen, clamped (beg_of_row).  A tile that follows the last one fetched 63 rows further up -- every tile
+	// but the first, unless the walk left its tile early -- takes each lane's quotient and remainder from that tile's and the constants of 63 qlen / tlen:
+	// a subtraction and a borrow where the division was a third of a tile's vector instructions (and in f64)
+	const u64 step63 = 63ull * qlen;
+	const uint32_t dq63 = (uint32_t)(step63 / tlen), dr63 = (uint32_t)(step63 % tlen);
+	uint32_t bq = 0, br = 0;                         // the lane's quotient and remainder in the tile fetched last (rows r >= 1)
+	auto tile_fetch = [&](int R_hi, int xs, TileRegs &t, bool follows){
 		const int r = R_hi - (int)lane;
 		uint32_t beg = 0;
 		if(type == BSA_MODE_GLOBAL && r >= 1){
-			const u64 n = (u64)(uint32_t)(r - 1) * qlen;
 			uint32_t c;
-			if(dbl_ok){
-				u64 qe = (u64)((double)n * inv_t);
-				long rem = (long)(n - qe * (u64)tlen);
-				if(rem < 0) qe--; else if(rem >= (long)tlen) qe++;
-				c = (uint32_t)qe;
-			} else c = (uint32_t)(n / tlen);
+			if(follows){
+				const uint32_t borrow = br < dr63 ? 1u : 0u;
+				br = br - dr63 + (borrow ? tlen : 0u);
+				c = bq - dq63 - borrow;
+			} else {
+				const u64 n = (u64)(uint32_t)(r - 1) * qlen;
+				if(dbl_ok){
+					u64 qe = (u64)((double)n * inv_t);
+					long rem = (long)(n - qe * (u64)tlen);
+					if(rem < 0){ qe--; rem += (long)tlen; } else if(rem >= (long)tlen){ qe++; rem -= (long)tlen; }
+					c = (uint32_t)qe; br = (uint32_t)rem;
+				} else { c = (uint32_t)(n / tlen); br = (uint32_t)(n - (u64)c * tlen); }
+			}
+			bq = c;
 			c = (c < BW / 2) ? 0u : c - BW / 2;
 			beg = (c + BW > qround) ? qround - BW : c;
 		}
@@ -1071,7 +1084,7 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	if(!bad && x >= 0) q_refill(x);
 	while(!bad && x >= 0 && y >= 0){
 		const int R_hi = y + 1;
-		if(pf_R != R_hi) tile_fetch(R_hi, x, pf);
+		if(pf_R != R_hi) tile_fetch(R_hi, x, pf, false);
 		__syncthreads();
 #pragma unroll
 		for(int w = 0; w < EW_WW; w++){
@@ -1088,7 +1101,7 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		const uint32_t begn = s_beg[(lane + 1u) & 63u], wsn = s_ws[(lane + 1u) & 63u];
 		// the next tile starts 63 rows further up: its rows travel while this one is walked
 		pf_R = R_hi - 63;
-		if(pf_R >= 1) tile_fetch(pf_R, x - 63, pf);
+		if(pf_R >= 1) tile_fetch(pf_R, x - 63, pf, true);
 		// ---- the lane's cells as 32-bit masks over query columns cbase .. cbase + 31 (cbase = its column on the walker's
 		// diagonal - 16): IM = "insertion" (u3, u4) == (0, 1) on the lane's own row, DM = "deletion" (u1, u2) == (1, 0) on the
 		// row above and not IM, VM = both lookups lie inside the band and inside the LDS windows.  A cell stops the diagonal
