@@ -32,6 +32,14 @@ struct Edge { uint32_t from, to, cov, next_out, next_in; };       // edge 0 is "
 
 inline double now_s(){ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// No exception crosses the C ABI: the containers below allocate (a window's graph grows with every read), and a failed allocation is BSA_E_NOMEM
+// to the caller, who may bsa_pog_abort / bsa_pog_clear and go on.
+template<class F> inline int guarded(F &&f){
+	try { return f(); }
+	catch(const std::bad_alloc&){ return BSA_E_NOMEM; }
+	catch(...){ return BSA_E_ARG; }
+}
+
 }  // namespace
 
 struct bsa_pog {
@@ -170,6 +178,7 @@ struct bsa_pog {
 };
 
 extern "C" int bsa_pog_create(const bsa_pog_params_t *par, bsa_pog_t **out){
+	return guarded([&]() -> int {
 	if(!par || !out) return BSA_E_ARG;
 	if(par->alnmode < 0 || par->alnmode > 2 || par->bandwidth < 0 || par->nrec < 0 || par->seqcore < 0) return BSA_E_ARG;
 	bsa_pog *g = new (std::nothrow) bsa_pog();
@@ -179,6 +188,7 @@ extern "C" int bsa_pog_create(const bsa_pog_params_t *par, bsa_pog_t **out){
 	memset(&g->res, 0, sizeof(g->res)); memset(&g->rd, 0, sizeof(g->rd));
 	*out = g;
 	return BSA_OK;
+	});
 }
 
 extern "C" void bsa_pog_destroy(bsa_pog_t *g){ delete g; }
@@ -192,6 +202,7 @@ extern "C" void bsa_pog_clear(bsa_pog_t *g){
 }
 
 extern "C" int bsa_pog_add_read(bsa_pog_t *g, const uint8_t *bases, uint32_t len, uint32_t *rid_out){
+	return guarded([&]() -> int {
 	if(!g || (len && !bases) || g->stage != 0) return BSA_E_ARG;
 	if(g->ndoff.size() >= 0x3FFFu || len > 0x0FFFFFFFu) return BSA_E_ARG;                    // BSPOA_RDCNT_MAX, BSPOA_RDLEN_MAX (bspoa.h:22-23)
 	for(uint32_t i = 0; i < len; i++) if(bases[i] > 3) return BSA_E_ARG;
@@ -217,9 +228,11 @@ extern "C" int bsa_pog_add_read(bsa_pog_t *g, const uint8_t *bases, uint32_t len
 	}
 	if(rid_out) *rid_out = r;
 	return BSA_OK;
+	});
 }
 
 extern "C" int bsa_pog_import(bsa_pog_t *g, const bsa_pog_snapshot_t *s, const uint8_t *const *read_bases){
+	return guarded([&]() -> int {
 	(void)read_bases;
 	if(!g || !s || !s->nodes || !s->ndoff || !s->rdlen || !s->out_off || !s->in_off) return BSA_E_ARG;
 	bsa_pog_clear(g);
@@ -261,6 +274,7 @@ extern "C" int bsa_pog_import(bsa_pog_t *g, const bsa_pog_snapshot_t *s, const u
 		}
 	}
 	return BSA_OK;
+	});
 }
 
 extern "C" int bsa_pog_export(const bsa_pog_t *g, uint32_t *nnodes, uint32_t *nreads, uint32_t *nedges, uint32_t *head, uint32_t *tail,
@@ -308,6 +322,7 @@ extern "C" void bsa_pog_seconds(const bsa_pog_t *g, double out[5]){ if(g && out)
 
 // ---- P2: sel_nodes_bspoa (bspoa.h:1887-2020)
 extern "C" int bsa_pog_select(bsa_pog_t *g, uint32_t rid, uint32_t rbeg, uint32_t rlen, bsa_pog_read_t *rd, const uint32_t **sel){
+	return guarded([&]() -> int {
 	if(!g || rid >= g->ndoff.size() || (uint64_t)rbeg + rlen > g->rdlen[rid]) return BSA_E_ARG;
 	if(g->stage != 0) return BSA_E_ARG;
 	// a read already chained into the graph would have to be cut out first (realn, cut_rdnode_bspoa bspoa.h:741-795): not implemented
@@ -374,6 +389,7 @@ extern "C" int bsa_pog_select(bsa_pog_t *g, uint32_t rid, uint32_t rbeg, uint32_
 	if(sel) *sel = g->sels.data();
 	g->secs[0] += now_s() - t0;
 	return BSA_OK;
+	});
 }
 
 static inline uint32_t roundup16(uint32_t v){ return (v + 15u) / 16u * 16u; }
@@ -385,6 +401,7 @@ extern "C" int bsa_pog_needs_guide(const bsa_pog_t *g, uint32_t reflen){
 
 // ---- P3: prepare_rd_align_bspoa (bspoa.h:2022-2230)
 extern "C" int bsa_pog_place(bsa_pog_t *g, const bsa_pog_guide_t *gd, const int32_t *cpos_sel, bsa_pog_read_t *rd){
+	return guarded([&]() -> int {
 	if(!g || g->stage != 1) return BSA_E_ARG;
 	const double t0 = now_s();
 	const uint32_t seqlen = g->rd.qlen;
@@ -452,6 +469,7 @@ extern "C" int bsa_pog_place(bsa_pog_t *g, const bsa_pog_guide_t *gd, const int3
 	if(rd) *rd = g->rd;
 	g->secs[1] += now_s() - t0;
 	return BSA_OK;
+	});
 }
 
 // ---- the program: the traversal of align_rd_bspoacore (bspoa.h:2515-2618) recorded instead of computed.  A stack of complete nodes, a node is
@@ -460,6 +478,7 @@ extern "C" int bsa_pog_place(bsa_pog_t *g, const bsa_pog_guide_t *gd, const int3
 // folds them two at a time in visiting order (a node with more than two is preceded by partial nodes).
 extern "C" int bsa_pog_program(bsa_pog_t *g, const bsa_poa_node_t **nodes, size_t *nnodes, const bsa_poa_edge_t **pedges, size_t *nedges,
 		const bsa_poa_cand_t **cands, size_t *ncands, const uint8_t **query, bsa_sweep_params_t *par){
+	return guarded([&]() -> int {
 	if(!g || g->stage < 2) return BSA_E_ARG;
 	const double t0 = now_s();
 	const uint32_t nhead = g->rd.nhead, ntail = g->rd.ntail, bw = g->rd.bandwidth, slen = g->rd.slen;
@@ -545,9 +564,11 @@ extern "C" int bsa_pog_program(bsa_pog_t *g, const bsa_poa_node_t **nodes, size_
 	}
 	g->secs[2] += now_s() - t0;
 	return BSA_OK;
+	});
 }
 
 extern "C" int bsa_pog_run(bsa_pog_t *g, bsa_pog_backend_fn fn, void *user, bsa_poa_result_t *res, const bsa_poa_event_t **events){
+	return guarded([&]() -> int {
 	if(!g || g->stage < 2) return BSA_E_ARG;
 	bsa_sweep_params_t sp;
 	const uint8_t *q = nullptr;
@@ -574,6 +595,7 @@ extern "C" int bsa_pog_run(bsa_pog_t *g, bsa_pog_backend_fn fn, void *user, bsa_
 	if(res) *res = g->res;
 	if(events) *events = g->events.data();
 	return BSA_OK;
+	});
 }
 
 extern "C" int bsa_pog_aux_edges(const bsa_pog_t *g, const uint64_t **list, size_t *n){
@@ -583,15 +605,18 @@ extern "C" int bsa_pog_aux_edges(const bsa_pog_t *g, const uint64_t **list, size
 }
 
 extern "C" int bsa_pog_abort(bsa_pog_t *g){
+	return guarded([&]() -> int {
 	if(!g) return BSA_E_ARG;
-	if(g->stage == 0) return BSA_OK;
+	if(g->stage == 0 && g->todels.empty()) return BSA_OK;        // (a selection that failed half-way has left its auxiliary edges)
 	g->drop_aux();
 	g->stage = 0;
 	return BSA_OK;
+	});
 }
 
 // ---- the surgery (alignment2graph_bspoa bspoa.h:2286, 2393-2405, 2501-2511; align_rd_bspoa :2652-2657)
 extern "C" int bsa_pog_apply(bsa_pog_t *g, bsa_result_t *rs_out, uint32_t *events_gnode){
+	return guarded([&]() -> int {
 	if(!g || g->stage != 4) return BSA_E_ARG;
 	const double t0 = now_s();
 	const uint32_t rid = g->cur_rid, rbeg = g->cur_rbeg, qlen = g->rd.qlen, qb = g->rd.qb;
@@ -632,4 +657,5 @@ extern "C" int bsa_pog_apply(bsa_pog_t *g, bsa_result_t *rs_out, uint32_t *event
 	if(rs_out) *rs_out = rs;
 	g->secs[4] += now_s() - t0;
 	return BSA_OK;
+	});
 }

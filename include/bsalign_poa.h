@@ -25,7 +25,10 @@
  * bsa_kmer_edit_batch).  refmode (a reference sequence with SAM CIGARs as read 0, bspoa.h:2055-2085) and re-alignment of a
  * read already in the graph (realn, cut_rdnode_bspoa) are not implemented: bsa_pog_select returns BSA_E_UNSUPPORTED.
  *
- * Plain C types only.  Every function returns BSA_OK (0) or a negative BSA_E_* code of bsalign_hip.h.
+ * Plain C types only.  Every function returns BSA_OK (0) or a negative BSA_E_* code of bsalign_hip.h; no C++ exception leaves
+ * the library (a failed host allocation is BSA_E_NOMEM).  After BSA_E_NOMEM from bsa_pog_apply the graph may hold half of a
+ * read's surgery: bsa_pog_clear (or bsa_pog_import of the caller's copy) before going on; after it from any earlier step
+ * bsa_pog_abort takes the read's auxiliary edges back and leaves the graph as it was.
  */
 #ifndef BSALIGN_POA_H
 #define BSALIGN_POA_H
