@@ -425,7 +425,8 @@ static inline void bsa_poa_graph_export_free(bsa_poa_graph_export_t *x){
 	memset(x, 0, sizeof(*x));
 }
 
-static inline void bsa_poa_graph_export(BSPOA *g, bsa_poa_graph_export_t *x){
+/* returns 0, or -1 when the host has no memory for the copy (nothing is left allocated) */
+static inline int bsa_poa_graph_export(BSPOA *g, bsa_poa_graph_export_t *x){
 	const u4i n = (u4i)g->nodes->size, nr = (u4i)g->seqs->nseq;
 	u4i i, ei, ne = 0, k;
 	bspoaedge_t *e;
@@ -433,6 +434,7 @@ static inline void bsa_poa_graph_export(BSPOA *g, bsa_poa_graph_export_t *x){
 	x->nodes = (bsa_pog_node_t*)calloc((size_t)n + 1, sizeof(bsa_pog_node_t));
 	x->ndoff = (uint32_t*)calloc((size_t)nr + 1, 4); x->rdlen = (uint32_t*)calloc((size_t)nr + 1, 4);
 	x->out_off = (uint32_t*)calloc((size_t)n + 2, 4); x->in_off = (uint32_t*)calloc((size_t)n + 2, 4);
+	if(!x->nodes || !x->ndoff || !x->rdlen || !x->out_off || !x->in_off){ bsa_poa_graph_export_free(x); return -1; }
 	for(i=0;i<n;i++){
 		const bspoanode_t *u = ref_bspoanodev(g->nodes, i);
 		bsa_pog_node_t *d = x->nodes + i;
@@ -442,6 +444,7 @@ static inline void bsa_poa_graph_export(BSPOA *g, bsa_poa_graph_export_t *x){
 	}
 	for(i=0;i<nr;i++){ x->ndoff[i] = g->ndoffs->buffer[i]; x->rdlen[i] = g->seqs->rdlens->buffer[i]; }
 	x->out_to = (uint32_t*)calloc((size_t)ne + 1, 4); x->out_cov = (uint32_t*)calloc((size_t)ne + 1, 4); x->in_from = (uint32_t*)calloc((size_t)ne + 1, 4);
+	if(!x->out_to || !x->out_cov || !x->in_from){ bsa_poa_graph_export_free(x); return -1; }
 	for(i=0,k=0;i<n;i++){
 		x->out_off[i] = k;
 		for(ei=ref_bspoanodev(g->nodes, i)->edge;ei;ei=e->next){ e = ref_bspoaedgev(g->edges, ei); x->out_to[k] = e->node; x->out_cov[k] = e->cov; k ++; }
@@ -455,6 +458,7 @@ static inline void bsa_poa_graph_export(BSPOA *g, bsa_poa_graph_export_t *x){
 	x->snap.nnodes = n; x->snap.nreads = nr; x->snap.head = g->HEAD; x->snap.tail = g->TAIL;
 	x->snap.nodes = x->nodes; x->snap.ndoff = x->ndoff; x->snap.rdlen = x->rdlen;
 	x->snap.out_off = x->out_off; x->snap.out_to = x->out_to; x->snap.out_cov = x->out_cov; x->snap.in_off = x->in_off; x->snap.in_from = x->in_from;
+	return 0;
 }
 
 static inline void bsa_poa_pog_params(const BSPOAPar *par, bsa_pog_params_t *pp){
@@ -487,7 +491,7 @@ static inline int bsa_poa_pog_sync(BSPOA *g, BSPOAPar *par, bsa_poa_adapter_t *a
 		}
 	} else {
 		bsa_poa_graph_export_t x;
-		bsa_poa_graph_export(g, &x);
+		if(bsa_poa_graph_export(g, &x) != 0) return BSA_E_NOMEM;
 		rc = bsa_pog_import(ad->pog, &x.snap, NULL);
 		bsa_poa_graph_export_free(&x);
 		if(rc != BSA_OK) return rc;

@@ -288,7 +288,7 @@ static int graphs_equal(BSPOA *g, bsa_pog_t *pog, uint64_t *nn, uint64_t *ne){
 	uint32_t n = 0, nr = 0, nedge = 0, hd = 0, tl = 0, i;
 	bsa_pog_node_t *nodes; uint32_t *ndoff, *rdlen, *oo, *ot, *oc, *io, *inf;
 	int ok = 1;
-	bsa_poa_graph_export(g, &x);
+	if(bsa_poa_graph_export(g, &x) != 0){ fprintf(stderr, "ref_poa_harness: out of memory\n"); abort(); }
 	if(bsa_pog_export(pog, &n, &nr, &nedge, &hd, &tl, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL) != BSA_OK){ bsa_poa_graph_export_free(&x); return 0; }
 	if(n != x.snap.nnodes || nr != x.snap.nreads || hd != x.snap.head || tl != x.snap.tail || nedge != x.out_off[n]){ bsa_poa_graph_export_free(&x); return 0; }
 	nodes = (bsa_pog_node_t*)calloc((size_t)n + 1, sizeof(bsa_pog_node_t)); ndoff = (uint32_t*)calloc((size_t)nr + 1, 4); rdlen = (uint32_t*)calloc((size_t)nr + 1, 4);
@@ -442,7 +442,7 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 		if(snapping){
 			seqalign_result_t krs;
 			memset(shdr, 0, sizeof(shdr)); ZEROS(&krs);
-			bsa_poa_graph_export(g, &snapx);
+			if(bsa_poa_graph_export(g, &snapx) != 0){ fprintf(stderr, "ref_poa_harness: out of memory\n"); abort(); }
 			shdr[0] = snapx.snap.nnodes; shdr[1] = snapx.snap.nreads; shdr[2] = snapx.out_off[snapx.snap.nnodes]; shdr[6] = g->HEAD; shdr[7] = g->TAIL;
 			shdr[13] = g->cns->size; shdr[18] = rid; shdr[19] = (uint64_t)rlen;
 			/* the guide alignment prepare_rd_align_bspoa is about to make (bspoa.h:2086-2091): the same call, kept */
@@ -607,7 +607,7 @@ static void poa_finish(ref_poa_t *p){
 		/* the graph the last surgery left */
 		bsa_poa_graph_export_t x; uint64_t hdr[20];
 		memset(hdr, 0, sizeof(hdr));
-		bsa_poa_graph_export(g, &x);
+		if(bsa_poa_graph_export(g, &x) != 0){ fprintf(stderr, "ref_poa_harness: out of memory\n"); abort(); }
 		hdr[0] = x.snap.nnodes; hdr[1] = x.snap.nreads; hdr[2] = x.out_off[x.snap.nnodes]; hdr[6] = g->HEAD; hdr[7] = g->TAIL; hdr[18] = (uint64_t)-1;
 		snap_record(p, &x, hdr, NULL, NULL, NULL);
 		bsa_poa_graph_export_free(&x);
