@@ -865,24 +865,6 @@ def main():
             pcie_same = rcb == 0 and bool(np.array_equal(h_out, out)) and bool(np.array_equal(h_off.astype(np.int64), off)) and bool(np.array_equal(h_cig[:ncig], cig_all))
             del h_cig
 
-        def align_shard(sh):
-            m = len(sh["qlen"])
-            o = torch.zeros(max(m, 1) * 10, dtype=torch.int32, device=dev)
-            f = torch.zeros(m + 1, dtype=torch.int64, device=dev)
-            stt = torch.zeros(max(m, 1), dtype=torch.int32, device=dev)
-            if m:
-                pl = make_plan(sh["qoff"], sh["qlen"], sh["toff"], sh["tlen"])
-                pl.run(sh["seqs"], o, d_cig, f, stt)
-                ctx.sync()
-                pl.close()
-            return o.view(-1, 10)[:m], d_cig, f
-
-        exchange = exchange_selfcheck(dist, rank, world, dev, host, bw if bw else 128, align=align_shard,
-                                      expect=(out, cig_all, off) if rank == 0 else None)
-        if rank == 0:
-            exchange["host_pointer_call_identical"] = pcie_same
-        host = None
-
     if rank == 0:
         import support as S
         # parity spot check (outside the timed region): first pairs of the batch vs the oracle
@@ -937,10 +919,48 @@ def main():
                                           "launches_per_step": klaunch if dom_trace else tlaunch}},
             "checks": {"pairs_flagged": nbad, "cigar_words": ncig, "oracle_identical_first8": ident},
         }
-        if exchange is not None:
-            line["exchange"] = exchange
         if world == 1 and args.cpu_pairs >= 0:
             line["cpu_baseline"] = cpu_baseline(args, L, bw, sc, mode)
+    # ---- the shard exchange on this very batch, after the line is complete: a fault or a hang of the exchange (RCCL at more than one rank has only
+    # ever run here over gloo / shared memory: no multi-GPU node) must not cost the run its measured line
+    if not args.no_exchange and args.cpu_pairs >= 0:
+        import threading
+        finished = threading.Event()
+        limit = float(os.environ.get("BSA_BENCH_EXCHANGE_TIMEOUT", "300"))
+
+        def watchdog():
+            if not finished.wait(limit):
+                if rank == 0:
+                    line["exchange"] = {"error": "the shard exchange did not finish within %d s; the line is printed without it" % int(limit)}
+                    emit(line)
+                os._exit(0)
+
+        if world > 1:
+            threading.Thread(target=watchdog, daemon=True).start()
+
+        def align_shard(sh):
+            m = len(sh["qlen"])
+            o = torch.zeros(max(m, 1) * 10, dtype=torch.int32, device=dev)
+            f = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+            stt = torch.zeros(max(m, 1), dtype=torch.int32, device=dev)
+            if m:
+                pl = make_plan(sh["qoff"], sh["qlen"], sh["toff"], sh["tlen"])
+                pl.run(sh["seqs"], o, d_cig, f, stt)
+                ctx.sync()
+                pl.close()
+            return o.view(-1, 10)[:m], d_cig, f
+
+        try:
+            exchange = exchange_selfcheck(dist, rank, world, dev, host, bw if bw else 128, align=align_shard,
+                                          expect=(out, cig_all, off) if rank == 0 else None)
+            if rank == 0:
+                exchange["host_pointer_call_identical"] = pcie_same
+        except Exception as ex:          # (reported in the line, not raised)
+            exchange = {"error": "%s: %s" % (type(ex).__name__, ex)} if rank == 0 else None
+        finished.set()
+        host = None
+        if rank == 0 and exchange is not None:
+            line["exchange"] = exchange
     if plan is not None:
         plan.close()
     ctx.close()
