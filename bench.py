@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="align8", choices=["align8", "edit", "poa"])
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: 100000 for align8, 16384 for edit; poa: POA windows, 16384)")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: 100000 for align8, 32768 for edit -- 210 GB of row planes, four waves per SIMD; poa: POA windows, 16384)")
     ap.add_argument("--length", type=int, default=0, help="target length (default 10000 / 100000; poa: graph positions per window, 10000)")
     ap.add_argument("--bw", type=int, default=0, help="bandwidth (default 128 / 256 / 128); -1 = the reference's bandwidth 0, the whole query")
     ap.add_argument("--mode", default="global", choices=["global", "overlap", "extend"], help="pairwise workloads only (the headline configurations are global)")
@@ -768,7 +768,7 @@ def main():
         L = args.length or 10000
         bw = args.bw or 128
     else:
-        n = args.pairs or 16384
+        n = args.pairs or 32768          # 100 kbp pairs at bandwidth 256: 64 bytes a row, 210 GB of row planes -- the batch one MI355X holds (16384 pairs are two waves per SIMD: 4.8 k GCUPS against 6.2 k)
         L = args.length or 100000
         bw = args.bw or 256
     if bw < 0:
@@ -977,7 +977,7 @@ def main():
 
 
 def secondary_lines(args):
-    """`bench.py` with no workload flags also measures the edit path (C3: 16384 x 100 kbp, bandwidth 256) and the POA's sweep + walk (256 windows x 12 reads x
+    """`bench.py` with no workload flags also measures the edit path (C3: 32768 x 100 kbp, bandwidth 256) and the POA's sweep + walk (256 windows x 12 reads x
     1.5 kbp: programs recorded from the reference's end_bspoa where oracle/_ref exists, else the committed fixture programs) -- each as a run of this very script
     with its own steps, roofline and cpu_baseline, its JSON line embedded under "secondary"."""
     import subprocess
