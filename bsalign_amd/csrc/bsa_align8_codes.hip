@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
 			const int n = k - k0;
 			// n match / mismatch columns (possibly none): the count goes to the token key, the mismatches to the lanes' own counts (vector work on a
-			// unit the walk leaves idle; masks, popcounts and additions of the scalar unit were a sixth of its instructions)
+			// unit that had room; masks, popcounts and additions of the scalar unit were a sixth of the walk's instructions when it was bound by them)
 			vmis += (uint32_t)((int)lane - k0) < (uint32_t)n ? nei : 0u;
 			key += (uint32_t)n;
 			x -= n; y -= n;

@@ -1155,7 +1155,7 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 			const uint32_t c = (31u - sh) & 31u;
 			// Where the diagonal run from lane k0 ends: each lane's verdict in the sign bit of one word, one ballot.  A cell stops the run when its bases
 			// differ and the masks say gap or cannot tell (outside the 32 columns: the literal step), when it is not the tile's, or left of the query;
-			// lanes below k0 are behind the walk.  (All of it vector work: the walk is bound by the CU's one scalar unit.)
+			// lanes below k0 are behind the walk.  (All of it vector work: as three 64-bit mask operations and a select each on the scalar unit these tests were what the walk was bound by.)
 			uint32_t st = sh < 32u ? SM << (sh & 31u) : 0x80000000u;
 			const uint32_t nei = qb != tb ? 1u : 0u;
 			st = nei ? st : 0u;
