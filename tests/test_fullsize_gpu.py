@@ -229,11 +229,13 @@ def test_c5_real_per_gpu_share_in_chunks():
     ctx.close()
 
 
-def test_c3_full_size_properties():
-    """configuration C3: 16384 synthetic 100 kbp pairs, edit path, global, bandwidth 256"""
+@pytest.mark.parametrize("n", [16384, 32768])
+def test_c3_full_size_properties(n):
+    """configuration C3: synthetic 100 kbp pairs, edit path, global, bandwidth 256 -- 16384 pairs (the batch of the earlier rounds) and 32768 (bench.py's
+    batch since round 5: 210 GB of row planes)"""
     import torch
     import bsalign_amd as B
-    n, L, bw = 16384, 100000, 256
+    L, bw = 100000, 256
     dev = torch.device("cuda", 0)
     ctx = B.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -275,7 +277,7 @@ def test_c3_full_size_properties():
     assert np.isin(op, (0, 1, 2)).all() and (np.diff(off) > 0).all()
     assert (np.add.reduceat(np.where(op != 2, ln, 0), starts) == qlen).all() and (np.add.reduceat(np.where(op != 1, ln, 0), starts) == L).all()
     assert (np.add.reduceat(np.where(op == 1, ln, 0), starts) == ins).all() and (np.add.reduceat(np.where(op == 2, ln, 0), starts) == dele).all()
-    for k in (0, 4095, 8192, 16383):
+    for k in (0, n // 4 - 1, n // 2, n - 1):
         q, t = S.synth_pair(k, L)
         res, cg, _ = S.oracle_edit(q, t, S.MODE_GLOBAL, bw)
         assert np.array_equal(out[k], res) and np.array_equal(cig[int(off[k]):int(off[k + 1])], cg), k
