@@ -119,6 +119,8 @@ def lib():
         L.bsa_ctx_last_trace_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
         L.bsa_ctx_last_kernel_name.argtypes = [vp, C.c_int]
         L.bsa_ctx_last_kernel_name.restype = C.c_char_p
+        L.bsa_ctx_last_handover.argtypes = [vp]
+        L.bsa_ctx_last_handover.restype = C.c_long
         L.bsa_set_score_matrix.argtypes = [C.POINTER(C.c_int8), C.c_int8, C.c_int8]
         L.bsa_set_score_matrix.restype = None
         L.bsa_align_batch.argtypes = [vp, u8p, C.c_size_t, u64p, u32p, u64p, u32p, C.c_size_t, C.POINTER(AlignParams),
@@ -261,6 +263,10 @@ class Context:
         ms, n = C.c_double(), C.c_long()
         self._chk(lib().bsa_ctx_last_trace_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def last_handover(self):
+        """pairs of the last align_batch call that were re-run through the literal kernels"""
+        return int(lib().bsa_ctx_last_handover(self.h))
 
     def last_kernel_names(self):
         return lib().bsa_ctx_last_kernel_name(self.h, 0).decode(), lib().bsa_ctx_last_kernel_name(self.h, 1).decode()

@@ -38,7 +38,7 @@ struct SysHdr { int32_t score, qe, te, reserved; };      // the alignment's end 
 // bit 31 - (t & 31) -- every 32 steps the wave stores ONE contiguous kilobyte.
 // Two-piece gaps: boundary entries carry Q as well (16 bytes), and a cell has eight facts {A, D, D2, B | R1, R2, Od1, Od2} (section 3: the
 // 8-bit codes of the compact path) -- two kilobytes per tile, stored as two contiguous kilobytes.
-static __host__ __device__ inline uint32_t bsa_sys_words(uint32_t qlen){ return (qlen + 63u + 31u) / 32u; }
+static __host__ __device__ inline uint32_t bsa_sys_words(uint32_t qlen){ return (((qlen + 15u) & ~15u) + 63u + 31u) / 32u; }      // wavefront steps of the reference's whole band (roundup(qlen, 16) columns: the checked kernel runs the padding cells too)
 static __host__ __device__ inline size_t bsa_sys_bnd_off(){ return sizeof(SysHdr); }
 static __host__ __device__ inline size_t bsa_sys_lasth_off(uint32_t qlen, int pw){ return bsa_sys_bnd_off() + ((size_t)qlen + 256) * (pw == 2 ? 16 : 8); }      // H of the last target row (overlap / extend: row_max)
 static __host__ __device__ inline size_t bsa_sys_codes_off(uint32_t qlen, int pw){ return (bsa_sys_lasth_off(qlen, pw) + ((size_t)qlen + 64) * 4 + 1023) & ~(size_t)1023; }
@@ -48,17 +48,26 @@ size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen, int pw){
 	return ((bsa_sys_codes_off(qlen, pw) + bsa_sys_codes_bytes(qlen, tlen, pw) + ((size_t)qlen + tlen + 16) * 4) + 1023) & ~(size_t)1023;
 }
 
-bool bsa_align8_sys_supported(const Align8Args &a, int pw){
+// 0: not for this kernel; 1: inside the static guard (nothing of the reference's int8 arithmetic can clamp); 2: outside it, but the
+// kernel can CHECK, pair by pair, that nothing did (k_align8_fwd_sys<.., CHK = true>, below).
+int bsa_align8_sys_supported(const Align8Args &a, int pw){
 	int g = -((int)(int8_t)(a.gapo1 + a.gape1));
 	const int m = a.smax, n = -a.smin;
-	if(m < 0 || n < 0 || g < 0 || (int8_t)a.gape1 > 0 || (int8_t)a.gapo1 > 0 || ((int8_t)a.gapo1 == 0) != (pw == 0)) return false;
+	if(m < 0 || n < 0 || g < 0 || (int8_t)a.gape1 > 0 || (int8_t)a.gapo1 > 0 || ((int8_t)a.gapo1 == 0) != (pw == 0)) return 0;
 	if(pw == 2){
 		// piece 2 opens dearer and extends cheaper (bsalign.h:2084-2092); the bound is taken with the dearer opening
 		const int ge = -(int)(int8_t)a.gape1, go = -(int)(int8_t)a.gapo1, ge2 = -(int)(int8_t)a.gape2, go2 = -(int)(int8_t)a.gapo2;
-		if(ge2 < 0 || go2 <= go || ge2 >= ge) return false;
+		if(ge2 < 0 || go2 <= go || ge2 >= ge) return 0;
 		g = max(g, go2 + ge2);
 	}
-	return m + 3 * g <= 64 && n + m + g <= 100;
+	if(m + 3 * g <= 64 && n + m + g <= 100) return 1;
+	// The checked form (see the kernel): substitution scores no lower than the -63 sentinel, gap costs that keep h + gapoe and the stored e / q
+	// inside int8 whatever the cell holds, row -1's first difference (row_init, bsalign.h:2100) not truncated, penalties that are what their
+	// int8 truncations say.
+	if((int)a.gapo1 + (int)a.gape1 != (int)(int8_t)(a.gapo1 + a.gape1) || (int)a.gape1 != (int)(int8_t)a.gape1 || (int)a.gapo1 != (int)(int8_t)a.gapo1) return 0;
+	if(pw == 2 && ((int)a.gape2 != (int)(int8_t)a.gape2 || (int)a.gapo2 != (int)(int8_t)a.gapo2 || (int)a.gapo2 + (int)a.gape2 < -63)) return 0;
+	if(n > 63 || m > 63 || g > 63 || -g - n - m < -128) return 0;
+	return 2;
 }
 
 // Scores are carried times 32: the five low bits of the H register hold the query code of the column (code << 3), which travels down
@@ -72,8 +81,27 @@ bool bsa_align8_sys_supported(const Align8Args &a, int pw){
 // never wraps); one barrier per 64 steps keeps writer and reader an epoch apart.  Wave 0's upper boundary and the last wave's lower one
 // go through HBM as before, 64 columns per access.  Four waves cut a pair's latency (and the memory a full chip needs) by four.
 #define SYS_LAG 192
-template<int PW, int NWV>
-__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(PW == 2 ? 2 : 4))) k_align8_fwd_sys(const Align8Args a){
+//
+// CHK (scores outside the static guard, bsa_align8_sys_supported() == 2): exact arithmetic is the reference's arithmetic on a pair as long as
+// none of its saturating int8 operations changes a value that is used and no running block's F (G) restart at -63 (bsalign.h:2897, 2909)
+// wins against the F that really arrives.  Going through row_cal's operations (bsalign.h:2885-2960; e, u the stored row, D = H(x-1, y-1)):
+//   e + u (adds)                clamps at -128 only; h = max(e + u, S, f) >= S >= -63 hides it, and the stored e' = max(.. - h, gapoe) as well
+//   f + gape, h + gapoe         the first clamps at -128 only and then loses against h + gapoe >= -63 - g >= -128; the second cannot (g <= 63)
+//   (e + u + gape) - h          clamps at -128 only, below gapoe either way
+//   u' = h - v, v' = h - u      the new row's horizontal and vertical differences H(x, y) - H(x-1, y), H(x, y) - H(x, y-1): CHECKED per cell
+//   f' = max(..) - u            = F(x+1, y) - H(x, y-1) <= v' + gape from above; from below >= -2 g (row 0: >= -63 - g): inside int8
+//   F-penetration (:2639-2652)  its int -> int8 truncation needs a value above 127; every candidate is <= the F that arrives <= h <= 127
+//   block restart               F(x, y) - D >= -63 CHECKED per cell (x >= 1): then max(-63, F) = F at every block start, whatever W is
+// (two pieces: the same for q / G with gapo2 + gape2; linear gaps: e + u is u + gape).  So a lane tracks the minimum and maximum of its cells' two
+// differences and the minimum of F - D (G - D); a pair any of whose cells leaves [-128, 127] resp. goes below -63 is flagged BSA_ST_TRACE and
+// left to the literal kernels (bsa_align_batch re-runs it there).  Overlap / extend: row_max (bsalign.h:3213) also looks at the band's padding
+// cells behind the query (S = -63, up to 15 of them), so there the checked kernel computes and checks those as well (marker bit 2 of a
+// boundary entry; nothing of theirs is kept -- in exact arithmetic a padding cell never exceeds its left neighbour).
+#ifndef SYS_CHK_WAVES
+#define SYS_CHK_WAVES 4
+#endif
+template<int PW, int NWV, bool CHK>
+__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(PW == 2 ? 2 : CHK ? SYS_CHK_WAVES : 4))) k_align8_fwd_sys(const Align8Args a){
 	using Ent = typename std::conditional<PW == 2, int4, int2>::type;        // a boundary cell: {H * 32 | q << 3, E * 32 [, Q * 32, -]}
 	auto ent = [](int p_, int e_, int q_) -> Ent { if constexpr(PW == 2) return make_int4(p_, e_, q_, 0); else return make_int2(p_, e_); };
 	__shared__ Ent rg[NWV + 1][256 + 2];            // rg[w]: the row above wave w's rows, rg[w + 1]: its own last row; {H * 32 | q << 3, E * 32} per column
@@ -97,14 +125,16 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(P
 	const int first_u = ovl ? 0 : (int)(int8_t)(GOE + a.smin - a.smax), B0 = ovl ? 0 : a.smax - a.smin;
 	int32_t *lastH = (int32_t*)(slot + bsa_sys_lasth_off((uint32_t)qlen, PW));
 	long long bestc = (long long)0x8000000000000000ull;                              // best cell of the last query column: (score, first row) as one key
-	const int nsb = (tlen + 64 * NWV - 1) / (64 * NWV), nsteps = qlen + 63, cmax = qlen + 192;
+	const int xlim = (CHK && ends) ? ((qlen + 15) & ~15) : qlen;                     // columns computed: the query's, or (checked, overlap / extend) the reference's whole band
+	const int nsb = (tlen + 64 * NWV - 1) / (64 * NWV), nsteps = xlim + 63, cmax = xlim + 192;
+	int badl = 0;                                                                    // CHK: this lane saw a cell the reference's int8 arithmetic may treat differently
 	const int Ttot = nsteps + 1 + SYS_LAG * (NWV - 1);
 	// row -1 (row_init): H = gapo + gape (x + 1), e = -63, with the query codes
 	for(int c = (int)threadIdx.x; c < cmax; c += 64 * NWV){
 		int h = ovl ? 0 : GOE + GE * c;
 		if(PW == 2 && !ovl){ const int n1 = min(c, xp - 1); h = GOE + n1 * GE + (c - n1) * GP; }
 		const int q = (c < qlen) ? ((int)qp[c] & 3) : 0;
-		bnd[c] = ent(h * 32 + q * 8, (h + BSA_EPI8_MIN) * 32, (h + BSA_EPI8_MIN) * 32);
+		bnd[c] = ent(h * 32 + q * 8 + ((CHK && c >= qlen) ? 4 : 0), (h + BSA_EPI8_MIN) * 32, (h + BSA_EPI8_MIN) * 32);
 	}
 	for(int sb = 0; sb < nsb; sb++){
 		__builtin_amdgcn_s_waitcnt(0);                           // the boundary row is in memory before this super-block reads it
@@ -120,6 +150,7 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(P
 		int P = 0, E = 0, Q = 0, Hd = 0, F = 0, G = 0;
 		uint32_t pM = 0, pD = 0, pR = 0, pO = 0;                 // NOT-facts, newest step in bit 0 (two pieces: pM = A, pR / pO = R1 / Od1)
 		uint32_t pD2 = 0, pB = 0, pR2 = 0, pO2 = 0;             // two pieces: D2, B (as it is), R2, Od2
+		int chi = 0, clo = 0, cfl = 0;                           // CHK: max / min of the cells' differences, min of F - D (G - D)
 		uint4 *cp = (uint4*)codes + ((size_t)blk * NW * (PW == 2 ? 128 : 64) + lane);
 		Ent nxt = ent(0, 0, 0);
 		if(wv == 0){ irng[lane] = bnd[lane]; irng[64 + lane] = bnd[64 + lane]; nxt = bnd[128 + lane]; }
@@ -158,10 +189,13 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(P
 			int Qu = 0;
 			if constexpr(PW == 2) Qu = sys_shr1(b.z, Q);
 			const int Hu = Pi & ~31;
-			const int S = __builtin_amdgcn_sbfe(mr, (unsigned)Pi, 8u);
+			int S = __builtin_amdgcn_sbfe(mr, (unsigned)Pi, 8u);
 			const int Ein = (PW == 0) ? Hu + GE5 : Eu;
+			if constexpr(CHK && GEN){ if(Pi & 4) S = BSA_EPI8_MIN; }                      // a padding cell behind the query (bsalign.h:2166-2191: profile rows beyond qlen hold -63)
 			int diag = S * 32 + Hd, cmpM = 0, cmpD = 0, cmpD2 = 0;
 			const bool col0 = GEN && t == lane;
+			int dF = 0;
+			if constexpr(CHK){ dF = F - Hd; if constexpr(PW == 2) dF = min(dF, G - Hd); }  // what arrives from the left, in the cell's frame
 			if constexpr(GEN){
 				if(col0){
 					// band cell 0: the seed rule and the F restart; the M / D facts of column 0 in their own frames
@@ -182,6 +216,16 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(P
 			}
 			int H = max(max(diag, Ein), F);
 			if constexpr(PW == 2) H = max(max(H, Qu), G);
+			if constexpr(CHK){
+				const int dU = H - (P & ~31), dV = H - Hu;                                // u' = H(x, y) - H(x-1, y), v' = H(x, y) - H(x, y-1)
+				if constexpr(!GEN){
+					chi = max(chi, max(dU, dV)); clo = min(clo, min(dU, dV)); cfl = min(cfl, dF);
+				} else {
+					const int x = t - lane;
+					if(x >= 0 && x < xlim){ chi = max(chi, dV); clo = min(clo, dV); }
+					if(x >= 1 && x < xlim){ chi = max(chi, dU); clo = min(clo, dU); cfl = min(cfl, dF); }
+				}
+			}
 			const int t1 = H + GOE5;
 			if constexpr(PW == 2){
 				// the eight facts of the two-piece codes (section 3): A = M or (neither D nor D2 and both insertion chains equal h), D, D2,
@@ -269,7 +313,13 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(P
 			if(NWV > 1) __syncthreads();
 		}
 		if(wv == NWV - 1 && !lastsb)
-			for(int c0 = drained; c0 < qlen; c0 += 64){ const int c = c0 + lane; if(c < qlen) bnd[c] = orng[c & 255]; }
+			for(int c0 = drained; c0 < xlim; c0 += 64){ const int c = c0 + lane; if(c < xlim) bnd[c] = orng[c & 255]; }
+		if constexpr(CHK){
+			if(live && y < tlen && (chi > 127 * 32 || clo < -128 * 32 || cfl < BSA_EPI8_MIN * 32)) badl = 1;
+		}
+	}
+	if constexpr(CHK){
+		if(__any(badl) && lane == 0) atomicOr(&a.status[pair], BSA_ST_TRACE);       // the traceback kernel leaves a flagged pair alone
 	}
 	if(ends){
 		// overlap / extend: the best cell of the last query column (first row on ties), replaced by row_max of the last target row if that
@@ -493,10 +543,12 @@ hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_q
 	// (2000 bp x 30000 pairs: 68 ms against 100; 10 kbp x 4096: 290 against 237)
 	int nwv = (max_qlen >= 1024u && a.count < 5120u) ? 4 : 1;          // (87 VGPRs: five waves per SIMD, 5120 on the chip -- a wave per pair fills it from there on)
 	if(const char *e = bsa_env("BSA_ALIGN8_SYS_WAVES")){ const int v = atoi(e); if(v == 1 || v == 2 || v == 4 || v == 8) nwv = v; }
-#define SYS_LAUNCH(N_) do { if(pw == 0) hipLaunchKernelGGL((k_align8_fwd_sys<0, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); \
-		else if(pw == 1) hipLaunchKernelGGL((k_align8_fwd_sys<1, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); \
-		else hipLaunchKernelGGL((k_align8_fwd_sys<2, N_>), dim3(a.count), dim3(64 * N_), 0, st, a); } while(0)
+#define SYS_LAUNCH_(N_, C_) do { if(pw == 0) hipLaunchKernelGGL((k_align8_fwd_sys<0, N_, C_>), dim3(a.count), dim3(64 * N_), 0, st, a); \
+		else if(pw == 1) hipLaunchKernelGGL((k_align8_fwd_sys<1, N_, C_>), dim3(a.count), dim3(64 * N_), 0, st, a); \
+		else hipLaunchKernelGGL((k_align8_fwd_sys<2, N_, C_>), dim3(a.count), dim3(64 * N_), 0, st, a); } while(0)
+#define SYS_LAUNCH(N_) do { if(a.sys_chk) SYS_LAUNCH_(N_, true); else SYS_LAUNCH_(N_, false); } while(0)
 	if(nwv == 8) SYS_LAUNCH(8); else if(nwv == 4) SYS_LAUNCH(4); else if(nwv == 2) SYS_LAUNCH(2); else SYS_LAUNCH(1);
+#undef SYS_LAUNCH_
 #undef SYS_LAUNCH
 	return hipGetLastError();
 }

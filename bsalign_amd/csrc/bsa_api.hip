@@ -36,6 +36,7 @@ struct bsa_ctx {
 	std::vector<hipEvent_t> tev;     // the same for the traceback launches (on the stream they run on)
 	size_t tev_used = 0;
 	std::string fwd_name, trace_name;    // kernels behind those two timings
+	long last_handover = 0;              // pairs the last bsa_align_batch re-ran through the literal kernels
 	double diagdp_ms = 0;
 	// small device buffers kept between calls (slot 0: a plan's metadata pool, slot 1: the host-pointer wrapper's buffers): a batch
 	// of one pair otherwise spends more time in hipMalloc / hipFree than in its kernels
@@ -171,6 +172,7 @@ extern "C" int bsa_ctx_last_trace_ms(bsa_ctx_t *c, double *ms, long *launches){
 	return BSA_OK;
 }
 thread_local const char *bsa_last_fwd_kernel = nullptr, *bsa_last_trace_kernel = nullptr;
+extern "C" long bsa_ctx_last_handover(bsa_ctx_t *c){ return c ? c->last_handover : 0; }
 extern "C" const char *bsa_ctx_last_kernel_name(bsa_ctx_t *c, int traceback){ return !c ? "" : traceback ? c->trace_name.c_str() : c->fwd_name.c_str(); }
 
 static int ctx_trace_event_pair(bsa_ctx *c, hipEvent_t *a, hipEvent_t *b){
@@ -712,6 +714,7 @@ struct bsa_align_plan : PlanBase {
 	uint32_t ref_bw = 0;                         // a whole-query band widened to bw: the reference's own bandwidth (1 = per pair), see bsa_align_plan_create
 	bool static_band = false;                    // no query is longer than the band: it never moves
 	bool sys = false;                            // whole-query bands above 256 columns, global mode: the systolic wavefront (bsa_align8_sys.hip)
+	bool sys_chk = false;                        // ... with scores outside the static guard: the kernel checks every pair (Align8Args::sys_chk)
 	uint32_t max_qlen = 0;
 	size_t stage_bytes = 0;                      // staged bytes of all pairs (which staging kernel)
 	uint32_t qpad = 0, tpad = 16;
@@ -771,7 +774,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	// Whole-query bands above 256 columns (the reference CLI's default on long reads; `bsalign align` defaults to overlap mode): all three modes, linear or affine gaps, scores inside
 	// the exact-arithmetic guard -> the systolic wavefront with its own code rows and traceback (bsa_align8_sys.hip) instead of the
 	// LDS-resident run-time-width kernel.  BSA_ALIGN8_SYS=0 keeps the old dispatch.
-	bool sys = false; uint32_t max_qlen = 0;
+	bool sys = false, sys_chk = false; uint32_t max_qlen = 0;
 	for(size_t k = 0; k < n; k++) max_qlen = std::max(max_qlen, qlen[k]);
 	// (two-piece gaps: the register kernels stop at 128 columns, so the systolic kernel takes over from there)
 	const uint32_t sys_from = (bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)std::max(max_bw, 16u)) == 2) ? 128u : 256u;
@@ -787,7 +790,10 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 			for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)par->matrix[i]); smin = std::min(smin, (int)par->matrix[i]); }
 			t.smax = smax; t.smin = smin;
 			const int pwa = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, 16), pwb = bsa_get_piecewise(par->gapo1, par->gape1, par->gapo2, par->gape2, (int)max_bw);
-			sys = pwa == pwb && bsa_align8_sys_supported(t, pwb);
+			const int lvl = pwa == pwb ? bsa_align8_sys_supported(t, pwb) : 0;
+			const char *ce = bsa_env("BSA_ALIGN8_SYS_CHK");                 // =0: scores outside the static guard keep the run-time-width kernel; =1: the checked kernel inside the guard as well (tests)
+			sys = lvl == 1 || (lvl == 2 && !(ce && ce[0] == '0'));
+			sys_chk = sys && (lvl == 2 || (ce && ce[0] == '1'));
 			if(sys){
 				// the kernel carries scores times 32 in 32-bit registers: |H| <= (qlen + tlen) x the largest step
 				uint32_t max_tlen = 0;
@@ -799,7 +805,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 	}
 	bsa_align_plan *p = new bsa_align_plan();
 	p->ctx = c; p->n = n; p->par = *par; p->bw = bw;
-	p->sys = sys; p->max_qlen = max_qlen;
+	p->sys = sys; p->sys_chk = sys && sys_chk; p->max_qlen = max_qlen;
 	p->ref_bw = widened ? (bw_req ? bw_req : 1u) : sys ? bw_req : 0u;
 	p->static_band = bw != 0 && n > 0;
 	for(size_t k = 0; k < n && p->static_band; k++) p->static_band = qlen[k] <= bw;
@@ -880,7 +886,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	memset(&a, 0, sizeof(a));
 	a.qst = p->d_qst; a.tst = p->d_tst; a.qpoff = p->d_qpoff; a.tpoff = p->d_tpoff;
 	a.qlen = p->d_qlen; a.tlen = p->d_tlen; a.order = p->d_order; a.slot_off = p->d_slot;
-	a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode; a.ref_bw = p->ref_bw; a.static_band = p->static_band ? 1u : 0u;
+	a.status = status; a.bw = p->bw; a.rowb = p->rowb; a.mode = p->par.mode; a.ref_bw = p->ref_bw; a.static_band = p->static_band ? 1u : 0u; a.sys_chk = p->sys_chk ? 1u : 0u;
 	a.gapo1 = p->par.gapo1; a.gape1 = p->par.gape1; a.gapo2 = p->par.gapo2; a.gape2 = p->par.gape2;
 	int smax = -127, smin = 127;
 	for(int i = 0; i < 16; i++){ smax = std::max(smax, (int)p->par.matrix[i]); smin = std::min(smin, (int)p->par.matrix[i]); a.matrix[i] = p->par.matrix[i]; }
@@ -902,7 +908,7 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 		fwd_x = (pw == 2) || (!force_pk && bsa_align8_x_supported(a, pw));       // (two-piece gaps: the only forward kernel of the compact path)
 	}
 	if(codes && fwd_x && bsa_align8_do2_supported(a, pw) && bsa_align8_trace_reads_do2(a, pw)) a.code_fmt = 1u;      // two-bit D / Od fields (bsa_common.h)
-	c->fwd_name = sys ? "k_align8_fwd_sys (whole-query band, systolic wavefront, 4-bit traceback codes)" : (fwd_x && pw == 2) ? "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)"
+	c->fwd_name = (sys && p->sys_chk) ? "k_align8_fwd_sys<CHK> (whole-query band, systolic wavefront checking every pair against the int8 range, 4-bit traceback codes)" : sys ? "k_align8_fwd_sys (whole-query band, systolic wavefront, 4-bit traceback codes)" : (fwd_x && pw == 2) ? "k_align8_fwd_x2 (exact-arithmetic forward DP, two-piece gaps, 8-bit traceback codes)"
 		: fwd_x ? "k_align8_fwd_x (exact-arithmetic forward DP, 4-bit traceback codes)" : codes ? "k_align8_fwd_pk<.,.,true> (packed forward DP, 4-bit traceback codes)"
 		: generic ? "k_align8_fwd_gen (run-time bandwidth, row records)" : "k_align8_fwd_pk / k_align8_fwd (row records)";
 	c->trace_name = sys ? "k_align8_trace_sys" : codes ? "" : "k_align8_backcal";
@@ -967,6 +973,7 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 			const int present = (cnt[0] != 0) + (cnt[1] != 0) + (cnt[2] != 0) + (cnt[3] != 0);
 			if(present > 1){
 				std::vector<std::vector<uint32_t>> pc(n);          // per pair CIGAR words
+				size_t still_flagged = 0; long handed = 0;
 				for(int cl = 0; cl < 4; cl++){
 					if(!cnt[cl]) continue;
 					const size_t m = cnt[cl];
@@ -981,8 +988,10 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 					const int rcs = bsa_align_batch(c, seqs, seqs_bytes, sq.data(), sql.data(), stt.data(), stl.data(), m, par, sout.data(),
 						cigar ? scig.data() : nullptr, scap, (cigar && cigar_off) ? soff.data() : nullptr, sst.data());
 					if(rcs != BSA_OK) return rcs;
+					handed += c->last_handover;
 					for(size_t j = 0; j < m; j++){
 						out[idx[j]] = sout[j];
+						if(sst[j] & BSA_ST_TRACE) still_flagged++;
 						if(status) status[idx[j]] = sst[j];
 						if(cigar && cigar_off) pc[idx[j]].assign(scig.begin() + soff[j], scig.begin() + soff[j + 1]);
 					}
@@ -994,11 +1003,15 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 					if(w > cigar_cap_words){ c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
 					for(size_t k = 0; k < n; k++) if(!pc[k].empty()) memcpy(cigar + cigar_off[k], pc[k].data(), pc[k].size() * 4);
 				}
+				c->last_handover = handed;
+				// the rule of the single-plan path below (finish()): without a status array an undecided pair is an error, never a silent zeroed record
+				if(status == nullptr && still_flagged){ c->err = "pairs left undecided (BSA_ST_TRACE) and no status array to report them in"; return BSA_E_UNSUPPORTED; }
 				return BSA_OK;
 			}
 		}
 	}
 	bsa_align_plan_t *p = nullptr;
+	if(!(par->mode & BSA_MODE_ROWRECORDS)) c->last_handover = 0;
 	const bool timing = bsa_env("BSA_API_TIMING") != nullptr;          // (stderr: where a host-pointer batch spends its wall time)
 	const auto tm0 = std::chrono::steady_clock::now();
 	int rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
@@ -1046,6 +1059,7 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	};
 	if(idx.empty()) return finish(left_flagged);
 	const size_t m = idx.size();
+	c->last_handover = (long)m;
 	if(timing) fprintf(stderr, "[bsa_align_batch] %zu pairs handed over to the literal kernels\n", m);
 	std::vector<uint64_t> sq(m), stt(m), soff(m + 1);
 	std::vector<uint32_t> sql(m), stl(m), sst(m);

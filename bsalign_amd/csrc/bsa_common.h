@@ -36,6 +36,7 @@ struct Align8Args {
 	uint32_t ref_bw;            // compact path, a whole-query band widened to `bw` (bsa_api.hip): the reference's own bandwidth (1 = per pair roundup(qlen, 16)); 0 = bw
 	uint32_t code_fmt;          // compact slots, one-piece gaps at bandwidth 128: 0 = four flag planes a block, 1 = M, R and two-bit D / Od fields (below)
 	uint32_t max_tlen;          // longest target of the launch (pairs are ordered by target length: that of position `first`)
+	uint32_t sys_chk;           // systolic whole-query kernel: scores outside the static guard -- the kernel checks every pair and flags (BSA_ST_TRACE) the ones on which the reference's int8 arithmetic may clamp
 	uint32_t *xq; uint64_t xq_bytes;    // control words + band states of the persistent forward kernel (k_align8_fwd_xq), or null
 	int32_t  mode;
 	int32_t  gapo1, gape1, gapo2, gape2;
@@ -224,7 +225,7 @@ extern thread_local const char *bsa_last_fwd_kernel, *bsa_last_trace_kernel;
 hipError_t bsa_launch_align8_fwd_x(const Align8Args &a, int pw, hipStream_t st);
 size_t bsa_align8_xq_bytes(uint32_t bw, int pw, uint32_t count);       // what Align8Args::xq must hold for a launch of `count` pairs (0: no persistent form)
 // whole-query bands above 256 columns, global mode: systolic wavefront + its own code layout and traceback (bsa_align8_sys.hip)
-bool bsa_align8_sys_supported(const Align8Args &a, int pw);
+int bsa_align8_sys_supported(const Align8Args &a, int pw);          // 0 no, 1 inside the static guard, 2 with the kernel checking every pair (Align8Args::sys_chk)
 size_t bsa_align8_sys_slot_bytes(uint32_t qlen, uint32_t tlen, int pw);
 hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_qlen, hipStream_t st);
 hipError_t bsa_launch_align8_trace_sys(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, const uint64_t *slot_end, hipStream_t st);

@@ -103,6 +103,10 @@ int         bsa_ctx_last_kernel_ms(bsa_ctx_t *ctx, double *ms, long *launches, d
  * (traceback = 0: forward DP, 1: traceback) */
 int         bsa_ctx_last_trace_ms(bsa_ctx_t *ctx, double *ms, long *launches);
 const char *bsa_ctx_last_kernel_name(bsa_ctx_t *ctx, int traceback);
+/* pairs of the last bsa_align_batch call that the compact (code) path left undecided and the literal kernels re-ran
+ * (the hand-over described at bsa_align_batch; with scores outside the static guard: the pairs the checked whole-query
+ * kernel flagged) */
+long        bsa_ctx_last_handover(bsa_ctx_t *ctx);
 void        bsa_set_score_matrix(int8_t matrix[16], int8_t mat, int8_t mis);   /* bsalign.h:323 */
 
 /* ---- 8-bit banded striped pairwise alignment (A-rows) ------------------------------------------

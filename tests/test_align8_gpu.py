@@ -6,6 +6,13 @@ import support as S
 
 pytestmark = pytest.mark.gpu
 
+# scores outside the static exact-arithmetic guard (m + 3 g <= 64, n + m + g <= 100): lane-exact kernels, or the checked whole-query kernel
+BIG_SCORINGS = {
+    "big": (10, -30, -20, -10, 0, 0),
+    "biglinear": (9, -25, 0, -24, 0, 0),
+    "big2piece": (6, -20, -12, -8, -30, -3),
+}
+
 SCORINGS = {
     "affine": (2, -6, -3, -2, 0, 0),
     "paper": (2, -2, -4, -2, 0, 0),
@@ -78,6 +85,10 @@ def test_generic_bandwidths(ctx, bw):
         _check(ctx, pairs, mode, bw, SCORINGS["affine"])
     _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS["twopiece"])
     _check(ctx, pairs, S.MODE_GLOBAL, bw, SCORINGS["linear"] if "linear" in SCORINGS else SCORINGS["affine"])
+    # scores outside the exact-arithmetic guard, all three modes: the int8 saturation of the reference cell by cell
+    for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+        _check(ctx, pairs[:24], mode, bw, BIG_SCORINGS["big"])
+    _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, BIG_SCORINGS["big2piece"])
 
 
 def test_bandwidth_zero_is_full_query(ctx):
@@ -461,9 +472,62 @@ def test_whole_query_bands_above_256_columns_run_the_systolic_wavefront(ctx, bw,
     monkeypatch.setenv("BSA_ALIGN8_SYS_TRACE", "lane")
     _check(ctx, pairs, S.MODE_OVERLAP, bw, SCORINGS["twopiece"])
     monkeypatch.delenv("BSA_ALIGN8_SYS_TRACE")
-    # scorings outside the guard keep the run-time-width kernel
-    _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, (10, -30, -20, -10, 0, 0))
+    # scorings the checked kernel cannot take either (row -1's first difference gapo + gape + min - max does not fit int8) keep the run-time-width kernel
+    _check(ctx, pairs[:16], S.MODE_GLOBAL, bw, (50, -50, -20, -10, 0, 0))
     assert "sys" not in ctx.last_kernel_names()[0]
+
+
+@pytest.mark.parametrize("bw", [0, 1008])
+def test_whole_query_bands_with_scores_outside_the_guard_run_the_checked_systolic_kernel(ctx, bw, monkeypatch):
+    """whole-query bands above 256 columns with scores outside the static guard (they ran the run-time-width
+    kernel at 28 GCUPS): the systolic kernel in its CHECKED form -- every pair's cells are tested against the int8 range the
+    reference computes in (and the -63 restart of its running blocks), a pair that fails is flagged and re-run by the literal
+    kernels.  Results equal the lane-exact oracle's in all three modes and gap models; on ordinary pairs nothing is handed over;
+    the unchecked run-time-width kernel (BSA_ALIGN8_SYS_CHK=0) gives the same."""
+    import bsalign_amd as B
+    rng = np.random.default_rng(9100 + bw)
+    top = bw if bw else 3000
+    lens = [l for l in (257, 272, 273, 300, 320, 500, 511, 512, 513, 700, 1000, 1008, 1500, 2047, 2048, 2049, 3000) if l <= top]
+    pairs = [(q[:top] if len(q) > top else q, t) for q, t in _mk_pairs(rng, 60, lens, eps_list=(0.0, 0.05, 0.2, 0.4), ratios=(1.0, 1.0, 0.5, 0.9, 1.1))]
+    pairs = [(q, t) for q, t in pairs if len(q) > 256 or bw]
+    pairs.append((pairs[0][0], pairs[0][1][:1]))            # a one-row target
+    pairs.append((pairs[1][0], pairs[1][1][:63]))
+    pairs.append((pairs[2][0], pairs[2][1][:65]))
+    for scname, sc in BIG_SCORINGS.items():
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP, S.MODE_EXTEND):
+            _check(ctx, pairs, mode, bw, sc)
+            names = ctx.last_kernel_names()
+            assert "k_align8_fwd_sys<CHK>" in names[0] and "k_align8_trace_sys" in names[1], names
+            if scname != "big2piece":
+                assert ctx.last_handover() <= 2, (scname, mode, ctx.last_handover())       # (a deletion run that reaches row -1 is the literal path's, DESIGN section 5)
+    par = B.make_params(S.MODE_OVERLAP, bw, *BIG_SCORINGS["big"])
+    out_s, cig_s, st_s = ctx.align_batch(pairs, par)
+    monkeypatch.setenv("BSA_ALIGN8_SYS_CHK", "0")
+    out_g, cig_g, st_g = ctx.align_batch(pairs, par)
+    assert "gen" in ctx.last_kernel_names()[0]
+    monkeypatch.delenv("BSA_ALIGN8_SYS_CHK")
+    assert np.array_equal(out_s, out_g) and np.array_equal(st_s, st_g) and all(np.array_equal(a, b) for a, b in zip(cig_s, cig_g))
+    # the checked kernel inside the guard (forced): same results as the unchecked one, nothing flagged
+    monkeypatch.setenv("BSA_ALIGN8_SYS_CHK", "1")
+    for mode in (S.MODE_GLOBAL, S.MODE_EXTEND):
+        _check(ctx, pairs, mode, bw, SCORINGS["affine"])
+        assert "k_align8_fwd_sys<CHK>" in ctx.last_kernel_names()[0] and ctx.last_handover() <= 2
+
+
+def test_checked_systolic_kernel_flags_what_the_int8_arithmetic_clamps(ctx):
+    """gap costs so large that the F entering a running block can lie below the block's own restart value of -63 (gapo + gape
+    below -31: the striping of the reference's band then shows in the result): the checked kernel must flag such pairs (they are
+    re-run by the lane-exact kernels) -- results equal the oracle's either way, and pairs are indeed handed over"""
+    import bsalign_amd as B
+    rng = np.random.default_rng(9200)
+    pairs = _mk_pairs(rng, 40, [300, 500, 700, 1000], eps_list=(0.02, 0.1, 0.3), ratios=(1.0, 0.9, 1.1))
+    handed = 0
+    for sc in ((40, -40, -20, -25, 0, 0), (20, -40, -25, -15, 0, 0), (5, -60, -3, -60, 0, 0)):
+        for mode in (S.MODE_GLOBAL, S.MODE_OVERLAP):
+            _check(ctx, pairs, mode, 0, sc)
+            assert "k_align8_fwd_sys<CHK>" in ctx.last_kernel_names()[0], ctx.last_kernel_names()
+            handed += ctx.last_handover()
+    assert handed > 0
 
 
 def test_whole_query_plan_with_mixed_lengths_on_device_pointers(ctx):
