@@ -90,6 +90,19 @@ double fewer_errors(uint32_t n, uint32_t k, double p, LogFactorial &lf){
 
 }  // namespace
 
+// The model's tables and constants for the device form (bsa_cns_dev.hip): the logarithms are taken HERE, by the host's libm, so that the
+// sums the device forms from them are the host's bit for bit.  cost / next as in StepModel; lf[k] = log(k!) for k <= nlf - 1;
+// consts = { ln 10, log(psub), log(1 - psub), (double)psub }.
+extern "C" void bsa_cns_model_internal(const bsa_cns_params_t *par, double *cost, uint8_t *next, double *lf, uint32_t nlf, double *consts){
+	const StepModel model(*par);
+	memcpy(cost, model.cost, sizeof(model.cost));
+	memcpy(next, model.next, sizeof(model.next));
+	LogFactorial f;
+	for(uint32_t k = 0; k < nlf; k++) lf[k] = f(k);
+	const double psub = par->psub;
+	consts[0] = std::log(10.0); consts[1] = std::log(psub); consts[2] = std::log(1 - psub); consts[3] = psub;
+}
+
 extern "C" int bsa_msa_call_consensus(uint8_t *cols, const uint32_t *idxs, uint32_t nall, uint32_t nseq, uint32_t nmax, uint32_t mlen,
 		const bsa_cns_params_t *par, uint8_t *cns, uint8_t *qlt, uint8_t *alt, uint32_t *clen, double *score){
 	if(!par || (mlen && !cols) || nseq > nall || nmax > nall) return BSA_E_ARG;

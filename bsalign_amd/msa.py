@@ -87,3 +87,53 @@ def text(cols, idxs, nseq, mlen, cns, qlt, alt, label, mbeg=0, mend=0, linewidth
     nvar = 0 if var is None else var.size
     return _two_pass(lambda o, cap, need: lib().bsa_msa_text(_p(cols), _p(idxs), nseq, mlen, _p(cns), _p(qlt), _p(alt), _p(var), nvar,
                                                             label.encode(), mbeg, mend, linewidth, o, cap, C.byref(need)))
+
+
+CNS_WINDOW_DTYPE = np.dtype([("cols_off", np.uint64), ("idxs_off", np.uint64), ("out_off", np.uint64),
+                             ("nall", np.uint32), ("nseq", np.uint32), ("nmax", np.uint32), ("mlen", np.uint32)])
+
+
+def call_consensus(cols, idxs, nall, nseq, nmax, mlen, par7):
+    """host form (bsa_msa_call_consensus = cns_bspoa): -> (cns, qlt, alt, score); the three consensus bytes of `cols` are overwritten"""
+    L = lib()
+    L.bsa_msa_call_consensus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    cns, qlt, alt = (np.zeros(mlen + 1, np.uint8) for _ in range(3))
+    clen, score = C.c_uint32(), C.c_double()
+    par7 = np.ascontiguousarray(par7, np.float32)
+    rc = L.bsa_msa_call_consensus(_p(cols), _p(idxs), nall, nseq, nmax, mlen, _p(par7), _p(cns), _p(qlt), _p(alt), C.byref(clen), C.byref(score))
+    if rc != 0:
+        raise BsaError(rc)
+    return cns[:clen.value], qlt[:clen.value], alt[:clen.value], score.value
+
+
+def call_consensus_batch(ctx, windows, par7):
+    """device form (bsa_msa_call_consensus_batch): windows = [(cols uint8 [ncolumns * (nall + 3)], idxs uint32 [mlen] or None, nall, nseq, nmax, mlen)];
+    -> [(cns, qlt, alt, score, cols with the three consensus bytes of every column written)]"""
+    L = lib()
+    L.bsa_msa_call_consensus_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    n = len(windows)
+    win = np.zeros(n, CNS_WINDOW_DTYPE)
+    cparts, iparts = [], []
+    cacc = iacc = oacc = 0
+    for k, (cols, idxs, nall, nseq, nmax, mlen) in enumerate(windows):
+        cols = np.ascontiguousarray(cols, np.uint8).reshape(-1)
+        win[k] = (cacc, np.uint64(0xFFFFFFFFFFFFFFFF) if idxs is None else iacc, oacc, nall, nseq, nmax, mlen)
+        cparts.append(cols); cacc += cols.size
+        if idxs is not None:
+            iparts.append(np.ascontiguousarray(idxs, np.uint32)); iacc += len(idxs)
+        oacc += mlen
+    blob = np.concatenate(cparts) if cparts else np.zeros(0, np.uint8)
+    iblob = np.concatenate(iparts) if iparts else np.zeros(0, np.uint32)
+    cns, qlt, alt = (np.zeros(max(oacc, 1), np.uint8) for _ in range(3))
+    clen = np.zeros(max(n, 1), np.uint32); score = np.zeros(max(n, 1), np.float64)
+    par7 = np.ascontiguousarray(par7, np.float32)
+    rc = L.bsa_msa_call_consensus_batch(ctx.h, _p(blob), blob.size, _p(iblob) if iblob.size else None, iblob.size, _p(win), n, _p(par7),
+                                        _p(cns), _p(qlt), _p(alt), oacc, _p(clen), _p(score))
+    if rc != 0:
+        raise BsaError(rc)
+    out = []
+    for k, (cols, idxs, nall, nseq, nmax, mlen) in enumerate(windows):
+        o = int(win[k]["out_off"]); m = int(clen[k]); c0 = int(win[k]["cols_off"])
+        out.append((cns[o:o + m].copy(), qlt[o:o + m].copy(), alt[o:o + m].copy(), float(score[k]), blob[c0:c0 + np.asarray(cols).size].copy()))
+    return out

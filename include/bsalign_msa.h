@@ -63,6 +63,20 @@ typedef struct { float psub, pins, pdel, piex, pdex, hins, hdel; } bsa_cns_param
 int bsa_msa_call_consensus(uint8_t *cols, const uint32_t *idxs, uint32_t nall, uint32_t nseq, uint32_t nmax, uint32_t mlen,
                            const bsa_cns_params_t *par, uint8_t *cns, uint8_t *qlt, uint8_t *alt, uint32_t *clen, double *score);
 
+/* The same for MANY windows on the device (bsa_cns_dev.hip; needs a context of libbsalign_hip, include/bsalign_hip.h): window k's columns
+ * start at cols + win[k].cols_off (mrow = nall + 3 as above), its column order at idxs + win[k].idxs_off (words; ~0: storage order), its
+ * consensus / qualities go to cns / qlt / alt + win[k].out_off (room for mlen each), clen[k] / score[k] as above.  One wave runs a window's
+ * columns (the automaton is sequential in them), the windows run side by side.  Every sum over the reads is formed in the host form's order
+ * from the host's own logarithm tables, so it has the host's bits; the merges log(exp a + exp b) use the device's exp / log, which may
+ * differ from the host libm's in the last place: consensus, both quality strings and the three bytes of every column are the host form's
+ * (and the reference's) byte for byte on everything tested (tests/test_cns_gpu.py), score[k] to a relative 1e-12.
+ * Returns BSA_E_UNSUPPORTED above ~9900 reads in a window (the per-read state lives in LDS). */
+typedef struct { uint64_t cols_off, idxs_off, out_off; uint32_t nall, nseq, nmax, mlen; } bsa_cns_window_t;
+struct bsa_ctx;
+int bsa_msa_call_consensus_batch(struct bsa_ctx *ctx, uint8_t *cols, size_t cols_bytes, const uint32_t *idxs, size_t idxs_words,
+                                 const bsa_cns_window_t *win, size_t nwin, const bsa_cns_params_t *par,
+                                 uint8_t *cns, uint8_t *qlt, uint8_t *alt, size_t out_bytes, uint32_t *clen, double *score);
+
 #ifdef __cplusplus
 }
 #endif
