@@ -932,8 +932,9 @@ def main():
             if not finished.wait(limit):
                 if rank == 0:
                     line["exchange"] = {"error": "the shard exchange did not finish within %d s; the line is printed without it" % int(limit)}
+                    line["exchange_ok"] = False                # top level, for the driver: the measured numbers above stand, the N-rank exchange did NOT work
                     emit(line)
-                os._exit(0)
+                os._exit(0 if rank == 0 else 3)               # (a hung collective cannot be torn down in order; the other ranks leave with a failure code)
 
         if world > 1:
             threading.Thread(target=watchdog, daemon=True).start()
@@ -961,6 +962,7 @@ def main():
         host = None
         if rank == 0 and exchange is not None:
             line["exchange"] = exchange
+            line["exchange_ok"] = bool(exchange.get("gathered_identical_to_rank0_whole_batch")) and "error" not in exchange
     if plan is not None:
         plan.close()
     ctx.close()

@@ -282,7 +282,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 #endif
 	constexpr int KD = NQ + 12;                           // dwords per block in the window: 48 bytes of band movement between refills
 	constexpr uint32_t QOFFMAX = 4u * (uint32_t)(KD - NQ - 1) + 3u;      // the last offset at which dwords k .. k + NQ are all inside
-	static_assert(!QWIN || 4 * KD - W <= 96, "the window reads behind the band: the staged query's padding (bsa_api.hip: qpad = bandwidth + 32) must cover it");
+	static_assert(!QWIN || 4 * KD - W <= BSA_QPAD_TAIL, "the window reads 4 KD - W bytes behind the band's last block: the staged query's padding (bsa_api.hip: qpad = bandwidth + BSA_QPAD_TAIL) must cover it");
 	__shared__ uint32_t x_qwin[(QWIN && !EXT) ? NWV : 1][(QWIN && !EXT) ? 2 * KD : 1][64];
 	uint32_t *const qwp = EXT ? ext_qwin + (size_t)(lt >> 6) * (2 * KD * 64) + (lt & 63) : &x_qwin[(QWIN && !EXT && NWV > 1) ? (lt >> 6) : 0][0][lt & 63];
 	uint32_t wbase = 0x40000000u;                          // band offset the window starts at (this value: no window yet)
@@ -915,22 +915,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPS))) 
 		// BOUNDED wait (an item's predecessor was handed out earlier, i.e. is running: in a healthy launch this loop hardly ever turns).  Should the
 		// predecessor never arrive -- a fault in its wave, a future change of the ticket order -- the wave gives up after about two seconds
 		// (2^22 turns of s_sleep 16 = 1024 cycles), raises q.ctl[1] and flags its pairs BSA_ST_DEVICE instead of hanging the device: flagged pairs
-		// are skipped by every later segment and by the traceback (zeroed result), the plan's run returns BSA_E_HIP.
+		// are skipped by every later segment and by the traceback (zeroed result).  bsa_align_batch scans the status words and returns BSA_E_HIP;
+		// a caller of the device-pointer form (bsa_align_run is asynchronous) finds the flag in its status array (include/bsalign_hip.h).
+		// A wave waits for ITS predecessor only: another group's give-up does not end the wait of a healthy one.
 		uint32_t gaveup = 0;
 		if(threadIdx.x == 0u){
 			uint32_t turns = 0;
 			while(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s){
 				__builtin_amdgcn_s_sleep(16);
-				if(++turns >= q.spin_cap || ((turns & 1023u) == 0u && __hip_atomic_load(q.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)){ gaveup = 1; break; }
+				if(++turns >= q.spin_cap){ gaveup = 1; break; }
 			}
 		}
 		gaveup = (uint32_t)__builtin_amdgcn_readfirstlane((int)gaveup);
 		if(gaveup){
 			const uint32_t pg = (g * 64u + threadIdx.x) / (uint32_t)L;
 			if((threadIdx.x & (uint32_t)(L - 1)) == 0u && pg < a.count) atomicOr(&a.status[a.order[a.first + pg]], BSA_ST_DEVICE);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the flags are visible before the successor (which acquires after its wait) is let go
 			if(threadIdx.x == 0u){
 				atomicOr(q.ctl + 1, 1u);
-				__hip_atomic_fetch_max(done, s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // successors go on (and skip the flagged pairs)
+				__hip_atomic_fetch_max(done, s + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);          // successors go on (and skip the flagged pairs)
 			}
 			return;
 		}

@@ -818,7 +818,7 @@ extern "C" int bsa_align_plan_create(bsa_ctx_t *c, const uint64_t *qoff, const u
 		delete p; return BSA_E_UNSUPPORTED;
 	}
 	p->rowb = bw ? 16u * bsa_tile_bytes(bw / 16u, p->pw) : 0u;
-	p->qpad = max_bw + 96;          // (the forward kernels' query window reads up to 48 bytes behind the band's last block: bsa_align8_x.hip, x_qwin)
+	p->qpad = max_bw + BSA_QPAD_TAIL;          // (the forward kernels' query window reads up to 48 bytes behind the band's last block: bsa_align8_x.hip, x_qwin)
 	{
 		// compact traceback where its preconditions hold (BSA_ALIGN8_LITERAL=1 keeps the row-record path)
 		const char *le = bsa_env("BSA_ALIGN8_LITERAL");

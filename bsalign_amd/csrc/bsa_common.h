@@ -17,6 +17,9 @@ extern "C" void bsa_env_reload(void);
 #define BSA_QPAD_CODE  4                       // staged query code for columns >= qlen (S = -63, bsalign.h:2157-2160)
 
 // device-side description of one batch chunk of the 8-bit path
+// bytes of padding behind the band of a staged query (bsa_api.hip: qpad = widest band + BSA_QPAD_TAIL): the forward kernels' LDS query window
+// (bsa_align8_x.hip, x_qwin) reads up to 4 KD - W = 48 bytes behind the band's last block; one constant for the plan and the kernels' static_assert
+#define BSA_QPAD_TAIL 96
 struct Align8Args {
 	// staged sequences: query codes padded with BSA_QPAD_CODE, target bytes
 	const uint8_t  *qst;        // staged queries

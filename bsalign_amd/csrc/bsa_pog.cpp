@@ -252,6 +252,25 @@ extern "C" int bsa_pog_import(bsa_pog_t *g, const bsa_pog_snapshot_t *s, const u
 	// out-lists first (they make the edges), then every in-list links the same edges in its own order
 	const uint32_t ne = s->out_off[n];
 	if(s->in_off[n] != ne || (ne && (!s->out_to || !s->out_cov || !s->in_from))) return BSA_E_ARG;
+	// a snapshot comes from outside (fixtures, a binding's copy of another graph): nothing below may trust it.  Offsets start at zero and never
+	// decrease (so no list reaches past `ne`); every ring's header is a header and the ring closes; every edge is linked into ONE in-list.
+	if(s->out_off[0] != 0 || s->in_off[0] != 0) return BSA_E_ARG;
+	for(uint32_t u = 0; u < n; u++) if(s->out_off[u + 1] < s->out_off[u] || s->in_off[u + 1] < s->in_off[u] || s->out_off[u + 1] > ne || s->in_off[u + 1] > ne) return BSA_E_ARG;
+	{
+		std::vector<uint8_t> seen(n, 0);
+		for(uint32_t i = 0; i < n; i++){
+			const uint32_t h = g->header[i];
+			if(g->header[h] != h) return BSA_E_ARG;
+			if(i != h || seen[h]) continue;
+			uint32_t x = h, steps = 0;
+			do {                                                        // the ring of h: every member names h, next / prev agree, back at h within n steps
+				if(g->header[x] != h || g->prev[g->next[x]] != x || seen[x] || ++steps > n) return BSA_E_ARG;
+				seen[x] = 1; x = g->next[x];
+			} while(x != h);
+		}
+		for(uint32_t i = 0; i < n; i++) if(!seen[i]) return BSA_E_ARG;   // (a node whose ring never reaches its header)
+	}
+	std::vector<uint8_t> linked((size_t)ne + 1, 0);
 	g->edges.resize((size_t)ne + 1);
 	for(uint32_t u = 0; u < n; u++){
 		uint32_t *p = &g->out[u];
@@ -269,7 +288,8 @@ extern "C" int bsa_pog_import(bsa_pog_t *g, const bsa_pog_snapshot_t *s, const u
 			if(u >= n) return BSA_E_ARG;
 			uint32_t e = 0;
 			for(uint32_t j = s->out_off[u]; j < s->out_off[u + 1]; j++) if(s->out_to[j] == v){ e = j + 1; break; }
-			if(!e) return BSA_E_ARG;
+			if(!e || linked[e]) return BSA_E_ARG;                 // no such edge, or already in an in-list (a duplicate would close the list on itself)
+			linked[e] = 1;
 			*p = e; p = &g->edges[e].next_in;
 		}
 	}

@@ -62,7 +62,8 @@ extern "C" {
                                     bsa_align_batch does that itself. */
 #define BSA_ST_DEVICE      8u   /* the device gave the pair up: a wave of the segmented forward pass waited for the previous segment's
                                     state longer than its bound (about two seconds) -- a fault, never an input property.  Result zeroed;
-                                    bsa_align_batch returns BSA_E_HIP when any pair carries it. */
+                                    bsa_align_batch returns BSA_E_HIP when any pair carries it.  bsa_align_run (device pointers) is
+                                    asynchronous and returns BSA_OK: its caller finds the flag in the status array it passed. */
 
 /* == seqalign_result_t (bsalign.h:213-218): 10 x int32, [qb,qe) x [tb,te) half-open */
 typedef struct {

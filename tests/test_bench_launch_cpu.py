@@ -29,3 +29,21 @@ def test_gpus_2_started_plainly_spawns_two_ranks():
 def test_world_size_that_differs_from_gpus_is_refused():
     r = _run(["--gpus", "4", "--launch-check"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "--gpus 4" in r.stderr
+
+
+import pytest
+
+
+@pytest.mark.parametrize("scenario", ["large"] + (["huge"] if os.environ.get("BSA_TEST_HUGE") else []))
+def test_c_level_exchange_at_c2_pair_count_with_offsets_beyond_4_gib(tmp_path, scenario):
+    """the C-level exchange (bsa_shard_scatter / bsa_shard_gather behind the RCCL-shaped wire interface, here over shared
+    memory between two processes) on 100 000 pairs whose offsets in the root's blob pass 4 GiB: ranges balanced by cells, every rank's shard
+    found at the offsets the scatter reports (marked pairs where they belong, nothing else in the shard), records and CIGAR words of all
+    pairs back in order.  BSA_TEST_HUGE=1 adds the same with 21-23 kbp sequences: 4.4 GB through the wire, every rank's OWN shard beyond
+    ... 2 GiB and the root's dense blob beyond 4 GiB (two minutes; run once in round 6, green)"""
+    import test_shard_cpu as T
+    got = T._run_c_exchange(2, scenario, tmp_path)
+    assert all(kind == "ok" and val[0] for _, kind, val in got), got
+    ranges = sorted((val[1], val[2]) for _, _, val in got)
+    assert ranges[0][0] == 0 and ranges[0][1] + ranges[1][1] == 100000 and ranges[1][0] == ranges[0][1]
+    assert abs(ranges[0][1] - 50000) < 1500                  # (balanced by cells: lengths are uniform, so close to the middle)

@@ -53,3 +53,35 @@ def test_misuse_is_refused():
         assert len(pog.aux_edges()) == 0
     finally:
         pog.close()
+
+
+def test_import_refuses_broken_snapshots():
+    """bsa_pog_import is a public entry point fed from fixtures and bindings: offsets that decrease or pass the edge count, an edge
+    named twice in an in-list, a header that is not one, a ring that does not close -- BSA_E_ARG, never a write past the arrays or an endless loop"""
+    from bsalign_amd import poa as PG
+    import bsalign_amd as B
+    import copy
+    case = F.load()[0]
+    good = case["snaps"][2]
+    pog = PG.Pog(**case["par"])
+    try:
+        pog.import_graph(good)                                   # the untouched snapshot is taken
+
+        def broken(edit):
+            sn = {k: (v.copy() if hasattr(v, "copy") else copy.copy(v)) for k, v in good.items()}
+            edit(sn)
+            with pytest.raises(B.BsaError):
+                pog.import_graph(sn)
+
+        n = len(good["nodes"])
+        broken(lambda sn: sn["out_off"].__setitem__(n // 2, sn["out_off"][n] + 5))          # an out-list reaching past the edges
+        broken(lambda sn: sn["in_off"].__setitem__(n // 2, sn["in_off"][n // 2 + 1] + 1))  # decreasing offsets
+        broken(lambda sn: sn["out_off"].__setitem__(0, 1))
+        k = next(i for i in range(n) if good["in_off"][i + 1] - good["in_off"][i] >= 1 and good["in_off"][i + 1] < good["in_off"][n])
+        broken(lambda sn: sn["in_from"].__setitem__(int(sn["in_off"][k + 1]), sn["in_from"][int(sn["in_off"][k])]) or sn["in_off"].__setitem__(k + 1, sn["in_off"][k + 1] + 1))
+        m = next(i for i in range(n) if good["nodes"]["header"][i] != i)
+        broken(lambda sn: sn["nodes"]["header"].__setitem__(int(good["nodes"]["header"][m]), m))        # the header's header is a member
+        broken(lambda sn: sn["nodes"]["next"].__setitem__(m, m))                                        # a ring that never returns to its header
+        pog.import_graph(good)
+    finally:
+        pog.close()

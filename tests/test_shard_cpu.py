@@ -202,6 +202,32 @@ def _c_batch(n=257, seed=5):
     return seqs, off, qlen, off + qlen, tlen
 
 
+def _c_batch_large(with_seqs, huge, n=100000, seed=6):
+    """C2's pair count with offsets beyond 4 GiB (the 64-bit arithmetic of the exchange): the blob is untouched zero pages but for a marker
+    in every 499th pair -- its index in its query's first four bytes, one byte at each sequence's end.  huge: lengths of 21-23 kbp, the
+    blob itself (and every rank's shard) passes 4 GiB, two minutes of copying through the shared-memory wire; else lengths a tenth of
+    that and a 5 GiB hole in the root's blob before the second half of the pairs (64-bit offsets on the root's side only)"""
+    rng = np.random.default_rng(seed)
+    lo, hi = (21000, 23000) if huge else (2100, 2300)
+    qlen = rng.integers(lo, hi, size=n).astype(np.uint32)
+    tlen = rng.integers(lo, hi, size=n).astype(np.uint32)
+    tot = qlen.astype(np.uint64) + tlen
+    off = np.concatenate([[0], np.cumsum(tot)[:-1]]).astype(np.uint64)
+    if not huge:
+        off[n // 2:] += np.uint64(5 << 30)
+        tot = tot.copy(); tot[-1] += np.uint64(5 << 30)          # (the blob's size below: the last pair's end)
+    assert int(off[-1]) > (1 << 32)
+    seqs = None
+    if with_seqs:
+        seqs = np.zeros(int(off[-1]) + int(qlen[-1]) + int(tlen[-1]), np.uint8)
+        for g in range(0, n, 499):
+            o = int(off[g])
+            seqs[o:o + 4] = np.frombuffer(np.uint32(g).tobytes(), np.uint8)
+            seqs[o + int(qlen[g]) - 1] = 1 + g % 3
+            seqs[o + int(qlen[g]) + int(tlen[g]) - 1] = 1 + g % 2
+    return seqs, off, qlen, off + qlen, tlen
+
+
 def _fake_results(first, count, qlen, tlen):
     """what a rank would hand to the gather: a result record and a few CIGAR words per pair, functions of the pair's global index"""
     out = np.zeros((count, 10), np.int32)
@@ -235,9 +261,10 @@ def _worker_c_exchange(rank, world, idfile, q, scenario):
             ident = (C.c_uint8 * 128).from_buffer_copy(open(idfile, "rb").read())
         comm = C.c_void_p()
         assert L.bsa_shard_comm_create(None, rank, world, ident, C.byref(comm)) == 0
-        seqs, qoff, qlen, toff, tlen = _c_batch()
-        n = len(qlen)
         root = 1 if scenario == "root1" else 0
+        large = scenario in ("large", "huge")
+        seqs, qoff, qlen, toff, tlen = _c_batch_large(rank == root, scenario == "huge") if large else _c_batch()
+        n = len(qlen)
         first, count, nbytes, blob = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_void_p()
         cap = 3 if (scenario == "small_cap" and rank == 1) else n
         lq, lt, lqo, lto = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
@@ -255,7 +282,18 @@ def _worker_c_exchange(rank, world, idfile, q, scenario):
         raw = (C.c_uint8 * nbytes.value).from_address(blob.value)
         got = np.frombuffer(raw, np.uint8)
         ok = bool(np.array_equal(lq[:cn], qlen[f0:f0 + cn]) and np.array_equal(lt[:cn], tlen[f0:f0 + cn]))
-        for i in range(cn):
+        if large:
+            # the marked pairs at the offsets the scatter reported, the blob's size, nothing but zeros in between (a sum over the whole shard)
+            marks = 0
+            for g in range(((f0 + 498) // 499) * 499, f0 + cn, 499):
+                i = g - f0
+                qo, to = int(lqo[i]), int(lto[i])
+                ok &= bool(int(np.frombuffer(got[qo:qo + 4].tobytes(), np.uint32)[0]) == g and got[qo + int(qlen[g]) - 1] == 1 + g % 3 and got[to + int(tlen[g]) - 1] == 1 + g % 2)
+                marks += sum(int(b) for b in np.frombuffer(np.uint32(g).tobytes(), np.uint8)) + (1 + g % 3 if int(qlen[g]) > 4 else 0) + 1 + g % 2
+            ok &= bool(int(got.sum(dtype=np.uint64)) == marks)
+            ok &= bool(nbytes.value >= int((qlen[f0:f0 + cn].astype(np.uint64) + tlen[f0:f0 + cn]).sum()))
+            ok &= bool(int(lqo[cn - 1]) + int(qlen[f0 + cn - 1]) <= nbytes.value and int(lto[cn - 1]) + int(tlen[f0 + cn - 1]) <= nbytes.value)
+        for i in range(0 if not large else cn, cn):
             g = f0 + i
             ok &= bool(np.array_equal(got[int(lqo[i]):int(lqo[i]) + int(qlen[g])], seqs[int(qoff[g]):int(qoff[g]) + int(qlen[g])]))
             ok &= bool(np.array_equal(got[int(lto[i]):int(lto[i]) + int(tlen[g])], seqs[int(toff[g]):int(toff[g]) + int(tlen[g])]))
