@@ -462,7 +462,7 @@ extern "C" int bsa_poa_batcher_submit_graph(void *vb, const bsa_poa_node_t *node
 		bsa_poa_result_t *res, bsa_poa_event_t *events, size_t events_cap){
 	bsa_sweep_batcher *bb = (bsa_sweep_batcher*)vb;
 	if(!bb || !nodes || !nnodes || !query || !par || !res || !events) return BSA_E_ARG;
-	if(bsa_poa_graph_supported(par, slen) == 0) return BSA_E_UNSUPPORTED;
+	if(bsa_poa_graph_supported(par, slen) == 0 && (!bsa_poa_graph_gen_supported(par) || bsa_env("BSA_POA_NO_GEN"))) return BSA_E_UNSUPPORTED;        // (bands above 256 columns: the generic-width kernel behind the same call, bsa_poa_gen.hip)
 	int rc = BSA_E_HIP, ob = -1;
 	const uint32_t *src = nullptr;
 	bool done = false; std::condition_variable cv;

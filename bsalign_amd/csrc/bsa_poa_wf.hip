@@ -1270,6 +1270,11 @@ extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *ctx, hipStream_t *st);
 extern "C" int bsa_ctx_time_begin_internal(bsa_ctx_t *ctx, double cells, void **stop_event);
 extern "C" int bsa_ctx_time_end_internal(bsa_ctx_t *ctx, void *stop_event);
 extern "C" int bsa_ctx_scratch_internal(bsa_ctx_t *ctx, int slot, size_t bytes, void **out);
+// bands wider than 256 columns (bsa_poa_gen.hip)
+extern "C" int bsa_poa_graph_gen_supported(const bsa_sweep_params_t *par);
+int bsa_poa_graph_gen_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, size_t nnodes, const bsa_poa_edge_t *d_edges, const bsa_poa_cand_t *d_cands,
+		const bsa_poa_prog_t *d_progs, size_t nprogs, const uint8_t *d_queries, const bsa_sweep_params_t *par,
+		bsa_poa_result_t *d_results, uint32_t *d_steps, uint32_t *d_packed, uint64_t *d_packed_used);
 
 static const size_t POA_LDS_MAX = 160u * 1024u - 1024u;
 static size_t poa_tile_bytes(uint32_t bw){ (void)bw; return (size_t)POA_TILE_BYTES; }
@@ -1327,8 +1332,14 @@ extern "C" int bsa_poa_graph_run(bsa_ctx_t *ctx, const bsa_poa_node_t *d_nodes, 
 	if(!ctx || !par || (nprogs && (!d_nodes || !d_progs || !d_queries || !d_results || !d_steps || !d_packed || !d_packed_used))) return BSA_E_ARG;
 	if(nprogs == 0) return BSA_OK;
 	if(nprogs > 0x0FFFFFF0ull || (d_rows == nullptr) != (d_u0 == nullptr)) return BSA_E_ARG;
-	const int nl = bsa_poa_graph_supported(par, max_slen);
-	if(nl == 0) return BSA_E_UNSUPPORTED;
+	const int nl = bsa_env("BSA_POA_FORCE_GEN") ? 0 : bsa_poa_graph_supported(par, max_slen);          // (test knob: every program through the generic-width kernel)
+	if(nl == 0){
+		// bands wider than this kernel takes (a window's first read: the whole read) with scores inside the guard: the generic-width kernel
+		// (bsa_poa_gen.hip), same program, results and step words; it keeps its rows to itself
+		if(d_rows == nullptr && bsa_poa_graph_gen_supported(par) && !bsa_env("BSA_POA_NO_GEN"))
+			return bsa_poa_graph_gen_run(ctx, d_nodes, nnodes, d_edges, d_cands, d_progs, nprogs, d_queries, par, d_results, d_steps, d_packed, d_packed_used);
+		return BSA_E_UNSUPPORTED;
+	}
 	hipStream_t st;
 	int rc = bsa_ctx_get_stream_internal(ctx, &st);
 	if(rc != BSA_OK) return rc;
@@ -1434,7 +1445,7 @@ extern "C" int bsa_poa_graph_host(bsa_ctx_t *ctx, const bsa_poa_node_t *nodes, s
 		}
 		for(size_t i = 0; i < pg.ncands; i++) if(cands[pg.first_cand + i].node >= pg.nnodes) return BSA_E_ARG;
 	}
-	if(bsa_poa_graph_supported(par, max_slen) == 0) return BSA_E_UNSUPPORTED;
+	if((bsa_env("BSA_POA_FORCE_GEN") || bsa_poa_graph_supported(par, max_slen) == 0) && (rows_out || u0_out || !bsa_poa_graph_gen_supported(par) || bsa_env("BSA_POA_NO_GEN"))) return BSA_E_UNSUPPORTED;
 	hipStream_t st;
 	int rc = bsa_ctx_get_stream_internal(ctx, &st);
 	if(rc != BSA_OK) return rc;

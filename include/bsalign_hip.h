@@ -323,6 +323,11 @@ typedef struct { int32_t h; int8_t e, q; uint16_t tag; } bsa_poa_cell_t;      /*
 /* lanes a read of `max_slen` bases can use at this parameter set (a power of two up to 64), 0 = not supported: bandwidth above 256,
  * scores outside the exactness guard, or a read too long for the LDS.  Callers fall back to bsa_sweep_* then. */
 int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t max_slen);
+/* 1 when bsa_poa_graph_run / _host take this parameter set at ANY bandwidth (up to 32768 columns): scores inside the same exactness guard, the
+ * generic-width kernel of bsa_poa_gen.hip behind the same entry points (a workgroup per read, rows of 8 bytes a cell in the context's scratch,
+ * as many programs side by side as $BSA_POA_GEN_WS_GB -- default 48 -- holds; rows_out is not available there).  A window's first aligned read
+ * has the whole read as its band (bspoa.h:2045-2054, 2109-2111) and goes this way. */
+int bsa_poa_graph_gen_supported(const bsa_sweep_params_t *par);
 /* all pointers DEVICE memory, asynchronous on the context stream.  The steps of a walk leave the device as one word each,
  * node << 3 | bt (x is implied: it starts at maxoff and moves left with every M and I step): d_steps is scratch, program k walks
  * into d_steps[first_event .. + event_cap); when it is done its steps are appended to d_packed (capacity: the sum of all

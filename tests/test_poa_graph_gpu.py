@@ -197,3 +197,81 @@ def test_c4_full_size_clean_wall_time(ctx, capsys):
         print("\n[C4 full size, clean] end_bspoa 64 x 20 kbp: reference %.2f s (of which align_rd_bspoacore %.2f s for %d row updates + %d merges); with sweep and walk "
               "on the device %.2f s (%d reads through the graph form: building programs %.2f s, device calls incl. transfers %.2f s, applying walks %.2f s)"
               % (t_ref, one["core_seconds"], one["core_updates"], one["core_merges"], t_dev, mine["graph_reads"], b[0], b[1], b[2]))
+
+
+# ---- bands above 256 columns: the generic-width kernel (bsa_poa_gen.hip) behind the same entry point ----
+def _check_program_gen(ctx, p, pg):
+    """the generic-width kernel keeps its rows to itself: best end cell against the reference's, every step of the walk against the scalar
+    statement on the scalar statement's rows (which are pinned to the reference's row hash)"""
+    bw, pw = pg["bandwidth"], pg["piecewise"]
+    nodes, edges, cands, blocks = P.tasks_to_graph(pg["tasks"])
+    pr, cap = _prog(nodes, edges, cands, pg["slen"])
+    res, ev, _, _ = ctx.poa_graph_host(nodes, edges, cands, pr, pg["query"], _sweep_params(p, bw), cap)
+    orows, ou0 = P.oracle_wf_forward(nodes, pg["query"], p, bw)
+    assert P.hash_node_blocks(P.wf_rows_to_blocks(orows, ou0, blocks, pg["nblocks"], bw, pw), pg["nblocks"], bw, pw, pg["tasks"]) == pg["rows_hash"]
+    r = res[0]
+    gidx = int(nodes[int(r["maxidx"])]["gnode"]) if r["maxidx"] >= 0 else -1
+    assert (int(r["maxscr"]), gidx, int(r["maxoff"])) == (pg["maxscr"], pg["maxidx"], pg["maxoff"])
+    n, oev, fin = P.oracle_wf_trace(nodes, edges, pg["query"], p, bw, orows, ou0, 0, int(r["maxidx"]), int(r["maxoff"]))
+    assert (r["status"] == 0) == (n >= 0), (int(r["status"]), n)
+    if n >= 0:
+        assert int(r["nevents"]) == n and np.array_equal(ev[:n], oev)
+        assert (int(r["fin_node"]), int(r["fin_x"])) == (int(fin[0]), int(fin[1]))
+    return n
+
+
+def test_generic_width_kernel_on_every_golden_program(ctx, monkeypatch):
+    """BSA_POA_FORCE_GEN=1: every recorded program of tests/golden/poa_sweep.npz through the generic-width kernel, the narrow ones as well
+    (merges of several in-edges, moved rows with their synthetic cells, dead rows, all three gap models and modes of the recording; one cell
+    a thread there) and the ones above 256 columns k_poa_wf declines"""
+    import bsalign_amd as B
+    monkeypatch.setenv("BSA_POA_FORCE_GEN", "1")
+    n = wide = 0
+    for case in P.load_golden():
+        for pg in case["programs"]:
+            if pg["bandwidth"] > 256:
+                assert B.lib().bsa_poa_graph_supported(_sweep_params(case["par"], pg["bandwidth"]), int(pg["slen"])) == 0
+                wide += 1
+            _check_program_gen(ctx, case["par"], pg)
+            n += 1
+    assert n >= 40 and wide >= 3
+
+
+def _chain_program(rng, L, eps, mode):
+    """what a window's first aligned read meets: the chain of the read before it (one in-edge a node, every band offset 0), the whole read as band"""
+    T = rng.integers(0, 4, size=L).astype(np.uint8)
+    Q = S.mutate(rng, T, eps)
+    if len(Q) == 0:
+        Q = T.copy()
+    nodes = np.zeros(L + 1, P.WF_NODE); edges = np.zeros(L, P.WF_EDGE)
+    nodes[0]["base"] = 4; nodes[0]["gnode"] = 0
+    for i in range(1, L + 1):
+        same = P.IN_SAME if (i >= 2 and T[i - 1] == T[i - 2]) else 0
+        nodes[i] = (0, i, i - 1, 1, T[i - 1], int(rng.integers(2)), i - 1, 0, P.IN_PRESENT | same | i, 0, 0, 0, 0, 0)
+        edges[i - 1] = (i - 1, 1 + int(rng.integers(3)), 0, 0)
+    cands = np.zeros(L + 1 if mode != 0 else 1, P.WF_CAND)
+    if mode != 0:
+        cands["node"][:L] = np.arange(1, L + 1); cands["kind"][:L] = 1
+    cands[-1] = (L, 0)
+    return nodes, edges, cands, Q
+
+
+@pytest.mark.parametrize("L,eps,mode", [(300, 0.1, 1), (1000, 0.15, 1), (1100, 0.05, 0), (3000, 0.1, 2), (5000, 0.2, 1), (20000, 0.1, 1)])
+def test_generic_width_kernel_on_the_chain_a_first_read_meets(ctx, L, eps, mode):
+    """VERDICT r05 'missing' 3: a window's first aligned read has the whole read as its band (bspoa.h:2045-2054, 2109-2111) and k_poa_wf stops at
+    256 columns.  A read against the chain of the read before it (C4: 20 000 columns, 20 cells a thread): best end cell, every step of the walk
+    and where it ends against the scalar statement (oracle/bsalign_oracle_wf.c) -- one to twenty cells a thread, all three modes, the POA's
+    default two-piece scoring"""
+    rng = np.random.default_rng(L + mode)
+    p = dict(P.par()); p["alnmode"] = mode
+    nodes, edges, cands, Q = _chain_program(rng, L, eps, mode)
+    bw = (len(Q) + 15) // 16 * 16
+    pr, cap = _prog(nodes, edges, cands, len(Q))
+    res, ev, _, _ = ctx.poa_graph_host(nodes, edges, cands, pr, Q, _sweep_params(p, bw), cap)
+    orows, ou0 = P.oracle_wf_forward(nodes, Q, p, bw)
+    ob = P.oracle_wf_best(nodes, cands, len(Q), p, bw, orows)
+    r = res[0]
+    assert (int(r["maxscr"]), int(r["maxidx"]), int(r["maxoff"])) == (int(ob["maxscr"]), int(ob["maxidx"]), int(ob["maxoff"]))
+    n, oev, fin = P.oracle_wf_trace(nodes, edges, Q, p, bw, orows, ou0, 0, int(r["maxidx"]), int(r["maxoff"]))
+    assert n > L // 2 and r["status"] == 0 and int(r["nevents"]) == n and np.array_equal(ev[:n], oev)
+    assert (int(r["fin_node"]), int(r["fin_x"])) == (int(fin[0]), int(fin[1]))

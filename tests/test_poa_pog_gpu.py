@@ -38,7 +38,9 @@ def test_every_step_in_the_shadow_of_the_reference_with_the_device_between(ctx, 
     assert r["bad"] == 0, [(i, rc["mismatch"]) for i, rc in enumerate(r["recs"]) if rc["mismatch"]]
     g = r["pog"]
     aligned = min(len(reads) + 1, p["seqcore"]) - 1
-    assert g["declined"] <= 1 and g["imports"] <= g["declined"] and g["reads"] == aligned - g["declined"]
+    # round 6: no read is declined -- a window's first aligned read (the whole read as band) runs the generic-width kernel (bsa_poa_gen.hip) --, so the
+    # library's graph is built once and never re-imported from the reference
+    assert g["declined"] == 0 and g["imports"] == 0 and g["reads"] == aligned
     assert g["steps"] > aligned * 1000 and g["graph_edges"] > 0 and g["program_bytes"] > 0
 
 
@@ -92,6 +94,7 @@ def test_c4_full_size_on_the_librarys_graph(ctx, capsys):
     t0 = time.time(); old = P.run_ref_graph(reads, 6, p, record=False, lib=lib, backend="device"); t_old = time.time() - t0
     assert np.array_equal(mine["cns"], ref["cns"]) and np.array_equal(mine["qlt"], ref["qlt"]) and np.array_equal(mine["alt"], ref["alt"]) and mine["msa"] == ref["msa"]
     g = mine["pog"]
+    assert g["declined"] == 0 and g["imports"] == 0 and g["reads"] == min(len(reads) + 1, p["seqcore"]) - 1      # every read of the default end_bspoa on the library's graph
     bs, ls = g["binding_seconds"], g["library_seconds"]
     with capsys.disabled():
         print("\n[C4 full size, clean] end_bspoa 64 x 20 kbp: reference %.2f s; on the library's own graph %.2f s (%d reads, %d declined; binding: mirror %.2f s, guide alignment + "
