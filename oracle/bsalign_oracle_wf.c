@@ -336,7 +336,7 @@ int orc_wf_backend(void *user, const orc_wf_node_t *nodes, size_t nnodes, const 
 	orc_sweep_result_t best;
 	long n;
 	(void)user; (void)nedges;
-	if(bw > 256) return -6;                 /* BSA_E_UNSUPPORTED: the device declines these as well (bsa_poa_graph_supported) */
+	/* (round 6: any width -- the device takes bands above 256 columns through its generic-width kernel, bsa_poa_gen.hip) */
 	rows = (orc_wf_cell_t*)malloc((size_t)nnodes * bw * sizeof(orc_wf_cell_t));
 	u0 = (int32_t*)malloc((size_t)nnodes * sizeof(int32_t));
 	orc_wf_forward(nodes, (uint32_t)nnodes, query, slen, par, rows, u0);
