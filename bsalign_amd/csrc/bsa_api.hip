@@ -1160,7 +1160,7 @@ extern "C" int bsa_ctx_get_stream_internal(bsa_ctx_t *c, hipStream_t *st){
 // ------------------------------------------------------------------------------------------------
 struct bsa_edit_plan : PlanBase {
 	bsa_edit_params_t par;
-	uint32_t pad_rows = 4;
+	uint32_t pad_rows = 12;         // (row format 1 rounds a slot's rows up to a tile of eight: at least four spare rows stay behind them)
 	uint64_t *d_qboff = nullptr, *d_qbits = nullptr;
 	uint32_t *d_qwords = nullptr;
 	int32_t *d_sbeg = nullptr;
@@ -1279,6 +1279,7 @@ extern "C" int bsa_edit_run(bsa_edit_plan_t *p, const uint8_t *d_seqs, bsa_resul
 			const Sub &sb = p->subs[x];
 			EditArgs b = a; b.first = sb.first; b.count = sb.count; b.rows = half;
 			b.bw = sb.bw <= BSA_EDIT_REG_BW ? sb.bw : 0u; b.wide = sb.bw <= BSA_EDIT_REG_BW ? 0u : (sb.bw & 0xFFu);
+			b.row_fmt = (ch.nsub == 1u && sb.count == ch.count && ch.bw == sb.bw && bsa_edit_tiled_ok(b.bw, ch.count, b.mode)) ? 1u : 0u;
 			HIPCHK(c, bsa_launch_edit_fwd(b, s));
 		}
 		return BSA_OK;
@@ -1286,6 +1287,7 @@ extern "C" int bsa_edit_run(bsa_edit_plan_t *p, const uint8_t *d_seqs, bsa_resul
 	auto trace = [&](const Chunk &ch, uint8_t *half, hipStream_t s) -> int {
 		EditArgs b = a; b.first = ch.first; b.count = ch.count; b.rows = half;
 		b.bw = ch.bw <= BSA_EDIT_REG_BW ? ch.bw : 0u;               // several classes or wide bands: every pair works out its own
+		b.row_fmt = (ch.nsub == 1u && p->subs[ch.sub0].count == ch.count && p->subs[ch.sub0].bw == ch.bw && bsa_edit_tiled_ok(b.bw, ch.count, b.mode)) ? 1u : 0u;      // (the same test as the forward launch of this chunk)
 		HIPCHK(c, bsa_launch_edit_trace(b, d_out, cnt, s));
 		return BSA_OK;
 	};

@@ -159,7 +159,17 @@ struct EditArgs {
 	uint32_t wide;                  // bw == 0 only: words per lane of the wave-per-pair kernel for static bands (1, 2, 4, 8), 0 = none
 	uint32_t pad_rows;              // spare row records at the end of every slot (CIGAR scratch)
 	int32_t  mode;
+	uint32_t row_fmt;               // 0: row r = [plane0: NW u64][plane1: NW u64]; 1: TILED (k_edit_fwd_grp32 + k_edit_trace_wave, bsa_edit_row_dword)
 };
+
+// Row format 1 of the edit path (round 6): the walk of a banded alignment needs, of every row, the 32 columns around its diagonal -- one or two of a
+// row's 32-bit words per plane -- but a 64-byte row is one memory request whatever part of it is wanted (profiles/r06_fetch_size_calibration.txt),
+// and the walker, reading every row whole, was at the HBM ceiling.  So rows are TILED eight at a time: tile t = rows 8 t .. 8 t + 7, inside it the
+// 64-byte block of 32-bit column word h holds that word of both planes of the eight rows -- dword (r & 7) * 2 + plane -- and a lane of the forward
+// kernel (which owns word h of its pair) fills one block over eight consecutive rows.  The walker fetches three blocks per tile instead of eight.
+static inline __host__ __device__ size_t bsa_edit_row_dword(uint32_t NH, uint32_t r, uint32_t plane, uint32_t h){      // dword index of (row, plane, 32-bit word) in a tiled slot; NH = words per plane
+	return (size_t)(r >> 3) * (16u * NH) + (size_t)h * 16u + (r & 7u) * 2u + plane;
+}
 
 #ifdef __HIPCC__
 // Buffered tile writer used by the forward kernels: RW dwords per block record, TG rows per tile.
@@ -234,6 +244,7 @@ hipError_t bsa_launch_align8_fwd_sys(const Align8Args &a, int pw, uint32_t max_q
 hipError_t bsa_launch_align8_trace_sys(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, const uint64_t *slot_end, hipStream_t st);
 hipError_t bsa_launch_align8_trace_codes(const Align8Args &a, int pw, bsa_result_t *out, uint32_t *cig_cnt, hipStream_t st);
 bool bsa_edit_supported_bw(uint32_t bw);
+bool bsa_edit_tiled_ok(uint32_t bw, uint32_t count, int mode);       // row format 1 for a launch class that fills its chunk alone (bsa_edit.hip)
 hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen,
 		const uint64_t *qpoff, const uint64_t *tpoff, const uint64_t *qboff, const uint32_t *qwords,
 		uint8_t *qst, uint8_t *tst, uint64_t *qbits, uint32_t *status, uint32_t n, hipStream_t st);

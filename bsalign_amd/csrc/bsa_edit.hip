@@ -512,7 +512,10 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp(const EditArgs a){
 // the block step is one instruction per operation, the band shift is one v_alignbit_b32 per plane, and the same batch is
 // twice the waves (C3: two per SIMD), which interleave.  Row records are identical (natural bit order: the 32-bit word h of
 // a plane is the low / high half of the 64-bit word h / 2).
-template<int G>
+// TILED: rows in format 1 (bsa_common.h).  A lane's word of both planes of eight consecutive rows is ONE 64-byte block: the row loop runs a tile at a
+// time, the eight rows wait in registers and leave as four 16-byte stores -- written piecemeal (eight bytes a row) the blocks were merged by the L2 only
+// while few waves were in flight (32768 pairs: 156 ms instead of 90), staged through LDS the kernel paid 12 % more instructions.
+template<int G, bool TILED>
 __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 	constexpr uint32_t PPW = 64u / G;
 	constexpr u64 GS = G == 2 ? 0x5555555555555555ull : G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;   // first lane of every group
@@ -533,7 +536,9 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 	const bool word = gl < NH, top = gl + 1u == NH;
 	const uint32_t tl = live ? tlen : 0u;
 	uint32_t pv = ~0u, mv = 0u;
-	if(live && word){ rows[gl] = 0u; rows[NH + gl] = ~0u; }              // row_init (:653-656)
+	if(live && word){                                                     // row_init (:653-656)
+		if constexpr(!TILED){ rows[gl] = 0u; rows[NH + gl] = ~0u; }          // (TILED: the initial row leaves with tile 0)
+	}
 	uint32_t q0 = word ? Q0m[gl] : 0u, q1 = word ? Q1m[gl] : 0u;           // query planes at band offset 0
 	// the top lane keeps the query bits behind the band end: position lpos sits in (l?c, l?n) at bit lpos & 31
 	uint32_t lpos = BW;
@@ -547,8 +552,9 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 	int slast = (int)qlen, smin = 0x7FFFFFFF, ry = (int)tlen - 1;
 	const u64 hin0_mask = overlap ? 0ull : GS;
 	u64 tw = 0;
-	uint32_t *rp = rows + 2u * NH + gl;                                     // this lane's word of the row being written
-	for(uint32_t i = 0; __any(i < tl); i++){
+	uint32_t *rp = rows + 2u * NH + gl;                                     // this lane's word of the row being written (format 0)
+	// one row of the DP (everything but the row record's store); returns whether this lane's word took part
+	auto row_step = [&](const uint32_t i) -> bool {
 		const bool on = i < tl;
 		if((i & 7u) == 0u){                                       // (uniform) the next eight target bases; waited for here, once per eight rows,
 			if(on) tw = *(const u64*)(tp + i);                    // so that no row waits for the previous row's stores (vmcnt counts both)
@@ -616,13 +622,38 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 		if(act){
 			pv = Mh | ~(Xv | Ph);
 			mv = Ph & Xv;
-			rp[0] = mv; rp[NH] = pv;
 			if(type != BSA_MODE_GLOBAL && slast < smin){ smin = slast; ry = (int)i; }
 		}
 		rb0 = on ? rb1 : rb0;
 		quo += qstep;
 		if(rem >= tlen - rstep){ rem -= tlen - rstep; quo++; } else rem += rstep;     // no 33-bit sum
-		rp += 2u * NH;
+			return act;
+	};
+	if constexpr(!TILED){
+		for(uint32_t i = 0; __any(i < tl); i++){
+			if(row_step(i)){ rp[0] = mv; rp[NH] = pv; }
+			rp += 2u * NH;
+		}
+	} else {
+		// a tile at a time: rows 8 t .. 8 t + 7 (row 0 is the initial row, row r the one of target base r - 1), this lane's word of both planes of the
+		// eight rows in sixteen registers, then ONE 64-byte block as four 16-byte stores (a lane whose pair ends inside the tile stores what it has;
+		// the slots past its last row hold that row again -- nobody reads them)
+		uint32_t bm[8], bp_[8];
+		bm[0] = 0u; bp_[0] = ~0u;
+		for(uint32_t t8 = 0; __any((t8 ? t8 - 1u : 0u) < tl || t8 == 0u); t8 += 8u){
+#pragma unroll
+			for(uint32_t j = 0; j < 8u; j++){
+				if(j == 0u && t8 == 0u) continue;                                // (the initial row)
+				row_step(t8 + j - 1u);
+				bm[j] = mv; bp_[j] = pv;
+			}
+			if(live && word && t8 <= tl){
+				uint4 *dst = (uint4*)(rows + (size_t)(t8 >> 3) * (16u * NH) + (size_t)gl * 16u);
+#pragma unroll
+				for(int k = 0; k < 4; k++) dst[k] = make_uint4(bm[2 * k], bp_[2 * k], bm[2 * k + 1], bp_[2 * k + 1]);
+			}
+			if(!__any(t8 + 7u < tl)) break;
+		}
 	}
 	if(live && gl == 0u) a.fwd_sbeg[ppos] = sbeg;
 	if(live && gl == (type != BSA_MODE_GLOBAL ? lastw : 0u)){ a.fwd_smin[ppos] = smin; a.fwd_ry[ppos] = ry; }
@@ -893,8 +924,14 @@ __global__ void __launch_bounds__(64) k_edit_trace(const EditArgs a, bsa_result_
 // lane's row is fixed for the tile; the query bases sit in a 512-byte LDS window refilled every few tiles.  A lookup
 // outside the band (the reference's unsigned position arithmetic, plane_bit above) or outside the window takes the
 // literal per-lane path with plain loads.
+// TILED (row format 1, bsa_common.h; bands of 64 / 128 / 256 columns): the rows sit eight to a tile, a 64-byte block per 32-bit column word, and a lane
+// fetches THREE dwords per plane of its row -- the 96 columns around where the walker's diagonal is expected to cross it (the estimate is made a tile
+// ahead; the drift of a tile's indels is a few columns, and what falls outside is looked up literally) -- so a tile of 64 rows costs 24 blocks of 64
+// bytes instead of 64 rows of 64 (of 32 * NW) bytes.
 #define EW_WW 4
 #define EW_QWIN 512
+#define EW_TD 3               // TILED: dwords per plane and row in the window
+template<bool TILED>
 __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_result_t *out, uint32_t *cig_cnt){
 	__shared__ uint32_t tile[64][4 * EW_WW + 1];     // rows padded to 17 dwords: lanes 64 bytes apart would meet in 4 of the 64 banks
 	__shared__ uint32_t s_beg[64], s_ws[64];
@@ -909,12 +946,19 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	const uint8_t *qs = a.qst + a.qpoff[pair];
 	const uint8_t *ts = a.tst + a.tpoff[pair];
 	const u64 *rows = (const u64*)(a.rows + a.slot_off[ppos]);
+	const uint32_t *rowsd = (const uint32_t*)rows;
+	const uint32_t NH = 2u * NW;
 	const int type = a.mode & 3;
 	const uint32_t qround = (qlen + 63u) / 64u * 64u;
 	auto plane_bit = [&](uint32_t row, int plane, long pos) -> int {         // as in k_edit_trace
 		const uint32_t pu = (uint32_t)pos;
 		const uint32_t p = ((pu / NW) & 63u) * NW + (pu % NW);
-		return (int)((rows[(size_t)row * (2 * NW) + (size_t)plane * NW + (p >> 6)] >> (p & 63u)) & 1ull);
+		if constexpr(TILED) return (int)((rowsd[bsa_edit_row_dword(NH, row, (uint32_t)plane, p >> 5)] >> (p & 31u)) & 1u);
+		else return (int)((rows[(size_t)row * (2 * NW) + (size_t)plane * NW + (p >> 6)] >> (p & 63u)) & 1ull);
+	};
+	auto row_word = [&](uint32_t row, uint32_t plane, uint32_t w) -> u64 {    // 64-bit word w of a plane of a row
+		if constexpr(TILED) return (u64)rowsd[bsa_edit_row_dword(NH, row, plane, 2u * w)] | ((u64)rowsd[bsa_edit_row_dword(NH, row, plane, 2u * w + 1u)] << 32);
+		else return rows[(size_t)row * (2 * NW) + (size_t)plane * NW + w];
 	};
 	auto beg_of_row = [&](uint32_t r) -> uint32_t {
 		if(r == 0 || type != BSA_MODE_GLOBAL) return 0u;
@@ -926,21 +970,19 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	int rx = (int)qlen - 1, ry = (int)tlen - 1, smin = 0x7FFFFFFF, score = 0;
 	if(type == BSA_MODE_GLOBAL){
 		const uint32_t rbl = beg_of_row(tlen);
-		const u64 *lr = rows + (size_t)tlen * (2 * NW);
 		int part = 0;
-		for(uint32_t k = lane; k < NW; k += 64u) part += __popcll(lr[NW + k]) - __popcll(lr[k]);
+		for(uint32_t k = lane; k < NW; k += 64u) part += __popcll(row_word(tlen, 1u, k)) - __popcll(row_word(tlen, 0u, k));
 		for(uint32_t k = qlen + 1u + lane; k <= rbl + BW; k += 64u) part += plane_bit(tlen, 0, (long)(k - 1 - rbl)) - plane_bit(tlen, 1, (long)(k - 1 - rbl));
 		for(int o = 32; o; o >>= 1) part += __shfl_xor(part, o);
 		score = a.fwd_sbeg[ppos] + part;
 	} else {
 		smin = a.fwd_smin[ppos]; ry = a.fwd_ry[ppos];
 		if(type == BSA_MODE_EXTEND){     // striped_seqedit_rowmin (:813-963): first strict minimum of the prefix sums of the last row
-			const u64 *lr = rows + (size_t)tlen * (2 * NW);
 			// lane l owns words l, l + 64, ... : word totals first, then the scan inside the words
 			int best = (int)tlen; uint32_t pmin = 0; int base = (int)tlen;
 			for(uint32_t w0 = 0; w0 < NW; w0 += 64u){
 				const uint32_t w = w0 + lane;
-				const u64 pl0 = w < NW ? lr[w] : 0ull, pl1 = w < NW ? lr[NW + w] : 0ull;
+				const u64 pl0 = w < NW ? row_word(tlen, 0u, w) : 0ull, pl1 = w < NW ? row_word(tlen, 1u, w) : 0ull;
 				int tot = __popcll(pl1) - __popcll(pl0), pre = tot;         // inclusive prefix over the lanes
 				for(int o = 1; o < 64; o <<= 1){ const int v = __shfl_up(pre, o); if((int)lane >= o) pre += v; }
 				int sc = base + pre - tot, lb = 0x7FFFFFFF; uint32_t lp = 0;
@@ -1004,6 +1046,9 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		tok_flush(ntok); ntok = 0u;
 	};
 	int x = rx, y = ry;
+#ifdef EDIT_DBG
+	uint32_t dbg_lit = 0, dbg_tiles = 0, dbg_demand = 0;
+#endif
 	uint32_t vmis = 0;                               // this lane's mismatch count (summed over the wave at the end)
 	const bool bad = (rx >= (int)qlen);
 	rs.qe = x + 1; rs.te = y + 1;
@@ -1041,6 +1086,13 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 			beg = (c + BW > qround) ? qround - BW : c;
 		}
 		uint32_t ws = 0;
+		if constexpr(TILED){
+			// the window's first dword: the 32 columns the lane will look at start 16 left of the diagonal's column in this row; one more dword to either
+			// side.  The row is a RING of NH dwords (NH a power of two): a position outside the band is looked up where the reference's unsigned
+			// arithmetic lands (plane_bit), the position modulo BW -- a walk that runs along the band's edge stays on the fast path
+			const int oe = (xs - (int)lane - 16) - (int)beg;
+			ws = (uint32_t)((oe - 16) >> 5) & (NH - 1u);
+		} else
 		if(NW > EW_WW){
 			const int pe = (xs - (int)lane) - (int)beg;
 			int w = (pe >> 6) - 1;
@@ -1049,6 +1101,18 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		}
 		t.beg = beg; t.ws = ws;
 		t.tb = r >= 1 ? (uint32_t)ts[r - 1] : 0xffu;
+		if constexpr(TILED){
+			// three unconditional loads (nothing after them depends on the data until the tile is used: the next tile's rows travel while this one is
+			// walked): dwords ws, ws + 1, ws + 2 of the row's ring.  A row above the first is clamped: it belongs to a lane that stops the walk anyway.
+			const uint32_t rr = r > 0 ? (uint32_t)r : 0u;
+			const uint32_t *bp = rowsd + bsa_edit_row_dword(NH, rr, 0u, 0u);
+			const uint32_t h1 = (ws + 1u) & (NH - 1u), h2 = (ws + 2u) & (NH - 1u);
+			const uint2 d0 = *(const uint2*)(bp + ws * 16u), d1 = *(const uint2*)(bp + h1 * 16u), d2 = *(const uint2*)(bp + h2 * 16u);
+			t.w[0][0] = (u64)d0.x | ((u64)d1.x << 32); t.w[0][1] = (u64)d2.x;
+			t.w[1][0] = (u64)d0.y | ((u64)d1.y << 32); t.w[1][1] = (u64)d2.y;
+#pragma unroll
+			for(int w = 2; w < EW_WW; w++){ t.w[0][w] = 0ull; t.w[1][w] = 0ull; }
+		} else
 		if(r >= 0){
 			const u64 *rp = rows + (size_t)(uint32_t)r * (2 * NW) + ws;
 			if(NW == EW_WW){
@@ -1084,6 +1148,9 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 	if(!bad && x >= 0) q_refill(x);
 	while(!bad && x >= 0 && y >= 0){
 		const int R_hi = y + 1;
+#ifdef EDIT_DBG
+		dbg_tiles++; if(pf_R != R_hi) dbg_demand++;
+#endif
 		if(pf_R != R_hi) tile_fetch(R_hi, x, pf, false);
 		__syncthreads();
 #pragma unroll
@@ -1107,11 +1174,22 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		// row above and not IM, VM = both lookups lie inside the band and inside the LDS windows.  A cell stops the diagonal
 		// run when the bases differ and (IM | DM | ~VM); what ~VM stopped is looked up literally.
 		const int cbase = (x - (int)lane) - 16;
-		const bool pow2row = NW <= (uint32_t)EW_WW && (NW & (NW - 1u)) == 0u;
+		const bool pow2row = !TILED && NW <= (uint32_t)EW_WW && (NW & (NW - 1u)) == 0u;
 		uint32_t IM, DM, VM;
 		{
 			auto window = [&](uint32_t row, int o, uint32_t wsr, uint32_t &p0w, uint32_t &p1w) -> uint32_t {   // bits o .. o + 31 of both planes of a row; returns their validity
 				const uint32_t sft = (uint32_t)o & 31u;
+				if constexpr(TILED){
+					// EW_TD dwords per plane from dword wsr of the row's ring on (tile[row][0 ..] / tile[row][2 EW_WW ..]); bit o + c is there when its
+					// dword, counted from wsr around the ring, is one of the EW_TD
+					const uint32_t d0 = ((uint32_t)(o >> 5) - wsr) & (NH - 1u), d1 = (d0 + 1u) & (NH - 1u);
+					const bool inA = d0 < (uint32_t)EW_TD, inB = d1 < (uint32_t)EW_TD;
+					const uint32_t a0 = inA ? tile[row][d0 & 3u] : 0u, b0 = inB ? tile[row][d1 & 3u] : 0u;
+					const uint32_t a1 = inA ? tile[row][2 * EW_WW + (d0 & 3u)] : 0u, b1 = inB ? tile[row][2 * EW_WW + (d1 & 3u)] : 0u;
+					p0w = __builtin_amdgcn_alignbit(b0, a0, sft); p1w = __builtin_amdgcn_alignbit(b1, a1, sft);
+					const uint32_t lowm = sft ? ((1u << (32u - sft)) - 1u) : ~0u;             // the bits that come from dword d0
+					return (inA ? lowm : 0u) | (inB ? ~lowm : 0u);
+				}
 				if(pow2row){
 					// the whole row is in LDS and NW is a power of two: a position outside the band is looked up where the reference's
 					// unsigned arithmetic lands (plane_bit), which is then simply the position modulo BW -- the row read as a ring
@@ -1175,6 +1253,9 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 			bool isI, isD;
 			if(ek & 2u){ isI = ek & 1u; isD = !isI; }                  // (a stop inside VM is I or D)
 			else {
+#ifdef EDIT_DBG
+				dbg_lit++;
+#endif
 				// literally (bsalign.h:986-1010), the lookups as plain loads: outside the band or the windows
 				const long pb1 = (long)x - (long)__builtin_amdgcn_readlane((int)beg, k), pb0 = (long)x - (long)__builtin_amdgcn_readlane((int)begn, k);
 				const int u3 = plane_bit((uint32_t)y + 1u, 0, pb1), u4 = plane_bit((uint32_t)y + 1u, 1, pb1);
@@ -1212,6 +1293,9 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 		rs.score = 0; rs.qb = rs.qe = rs.tb = rs.te = 0; rs.mat = rs.mis = rs.ins = rs.del = rs.aln = 0;
 		ncig = 0;
 	}
+#ifdef EDIT_DBG
+	if(lane == 0 && blockIdx.x < 12u) printf("walk %u (tiled %d): %u tiles, %u fetched on demand, %u literal steps, qlen %u tlen %u\n", blockIdx.x, (int)TILED, dbg_tiles, dbg_demand, dbg_lit, qlen, tlen);
+#endif
 	if(lane == 0){ out[pair] = rs; cig_cnt[ppos] = ncig; }
 }
 
@@ -1281,6 +1365,24 @@ hipError_t bsa_launch_edit_stage(const uint8_t *seqs, const uint64_t *qoff, cons
 	return hipGetLastError();
 }
 
+// Row format 1 (tiled, bsa_common.h) is a contract between ONE forward kernel and ONE traceback kernel: k_edit_fwd_grp32 and k_edit_trace_wave.  It is
+// taken for a launch class that both launchers below give to exactly those two -- a band of 64 / 128 / 256 columns, few enough pairs for a walk per
+// wave -- and that fills a chunk alone (bsa_edit_run sets EditArgs::row_fmt from this for the forward and the traceback launch of the chunk alike).
+// BSA_EDIT_TILED=0 keeps format 0; any of the kernel-choice knobs does as well.
+bool bsa_edit_tiled_ok(uint32_t bw, uint32_t count, int mode){
+	(void)mode;
+	const char *te = bsa_env("BSA_EDIT_TILED");
+	if(te && te[0] == '0') return false;
+	if(bsa_env("BSA_EDIT_GRP") || bsa_env("BSA_EDIT_GRP32") || bsa_env("BSA_EDIT_TRACE_WAVE") || bsa_env("BSA_EDIT_TRACE_LANES") || bsa_env("BSA_EDIT_TRACE_COOP") || bsa_env("BSA_EDIT_FWD_LANES")) return false;
+	const uint32_t nw = bw / 64u;
+	if(!(bw == 64u || bw == 128u || bw == 256u) || count == 0u) return false;
+	const uint32_t G32 = nw <= 1u ? 2u : nw <= 2u ? 4u : 8u;
+	if((uint64_t)count * G32 / 64u > 65536u) return false;                          // k_edit_fwd_grp32's own condition
+	int dev = 0, cus = 256;
+	if(hipGetDevice(&dev) == hipSuccess){ int v = 0; if(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+	return count <= 8u * (uint32_t)cus * 32u;                                         // k_edit_trace_wave's (narrow bands)
+}
+
 hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 	if(a.count == 0) return hipSuccess;
 	// pairs per wave of the register kernels (BSA_EDIT_FWD_LANES overrides, for measurements).  64 is best: a wave's time
@@ -1307,11 +1409,20 @@ hipError_t bsa_launch_edit_fwd(const EditArgs &a, hipStream_t st){
 			if(g32){
 				bsa_last_fwd_kernel = "k_edit_fwd_grp32 (forward DP, 32-bit words, 2 NW lanes per pair)";
 				const uint32_t ppw = 64u / G32, gblocks = ((a.count + ppw - 1) / ppw + 3) / 4;
+				if(a.row_fmt == 1u){
+					bsa_last_fwd_kernel = "k_edit_fwd_grp32 (forward DP, 32-bit words, 2 NW lanes per pair, rows tiled eight at a time)";
+					switch(G32){
+						case 2: hipLaunchKernelGGL((k_edit_fwd_grp32<2, true>), dim3(gblocks), dim3(256), 0, st, a); break;
+						case 4: hipLaunchKernelGGL((k_edit_fwd_grp32<4, true>), dim3(gblocks), dim3(256), 0, st, a); break;
+						default: hipLaunchKernelGGL((k_edit_fwd_grp32<8, true>), dim3(gblocks), dim3(256), 0, st, a); break;
+					}
+					return hipGetLastError();
+				}
 				switch(G32){
-					case 2: hipLaunchKernelGGL((k_edit_fwd_grp32<2>), dim3(gblocks), dim3(256), 0, st, a); break;
-					case 4: hipLaunchKernelGGL((k_edit_fwd_grp32<4>), dim3(gblocks), dim3(256), 0, st, a); break;
-					case 8: hipLaunchKernelGGL((k_edit_fwd_grp32<8>), dim3(gblocks), dim3(256), 0, st, a); break;
-					default: hipLaunchKernelGGL((k_edit_fwd_grp32<16>), dim3(gblocks), dim3(256), 0, st, a); break;
+					case 2: hipLaunchKernelGGL((k_edit_fwd_grp32<2, false>), dim3(gblocks), dim3(256), 0, st, a); break;
+					case 4: hipLaunchKernelGGL((k_edit_fwd_grp32<4, false>), dim3(gblocks), dim3(256), 0, st, a); break;
+					case 8: hipLaunchKernelGGL((k_edit_fwd_grp32<8, false>), dim3(gblocks), dim3(256), 0, st, a); break;
+					default: hipLaunchKernelGGL((k_edit_fwd_grp32<16, false>), dim3(gblocks), dim3(256), 0, st, a); break;
 				}
 				return hipGetLastError();
 			}
@@ -1375,8 +1486,9 @@ hipError_t bsa_launch_edit_trace(const EditArgs &a, bsa_result_t *out, uint32_t 
 		if(const char *e = bsa_env("BSA_EDIT_TRACE_WAVE")) wave = e[0] == '1';
 		if(bsa_env("BSA_EDIT_TRACE_LANES") || bsa_env("BSA_EDIT_TRACE_COOP")) wave = false;
 		if(wave){
-			bsa_last_trace_kernel = "k_edit_trace_wave";
-			hipLaunchKernelGGL(k_edit_trace_wave, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
+			bsa_last_trace_kernel = a.row_fmt == 1u ? "k_edit_trace_wave (rows tiled eight at a time)" : "k_edit_trace_wave";
+			if(a.row_fmt == 1u) hipLaunchKernelGGL(k_edit_trace_wave<true>, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
+			else hipLaunchKernelGGL(k_edit_trace_wave<false>, dim3(a.count), dim3(64), 0, st, a, out, cig_cnt);
 			return hipGetLastError();
 		}
 	}

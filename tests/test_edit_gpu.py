@@ -59,6 +59,34 @@ def test_benchmark_shape_100k_bw256(ctx):
     _check(ctx, pairs, S.MODE_GLOBAL, 256)
 
 
+@pytest.mark.parametrize("mode,bw", [(S.MODE_GLOBAL, 256), (S.MODE_GLOBAL, 128), (S.MODE_GLOBAL, 64), (S.MODE_OVERLAP, 256), (S.MODE_EXTEND, 192)])
+def test_rows_tiled_eight_at_a_time(ctx, mode, bw, monkeypatch):
+    """row format 1 (round 6; bsa_common.h): k_edit_fwd_grp32 writes a pair's rows eight to a tile, a 64-byte block per 32-bit column word, and
+    k_edit_trace_wave fetches three dwords per plane and row around the walk's diagonal.  Pairs that stay on the diagonal, pairs whose indels
+    carry the path across the band (the window misses: the literal lookups), rows that end a tile and targets of 1 .. 17 rows; the oracle's
+    result, and the same bytes as format 0 (BSA_EDIT_TILED=0)"""
+    rng = np.random.default_rng(600 + bw + mode)
+    pairs = [_mk(rng, int(rng.choice([300, 700, 1500, 3000, 6000])), float(rng.choice([0.0, 0.01, 0.1, 0.2, 0.35])), float(rng.choice([1.0, 1.0, 0.97, 1.03])))
+             for _ in range(80)]
+    pairs += [_mk(rng, 4000, 0.3, 1.0) for _ in range(6)]
+    if mode == S.MODE_GLOBAL:
+        # one launch class, the whole batch at this band width: the reference widens the band of a pair whose query is much longer than its target (bsalign.h:1055-1067)
+        pairs = [(q, t) for q, t in pairs if len(q) > bw and (len(q) + len(t) - 1) // len(t) + 1 <= bw]
+    _check(ctx, pairs, mode, bw)
+    names = ctx.last_kernel_names()
+    out1, cig1, st1 = ctx.edit_batch(pairs, mode, bw)
+    monkeypatch.setenv("BSA_EDIT_TILED", "0")
+    out0, cig0, st0 = ctx.edit_batch(pairs, mode, bw)
+    assert "tiled" not in ctx.last_kernel_names()[0]
+    assert np.array_equal(out1, out0) and np.array_equal(st1, st0) and all(np.array_equal(x, y) for x, y in zip(cig1, cig0))
+    if bw in (64, 128, 256) and mode == S.MODE_GLOBAL:
+        assert len(pairs) > 40 and "tiled" in names[0] and "tiled" in names[1], names
+    monkeypatch.delenv("BSA_EDIT_TILED")
+    # ragged companions (targets of 1 .. 17 rows, queries cut in half: other launch classes join the batch, whatever kernels take them)
+    rag = [(q, t[:k]) for k, (q, t) in zip(range(1, 18), pairs)] + [(q[:max(1, len(q) // 2)], t) for q, t in pairs[:6]]
+    _check(ctx, rag + pairs[:8], mode, bw)
+
+
 def test_golden_edit_cases(ctx):
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "edit.npz"))
@@ -144,7 +172,7 @@ def test_golden_wide_bands_from_the_reference(ctx):
 
 
 @pytest.mark.parametrize("env", [{"BSA_EDIT_GRP": "0"}, {"BSA_EDIT_GRP": "1"}, {"BSA_EDIT_TRACE_COOP": "0"}, {"BSA_EDIT_TRACE_LANES": "16"},
-                                 {"BSA_EDIT_NO_MERGE": "1"}, {"BSA_EDIT_TRACE_WAVE": "0"}, {"BSA_EDIT_TRACE_WAVE": "1"}, {"BSA_EDIT_GRP32": "0"}, {"BSA_EDIT_GRP32": "1"}], ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
+                                 {"BSA_EDIT_NO_MERGE": "1"}, {"BSA_EDIT_TILED": "0"}, {"BSA_EDIT_TRACE_WAVE": "0"}, {"BSA_EDIT_TRACE_WAVE": "1"}, {"BSA_EDIT_GRP32": "0"}, {"BSA_EDIT_GRP32": "1"}], ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
 def test_golden_cases_on_every_kernel_variant(ctx, monkeypatch, env):
     """the launchers pick kernels by batch size; force each alternative (pair-per-lane / grouped forward kernels, plain /
     cooperative traceback, many pairs per wave, one walk per wave or never, no class merging) and replay the reference's results"""
