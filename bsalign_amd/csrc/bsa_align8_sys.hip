@@ -91,7 +91,7 @@ int bsa_align8_sys_supported(const Align8Args &a, int pw){
 //   u' = h - v, v' = h - u      the new row's horizontal and vertical differences H(x, y) - H(x-1, y), H(x, y) - H(x, y-1): CHECKED per cell
 //   f' = max(..) - u            = F(x+1, y) - H(x, y-1) <= v' + gape from above; from below >= -2 g (row 0: >= -63 - g): inside int8
 //   F-penetration (:2639-2652)  its int -> int8 truncation needs a value above 127; every candidate is <= the F that arrives <= h <= 127
-//   block restart               F(x, y) - D >= -63 CHECKED per cell (x >= 1): then max(-63, F) = F at every block start, whatever W is
+//   block restart               F(x, y) - D >= -63 CHECKED per query column (x >= 1): then max(-63, F) = F at every block start, whatever W is
 // (two pieces: the same for q / G with gapo2 + gape2; linear gaps: e + u is u + gape).  So a lane tracks the minimum and maximum of its cells' two
 // differences and the minimum of F - D (G - D); a pair any of whose cells leaves [-128, 127] resp. goes below -63 is flagged BSA_ST_TRACE and
 // left to the literal kernels (bsa_align_batch re-runs it there).  Overlap / extend: row_max (bsalign.h:3213) also looks at the band's padding
@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(P
 				} else {
 					const int x = t - lane;
 					if(x >= 0 && x < xlim){ chi = max(chi, dV); clo = min(clo, dV); }
-					if(x >= 1 && x < xlim){ chi = max(chi, dU); clo = min(clo, dU); cfl = min(cfl, dF); }
+					if(x >= 1 && x < xlim){ chi = max(chi, dU); clo = min(clo, dU); }
+					if(x >= 1 && x < qlen) cfl = min(cfl, dF);                             // (a padding cell is never a block start: all of them lie inside the last block, whose start is a query column)
 				}
 			}
 			const int t1 = H + GOE5;
@@ -316,6 +317,9 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(P
 			for(int c0 = drained; c0 < xlim; c0 += 64){ const int c = c0 + lane; if(c < xlim) bnd[c] = orng[c & 255]; }
 		if constexpr(CHK){
 			if(live && y < tlen && (chi > 127 * 32 || clo < -128 * 32 || cfl < BSA_EPI8_MIN * 32)) badl = 1;
+#ifdef SYS_DBG
+			if(live && y < tlen && (chi > 127 * 32 || clo < -128 * 32 || cfl < BSA_EPI8_MIN * 32) && blockIdx.x < 4u) printf("pair %u row %d (qlen %d tlen %d): max diff %d min diff %d min F - D %d\n", pair, y, qlen, tlen, chi / 32, clo / 32, cfl / 32);
+#endif
 		}
 	}
 	if constexpr(CHK){

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -656,10 +657,12 @@ static int run_prologue(PlanBase *p, bool want_cig, size_t cigar_cap_words){
 	return BSA_OK;
 }
 
-// host-pointer convenience wrapper shared by both paths: copy in, run, copy out, synchronise
-template<class RunFn>
+// host-pointer convenience wrapper shared by both paths: copy in, run, copy out, synchronise.  prep() is the host-side planning (bsa_*_plan_create:
+// tens of milliseconds for 100 k pairs): for a large blob it runs on the calling thread WHILE a helper thread feeds the upload -- a copy from pageable
+// memory keeps its host thread busy for its whole duration -- so the two no longer add up (C2: 29 ms of planning under a 50 ms upload).
+template<class PrepFn, class RunFn>
 static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t n, bsa_result_t *out, uint32_t *cigar,
-		size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status, RunFn run){
+		size_t cigar_cap_words, uint64_t *cigar_off, uint32_t *status, PrepFn prep, RunFn run){
 	uint8_t *d_seqs = nullptr; bsa_result_t *d_out = nullptr; uint32_t *d_cig = nullptr, *d_status = nullptr; uint64_t *d_off = nullptr;
 	uint8_t *pool = nullptr; bool pool_kept = false;            // one allocation for the five buffers
 	auto cleanup = [&](){ ctx_buf_put(c, 1, pool, pool_kept); pool = nullptr; };
@@ -671,8 +674,19 @@ static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t
 	TRYH(ctx_buf_get(c, 1, total, (void**)&pool, &pool_kept));
 	d_seqs = pool + o_seqs; d_out = (bsa_result_t*)(pool + o_out); d_status = (uint32_t*)(pool + o_st);
 	if(want_cig){ d_off = (uint64_t*)(pool + o_off); d_cig = (uint32_t*)(pool + o_cig); }
-	TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
-	int rc = run(d_seqs, d_out, d_cig, d_off, d_status);
+	int rc;
+	if(seqs_bytes >= ((size_t)64 << 20) && !bsa_env("BSA_BATCH_NO_UPLOAD_THREAD")){
+		hipError_t uperr = hipSuccess;
+		std::thread upl([&]{ (void)hipSetDevice(c->device); uperr = hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream); });
+		rc = prep();
+		upl.join();
+		if(uperr != hipSuccess){ c->err = std::string("upload of the sequences: ") + hipGetErrorString(uperr); cleanup(); return BSA_E_HIP; }
+	} else {
+		TRYH(hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream));
+		rc = prep();
+	}
+	if(rc != BSA_OK){ (void)hipStreamSynchronize(c->stream); cleanup(); return rc; }
+	rc = run(d_seqs, d_out, d_cig, d_off, d_status);
 	if(rc != BSA_OK){ cleanup(); return rc; }
 	if(total - o_out <= ((size_t)1 << 20)){
 		// a small batch: everything that goes back in ONE copy (results, status, offsets, the whole arena), then handed out
@@ -1014,15 +1028,14 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	if(!(par->mode & BSA_MODE_ROWRECORDS)) c->last_handover = 0;
 	const bool timing = bsa_env("BSA_API_TIMING") != nullptr;          // (stderr: where a host-pointer batch spends its wall time)
 	const auto tm0 = std::chrono::steady_clock::now();
-	int rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
-	if(rc != BSA_OK) return rc;
-	const auto tm1 = std::chrono::steady_clock::now();
-	std::vector<uint32_t> st_own;
-	uint32_t *st = status;
-	const bool codes = p->codes || p->sys;           // both read the traceback off codes and may hand a pair over
-	if(codes && !st){ st_own.resize(n); st = st_own.data(); }
-	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, st,
+	std::vector<uint32_t> st_own(status ? 0 : n);      // (a path that reads the traceback off codes may hand a pair over: it needs the flags even when the caller does not)
+	uint32_t *st = status ? status : st_own.data();
+	auto tm1 = tm0;
+	int rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, st,
+		[&]{ const int r = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p); tm1 = std::chrono::steady_clock::now(); return r; },
 		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_align_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });
+	if(!p) return rc;
+	const bool codes = p->codes || p->sys;           // both read the traceback off codes and may hand a pair over
 	if(timing){
 		const auto tm2 = std::chrono::steady_clock::now();
 		fprintf(stderr, "[bsa_align_batch] %zu pairs, mode %d, bandwidth %u: plan %.3f s (workspace %.1f GB, %zu chunks), staging + kernels + copies %.3f s, forward kernel %s\n", n, par->mode & 3, par->bandwidth,
@@ -1311,12 +1324,12 @@ extern "C" int bsa_edit_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_byt
 	bsa_edit_plan_t *p = nullptr;
 	const bool timing = bsa_env("BSA_BATCH_TIMING") != nullptr;        // host-side phase times on stderr
 	const auto t0 = std::chrono::steady_clock::now();
-	int rc = bsa_edit_plan_create(c, qoff, qlen, toff, tlen, n, par, &p);
-	if(rc != BSA_OK) return rc;
-	const auto t1 = std::chrono::steady_clock::now();
-	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, status,
+	auto t1 = t0;
+	int rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, status,
+		[&]{ const int r = bsa_edit_plan_create(c, qoff, qlen, toff, tlen, n, par, &p); t1 = std::chrono::steady_clock::now(); return r; },
 		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_edit_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });
 	const auto t2 = std::chrono::steady_clock::now();
+	if(!p) return rc;
 	const size_t nch = p->chunks.size(), nsub = p->subs.size();
 	bsa_edit_plan_destroy(p);
 	if(timing) fprintf(stderr, "[bsa_edit_batch] %zu pairs: plan %.1f ms (%zu chunks, %zu forward launches), copy + run + copy %.1f ms, destroy %.1f ms\n", n,

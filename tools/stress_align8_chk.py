@@ -23,6 +23,8 @@ def draw_scoring(rng):
         g = go + ge
         if g > 63 or g + n + m > 128:
             continue
+        if g > 31 and rng.random() < 0.75:      # above 31 the -63 restart of the running blocks binds and nearly every pair is handed over: mostly draw what the checked kernel decides itself
+            continue
         if kind == 2:
             ge2 = int(rng.integers(0, ge)); go2 = int(rng.integers(go + 1, 64))
             if go2 + ge2 > 63 or go2 + ge2 <= g or go2 + ge2 + n + m > 128 or ge2 >= ge:
