@@ -577,7 +577,7 @@ def main_poa_recorded(args):
                      "issue": issue_fractions(ent, kms_tot / nl),
                      "traffic_from": (ent or {}).get("source") if traffic else None,
                      "note": "not HBM-bound: one wave per read, a graph node per trip (about 180 instructions); a lone wave is bound by its own dependent latencies, thousands of "
-                             "windows in flight by VALU issue (DESIGN section 4b); about 6 KB of LDS per read, five waves per SIMD"},
+                             "windows in flight by VALU issue (HISTORY section 4b); about 6 KB of LDS per read, five waves per SIMD"},
         "checks": {"best_end_cell_identical_all_programs": bool(ident), "programs": nprog_total},
         "cpu_baseline": cpub,
         "lockstep_end_to_end": e2e,

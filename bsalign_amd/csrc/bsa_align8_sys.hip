@@ -17,7 +17,7 @@
 //     (clamped to 63) if >= u[0] + e[0], else -63; every later row has ubegs[0] = H(0, y-1), u[0] = 0 (the re-basing of :2632-2633)
 //   * F restarts from "H above - 63" at every running block of W = bw / 16 cells (bsalign.h:2909-2931 + the F-penetration :2639-2652):
 //     never binding inside the guard (see the kernel), so the striping of the reference's band does not enter
-// Traceback codes (the four facts backcal tests per cell): M (h == S-path; at column 0 against the UNclamped
+// Traceback codes (the four facts backcal tests per cell, HISTORY section 3): M (h == S-path; at column 0 against the UNclamped
 // rh + S), D (h == u + e; at column 0 in the frame mismatch of the re-based row: h - rh == u[0] + e[0]), R (h + gapo + gape >= f + gape:
 // an insertion reaching the next cell opens here), Od (the stored e is a fresh opening).  Row y, columns 32 k .. 32 k + 31: four
 // dwords {M, D, R, Od} of the wavefront steps t = x + (y & 63), 32 k <= t < 32 k + 32, step t at bit 31 - (t & 31); the 64 rows of a block

@@ -71,7 +71,7 @@ static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t 
 	return bsa_begs_bytes(tlen) + bsa_groups(tlen, bsa_tile_rows(W, pw)) * 16 * (size_t)bsa_tile_bytes(W, pw);
 }
 
-// COMPACT (4-bit code) slot of the global-mode fast path (bsa_align8_pk.hip, CODES = true):
+// COMPACT (4-bit code) slot of the global-mode fast path (bsa_align8_pk.hip, CODES = true; HISTORY.md section 3):
 //   int32 begs[tlen + 2]  (begs[tlen + 1] = final score, global mode)  |  code rows 0 .. tlen-1  |  BSA_CODE_SPARE_ROWS
 //   spare rows: CIGAR scratch of the traceback and, in overlap / extend mode, the end record the forward pass leaves
 //   at the start of the spare area (bsa_code_end_t followed by the last row's u bytes in natural band order)
@@ -87,7 +87,7 @@ static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t 
 //   dword 0: A | D << 8 | D2 << 16 | B << 24        dword 1: R1 | R2 << 8 | Od1 << 16 | Od2 << 24
 // D / D2: h == u + e / h == u + q.  A and B fold M and "which insertion chain equals h" (I1: h == f, I2: h == g), which are
 // only consulted where D = D2 = 0:  D or D2 set: A is M.  Else (A, B) = (1, 0) M; (1, 1) not M, both chains; (0, 1) chain 1
-// only; (0, 0) chain 2 only.  R1 / R2, Od1 / Od2: the flags R, Od of the two pieces (DESIGN.md section 3 states the rules).
+// only; (0, 0) chain 2 only.  R1 / R2, Od1 / Od2: the flags R, Od of the two pieces (HISTORY.md section 3 states the rules).
 // TILING: the traceback walks up the rows while its position inside the band drifts slowly (the band follows the
 // diagonal), so it wants a few blocks of many rows, not whole rows.  Rows are stored in groups of four; inside a
 // group the four rows of ONE block are adjacent (16 CW bytes), blocks follow each other:

@@ -32,7 +32,7 @@
 #endif
 
 /* WHEN the device is attached.  One POA is sequential in its reads and a lone wave of the device runs a read's DP several times slower than a host
- * core; the device pays by running many windows at once.  Measured on the MI355X box (16 host threads, windows of 12 reads x
+ * core (HISTORY.md section 4b); the device pays by running many windows at once.  Measured on the MI355X box (16 host threads, windows of 12 reads x
  * 1.5 kbp, tests/test_poa_pog_gpu.py::test_where_many_windows_start_to_pay): 1 window 0.042 s on the device path against 0.024 s for the reference,
  * 16: 0.074 / 0.030, 32: 0.086 / 0.067, 64: 0.117 / 0.123, 128: 0.183 / 0.241.  Below BSA_POA_MIN_WINDOWS windows in flight this binding therefore
  * leaves BSPOA.devsweep NULL -- the reference's own end_bspoa on host threads, which is this header's caller's code, not a path of libbsalign_hip --

@@ -499,7 +499,7 @@ def test_whole_query_bands_with_scores_outside_the_guard_run_the_checked_systoli
             names = ctx.last_kernel_names()
             assert "k_align8_fwd_sys<CHK>" in names[0] and "k_align8_trace_sys" in names[1], names
             if scname != "big2piece":
-                assert ctx.last_handover() <= 2, (scname, mode, ctx.last_handover())       # (a deletion run that reaches row -1 is the literal path's)
+                assert ctx.last_handover() <= 2, (scname, mode, ctx.last_handover())       # (a deletion run that reaches row -1 is the literal path's, HISTORY section 5)
     par = B.make_params(S.MODE_OVERLAP, bw, *BIG_SCORINGS["big"])
     out_s, cig_s, st_s = ctx.align_batch(pairs, par)
     monkeypatch.setenv("BSA_ALIGN8_SYS_CHK", "0")
@@ -557,7 +557,7 @@ def test_whole_query_plan_with_mixed_lengths_on_device_pointers(ctx):
             if m == S.ORC_ERR_TRACE:              # the reference's own traceback does not terminate here: the device must say so
                 assert st[k] & B.ST_TRACE, (mode, k, len(q), len(t))
                 continue
-            if st[k] & B.ST_TRACE:                # the code traceback declined (a deletion run reaching row -1 / decided at column 0)
+            if st[k] & B.ST_TRACE:                # the code traceback declined (a deletion run reaching row -1 / decided at column 0, HISTORY section 5)
                 handed.append(k)
                 continue
             assert st[k] == 0 and np.array_equal(out[k], res) and np.array_equal(cig[int(off[k]):int(off[k + 1])], ocig), (mode, k, len(q), len(t))

@@ -37,7 +37,7 @@ def test_end_bspoa_with_the_sweep_on_the_device(ctx, kw):
 
 def test_c4_scaled_wall_time(ctx, capsys):
     """BASELINE config C4 scaled down (32 reads x 4 kbp, default POA parameters): same consensus, and the wall time of
-    end_bspoa with the sweep on the CPU (reference) and on the device (one window = latency-bound)"""
+    end_bspoa with the sweep on the CPU (reference) and on the device (one window = latency-bound, HISTORY section 4)"""
     _attach(ctx)
     p = P.par()
     reads = P.synth_reads(20240611 & 0xFFFF, 4000, 32, eps=(0.1,))

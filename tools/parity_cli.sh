@@ -19,7 +19,7 @@ mk("$D/mid.fa", 4000, [300, 700, 1500, 3000], [0.05, 0.1, 0.15])
 PY
 REF=oracle/_ref/bsalign_ref_cli; HIP=bsalign_amd/bsalign-hip
 bad=0; tot=0
-# (the reference's traceback crashes or hangs on rare inputs, DESIGN section 2: then the records it printed before are compared, and bsalign-hip --
+# (the reference's traceback crashes or hangs on rare inputs, HISTORY section 2: then the records it printed before are compared, and bsalign-hip --
 # which reports such a pair on stderr and goes on -- must agree with them)
 chk(){
 	$HIP "$@" > $D/a.txt 2>/dev/null; timeout 600 $REF "$@" > $D/b.txt 2>/dev/null; local rc=$?
