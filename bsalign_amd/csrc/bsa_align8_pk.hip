@@ -673,7 +673,8 @@ bool bsa_align8_codes_supported(const Align8Args &a, int pw){
 	if(!bsa_align8_pk_supported(a, pw) || pw > 1) return false;
 	const int g = -((int)(int8_t)(a.gapo1 + a.gape1)), m = a.smax, n = -a.smin;
 	if(m < 0 || n < 0 || g < 0) return false;
-	return m + 3 * g <= 64 && n + m + g <= 100;
+	// (m + 2 n <= 128: row 0's seed at column 0, (min - max) + S, is inserted as a byte (bsalign.h:2910); a mismatch there must not wrap it)
+	return m + 3 * g <= 64 && n + m + g <= 100 && m + 2 * n <= 128;
 }
 
 hipError_t bsa_launch_align8_fwd_codes(const Align8Args &a, int pw, hipStream_t st){

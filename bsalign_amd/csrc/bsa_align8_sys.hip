@@ -60,7 +60,9 @@ int bsa_align8_sys_supported(const Align8Args &a, int pw){
 		if(ge2 < 0 || go2 <= go || ge2 >= ge) return 0;
 		g = max(g, go2 + ge2);
 	}
-	if(m + 3 * g <= 64 && n + m + g <= 100) return 1;
+	// (m + 2 n <= 128: the seed of row 0, column 0 -- (min - max) + S in global / extend mode, bsalign.h:2899-2910 -- stays a byte even on a mismatch;
+	// beyond, the reference's byte wraps: the kernel wraps it too, and the checked form then sees the differences that leave int8)
+	if(m + 3 * g <= 64 && n + m + g <= 100 && m + 2 * n <= 128) return 1;
 	// The checked form (see the kernel): substitution scores no lower than the -63 sentinel, gap costs that keep h + gapoe and the stored e / q
 	// inside int8 whatever the cell holds, row -1's first difference (row_init, bsalign.h:2100) not truncated, penalties that are what their
 	// int8 truncations say.
@@ -206,6 +208,7 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(P
 					int h0 = rh - ub0 + S;
 					const int tt = u0 + (PW == 0 ? GE : PW == 1 ? e0 : max(e0, q0));
 					h0 = (h0 >= tt) ? min(h0, BSA_EPI8_MAX) : BSA_EPI8_MIN;
+					h0 = (int)(int8_t)h0;                                      // mm_insert_epi8 (bsalign.h:2910): row 0 of global / extend mode can seed below -128 (a mismatch at (0, 0): min - max + min), and the byte wraps
 					diag = (ub0 + h0) * 32;
 					cmpM = (rh + S) * 32;
 					cmpD = (rh + u0 + (PW == 0 ? GOE : e0)) * 32;

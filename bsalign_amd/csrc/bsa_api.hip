@@ -657,6 +657,7 @@ static int run_prologue(PlanBase *p, bool want_cig, size_t cigar_cap_words){
 	return BSA_OK;
 }
 
+static hipError_t par_copy(int device, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);      // (below: large pageable copies in pieces on threads of their own)
 // host-pointer convenience wrapper shared by both paths: copy in, run, copy out, synchronise.  prep() is the host-side planning (bsa_*_plan_create:
 // tens of milliseconds for 100 k pairs): for a large blob it runs on the calling thread WHILE a helper thread feeds the upload -- a copy from pageable
 // memory keeps its host thread busy for its whole duration -- so the two no longer add up (C2: 29 ms of planning under a 50 ms upload).
@@ -677,7 +678,7 @@ static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t
 	int rc;
 	if(seqs_bytes >= ((size_t)64 << 20) && !bsa_env("BSA_BATCH_NO_UPLOAD_THREAD")){
 		hipError_t uperr = hipSuccess;
-		std::thread upl([&]{ (void)hipSetDevice(c->device); uperr = hipMemcpyAsync(d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice, c->stream); });
+		std::thread upl([&]{ (void)hipSetDevice(c->device); uperr = par_copy(c->device, d_seqs, seqs, seqs_bytes, hipMemcpyHostToDevice); });      // (arrived when it returns: the run's kernels need no event)
 		rc = prep();
 		upl.join();
 		if(uperr != hipSuccess){ c->err = std::string("upload of the sequences: ") + hipGetErrorString(uperr); cleanup(); return BSA_E_HIP; }
@@ -709,7 +710,7 @@ static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t
 	TRYH(hipStreamSynchronize(c->stream));
 	if(want_cig){
 		if(cigar_off[n] > cigar_cap_words){ cleanup(); c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
-		TRYH(hipMemcpy(cigar, d_cig, cigar_off[n] * 4, hipMemcpyDeviceToHost));
+		TRYH(par_copy(c->device, cigar, d_cig, cigar_off[n] * 4, hipMemcpyDeviceToHost));
 	}
 #undef TRYH
 	cleanup();
@@ -959,6 +960,192 @@ extern "C" int bsa_align_run(bsa_align_plan_t *p, const uint8_t *d_seqs, bsa_res
 	return rc8;
 }
 
+
+// A copy between PAGEABLE host memory and the device keeps its host thread busy staging (measured on the MI355X box: one thread moves about 30 GB/s up
+// and 10 GB/s down), so a large one is cut into pieces that travel on threads and streams of their own; returns when all of it has arrived.
+static hipError_t par_copy(int device, void *dst, const void *src, size_t bytes, hipMemcpyKind kind){
+	unsigned T = 4;
+	if(const char *e = bsa_env("BSA_COPY_THREADS")){ const int v = atoi(e); if(v >= 1 && v <= 16) T = (unsigned)v; }
+	if(bytes < ((size_t)32 << 20) || T == 1){
+		hipStream_t st = nullptr;
+		hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+		if(e != hipSuccess) return e;
+		e = hipMemcpyAsync(dst, src, bytes, kind, st);
+		if(e == hipSuccess) e = hipStreamSynchronize(st);
+		(void)hipStreamDestroy(st);
+		return e;
+	}
+	const size_t piece = ((bytes + T - 1) / T + 4095) & ~(size_t)4095;
+	std::vector<hipError_t> errs(T, hipSuccess);
+	std::vector<std::thread> th;
+	for(unsigned t = 0; t < T; t++){
+		const size_t lo = (size_t)t * piece;
+		if(lo >= bytes) break;
+		const size_t len = std::min(piece, bytes - lo);
+		th.emplace_back([=, &errs]{
+			(void)hipSetDevice(device);
+			hipStream_t st = nullptr;
+			hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+			if(e == hipSuccess) e = hipMemcpyAsync((uint8_t*)dst + lo, (const uint8_t*)src + lo, len, kind, st);
+			if(e == hipSuccess) e = hipStreamSynchronize(st);
+			if(st) (void)hipStreamDestroy(st);
+			errs[t] = e;
+		});
+	}
+	for(std::thread &x : th) x.join();
+	for(hipError_t e : errs) if(e != hipSuccess) return e;
+	return hipSuccess;
+}
+
+// ---- a large host-pointer batch in TWO slices (round 6) --------------------------------------------------------------
+// A caller with host buffers pays the upload in front of the kernels and the download behind them: C2 176-180 ms against 72 ms on resident
+// inputs.  With the batch cut in two -- 50 000 pairs still fill the chip, smaller launches do not -- slice B's sequences
+// travel while slice A's kernels run, and slice A's results go back while slice B's run: a helper thread feeds the uploads (a copy from
+// pageable memory keeps its host thread busy), the calling thread plans both slices under the first upload, launches, and collects.
+// Each slice is an ordinary plan + run on the context's stream; both read the ONE device copy of the blob at the caller's offsets and write
+// their own results, offsets and CIGAR arena.  Returns BSA_OK with *done = true, an error, or *done = false when the batch is not for this
+// path (small, a bandwidth that makes width classes, byte ranges of the slices that cannot be told apart): the caller goes on as before.
+static int align_batch_sliced(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff,
+		const uint32_t *tlen, size_t n, const bsa_align_params_t *par, bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words, uint64_t *cigar_off,
+		uint32_t *st, bool *done, bool *codes_out){
+	*done = false;
+	const char *se = bsa_env("BSA_BATCH_SLICES");
+	const bool forced = se && se[0] == '2';
+	if(se && se[0] == '1') return BSA_OK;
+	const uint32_t bw_req = (par->bandwidth + 15u) / 16u * 16u;
+	if(bw_req == 0 || !bsa_align8_supported_bw(bw_req) || (par->mode & BSA_MODE_ROWRECORDS)) return BSA_OK;
+	if(!forced && (n < 80000 || seqs_bytes < ((size_t)512 << 20))) return BSA_OK;
+	if(n < 2 || (cigar && cigar_off && cigar_cap_words > ((size_t)1 << 31))) return BSA_OK;
+	// the cut: half of the bytes
+	size_t tot = 0, h = 0;
+	for(size_t k = 0; k < n; k++) tot += (size_t)qlen[k] + tlen[k];
+	{ size_t acc = 0; while(h < n && acc < tot / 2){ acc += (size_t)qlen[h] + tlen[h]; h++; } }
+	if(h == 0 || h >= n) return BSA_OK;
+	// the byte intervals a slice reads, merged (gaps below 64 KB travel along); many scattered intervals: not for this path
+	struct Iv { size_t lo, hi; };
+	auto intervals = [&](size_t k0, size_t k1, std::vector<Iv> &v) -> bool {
+		std::vector<Iv> raw; raw.reserve(2 * (k1 - k0));
+		for(size_t k = k0; k < k1; k++){ if(qlen[k]) raw.push_back({(size_t)qoff[k], (size_t)qoff[k] + qlen[k]}); if(tlen[k]) raw.push_back({(size_t)toff[k], (size_t)toff[k] + tlen[k]}); }
+		std::sort(raw.begin(), raw.end(), [](const Iv &a, const Iv &b){ return a.lo < b.lo; });
+		for(const Iv &x : raw){
+			if(!v.empty() && x.lo <= v.back().hi + ((size_t)64 << 10)) v.back().hi = std::max(v.back().hi, x.hi);
+			else { if(v.size() >= 64) return false; v.push_back(x); }
+		}
+		return true;
+	};
+	std::vector<Iv> ivA, ivB;
+	if(!intervals(0, h, ivA) || !intervals(h, n, ivB)) return BSA_OK;
+	// what slice A uploaded need not travel again
+	{
+		std::vector<Iv> rest;
+		for(Iv x : ivB){
+			for(const Iv &a : ivA){
+				if(a.hi <= x.lo || a.lo >= x.hi) continue;
+				if(a.lo > x.lo) rest.push_back({x.lo, a.lo});
+				x.lo = std::min(x.hi, a.hi);
+			}
+			if(x.lo < x.hi) rest.push_back(x);
+		}
+		ivB.swap(rest);
+	}
+	(void)hipSetDevice(c->device);
+	const bool tmg = bsa_env("BSA_API_TIMING") != nullptr;
+	const auto ts0 = std::chrono::steady_clock::now();
+	auto since = [&](){ return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count(); };
+	double t_alloc = 0, t_plan = 0, t_join = 0, t_launch = 0, t_colA = 0, t_colB = 0;
+	const bool want_cig = cigar && cigar_off;
+	const size_t nA = h, nB = n - h;
+	auto up = [](size_t b){ return (std::max<size_t>(b, 8) + 255) & ~(size_t)255; };
+	const size_t o_seqs = 0, o_out = o_seqs + up(seqs_bytes), o_st = o_out + up(n * sizeof(bsa_result_t)), o_offA = o_st + up(n * 4), o_offB = o_offA + up((nA + 1) * 8),
+		o_cigA = o_offB + up((nB + 1) * 8), o_cigB = o_cigA + (want_cig ? up(cigar_cap_words * 4) : 0), total = o_cigB + (want_cig ? up(cigar_cap_words * 4) : 0);
+	uint8_t *pool = nullptr; bool kept = false;
+	if(ctx_buf_get(c, 1, total, (void**)&pool, &kept) != hipSuccess){ (void)hipGetLastError(); return BSA_OK; }      // (not enough memory for two arenas: the plain path)
+	hipStream_t ups = nullptr, dns = nullptr;
+	hipEvent_t evA = nullptr, evB = nullptr, doneA = nullptr, doneB = nullptr;
+	bsa_align_plan_t *pA = nullptr, *pB = nullptr;
+	int rc = BSA_OK;
+	auto cleanup = [&](){
+		(void)hipStreamSynchronize(c->stream);
+		if(ups){ (void)hipStreamSynchronize(ups); (void)hipStreamDestroy(ups); }
+		if(dns){ (void)hipStreamSynchronize(dns); (void)hipStreamDestroy(dns); }
+		for(hipEvent_t e : {evA, evB, doneA, doneB}) if(e) (void)hipEventDestroy(e);
+		if(pA) bsa_align_plan_destroy(pA);
+		if(pB) bsa_align_plan_destroy(pB);
+		ctx_buf_put(c, 1, pool, kept);
+	};
+#define SL(call) do { if(rc == BSA_OK){ hipError_t _e = (call); if(_e != hipSuccess){ c->err = std::string(#call) + ": " + hipGetErrorString(_e); rc = BSA_E_HIP; } } } while(0)
+	SL(hipStreamCreateWithFlags(&ups, hipStreamNonBlocking)); SL(hipStreamCreateWithFlags(&dns, hipStreamNonBlocking));
+	SL(hipEventCreateWithFlags(&evA, hipEventDisableTiming)); SL(hipEventCreateWithFlags(&evB, hipEventDisableTiming));
+	SL(hipEventCreateWithFlags(&doneA, hipEventDisableTiming)); SL(hipEventCreateWithFlags(&doneB, hipEventDisableTiming));
+	if(rc != BSA_OK){ cleanup(); return rc; }
+	t_alloc = since();
+	uint8_t *d_seqs = pool + o_seqs;
+	bsa_result_t *d_out = (bsa_result_t*)(pool + o_out); uint32_t *d_st = (uint32_t*)(pool + o_st);
+	uint64_t *d_offA = want_cig ? (uint64_t*)(pool + o_offA) : nullptr, *d_offB = want_cig ? (uint64_t*)(pool + o_offB) : nullptr;
+	uint32_t *d_cigA = want_cig ? (uint32_t*)(pool + o_cigA) : nullptr, *d_cigB = want_cig ? (uint32_t*)(pool + o_cigB) : nullptr;
+	// the uploads on a thread of their own: A's intervals, event, B's, event
+	hipError_t uperr = hipSuccess;
+	std::atomic<int> recorded{0};                       // 1: evA is recorded (slice A's copies are in the upload stream), 2: evB as well; -1: failed
+	std::thread upl([&]{
+		(void)hipSetDevice(c->device);
+		for(const Iv &x : ivA) if(uperr == hipSuccess) uperr = par_copy(c->device, d_seqs + x.lo, seqs + x.lo, x.hi - x.lo, hipMemcpyHostToDevice);
+		if(uperr == hipSuccess) uperr = hipEventRecord(evA, ups);
+		recorded.store(uperr == hipSuccess ? 1 : -1, std::memory_order_release);
+		for(const Iv &x : ivB) if(uperr == hipSuccess) uperr = par_copy(c->device, d_seqs + x.lo, seqs + x.lo, x.hi - x.lo, hipMemcpyHostToDevice);
+		if(uperr == hipSuccess) uperr = hipEventRecord(evB, ups);
+		recorded.store(uperr == hipSuccess ? 2 : -1, std::memory_order_release);
+	});
+	auto wait_recorded = [&](int want){ for(;;){ const int r = recorded.load(std::memory_order_acquire); if(r < 0 || r >= want) return r; std::this_thread::yield(); } };
+	rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, nA, par, &pA);
+	if(rc == BSA_OK) rc = bsa_align_plan_create(c, qoff + h, qlen + h, toff + h, tlen + h, nB, par, &pB);
+	t_plan = since();
+	if(rc != BSA_OK){ upl.join(); cleanup(); return rc; }
+	*codes_out = pA->codes || pA->sys;
+	// slice A as soon as its bytes are on their way (a wait on an event that is not recorded yet would be no wait), then slice B behind it on the same
+	// stream: B's kernels wait for B's bytes only
+	if(wait_recorded(1) < 0) rc = BSA_E_HIP;
+	SL(hipStreamWaitEvent(c->stream, evA, 0));
+	if(rc == BSA_OK) rc = bsa_align_run(pA, d_seqs, d_out, d_cigA, cigar_cap_words, d_offA, d_st);
+	SL(hipEventRecord(doneA, c->stream));
+	if(rc == BSA_OK && wait_recorded(2) < 0) rc = BSA_E_HIP;
+	t_join = since();
+	SL(hipStreamWaitEvent(c->stream, evB, 0));
+	if(rc == BSA_OK) rc = bsa_align_run(pB, d_seqs, d_out + nA, d_cigB, cigar_cap_words, d_offB, d_st + nA);
+	SL(hipEventRecord(doneB, c->stream));
+	upl.join();
+	if(uperr != hipSuccess && rc == BSA_OK){ c->err = std::string("upload of the sequences: ") + hipGetErrorString(uperr); rc = BSA_E_HIP; }
+	// slice A's results go back while slice B runs
+	uint64_t totA = 0, totB = 0;
+	auto collect = [&](hipEvent_t ev, size_t k0, size_t m, const uint64_t *d_off, const uint32_t *d_cig, uint64_t base, uint64_t *tot_out){
+		SL(hipStreamWaitEvent(dns, ev, 0));
+		SL(hipMemcpyAsync(out + k0, d_out + k0, m * sizeof(bsa_result_t), hipMemcpyDeviceToHost, dns));
+		SL(hipMemcpyAsync(st + k0, d_st + k0, m * 4, hipMemcpyDeviceToHost, dns));
+		if(want_cig){
+			SL(hipMemcpyAsync(cigar_off + k0 + (k0 ? 1 : 0), d_off + (k0 ? 1 : 0), (m + (k0 ? 0 : 1)) * 8, hipMemcpyDeviceToHost, dns));      // (slice B's first offset is slice A's total)
+			SL(hipStreamSynchronize(dns));
+			if(rc != BSA_OK) return;
+			const uint64_t t = cigar_off[k0 + m];
+			*tot_out = t;
+			if(base + t > cigar_cap_words){ c->err = "cigar arena too small"; rc = BSA_E_CIGAR_CAP; return; }
+			SL(par_copy(c->device, cigar + base, d_cig, t * 4, hipMemcpyDeviceToHost));
+			if(base) for(size_t k = k0 + 1; k <= k0 + m; k++) cigar_off[k] += base;
+		}
+		SL(hipStreamSynchronize(dns));
+	};
+	t_launch = since();
+	collect(doneA, 0, nA, d_offA, d_cigA, 0, &totA);
+	t_colA = since();
+	if(rc == BSA_OK) collect(doneB, nA, nB, d_offB, d_cigB, totA, &totB);
+	t_colB = since();
+	if(tmg) fprintf(stderr, "[bsa_align_batch] %zu pairs in two slices of %zu and %zu (uploads of %zu and %zu intervals): ms since entry -- buffers %.1f, both plans %.1f, uploads issued %.1f, both runs launched %.1f, slice A back %.1f, slice B back %.1f\n",
+		n, nA, nB, ivA.size(), ivB.size(), t_alloc, t_plan, t_join, t_launch, t_colA, t_colB);
+#undef SL
+	cleanup();
+	if(tmg) fprintf(stderr, "[bsa_align_batch] ... buffers, plans, streams released %.1f\n", since());
+	if(rc == BSA_OK) *done = true;
+	return rc;
+}
+
 extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_bytes,
 		const uint64_t *qoff, const uint32_t *qlen, const uint64_t *toff, const uint32_t *tlen, size_t n,
 		const bsa_align_params_t *par, bsa_result_t *out, uint32_t *cigar, size_t cigar_cap_words,
@@ -1031,17 +1218,22 @@ extern "C" int bsa_align_batch(bsa_ctx_t *c, const uint8_t *seqs, size_t seqs_by
 	std::vector<uint32_t> st_own(status ? 0 : n);      // (a path that reads the traceback off codes may hand a pair over: it needs the flags even when the caller does not)
 	uint32_t *st = status ? status : st_own.data();
 	auto tm1 = tm0;
-	int rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, st,
+	bool sliced = false, codes = false;
+	int rc = align_batch_sliced(c, seqs, seqs_bytes, qoff, qlen, toff, tlen, n, par, out, cigar, cigar_cap_words, cigar_off, st, &sliced, &codes);
+	if(rc != BSA_OK) return rc;
+	if(!sliced){
+	rc = batch_host(c, seqs, seqs_bytes, n, out, cigar, cigar_cap_words, cigar_off, st,
 		[&]{ const int r = bsa_align_plan_create(c, qoff, qlen, toff, tlen, n, par, &p); tm1 = std::chrono::steady_clock::now(); return r; },
 		[&](uint8_t *ds, bsa_result_t *dout, uint32_t *dc, uint64_t *doff, uint32_t *dst){ return bsa_align_run(p, ds, dout, dc, cigar_cap_words, doff, dst); });
 	if(!p) return rc;
-	const bool codes = p->codes || p->sys;           // both read the traceback off codes and may hand a pair over
+	codes = p->codes || p->sys;           // both read the traceback off codes and may hand a pair over
 	if(timing){
 		const auto tm2 = std::chrono::steady_clock::now();
 		fprintf(stderr, "[bsa_align_batch] %zu pairs, mode %d, bandwidth %u: plan %.3f s (workspace %.1f GB, %zu chunks), staging + kernels + copies %.3f s, forward kernel %s\n", n, par->mode & 3, par->bandwidth,
 			std::chrono::duration<double>(tm1 - tm0).count(), (double)c->ws_bytes / 1e9, p->chunks.size(), std::chrono::duration<double>(tm2 - tm1).count(), c->fwd_name.c_str());
 	}
 	bsa_align_plan_destroy(p);
+	}
 	if(rc != BSA_OK || !codes) return rc;
 	for(size_t k = 0; k < n; k++) if(st[k] & BSA_ST_DEVICE){ c->err = "forward pass: a row-segment hand-over timed out (BSA_ST_DEVICE)"; return BSA_E_HIP; }
 	// ---- hand-over: pairs the compact traceback could not decide go through the literal kernels, so that a flag that

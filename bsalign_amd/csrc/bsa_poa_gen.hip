@@ -448,7 +448,7 @@ extern "C" int bsa_poa_graph_gen_supported(const bsa_sweep_params_t *par){
 		if(ge2 < 0 || go2 < 0 || rp->gape1 > rp->gape2) return 0;
 		g = std::max(g, go2 + ge2);
 	}
-	if(m + 3 * g > 64 || n + m + g > 100) return 0;
+	if(m + 3 * g > 64 || n + m + g > 100 || m + 2 * n > 128) return 0;      // (m + 2 n: the head row's seed (min - max) + S stays a byte on a mismatch, bsalign.h:2899-2910)
 	if(std::min((int)rp->X, -g) - 1 - m - g < -100) return 0;
 	return 1;
 }

@@ -1318,7 +1318,7 @@ extern "C" int bsa_poa_graph_supported(const bsa_sweep_params_t *par, uint32_t m
 		if(ge2 < 0 || go2 < 0) return 0;
 		g = std::max(g, go2 + ge2);
 	}
-	if(m + 3 * g > 64 || n + m + g > 100) return 0;
+	if(m + 3 * g > 64 || n + m + g > 100 || m + 2 * n > 128) return 0;      // (m + 2 n: the head row's seed (min - max) + S stays a byte on a mismatch, bsalign.h:2899-2910)
 	if(std::min((int)rp->X, -g) - 1 - m - g < -100) return 0;
 	if((int)(bw / 16) * ge > 60) return 0;
 	for(uint32_t nl = 64; nl >= 8; nl >>= 1)
