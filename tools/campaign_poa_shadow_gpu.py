@@ -1,7 +1,8 @@
 """Randomised shadow campaign for the graph-form POA kernel (run on the GPU box: gpurun -- python tools/campaign_poa_shadow_gpu.py SEED N):
 inside real end_bspoa runs of the reference (oracle/_ref, harness mode 5), read after read, the device's best end cell and every step of
 its walk are compared with what the reference's own align_rd_bspoacore + alignment2graph_bspoa do on the same graph.  Parameter sets are
-drawn from modes x gap models x bandwidths x read lengths / error rates.  BSA_POA_FWD=wf runs the wavefront forward pass instead."""
+drawn from modes x gap models x bandwidths x read lengths / error rates.  BSA_POA_FWD=wf runs the wavefront forward pass instead,
+BSA_POA_FORCE_GEN=1 sends every read through the generic-width kernel (bsa_poa_gen.hip)."""
 import os
 import sys
 
@@ -24,7 +25,7 @@ def main():
     T._attach(lib, ctx)
     tot_reads = tot_steps = bad = declined = 0
     for k in range(n):
-        kw = dict(alnmode=int(rng.integers(3)), bandwidth=int(rng.choice([32, 64, 96, 128, 128, 128, 192, 256])))
+        kw = dict(alnmode=int(rng.integers(3)), bandwidth=int(rng.choice([32, 64, 96, 128, 128, 128, 192, 256, 0, 320, 512])))      # (0 / above 256: every read through the generic-width kernel, as a window's first read always is)
         gaps = int(rng.integers(3))
         if gaps == 0:
             kw.update(O=0, E=-2, Q=0, P=0)
