@@ -1153,10 +1153,16 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 #endif
 		if(pf_R != R_hi) tile_fetch(R_hi, x, pf, false);
 		__syncthreads();
+		if constexpr(TILED){
+			// three dwords a plane: slots 0 .. 2 and 2 EW_WW .. 2 EW_WW + 2 (the window() of this format reads no others)
+			tile[lane][0] = (uint32_t)pf.w[0][0]; tile[lane][1] = (uint32_t)(pf.w[0][0] >> 32); tile[lane][2] = (uint32_t)pf.w[0][1];
+			tile[lane][2 * EW_WW] = (uint32_t)pf.w[1][0]; tile[lane][2 * EW_WW + 1] = (uint32_t)(pf.w[1][0] >> 32); tile[lane][2 * EW_WW + 2] = (uint32_t)pf.w[1][1];
+		} else {
 #pragma unroll
 		for(int w = 0; w < EW_WW; w++){
 			tile[lane][2 * w] = (uint32_t)pf.w[0][w]; tile[lane][2 * w + 1] = (uint32_t)(pf.w[0][w] >> 32);
 			tile[lane][2 * EW_WW + 2 * w] = (uint32_t)pf.w[1][w]; tile[lane][2 * EW_WW + 2 * w + 1] = (uint32_t)(pf.w[1][w] >> 32);
+		}
 		}
 		s_beg[lane] = pf.beg; s_ws[lane] = pf.ws;
 		const uint32_t beg = pf.beg, ws = pf.ws, tb = pf.tb;
