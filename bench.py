@@ -979,13 +979,16 @@ def main():
 
 
 def secondary_lines(args):
-    """`bench.py` with no workload flags also measures the edit path (C3: 32768 x 100 kbp, bandwidth 256) and the POA's sweep + walk (4096 windows x 12 reads x
-    1.5 kbp: programs recorded from the reference's end_bspoa where oracle/_ref exists, else the committed fixture programs) -- each as a run of this very script
+    """`bench.py` with no workload flags also measures the edit path (C3: 32768 x 100 kbp, bandwidth 256), the POA's sweep + walk (4096 windows x 12 reads x
+    1.5 kbp: programs recorded from the reference's end_bspoa where oracle/_ref exists, else the committed fixture programs) and whole-query bands with scores
+    outside the static guard (2048 x 10 kbp, 10,-30,-20,-10) -- each as a run of this very script
     with its own steps, roofline and cpu_baseline, its JSON line embedded under "secondary"."""
     import subprocess
     out = []
+    # (third: `bsalign align -W 0` with scores outside the static exactness guard -- the shape that ran below the CPU until round 6 -- on the checked systolic kernel)
     for extra in (["--workload", "edit", "--steps", "3", "--warmup", "1", "--no-exchange"],
-                  ["--workload", "poa", "--pairs", "4096", "--steps", "5", "--warmup", "1"]):
+                  ["--workload", "poa", "--pairs", "4096", "--steps", "5", "--warmup", "1"],
+                  ["--pairs", "2048", "--length", "10000", "--bw", "-1", "--scoring", "10,-30,-20,-10,0,0", "--steps", "3", "--warmup", "1", "--no-exchange"]):
         t0 = time.perf_counter()
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra, capture_output=True, text=True, timeout=900)
