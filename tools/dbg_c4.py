@@ -13,7 +13,7 @@ reads = P.synth_reads(20240611 & 0xFFFF, 20000, nreads, eps=(0.1,))
 r = P.run_ref_graph(reads, 5, p, record=True, lib=P.ref_poa_trace(), backend="oracle")
 print("bad", r["bad"], "graph reads", r["graph_reads"])
 for k, rd in enumerate(r["recs"]):
-    if "nodes" not in rd or len(rd["nodes"]) < 2 or rd["bandwidth"] > 256 or k < int(os.environ.get("DBG_FROM", "0")):
+    if "nodes" not in rd or len(rd["nodes"]) < 2 or k < int(os.environ.get("DBG_FROM", "0")):
         continue
     cap = 2 * (rd["slen"] + len(rd["nodes"])) + 64
     pr = np.zeros(1, P.WF_PROG)
