@@ -28,6 +28,11 @@
 #include "bsa_common.h"
 #include "bsa_dpp.h"
 #include <algorithm>
+#ifndef XQ_BEGS16
+#define XQ_BEGS16 0              // 1: band offsets leave sixteen rows (one 64-byte line) at a time instead of four (16 bytes at an odd dword).  Measured at C2 with
+                                 // slots at multiples of 256 bytes: WRITE_SIZE 80.0 -> 69.7 GB (= the 69.6 GB the kernel has to store), forward 59.6 -> 60.2 ms (two-piece
+                                 // gaps 123.9 -> 125.5): the partial lines cost traffic, not time, and the kernel is bound by its instructions -- off
+#endif
 
 typedef short xv2s __attribute__((ext_vector_type(2)));
 typedef unsigned short xv2u __attribute__((ext_vector_type(2)));
@@ -280,7 +285,12 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 #else
 	constexpr bool QWIN = !STATIC && PW != 2 && W == 16;      // (measured: two-piece gaps at 251 registers lose 3 % with it, eight cells a half gain nothing)
 #endif
-	constexpr int KD = NQ + 12;                           // dwords per block in the window: 48 bytes of band movement between refills
+	// band offsets leave sixteen rows at a time through four LDS dwords a lane (below, "band offsets"); the window gives them up -- 40 instead of 48 bytes of
+	// band movement between refills -- so that the block's LDS stays what three waves per SIMD allow (one KB more a wave cost 5 % of the launch)
+	constexpr bool BQ16 = XQ_BEGS16 && L == 4 && !EXT;
+	__shared__ uint32_t x_bq[BQ16 ? NWV : 1][BQ16 ? 4 : 1][64];
+	uint32_t *const bqp = &x_bq[(BQ16 && NWV > 1) ? (lt >> 6) : 0][0][lt & 63];
+	constexpr int KD = NQ + ((BQ16 && QWIN) ? 10 : 12);   // dwords per block in the window
 	constexpr uint32_t QOFFMAX = 4u * (uint32_t)(KD - NQ - 1) + 3u;      // the last offset at which dwords k .. k + NQ are all inside
 	static_assert(!QWIN || 4 * KD - W <= BSA_QPAD_TAIL, "the window reads 4 KD - W bytes behind the band's last block: the staged query's padding (bsa_api.hip: qpad = bandwidth + BSA_QPAD_TAIL) must cover it");
 	__shared__ uint32_t x_qwin[(QWIN && !EXT) ? NWV : 1][(QWIN && !EXT) ? 2 * KD : 1][64];
@@ -726,9 +736,26 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		if(act){
 			// band offsets: lane (i mod L) keeps the offset of row i, the group stores them together
 			constexpr uint32_t LM = (uint32_t)(L - 1);
-			if((i & LM) == (uint32_t)jl) begq = (int)rbeg;
 			const bool lastrow = i + 1u == tlen;
+			if constexpr (BQ16){
+				// Four rows of offsets are 16 bytes at an odd dword: stored as they come, every piece is a partial sector that the L2 has written back long
+				// before its neighbours arrive (48 us later).  The lane keeps its last four offsets in LDS slots of its own (slot (row >> 2) & 3) and the
+				// pair stores begs[16 k .. 16 k + 15] -- rows 16 k - 1 .. 16 k + 14, one whole line -- when row 16 k + 14 is done; what is pending at the end of
+				// the pair or of the segment leaves row by row.
+				if((i & 3u) == (uint32_t)jl) bqp[64u * ((i >> 2) & 3u)] = rbeg;
+				if((i & 15u) == 14u || lastrow || i + 1u == row1){
+					const uint32_t pf = (i >= 15u) ? (((i - 15u) & ~15u) + 15u) : 0u;          // first row no earlier flush has taken
+					const int lo = (int)max(row0, pf);
+#pragma unroll
+					for(int sl = 0; sl < 4; sl++){
+						const int row = (int)i - (int)((i - (uint32_t)(4 * sl + jl)) & 15u);
+						if(row >= lo) begs[row + 1] = (int)bqp[64 * sl];
+					}
+				}
+			} else {
+			if((i & LM) == (uint32_t)jl) begq = (int)rbeg;
 			if(((i & LM) == LM || lastrow) && (uint32_t)jl <= (i & LM)) begs[(i & ~LM) + 1u + (uint32_t)jl] = begq;
+			}
 			// H at band position pos of the new row: ubegs of its block + the block's u up to it (getscore, bsalign.h:3187-3197);
 			// meaningful in the lane that owns the block
 			auto score_at = [&](uint32_t pos) -> int {

@@ -488,7 +488,9 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 	bsa_ctx *c = p->ctx;
 	const size_t n = order.size();
 	size_t total = 0, biggest = 0;
-	for(size_t pos = 0; pos < n; pos++){ total += need[pos]; biggest = std::max(biggest, need[pos]); }
+	// (slots start at multiples of 256 bytes -- bsa_begs_bytes; a slot's END, where the walkers leave their CIGAR words, stays where the pair's own need puts it)
+	auto up256 = [](size_t b){ return (b + 255) & ~(size_t)255; };
+	for(size_t pos = 0; pos < n; pos++){ total += up256(need[pos]); biggest = std::max(biggest, up256(need[pos])); }
 	const size_t budget = ctx_ws_budget(c, total);
 	if(biggest > budget){ c->err = "workspace limit too small for one pair"; return BSA_E_NOMEM; }
 	// Both kernels are row-serial per pair, so throughput = pairs in flight / per-pair latency: chunks are made as
@@ -537,11 +539,11 @@ static int plan_chunks(PlanBase *p, const std::vector<uint32_t> &order, const st
 		maxacc = std::max(maxacc, acc);
 	};
 	for(size_t pos = 0; pos < n; pos++){
-		if(pos > first && (acc + need[pos] > cap || (!mix_classes && bwv[pos] != bwv[first]) || pos - first >= cap_pairs)){
+		if(pos > first && (acc + up256(need[pos]) > cap || (!mix_classes && bwv[pos] != bwv[first]) || pos - first >= cap_pairs)){
 			close((uint32_t)pos);
 			first = (uint32_t)pos; acc = 0;
 		}
-		slot[pos] = acc; acc += need[pos]; slot_end[pos] = acc;
+		slot[pos] = acc; slot_end[pos] = acc + need[pos]; acc += up256(need[pos]);
 	}
 	if(n > first) close((uint32_t)n);
 	p->half_bytes = (maxacc + 255) & ~(size_t)255;
@@ -1097,17 +1099,18 @@ static int align_batch_sliced(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes
 	});
 	auto wait_recorded = [&](int want){ for(;;){ const int r = recorded.load(std::memory_order_acquire); if(r < 0 || r >= want) return r; std::this_thread::yield(); } };
 	rc = bsa_align_plan_create(c, qoff, qlen, toff, tlen, nA, par, &pA);
-	if(rc == BSA_OK) rc = bsa_align_plan_create(c, qoff + h, qlen + h, toff + h, tlen + h, nB, par, &pB);
 	t_plan = since();
 	if(rc != BSA_OK){ upl.join(); cleanup(); return rc; }
 	*codes_out = pA->codes || pA->sys;
-	// slice A as soon as its bytes are on their way (a wait on an event that is not recorded yet would be no wait), then slice B behind it on the same
-	// stream: B's kernels wait for B's bytes only
+	// slice A as soon as its plan stands and its bytes are on their way (a wait on an event that is not recorded yet would be no wait); slice B is
+	// planned while A's kernels run and goes behind them on the same stream: B's kernels wait for B's bytes only
 	if(wait_recorded(1) < 0) rc = BSA_E_HIP;
 	SL(hipStreamWaitEvent(c->stream, evA, 0));
 	if(rc == BSA_OK) rc = bsa_align_run(pA, d_seqs, d_out, d_cigA, cigar_cap_words, d_offA, d_st);
 	SL(hipEventRecord(doneA, c->stream));
-	if(rc == BSA_OK && wait_recorded(2) < 0) rc = BSA_E_HIP;
+	if(rc == BSA_OK) rc = bsa_align_plan_create(c, qoff + h, qlen + h, toff + h, tlen + h, nB, par, &pB);
+	if(rc != BSA_OK){ upl.join(); cleanup(); return rc; }
+	if(wait_recorded(2) < 0) rc = BSA_E_HIP;
 	t_join = since();
 	SL(hipStreamWaitEvent(c->stream, evB, 0));
 	if(rc == BSA_OK) rc = bsa_align_run(pB, d_seqs, d_out + nA, d_cigB, cigar_cap_words, d_offB, d_st + nA);
@@ -1137,7 +1140,7 @@ static int align_batch_sliced(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes
 	t_colA = since();
 	if(rc == BSA_OK) collect(doneB, nA, nB, d_offB, d_cigB, totA, &totB);
 	t_colB = since();
-	if(tmg) fprintf(stderr, "[bsa_align_batch] %zu pairs in two slices of %zu and %zu (uploads of %zu and %zu intervals): ms since entry -- buffers %.1f, both plans %.1f, uploads issued %.1f, both runs launched %.1f, slice A back %.1f, slice B back %.1f\n",
+	if(tmg) fprintf(stderr, "[bsa_align_batch] %zu pairs in two slices of %zu and %zu (uploads of %zu and %zu intervals): ms since entry -- buffers %.1f, plan of slice A %.1f, slice A launched + slice B planned + uploads issued %.1f, both runs launched %.1f, slice A back %.1f, slice B back %.1f\n",
 		n, nA, nB, ivA.size(), ivB.size(), t_alloc, t_plan, t_join, t_launch, t_colA, t_colB);
 #undef SL
 	cleanup();

@@ -65,7 +65,9 @@ static inline __host__ __device__ uint32_t bsa_blk_cells(uint32_t W, int pw){ re
 static inline __host__ __device__ uint32_t bsa_blk_bytes(uint32_t W, int pw){ return bsa_blk_cells(W, pw) + 4u; }
 static inline __host__ __device__ uint32_t bsa_tile_rows(uint32_t W, int pw){ uint32_t g = 64u / bsa_blk_bytes(W, pw); return g ? g : 1u; }
 static inline __host__ __device__ uint32_t bsa_tile_bytes(uint32_t W, int pw){ return (bsa_tile_rows(W, pw) * bsa_blk_bytes(W, pw) + 15u) & ~15u; }
-static inline __host__ __device__ size_t bsa_begs_bytes(uint32_t tlen){ return (((size_t)tlen + 2) * 4 + 15) & ~(size_t)15; }
+// (a multiple of 256 bytes, and slots start at multiples of 256 -- bsa_api.hip rounds what a pair needs: a code row, a group of four and a line of sixteen band
+// offsets then never straddle a 64-byte line; with 16-byte rounding three pairs in four had every row across two lines and the L2 wrote some of them back half filled)
+static inline __host__ __device__ size_t bsa_begs_bytes(uint32_t tlen){ return (((size_t)tlen + 2) * 4 + 255) & ~(size_t)255; }
 static inline __host__ __device__ size_t bsa_groups(uint32_t tlen, uint32_t G){ return ((size_t)tlen + 1 + G - 1) / G + 1; }   // + 1 spare group
 static inline __host__ __device__ size_t bsa_slot_bytes(uint32_t tlen, uint32_t W, int pw){
 	return bsa_begs_bytes(tlen) + bsa_groups(tlen, bsa_tile_rows(W, pw)) * 16 * (size_t)bsa_tile_bytes(W, pw);

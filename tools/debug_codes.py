@@ -31,7 +31,7 @@ def run(pairs, par, which, W):
     slots = []
     for k in range(n):
         tl = int(tlen[k])
-        nb = (((tl + 2) * 4 + 15) & ~15) + ((tl + 3) // 4 * 4) * 64 * CW
+        nb = (((tl + 2) * 4 + 255) & ~255) + ((tl + 3) // 4 * 4) * 64 * CW
         slots.append(plan.debug_slot(k, nb).copy())
     return d_out.cpu().numpy().reshape(n, 10), d_st.cpu().numpy(), slots
 
@@ -66,7 +66,7 @@ def main():
         if not np.array_equal(ga, gb):
             r = int(np.nonzero(ga != gb)[0][0])
             print("  begs first differ at index", r, "(row", r - 1, ") pk", ga[r:r + 4], "x", gb[r:r + 4], "last (score) pk", ga[tl + 1], "x", gb[tl + 1])
-        bb = ((tl + 2) * 4 + 15) & ~15
+        bb = ((tl + 2) * 4 + 255) & ~255
         # tiled rows (bsa_common.h): groups of four rows, inside a group [block][row % 4][CW dwords]
         def untile(x):
             g = x[bb:].view(np.uint32).reshape(-1, 16, 4, CW)

@@ -43,7 +43,7 @@ def main():
         blk = cells + 4
         tg = max(64 // blk, 1)
         tileb = (tg * blk + 15) & ~15
-        begs_bytes = ((tl + 2) * 4 + 15) & ~15
+        begs_bytes = ((tl + 2) * 4 + 255) & ~255
         ngroups = (tl + 1 + tg - 1) // tg + 1
         nbytes = begs_bytes + ngroups * 16 * tileb
         slot = plan.debug_slot(k, nbytes)
