@@ -71,6 +71,7 @@ struct bsa_pog {
 	bsa_poa_result_t res;
 	bsa_pog_read_t rd;
 	uint32_t cur_rid = 0, cur_rbeg = 0;
+	bool realn = false;                               // bsa_pog_cut ran: the next selection is over every read (bspoa.h:2636-2642)
 	int stage = 0;                                    // 0 idle, 1 selected, 2 placed, 3 program built, 4 run
 	double secs[5] = {0, 0, 0, 0, 0};
 
@@ -138,15 +139,70 @@ struct bsa_pog {
 		chg_edge(u, v, 1);
 		flags[u] |= BSA_POG_F_RDD; flags[v] |= BSA_POG_F_RDC;
 	}
-	// every edge of header `a` on one side moves to header `b`, coverage added to what b already has
-	// (_mov_node_edges_bspoacore with BSPOA_EMOVTYPE_MOVALL, bspoa.h:689-735: the changes are listed first, then applied in list order)
-	void move_edges(uint32_t a, uint32_t b, int dir){
-		std::vector<std::pair<uint32_t, uint32_t>> lst;          // (other end, coverage)
-		for(uint32_t e = dir ? in[a] : out[a]; e; e = dir ? edges[e].next_in : edges[e].next_out) lst.emplace_back(dir ? edges[e].from : edges[e].to, edges[e].cov);
-		for(auto &x : lst){
-			if(dir){ chg_edge(x.first, a, -(int)x.second); chg_edge(x.first, b, (int)x.second); }
-			else { chg_edge(a, x.first, -(int)x.second); chg_edge(b, x.first, (int)x.second); }
+	// _mov_node_edges_bspoacore (bspoa.h:683-735): the edges of header `a` on one side (dir 0: out, 1: in) are split between `a` and header `b`.  movtype is the
+	// reference's nibble matrix: what of an edge's coverage stays (column 1) or moves (column 0), for ordinary edges (row 0) and for the edge to / from the
+	// ring of `spec` (row 1) -- F: all of it, E: all but one, 1: one, 0: nothing.  MOVALL 0x0F0F, KPTONE 0x1E0F (the spec edge keeps one), MOVONE 0xE1F0 (one
+	// of the spec edge moves, everything else stays).  The changes are listed first, then applied in list order.
+	static constexpr int MOVALL = 0x0F0F, KPTONE = 0x1E0F, MOVONE = 0xE1F0;
+	void move_edges(uint32_t a, uint32_t b, int dir, uint32_t spec = 0xFFFFFFFFu, int movtype = MOVALL){
+		const uint32_t spec_node = spec < nnodes() ? header[spec] : spec;
+		struct Chg { uint32_t other; int keep_delta, moved; };
+		std::vector<Chg> lst;
+		for(uint32_t e = dir ? in[a] : out[a]; e; e = dir ? edges[e].next_in : edges[e].next_out){
+			const uint32_t other = dir ? edges[e].from : edges[e].to;
+			const int ecov = (int)edges[e].cov;
+			int covs[4] = {other == spec_node ? 0 : ecov, other == spec_node ? ecov : 0, 0, 0};
+			for(int i = 0; i < 2; i++) for(int j = 0; j < 2; j++){
+				switch((movtype >> (4 * (i * 2 + j))) & 0xF){
+					case 0xF: covs[3 - j] += covs[i]; break;
+					case 0xE: covs[3 - j] += std::max(covs[i] - 1, 0); break;
+					case 0x1: covs[3 - j] += std::min(covs[i], 1); break;
+					default: break;
+				}
+			}
+			lst.push_back({other, covs[2] - ecov, covs[3]});
 		}
+		for(const Chg &x : lst){
+			if(dir){ chg_edge(x.other, a, x.keep_delta); chg_edge(x.other, b, x.moved); }
+			else { chg_edge(a, x.other, x.keep_delta); chg_edge(b, x.other, x.moved); }
+		}
+	}
+	// disconnect_rdnode_bspoa (bspoa.h:640-649)
+	void disconnect_rdnode(uint32_t r, int p){
+		const uint32_t u = rdnode(r, p - 1);
+		if(!(flags[u] & BSA_POG_F_RDD)) return;
+		const uint32_t v = rdnode(r, p);
+		chg_edge(u, v, -1);
+		flags[u] &= (uint8_t)~BSA_POG_F_RDD; flags[v] &= (uint8_t)~BSA_POG_F_RDC;
+	}
+	// cut_rdnode_bspoa(.., BSPOA_RDNODE_CUTALL) (bspoa.h:741-795): the base leaves its ring -- taking along one unit of the two edges that chain it to its
+	// read's neighbours, or, when it was the ring's representative, leaving everything but those to the ring's new representative (its former `prev`) --
+	// and is unchained from its read
+	void cut_rdnode(uint32_t r, int p){
+		const uint32_t u = rdnode(r, p);
+		const uint32_t nb[2] = {u + 1u, u - 1u};
+		const uint32_t h0 = header[u], h1 = prev[u];
+		const uint16_t nodecov = cov[h0];
+		if(next[u] != u){
+			next[prev[u]] = next[u]; prev[next[u]] = prev[u];
+			next[u] = prev[u] = header[u] = u;
+			uint32_t x;
+			if(h0 == u){
+				x = h1;
+				for(;;){ header[x] = h1; if(next[x] == h1) break; x = next[x]; }
+				x = h1;
+				move_edges(u, x, 0, nb[0], (flags[u] & BSA_POG_F_RDD) ? KPTONE : MOVALL);
+				move_edges(u, x, 1, nb[1], (flags[u] & BSA_POG_F_RDC) ? KPTONE : MOVALL);
+			} else {
+				x = h0;
+				if(flags[u] & BSA_POG_F_RDD) move_edges(x, u, 0, nb[0], MOVONE);
+				if(flags[u] & BSA_POG_F_RDC) move_edges(x, u, 1, nb[1], MOVONE);
+			}
+			cov[header[x]] = (uint16_t)(nodecov - 1);
+			cov[header[u]] = 1;
+		}
+		disconnect_rdnode(r, p);
+		disconnect_rdnode(r, p + 1);
 	}
 	// merge_nodes_bspoa (bspoa.h:797-894): the rings of n1 and n2 become one; the representative is the ring with more bases, the lower read on a tie
 	uint32_t merge_nodes(uint32_t n1, uint32_t n2){
@@ -340,19 +396,31 @@ extern "C" int bsa_pog_get_cpos(const bsa_pog_t *g, const uint32_t *idx, int32_t
 }
 extern "C" void bsa_pog_seconds(const bsa_pog_t *g, double out[5]){ if(g && out) for(int k = 0; k < 5; k++) out[k] = g->secs[k]; }
 
+// ---- the realn entry of align_rd_bspoa (bspoa.h:2626-2630): the stretch leaves the graph base by base
+extern "C" int bsa_pog_cut(bsa_pog_t *g, uint32_t rid, uint32_t rbeg, uint32_t rlen){
+	return guarded([&]() -> int {
+	if(!g || rid >= g->ndoff.size() || (uint64_t)rbeg + rlen > g->rdlen[rid] || g->stage != 0) return BSA_E_ARG;
+	if(rid) for(uint32_t p = rbeg; p < rbeg + rlen; p++) g->cut_rdnode(rid, (int)p);          // (read 0, the backbone, stays: `if(realn && rid)`)
+	g->realn = true;
+	return BSA_OK;
+	});
+}
+
 // ---- P2: sel_nodes_bspoa (bspoa.h:1887-2020)
 extern "C" int bsa_pog_select(bsa_pog_t *g, uint32_t rid, uint32_t rbeg, uint32_t rlen, bsa_pog_read_t *rd, const uint32_t **sel){
 	return guarded([&]() -> int {
 	if(!g || rid >= g->ndoff.size() || (uint64_t)rbeg + rlen > g->rdlen[rid]) return BSA_E_ARG;
 	if(g->stage != 0) return BSA_E_ARG;
-	// a read already chained into the graph would have to be cut out first (realn, cut_rdnode_bspoa bspoa.h:741-795): not implemented
-	for(uint32_t p = rbeg; p <= rbeg + rlen; p++) if(g->flags[g->rdnode(rid, (int)p)] & BSA_POG_F_RDC) return BSA_E_UNSUPPORTED;
+	// a stretch that is still chained into the graph has to be cut out first (bsa_pog_cut: the realn entry of align_rd_bspoa, bspoa.h:2626-2630)
+	for(uint32_t p = rbeg; p <= rbeg + rlen; p++) if(g->flags[g->rdnode(rid, (int)p)] & BSA_POG_F_RDC) return BSA_E_ARG;
 	const double t0 = now_s();
 	g->grow_scratch();
 	const uint32_t nreads = (uint32_t)g->ndoff.size();
 	const uint32_t nmsa = g->par.seqcore ? std::min<uint32_t>(nreads, (uint32_t)g->par.seqcore) : nreads;
-	const uint32_t r0 = g->par.nrec ? (uint32_t)std::max(0, (int)rid - g->par.nrec - 1) : 0u;
-	const uint32_t r1 = g->par.nrec ? rid : 0xFFFFu;                         // reads [r0, r1) (bspoa.h:2636-2642)
+	const bool recent = g->par.nrec && !g->realn;                            // (a re-aligned stretch is selected against every read)
+	g->realn = false;
+	const uint32_t r0 = recent ? (uint32_t)std::max(0, (int)rid - g->par.nrec - 1) : 0u;
+	const uint32_t r1 = recent ? rid : 0xFFFFu;                              // reads [r0, r1) (bspoa.h:2636-2642)
 	const uint32_t nhead = g->header[g->rdnode(rid, (int)rbeg - 1)], ntail = g->header[g->rdnode(rid, (int)(rbeg + rlen))];
 	for(uint32_t s : g->sels) g->sel_bit[s] = 0;
 	g->sels.clear(); g->todels.clear();
@@ -430,6 +498,37 @@ extern "C" int bsa_pog_place(bsa_pog_t *g, const bsa_pog_guide_t *gd, const int3
 	int tb = 0, te = (int)reflen;
 	const uint32_t *cgs = nullptr; uint32_t ncg = 0;
 	uint32_t x = 0, y = 0;
+	const bool ends = g->par.bwtrigger && g->rd.nhead == g->HEAD && g->rd.ntail == g->TAIL;
+	if(ends && gd && gd->sam && gd->ncigar){
+		// refmode: the read's SAM CIGAR against the backbone places the band (bspoa.h:2055-2085).  Leading D / N / H and I / S runs are margins; so are the
+		// trailing ones -- where the reference adds the length of the word BEHIND the one it tests (`cgs[i]` for `cgs[i - 1]`, bspoa.h:2073): kept, so
+		// cigar[ncigar] must be readable (the reference reads the next read's first word, or whatever follows, there)
+		if(!gd->cigar) return BSA_E_ARG;
+		const uint32_t *c0 = gd->cigar; uint32_t nc = gd->ncigar, i;
+		x = y = 0;
+		for(i = 0; i < nc; i++){
+			const uint32_t op = c0[i] & 0xfu;
+			if(op == 2u || op == 3u || op == 5u) y += c0[i] >> 4;
+			else if(op == 1u || op == 4u) x += c0[i] >> 4;
+			else break;
+		}
+		c0 += i; nc -= i;
+		g->rd.qb = x; tb = (int)y;
+		x = y = 0;
+		for(i = nc; i; i--){
+			const uint32_t op = c0[i - 1] & 0xfu;
+			if(op == 2u || op == 3u || op == 5u) y += c0[i - 1] >> 4;
+			else if(op == 1u || op == 4u) x += c0[i] >> 4;
+			else break;
+		}
+		nc = i;
+		g->rd.qe = g->rd.qlen - x; g->rd.slen = g->rd.qe - g->rd.qb;
+		te = (int)(reflen - y);                                                   // (g->backbone - y: the caller passes the backbone's length as reflen in refmode)
+		x = 0; y = (uint32_t)tb;
+		tb = (tb >= (int)(bw / 2)) ? tb - (int)(bw / 4) : 0;
+		te = (reflen - (uint32_t)te >= bw / 2) ? te + (int)(bw / 4) : (int)reflen;
+		cgs = c0; ncg = nc;
+	} else
 	if(bsa_pog_needs_guide(g, reflen)){
 		if(!gd || !gd->have) return BSA_E_ARG;
 		g->rd.qb = (uint32_t)gd->qb; g->rd.qe = (uint32_t)gd->qe; g->rd.slen = g->rd.qe - g->rd.qb;

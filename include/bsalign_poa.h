@@ -22,8 +22,9 @@
  * What stays outside (out of scope): the MSA column order and the running consensus (msa_bspoa,
  * simple_cns_bspoa) -- a caller supplies, per read, the column position `cpos` of the selected nodes and the guide alignment of
  * the read against its consensus (a seqalign_result_t + CIGAR: kmer_striped_seqedit_pairwise, or this library's
- * bsa_kmer_edit_batch).  refmode (a reference sequence with SAM CIGARs as read 0, bspoa.h:2055-2085) and re-alignment of a
- * read already in the graph (realn, cut_rdnode_bspoa) are not implemented: bsa_pog_select returns BSA_E_UNSUPPORTED.
+ * bsa_kmer_edit_batch).  refmode (read 0 a reference sequence, the other reads with their SAM CIGARs against it, bspoa.h:2039-2085):
+ * the caller passes the backbone's length as the guide's `reflen` and the read's SAM CIGAR with `sam` set.  Re-alignment of a stretch that is
+ * already in the graph (the realn entry of align_rd_bspoa, bspoa.h:2626-2630): bsa_pog_cut, then the five steps as for a new read.
  *
  * Plain C types only.  Every function returns BSA_OK (0) or a negative BSA_E_* code of bsalign_hip.h; no C++ exception leaves
  * the library (a failed host allocation is BSA_E_NOMEM).  After BSA_E_NOMEM from bsa_pog_apply the graph may hold half of a
@@ -83,6 +84,8 @@ typedef struct {
 	int32_t  qb, qe, tb, te;      /* seqalign_result_t of the read (query) against the consensus (target) */
 	const uint32_t *cigar;        /* its CIGAR words, len << 4 | op */
 	uint32_t ncigar;
+	int32_t  sam;                 /* refmode: `cigar` is the read's SAM CIGAR against the backbone (ops M I D N S H = X: 0 1 2 3 4 5 7 8), `have` and qb .. te are
+	                                 not read, reflen = the backbone's length, and cigar[ncigar] must be readable (bspoa.h:2073 reads one word behind the one it tests) */
 } bsa_pog_guide_t;
 
 /* what select / place decided for the read (g->qb, g->qe, g->slen, g->bandwidth, bspoa.h:2035-2110) */
@@ -115,6 +118,10 @@ int  bsa_pog_export(const bsa_pog_t *g, uint32_t *nnodes, uint32_t *nreads, uint
  * [max(0, rid - nrec - 1), rid) between the rings of its two ends --, in-degrees, auxiliary edges that make every selected node
  * reachable.  *sel (owned by g, valid until the next select) lists the selected headers in the reference's order. */
 int  bsa_pog_select(bsa_pog_t *g, uint32_t rid, uint32_t rbeg, uint32_t rlen, bsa_pog_read_t *rd, const uint32_t **sel);
+/* the realn entry of align_rd_bspoa (bspoa.h:2626-2630, cut_rdnode_bspoa :741-795): the bases [rbeg, rbeg + rlen) of a read that is already in the graph
+ * leave their rings (a ring's representative hands its edges to the next member) and are unchained; the bsa_pog_select that follows takes every read of
+ * the window into the selection, whatever nrec says (bspoa.h:2636-2642).  Read 0, the backbone, is never cut. */
+int  bsa_pog_cut(bsa_pog_t *g, uint32_t rid, uint32_t rbeg, uint32_t rlen);
 /* does prepare_rd_align consult a guide alignment for this read (bspoa.h:2054, 2086)?  reflen = the consensus' length */
 int  bsa_pog_needs_guide(const bsa_pog_t *g, uint32_t reflen);
 /* P3 prepare_rd_align_bspoa without its profiles and row arena (the device builds its own): band width, [qb, qe), every selected

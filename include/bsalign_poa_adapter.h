@@ -503,9 +503,11 @@ static inline int bsa_poa_pog_sync(BSPOA *g, BSPOAPar *par, bsa_poa_adapter_t *a
 
 /* Drop-in for the body of align_rd_bspoa (bspoa.h:2632-2657) between `if(rlen == 0) return rs` and its return: selection, band placement, DP,
  * walk and surgery through the library's own graph (bsa_pog_*), then the same steps applied to the reference's graph so that msa_bspoa / cns_bspoa
- * go on from it.  Returns 1 with *out filled, or 0 when the read has to take the reference's own path (refmode, a shape the kernel declines):
- * the caller goes on with sel_nodes_bspoa etc. and the mirror is re-imported before the next read. */
-static inline int bsa_poa_align_rd_pog(BSPOA *g, BSPOAPar *par, u2i rid, int rbeg, int rlen, bsa_poa_adapter_t *ad, seqalign_result_t *out){
+ * go on from it.  realn: align_rd_bspoa's own flag -- the stretch was just cut out of the reference's graph (bspoa.h:2626-2630) and is cut out of the
+ * mirror here (bsa_pog_cut).  refmode: the band comes from the read's SAM CIGAR when one was pushed with it (bspoa.h:2055-2085).  Returns 1 with *out
+ * filled, or 0 when the read has to take the reference's own path (a shape the kernel declines): the caller goes on with sel_nodes_bspoa etc. and
+ * the mirror is re-imported before the next read. */
+static inline int bsa_poa_align_rd_pog(BSPOA *g, BSPOAPar *par, int realn, u2i rid, int rbeg, int rlen, bsa_poa_adapter_t *ad, seqalign_result_t *out){
 	bsa_pog_read_t rd;
 	bsa_pog_guide_t gd;
 	bsa_poa_result_t res;
@@ -518,9 +520,10 @@ static inline int bsa_poa_align_rd_pog(BSPOA *g, BSPOAPar *par, u2i rid, int rbe
 	u4i k, nhead, ntail;
 	int rc, col, x;
 	double t0, t1;
-	if(!ad->use_pog || ad->run_graph == NULL || g->par->refmode) return 0;
+	if(!ad->use_pog || ad->run_graph == NULL) return 0;
 	t0 = bsa_poa_now();
 	if(bsa_poa_pog_sync(g, par, ad) != BSA_OK){ ad->pog_stale = 1; return 0; }
+	if(realn && bsa_pog_cut(ad->pog, rid, (uint32_t)rbeg, (uint32_t)rlen) != BSA_OK){ ad->pog_stale = 1; ad->pog_declined ++; return 0; }          /* (a mirror re-imported just now holds the stretch cut already: cutting it again changes nothing) */
 	t1 = bsa_poa_now(); ad->pog_seconds[0] += t1 - t0; t0 = t1;
 	rc = bsa_pog_select(ad->pog, rid, (uint32_t)rbeg, (uint32_t)rlen, &rd, &sel);
 	if(rc != BSA_OK){ ad->pog_stale = 1; ad->pog_declined ++; return 0; }
@@ -531,7 +534,11 @@ static inline int bsa_poa_align_rd_pog(BSPOA *g, BSPOAPar *par, u2i rid, int rbe
 	bitseq_basebank(g->seqs->rdseqs, g->seqs->rdoffs->buffer[rid] + rbeg, g->qlen, g->qseq->buffer);
 	g->qseq->size = g->qlen;
 	memset(&gd, 0, sizeof(gd));
-	gd.reflen = (uint32_t)g->cns->size;
+	gd.reflen = g->par->refmode ? (uint32_t)g->backbone : (uint32_t)g->cns->size;
+	if(g->par->refmode && g->cges->buffer[rid] > g->cgbs->buffer[rid]){
+		/* (bspoa.h:2073 reads the word behind the read's CIGAR; so does the library: the caller of push_bspoacore keeps one readable, as for the reference) */
+		gd.sam = 1; gd.cigar = g->cigars->buffer + g->cgbs->buffer[rid]; gd.ncigar = (uint32_t)(g->cges->buffer[rid] - g->cgbs->buffer[rid]);
+	} else
 	if(bsa_pog_needs_guide(ad->pog, gd.reflen)){
 		if(par->ksz) krs = kmer_striped_seqedit_pairwise(par->ksz, g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, g->memp, g->stack, 0);
 		else krs = striped_seqedit_pairwise(g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, par->alnmode, 0, g->memp, g->stack, 0);

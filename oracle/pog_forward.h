@@ -34,6 +34,7 @@ POG_FWD(int, bsa_pog_run, (bsa_pog_t *a, bsa_pog_backend_fn b, void *c, bsa_poa_
 POG_FWD(int, bsa_pog_apply, (bsa_pog_t *a, bsa_result_t *b, uint32_t *c), (a, b, c), BSA_E_UNSUPPORTED)
 POG_FWD(int, bsa_pog_aux_edges, (const bsa_pog_t *a, const uint64_t **b, size_t *c), (a, b, c), BSA_E_UNSUPPORTED)
 POG_FWD(int, bsa_pog_abort, (bsa_pog_t *a), (a), BSA_E_UNSUPPORTED)
+POG_FWD(int, bsa_pog_cut, (bsa_pog_t *a, uint32_t b, uint32_t c, uint32_t d), (a, b, c, d), BSA_E_UNSUPPORTED)
 POG_FWD(int, bsa_pog_set_cpos, (bsa_pog_t *a, const uint32_t *b, const int32_t *c, size_t d), (a, b, c, d), BSA_E_UNSUPPORTED)
 POG_FWD(int, bsa_pog_get_cpos, (const bsa_pog_t *a, const uint32_t *b, int32_t *c, size_t d), (a, b, c, d), BSA_E_UNSUPPORTED)
 POG_FWDV(bsa_pog_seconds, (const bsa_pog_t *a, double *b), (a, b))
@@ -44,7 +45,7 @@ static int pog_forward_attach(void *handle){
 #define POG_GET(name) do { pogp_##name = (pogfn_##name)dlsym(handle, #name); if(pogp_##name == NULL) missing ++; } while(0)
 	POG_GET(bsa_pog_create); POG_GET(bsa_pog_destroy); POG_GET(bsa_pog_clear); POG_GET(bsa_pog_add_read); POG_GET(bsa_pog_import); POG_GET(bsa_pog_export);
 	POG_GET(bsa_pog_select); POG_GET(bsa_pog_needs_guide); POG_GET(bsa_pog_place); POG_GET(bsa_pog_program); POG_GET(bsa_pog_run); POG_GET(bsa_pog_apply);
-	POG_GET(bsa_pog_aux_edges); POG_GET(bsa_pog_abort); POG_GET(bsa_pog_set_cpos); POG_GET(bsa_pog_get_cpos); POG_GET(bsa_pog_seconds);
+	POG_GET(bsa_pog_aux_edges); POG_GET(bsa_pog_abort); POG_GET(bsa_pog_cut); POG_GET(bsa_pog_set_cpos); POG_GET(bsa_pog_get_cpos); POG_GET(bsa_pog_seconds);
 #undef POG_GET
 	return missing;
 }

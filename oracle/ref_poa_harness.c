@@ -162,6 +162,10 @@ typedef struct {
 	/* record_programs & 4 (mode 5): the flat graph BEFORE every aligned read with what the reference then decided (tests/golden/make_golden_poa_pog.py) */
 	uint8_t *snap; size_t nsnap, capsnap;
 	uint64_t *snapoff; size_t nsnaprec, capsnaprec;
+	/* refmode: the reads' SAM CIGARs against read 0 (read k: cigs[coffs[k] .. coffs[k + 1])), pushed with the reads; realn_pass (mode 8): after the first
+	 * stage every aligned read has a stretch re-aligned through the realn entry of align_rd_bspoa (1: its middle half, 2: the whole read) */
+	const uint32_t *cigs; const uint64_t *coffs;
+	int realn_pass;
 } ref_poa_t;
 
 /* one snapshot record: 20 x u64 header [nnodes, nreads, nedges, ncigar, nsel, naux, head, tail, guide.have, qb, qe, tb, te, reflen, bandwidth, slen, rd.qb, rd.qe, rid, rlen]
@@ -228,6 +232,10 @@ void ref_poa_destroy(void *vp){
 	free(p->gnodes); free(p->gedges); free(p->gcands); free(p->gtrace); free(p->cur_trace); free(p->snap); free(p->snapoff);
 	free(p);
 }
+
+void ref_poa_set_refmode(void *vp, int refmode){ ((ref_poa_t*)vp)->g->par->refmode = refmode; }
+void ref_poa_set_cigars(void *vp, const uint32_t *cigs, const uint64_t *coffs){ ((ref_poa_t*)vp)->cigs = cigs; ((ref_poa_t*)vp)->coffs = coffs; }
+void ref_poa_set_realn_pass(void *vp, int how){ ((ref_poa_t*)vp)->realn_pass = how; }
 
 static void record_read(ref_poa_t *p, seqalign_result_t rs, int mismatch, uint64_t rows_hash){
 	BSPOA *g = p->g;
@@ -311,11 +319,11 @@ static int graphs_equal(BSPOA *g, bsa_pog_t *pog, uint64_t *nn, uint64_t *ne){
 	return ok;
 }
 
-static seqalign_result_t poa_align_read_shadow_pog(ref_poa_t *p, u2i rid){
+/* one read (realn 0: the whole read rid, rbeg = 0) or one stretch of a read that is already in the graph (realn 1: cut out of both graphs first, bspoa.h:2626-2630) */
+static seqalign_result_t poa_align_read_shadow_pog(ref_poa_t *p, u2i rid, int rbeg, int rlen, int realn){
 	BSPOA *g = p->g;
 	BSPOAPar *par = g->par;
 	seqalign_result_t rs, krs;
-	const int rlen = g->seqs->rdlens->buffer[rid];
 	bsa_pog_read_t rd;
 	bsa_pog_guide_t gd;
 	const uint32_t *sel = NULL;
@@ -336,12 +344,20 @@ static seqalign_result_t poa_align_read_shadow_pog(ref_poa_t *p, u2i rid){
 	/* ---- the library's selection, then the reference's */
 	if(bsa_poa_pog_sync(g, par, &p->ad) != BSA_OK) mismatch |= 512;
 	if(p->ad.pog_imports > p->ad.pog_declined) mismatch |= 512;            /* the mirror is only ever re-imported after a read the kernel declined (a whole-read band above 256 columns: a window's first read) */
-	rc = mismatch ? BSA_E_ARG : bsa_pog_select(p->ad.pog, rid, 0, (uint32_t)rlen, &rd, &sel);
+	if(realn){
+		int i;
+		if(rid) for(i = rbeg; i < rbeg + rlen; i++) cut_rdnode_bspoa(g, rid, i, BSPOA_RDNODE_CUTALL);
+		if(!mismatch){
+			if(bsa_pog_cut(p->ad.pog, rid, (uint32_t)rbeg, (uint32_t)rlen) != BSA_OK) mismatch |= 512;
+			else if(!graphs_equal(g, p->ad.pog, &p->pog_checked[4], &p->pog_checked[5])) mismatch |= 1024;          /* the two graphs after the cut */
+		}
+	}
+	rc = mismatch ? BSA_E_ARG : bsa_pog_select(p->ad.pog, rid, (uint32_t)rbeg, (uint32_t)rlen, &rd, &sel);
 	if(rc != BSA_OK) mismatch |= 512;
-	head = get_rdnode_bspoa(g, rid, -1)->header;
-	tail = get_rdnode_bspoa(g, rid, rlen)->header;
-	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
-	sel_nodes_bspoa(g, head, tail, rfirst, par->nrec ? rid : MAX_U2);
+	head = get_rdnode_bspoa(g, rid, rbeg - 1)->header;
+	tail = get_rdnode_bspoa(g, rid, rbeg + rlen)->header;
+	rfirst = (!realn && par->nrec) ? num_max(0, Int(rid) - par->nrec - 1) : 0;
+	sel_nodes_bspoa(g, head, tail, rfirst, (!realn && par->nrec) ? rid : MAX_U2);
 	if(!(mismatch & 512)){
 		if(rd.nhead != head || rd.ntail != tail || rd.nsel != g->sels->size) mismatch |= 16;
 		else for(k = 0; k < g->sels->size; k++) if(sel[k] != g->sels->buffer[k]){ mismatch |= 16; break; }
@@ -350,9 +366,13 @@ static seqalign_result_t poa_align_read_shadow_pog(ref_poa_t *p, u2i rid){
 	/* ---- the guide alignment (the same call prepare_rd_align_bspoa makes, bspoa.h:2087-2091), the library's placement, then the reference's */
 	if(!(mismatch & 512)){
 		clear_and_encap_u1v(g->qseq, (u4i)rlen);
-		bitseq_basebank(g->seqs->rdseqs, g->seqs->rdoffs->buffer[rid], (u4i)rlen, g->qseq->buffer);
+		bitseq_basebank(g->seqs->rdseqs, g->seqs->rdoffs->buffer[rid] + rbeg, (u4i)rlen, g->qseq->buffer);
 		g->qseq->size = (u4i)rlen;
-		gd.reflen = (uint32_t)g->cns->size;
+		gd.reflen = par->refmode ? (uint32_t)g->backbone : (uint32_t)g->cns->size;
+		if(par->refmode && g->cges->buffer[rid] > g->cgbs->buffer[rid]){
+			/* refmode: the read's SAM CIGAR places the band (bspoa.h:2055-2085); the word behind it is readable (ref_poa_run) */
+			gd.sam = 1; gd.cigar = g->cigars->buffer + g->cgbs->buffer[rid]; gd.ncigar = (uint32_t)(g->cges->buffer[rid] - g->cgbs->buffer[rid]);
+		} else
 		if(bsa_pog_needs_guide(p->ad.pog, gd.reflen)){
 			if(par->ksz) krs = kmer_striped_seqedit_pairwise(par->ksz, g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, g->memp, g->stack, 0);
 			else krs = striped_seqedit_pairwise(g->qseq->buffer, g->qseq->size, g->cns->buffer, g->cns->size, par->alnmode, 0, g->memp, g->stack, 0);
@@ -365,7 +385,7 @@ static seqalign_result_t poa_align_read_shadow_pog(ref_poa_t *p, u2i rid){
 		rc = bsa_pog_place(p->ad.pog, &gd, cps, &rd);
 		if(rc != BSA_OK) mismatch |= 512;
 	}
-	prepare_rd_align_bspoa(g, par, head, tail, rid, 0, rlen);
+	prepare_rd_align_bspoa(g, par, head, tail, rid, rbeg, rbeg + rlen);
 	if(!(mismatch & 512)){
 		int32_t *rp = (int32_t*)malloc(((size_t)rd.nsel + 1) * sizeof(int32_t));
 		if(rd.bandwidth != g->bandwidth || rd.qlen != g->qlen || rd.slen != g->slen || rd.qb != g->qb || rd.qe != g->qe) mismatch |= 32;
@@ -395,8 +415,8 @@ static seqalign_result_t poa_align_read_shadow_pog(ref_poa_t *p, u2i rid){
 	} else if(!(mismatch & 512)){ bsa_pog_abort(p->ad.pog); p->ad.pog_stale = 1; p->ad.pog_declined ++; }
 	if(lib_ok) p->ad.pog_reads ++;
 	score = bsa_poa_align_rd_core(g, par, rid, head, tail, &p->ad);
-	if(p->ad.have_trace) rs = bsa_poa_apply_trace(g, par, rid, 0, head, tail, &p->ad);
-	else rs = alignment2graph_bspoa(g, par, rid, 0, head, tail, g->maxidx, g->maxoff, NULL);
+	if(p->ad.have_trace) rs = bsa_poa_apply_trace(g, par, rid, (u4i)rbeg, head, tail, &p->ad);
+	else rs = alignment2graph_bspoa(g, par, rid, (u4i)rbeg, head, tail, g->maxidx, g->maxoff, NULL);
 	rs.qb += g->qb; rs.qe += g->qb; rs.score = score;
 	for(k=0;k<g->todels->size;k++){
 		chg_edge_bspoa(g, ref_bspoanodev(g->nodes, g->todels->buffer[k] >> 32), ref_bspoanodev(g->nodes, g->todels->buffer[k] & MAX_U4), -1, NULL);
@@ -431,9 +451,9 @@ static seqalign_result_t poa_align_read(ref_poa_t *p, u2i rid){
 	if(rlen == 0) return rs;
 	if(p->mode == 9 || p->mode == 10){
 		/* the product's path, as the patched align_rd_bspoa takes it */
-		if(bsa_poa_align_rd_pog(g, par, rid, 0, rlen, &p->ad, &rs)){ record_read(p, rs, 0, 0); return rs; }
+		if(bsa_poa_align_rd_pog(g, par, 0, rid, 0, rlen, &p->ad, &rs)){ record_read(p, rs, 0, 0); return rs; }
 	}
-	if(p->mode == 8) return poa_align_read_shadow_pog(p, rid);
+	if(p->mode == 8) return poa_align_read_shadow_pog(p, rid, 0, rlen, 0);
 	head = get_rdnode_bspoa(g, rid, -1)->header;
 	tail = get_rdnode_bspoa(g, rid, rlen)->header;
 	rfirst = par->nrec ? num_max(0, Int(rid) - par->nrec - 1) : 0;
@@ -603,6 +623,33 @@ static void poa_finish(ref_poa_t *p){
 		poa_align_read(p, rid);
 		g->nrds ++;
 	}
+	if(p->mode == 8 && p->realn_pass){
+		/* the realn entry of align_rd_bspoa (the reference's own caller of it, remsa_lsps_bspoa bspoa.h:5463-5556, is compiled out of main.c): a stretch of
+		 * every aligned read is cut out of the graph and aligned again, against every read of the window */
+		for(rid=1;rid<g->nmsa;rid++){
+			const int len = (int)g->seqs->rdlens->buffer[rid];
+			const int rb = p->realn_pass == 2 ? 0 : len / 4, rl = p->realn_pass == 2 ? len : len / 2;
+			if(rl > 0) poa_align_read_shadow_pog(p, rid, rb, rl, 1);
+		}
+	}
+	if(p->mode != 8 && p->realn_pass){
+		/* the same pass outside the shadow: the product's path (modes 9 / 10: the patched align_rd_bspoa -- the reference's cut, then bsa_poa_align_rd_pog with
+		 * its realn flag) or the untouched reference function */
+		for(rid=1;rid<g->nmsa;rid++){
+			const int len = (int)g->seqs->rdlens->buffer[rid];
+			const int rb = p->realn_pass == 2 ? 0 : len / 4, rl = p->realn_pass == 2 ? len : len / 2;
+			seqalign_result_t rs;
+			int i;
+			if(rl <= 0) continue;
+			if(p->mode == 9 || p->mode == 10){
+				for(i = rb; i < rb + rl; i++) cut_rdnode_bspoa(g, rid, i, BSPOA_RDNODE_CUTALL);
+				clear_u8v(g->todels);
+				if(bsa_poa_align_rd_pog(g, g->par, 1, rid, rb, rl, &p->ad, &rs)){ record_read(p, rs, 0, 0); continue; }
+			}
+			rs = align_rd_bspoa(g, g->par, 1, rid, rb, rl);
+			record_read(p, rs, 0, 0);
+		}
+	}
 	if(p->mode == 5 && (p->record_programs & 4)){
 		/* the graph the last surgery left */
 		bsa_poa_graph_export_t x; uint64_t hdr[20];
@@ -656,8 +703,10 @@ int ref_poa_run(void *vp, const uint8_t *reads, const uint64_t *offs, const uint
 	for(k = 0; k < nreads; k++){
 		for(i = 0; i < lens[k]; i++) buf[i] = "ACGT"[reads[offs[k] + i] & 3];
 		buf[lens[k]] = 0;
-		push_bspoa(g, buf, lens[k]);
+		if(p->cigs && p->coffs) push_bspoacore(g, buf, lens[k], (u4i*)(p->cigs + p->coffs[k]), (u4i)(p->coffs[k + 1] - p->coffs[k]));
+		else push_bspoa(g, buf, lens[k]);
 	}
+	if(p->cigs){ encap_u4v(g->cigars, 1); g->cigars->buffer[g->cigars->size] = 0; }          /* (bspoa.h:2073 reads the word behind a read's CIGAR) */
 	free(buf);
 	if(mode == 0) end_bspoa(g);
 	else poa_finish(p);

@@ -133,7 +133,7 @@ def parse_snapshot(blob, o):
     return d
 
 
-def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
+def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle", refmode=0, cigars=None, realn_pass=0):
     """modes 5 / 6 of the harness (graph form of the binding).  backend "oracle": orc_wf_backend + orc_sweep_run on the CPU;
     "device": whatever the GPU test attached with ref_poa_set_graph_host / ref_poa_set_device.
     -> dict like run_ref_poa, plus per read (mode 5, record) nodes / edges / cands / trace / fin and the counts of reads per form"""
@@ -150,6 +150,20 @@ def run_ref_graph(reads, mode, p, record=True, lib=None, backend="oracle"):
     offs = np.zeros(len(reads), dtype=np.uint64)
     offs[1:] = np.cumsum(lens)[:-1]
     blob = np.concatenate(reads).astype(np.uint8)
+    # refmode: read 0 is the reference, `cigars` (one uint32 array per read, len << 4 | op) the reads' SAM CIGARs against it (bspoa.h:2055-2085);
+    # realn_pass (mode 8): after the first stage a stretch of every aligned read goes through the realn entry of align_rd_bspoa (1: middle half, 2: whole read)
+    if refmode or cigars is not None or realn_pass:
+        r.ref_poa_set_refmode.argtypes = [C.c_void_p, C.c_int]; r.ref_poa_set_refmode.restype = None
+        r.ref_poa_set_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; r.ref_poa_set_cigars.restype = None
+        r.ref_poa_set_realn_pass.argtypes = [C.c_void_p, C.c_int]; r.ref_poa_set_realn_pass.restype = None
+        r.ref_poa_set_refmode(h, int(refmode))
+        r.ref_poa_set_realn_pass(h, int(realn_pass))
+    cig_blob = coffs = None
+    if cigars is not None:
+        coffs = np.zeros(len(reads) + 1, dtype=np.uint64)
+        coffs[1:] = np.cumsum([len(c) for c in cigars])
+        cig_blob = np.concatenate([np.asarray(c, dtype=np.uint32) for c in cigars] + [np.zeros(1, np.uint32)])
+        r.ref_poa_set_cigars(h, cig_blob.ctypes.data, coffs.ctypes.data)
     bad = r.ref_poa_run(h, blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads), mode,
                         C.cast(o.orc_sweep_run, C.c_void_p) if backend == "oracle" else None, int(record))
     n = r.ref_poa_cns_len(h)

@@ -44,6 +44,42 @@ def test_every_step_in_the_shadow_of_the_reference_with_the_device_between(ctx, 
     assert g["steps"] > aligned * 1000 and g["graph_edges"] > 0 and g["program_bytes"] > 0
 
 
+@pytest.mark.parametrize("how,kw", [(1, dict()), (2, dict(bandwidth=64, nrec=0)), (1, dict(alnmode=0, Q=0, P=0)), (2, dict(bwtrigger=0, bandwidth=0))])
+def test_re_aligned_stretches_with_the_device_between(ctx, how, kw):
+    """the realn entry of align_rd_bspoa (bsa_pog_cut, bspoa.h:741-795, 2626-2630): after the first stage a stretch of every aligned read is cut out of both
+    graphs and aligned again -- a stretch between inner nodes takes the whole stretch as its band (up to 1250 columns here: the generic-width kernel)"""
+    lib = P.ref_poa()
+    _attach(lib, ctx)
+    p = P.par(**kw)
+    reads = P.synth_reads(560 + how + len(kw), 600 if kw.get("bandwidth", 1) == 0 else 2500, 10, eps=(0.05, 0.12))
+    r = P.run_ref_graph(reads, 8, p, record=False, lib=lib, backend="device", realn_pass=how)
+    assert r["bad"] == 0, [(i, rc["mismatch"]) for i, rc in enumerate(r["recs"]) if rc["mismatch"]]
+    g = r["pog"]
+    assert len(r["recs"]) == 2 * len(reads) and g["declined"] == 0 and g["imports"] == 0 and g["reads"] == 2 * len(reads)
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_refmode_with_the_device_between(ctx, k):
+    """refmode (bspoa.h:2039-2085): read 0 a reference sequence, bands from the reads' SAM CIGARs (k even) or from the guide alignment against it (k odd)"""
+    from test_poa_pog_cpu import _sam_cigars
+    lib = P.ref_poa()
+    _attach(lib, ctx)
+    p = [P.par(shuffle=0), P.par(shuffle=0, alnmode=0), P.par(shuffle=0, bandwidth=64, Q=0, P=0), P.par(shuffle=1)][k]
+    rng = np.random.default_rng(4300 + k)
+    T = rng.integers(0, 4, size=3000).astype(np.uint8)
+    reads = [T] + [np.asarray(S.mutate(rng, T, float(rng.choice((0.04, 0.1)))), dtype=np.uint8) for _ in range(11)]
+    cigs = None
+    if k % 2 == 0:
+        reads, cigs = _sam_cigars(reads, rng)
+    r = P.run_ref_graph(reads, 8, p, record=False, lib=lib, backend="device", refmode=1, cigars=cigs)
+    assert r["bad"] == 0, [(i, rc["mismatch"]) for i, rc in enumerate(r["recs"]) if rc["mismatch"]]
+    g = r["pog"]
+    assert g["reads"] == len(reads) - 1 and g["declined"] == 0 and g["imports"] == 0
+    ref = P.run_ref_graph(reads, 1, p, record=False, refmode=1, cigars=cigs)
+    mine = P.run_ref_graph(reads, 9, p, record=False, lib=lib, backend="device", refmode=1, cigars=cigs)
+    assert np.array_equal(mine["cns"], ref["cns"]) and np.array_equal(mine["qlt"], ref["qlt"]) and np.array_equal(mine["alt"], ref["alt"]) and mine["msa"] == ref["msa"]
+
+
 def test_end_bspoa_on_the_librarys_graph(ctx):
     lib = P.ref_poa()
     _attach(lib, ctx)
