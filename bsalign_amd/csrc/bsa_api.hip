@@ -47,17 +47,31 @@ struct bsa_ctx {
 	void *xq = nullptr; size_t xq_bytes = 0;          // control words + band states of the persistent 8-bit forward kernel (k_align8_fwd_xq), grown on demand
 };
 
-static const size_t BSA_KEEP_MAX = (size_t)64 << 20;      // larger requests are plain allocations
+static const size_t BSA_KEEP_MAX = (size_t)64 << 20;      // slot 0 (a plan's metadata): larger requests are plain allocations
+// slot 1, the host-pointer wrappers' buffers (sequences up, records and CIGAR words down), stays with the context up to 16 GB: a caller that sends batch after
+// batch otherwise pays the allocation every time -- 0.4 ms when the memory is at hand, 770 ms measured for the 11.5 GB of the second C3-sized call on a device
+// that is 80 % full.  (BSA_KEEP_HOST_MB overrides; the workspace budget is taken from what is free, so a kept buffer only ever makes chunks smaller.)
+static size_t keep_max(int slot){
+	if(slot != 1) return BSA_KEEP_MAX;
+	if(const char *e = bsa_env("BSA_KEEP_HOST_MB")){ const long v = atol(e); if(v >= 0) return (size_t)v << 20; }
+	return (size_t)16 << 30;
+}
 // a device buffer of at least `bytes`; *kept says whether it is the context's (released with ctx_buf_put) or the caller's to free
 static hipError_t ctx_buf_get(bsa_ctx *c, int slot, size_t bytes, void **out, bool *kept){
 	*kept = false;
-	if(bytes <= BSA_KEEP_MAX && !c->keep_busy[slot]){
+	const size_t kmax = keep_max(slot);
+	if(bytes <= kmax && !c->keep_busy[slot]){
 		if(c->keep_bytes[slot] < bytes){
 			if(c->keep[slot]){ (void)hipFree(c->keep[slot]); c->keep[slot] = nullptr; c->keep_bytes[slot] = 0; }
-			const size_t want = std::max<size_t>(bytes * 2, (size_t)1 << 20);
-			const hipError_t e = hipMalloc(&c->keep[slot], std::min(want, BSA_KEEP_MAX));
-			if(e != hipSuccess){ c->keep[slot] = nullptr; return e; }
-			c->keep_bytes[slot] = std::min(want, BSA_KEEP_MAX);
+			// small buffers double (a batch of one pair after another), large ones are rounded up to 256 MB
+			const size_t want = bytes <= BSA_KEEP_MAX ? std::min(std::max<size_t>(bytes * 2, (size_t)1 << 20), BSA_KEEP_MAX) : ((bytes + (((size_t)256 << 20) - 1)) & ~(((size_t)256 << 20) - 1));
+			hipError_t e = hipMalloc(&c->keep[slot], want);
+			if(e != hipSuccess){
+				// (not that much at hand: a plain allocation of what was asked for)
+				c->keep[slot] = nullptr; (void)hipGetLastError();
+				return hipMalloc(out, bytes);
+			}
+			c->keep_bytes[slot] = want;
 		}
 		c->keep_busy[slot] = true; *kept = true; *out = c->keep[slot];
 		return hipSuccess;
@@ -674,7 +688,12 @@ static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t
 	auto up = [](size_t b){ return (std::max<size_t>(b, 8) + 255) & ~(size_t)255; };
 	const size_t o_seqs = 0, o_out = o_seqs + up(seqs_bytes), o_st = o_out + up(n * sizeof(bsa_result_t)), o_off = o_st + up(n * sizeof(uint32_t));
 	const size_t o_cig = o_off + (want_cig ? up((n + 1) * sizeof(uint64_t)) : 0), total = o_cig + (want_cig ? up(cigar_cap_words * 4) : 0);
+	const bool tmg = bsa_env("BSA_API_TIMING") != nullptr;          // (stderr: where a host-pointer batch spends its wall time)
+	const auto ts0 = std::chrono::steady_clock::now();
+	auto since = [&](){ return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count(); };
+	double t_buf = 0, t_prep = 0, t_run = 0, t_res = 0;
 	TRYH(ctx_buf_get(c, 1, total, (void**)&pool, &pool_kept));
+	t_buf = since();
 	d_seqs = pool + o_seqs; d_out = (bsa_result_t*)(pool + o_out); d_status = (uint32_t*)(pool + o_st);
 	if(want_cig){ d_off = (uint64_t*)(pool + o_off); d_cig = (uint32_t*)(pool + o_cig); }
 	int rc;
@@ -689,8 +708,10 @@ static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t
 		rc = prep();
 	}
 	if(rc != BSA_OK){ (void)hipStreamSynchronize(c->stream); cleanup(); return rc; }
+	t_prep = since();
 	rc = run(d_seqs, d_out, d_cig, d_off, d_status);
 	if(rc != BSA_OK){ cleanup(); return rc; }
+	t_run = since();
 	if(total - o_out <= ((size_t)1 << 20)){
 		// a small batch: everything that goes back in ONE copy (results, status, offsets, the whole arena), then handed out
 		std::vector<uint8_t> back(total - o_out);
@@ -710,12 +731,16 @@ static int batch_host(bsa_ctx *c, const uint8_t *seqs, size_t seqs_bytes, size_t
 	if(status) TRYH(hipMemcpyAsync(status, d_status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	if(want_cig) TRYH(hipMemcpyAsync(cigar_off, d_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 	TRYH(hipStreamSynchronize(c->stream));
+	t_res = since();
 	if(want_cig){
 		if(cigar_off[n] > cigar_cap_words){ cleanup(); c->err = "cigar arena too small"; return BSA_E_CIGAR_CAP; }
 		TRYH(par_copy(c->device, cigar, d_cig, cigar_off[n] * 4, hipMemcpyDeviceToHost));
 	}
 #undef TRYH
+	const double t_cig = since();
 	cleanup();
+	if(tmg) fprintf(stderr, "[host-pointer batch] %zu pairs, %.1f MB up, %.1f MB of CIGAR words down: ms since entry -- buffers %.1f, plan + upload %.1f, launched %.1f, kernels done + records back %.1f, CIGAR words back %.1f, released %.1f\n",
+		n, seqs_bytes / 1e6, want_cig ? cigar_off[n] * 4 / 1e6 : 0.0, t_buf, t_prep, t_run, t_res, t_cig, since());
 	return BSA_OK;
 }
 
