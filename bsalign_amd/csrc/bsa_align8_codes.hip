@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes_wave(const Align8Args
 			const uint32_t gk = g & (od | ~dl31);
 			g = (int)lane == k0 ? gk : g;
 			g = (int)lane < k0 ? 0x80000000u : g;
-			const uint64_t stopm = __ballot((int)g >= 0);
+			const uint64_t stopm = __ballot((int)g >= 0);               // (the lanes-below-k0 mask on the scalar side instead -- one vector compare, two scalar operations -- was measured slower: 8.85 against 8.78 ms, two-piece 17.1 against 16.4: the walk is as close to the scalar unit's rate as to the vector units')
 			dl31 &= ~(uint32_t)__builtin_amdgcn_readlane((int)od, k0);      // the run ends at this cell, which is then an ordinary one
 			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
 			const int n = k - k0;
@@ -1218,7 +1218,7 @@ __global__ void __launch_bounds__(64) k_align8_trace_codes2_wave(const Align8Arg
 			const uint32_t gk = g & (odr | (odr << 1) | ndl);
 			g = (int)lane == k0 ? gk : g;
 			g = (int)lane < k0 ? 0x80000000u : g;
-			const uint64_t stopm = __ballot((int)g >= 0);
+			const uint64_t stopm = __ballot((int)g >= 0);               // (the lanes-below-k0 mask on the scalar side instead -- one vector compare, two scalar operations -- was measured slower: 8.85 against 8.78 ms, two-piece 17.1 against 16.4: the walk is as close to the scalar unit's rate as to the vector units')
 			if((uint32_t)__builtin_amdgcn_readlane((int)od, k0) & dl){ dl = 0u; ndl = 0x80000000u; }      // Od of the run's piece: the run ends at this cell
 			const int k = stopm ? (int)__builtin_ctzll(stopm) : 64;
 			const int n = k - k0;

@@ -315,7 +315,11 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	const int rby_lane = (lt & (64 - L)) << 2;                   // byte address of lane 0 of this group for ds_bpermute
 	const uint32_t kd1 = last ? 0x01000000u : 0u;          // band cell bw - 1 after a slide by one: x == bw, no deletion there (bsalign.h:3672-3678)
 
-	while(i < row1 && __any(i < tlen)){
+	// Wave-level tests: ONE vector compare into a scalar mask, the pair's liveness ANDed in on the scalar unit.  (`__any(act && x)` is the library's
+	// __ockl_wfany_i32 on an `and` of two conditions: the backend materialises the predicate as 0 / 1 in a register and compares it again -- two to three
+	// vector instructions a test, six tests a row.)
+	uint64_t actm = 0;
+	while(i < row1 && (actm = __builtin_amdgcn_ballot_w64(i < tlen)) != 0ull){
 		const bool act = i < tlen;
 		if(!STATIC && mode == BSA_MODE_GLOBAL && (i & (uint32_t)(L - 1)) == 0u)
 			rby_tab = (int)((1.0 * (double)(i + (uint32_t)jl) / (double)tlen) * (double)qlen);      // bsalign.h:4009, row i + jl
@@ -332,7 +336,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		else if(PW < 2) rh = gapo1 + gape1 * (int)i;
 		else rh = max(gapo1 + gape1 * (int)i, gapo2 + gape2 * (int)i);
 		// ---- row_movx (bsalign.h:2244-2392): the row is held slid by one cell; correct what did not move that way
-		if(!STATIC && __any(act && mov != 1u)){
+		if(!STATIC && (__builtin_amdgcn_ballot_w64(mov != 1u) & actm) != 0ull){
 			if(__any(act && mov >= (uint32_t)BW)){
 				// the band jumped past everything it held: zero rows, every ubegs = SCORE_MIN (bsalign.h:2253-2259);
 				// rh = H at the last cell of the previous row (getscore(bw - 1))
@@ -401,7 +405,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				for(int n = 0; n < NQ; n++){ qlo[n] = act ? sqlo[n] : 0x04040404u; qhi[n] = act ? sqhi[n] : 0x04040404u; }
 			} else if constexpr (QWIN){
 				uint32_t off = rbeg - wbase;
-				if(__any(act && off > QOFFMAX)){
+				if((__builtin_amdgcn_ballot_w64(off > QOFFMAX) & actm) != 0ull){
 					// refill: KD dwords of each block from the band offset of this row
 					if(act && off > QOFFMAX){
 						const uint8_t *pl = qp + rbeg + jl * W, *ph = qp + rbeg + (jl + L) * W;
@@ -442,7 +446,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		// (or jumped past the whole band: ubegs[0] = SCORE_MIN) need it.
 		uint32_t hc0 = S[0];
 		uint32_t q0m = 0, q0d = 0, q0d2 = 0;          // rows starting at query column 0: what h is compared with for M and D (bsalign.h:3763-3767)
-		if(__any(act && (mov == 0u || mov >= (uint32_t)BW))){
+		if((__builtin_amdgcn_ballot_w64(mov - 1u >= (uint32_t)BW - 1u) & actm) != 0ull){          // mov == 0 or mov >= BW
 			const int s0 = x_lo8(S[0]) + 2 * GE, u0 = x_lo8(U[0]) + GE, e0 = GE - x_lo8(NE[0]);
 			const int qq0 = (PW == 2) ? GE - x_lo8(NQ2[0]) : e0;
 			const int t0 = u0 + max(e0, qq0);
@@ -553,7 +557,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		if(first) tmpU0 = (tmpU0 & 0xffff0000u) | (NGEQ & 0xffffu);
 		const uint32_t Psh = x_shift_down<L>(PN, 0u, first);           // ubegs[b] - ubegs[0] - b W gape of the block's own start
 		// ---- flags of special cells, then the code row (bsa_common.h "COMPACT slot"); M, D, R were accumulated inverted
-		if(__any(act && rbeg == 0u)){
+		if((__builtin_amdgcn_ballot_w64(rbeg == 0u) & actm) != 0ull){
 			if(first && rbeg == 0u){
 				const uint32_t hl = hfirst & 0xffffu;
 				const uint32_t b0 = 1u << TOPBIT;
@@ -568,7 +572,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				if constexpr (PW == 2) accD2[0] = (accD2[0] & ~b0) | ((hl == q0d2) ? 0u : b0);
 			}
 		}
-		if(__any(act && mov > 1u)){          // (the general form covers mov == 1 of the other pairs of the wave)
+		if((__builtin_amdgcn_ballot_w64(mov > 1u) & actm) != 0ull){          // (the general form covers mov == 1 of the other pairs of the wave)
 			// cells at / beyond the end of the previous row's band: x == bw decides M or I only, x > bw is always I
 #pragma unroll
 			for(int hf = 0; hf < 2; hf++){

@@ -1244,8 +1244,12 @@ __global__ void __launch_bounds__(64) k_edit_trace_wave(const EditArgs a, bsa_re
 			const uint32_t nei = qb != tb ? 1u : 0u;
 			st = nei ? st : 0u;
 			st |= TL | (uint32_t)(xs - (int)lane);                   // (the sign of xs - lane: columns left of the query)
+#ifdef EDIT_WALK_VMASK
 			st = (int)lane < k0 ? 0u : st;
 			const u64 stopm = __ballot((int)st < 0);                // lane 63 always stops
+#else
+			const u64 stopm = __builtin_amdgcn_ballot_w64((int)st < 0) & (~0ull << k0);                // lane 63 always stops; lanes below k0 masked on the scalar side (one compare instead of compare, select, 0 / 1, compare)
+#endif
 			// what the cell is if the walk stops on it: bit 0 insertion, bit 1 decided by the masks, bit 2 the tile's own
 			const uint32_t ev = (sh < 32u ? ((IM >> c) & 1u) | (((VM >> c) & 1u) << 1) : 0u) | TE;
 			const int k = __builtin_ctzll(stopm);
