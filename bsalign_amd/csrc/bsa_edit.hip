@@ -534,6 +534,7 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 	const bool overlap = type == BSA_MODE_OVERLAP;
 	const uint32_t qround = (qlen + 63u) / 64u * 64u;
 	const bool word = gl < NH, top = gl + 1u == NH;
+	const u64 wordm = __builtin_amdgcn_ballot_w64(word && !top);             // lanes whose word hands a delta on
 	const uint32_t tl = live ? tlen : 0u;
 	uint32_t pv = ~0u, mv = 0u;
 	if(live && word){                                                     // row_init (:653-656)
@@ -570,8 +571,8 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 		uint32_t movx = on ? rb1 - rb0 : 0u;
 		// ---- row_movx (:658-721)
 		if(overlap) sbeg = 0; else if(on) sbeg += 1;
-		if(__any(movx >= 32u)){
-			while(__any(movx >= 32u)){                                        // whole words (rare)
+		if(__builtin_amdgcn_ballot_w64(movx >= 32u) != 0ull){
+			while(__builtin_amdgcn_ballot_w64(movx >= 32u) != 0ull){                                        // whole words (rare)
 				uint32_t np = (uint32_t)DPP_SHL(0, (int)pv, 1), nm = (uint32_t)DPP_SHL(0, (int)mv, 1), nq0 = (uint32_t)DPP_SHL(0, (int)q0, 1), nq1 = (uint32_t)DPP_SHL(0, (int)q1, 1);
 				if(top){ np = ~0u; nm = 0u; nq0 = __builtin_amdgcn_alignbit(l0n, l0c, lpos & 31u); nq1 = __builtin_amdgcn_alignbit(l1n, l1c, lpos & 31u); }
 				if(movx >= 32u){
@@ -601,17 +602,19 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 		const uint32_t x0 = (tb & 1u) ? 0u : ~0u, x1 = (tb & 2u) ? 0u : ~0u;
 		const uint32_t nvalid = (rb1 < qlen) ? qlen - rb1 : 0u;          // band cells that are real query columns
 		uint32_t Eq = (q0 ^ x0) & (q1 ^ x1);
-		if(__any(nvalid < BW)){ const uint32_t lo = gl * 32u; Eq &= (nvalid > lo) ? (nvalid - lo >= 32u ? ~0u : ((1u << (nvalid - lo)) - 1u)) : 0u; }
+		if(__builtin_amdgcn_ballot_w64(nvalid < BW) != 0ull){ const uint32_t lo = gl * 32u; Eq &= (nvalid > lo) ? (nvalid - lo >= 32u ? ~0u : ((1u << (nvalid - lo)) - 1u)) : 0u; }
 		const uint32_t Xv = Eq | mv;
 		const uint32_t e1 = Eq | 1u;
 		const uint32_t t0 = (((Eq & pv) + pv) ^ pv) | Eq;
 		const uint32_t t1 = (((e1 & pv) + pv) ^ pv) | e1;
 		const uint32_t ph0 = (mv | ~(t0 | pv)) >> 31, mh0 = (pv & t0) >> 31;
 		const uint32_t ph1 = (mv | ~(t1 | pv)) >> 31, mh1 = (pv & t1) >> 31;
-		const bool link = act && !top;                                        // the top word's outgoing delta leaves the band
-		const u64 A = __ballot(link && mh0 > ph0), B = __ballot(link && mh1 > ph1);
+		// (the top word's outgoing delta leaves the band.  One vector compare a ballot, the lanes that take part ANDed in on the scalar side: a ballot of
+		// `link && ...` is an `and` of conditions, which the backend materialises as 0 / 1 in a register and compares again -- eight vector instructions a row)
+		const u64 linkm = __builtin_amdgcn_ballot_w64(on) & wordm;
+		const u64 A = __builtin_amdgcn_ballot_w64(mh0 > ph0) & linkm, B = __builtin_amdgcn_ballot_w64(mh1 > ph1) & linkm;
 		const u64 C = uniform64(chain_neg(A, B));                             // bit l: a negative delta enters lane l
-		const u64 PA = __ballot(link && ph0 > mh0), PB = __ballot(link && ph1 > mh1);
+		const u64 PA = __builtin_amdgcn_ballot_w64(ph0 > mh0) & linkm, PB = __builtin_amdgcn_ballot_w64(ph1 > mh1) & linkm;
 		const u64 Ppos = uniform64(((((PA & ~C) | (PB & C)) << 1) & ~GS) | hin0_mask);   // left of the band v = +1, 0 in overlap mode (:770)
 		const uint32_t Xh = mask_pick(t0, t1, C);
 		uint32_t Ph = mv | ~(Xh | pv);
@@ -640,7 +643,7 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 		// the slots past its last row hold that row again -- nobody reads them)
 		uint32_t bm[8], bp_[8];
 		bm[0] = 0u; bp_[0] = ~0u;
-		for(uint32_t t8 = 0; __any((t8 ? t8 - 1u : 0u) < tl || t8 == 0u); t8 += 8u){
+		for(uint32_t t8 = 0; t8 == 0u || __builtin_amdgcn_ballot_w64(t8 - 1u < tl) != 0ull; t8 += 8u){
 #pragma unroll
 			for(uint32_t j = 0; j < 8u; j++){
 				if(j == 0u && t8 == 0u) continue;                                // (the initial row)
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(256) k_edit_fwd_grp32(const EditArgs a){
 #pragma unroll
 				for(int k = 0; k < 4; k++) dst[k] = make_uint4(bm[2 * k], bp_[2 * k], bm[2 * k + 1], bp_[2 * k + 1]);
 			}
-			if(!__any(t8 + 7u < tl)) break;
+			if(__builtin_amdgcn_ballot_w64(t8 + 7u < tl) == 0ull) break;
 		}
 	}
 	if(live && gl == 0u) a.fwd_sbeg[ppos] = sbeg;
