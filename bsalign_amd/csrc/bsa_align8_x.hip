@@ -199,14 +199,16 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	const uint32_t GQQ = x_q8(gapo2), NGQQ = x_q8(-gapo2), NGQQ1 = x_q8(-gapo2 - 1), DPQ = x_q8(DP);
 	const uint32_t GE16 = x_i16(GE), WGE16 = x_i16(W * GE);
 	const uint32_t PADS = (uint32_t)((BSA_EPI8_MIN - 2 * GE) & 0xff) * 0x01010101u;    // S~ beyond the query end
-	uint32_t mrs[4];                                       // S~ rows per target base
-#pragma unroll
-	for(int t = 0; t < 4; t++){
+	// S~ rows per target base: four dwords in LDS, read by the lanes with their row's base as the index (every wave of the block writes the same values)
+	__shared__ uint32_t x_mtab[4];
+	if((lt & 63) < 4){
+		const int t = lt & 3;
 		uint32_t w = 0;
 #pragma unroll
 		for(int q = 0; q < 4; q++) w |= (uint32_t)(((int)a.matrix[q * 4 + t] - 2 * GE) & 0xff) << (8 * q);
-		mrs[t] = w;
+		x_mtab[t] = w;
 	}
+	__builtin_amdgcn_wave_barrier();
 
 	uint32_t U[W], NE[W], NQ2[(PW == 2) ? W : 1];     // NQ2: gape1 - q of piece 2
 	uint32_t PN;                  // packed int16: ubegs[b+1] - ubegs[0] - (b+1) W gape for b = jl (low) and jl + L (high)
@@ -398,7 +400,9 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		// ---- sequences, S~(x, y)
 		uint32_t S[W];
 		{
-			const int tb = (int)((twin >> (8u * (i & 7u))) & 3u);
+			// the target base of this row (i is uniform: the half of the eight-base window is picked on the scalar side), as the byte offset of its S~ row
+			const uint32_t tw32 = (i & 4u) ? (uint32_t)(twin >> 32) : (uint32_t)twin;
+			const uint32_t tb4 = __builtin_amdgcn_ubfe(tw32, 8u * (i & 3u), 2u) << 2;
 			uint32_t qlo[NQ], qhi[NQ];
 			if constexpr (STATIC){
 #pragma unroll
@@ -431,7 +435,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 #pragma unroll
 				for(int n = 0; n < NQ; n++){ qlo[n] = 0x04040404u; qhi[n] = 0x04040404u; }
 			}
-			const uint32_t mr = (tb == 0) ? mrs[0] : (tb == 1) ? mrs[1] : (tb == 2) ? mrs[2] : mrs[3];
+			// (a four-way select among uniform values compiles to three nested exec-mask regions with v_readlane hazards: one LDS read instead)
+			const uint32_t mr = *(const uint32_t*)((const uint8_t*)x_mtab + tb4);
 			uint32_t slo[NQ], shi[NQ];
 #pragma unroll
 			for(int n = 0; n < NQ; n++){ slo[n] = __builtin_amdgcn_perm(PADS, mr, qlo[n]); shi[n] = __builtin_amdgcn_perm(PADS, mr, qhi[n]); }
