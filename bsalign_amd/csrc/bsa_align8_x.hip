@@ -61,6 +61,9 @@ static __device__ __forceinline__ int x_hi16(uint32_t x){ return (int)x >> 16; }
 // (no dpp_keep here: every consumer of these moves is a packed, a three-operand or a select instruction, none of which can
 // absorb a DPP operand, so the v_subrev_u32_dpp fold that bsa_dpp.h guards against cannot happen)
 #define XDPP(old, x, ctrl, bank) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(x), (ctrl), 0xf, (bank), false))
+// lanes without a source read 0 (bound_ctrl): the same values as XDPP(0, ...), but the compiler need not put a zero into the destination first -- with
+// old = 0 every one of these moves was preceded by a v_mov_b32 v, 0 (ten a row on the headline shape)
+#define XDPPZ(x, ctrl, bank) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xf, (bank), true))
 #define XQP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 #define XROW_SHL(n) (0x100 + (n))
 #define XROW_SHR(n) (0x110 + (n))
@@ -69,12 +72,12 @@ static __device__ __forceinline__ int x_hi16(uint32_t x){ return (int)x >> 16; }
 // A pair owns a group of L = 8 or 4 consecutive lanes (two or four groups per 16-lane DPP row).
 // value of the first / last lane of every group, in all its lanes
 template<int L> static __device__ __forceinline__ uint32_t x_bcast_first(uint32_t x){
-	const uint32_t s = XDPP(0, x, XQP(0, 0, 0, 0), 0xf);
+	const uint32_t s = XDPPZ(x, XQP(0, 0, 0, 0), 0xf);
 	if constexpr (L == 4) return s;
 	else return XDPP(s, s, XROW_SHR(4), 0xA);          // lanes 4..7 <- lanes 0..3
 }
 template<int L> static __device__ __forceinline__ uint32_t x_bcast_last(uint32_t x){
-	const uint32_t s = XDPP(0, x, XQP(3, 3, 3, 3), 0xf);
+	const uint32_t s = XDPPZ(x, XQP(3, 3, 3, 3), 0xf);
 	if constexpr (L == 4) return s;
 	else return XDPP(s, s, XROW_SHL(4), 0x5);          // lanes 0..3 <- lanes 4..7
 }
@@ -83,22 +86,22 @@ template<int L> static __device__ __forceinline__ uint32_t x_shift_down(uint32_t
 	if constexpr (L == 4){
 		// a pair is one DPP quad: ONE rotation brings every lane its neighbour and lane 0 the last lane's value, ONE byte permute (the
 		// selector is a loop invariant of the lane) puts that value's low half above the fill in lane 0 and leaves the others as they are
-		const uint32_t r = XDPP(0, x, XQP(3, 0, 1, 2), 0xf);
+		const uint32_t r = XDPPZ(x, XQP(3, 0, 1, 2), 0xf);
 		return __builtin_amdgcn_perm(r, fill_lo, first ? 0x05040100u : 0x07060504u);
 	}
-	const uint32_t s = XDPP(0, x, XROW_SHR(1), 0xf);
-	const uint32_t w = XDPP(0, x, XROW_SHL(L - 1), 0xf);  // first lane <- last lane
+	const uint32_t s = XDPPZ(x, XROW_SHR(1), 0xf);
+	const uint32_t w = XDPPZ(x, XROW_SHL(L - 1), 0xf);  // first lane <- last lane
 	const uint32_t fix = (w << 16) | (fill_lo & 0xffffu);
 	return first ? fix : s;
 }
 // block b receives the value of block b + 1; block 2L - 1 receives fill (given in both halves)
 template<int L> static __device__ __forceinline__ uint32_t x_shift_up(uint32_t x, uint32_t fill, bool last){
 	if constexpr (L == 4){
-		const uint32_t r = XDPP(0, x, XQP(1, 2, 3, 0), 0xf);             // (lane 3 receives lane 0's value: its high half goes below the fill)
+		const uint32_t r = XDPPZ(x, XQP(1, 2, 3, 0), 0xf);             // (lane 3 receives lane 0's value: its high half goes below the fill)
 		return __builtin_amdgcn_perm(fill, r, last ? 0x05040302u : 0x03020100u);
 	}
-	const uint32_t s = XDPP(0, x, XROW_SHL(1), 0xf);
-	const uint32_t w = XDPP(0, x, XROW_SHR(L - 1), 0xf);  // last lane <- first lane
+	const uint32_t s = XDPPZ(x, XROW_SHL(1), 0xf);
+	const uint32_t w = XDPPZ(x, XROW_SHR(L - 1), 0xf);  // last lane <- first lane
 	const uint32_t fix = __builtin_amdgcn_alignbit(fill, w, 16);        // {fill.lo, w.hi}
 	return last ? fix : s;
 }
@@ -114,9 +117,9 @@ template<int L> static __device__ __forceinline__ uint32_t x_scan_max(uint32_t x
 }
 // sum over the lanes of a group, per half, in every lane
 template<int L> static __device__ __forceinline__ uint32_t x_sum(uint32_t x){
-	x = x_add(x, XDPP(0, x, XQP(1, 0, 3, 2), 0xf));
-	x = x_add(x, XDPP(0, x, XQP(2, 3, 0, 1), 0xf));
-	if constexpr (L == 8) x = x_add(x, XDPP(0, x, XHALF_MIRROR, 0xf));
+	x = x_add(x, XDPPZ(x, XQP(1, 0, 3, 2), 0xf));
+	x = x_add(x, XDPPZ(x, XQP(2, 3, 0, 1), 0xf));
+	if constexpr (L == 8) x = x_add(x, XDPPZ(x, XHALF_MIRROR, 0xf));
 	return x;
 }
 
@@ -859,7 +862,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			uint32_t inu;
 			if constexpr (L == 4) inu = x_shift_up<L>(tmpU0, NEWU0, last);
 			else {
-				const uint32_t nxt = XDPP(0, tmpU0, XROW_SHL(1), 0xf);          // (a DPP move must not sit in an arm of ?: -- only one arm runs)
+				const uint32_t nxt = XDPPZ(tmpU0, XROW_SHL(1), 0xf);          // (a DPP move must not sit in an arm of ?: -- only one arm runs)
 				inu = last ? __builtin_amdgcn_alignbit(NEWU0, bc0, 16) : nxt;
 			}
 			const uint32_t inne = x_shift_up<L>(tmpNE0, NEWNE, last);

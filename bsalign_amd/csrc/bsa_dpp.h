@@ -7,10 +7,13 @@
 // dpp(vdst) - vsrc instead of vdst - dpp(vsrc) (measured on hardware, scratch/dpp_test.hip); keeping the move
 // explicit costs one VALU op and is always right.
 static __device__ __forceinline__ int dpp_keep(int x){ asm("" : "+v"(x)); return x; }
-#define DPP_SHR(fill, x, n)  dpp_keep(__builtin_amdgcn_update_dpp((fill), (x), 0x110 + (n), 0xf, 0xf, false))  // lane j <- lane j-n (row of 16)
-#define DPP_SHL(fill, x, n)  dpp_keep(__builtin_amdgcn_update_dpp((fill), (x), 0x100 + (n), 0xf, 0xf, false))  // lane j <- lane j+n
-#define DPP_BCAST(x, n)      dpp_keep(__builtin_amdgcn_update_dpp(0, (x), 0x150 + (n), 0xf, 0xf, false))       // row_newbcast:n
-#define DPP_ROR(x, n)        dpp_keep(__builtin_amdgcn_update_dpp(0, (x), 0x120 + (n), 0xf, 0xf, false))       // row rotate right
+// (a fill that is the constant 0 is what bound_ctrl gives a lane without a source: then the compiler need not put the fill into the destination first --
+// with old = 0 every such move was preceded by a v_mov_b32 v, 0)
+#define DPP_MOV_(fill, x, ctrl) ((__builtin_constant_p(fill) && (fill) == 0) ? __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xf, 0xf, true) : __builtin_amdgcn_update_dpp((fill), (x), (ctrl), 0xf, 0xf, false))
+#define DPP_SHR(fill, x, n)  dpp_keep(DPP_MOV_((fill), (x), 0x110 + (n)))  // lane j <- lane j-n (row of 16)
+#define DPP_SHL(fill, x, n)  dpp_keep(DPP_MOV_((fill), (x), 0x100 + (n)))  // lane j <- lane j+n
+#define DPP_BCAST(x, n)      dpp_keep(__builtin_amdgcn_update_dpp(0, (x), 0x150 + (n), 0xf, 0xf, true))       // row_newbcast:n (every lane has a source)
+#define DPP_ROR(x, n)        dpp_keep(__builtin_amdgcn_update_dpp(0, (x), 0x120 + (n), 0xf, 0xf, true))       // row rotate right
 
 #define BIGNEG (-(1 << 28))
 
