@@ -304,7 +304,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 	int begq = 0;
 	if(tlen != 0u && first && row0 == 0u) begs[0] = 0;
 	uint64_t twin = 0;
-	if(row0 < tlen) __builtin_memcpy(&twin, tp + row0, 8);
+	if(row0 < tlen){ __builtin_memcpy(&twin, tp + row0, 8); twin <<= 2; }
 	// STATIC: the band never moves, so a lane's query codes are the same on every row -- loaded once
 	uint32_t sqlo[STATIC ? NQ : 1], sqhi[STATIC ? NQ : 1];
 	if constexpr (STATIC){
@@ -330,9 +330,8 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 			rby_tab = (int)((1.0 * (double)(i + (uint32_t)jl) / (double)tlen) * (double)qlen);      // bsalign.h:4009, row i + jl
 		// ---- band offset of this row (bsalign.h:3932-3946)
 		if constexpr (!STATIC){
-			const bool moved = (mov != 0u) && (rbeg + BW < qlen);
-			const uint32_t room = qlen - (rbeg + BW);
-			mov = moved ? min(mov, room) : 0u;
+			// mov = (mov != 0 && rbeg + BW < qlen) ? min(mov, qlen - (rbeg + BW)) : 0 -- the room as a saturating difference makes it one minimum
+			mov = min(mov, __builtin_elementwise_sub_sat(qlen, rbeg + (uint32_t)BW));
 			rbeg += mov;
 		}
 		int rh;
@@ -341,7 +340,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		else if(PW < 2) rh = gapo1 + gape1 * (int)i;
 		else rh = max(gapo1 + gape1 * (int)i, gapo2 + gape2 * (int)i);
 		// ---- row_movx (bsalign.h:2244-2392): the row is held slid by one cell; correct what did not move that way
-		if(!STATIC && (__builtin_amdgcn_ballot_w64(mov != 1u) & actm) != 0ull){
+		if(!STATIC && __builtin_expect((__builtin_amdgcn_ballot_w64(mov != 1u) & actm) != 0ull, 0)){
 			if(__any(act && mov >= (uint32_t)BW)){
 				// the band jumped past everything it held: zero rows, every ubegs = SCORE_MIN (bsalign.h:2253-2259);
 				// rh = H at the last cell of the previous row (getscore(bw - 1))
@@ -404,15 +403,16 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		uint32_t S[W];
 		{
 			// the target base of this row (i is uniform: the half of the eight-base window is picked on the scalar side), as the byte offset of its S~ row
+			// (the window holds the bases times four: a base is 0 .. 3, so nothing crosses a byte)
 			const uint32_t tw32 = (i & 4u) ? (uint32_t)(twin >> 32) : (uint32_t)twin;
-			const uint32_t tb4 = __builtin_amdgcn_ubfe(tw32, 8u * (i & 3u), 2u) << 2;
+			const uint32_t tb4 = __builtin_amdgcn_ubfe(tw32, 8u * (i & 3u), 4u);
 			uint32_t qlo[NQ], qhi[NQ];
 			if constexpr (STATIC){
 #pragma unroll
 				for(int n = 0; n < NQ; n++){ qlo[n] = act ? sqlo[n] : 0x04040404u; qhi[n] = act ? sqhi[n] : 0x04040404u; }
 			} else if constexpr (QWIN){
 				uint32_t off = rbeg - wbase;
-				if((__builtin_amdgcn_ballot_w64(off > QOFFMAX) & actm) != 0ull){
+				if(__builtin_expect((__builtin_amdgcn_ballot_w64(off > QOFFMAX) & actm) != 0ull, 0)){
 					// refill: KD dwords of each block from the band offset of this row
 					if(act && off > QOFFMAX){
 						const uint8_t *pl = qp + rbeg + jl * W, *ph = qp + rbeg + (jl + L) * W;
@@ -454,7 +454,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		// (or jumped past the whole band: ubegs[0] = SCORE_MIN) need it.
 		uint32_t hc0 = S[0];
 		uint32_t q0m = 0, q0d = 0, q0d2 = 0;          // rows starting at query column 0: what h is compared with for M and D (bsalign.h:3763-3767)
-		if((__builtin_amdgcn_ballot_w64(mov - 1u >= (uint32_t)BW - 1u) & actm) != 0ull){          // mov == 0 or mov >= BW
+		if(__builtin_expect((__builtin_amdgcn_ballot_w64(mov - 1u >= (uint32_t)BW - 1u) & actm) != 0ull, 0)){          // mov == 0 or mov >= BW
 			const int s0 = x_lo8(S[0]) + 2 * GE, u0 = x_lo8(U[0]) + GE, e0 = GE - x_lo8(NE[0]);
 			const int qq0 = (PW == 2) ? GE - x_lo8(NQ2[0]) : e0;
 			const int t0 = u0 + max(e0, qq0);
@@ -565,7 +565,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		if(first) tmpU0 = (tmpU0 & 0xffff0000u) | (NGEQ & 0xffffu);
 		const uint32_t Psh = x_shift_down<L>(PN, 0u, first);           // ubegs[b] - ubegs[0] - b W gape of the block's own start
 		// ---- flags of special cells, then the code row (bsa_common.h "COMPACT slot"); M, D, R were accumulated inverted
-		if((__builtin_amdgcn_ballot_w64(rbeg == 0u) & actm) != 0ull){
+		if(__builtin_expect((__builtin_amdgcn_ballot_w64(rbeg == 0u) & actm) != 0ull, 0)){
 			if(first && rbeg == 0u){
 				const uint32_t hl = hfirst & 0xffffu;
 				const uint32_t b0 = 1u << TOPBIT;
@@ -580,7 +580,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 				if constexpr (PW == 2) accD2[0] = (accD2[0] & ~b0) | ((hl == q0d2) ? 0u : b0);
 			}
 		}
-		if((__builtin_amdgcn_ballot_w64(mov > 1u) & actm) != 0ull){          // (the general form covers mov == 1 of the other pairs of the wave)
+		if(__builtin_expect((__builtin_amdgcn_ballot_w64(mov > 1u) & actm) != 0ull, 0)){          // (the general form covers mov == 1 of the other pairs of the wave)
 			// cells at / beyond the end of the previous row's band: x == bw decides M or I only, x > bw is always I
 #pragma unroll
 			for(int hf = 0; hf < 2; hf++){
@@ -876,7 +876,7 @@ static __device__ __forceinline__ void x_forward(const Align8Args &a, const uint
 		rzl -= (uint32_t)rbz;          // (meaningless once the pair has no row left: only read under `act`)
 		// (the next eight target bases.  The compiler waits for them at the top of the next row, with `s_waitcnt vmcnt(0)` on every row; forcing the wait
 		// into this branch instead -- once per eight rows, fully exposed -- was measured slower: 60.0 against 59.8 ms, two-piece gaps 129.8 against 127.1)
-		if((i & 7u) == 0u && i < tlen) __builtin_memcpy(&twin, tp + i, 8);
+		if((i & 7u) == 0u && i < tlen){ __builtin_memcpy(&twin, tp + i, 8); twin <<= 2; }
 	}
 	if(st != nullptr && row1 < tlen){
 		// write-through stores (sc1): the next segment usually runs on another CU, often on another XCD, and a release fence here
