@@ -254,7 +254,7 @@ extern "C" void bsa_pog_clear(bsa_pog_t *g){
 	g->header.clear(); g->next.clear(); g->prev.clear(); g->out.clear(); g->in.clear(); g->pos.clear(); g->cpos.clear(); g->rid.clear(); g->cov.clear();
 	g->base.clear(); g->flags.clear(); g->edges.resize(1); g->efree.clear(); g->ndoff.clear(); g->rdlen.clear(); g->HEAD = g->TAIL = 0;
 	g->sel_bit.clear(); g->bonus.clear(); g->nct.clear(); g->vst.clear(); g->loc.clear(); g->voff.clear(); g->rpos.clear(); g->mpos.clear();
-	g->sels.clear(); g->todels.clear(); g->stage = 0;
+	g->sels.clear(); g->todels.clear(); g->stage = 0; g->realn = false;
 }
 
 extern "C" int bsa_pog_add_read(bsa_pog_t *g, const uint8_t *bases, uint32_t len, uint32_t *rid_out){
@@ -726,6 +726,7 @@ extern "C" int bsa_pog_aux_edges(const bsa_pog_t *g, const uint64_t **list, size
 extern "C" int bsa_pog_abort(bsa_pog_t *g){
 	return guarded([&]() -> int {
 	if(!g) return BSA_E_ARG;
+	g->realn = false;                                           // (a cut that no selection followed)
 	if(g->stage == 0 && g->todels.empty()) return BSA_OK;        // (a selection that failed half-way has left its auxiliary edges)
 	g->drop_aux();
 	g->stage = 0;
