@@ -405,7 +405,20 @@ __global__ void k_cnt_by_pair(const uint32_t *order, const uint32_t *cnt_pos, co
 	if(p >= n) return;
 	const uint32_t pair = order[p];
 	cnt_pair[pair] = cnt_pos[p];
-	src_pair[pair] = off_pos[p];
+	src_pair[pair] = off_pos ? off_pos[p] : (uint64_t)p;
+}
+
+// a plan of ONE chunk: the slots are all still there when the offsets by pair are known, so the words go from the tails of the slots straight to their
+// place (src_pair[pair] = the pair's position: k_cnt_by_pair with off_pos == nullptr) -- no pass through the scratch arena (0.25 ms of C2's step)
+__global__ void __launch_bounds__(256) k_cigar_final_direct(const uint8_t *rows, const uint64_t *slot_end, const uint32_t *cnt_pair, const uint64_t *pos_pair,
+		const uint64_t *dst_off, uint32_t *dst, uint64_t cap, uint32_t n){
+	const uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if(g >= n) return;
+	const uint32_t c = cnt_pair[g];
+	const uint64_t d = dst_off[g];
+	if(d + c > cap) return;
+	const uint32_t *src = (const uint32_t*)(rows + slot_end[pos_pair[g]]) - c;
+	for(uint32_t i = lane; i < c; i += 64) dst[d + i] = src[i];
 }
 
 __global__ void __launch_bounds__(256) k_cigar_final(const uint32_t *tmp, const uint32_t *cnt_pair, const uint64_t *src_pair,
@@ -610,6 +623,7 @@ static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t ci
 	const uint32_t n = (uint32_t)p->n;
 	int rc;
 	c->sev_used = 0;
+	const bool direct = want_cig && p->chunks.size() == 1 && !p->two_halves && !bsa_env("BSA_CIGAR_VIA_ARENA");      // (see k_cigar_final_direct)
 	HIPCHK(c, hipMemsetAsync(p->d_carry, 0, sizeof(uint64_t), sf));
 	std::vector<hipEvent_t> trace_done(p->chunks.size());
 	if(p->two_halves){
@@ -632,7 +646,7 @@ static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t ci
 		HIPCHK(c, hipEventRecord(t0, stt));
 		rc = trace(ch, half, stt); if(rc != BSA_OK) return rc;
 		HIPCHK(c, hipEventRecord(t1, stt));
-		if(want_cig){
+		if(want_cig && !direct){
 			HIPCHK(c, launch_excl_scan(stt, p->d_cnt_pos + ch.first, p->d_off_pos + ch.first, ch.count, p->d_carry, p->d_scan_tmp));
 			hipLaunchKernelGGL(k_cigar_collect, dim3((ch.count + 3) / 4), dim3(256), 0, stt, half, p->d_slot_end,
 				ch.first, ch.count, p->d_cnt_pos, p->d_off_pos, p->d_tmp, (uint64_t)cigar_cap_words);
@@ -649,10 +663,11 @@ static int run_pipeline(PlanBase *p, bool want_cig, uint32_t *d_cigar, size_t ci
 	}
 	c->last_cells = p->cells;
 	if(want_cig){
-		hipLaunchKernelGGL(k_cnt_by_pair, dim3((n + 255) / 256), dim3(256), 0, sf, p->d_order, p->d_cnt_pos, p->d_off_pos, p->d_cnt_pair, p->d_src_pair, n);
+		hipLaunchKernelGGL(k_cnt_by_pair, dim3((n + 255) / 256), dim3(256), 0, sf, p->d_order, p->d_cnt_pos, direct ? (const uint64_t*)nullptr : p->d_off_pos, p->d_cnt_pair, p->d_src_pair, n);
 		HIPCHK(c, hipGetLastError());
 		HIPCHK(c, launch_excl_scan(sf, p->d_cnt_pair, d_cigar_off, n, (uint64_t*)nullptr, p->d_scan_tmp));
-		hipLaunchKernelGGL(k_cigar_final, dim3((n + 3) / 4), dim3(256), 0, sf, p->d_tmp, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
+		if(direct) hipLaunchKernelGGL(k_cigar_final_direct, dim3((n + 3) / 4), dim3(256), 0, sf, c->ws, p->d_slot_end, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
+		else hipLaunchKernelGGL(k_cigar_final, dim3((n + 3) / 4), dim3(256), 0, sf, p->d_tmp, p->d_cnt_pair, p->d_src_pair, d_cigar_off, d_cigar, (uint64_t)cigar_cap_words, n);
 		HIPCHK(c, hipGetLastError());
 	} else if(d_cigar_off){
 		HIPCHK(c, hipMemsetAsync(d_cigar_off, 0, sizeof(uint64_t) * ((size_t)n + 1), sf));
@@ -666,7 +681,8 @@ static int run_prologue(PlanBase *p, bool want_cig, size_t cigar_cap_words){
 	c->ev_used = 0; c->tev_used = 0; c->last_cells = 0;
 	int rc = ctx_ws_reserve(c, p->half_bytes * p->nbuf);
 	if(rc != BSA_OK) return rc;
-	if(want_cig && p->tmp_words < cigar_cap_words){
+	const bool direct = p->chunks.size() == 1 && !p->two_halves && !bsa_env("BSA_CIGAR_VIA_ARENA");          // (run_pipeline: no pass through the arena)
+	if(want_cig && !direct && p->tmp_words < cigar_cap_words){
 		if(p->d_tmp){ HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->aux_stream)); (void)hipFree(p->d_tmp); p->d_tmp = nullptr; }
 		if(hipMalloc((void**)&p->d_tmp, std::max<size_t>(cigar_cap_words, 1) * 4) != hipSuccess){ c->err = "cigar staging allocation failed"; (void)hipGetLastError(); return BSA_E_NOMEM; }
 		p->tmp_words = cigar_cap_words;
